@@ -1,0 +1,179 @@
+"""ctypes binding of include/frequensee.h (libfrequensee.so, HIP/gfx950).
+
+There is no fallback: if the shared library is missing or a HIP device is unavailable every compute
+call raises.  The product never imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrequensee.so")
+
+MAX_BANDS = 8
+NO_MATERIAL = 0xFFFF
+MAX_DEPTH = 64
+
+OK = 0
+ERR_INVALID_ARGUMENT = 1
+ERR_NO_DEVICE = 2
+ERR_HIP = 3
+ERR_NOT_COMMITTED = 4
+ERR_BAD_HANDLE = 5
+ERR_SIZE_MISMATCH = 6
+ERR_OUT_OF_MEMORY = 7
+
+FLAG_FIXED_NORM_1000 = 1
+FLAG_FLUSH_BEFORE_RECONSTRUCT = 2
+FLAG_COSINE_SAMPLING = 4
+
+# every symbol include/frequensee.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "fs_config_default", "fs_params_default", "fs_abi_version", "fs_context_create", "fs_context_destroy",
+    "fs_last_error", "fs_scene_set_triangles", "fs_scene_set_materials", "fs_scene_commit", "fs_source_create",
+    "fs_source_destroy", "fs_source_set_position", "fs_listener_set_position", "fs_compute_energy_response",
+    "fs_compute_energy_response_async", "fs_energy_device_ptr", "fs_reconstruct_impulse_response",
+    "fs_reconstruct_impulse_response_async", "fs_synchronize", "fs_get_impulse_response",
+    "fs_copy_impulse_response", "fs_copy_band_impulse_response", "fs_get_energy_buffer", "fs_flush_energy_buffer",
+    "fs_add_energy_at_delay", "fs_update_energy_buffer", "fs_num_bins", "fs_num_samples", "fs_trace_rays",
+    "fs_set_profiling", "fs_get_stats", "fs_reset_stats",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("num_bands", C.c_int32),
+        ("sample_rate", C.c_int32),
+        ("num_channels", C.c_int32),
+        ("simulated_duration", C.c_float),
+        ("bin_duration", C.c_float),
+        ("rank", C.c_int32),
+        ("world_size", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("num_rays", C.c_uint32),
+        ("depth", C.c_int32),
+        ("russian_roulette", C.c_int32),
+        ("rr_prob", C.c_float),
+        ("max_trace_dist", C.c_float),
+        ("surface_offset", C.c_float),
+        ("connect_pullback", C.c_float),
+        ("dist_divisor", C.c_float),
+        ("min_seg", C.c_float),
+        ("prob_exponent", C.c_float),
+        ("energy_clamp", C.c_float),
+        ("energy_gain", C.c_float),
+        ("sound_speed", C.c_float),
+        ("air_absorption", C.c_float * MAX_BANDS),
+        ("samples_per_bin", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint64),
+        ("rays", C.c_uint64),
+        ("pairs", C.c_uint64),
+        ("trace_kernel_ms_sum", C.c_double),
+        ("trace_kernel_ms_last", C.c_double),
+        ("reconstruct_ms_sum", C.c_double),
+        ("timed_frames", C.c_uint64),
+        ("bvh_nodes", C.c_uint32),
+        ("triangles", C.c_uint32),
+        ("scene_bytes", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class FrequenSeeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"frequensee status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libfrequensee.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u16p, f32p = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p
+    sig = {
+        "fs_config_default": (None, [C.POINTER(Config)]),
+        "fs_params_default": (None, [C.POINTER(Params)]),
+        "fs_abi_version": (C.c_int, []),
+        "fs_context_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
+        "fs_context_destroy": (C.c_int, [vp]),
+        "fs_last_error": (C.c_char_p, [vp]),
+        "fs_scene_set_triangles": (C.c_int, [vp, f32p, u16p, i32]),
+        "fs_scene_set_materials": (C.c_int, [vp, f32p, f32p, f32p, i32, i32]),
+        "fs_scene_commit": (C.c_int, [vp]),
+        "fs_source_create": (C.c_int, [vp, C.POINTER(i32)]),
+        "fs_source_destroy": (C.c_int, [vp, i32]),
+        "fs_source_set_position": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
+        "fs_listener_set_position": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "fs_compute_energy_response": (C.c_int, [vp, i32, C.POINTER(Params), f32p]),
+        "fs_compute_energy_response_async": (C.c_int, [vp, i32, C.POINTER(Params)]),
+        "fs_energy_device_ptr": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "fs_reconstruct_impulse_response": (C.c_int, [vp, i32, C.POINTER(Params)]),
+        "fs_reconstruct_impulse_response_async": (C.c_int, [vp, i32, C.POINTER(Params)]),
+        "fs_synchronize": (C.c_int, [vp]),
+        "fs_get_impulse_response": (C.c_int, [vp, i32, i32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(i32)]),
+        "fs_copy_impulse_response": (C.c_int, [vp, i32, i32, f32p, i32]),
+        "fs_copy_band_impulse_response": (C.c_int, [vp, i32, i32, f32p, i32]),
+        "fs_get_energy_buffer": (C.c_int, [vp, i32, f32p, i32]),
+        "fs_flush_energy_buffer": (C.c_int, [vp, i32]),
+        "fs_add_energy_at_delay": (C.c_int, [vp, i32, i32, C.c_float, C.c_float]),
+        "fs_update_energy_buffer": (C.c_int, [vp, i32, f32p, i32]),
+        "fs_num_bins": (C.c_int, [vp]),
+        "fs_num_samples": (C.c_int, [vp]),
+        "fs_trace_rays": (C.c_int, [vp, f32p, f32p, f32p, i32, i32, vp, f32p, vp, f32p]),
+        "fs_set_profiling": (C.c_int, [vp, i32]),
+        "fs_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "fs_reset_stats": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def default_config(**kw) -> Config:
+    c = Config()
+    load().fs_config_default(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load().fs_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k == "air_absorption":
+            for i, x in enumerate(v):
+                p.air_absorption[i] = float(x)
+        else:
+            setattr(p, k, v)
+    return p

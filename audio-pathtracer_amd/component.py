@@ -1,0 +1,320 @@
+"""Host-side mirror of the reference's plugin interface for the BDPT path, over the C ABI.
+
+  AudioRayTracingSubsystem  <->  UAudioRayTracingSubsystem   (Public/AudioRayTracingSubsystem.h:86-196)
+  FrequenSeeAudioComponent  <->  UFrequenSeeAudioComponent   (Public/FrequenSeeAudioComponent.h:20-154)
+
+Same method names, argument meaning and error behaviour (check() aborts become exceptions), so the
+parity tests read like tests of the reference.  All compute happens in libfrequensee.so (HIP).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import FrequenSeeError
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Context:
+    """Thin RAII wrapper of fs_context (one HIP device, one stream)."""
+
+    def __init__(self, num_bands=1, device=0, rank=0, world_size=1, stream=None, **cfg):
+        self.lib = _capi.load()
+        c = _capi.default_config(num_bands=num_bands, device=device, rank=rank, world_size=world_size, **cfg)
+        if stream is not None:
+            c.stream = C.c_void_p(int(stream))
+        self.cfg = c
+        h = C.c_void_p()
+        rc = self.lib.fs_context_create(C.byref(c), C.byref(h))
+        self.h = h
+        if rc != _capi.OK:
+            msg = self.lib.fs_last_error(h).decode() if h else "fs_context_create failed"
+            if h:
+                self.lib.fs_context_destroy(h)
+                self.h = None
+            raise FrequenSeeError(rc, msg)
+        self.num_bands = num_bands
+        self.num_bins = self.lib.fs_num_bins(self.h)
+        self.num_samples = self.lib.fs_num_samples(self.h)
+
+    def check(self, rc):
+        if rc != _capi.OK:
+            raise FrequenSeeError(rc, self.lib.fs_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fs_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene ----
+    def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None):
+        tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
+        mat = np.ascontiguousarray(material_ids, dtype=np.uint16).reshape(-1)
+        if mat.shape[0] != tri.shape[0]:
+            raise ValueError("material_ids length != number of triangles")
+        ab = np.ascontiguousarray(absorption, dtype=np.float32)
+        if ab.ndim == 1:
+            ab = ab.reshape(-1, 1)
+        opt = []
+        for a in (transmission, scattering):
+            opt.append(None if a is None else np.ascontiguousarray(a, dtype=np.float32).reshape(ab.shape))
+        self.check(self.lib.fs_scene_set_triangles(self.h, tri.ctypes.data, mat.ctypes.data, tri.shape[0]))
+        self.check(self.lib.fs_scene_set_materials(self.h, ab.ctypes.data,
+                                                   opt[0].ctypes.data if opt[0] is not None else None,
+                                                   opt[1].ctypes.data if opt[1] is not None else None,
+                                                   ab.shape[0], ab.shape[1]))
+        self.check(self.lib.fs_scene_commit(self.h))
+
+    def set_listener(self, xyz):
+        self.check(self.lib.fs_listener_set_position(self.h, _f3(xyz)))
+
+    def create_source(self, xyz=None) -> int:
+        s = C.c_int32(-1)
+        self.check(self.lib.fs_source_create(self.h, C.byref(s)))
+        if xyz is not None:
+            self.set_source_position(s.value, xyz)
+        return s.value
+
+    def destroy_source(self, src):
+        self.check(self.lib.fs_source_destroy(self.h, src))
+
+    def set_source_position(self, src, xyz):
+        self.check(self.lib.fs_source_set_position(self.h, src, _f3(xyz)))
+
+    # ---- hot path ----
+    def compute_energy_response(self, src, params, want_host=True):
+        out = np.empty((self.num_bands, self.num_bins), dtype=np.float32) if want_host else None
+        self.check(self.lib.fs_compute_energy_response(self.h, src, C.byref(params),
+                                                       out.ctypes.data if want_host else None))
+        return out
+
+    def compute_energy_response_async(self, src, params):
+        self.check(self.lib.fs_compute_energy_response_async(self.h, src, C.byref(params)))
+
+    def reconstruct_impulse_response(self, src, params=None):
+        self.check(self.lib.fs_reconstruct_impulse_response(self.h, src, C.byref(params) if params else None))
+
+    def reconstruct_impulse_response_async(self, src, params=None):
+        self.check(self.lib.fs_reconstruct_impulse_response_async(self.h, src, C.byref(params) if params else None))
+
+    def synchronize(self):
+        self.check(self.lib.fs_synchronize(self.h))
+
+    def energy_device_ptr(self, src):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.check(self.lib.fs_energy_device_ptr(self.h, src, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def impulse_response(self, src, channel=0):
+        """copy of the published channel IR (GetImpulseResponse()[channel])"""
+        out = np.empty(self.num_samples, dtype=np.float32)
+        self.check(self.lib.fs_copy_impulse_response(self.h, src, channel, out.ctypes.data, out.shape[0]))
+        return out
+
+    def impulse_response_view(self, src, channel=0):
+        """zero-copy view of the published front buffer (valid until the second-next publish)"""
+        p, n = C.POINTER(C.c_float)(), C.c_int32()
+        self.check(self.lib.fs_get_impulse_response(self.h, src, channel, C.byref(p), C.byref(n)))
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def band_impulse_response(self, src, band):
+        out = np.empty(self.num_samples, dtype=np.float32)
+        self.check(self.lib.fs_copy_band_impulse_response(self.h, src, band, out.ctypes.data, out.shape[0]))
+        return out
+
+    def energy_buffer(self, src):
+        out = np.empty((self.num_bands, self.num_bins), dtype=np.float32)
+        self.check(self.lib.fs_get_energy_buffer(self.h, src, out.ctypes.data, out.size))
+        return out
+
+    def trace_rays(self, origins, dirs, tmax, any_hit=False):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        tm = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, dtype=np.float32), (n,)))
+        hit = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float32)
+        tri = np.full(n, -1, dtype=np.int32)
+        nrm = np.zeros((n, 3), dtype=np.float32)
+        self.check(self.lib.fs_trace_rays(self.h, o.ctypes.data, d.ctypes.data, tm.ctypes.data, n, int(any_hit),
+                                          hit.ctypes.data, t.ctypes.data, tri.ctypes.data, nrm.ctypes.data))
+        return hit.astype(bool), t, tri, nrm
+
+    def set_profiling(self, on=True):
+        self.check(self.lib.fs_set_profiling(self.h, int(on)))
+
+    def stats(self):
+        s = _capi.Stats()
+        self.check(self.lib.fs_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self.check(self.lib.fs_reset_stats(self.h))
+
+
+class FrequenSeeAudioComponent:
+    """UFrequenSeeAudioComponent's energy/IR surface (FSAC.h:69-91, 112-113, 133-143)."""
+
+    def __init__(self, location=(0.0, 0.0, 0.0)):
+        self._location = np.asarray(location, dtype=np.float32)
+        self._subsys = None
+        self._src = None
+        self.bApplyReverb = True  # FSAC.h:60
+
+    # OnRegister / OnUnregister (FSAC.cpp:42-64): auto-hook into the subsystem
+    def OnRegister(self, subsystem: "AudioRayTracingSubsystem"):
+        subsystem.RegisterSource(self)
+
+    def OnUnregister(self):
+        if self._subsys is not None:
+            self._subsys.UnRegisterSource(self)
+
+    def _ctx(self) -> Context:
+        if self._subsys is None:
+            raise RuntimeError("component is not registered with an AudioRayTracingSubsystem")
+        return self._subsys.ctx
+
+    @property
+    def NumBins(self):
+        return self._ctx().num_bins
+
+    @property
+    def NumSamples(self):
+        return self._ctx().num_samples
+
+    def GetComponentLocation(self):
+        return self._location.copy()
+
+    def SetComponentLocation(self, xyz):
+        self._location = np.asarray(xyz, dtype=np.float32)
+        if self._subsys is not None:
+            self._ctx().set_source_position(self._src, self._location)
+
+    @property
+    def EnergyBuffer(self):
+        """[NumBins] for one band (the reference), [bands][NumBins] otherwise"""
+        e = self._ctx().energy_buffer(self._src)
+        return e[0] if e.shape[0] == 1 else e
+
+    def FlushEnergyBuffer(self):  # FSAC.h:76-79
+        c = self._ctx()
+        c.check(c.lib.fs_flush_energy_buffer(c.h, self._src))
+
+    def UpdateEnergyBuffer(self, NewEnergyValues):  # FSAC.h:81-85 (check -> exception)
+        c = self._ctx()
+        v = np.ascontiguousarray(NewEnergyValues, dtype=np.float32)
+        c.check(c.lib.fs_update_energy_buffer(c.h, self._src, v.ctypes.data, v.size))
+
+    def AddEnergyAtDelay(self, DelaySeconds, EnergyValue, Band=0):  # FSAC.h:87-91
+        c = self._ctx()
+        c.check(c.lib.fs_add_energy_at_delay(c.h, self._src, Band, float(DelaySeconds), float(EnergyValue)))
+
+    def ReconstructImpulseResponse(self, params=None):  # FSAC.cpp:320-380
+        self._ctx().reconstruct_impulse_response(self._src, params)
+
+    def GetImpulseResponse(self):  # FSAC.h:113 -> [NumChannels][NumSamples]
+        c = self._ctx()
+        return [c.impulse_response_view(self._src, ch) for ch in range(c.cfg.num_channels)]
+
+    def GetBandImpulseResponse(self, band):
+        return self._ctx().band_impulse_response(self._src, band)
+
+
+class AudioRayTracingSubsystem:
+    """UAudioRayTracingSubsystem's registries and per-source update (ARTS.h:86-196, ARTS.cpp:45-195)."""
+
+    USED_RAY_COUNT = 1000  # ARTS.h:176
+
+    def __init__(self, num_bands=1, device=0, rank=0, world_size=1, stream=None):
+        self.ctx = Context(num_bands=num_bands, device=device, rank=rank, world_size=world_size, stream=stream)
+        self.ActiveSources = []
+        self._geom = []          # registered (triangles, material_ids)
+        self._materials = None
+        self._dirty = True
+        self.params = _capi.default_params()
+
+    def Deinitialize(self):
+        self.ctx.close()
+
+    # RegisterGeometry / UnregisterGeometry (ARTS.h:99-100): a "component" is a triangle set + material ids
+    def RegisterGeometry(self, triangles, material_ids):
+        comp = (np.asarray(triangles, dtype=np.float32).reshape(-1, 3, 3),
+                np.asarray(material_ids, dtype=np.uint16).reshape(-1))
+        self._geom.append(comp)
+        self._dirty = True
+        return comp
+
+    def UnregisterGeometry(self, comp):
+        self._geom = [g for g in self._geom if g is not comp]
+        self._dirty = True
+
+    def SetMaterials(self, absorption, transmission=None, scattering=None):
+        self._materials = (absorption, transmission, scattering)
+        self._dirty = True
+
+    def _commit(self):
+        if not self._dirty:
+            return
+        if self._geom:
+            tri = np.concatenate([g[0] for g in self._geom], axis=0)
+            mat = np.concatenate([g[1] for g in self._geom], axis=0)
+        else:
+            tri, mat = np.zeros((0, 3, 3), np.float32), np.zeros((0,), np.uint16)
+        ab, tr, sc = self._materials if self._materials is not None else (
+            np.zeros((0, self.ctx.num_bands), np.float32), None, None)
+        self.ctx.set_scene(tri, mat, ab, tr, sc)
+        self._dirty = False
+
+    def RegisterSource(self, InComp: FrequenSeeAudioComponent):  # ARTS.cpp:45-48
+        InComp._subsys = self
+        InComp._src = self.ctx.create_source(InComp._location)
+        self.ActiveSources.append(InComp)
+
+    def UnRegisterSource(self, InComp: FrequenSeeAudioComponent):  # ARTS.cpp:50-53
+        if InComp in self.ActiveSources:
+            self.ActiveSources.remove(InComp)
+            self.ctx.destroy_source(InComp._src)
+            InComp._subsys = None
+            InComp._src = None
+
+    def SetListenerLocation(self, xyz):  # PlayerPawn->GetActorLocation(), ARTS.cpp:287
+        self.ctx.set_listener(xyz)
+
+    def UpdateSource(self, Src: FrequenSeeAudioComponent, params=None):
+        """ARTS.cpp:128-195: trace, evaluate, flush, deposit, reconstruct.  Returns the energy buffer."""
+        self._commit()
+        p = params or self.params
+        e = self.ctx.compute_energy_response(Src._src, p)
+        self.ctx.reconstruct_impulse_response(Src._src, p)
+        return e
+
+    def ForceUpdateSources(self):  # ARTS.cpp:883-886
+        for s in list(self.ActiveSources):
+            self.UpdateSource(s)
+
+    def Tick(self, DeltaTime):  # ARTS.cpp:55-85 without the 1 s warm-up: the caller drives every frame
+        if not self.ActiveSources:
+            return
+        self.ForceUpdateSources()
+
+    def LineTraceSingle(self, start, end):
+        """closest hit on the segment [start, end] (UWorld::LineTraceSingleByObjectType contract)"""
+        self._commit()
+        s, e = np.asarray(start, np.float32), np.asarray(end, np.float32)
+        d = e - s
+        ln = float(np.linalg.norm(d))
+        if ln <= 0:
+            return False, 0.0, -1, np.zeros(3, np.float32)
+        hit, t, tri, n = self.ctx.trace_rays(s[None], (d / ln)[None], ln)
+        return bool(hit[0]), float(t[0]), int(tri[0]), n[0]

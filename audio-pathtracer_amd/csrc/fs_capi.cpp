@@ -1,0 +1,753 @@
+// fs_capi.cpp — host side of the C ABI declared in include/frequensee.h.
+//
+// Mirrors the roles of UAudioRayTracingSubsystem (context lifetime, geometry/source registries,
+// per-source update: AudioRayTracingSubsystem.cpp:32-53, 128-195) and of UFrequenSeeAudioComponent's
+// buffers (EnergyBuffer, ImpulseBuffer: FrequenSeeAudioComponent.h:69-91, 113, 133-143).  All compute
+// is HIP on the context's stream; there is no CPU fallback.
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "fs_internal.hpp"
+
+using namespace fs;
+
+namespace {
+
+constexpr int kIrRing = 3;  // published IR ring: a returned pointer stays valid until the second-next publish
+
+struct Source {
+    bool alive = false;
+    float pos[3] = {0, 0, 0};
+    float* d_energy = nullptr;    // [B][bins]
+    float* d_ir_bands = nullptr;  // [B][samples]
+    float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
+    float* h_ir[kIrRing] = {nullptr, nullptr, nullptr};  // pinned host copies of the channel view
+    hipEvent_t ev[kIrRing] = {nullptr, nullptr, nullptr};
+    uint64_t seq_of[kIrRing] = {0, 0, 0};
+    uint64_t enqueued = 0;             // publishes enqueued so far
+    std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
+};
+
+struct TimedFrame {
+    hipEvent_t e[4];
+    bool has_trace = false, has_recon = false;
+};
+
+}  // namespace
+
+struct fs_context {
+    fs_config cfg{};
+    int num_bins = 0, num_samples = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool device_ok = false;
+    std::string err;
+
+    // scene (host staging + device)
+    std::vector<float> h_xyz;
+    std::vector<uint16_t> h_mat;
+    std::vector<float> h_absorption, h_transmission, h_scattering;
+    int32_t T = 0, M = 0;
+    bool committed = false;
+    Node64* d_nodes = nullptr;
+    Tri48* d_tris = nullptr;
+    float* d_absorption = nullptr;
+    DeviceScene scene{};
+    HostBVH bvh;
+
+    float listener[3] = {0, 0, 0};
+    std::vector<Source*> sources;
+
+    // subpath state (sized on demand)
+    SubpathState st{};
+    size_t cap_lanes = 0, cap_seg = 0;
+
+    // measurement
+    bool profiling = false;
+    std::vector<TimedFrame> pending;
+    std::vector<hipEvent_t> free_events;
+    fs_stats stats{};
+
+    int fail(int code, const std::string& m) {
+        err = m;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what) {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return FS_ERR_HIP;
+    }
+};
+
+#define FS_HIP(ctx, call)                                        \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return (ctx)->hip_fail(e_, #call); \
+    } while (0)
+
+namespace {
+
+Source* get_source(fs_context* ctx, fs_source h) {
+    if (h < 0 || (size_t)h >= ctx->sources.size()) return nullptr;
+    Source* s = ctx->sources[(size_t)h];
+    return (s && s->alive) ? s : nullptr;
+}
+
+void free_source(fs_context* ctx, Source* s) {
+    if (!s) return;
+    if (ctx->device_ok) {
+        (void)hipSetDevice(ctx->cfg.device);
+        if (s->d_energy) (void)hipFree(s->d_energy);
+        if (s->d_ir_bands) (void)hipFree(s->d_ir_bands);
+        if (s->d_ir_mono) (void)hipFree(s->d_ir_mono);
+        for (int i = 0; i < kIrRing; ++i) {
+            if (s->h_ir[i]) (void)hipHostFree(s->h_ir[i]);
+            if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+        }
+    }
+    delete s;
+}
+
+void free_scene(fs_context* ctx) {
+    if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+    if (ctx->d_tris) (void)hipFree(ctx->d_tris);
+    if (ctx->d_absorption) (void)hipFree(ctx->d_absorption);
+    ctx->d_nodes = nullptr; ctx->d_tris = nullptr; ctx->d_absorption = nullptr;
+    ctx->scene = DeviceScene{};
+    ctx->committed = false;
+}
+
+void free_state(fs_context* ctx) {
+    if (ctx->st.pos_sd) (void)hipFree(ctx->st.pos_sd);
+    if (ctx->st.misc) (void)hipFree(ctx->st.misc);
+    if (ctx->st.energy) (void)hipFree(ctx->st.energy);
+    if (ctx->st.seg_nd) (void)hipFree(ctx->st.seg_nd);
+    ctx->st = SubpathState{};
+    ctx->cap_lanes = ctx->cap_seg = 0;
+}
+
+hipEvent_t take_event(fs_context* ctx) {
+    if (!ctx->free_events.empty()) {
+        hipEvent_t e = ctx->free_events.back();
+        ctx->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// fold finished timed frames into the stats (call only after the stream has been synchronised)
+void resolve_timings(fs_context* ctx) {
+    for (TimedFrame& f : ctx->pending) {
+        float ms = 0.f;
+        if (f.has_trace && hipEventElapsedTime(&ms, f.e[0], f.e[1]) == hipSuccess) {
+            ctx->stats.trace_kernel_ms_sum += ms;
+            ctx->stats.trace_kernel_ms_last = ms;
+            ctx->stats.timed_frames++;
+        }
+        if (f.has_recon && hipEventElapsedTime(&ms, f.e[2], f.e[3]) == hipSuccess)
+            ctx->stats.reconstruct_ms_sum += ms;
+        for (int i = 0; i < 4; ++i)
+            if (f.e[i]) ctx->free_events.push_back(f.e[i]);
+    }
+    ctx->pending.clear();
+}
+
+// advance `front` over publishes whose D2H copy has completed (producer thread only)
+void poll_published(Source* s) {
+    uint64_t f = s->front.load(std::memory_order_relaxed);
+    while (f < s->enqueued) {
+        uint64_t next = f + 1;
+        int slot = (int)(next % kIrRing);
+        if (s->seq_of[slot] != next) break;
+        if (hipEventQuery(s->ev[slot]) != hipSuccess) break;
+        f = next;
+    }
+    s->front.store(f, std::memory_order_release);
+}
+
+int ensure_state(fs_context* ctx, uint32_t n_local, int depth) {
+    const int B = ctx->cfg.num_bands;
+    size_t lanes = 2 * (size_t)n_local;
+    size_t seg = (size_t)depth * (size_t)n_local;
+    if (lanes > ctx->cap_lanes) {
+        if (ctx->st.pos_sd) (void)hipFree(ctx->st.pos_sd);
+        if (ctx->st.misc) (void)hipFree(ctx->st.misc);
+        if (ctx->st.energy) (void)hipFree(ctx->st.energy);
+        ctx->st.pos_sd = nullptr; ctx->st.misc = nullptr; ctx->st.energy = nullptr;
+        ctx->cap_lanes = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.pos_sd, sizeof(float4) * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.misc, sizeof(float4) * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.energy, sizeof(float) * lanes * (size_t)B));
+        ctx->cap_lanes = lanes;
+    }
+    if (seg > ctx->cap_seg) {
+        if (ctx->st.seg_nd) (void)hipFree(ctx->st.seg_nd);
+        ctx->st.seg_nd = nullptr;
+        ctx->cap_seg = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_nd, sizeof(float) * seg));
+        ctx->cap_seg = seg;
+    }
+    return FS_OK;
+}
+
+int check_params(fs_context* ctx, const fs_params* p) {
+    if (!p) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    if (p->depth < 0 || p->depth > FS_MAX_DEPTH) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "depth out of range");
+    if (p->num_rays & 1u) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "num_rays must be even (source + listener subpaths)");
+    if (!(p->dist_divisor > 0.f) || !(p->sound_speed > 0.f))
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "dist_divisor and sound_speed must be positive");
+    return FS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_abi_version(void) { return FS_ABI_VERSION; }
+
+void fs_config_default(fs_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(fs_config);
+    c->device = 0;
+    c->num_bands = 1;
+    c->sample_rate = 48000;       // FSAC.h:133
+    c->num_channels = 2;          // FSAC.h:135
+    c->simulated_duration = 1.0f; // FSAC.h:136
+    c->bin_duration = 0.001f;     // FSAC.h:137
+    c->rank = 0;
+    c->world_size = 1;
+    c->stream = nullptr;
+}
+
+void fs_params_default(fs_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = sizeof(fs_params);
+    p->flags = 0;
+    p->seed = 0x5EEDull;
+    p->num_rays = 2000;            // USED_RAY_COUNT = 1000 pairs, ARTS.h:176
+    p->depth = 0;                  // unbounded, ARTS.cpp:294
+    p->russian_roulette = 1;
+    p->rr_prob = 0.9f;             // ARTS.cpp:282
+    p->max_trace_dist = 1000000.f; // ARTS.cpp:284
+    p->surface_offset = 0.1f;      // ARTS.cpp:345
+    p->connect_pullback = 0.1f;    // ARTS.cpp:253
+    p->dist_divisor = 1000.f;      // ARTS.cpp:373
+    p->min_seg = 1.0f;             // ARTS.cpp:375
+    p->prob_exponent = 0.1f;       // ARTS.cpp:398
+    p->energy_clamp = 1.0f;        // ARTS.cpp:410
+    p->energy_gain = 10.f;         // ARTS.cpp:413
+    p->sound_speed = 343.0f;       // ARTS.cpp:362
+    for (int b = 0; b < FS_MAX_BANDS; ++b) p->air_absorption[b] = 0.05f;  // ARTS.cpp:395
+    p->samples_per_bin = 0;
+}
+
+int fs_context_create(const fs_config* cfg, fs_context** out) {
+    if (!out) return FS_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    fs_config c;
+    fs_config_default(&c);
+    if (cfg) {
+        if (cfg->struct_size != sizeof(fs_config)) return FS_ERR_INVALID_ARGUMENT;
+        c = *cfg;
+        if (c.num_bands == 0) c.num_bands = 1;
+        if (c.sample_rate == 0) c.sample_rate = 48000;
+        if (c.num_channels == 0) c.num_channels = 2;
+        if (c.simulated_duration == 0.f) c.simulated_duration = 1.0f;
+        if (c.bin_duration == 0.f) c.bin_duration = 0.001f;
+        if (c.world_size == 0) c.world_size = 1;
+    }
+    if (c.num_bands < 1 || c.num_bands > FS_MAX_BANDS || c.world_size < 1 || c.rank < 0 || c.rank >= c.world_size ||
+        c.sample_rate < 1 || c.num_channels < 1 || !(c.simulated_duration > 0.f) || !(c.bin_duration > 0.f))
+        return FS_ERR_INVALID_ARGUMENT;
+    fs_context* ctx = new (std::nothrow) fs_context();
+    if (!ctx) return FS_ERR_OUT_OF_MEMORY;
+    ctx->cfg = c;
+    ctx->num_bins = (int)std::ceil(c.simulated_duration / c.bin_duration);             // FSAC.h:137 -> 1000
+    ctx->num_samples = (int)std::ceil(c.simulated_duration * (float)c.sample_rate);    // FSAC.h:138 -> 48000
+    *out = ctx;  // returned even on device failure so fs_last_error() can be read
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (c.device < 0 || c.device >= ndev) return ctx->fail(FS_ERR_NO_DEVICE, "device ordinal out of range");
+    e = hipSetDevice(c.device);
+    if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    if (c.stream) {
+        ctx->stream = (hipStream_t)c.stream;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        ctx->own_stream = true;
+    }
+    ctx->device_ok = true;
+    return FS_OK;
+}
+
+int fs_context_destroy(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (ctx->device_ok) {
+        (void)hipSetDevice(ctx->cfg.device);
+        (void)hipStreamSynchronize(ctx->stream);
+        resolve_timings(ctx);
+        for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+        free_scene(ctx);
+        free_state(ctx);
+    }
+    for (Source* s : ctx->sources) free_source(ctx, s);
+    if (ctx->device_ok && ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FS_OK;
+}
+
+const char* fs_last_error(const fs_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int fs_num_bins(const fs_context* ctx) { return ctx ? ctx->num_bins : 0; }
+int fs_num_samples(const fs_context* ctx) { return ctx ? ctx->num_samples : 0; }
+
+// ---- scene -----------------------------------------------------------------------------------------
+int fs_scene_set_triangles(fs_context* ctx, const float* xyz, const uint16_t* mat_id, int32_t T) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (T < 0 || (T > 0 && !xyz)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad triangle array");
+    if (T > (1 << 28)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "too many triangles");
+    for (size_t i = 0; i < 9 * (size_t)T; ++i)
+        if (!std::isfinite(xyz[i])) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "non-finite vertex coordinate");
+    ctx->h_xyz.assign(xyz, xyz + 9 * (size_t)T);
+    if (mat_id) ctx->h_mat.assign(mat_id, mat_id + T);
+    else ctx->h_mat.assign((size_t)T, (uint16_t)FS_NO_MATERIAL);
+    ctx->T = T;
+    ctx->committed = false;
+    return FS_OK;
+}
+
+int fs_scene_set_materials(fs_context* ctx, const float* absorption, const float* transmission,
+                           const float* scattering, int32_t M, int32_t B) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (M < 0 || (M > 0 && !absorption) || M >= (int32_t)FS_NO_MATERIAL)
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad material table");
+    if (B != ctx->cfg.num_bands) return ctx->fail(FS_ERR_SIZE_MISMATCH, "material bands != context num_bands");
+    size_t n = (size_t)M * (size_t)B;
+    ctx->h_absorption.assign(absorption, absorption + n);
+    if (transmission) ctx->h_transmission.assign(transmission, transmission + n); else ctx->h_transmission.clear();
+    if (scattering) ctx->h_scattering.assign(scattering, scattering + n); else ctx->h_scattering.clear();
+    ctx->M = M;
+    ctx->committed = false;
+    return FS_OK;
+}
+
+int fs_scene_commit(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(), ctx->T, ctx->bvh);
+    if (ctx->bvh.max_depth >= kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH deeper than the traversal stack");
+    size_t nb = ctx->bvh.nodes.size() * sizeof(Node64), tb = ctx->bvh.tris.size() * sizeof(Tri48);
+    size_t mb = ctx->h_absorption.size() * sizeof(float);
+    if (nb) {
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, nb));
+        FS_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->bvh.nodes.data(), nb, hipMemcpyHostToDevice));
+    }
+    if (tb) {
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_tris, tb));
+        FS_HIP(ctx, hipMemcpy(ctx->d_tris, ctx->bvh.tris.data(), tb, hipMemcpyHostToDevice));
+    }
+    if (mb) {
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_absorption, mb));
+        FS_HIP(ctx, hipMemcpy(ctx->d_absorption, ctx->h_absorption.data(), mb, hipMemcpyHostToDevice));
+    }
+    ctx->scene.nodes = ctx->d_nodes;
+    ctx->scene.tris = ctx->d_tris;
+    ctx->scene.absorption = ctx->d_absorption;
+    ctx->scene.num_nodes = (int32_t)ctx->bvh.nodes.size();
+    ctx->scene.num_tris = ctx->T;
+    ctx->scene.num_materials = ctx->M;
+    ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
+    ctx->stats.triangles = (uint32_t)ctx->T;
+    ctx->stats.scene_bytes = nb + tb + mb;
+    ctx->committed = true;
+    return FS_OK;
+}
+
+// ---- sources / listener ------------------------------------------------------------------------------
+int fs_source_create(fs_context* ctx, fs_source* out) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    Source* s = new (std::nothrow) Source();
+    if (!s) return ctx->fail(FS_ERR_OUT_OF_MEMORY, "source");
+    const size_t eb = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    const size_t ib = sizeof(float) * (size_t)ctx->num_samples;
+    auto bail = [&](hipError_t e, const char* what) {
+        int rc = ctx->hip_fail(e, what);
+        s->alive = false;
+        free_source(ctx, s);
+        return rc;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&s->d_energy, eb)) != hipSuccess) return bail(e, "hipMalloc(energy)");
+    if ((e = hipMalloc((void**)&s->d_ir_bands, ib * (size_t)ctx->cfg.num_bands)) != hipSuccess) return bail(e, "hipMalloc(ir_bands)");
+    if ((e = hipMalloc((void**)&s->d_ir_mono, ib)) != hipSuccess) return bail(e, "hipMalloc(ir_mono)");
+    if ((e = hipMemsetAsync(s->d_energy, 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(s->d_ir_bands, 0, ib * (size_t)ctx->cfg.num_bands, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(s->d_ir_mono, 0, ib, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    for (int i = 0; i < kIrRing; ++i) {
+        if ((e = hipHostMalloc((void**)&s->h_ir[i], ib, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+        std::memset(s->h_ir[i], 0, ib);  // ImpulseBuffer[ch].Init(0, NumSamples) FSAC.cpp:24-28
+        if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
+    s->alive = true;
+    // RegisterSource: ActiveSources.Add (ARTS.cpp:45-48); reuse a dead slot if any
+    for (size_t i = 0; i < ctx->sources.size(); ++i)
+        if (!ctx->sources[i]) { ctx->sources[i] = s; *out = (fs_source)i; return FS_OK; }
+    ctx->sources.push_back(s);
+    *out = (fs_source)(ctx->sources.size() - 1);
+    return FS_OK;
+}
+
+int fs_source_destroy(fs_context* ctx, fs_source h) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (ctx->device_ok) (void)hipStreamSynchronize(ctx->stream);
+    ctx->sources[(size_t)h] = nullptr;  // UnRegisterSource ARTS.cpp:50-53
+    free_source(ctx, s);
+    return FS_OK;
+}
+
+int fs_source_set_position(fs_context* ctx, fs_source h, const float xyz[3]) {
+    if (!ctx || !xyz) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    std::memcpy(s->pos, xyz, sizeof(float) * 3);
+    return FS_OK;
+}
+
+int fs_listener_set_position(fs_context* ctx, const float xyz[3]) {
+    if (!ctx || !xyz) return FS_ERR_INVALID_ARGUMENT;
+    std::memcpy(ctx->listener, xyz, sizeof(float) * 3);
+    return FS_OK;
+}
+
+// ---- hot path ------------------------------------------------------------------------------------------
+int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+
+    const int B = ctx->cfg.num_bands;
+    const uint64_t P = p->num_rays / 2;
+    const uint64_t W = (uint64_t)ctx->cfg.world_size, R = (uint64_t)ctx->cfg.rank;
+    const uint64_t p0 = P * R / W, p1 = P * (R + 1) / W;
+    KParams kp{};
+    kp.seed_lo = (uint32_t)p->seed;
+    kp.seed_hi = (uint32_t)(p->seed >> 32);
+    kp.pair_begin = (uint32_t)p0;
+    kp.num_local = (uint32_t)(p1 - p0);
+    kp.depth = p->depth > 0 ? p->depth : FS_MAX_DEPTH;
+    kp.russian_roulette = p->russian_roulette;
+    kp.cosine = (p->flags & FS_FLAG_COSINE_SAMPLING) ? 1 : 0;
+    kp.rr_prob = p->rr_prob;
+    kp.max_trace_dist = p->max_trace_dist;
+    kp.surface_offset = p->surface_offset;
+    kp.connect_pullback = p->connect_pullback;
+    kp.dist_divisor = p->dist_divisor;
+    kp.min_seg = p->min_seg;
+    kp.prob_exponent = p->prob_exponent;
+    kp.energy_clamp = p->energy_clamp;
+    kp.energy_gain = p->energy_gain;
+    kp.sound_speed = p->sound_speed;
+    kp.norm = (p->flags & FS_FLAG_FIXED_NORM_1000) ? 1.0f / 1000.0f : (P ? 1.0f / (float)P : 0.f);  // ARTS.cpp:164
+    for (int b = 0; b < FS_MAX_BANDS; ++b) kp.air[b] = p->air_absorption[b];
+    std::memcpy(kp.src, s->pos, sizeof(kp.src));
+    std::memcpy(kp.lis, ctx->listener, sizeof(kp.lis));
+    kp.num_bins = ctx->num_bins;
+
+    rc = ensure_state(ctx, kp.num_local, kp.depth);
+    if (rc) return rc;
+
+    TimedFrame tf{};
+    if (ctx->profiling) {
+        for (int i = 0; i < 4; ++i) tf.e[i] = nullptr;
+        tf.e[0] = take_event(ctx);
+        tf.e[1] = take_event(ctx);
+    }
+    // FlushEnergyBuffer ARTS.cpp:157-161
+    FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+    if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
+    launch_walk(B, ctx->scene, kp, ctx->st, ctx->stream);
+    launch_connect(B, ctx->scene, kp, ctx->st, s->d_energy, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    if (ctx->profiling) {
+        FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+        tf.has_trace = true;
+        ctx->pending.push_back(tf);
+    }
+    ctx->stats.frames++;
+    ctx->stats.pairs += kp.num_local;
+    ctx->stats.rays += 2ull * kp.num_local;
+    return FS_OK;
+}
+
+int fs_compute_energy_response(fs_context* ctx, fs_source h, const fs_params* p, float* energy_out) {
+    int rc = fs_compute_energy_response_async(ctx, h, p);
+    if (rc) return rc;
+    Source* s = get_source(ctx, h);
+    if (energy_out) {
+        FS_HIP(ctx, hipMemcpyAsync(energy_out, s->d_energy,
+                                   sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    resolve_timings(ctx);
+    return FS_OK;
+}
+
+int fs_energy_device_ptr(fs_context* ctx, fs_source h, void** dptr, size_t* bytes) {
+    if (!ctx || !dptr) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    *dptr = s->d_energy;
+    if (bytes) *bytes = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    return FS_OK;
+}
+
+int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    fs_params def;
+    if (!p) { fs_params_default(&def); p = &def; }
+    if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int B = ctx->cfg.num_bands;
+    int spb = p->samples_per_bin > 0 ? p->samples_per_bin
+                                     : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
+
+    poll_published(s);
+    // never overwrite the front buffer: at most two publishes in flight
+    if (s->enqueued >= 2) {
+        int slot = (int)((s->enqueued - 1) % kIrRing);
+        if (s->seq_of[slot] == s->enqueued - 1 && s->front.load(std::memory_order_relaxed) < s->enqueued - 1) {
+            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
+            poll_published(s);
+        }
+    }
+    TimedFrame tf{};
+    bool timed = ctx->profiling;
+    if (timed) {
+        for (int i = 0; i < 4; ++i) tf.e[i] = nullptr;
+        tf.e[2] = take_event(ctx);
+        tf.e[3] = take_event(ctx);
+        FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
+    }
+    if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)  // ARTS.cpp:191 literally
+        FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+    launch_reconstruct(s->d_energy, B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
+                       s->d_ir_mono, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    uint64_t seq = s->enqueued + 1;
+    int slot = (int)(seq % kIrRing);
+    FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->stream));
+    s->seq_of[slot] = seq;
+    s->enqueued = seq;
+    if (timed) {
+        FS_HIP(ctx, hipEventRecord(tf.e[3], ctx->stream));
+        tf.has_recon = true;
+        ctx->pending.push_back(tf);
+    }
+    return FS_OK;
+}
+
+int fs_synchronize(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (Source* s : ctx->sources)
+        if (s && s->alive) poll_published(s);
+    resolve_timings(ctx);
+    return FS_OK;
+}
+
+int fs_reconstruct_impulse_response(fs_context* ctx, fs_source h, const fs_params* p) {
+    int rc = fs_reconstruct_impulse_response_async(ctx, h, p);
+    if (rc) return rc;
+    return fs_synchronize(ctx);
+}
+
+int fs_get_impulse_response(fs_context* ctx, fs_source h, int32_t channel, const float** data, int32_t* n) {
+    if (!ctx || !data) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return FS_ERR_BAD_HANDLE;  // no err string write: may be called from the audio thread
+    if (channel < 0 || channel >= ctx->cfg.num_channels) return FS_ERR_INVALID_ARGUMENT;
+    uint64_t f = s->front.load(std::memory_order_acquire);
+    *data = s->h_ir[(int)(f % kIrRing)];  // f == 0: slot 0 still holds the zero-initialised IR
+    if (n) *n = ctx->num_samples;
+    return FS_OK;
+}
+
+int fs_copy_impulse_response(fs_context* ctx, fs_source h, int32_t channel, float* out, int32_t n) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
+    const float* p = nullptr;
+    int rc = fs_get_impulse_response(ctx, h, channel, &p, nullptr);
+    if (rc) return rc;
+    std::memcpy(out, p, sizeof(float) * (size_t)n);
+    return FS_OK;
+}
+
+int fs_copy_band_impulse_response(fs_context* ctx, fs_source h, int32_t band, float* out, int32_t n) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
+    if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipMemcpyAsync(out, s->d_ir_bands + (size_t)band * (size_t)ctx->num_samples, sizeof(float) * (size_t)n,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+// ---- energy-buffer helpers (FSAC.h:72-91) ---------------------------------------------------------------
+int fs_get_energy_buffer(fs_context* ctx, fs_source h, float* out, int32_t n) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipMemcpyAsync(out, s->d_energy, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+int fs_flush_energy_buffer(fs_context* ctx, fs_source h) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
+                               ctx->stream));
+    return FS_OK;
+}
+
+int fs_add_energy_at_delay(fs_context* ctx, fs_source h, int32_t band, float delay_seconds, float energy) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    launch_add_energy(s->d_energy + (size_t)band * (size_t)ctx->num_bins, ctx->num_bins, delay_seconds, energy,
+                      ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    return FS_OK;
+}
+
+int fs_update_energy_buffer(fs_context* ctx, fs_source h, const float* values, int32_t n) {
+    if (!ctx || !values) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    // check(NewEnergyValues.Num() == NumBins) FSAC.h:83 -> status instead of abort
+    if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipMemcpyAsync(s->d_energy, values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+// ---- engine line trace ------------------------------------------------------------------------------------
+int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, const float* tmax, int32_t N,
+                  int32_t any_hit, int32_t* hit, float* t, int32_t* tri, float* normal) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    if (N < 0 || (N > 0 && (!origins || !dirs || !tmax || !hit))) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad ray arrays");
+    if (!any_hit && N > 0 && (!t || !tri || !normal)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "closest-hit outputs required");
+    if (N == 0) return FS_OK;
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    float *d_o = nullptr, *d_d = nullptr, *d_tm = nullptr, *d_t = nullptr, *d_n = nullptr;
+    int32_t *d_hit = nullptr, *d_tri = nullptr;
+    size_t n3 = sizeof(float) * 3 * (size_t)N, n1 = sizeof(float) * (size_t)N;
+    int rc = FS_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_t); (void)hipFree(d_n);
+        (void)hipFree(d_hit); (void)hipFree(d_tri);
+    };
+#define FS_TRY(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) { rc = ctx->hip_fail(e_, #call); cleanup(); return rc; } \
+    } while (0)
+    FS_TRY(hipMalloc((void**)&d_o, n3));
+    FS_TRY(hipMalloc((void**)&d_d, n3));
+    FS_TRY(hipMalloc((void**)&d_tm, n1));
+    FS_TRY(hipMalloc((void**)&d_t, n1));
+    FS_TRY(hipMalloc((void**)&d_n, n3));
+    FS_TRY(hipMalloc((void**)&d_hit, n1));
+    FS_TRY(hipMalloc((void**)&d_tri, n1));
+    FS_TRY(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
+    FS_TRY(hipMemcpyAsync(d_d, dirs, n3, hipMemcpyHostToDevice, ctx->stream));
+    FS_TRY(hipMemcpyAsync(d_tm, tmax, n1, hipMemcpyHostToDevice, ctx->stream));
+    launch_trace_rays(ctx->scene, d_o, d_d, d_tm, N, any_hit, d_hit, d_t, d_tri, d_n, ctx->stream);
+    FS_TRY(hipGetLastError());
+    FS_TRY(hipMemcpyAsync(hit, d_hit, n1, hipMemcpyDeviceToHost, ctx->stream));
+    if (!any_hit) {
+        FS_TRY(hipMemcpyAsync(t, d_t, n1, hipMemcpyDeviceToHost, ctx->stream));
+        FS_TRY(hipMemcpyAsync(tri, d_tri, n1, hipMemcpyDeviceToHost, ctx->stream));
+        FS_TRY(hipMemcpyAsync(normal, d_n, n3, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FS_TRY(hipStreamSynchronize(ctx->stream));
+#undef FS_TRY
+    cleanup();
+    return FS_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------------
+int fs_set_profiling(fs_context* ctx, int32_t enabled) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    ctx->profiling = enabled != 0;
+    return FS_OK;
+}
+
+int fs_get_stats(fs_context* ctx, fs_stats* out) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (ctx->device_ok && !ctx->pending.empty()) {
+        FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        resolve_timings(ctx);
+    }
+    *out = ctx->stats;
+    return FS_OK;
+}
+
+int fs_reset_stats(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    fs_stats keep = ctx->stats;
+    ctx->stats = fs_stats{};
+    ctx->stats.bvh_nodes = keep.bvh_nodes;
+    ctx->stats.triangles = keep.triangles;
+    ctx->stats.scene_bytes = keep.scene_bytes;
+    return FS_OK;
+}
+
+}  // extern "C"

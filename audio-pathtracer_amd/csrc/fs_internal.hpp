@@ -1,0 +1,89 @@
+// fs_internal.hpp — internal types shared by the host library and the HIP kernels (gfx950).
+// Not part of the public boundary (that is include/frequensee.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/frequensee.h"
+
+namespace fs {
+
+// ---- device data layout (HBM) --------------------------------------------------------------------
+// BVH2 node, 64 B = half a 128-B cache line, holds BOTH children's boxes so one fetch decides both:
+//   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
+//   q3 = (child0, child1, -, -) as int bits; child >= 0: inner node index; child < 0: leaf,
+//   ~child = first_tri * 4 + (count - 1), count in 1..4; empty child: box lo=+inf hi=-inf, child = -1.
+struct alignas(16) Node64 {
+    float4 q0, q1, q2;
+    int32_t c0, c1;
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(Node64) == 64, "Node64 must be 64 B");
+
+// Triangle record, 48 B, stored in leaf order:
+//   a = (v0.x v0.y v0.z e1.x)  b = (e1.y e1.z e2.x e2.y)  c = (e2.z, material, input index, -)
+struct alignas(16) Tri48 {
+    float4 a, b, c;
+};
+static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 B");
+
+constexpr int kStackDepth = 32;   // per-lane traversal stack entries (LDS); the builder caps tree depth
+constexpr int kBlock = 256;       // 4 waves of 64 lanes
+
+struct DeviceScene {
+    const Node64* nodes;
+    const Tri48* tris;
+    const float* absorption;  // [M][B]
+    int32_t num_nodes;        // 0 = empty scene
+    int32_t num_tris;
+    int32_t num_materials;
+};
+
+// per-update constants handed to the kernels by value
+struct KParams {
+    uint32_t seed_lo, seed_hi;
+    uint32_t pair_begin;   // first global pair index of this rank
+    uint32_t num_local;    // pairs traced by this rank
+    int32_t depth;         // max segments per subpath (1..FS_MAX_DEPTH)
+    int32_t russian_roulette;
+    int32_t cosine;
+    float rr_prob, max_trace_dist, surface_offset, connect_pullback;
+    float dist_divisor, min_seg, prob_exponent, energy_clamp, energy_gain, sound_speed;
+    float norm;            // 1/P or 1/1000 (ARTS.cpp:164)
+    float air[FS_MAX_BANDS];
+    float src[3], lis[3];
+    int32_t num_bins;
+};
+
+// Subpath terminal state, SoA over 2*num_local subpaths (side-major: [0,n) source, [n,2n) listener).
+struct SubpathState {
+    float4* pos_sd;    // xyz = last node position, w = sum of scaled segment lengths (source side)
+    float4* misc;      // x = last node prob, y = material (bits), z = segments taken (bits), w = unused
+    float* energy;     // [B][2n] running product per band
+    float* seg_nd;     // [depth][n] listener-side scaled segment lengths, walk order
+};
+
+// ---- host BVH builder ------------------------------------------------------------------------------
+struct HostBVH {
+    std::vector<Node64> nodes;
+    std::vector<Tri48> tris;   // leaf order
+    int max_depth = 0;
+};
+// xyz [T][3][3], mat [T]; binned SAH, <= 4 triangles per leaf, boxes padded conservatively.
+void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out);
+
+// ---- kernel launchers (fs_kernels.hip) -----------------------------------------------------------------
+void launch_walk(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, hipStream_t s);
+void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
+                    hipStream_t s);
+void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,
+                        float* ir_bands, float* ir_mono, hipStream_t s);
+void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
+                       int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s);
+void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s);
+
+}  // namespace fs

@@ -1,0 +1,182 @@
+/*
+ * frequensee.h — C ABI of the MI355X-native FrequenSee acoustic BDPT path.
+ *
+ * Drop-in boundary for the per-frame bidirectional path trace + energy-buffer loop of the
+ * FrequenSee Unreal plugin (henreedev/audio-pathtracer).  Every entry point names the reference
+ * interface it replaces; paths are relative to Plugins/FrequenSee/Source/FrequenSee/ in the
+ * reference tree:
+ *   ARTS.h/.cpp = Public/AudioRayTracingSubsystem.h, Private/AudioRayTracingSubsystem.cpp
+ *   FSAC.h/.cpp = Public/FrequenSeeAudioComponent.h, Private/FrequenSeeAudioComponent.cpp
+ *   MAT.h, GEO.h = Public/AcousticMaterial.h, Public/AcousticGeometryComponent.h
+ *
+ * Conventions: extern "C", POD only, every call returns an int status (FS_OK == 0), no exception
+ * crosses the boundary, output buffers are caller-allocated, handles are opaque.  Positions are
+ * Unreal units (cm).  One context drives one HIP device; all GPU work of a context is ordered on
+ * one HIP stream (its own, or the caller's via fs_config.stream).  A context is not re-entrant:
+ * one producer thread calls compute/reconstruct; any number of threads may read published
+ * impulse responses (fs_get_impulse_response) concurrently with the producer.
+ *
+ * There is no CPU fallback: if no HIP device is usable every compute entry point fails with
+ * FS_ERR_NO_DEVICE.
+ */
+#ifndef FREQUENSEE_H
+#define FREQUENSEE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_ABI_VERSION 1
+#define FS_MAX_BANDS 8
+#define FS_NO_MATERIAL 0xFFFFu /* actor without UAcousticGeometryComponent / Material (ARTS.cpp:383) */
+#define FS_MAX_DEPTH 64        /* hard cap on segments per subpath when depth == 0 ("unbounded") */
+
+/* status codes (replace the reference's check()/UE_LOG error behaviour) */
+enum {
+    FS_OK = 0,
+    FS_ERR_INVALID_ARGUMENT = 1,
+    FS_ERR_NO_DEVICE = 2,     /* no usable HIP device / HIP runtime error at init */
+    FS_ERR_HIP = 3,           /* a HIP call failed; fs_last_error() has the text */
+    FS_ERR_NOT_COMMITTED = 4, /* scene not committed */
+    FS_ERR_BAD_HANDLE = 5,
+    FS_ERR_SIZE_MISMATCH = 6, /* UpdateEnergyBuffer's check(Num()==NumBins), FSAC.h:83 */
+    FS_ERR_OUT_OF_MEMORY = 7
+};
+
+/* compat flags: reproduce a reference quirk literally (default 0 = evident intent) */
+#define FS_FLAG_FIXED_NORM_1000 1u          /* ARTS.cpp:164 normaliser 1/USED_RAY_COUNT whatever NumRays is */
+#define FS_FLAG_FLUSH_BEFORE_RECONSTRUCT 2u /* ARTS.cpp:191 second FlushEnergyBuffer (IR becomes all zero) */
+#define FS_FLAG_COSINE_SAMPLING 4u          /* cosine-weighted bounce instead of VRandCone(n, 90 deg) */
+
+typedef struct fs_context fs_context;
+typedef int32_t fs_source; /* handle of one registered UFrequenSeeAudioComponent */
+
+/* Subsystem/component sizing constants (FSAC.h:133-139). Zero fields take the reference value. */
+typedef struct fs_config {
+    uint32_t struct_size;      /* = sizeof(fs_config) */
+    int32_t device;            /* HIP device ordinal */
+    int32_t num_bands;         /* B, 1..FS_MAX_BANDS; 1 = the reference (band slot 0 == Absorption[2]) */
+    int32_t sample_rate;       /* 48000  FSAC.h:133 */
+    int32_t num_channels;      /* 2      FSAC.h:135 */
+    float simulated_duration;  /* 1.0 s  FSAC.h:136 */
+    float bin_duration;        /* 0.001 s FSAC.h:137 */
+    int32_t rank;              /* multi-GPU: this process traces pairs [rank*P/W, (rank+1)*P/W) */
+    int32_t world_size;        /* W >= 1 */
+    void* stream;              /* optional hipStream_t owned by the caller (e.g. the harness's); NULL = own stream */
+} fs_config;
+
+/* Per-update parameters; defaults (fs_params_default) are the constants compiled into the reference. */
+typedef struct fs_params {
+    uint32_t struct_size;      /* = sizeof(fs_params) */
+    uint32_t flags;            /* FS_FLAG_* */
+    uint64_t seed;             /* counter-based RNG key (replaces the global rand() behind FMath::FRand) */
+    uint32_t num_rays;         /* R = source + listener subpaths per frame over all ranks; pairs P = R/2.
+                                  reference: NumRays = USED_RAY_COUNT = 1000 pairs = 2000 (ARTS.h:176) */
+    int32_t depth;             /* max segments per subpath; 0 = unbounded like ARTS.cpp:294 (capped at FS_MAX_DEPTH) */
+    int32_t russian_roulette;  /* 1 = ARTS.cpp:300-301 */
+    float rr_prob;             /* 0.9       ARTS.cpp:282 */
+    float max_trace_dist;      /* 1e6 cm    ARTS.cpp:284 */
+    float surface_offset;      /* 0.1 cm    ARTS.cpp:345 */
+    float connect_pullback;    /* 0.1 cm    ARTS.cpp:253 */
+    float dist_divisor;        /* 1000      ARTS.cpp:373 */
+    float min_seg;             /* 1.0       ARTS.cpp:375 */
+    float prob_exponent;       /* 0.1       ARTS.cpp:398 */
+    float energy_clamp;        /* 1.0       ARTS.cpp:410 */
+    float energy_gain;         /* 10        ARTS.cpp:413 */
+    float sound_speed;         /* 343       ARTS.cpp:362 */
+    float air_absorption[FS_MAX_BANDS]; /* 0.05 per band, ARTS.cpp:395 */
+    int32_t samples_per_bin;   /* 0 = reference's ceil(0.001f*48000) = 49 (FSAC.cpp:324) */
+} fs_params;
+
+typedef struct fs_stats {
+    uint64_t frames;             /* compute_energy_response calls */
+    uint64_t rays;               /* subpaths traced by this rank */
+    uint64_t pairs;              /* pairs traced by this rank */
+    double trace_kernel_ms_sum;  /* HIP-event time of the dominant kernel(s) on the context's stream */
+    double trace_kernel_ms_last;
+    double reconstruct_ms_sum;
+    uint64_t timed_frames;       /* frames contributing to *_ms_sum (profiling enabled) */
+    uint32_t bvh_nodes;
+    uint32_t triangles;
+    uint64_t scene_bytes;        /* device bytes of BVH + triangles + materials */
+} fs_stats;
+
+/* ---- lifecycle: UAudioRayTracingSubsystem::Initialize/Deinitialize (ARTS.cpp:32-42) ------------- */
+void fs_config_default(fs_config* cfg);
+void fs_params_default(fs_params* p);
+int fs_abi_version(void);
+int fs_context_create(const fs_config* cfg, fs_context** out);
+int fs_context_destroy(fs_context* ctx);
+const char* fs_last_error(const fs_context* ctx); /* replaces UE_LOG warnings; "" if none */
+
+/* ---- scene: RegisterGeometry/UnregisterGeometry (ARTS.h:99-100) + UAcousticMaterial (MAT.h:22-33) -- */
+/* xyz: [T][3][3] vertices, mat_id: [T] index into the material table or FS_NO_MATERIAL. Caller keeps ownership. */
+int fs_scene_set_triangles(fs_context* ctx, const float* xyz, const uint16_t* mat_id, int32_t T);
+/* absorption/transmission/scattering: [M][B] (FAcousticBand arrays, MAT.h:22-30); transmission and
+ * scattering may be NULL (the BDPT path reads Absorption only, ARTS.cpp:385). */
+int fs_scene_set_materials(fs_context* ctx, const float* absorption, const float* transmission,
+                           const float* scattering, int32_t M, int32_t B);
+int fs_scene_commit(fs_context* ctx); /* builds the flattened BVH and uploads it */
+
+/* ---- sources and listener: RegisterSource/UnRegisterSource (ARTS.h:103-104, ARTS.cpp:45-53),
+ *      GetActorLocation of the source owner / the player pawn (ARTS.cpp:287) ------------------------- */
+int fs_source_create(fs_context* ctx, fs_source* out);
+int fs_source_destroy(fs_context* ctx, fs_source src);
+int fs_source_set_position(fs_context* ctx, fs_source src, const float xyz[3]);
+int fs_listener_set_position(fs_context* ctx, const float xyz[3]);
+
+/* ---- the hot path ------------------------------------------------------------------------------- */
+/* ComputeEnergyResponse() == UpdateSource up to the deposit (ARTS.cpp:128-173): GenerateFullPaths
+ * (:201-233) -> GeneratePath x2 (:279-355) -> ConnectSubpaths (:235-277) -> EvaluatePath (:360-420)
+ * -> FlushEnergyBuffer + AddEnergyAtDelay(delay, gain/P) (:157-173, FSAC.h:76-91).
+ * Traces this rank's share of params->num_rays, leaves the band-major energy [B][num_bins] resident
+ * on the device and, if energy_out != NULL, copies it to the host (synchronous). */
+int fs_compute_energy_response(fs_context* ctx, fs_source src, const fs_params* params, float* energy_out);
+/* Same, enqueue only (no host sync). */
+int fs_compute_energy_response_async(fs_context* ctx, fs_source src, const fs_params* params);
+/* Device pointer of the source's energy buffer [B][num_bins] fp32 — the hook for a multi-GPU
+ * sum-reduce between compute and reconstruct (RCCL all-reduce on the same stream). */
+int fs_energy_device_ptr(fs_context* ctx, fs_source src, void** dptr, size_t* bytes);
+
+/* ReconstructImpulseResponse (FSAC.cpp:320-380, called at ARTS.cpp:192): energy -> per-band IR
+ * [B][num_samples] and the num_channels-channel view (both channels identical, FSAC.cpp:331) built
+ * from the band-mean energy; publishes the channel view to the host front buffer. */
+int fs_reconstruct_impulse_response(fs_context* ctx, fs_source src, const fs_params* params);
+int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source src, const fs_params* params);
+int fs_synchronize(fs_context* ctx);
+
+/* GetImpulseResponse() (FSAC.h:113): pointer to the PUBLISHED [num_samples] channel buffer, valid
+ * until the second-next publish; lock-free for the audio thread (RVB.cpp:136). */
+int fs_get_impulse_response(fs_context* ctx, fs_source src, int32_t channel, const float** data, int32_t* n);
+int fs_copy_impulse_response(fs_context* ctx, fs_source src, int32_t channel, float* out, int32_t n);
+int fs_copy_band_impulse_response(fs_context* ctx, fs_source src, int32_t band, float* out, int32_t n);
+
+/* ---- energy-buffer helpers of the component (FSAC.h:72-91), so a UE shim or a test can drive the
+ *      same sequence as ARTS.cpp:157-192 ------------------------------------------------------------ */
+int fs_get_energy_buffer(fs_context* ctx, fs_source src, float* out, int32_t n);          /* EnergyBuffer */
+int fs_flush_energy_buffer(fs_context* ctx, fs_source src);                                /* FSAC.h:76-79 */
+int fs_add_energy_at_delay(fs_context* ctx, fs_source src, int32_t band, float delay_seconds,
+                           float energy);                                                  /* FSAC.h:87-91 */
+int fs_update_energy_buffer(fs_context* ctx, fs_source src, const float* values, int32_t n); /* FSAC.h:81-85 */
+int fs_num_bins(const fs_context* ctx);    /* FSAC.h:137 */
+int fs_num_samples(const fs_context* ctx); /* FSAC.h:138 */
+
+/* ---- engine line trace the BVH kernel replaces (UWorld::LineTraceSingleByObjectType; call sites
+ *      ARTS.cpp:252-254 any-hit, :340-342 closest-hit). Batch query, host arrays. ------------------- */
+/* origins/dirs: [N][3] (dirs unit), tmax: [N]; out: hit[N] (0/1), t[N], tri[N] (input triangle index or -1),
+ * normal[N][3] (unit, facing the ray origin side). any_hit != 0: only hit[] is written. */
+int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, const float* tmax, int32_t N,
+                  int32_t any_hit, int32_t* hit, float* t, int32_t* tri, float* normal);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+int fs_set_profiling(fs_context* ctx, int32_t enabled); /* HIP events around the kernels on the stream */
+int fs_get_stats(fs_context* ctx, fs_stats* out);
+int fs_reset_stats(fs_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREQUENSEE_H */

@@ -1,0 +1,268 @@
+"""ctypes loader for the CPU oracle (oracle/fs_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (audio-pathtracer_amd/) never does.  See fs_oracle.h for provenance and the
+"parity unpinned" statement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_BANDS = 8
+NO_MATERIAL = 0xFFFF
+
+FLAG_FIXED_NORM_1000 = 1
+FLAG_FLUSH_BEFORE_RECONSTRUCT = 2
+FLAG_COSINE_SAMPLING = 4
+FLAG_BRUTE_FORCE = 8
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("num_pairs", C.c_uint32),
+        ("depth", C.c_int32),
+        ("russian_roulette", C.c_int32),
+        ("rr_prob", C.c_float),
+        ("max_trace_dist", C.c_float),
+        ("surface_offset", C.c_float),
+        ("connect_pullback", C.c_float),
+        ("dist_divisor", C.c_float),
+        ("min_seg", C.c_float),
+        ("prob_exponent", C.c_float),
+        ("energy_clamp", C.c_float),
+        ("energy_gain", C.c_float),
+        ("sound_speed", C.c_float),
+        ("air_absorption", C.c_float * MAX_BANDS),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("node_visits", C.c_uint64),
+        ("tri_tests", C.c_uint64),
+        ("closest_rays", C.c_uint64),
+        ("any_rays", C.c_uint64),
+        ("connected", C.c_uint64),
+        ("deposits", C.c_uint64),
+        ("path_nodes", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+    def add(self, other):
+        for k, _ in self._fields_:
+            setattr(self, k, getattr(self, k) + getattr(other, k))
+
+
+class Node(C.Structure):
+    _fields_ = [
+        ("pos", C.c_float * 3),
+        ("normal", C.c_float * 3),
+        ("material", C.c_uint32),
+        ("prob", C.c_float),
+    ]
+
+
+def build(native: bool = False, outdir: str | None = None) -> str:
+    """Compile the oracle.  native=True builds -O3 -march=native into outdir (CPU-baseline timing)."""
+    if native:
+        outdir = outdir or "/tmp"
+        os.makedirs(outdir, exist_ok=True)
+        subprocess.run(["make", "-s", "-C", _HERE, "native", f"OUT={outdir}"], check=True)
+        return os.path.join(outdir, "libfs_oracle_native.so")
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return os.path.join(_HERE, "libfs_oracle.so")
+
+
+_f3 = C.POINTER(C.c_float)
+
+
+def _bind(lib):
+    lib.fso_params_default.argtypes = [C.POINTER(Params)]
+    lib.fso_scene_create.restype = C.c_void_p
+    lib.fso_scene_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    lib.fso_scene_destroy.argtypes = [C.c_void_p]
+    lib.fso_scene_num_nodes.argtypes = [C.c_void_p]
+    lib.fso_scene_num_nodes.restype = C.c_int32
+    lib.fso_trace_closest.argtypes = [C.c_void_p, _f3, _f3, C.c_float, C.c_int32, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int32), _f3, C.POINTER(Counters)]
+    lib.fso_trace_closest.restype = C.c_int32
+    lib.fso_trace_any.argtypes = [C.c_void_p, _f3, _f3, C.c_float, C.c_int32, C.POINTER(Counters)]
+    lib.fso_trace_any.restype = C.c_int32
+    lib.fso_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.fso_u01.argtypes = [C.c_uint32]
+    lib.fso_u01.restype = C.c_float
+    lib.fso_sincos2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.fso_sample_sphere.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), _f3]
+    lib.fso_sample_cone.argtypes = [_f3, C.c_float, C.c_float, C.c_int32, _f3]
+    lib.fso_generate_path.argtypes = [C.c_void_p, C.POINTER(Params), C.c_uint32, C.c_uint32, _f3,
+                                      C.POINTER(Node), C.c_int32, C.POINTER(Counters)]
+    lib.fso_generate_path.restype = C.c_int32
+    lib.fso_connect.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Node), C.POINTER(Node), C.POINTER(Counters)]
+    lib.fso_connect.restype = C.c_int32
+    lib.fso_evaluate_path.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Node), C.c_int32,
+                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.fso_add_energy_at_delay.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]
+    lib.fso_add_energy_at_delay.restype = C.c_int32
+    lib.fso_num_bins.argtypes = [C.c_float, C.c_float]
+    lib.fso_num_bins.restype = C.c_int32
+    lib.fso_num_samples.argtypes = [C.c_float, C.c_int32]
+    lib.fso_num_samples.restype = C.c_int32
+    lib.fso_samples_per_bin.argtypes = [C.c_float, C.c_int32]
+    lib.fso_samples_per_bin.restype = C.c_int32
+    lib.fso_compute_energy.argtypes = [C.c_void_p, C.POINTER(Params), _f3, _f3, C.c_uint32, C.c_uint32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+    lib.fso_reconstruct.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fso_occlusion_attenuation.argtypes = [C.c_void_p, _f3, _f3, C.c_float, C.c_float, C.c_int32]
+    lib.fso_occlusion_attenuation.restype = C.c_float
+    return lib
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load(path: str | None = None):
+    """Load (building if needed) the portable oracle library."""
+    global _lib
+    if path is not None:
+        return _bind(C.CDLL(path))
+    with _lock:
+        if _lib is None:
+            so = os.path.join(_HERE, "libfs_oracle.so")
+            if not os.path.exists(so):
+                build()
+            _lib = _bind(C.CDLL(so))
+    return _lib
+
+
+def _vec3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load().fso_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k == "air_absorption":
+            for i, x in enumerate(v):
+                p.air_absorption[i] = float(x)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+class Scene:
+    """Triangle soup + per-band material table (what RegisterGeometry + UAcousticMaterial provide)."""
+
+    def __init__(self, tri_xyz, mat_id, absorption, lib=None):
+        self.lib = lib or load()
+        self.tri = np.ascontiguousarray(tri_xyz, dtype=np.float32).reshape(-1, 3, 3)
+        self.mat = np.ascontiguousarray(mat_id, dtype=np.uint16).reshape(-1)
+        self.absorption = np.ascontiguousarray(absorption, dtype=np.float32)
+        if self.absorption.ndim == 1:
+            self.absorption = self.absorption.reshape(-1, 1)
+        self.M, self.B = self.absorption.shape
+        self.T = self.tri.shape[0]
+        assert self.mat.shape[0] == self.T
+        self.h = self.lib.fso_scene_create(self.tri.ctypes.data, self.mat.ctypes.data, self.T,
+                                           self.absorption.ctypes.data, self.M, self.B)
+        if not self.h:
+            raise ValueError("fso_scene_create failed")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.fso_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # --- engine line-trace contract -------------------------------------------------------
+    def trace_closest(self, o, d, tmax=1e6, brute=False, counters=None):
+        t = C.c_float()
+        tri = C.c_int32(-1)
+        n = (C.c_float * 3)()
+        hit = self.lib.fso_trace_closest(self.h, _vec3(o), _vec3(d), tmax, int(brute), C.byref(t), C.byref(tri), n,
+                                         C.byref(counters) if counters is not None else None)
+        return bool(hit), float(t.value), int(tri.value), np.array(list(n), dtype=np.float32)
+
+    def trace_any(self, o, d, tmax, brute=False):
+        return bool(self.lib.fso_trace_any(self.h, _vec3(o), _vec3(d), tmax, int(brute), None))
+
+    # --- path pieces --------------------------------------------------------------------------
+    def generate_path(self, params, pair, side, start, max_nodes=130):
+        nodes = (Node * max_nodes)()
+        n = self.lib.fso_generate_path(self.h, C.byref(params), pair, side, _vec3(start), nodes, max_nodes, None)
+        return [nodes[i] for i in range(n)]
+
+    def connect(self, params, f, b):
+        return bool(self.lib.fso_connect(self.h, C.byref(params), C.byref(f), C.byref(b), None))
+
+    def evaluate_path(self, params, nodes):
+        arr = (Node * len(nodes))(*nodes)
+        gains = (C.c_float * MAX_BANDS)()
+        delay = C.c_float()
+        self.lib.fso_evaluate_path(self.h, C.byref(params), arr, len(nodes), gains, C.byref(delay))
+        return np.array(list(gains)[: self.B], dtype=np.float32), float(delay.value)
+
+    # --- frame --------------------------------------------------------------------------------
+    def compute_energy(self, params, src, lis, pair_begin=0, pair_end=None, num_bins=1000, want_f64=True):
+        """UpdateSource up to the deposit (ARTS.cpp:128-173) for pairs [pair_begin, pair_end)."""
+        if pair_end is None:
+            pair_end = params.num_pairs
+        e32 = np.zeros((self.B, num_bins), dtype=np.float32)
+        e64 = np.zeros((self.B, num_bins), dtype=np.float64) if want_f64 else None
+        c = Counters()
+        self.lib.fso_compute_energy(self.h, C.byref(params), _vec3(src), _vec3(lis), pair_begin, pair_end, num_bins,
+                                    e32.ctypes.data, e64.ctypes.data if want_f64 else None, C.byref(c))
+        return e32, e64, c
+
+    def compute_energy_mt(self, params, src, lis, threads, pair_begin=0, pair_end=None, num_bins=1000):
+        """All-cores CPU baseline: static partition of the pair range, private histograms, final sum.
+        ctypes releases the GIL during the foreign call, so plain Python threads run in parallel."""
+        if pair_end is None:
+            pair_end = params.num_pairs
+        n = pair_end - pair_begin
+        cuts = [pair_begin + (n * i) // threads for i in range(threads + 1)]
+
+        def work(i):
+            return self.compute_energy(params, src, lis, cuts[i], cuts[i + 1], num_bins, want_f64=True)
+
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            parts = list(ex.map(work, range(threads)))
+        e64 = sum(p[1] for p in parts)
+        c = Counters()
+        for p in parts:
+            c.add(p[2])
+        return e64.astype(np.float32), e64, c
+
+    def occlusion_attenuation(self, src, lis, listener_radius=50.0, raycast_distance=5000.0, bounces=10):
+        return float(self.lib.fso_occlusion_attenuation(self.h, _vec3(src), _vec3(lis), listener_radius,
+                                                        raycast_distance, bounces))
+
+
+def reconstruct(energy_row, sample_rate=48000, bin_duration=0.001, num_samples=48000, samples_per_bin=0, lib=None):
+    """ReconstructImpulseResponse (FSAC.cpp:320-380) for one energy row."""
+    lib = lib or load()
+    e = np.ascontiguousarray(energy_row, dtype=np.float32)
+    out = np.zeros(num_samples, dtype=np.float32)
+    lib.fso_reconstruct(e.ctypes.data, e.shape[0], sample_rate, bin_duration, num_samples, samples_per_bin,
+                        out.ctypes.data)
+    return out
+
+
+def add_energy_at_delay(buf, delay, e, bin_size_ms=1, lib=None):
+    lib = lib or load()
+    assert buf.dtype == np.float32 and buf.flags.c_contiguous
+    return lib.fso_add_energy_at_delay(buf.ctypes.data, buf.shape[0], bin_size_ms, delay, e)

@@ -1,0 +1,730 @@
+/*
+ * fs_oracle.c — CPU restatement of the FrequenSee BDPT hot path.  TEST INFRASTRUCTURE ONLY.
+ * See fs_oracle.h for scope, provenance and the "parity unpinned" statement.
+ *
+ * File:line citations are into /root/reference/Plugins/FrequenSee/Source/FrequenSee/:
+ *   ARTS.cpp = Private/AudioRayTracingSubsystem.cpp     ARTS.h = Public/AudioRayTracingSubsystem.h
+ *   FSAC.cpp = Private/FrequenSeeAudioComponent.cpp      FSAC.h = Public/FrequenSeeAudioComponent.h
+ *   MAT.h    = Public/AcousticMaterial.h
+ *
+ * Build with -ffp-contract=off: every float op below is a single IEEE-754 binary32 operation
+ * (+ - * / sqrtf fmaf), so the path geometry is reproducible bit-for-bit on any conforming target.
+ */
+#include "fs_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FSO_PI 3.1415926535897932f /* UE_PI */
+
+/* ------------------------------------------------------------------------------------------- */
+/* defaults = the constants compiled into the reference                        */
+/* ------------------------------------------------------------------------------------------- */
+void fso_params_default(fso_params* p) {
+    memset(p, 0, sizeof(*p));
+    p->seed = 0x5EEDull;
+    p->num_pairs = 1000;        /* USED_RAY_COUNT ARTS.h:176 */
+    p->depth = 0;               /* no cap in GeneratePath ARTS.cpp:294 */
+    p->russian_roulette = 1;
+    p->rr_prob = 0.9f;          /* ARTS.cpp:282 */
+    p->max_trace_dist = 1000000.f; /* ARTS.cpp:284 */
+    p->surface_offset = 0.1f;   /* ARTS.cpp:345 */
+    p->connect_pullback = 0.1f; /* ARTS.cpp:253 */
+    p->dist_divisor = 1000.f;   /* ARTS.cpp:373 */
+    p->min_seg = 1.0f;          /* ARTS.cpp:375 */
+    p->prob_exponent = 0.1f;    /* ARTS.cpp:398 */
+    p->energy_clamp = 1.0f;     /* ARTS.cpp:410 */
+    p->energy_gain = 10.f;      /* ARTS.cpp:413 */
+    p->sound_speed = 343.0f;    /* ARTS.cpp:362 */
+    for (int b = 0; b < FSO_MAX_BANDS; ++b) p->air_absorption[b] = 0.05f; /* ARTS.cpp:395 */
+    p->flags = 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* RNG: Philox4x32-10 (Salmon et al. 2011), replaces FMath::FRand's global rand()              */
+/* ------------------------------------------------------------------------------------------- */
+void fso_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* [0,1) with 24 mantissa bits (FRand contract: uniform float) */
+float fso_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
+/* draw block `block` of the stream (seed, pair, side, bounce) */
+static void fso_draw(uint64_t seed, uint32_t pair, uint32_t side, uint32_t bounce, uint32_t block, uint32_t out[4]) {
+    uint32_t ctr[4] = {pair, (bounce << 1) | (side & 1u), block, 0x46533031u /* 'FS01' */};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    fso_philox4x32_10(ctr, key, out);
+}
+
+/* sin/cos(2*pi*u), u in [0,1): quadrant reduction + Taylor polynomials evaluated with fmaf only,
+ * so CPU and GPU agree bit-for-bit (libm sinf/cosf are not reproducible across targets). */
+void fso_sincos2pi(float u, float* s_out, float* c_out) {
+    float q = floorf(fmaf(u, 4.0f, 0.5f));         /* nearest quarter turn, 0..4 */
+    float a = fmaf(q, -0.25f, u);                   /* [-1/8, 1/8], exact */
+    float x = a * 6.283185307179586f;               /* [-pi/4, pi/4] */
+    float x2 = x * x;
+    float sp = 2.7557319e-06f;                      /* 1/9! */
+    sp = fmaf(sp, x2, -1.9841270e-04f);             /* -1/7! */
+    sp = fmaf(sp, x2, 8.3333333e-03f);              /* 1/5! */
+    sp = fmaf(sp, x2, -1.6666667e-01f);             /* -1/3! */
+    float s = fmaf(sp * x2, x, x);
+    float cp = 2.4801587e-05f;                      /* 1/8! */
+    cp = fmaf(cp, x2, -1.3888889e-03f);             /* -1/6! */
+    cp = fmaf(cp, x2, 4.1666667e-02f);              /* 1/4! */
+    cp = fmaf(cp, x2, -0.5f);
+    float c = fmaf(cp, x2, 1.0f);
+    int k = ((int)q) & 3;
+    float ss, cc;
+    if (k == 0) { ss = s; cc = c; }
+    else if (k == 1) { ss = c; cc = -s; }
+    else if (k == 2) { ss = -s; cc = -c; }
+    else { ss = -c; cc = s; }
+    *s_out = ss; *c_out = cc;
+}
+
+/* FMath::VRand (ARTS.cpp:308): rejection in the cube until 1e-4 < |v|^2 <= 1, then normalise.
+ * r0 = block 0 of the bounce's stream (r0[0] was the roulette draw); retries use blocks 1.. */
+void fso_sample_sphere(uint64_t seed, uint32_t pair, uint32_t side, uint32_t bounce, const uint32_t r0[4],
+                       float dir[3]) {
+    uint32_t r[4] = {r0[1], r0[2], r0[3], 0};
+    for (uint32_t attempt = 0; attempt < 16; ++attempt) {
+        if (attempt > 0) fso_draw(seed, pair, side, bounce, attempt, r);
+        float x = fmaf(fso_u01(r[0]), 2.0f, -1.0f);
+        float y = fmaf(fso_u01(r[1]), 2.0f, -1.0f);
+        float z = fmaf(fso_u01(r[2]), 2.0f, -1.0f);
+        float l2 = x * x + y * y + z * z;
+        if (l2 > 1e-4f && l2 <= 1.0f) {
+            float inv = 1.0f / sqrtf(l2);
+            dir[0] = x * inv; dir[1] = y * inv; dir[2] = z * inv;
+            return;
+        }
+    }
+    dir[0] = 0.f; dir[1] = 0.f; dir[2] = 1.f;
+}
+
+/* FMath::VRandCone(n, pi/2) (ARTS.cpp:313): theta = 2 pi U; phi = fmod(acos(2V-1), pi/2);
+ * rotate n by phi about a perpendicular axis, then by theta about n; GetSafeNormal.
+ * With x = 2V-1: x > 0 -> (cos phi, sin phi) = (x, sqrt(1-x^2)); x <= 0 -> phi = acos(x) - pi/2 ->
+ * (cos phi, sin phi) = (sqrt(1-x^2), -x).  No acos/fmod needed.
+ * cosine != 0: cosine-weighted hemisphere (compat flag "cosine_sampling", quirk A.6-g). */
+void fso_sample_cone(const float n[3], float U, float V, int32_t cosine, float dir[3]) {
+    float cphi, sphi;
+    if (cosine) {
+        cphi = sqrtf(1.0f - V);
+        sphi = sqrtf(V);
+    } else {
+        float x = fmaf(V, 2.0f, -1.0f);
+        float r = sqrtf(fmaxf(0.0f, fmaf(-x, x, 1.0f)));
+        if (x > 0.0f) { cphi = x; sphi = r; } else { cphi = r; sphi = -x; }
+    }
+    float st, ct;
+    fso_sincos2pi(U, &st, &ct);
+    /* orthonormal basis (Duff et al. 2017, branchless) */
+    float sg = copysignf(1.0f, n[2]);
+    float a = -1.0f / (sg + n[2]);
+    float b = n[0] * n[1] * a;
+    float t0 = fmaf(sg * n[0] * n[0], a, 1.0f), t1 = sg * b, t2 = -sg * n[0];
+    float b0 = b, b1 = fmaf(n[1] * n[1], a, sg), b2 = -n[1];
+    float lx = sphi * ct, ly = sphi * st;
+    float d0 = fmaf(lx, t0, fmaf(ly, b0, cphi * n[0]));
+    float d1 = fmaf(lx, t1, fmaf(ly, b1, cphi * n[1]));
+    float d2 = fmaf(lx, t2, fmaf(ly, b2, cphi * n[2]));
+    float l2 = d0 * d0 + d1 * d1 + d2 * d2;
+    float inv = 1.0f / sqrtf(l2);
+    dir[0] = d0 * inv; dir[1] = d1 * inv; dir[2] = d2 * inv;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* scene: triangles + materials + reference BVH2 (binned SAH, <= 4 tris/leaf)                  */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct fso_tri { /* 48 B record: v0, e1, e2, material */
+    float v0[3]; float e1[3]; float e2[3];
+    uint32_t material; uint32_t id; uint32_t pad;
+} fso_tri;
+
+typedef struct fso_bnode { /* 32 B */
+    float lo[3]; float hi[3];
+    uint32_t left_first; /* inner: index of left child (right = left+1); leaf: first triangle */
+    uint32_t count;      /* 0 = inner */
+} fso_bnode;
+
+struct fso_scene {
+    int32_t T, M, B;
+    fso_tri* tris;       /* leaf order */
+    fso_tri* tris_orig;  /* input order (brute force scans ids ascending) */
+    float* absorption;   /* [M][B] */
+    fso_bnode* nodes;
+    int32_t num_nodes;
+    float pad;
+};
+
+static void tri_bounds(const fso_tri* t, float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; ++k) {
+        float a = t->v0[k], b = t->v0[k] + t->e1[k], c = t->v0[k] + t->e2[k];
+        lo[k] = fminf(a, fminf(b, c));
+        hi[k] = fmaxf(a, fmaxf(b, c));
+    }
+}
+
+typedef struct build_ctx {
+    fso_scene* s;
+    float* clo; float* chi; float* cen; /* per-triangle bounds/centroid, permuted with tris */
+} build_ctx;
+
+static void swap_tri(build_ctx* bc, int i, int j) {
+    if (i == j) return;
+    fso_tri tt = bc->s->tris[i]; bc->s->tris[i] = bc->s->tris[j]; bc->s->tris[j] = tt;
+    for (int k = 0; k < 3; ++k) {
+        float x;
+        x = bc->clo[3 * i + k]; bc->clo[3 * i + k] = bc->clo[3 * j + k]; bc->clo[3 * j + k] = x;
+        x = bc->chi[3 * i + k]; bc->chi[3 * i + k] = bc->chi[3 * j + k]; bc->chi[3 * j + k] = x;
+        x = bc->cen[3 * i + k]; bc->cen[3 * i + k] = bc->cen[3 * j + k]; bc->cen[3 * j + k] = x;
+    }
+}
+
+static float half_area(const float lo[3], const float hi[3]) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+#define FSO_BINS 16
+static void build_node(build_ctx* bc, uint32_t ni, int first, int count) {
+    fso_scene* s = bc->s;
+    fso_bnode* nd = &s->nodes[ni];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = first; i < first + count; ++i)
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], bc->clo[3 * i + k]); hi[k] = fmaxf(hi[k], bc->chi[3 * i + k]);
+            clo[k] = fminf(clo[k], bc->cen[3 * i + k]); chi[k] = fmaxf(chi[k], bc->cen[3 * i + k]);
+        }
+    for (int k = 0; k < 3; ++k) { nd->lo[k] = lo[k] - s->pad; nd->hi[k] = hi[k] + s->pad; }
+    if (count <= 4) { nd->left_first = (uint32_t)first; nd->count = (uint32_t)count; return; }
+
+    int best_axis = -1, best_split = -1; float best_cost = INFINITY;
+    for (int ax = 0; ax < 3; ++ax) {
+        float ext = chi[ax] - clo[ax];
+        if (!(ext > 0.0f)) continue;
+        float blo[FSO_BINS][3], bhi[FSO_BINS][3]; int bcnt[FSO_BINS];
+        for (int b = 0; b < FSO_BINS; ++b) {
+            bcnt[b] = 0;
+            for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; }
+        }
+        float scale = (float)FSO_BINS / ext;
+        for (int i = first; i < first + count; ++i) {
+            int b = (int)((bc->cen[3 * i + ax] - clo[ax]) * scale);
+            if (b < 0) b = 0; if (b >= FSO_BINS) b = FSO_BINS - 1;
+            bcnt[b]++;
+            for (int k = 0; k < 3; ++k) {
+                blo[b][k] = fminf(blo[b][k], bc->clo[3 * i + k]); bhi[b][k] = fmaxf(bhi[b][k], bc->chi[3 * i + k]);
+            }
+        }
+        float rarea[FSO_BINS]; int rcnt[FSO_BINS];
+        float rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY}; int rc = 0;
+        for (int b = FSO_BINS - 1; b >= 1; --b) {
+            for (int k = 0; k < 3; ++k) { rl[k] = fminf(rl[k], blo[b][k]); rh[k] = fmaxf(rh[k], bhi[b][k]); }
+            rc += bcnt[b]; rcnt[b] = rc; rarea[b] = rc ? half_area(rl, rh) : 0.0f;
+        }
+        float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY}; int lc = 0;
+        for (int b = 0; b < FSO_BINS - 1; ++b) {
+            for (int k = 0; k < 3; ++k) { ll[k] = fminf(ll[k], blo[b][k]); lh[k] = fmaxf(lh[k], bhi[b][k]); }
+            lc += bcnt[b];
+            if (lc == 0 || rcnt[b + 1] == 0) continue;
+            float cost = half_area(ll, lh) * (float)lc + rarea[b + 1] * (float)rcnt[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
+        }
+    }
+    int mid;
+    if (best_axis < 0) {
+        mid = first + count / 2; /* all centroids coincide: split by index */
+    } else {
+        float ext = chi[best_axis] - clo[best_axis];
+        float scale = (float)FSO_BINS / ext;
+        int i = first, j = first + count - 1;
+        while (i <= j) {
+            int b = (int)((bc->cen[3 * i + best_axis] - clo[best_axis]) * scale);
+            if (b < 0) b = 0; if (b >= FSO_BINS) b = FSO_BINS - 1;
+            if (b <= best_split) ++i; else { swap_tri(bc, i, j); --j; }
+        }
+        mid = i;
+        if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    uint32_t left = (uint32_t)s->num_nodes;
+    s->num_nodes += 2;
+    nd->left_first = left; nd->count = 0;
+    build_node(bc, left, first, mid - first);
+    build_node(bc, left + 1, mid, first + count - mid);
+}
+
+fso_scene* fso_scene_create(const float* xyz, const uint16_t* mat_id, int32_t T, const float* absorption,
+                            int32_t M, int32_t B) {
+    if (T < 0 || B < 1 || B > FSO_MAX_BANDS) return NULL;
+    fso_scene* s = (fso_scene*)calloc(1, sizeof(fso_scene));
+    s->T = T; s->M = M; s->B = B;
+    s->tris = (fso_tri*)calloc((size_t)(T > 0 ? T : 1), sizeof(fso_tri));
+    s->tris_orig = (fso_tri*)calloc((size_t)(T > 0 ? T : 1), sizeof(fso_tri));
+    s->absorption = (float*)calloc((size_t)(M > 0 ? M * B : 1), sizeof(float));
+    if (M > 0) memcpy(s->absorption, absorption, sizeof(float) * (size_t)M * (size_t)B);
+    float amax = 0.0f;
+    for (int i = 0; i < T; ++i) {
+        fso_tri* t = &s->tris[i];
+        const float* p = xyz + 9 * (size_t)i;
+        for (int k = 0; k < 3; ++k) {
+            t->v0[k] = p[k]; t->e1[k] = p[3 + k] - p[k]; t->e2[k] = p[6 + k] - p[k];
+            amax = fmaxf(amax, fmaxf(fabsf(p[k]), fmaxf(fabsf(p[3 + k]), fabsf(p[6 + k]))));
+        }
+        t->material = mat_id ? mat_id[i] : FSO_NO_MATERIAL;
+        t->id = (uint32_t)i;
+        s->tris_orig[i] = *t;
+    }
+    /* conservative box padding: far above float error of the slab/triangle tests, so the BVH result
+     * equals the brute-force result (the closest hit is a function of ray and triangles only) */
+    s->pad = fmaxf(0.01f, amax * 3.8146973e-06f /* 2^-18 */);
+    s->nodes = (fso_bnode*)calloc((size_t)(2 * (T > 0 ? T : 1)), sizeof(fso_bnode));
+    s->num_nodes = 1;
+    build_ctx bc;
+    bc.s = s;
+    bc.clo = (float*)malloc(sizeof(float) * 3 * (size_t)(T > 0 ? T : 1));
+    bc.chi = (float*)malloc(sizeof(float) * 3 * (size_t)(T > 0 ? T : 1));
+    bc.cen = (float*)malloc(sizeof(float) * 3 * (size_t)(T > 0 ? T : 1));
+    for (int i = 0; i < T; ++i) {
+        tri_bounds(&s->tris[i], &bc.clo[3 * i], &bc.chi[3 * i]);
+        for (int k = 0; k < 3; ++k) bc.cen[3 * i + k] = 0.5f * (bc.clo[3 * i + k] + bc.chi[3 * i + k]);
+    }
+    if (T > 0) build_node(&bc, 0, 0, T);
+    else { s->nodes[0].count = 0; s->nodes[0].left_first = 0; s->num_nodes = 0; }
+    free(bc.clo); free(bc.chi); free(bc.cen);
+    return s;
+}
+
+void fso_scene_destroy(fso_scene* s) {
+    if (!s) return;
+    free(s->tris); free(s->tris_orig); free(s->absorption); free(s->nodes); free(s);
+}
+int32_t fso_scene_num_nodes(const fso_scene* s) { return s->num_nodes; }
+
+/* ------------------------------------------------------------------------------------------- */
+/* ray queries: the engine contract of UWorld::LineTraceSingleByObjectType     */
+/* ------------------------------------------------------------------------------------------- */
+/* Moeller-Trumbore, two-sided, t in (0, tmax]; fixed operation order shared with the HIP kernel spec */
+static int tri_hit(const fso_tri* tr, const float o[3], const float d[3], float tmax, float* t_out) {
+    const float* e1 = tr->e1; const float* e2 = tr->e2;
+    float px = fmaf(d[1], e2[2], -(d[2] * e2[1]));
+    float py = fmaf(d[2], e2[0], -(d[0] * e2[2]));
+    float pz = fmaf(d[0], e2[1], -(d[1] * e2[0]));
+    float det = fmaf(e1[0], px, fmaf(e1[1], py, e1[2] * pz));
+    if (det == 0.0f) return 0;
+    float inv = 1.0f / det;
+    float sx = o[0] - tr->v0[0], sy = o[1] - tr->v0[1], sz = o[2] - tr->v0[2];
+    float u = fmaf(sx, px, fmaf(sy, py, sz * pz)) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return 0;
+    float qx = fmaf(sy, e1[2], -(sz * e1[1]));
+    float qy = fmaf(sz, e1[0], -(sx * e1[2]));
+    float qz = fmaf(sx, e1[1], -(sy * e1[0]));
+    float v = fmaf(d[0], qx, fmaf(d[1], qy, d[2] * qz)) * inv;
+    if (!(v >= 0.0f && (u + v) <= 1.0f)) return 0;
+    float t = fmaf(e2[0], qx, fmaf(e2[1], qy, e2[2] * qz)) * inv;
+    if (!(t > 0.0f && t <= tmax)) return 0;
+    *t_out = t;
+    return 1;
+}
+
+static void ray_inv(const float d[3], float inv[3]) {
+    for (int k = 0; k < 3; ++k) {
+        float x = d[k];
+        if (fabsf(x) < 1e-20f) x = copysignf(1e-20f, x);
+        inv[k] = 1.0f / x;
+    }
+}
+
+/* slab test against a padded box; returns entry distance or INFINITY on miss */
+static float box_hit(const fso_bnode* n, const float o[3], const float inv[3], float tmax) {
+    float t0x = (n->lo[0] - o[0]) * inv[0], t1x = (n->hi[0] - o[0]) * inv[0];
+    float t0y = (n->lo[1] - o[1]) * inv[1], t1y = (n->hi[1] - o[1]) * inv[1];
+    float t0z = (n->lo[2] - o[2]) * inv[2], t1z = (n->hi[2] - o[2]) * inv[2];
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+    return (tn <= tf) ? tn : INFINITY;
+}
+
+static void hit_normal(const fso_tri* tr, const float d[3], float n[3]) {
+    const float* e1 = tr->e1; const float* e2 = tr->e2;
+    float nx = fmaf(e1[1], e2[2], -(e1[2] * e2[1]));
+    float ny = fmaf(e1[2], e2[0], -(e1[0] * e2[2]));
+    float nz = fmaf(e1[0], e2[1], -(e1[1] * e2[0]));
+    float l2 = nx * nx + ny * ny + nz * nz;
+    float inv = 1.0f / sqrtf(l2);
+    nx *= inv; ny *= inv; nz *= inv;
+    float dn = fmaf(nx, d[0], fmaf(ny, d[1], nz * d[2]));
+    if (dn > 0.0f) { nx = -nx; ny = -ny; nz = -nz; } /* ImpactNormal faces the ray origin side */
+    n[0] = nx; n[1] = ny; n[2] = nz;
+}
+
+int32_t fso_trace_closest(const fso_scene* s, const float o[3], const float d[3], float tmax, int32_t brute,
+                          float* t_out, int32_t* tri_out, float n_out[3], fso_counters* c) {
+    float best_t = tmax; uint32_t best_id = 0xFFFFFFFFu; const fso_tri* best = NULL;
+    if (c) c->closest_rays++;
+    if (brute || s->num_nodes == 0) {
+        for (int i = 0; i < s->T; ++i) {
+            float t;
+            if (c) c->tri_tests++;
+            if (tri_hit(&s->tris_orig[i], o, d, best_t, &t)) {
+                if (t < best_t || best == NULL) { best_t = t; best = &s->tris_orig[i]; best_id = (uint32_t)i; }
+            }
+        }
+    } else {
+        float inv[3]; ray_inv(d, inv);
+        uint32_t stack[64]; int sp = 0;
+        if (c) c->node_visits++;
+        if (box_hit(&s->nodes[0], o, inv, best_t) != INFINITY) stack[sp++] = 0;
+        while (sp > 0) {
+            const fso_bnode* n = &s->nodes[stack[--sp]];
+            if (n->count) {
+                for (uint32_t i = n->left_first; i < n->left_first + n->count; ++i) {
+                    float t; const fso_tri* tr = &s->tris[i];
+                    if (c) c->tri_tests++;
+                    if (tri_hit(tr, o, d, best_t, &t)) {
+                        if (t < best_t || best == NULL || (t == best_t && tr->id < best_id)) {
+                            best_t = t; best = tr; best_id = tr->id;
+                        }
+                    }
+                }
+            } else {
+                uint32_t l = n->left_first;
+                if (c) c->node_visits += 2;
+                float tl = box_hit(&s->nodes[l], o, inv, best_t);
+                float tr_ = box_hit(&s->nodes[l + 1], o, inv, best_t);
+                if (tl != INFINITY && tr_ != INFINITY) {
+                    if (tl <= tr_) { stack[sp++] = l + 1; stack[sp++] = l; }
+                    else { stack[sp++] = l; stack[sp++] = l + 1; }
+                } else if (tl != INFINITY) stack[sp++] = l;
+                else if (tr_ != INFINITY) stack[sp++] = l + 1;
+            }
+        }
+    }
+    if (!best) return 0;
+    if (t_out) *t_out = best_t;
+    if (tri_out) *tri_out = (int32_t)best_id;
+    if (n_out) hit_normal(best, d, n_out);
+    return 1;
+}
+
+int32_t fso_trace_any(const fso_scene* s, const float o[3], const float d[3], float tmax, int32_t brute,
+                      fso_counters* c) {
+    float t;
+    if (c) c->any_rays++;
+    if (brute || s->num_nodes == 0) {
+        for (int i = 0; i < s->T; ++i) {
+            if (c) c->tri_tests++;
+            if (tri_hit(&s->tris_orig[i], o, d, tmax, &t)) return 1;
+        }
+        return 0;
+    }
+    float inv[3]; ray_inv(d, inv);
+    uint32_t stack[64]; int sp = 0;
+    if (c) c->node_visits++;
+    if (box_hit(&s->nodes[0], o, inv, tmax) != INFINITY) stack[sp++] = 0;
+    while (sp > 0) {
+        const fso_bnode* n = &s->nodes[stack[--sp]];
+        if (n->count) {
+            for (uint32_t i = n->left_first; i < n->left_first + n->count; ++i) {
+                if (c) c->tri_tests++;
+                if (tri_hit(&s->tris[i], o, d, tmax, &t)) return 1;
+            }
+        } else {
+            uint32_t l = n->left_first;
+            if (c) c->node_visits += 2;
+            float tl = box_hit(&s->nodes[l], o, inv, tmax);
+            float tr_ = box_hit(&s->nodes[l + 1], o, inv, tmax);
+            if (tl != INFINITY && tr_ != INFINITY) {
+                if (tl <= tr_) { stack[sp++] = l + 1; stack[sp++] = l; }
+                else { stack[sp++] = l; stack[sp++] = l + 1; }
+            } else if (tl != INFINITY) stack[sp++] = l;
+            else if (tr_ != INFINITY) stack[sp++] = l + 1;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* GeneratePath  ARTS.cpp:279-355                                                              */
+/* ------------------------------------------------------------------------------------------- */
+int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair, uint32_t side,
+                          const float start[3], fso_node* nodes, int32_t max_nodes, fso_counters* c) {
+    /* state variables ARTS.cpp:287-291 */
+    float pos[3] = {start[0], start[1], start[2]};
+    float nrm[3] = {0.f, 0.f, 0.f};
+    uint32_t mat = FSO_NO_MATERIAL;
+    float prob = 1.0f;
+    int has_normal = 0;
+    int brute = (p->flags & FSO_FLAG_BRUTE_FORCE) != 0;
+    int cosine = (p->flags & FSO_FLAG_COSINE_SAMPLING) != 0;
+    int32_t n = 0;
+    for (uint32_t k = 0;; ++k) {
+        /* 0. push node ARTS.cpp:296-297 */
+        if (n >= max_nodes) break;
+        fso_node* nd = &nodes[n++];
+        memcpy(nd->pos, pos, sizeof(pos)); memcpy(nd->normal, nrm, sizeof(nrm));
+        nd->material = mat; nd->prob = prob;
+        if (c) c->path_nodes++;
+        /* depth cap (build parameter; the reference loop is unbounded, quirk A.6-i) */
+        if (p->depth > 0 && (int32_t)k >= p->depth) break;
+        /* 1. Russian roulette ARTS.cpp:300-301 */
+        uint32_t r[4];
+        fso_draw(p->seed, pair, side, k, 0, r);
+        if (p->russian_roulette && !(fso_u01(r[0]) < p->rr_prob)) break; /* ARTS.cpp:349-353 */
+        /* 2. direction + probability ARTS.cpp:304-319 */
+        float dir[3];
+        if (!has_normal) {                               /* CurrentNormal.IsNearlyZero() */
+            fso_sample_sphere(p->seed, pair, side, k, r, dir);
+            float pdf = 1.0f / (4.0f * FSO_PI);
+            prob = pdf * p->rr_prob;
+        } else {
+            fso_sample_cone(nrm, fso_u01(r[1]), fso_u01(r[2]), cosine, dir);
+            float cos_theta = dir[0] * nrm[0] + dir[1] * nrm[1] + dir[2] * nrm[2];
+            float pdf = cos_theta / FSO_PI;
+            prob = pdf * p->rr_prob;
+        }
+        /* 3. closest hit on [pos, pos + dir * MAX_RAYCAST_DIST] ARTS.cpp:339-342 */
+        float t, hn[3]; int32_t tri;
+        if (fso_trace_closest(s, pos, dir, p->max_trace_dist, brute, &t, &tri, hn, c)) {
+            /* 4. ARTS.cpp:345-347 */
+            for (int q = 0; q < 3; ++q) {
+                float ip = fmaf(t, dir[q], pos[q]);
+                pos[q] = fmaf(p->surface_offset, hn[q], ip);
+                nrm[q] = hn[q];
+            }
+            has_normal = 1;
+            mat = s->tris_orig[tri].material;
+        }
+        /* on miss the state is unchanged and the loop continues (duplicate node, new prob) */
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* ConnectSubpaths  ARTS.cpp:235-277  — visible iff the line trace does NOT hit                */
+/* ------------------------------------------------------------------------------------------- */
+int32_t fso_connect(const fso_scene* s, const fso_params* p, const fso_node* f, const fso_node* b,
+                    fso_counters* c) {
+    float dx = b->pos[0] - f->pos[0], dy = b->pos[1] - f->pos[1], dz = b->pos[2] - f->pos[2];
+    float l2 = dx * dx + dy * dy + dz * dz;
+    if (!(l2 > 1e-8f)) { /* GetSafeNormal() == 0: zero-length trace, nothing to hit */
+        if (c) c->any_rays++;
+        return 1;
+    }
+    float len = sqrtf(l2);
+    float inv = 1.0f / len;
+    float d[3] = {dx * inv, dy * inv, dz * inv};
+    float tmax = len - p->connect_pullback; /* End = B - 0.1 * unit(B - F), ARTS.cpp:253 */
+    if (!(tmax > 0.0f)) { if (c) c->any_rays++; return 1; }
+    return !fso_trace_any(s, f->pos, d, tmax, (p->flags & FSO_FLAG_BRUTE_FORCE) != 0, c);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* EvaluatePath  ARTS.cpp:360-420  (one Energy per band; band b uses Absorption[b], A.3)       */
+/* ------------------------------------------------------------------------------------------- */
+void fso_evaluate_path(const fso_scene* s, const fso_params* p, const fso_node* nodes, int32_t n,
+                       float gains[FSO_MAX_BANDS], float* delay_seconds) {
+    int B = s->B;
+    float scaled = 0.0f;                        /* ScaledDistance ARTS.cpp:364 */
+    float E[FSO_MAX_BANDS];
+    for (int b = 0; b < B; ++b) E[b] = 1.0f;    /* Energy ARTS.cpp:365 */
+    for (int i = 0; i < n - 1; ++i) {
+        const fso_node* a = &nodes[i]; const fso_node* q = &nodes[i + 1];
+        float dx = q->pos[0] - a->pos[0], dy = q->pos[1] - a->pos[1], dz = q->pos[2] - a->pos[2];
+        float dist = sqrtf(dx * dx + dy * dy + dz * dz);     /* FVector::Dist ARTS.cpp:372 */
+        float nd = dist / p->dist_divisor;                    /* ARTS.cpp:373 */
+        scaled += nd;                                         /* ARTS.cpp:374 */
+        if (nd < p->min_seg) continue;                        /* ARTS.cpp:375-378 */
+        float nd2 = nd * nd;
+        float geo = 1.0f / (4 * FSO_PI * nd2);                /* ARTS.cpp:391 */
+        float pw = powf(a->prob, p->prob_exponent);           /* ARTS.cpp:398 */
+        for (int b = 0; b < B; ++b) {
+            float bsdf = 1.0f;                                /* ARTS.cpp:382-386 */
+            if (a->material != FSO_NO_MATERIAL && (int32_t)a->material < s->M)
+                bsdf = s->absorption[(size_t)a->material * (size_t)B + (size_t)b] / FSO_PI;
+            float e = E[b];
+            e *= bsdf;                                        /* ARTS.cpp:392 */
+            e *= geo;                                         /* ARTS.cpp:393 */
+            float media = expf(-p->air_absorption[b] * nd);   /* ARTS.cpp:396 */
+            e *= media;                                       /* ARTS.cpp:397 */
+            e /= pw;                                          /* ARTS.cpp:398 */
+            E[b] = e;
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        float e = (E[b] < p->energy_clamp) ? E[b] : p->energy_clamp; /* FMath::Min ARTS.cpp:410 */
+        gains[b] = e * p->energy_gain;                               /* ARTS.cpp:413 */
+    }
+    *delay_seconds = scaled / p->sound_speed;                        /* ARTS.cpp:419 */
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* energy buffer  FSAC.h:72-91,133-139                                                         */
+/* ------------------------------------------------------------------------------------------- */
+int32_t fso_num_bins(float simulated_duration, float bin_duration) {
+    return (int32_t)ceilf(simulated_duration / bin_duration); /* FSAC.h:137 */
+}
+int32_t fso_num_samples(float simulated_duration, int32_t sample_rate) {
+    return (int32_t)ceilf(simulated_duration * (float)sample_rate); /* FSAC.h:138 */
+}
+int32_t fso_samples_per_bin(float bin_duration, int32_t sample_rate) {
+    return (int32_t)ceilf(bin_duration * (float)sample_rate); /* FSAC.cpp:324: 48.000004f -> 49 */
+}
+
+int32_t fso_add_energy_at_delay(float* energy, int32_t num_bins, int32_t bin_size_ms, float delay_s, float e) {
+    float x = (delay_s * 1000.f) / (float)bin_size_ms;      /* FSAC.h:89 */
+    float fl = floorf(x);
+    int32_t bin;
+    if (!(fl > 0.0f)) bin = 0;                              /* also NaN */
+    else if (fl >= (float)(num_bins - 1)) bin = num_bins - 1;
+    else bin = (int32_t)fl;
+    energy[bin] += e;                                       /* FSAC.h:90 */
+    return bin;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* UpdateSource  ARTS.cpp:128-173 (pairs [pair_begin, pair_end))                               */
+/* ------------------------------------------------------------------------------------------- */
+void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src[3], const float lis[3],
+                        uint32_t pair_begin, uint32_t pair_end, int32_t num_bins, float* energy_f32,
+                        double* energy_f64, fso_counters* c) {
+    int B = s->B;
+    int32_t max_nodes = p->depth > 0 ? p->depth + 1 : FSO_MAX_NODES;
+    fso_node* fwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes);
+    fso_node* bwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes);
+    fso_node* all = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes * 2);
+    /* FlushEnergyBuffer ARTS.cpp:157-161 */
+    memset(energy_f32, 0, sizeof(float) * (size_t)B * (size_t)num_bins);
+    if (energy_f64) memset(energy_f64, 0, sizeof(double) * (size_t)B * (size_t)num_bins);
+    /* NormalizationFactor ARTS.cpp:164 (quirk A.6-c: literally 1/1000) */
+    float norm = (p->flags & FSO_FLAG_FIXED_NORM_1000) ? 1.0f / 1000.0f : 1.0f / (float)p->num_pairs;
+    for (uint32_t i = pair_begin; i < pair_end; ++i) {     /* GenerateFullPaths ARTS.cpp:215-230 */
+        int32_t nf = fso_generate_path(s, p, i, 0, src, fwd, max_nodes, c);
+        int32_t nb = fso_generate_path(s, p, i, 1, lis, bwd, max_nodes, c);
+        if (nf == 0 || nb == 0) continue;                  /* ARTS.cpp:237 */
+        if (!fso_connect(s, p, &fwd[nf - 1], &bwd[nb - 1], c)) continue;
+        if (c) c->connected++;
+        /* node order F0..Fk, Bm..B0 ARTS.cpp:262-267 */
+        memcpy(all, fwd, sizeof(fso_node) * (size_t)nf);
+        for (int32_t j = 0; j < nb; ++j) all[nf + j] = bwd[nb - 1 - j];
+        float gains[FSO_MAX_BANDS], delay;
+        fso_evaluate_path(s, p, all, nf + nb, gains, &delay);
+        int32_t bin = 0;
+        for (int b = 0; b < B; ++b) {
+            float e = gains[b];
+            e *= norm;                                     /* ARTS.cpp:170 */
+            bin = fso_add_energy_at_delay(energy_f32 + (size_t)b * (size_t)num_bins, num_bins, 1, delay, e);
+            if (energy_f64) energy_f64[(size_t)b * (size_t)num_bins + (size_t)bin] += (double)e;
+        }
+        if (c) c->deposits++;
+    }
+    free(fwd); free(bwd); free(all);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* ReconstructImpulseResponse  FSAC.cpp:320-380 (one channel / one band row)                   */
+/* ------------------------------------------------------------------------------------------- */
+void fso_reconstruct(const float* energy, int32_t num_bins, int32_t sample_rate, float bin_duration,
+                     int32_t num_samples, int32_t samples_per_bin_override, float* out) {
+    const float kEnergyThreshold = 1e-6f;                          /* FSAC.cpp:322 */
+    const float Pi4 = sqrtf(4.0f * FSO_PI);                        /* FSAC.cpp:323 */
+    int32_t spb = samples_per_bin_override > 0 ? samples_per_bin_override
+                                               : fso_samples_per_bin(bin_duration, sample_rate);
+    float* ir = (float*)calloc((size_t)num_samples, sizeof(float)); /* Memset 0 FSAC.cpp:335 */
+    for (int32_t bin = 0; bin < num_bins; ++bin) {
+        int32_t left = num_samples - bin * spb;
+        int32_t nbs = spb < left ? spb : left;                     /* FSAC.cpp:340 */
+        float e = 0.0f;
+        if (fabsf(energy[bin]) >= kEnergyThreshold)                /* FSAC.cpp:343 (Response and Norm alias) */
+            e = energy[bin] / sqrtf(energy[bin] * Pi4);            /* FSAC.cpp:345 */
+        float prev = 0.0f;
+        if (bin == 0) prev = e;                                    /* FSAC.cpp:348-351 */
+        else if (fabsf(energy[bin - 1]) >= kEnergyThreshold)
+            prev = energy[bin - 1] / sqrtf(energy[bin - 1] * Pi4); /* FSAC.cpp:352-355 */
+        for (int32_t bs = 0, smp = bin * spb; bs < nbs; ++bs, ++smp) {
+            float w = (float)bs / (float)spb;                      /* FSAC.cpp:359 */
+            float a = (1.0f - w) * prev;
+            float bb = w * e;
+            ir[smp] = a + bb;                                      /* FSAC.cpp:360-362 */
+        }
+    }
+    const float k = 0.25f;                                         /* FSAC.cpp:366 */
+    out[0] = ir[0];                                                /* FSAC.cpp:371 */
+    for (int32_t i = 1; i < num_samples; ++i) {
+        float a = k * ir[i];
+        float bb = (1.0f - k) * out[i - 1];
+        out[i] = a + bb;                                           /* FSAC.cpp:374 */
+    }
+    /* NormalizeImpulseResponse (FSAC.cpp:382-406) zeroes the UNFILTERED array, which is then
+     * replaced by Filtered (FSAC.cpp:377-378): the net result is the filtered signal. */
+    free(ir);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Legacy occlusion scalar: UpdateSound FSAC.cpp:295-299 -> CastDirectAudioRay FSAC.cpp:209-280 */
+/* Build contract: every triangle is its own obstacle "actor" is too fine; obstacles are keyed  */
+/* by material id (one UAcousticGeometryComponent per actor); the listener is a sphere.         */
+/* ------------------------------------------------------------------------------------------- */
+static int sphere_hit(const float o[3], const float d[3], const float c[3], float r, float tmax, float* t_out) {
+    float ox = o[0] - c[0], oy = o[1] - c[1], oz = o[2] - c[2];
+    float b = ox * d[0] + oy * d[1] + oz * d[2];
+    float cc = ox * ox + oy * oy + oz * oz - r * r;
+    float disc = b * b - cc;
+    if (disc < 0.0f) return 0;
+    float sq = sqrtf(disc);
+    float t = -b - sq;
+    if (t <= 0.0f) t = -b + sq;
+    if (!(t > 0.0f && t <= tmax)) return 0;
+    *t_out = t;
+    return 1;
+}
+
+float fso_occlusion_attenuation(const fso_scene* s, const float src[3], const float lis[3], float listener_radius,
+                                float raycast_distance, int32_t bounces) {
+    float dx = lis[0] - src[0], dy = lis[1] - src[1], dz = lis[2] - src[2];
+    float l2 = dx * dx + dy * dy + dz * dz;
+    if (!(l2 > 1e-8f)) return 0.0f;
+    float inv = 1.0f / sqrtf(l2);
+    float dir[3] = {dx * inv, dy * inv, dz * inv};            /* DirToPlayer.Normalize() FSAC.cpp:296 */
+    float pos[3] = {src[0], src[1], src[2]};
+    float max_dist = raycast_distance;
+    float energy = 1.0f;
+    while (bounces > 0 && energy > 0.0f) {                    /* FSAC.cpp:212 */
+        float o[3];
+        for (int k = 0; k < 3; ++k) o[k] = fmaf(dir[k], 0.1f, pos[k]);   /* DirectStart FSAC.cpp:232 */
+        float tt = INFINITY, ts = INFINITY, n[3]; int32_t tri = -1;
+        int ht = fso_trace_closest(s, o, dir, max_dist, 0, &tt, &tri, n, NULL);
+        int hs = sphere_hit(o, dir, lis, listener_radius, max_dist, &ts);
+        if (!ht && !hs) return 0.0f;                          /* no hit FSAC.cpp:279 */
+        if (hs && (!ht || ts <= tt)) {                        /* hit the player FSAC.cpp:253-270 */
+            float travel = raycast_distance - max_dist + ts;
+            travel *= 0.01f;
+            float time = travel / 343.0f;
+            if (time > 1.0f) return 0.0f;
+            energy *= expf(-0.0017f * travel);
+            return energy;
+        }
+        /* hit a different obstacle: continue through it FSAC.cpp:272-276 */
+        for (int k = 0; k < 3; ++k) pos[k] = fmaf(tt, dir[k], o[k]);
+        max_dist -= tt;
+        bounces -= 1;
+    }
+    return 0.0f;
+}
