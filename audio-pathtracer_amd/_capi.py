@@ -84,10 +84,12 @@ class Stats(C.Structure):
         ("frames", C.c_uint64),
         ("rays", C.c_uint64),
         ("pairs", C.c_uint64),
-        ("trace_kernel_ms_sum", C.c_double),
-        ("trace_kernel_ms_last", C.c_double),
+        ("walk_kernel_ms_sum", C.c_double),
+        ("walk_kernel_ms_last", C.c_double),
+        ("connect_kernel_ms_sum", C.c_double),
         ("reconstruct_ms_sum", C.c_double),
         ("timed_frames", C.c_uint64),
+        ("timed_reconstructs", C.c_uint64),
         ("bvh_nodes", C.c_uint32),
         ("triangles", C.c_uint32),
         ("scene_bytes", C.c_uint64),

@@ -33,7 +33,7 @@ struct Source {
 };
 
 struct TimedFrame {
-    hipEvent_t e[4];
+    hipEvent_t e[5];  // walk begin, walk end == connect begin, connect end | reconstruct begin, end
     bool has_trace = false, has_recon = false;
 };
 
@@ -143,15 +143,19 @@ hipEvent_t take_event(fs_context* ctx) {
 // fold finished timed frames into the stats (call only after the stream has been synchronised)
 void resolve_timings(fs_context* ctx) {
     for (TimedFrame& f : ctx->pending) {
-        float ms = 0.f;
-        if (f.has_trace && hipEventElapsedTime(&ms, f.e[0], f.e[1]) == hipSuccess) {
-            ctx->stats.trace_kernel_ms_sum += ms;
-            ctx->stats.trace_kernel_ms_last = ms;
+        float ms = 0.f, ms2 = 0.f;
+        if (f.has_trace && hipEventElapsedTime(&ms, f.e[0], f.e[1]) == hipSuccess &&
+            hipEventElapsedTime(&ms2, f.e[1], f.e[2]) == hipSuccess) {
+            ctx->stats.walk_kernel_ms_sum += ms;
+            ctx->stats.walk_kernel_ms_last = ms;
+            ctx->stats.connect_kernel_ms_sum += ms2;
             ctx->stats.timed_frames++;
         }
-        if (f.has_recon && hipEventElapsedTime(&ms, f.e[2], f.e[3]) == hipSuccess)
+        if (f.has_recon && hipEventElapsedTime(&ms, f.e[3], f.e[4]) == hipSuccess) {
             ctx->stats.reconstruct_ms_sum += ms;
-        for (int i = 0; i < 4; ++i)
+            ctx->stats.timed_reconstructs++;
+        }
+        for (int i = 0; i < 5; ++i)
             if (f.e[i]) ctx->free_events.push_back(f.e[i]);
     }
     ctx->pending.clear();
@@ -479,18 +483,20 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
 
     TimedFrame tf{};
     if (ctx->profiling) {
-        for (int i = 0; i < 4; ++i) tf.e[i] = nullptr;
+        for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
         tf.e[0] = take_event(ctx);
         tf.e[1] = take_event(ctx);
+        tf.e[2] = take_event(ctx);
     }
     // FlushEnergyBuffer ARTS.cpp:157-161
     FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     launch_walk(B, ctx->scene, kp, ctx->st, ctx->stream);
+    if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
     launch_connect(B, ctx->scene, kp, ctx->st, s->d_energy, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     if (ctx->profiling) {
-        FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+        FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
         tf.has_trace = true;
         ctx->pending.push_back(tf);
     }
@@ -548,10 +554,10 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     TimedFrame tf{};
     bool timed = ctx->profiling;
     if (timed) {
-        for (int i = 0; i < 4; ++i) tf.e[i] = nullptr;
-        tf.e[2] = take_event(ctx);
+        for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
         tf.e[3] = take_event(ctx);
-        FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
+        tf.e[4] = take_event(ctx);
+        FS_HIP(ctx, hipEventRecord(tf.e[3], ctx->stream));
     }
     if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)  // ARTS.cpp:191 literally
         FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
@@ -566,7 +572,7 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     s->seq_of[slot] = seq;
     s->enqueued = seq;
     if (timed) {
-        FS_HIP(ctx, hipEventRecord(tf.e[3], ctx->stream));
+        FS_HIP(ctx, hipEventRecord(tf.e[4], ctx->stream));
         tf.has_recon = true;
         ctx->pending.push_back(tf);
     }

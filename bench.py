@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — rays/s + IR-frames/s of the MI355X-native FrequenSee BDPT path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one complete frame of the hot path over one batch of synthetic input:
+  fs_compute_energy_response (walk + connect/deposit kernels)  [-> RCCL all-reduce of the energy
+  buffer when N>1]  ->  fs_reconstruct_impulse_response (energy -> 1 s / 48 kHz IR, published to host).
+Workload at N=1 = BASELINE.json configs[2] (the config the >=10 M rays/s target is quoted on):
+Scene_OldMine stand-in (100 000 triangles, procedural), 262 144 rays/frame (source + listener
+subpaths), depth 8, 8 bands.  N>1: weak scaling, 262 144 rays per GPU per frame, pairs sharded by
+global pair index, one all-reduce of [8][1000] fp32 per frame.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (walk_kernel, the
+dominant kernel; algorithmic bytes from the oracle's counters) and `cpu_baseline` (the oracle timed on
+this box's host cores on the same frame).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (scene, bands, rays per GPU per frame, depth)
+    "cfg2_starter_room": ("starter_room", 4, 16384, 8),
+    "cfg3_old_mine": ("old_mine", 8, 262144, 8),
+    "cfg4_old_mine_d12": ("old_mine", 8, 131072, 12),
+}
+
+
+class _CudaArray:
+    """expose a foreign device pointer to torch through __cuda_array_interface__ (zero copy)"""
+
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def algorithmic_bytes(cnt, rays, bands, depth_segments):
+    """SURVEY.md §8(d) per-frame figure, split per kernel.  cnt = oracle counters for the frame."""
+    walk_nodes = cnt["node_visits"] - cnt["any_node_visits"]
+    walk_tris = cnt["tri_tests"] - cnt["any_tri_tests"]
+    state = rays * (32 + 4 * bands)                       # terminal state written once ...
+    walk = 32 * walk_nodes + 48 * walk_tris + state + 4 * depth_segments
+    connect = (32 * cnt["any_node_visits"] + 48 * cnt["any_tri_tests"] + state  # ... and read once
+               + 4 * depth_segments + 4 * bands * cnt["deposits"] * 2 + 4 * bands * 1000)
+    return walk, connect
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg3_old_mine", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fixed-depth", action="store_true", help="Russian roulette off: every subpath takes `depth` segments")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = graft.load_package()
+    scene_name, bands, rays_per_gpu, depth = WORKLOADS[args.workload]
+    sc = pkg.scenes.by_name(scene_name, bands)
+    total_rays = rays_per_gpu * world
+    stream = torch.cuda.current_stream()
+    ctx = pkg.Context(num_bands=bands, device=local_rank, rank=rank, world_size=world, stream=stream.cuda_stream)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx.set_listener(sc.listener)
+    src = ctx.create_source(sc.source)
+    p = pkg.default_params(num_rays=total_rays, depth=depth, seed=args.seed,
+                           russian_roulette=0 if args.fixed_depth else 1)
+    eptr, ebytes = ctx.energy_device_ptr(src)
+    energy_t = torch.as_tensor(_CudaArray(eptr, (bands * ctx.num_bins,)), device=f"cuda:{local_rank}")
+
+    def frame():
+        ctx.compute_energy_response_async(src, p)
+        if world > 1:
+            dist.all_reduce(energy_t)          # RCCL sum of the [bands][bins] fp32 energy buffer
+        ctx.reconstruct_impulse_response_async(src, p)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    ctx.synchronize()
+    ctx.reset_stats()
+    ctx.set_profiling(True)                    # HIP events around the kernels on the launch stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.synchronize()
+    st = ctx.stats()
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # untimed: the same K frames without the profiling events, to show the events' cost
+    e_gpu = ctx.energy_buffer(src)
+    ir = ctx.impulse_response(src, 0)
+
+    result = None
+    if rank == 0:
+        rays_s = total_rays * args.steps / elapsed
+        ms_step = 1e3 * elapsed / args.steps
+        walk_ms = st["walk_kernel_ms_sum"] / max(st["timed_frames"], 1)
+        conn_ms = st["connect_kernel_ms_sum"] / max(st["timed_frames"], 1)
+        rec_ms = st["reconstruct_ms_sum"] / max(st["timed_reconstructs"], 1)
+        result = {
+            "metric": "rays/sec + IR-frames/sec (1s IR, depth 8)",
+            "value": rays_s,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {scene_name} {sc.num_triangles} tris, {rays_per_gpu} rays/frame/GPU "
+                                   f"(source+listener subpaths), depth {depth}, {bands} bands, "
+                                   f"{'fixed depth' if args.fixed_depth else 'Russian roulette 0.9'}",
+                       "rays_per_frame": total_rays, "pairs_per_frame": total_rays // 2, "depth": depth,
+                       "bands": bands, "triangles": sc.num_triangles, "sharding": f"pairs/{world}"},
+            "ir_frames_per_s": args.steps / elapsed,
+            "kernel_ms": {"walk": walk_ms, "connect": conn_ms, "reconstruct+publish": rec_ms},
+        }
+
+    # ---- oracle leg (rank 0, N=1 only): parity check, algorithmic bytes, CPU baseline ---------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle  # checker / CPU baseline only
+
+        lib = None
+        kind_note = "portable build"
+        try:
+            so = oracle.build(native=True, outdir=os.path.join("/tmp", f"fs_oracle_{os.getpid()}"))
+            lib = oracle.load(so)
+            kind_note = "-O3 -march=native build"
+        except Exception:
+            lib = oracle.load()
+        osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption, lib=lib)
+        op = oracle.default_params(num_pairs=total_rays // 2, depth=depth, seed=args.seed,
+                                   russian_roulette=0 if args.fixed_depth else 1)
+        # 1 thread on a bounded sample (the first 1/8 of the frame's pairs)
+        sample_pairs = max(1, (total_rays // 2) // 8)
+        t1 = time.perf_counter()
+        osc.compute_energy(op, sc.source, sc.listener, 0, sample_pairs)
+        t_1t = time.perf_counter() - t1
+        # all host cores on the whole frame (also gives the counters and the parity reference)
+        cores = min(os.cpu_count() or 1, 16)
+        t1 = time.perf_counter()
+        e32, e64, cnt = osc.compute_energy_mt(op, sc.source, sc.listener, cores)
+        t_mt = time.perf_counter() - t1
+        cnt = cnt.as_dict()
+        rms = [float(np.sqrt(np.mean((e_gpu[b].astype(np.float64) - e64[b]) ** 2)) /
+                     max(np.sqrt(np.mean(e64[b] ** 2)), 1e-300)) for b in range(bands)]
+        if max(rms) > 1e-3:
+            raise SystemExit(f"parity failure: relative RMS per band {rms}")
+        seg_entries = cnt["closest_rays"] // 2     # listener-side segment lengths stored for the bin sum
+        wb, cb = algorithmic_bytes(cnt, total_rays, bands, seg_entries)
+        walk_s = 1e-3 * result["kernel_ms"]["walk"]
+        achieved = wb / walk_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.workload, {}).get("walk_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "kernel": "walk_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "algorithmic_bytes_per_launch": wb, "avg_launch_ms": result["kernel_ms"]["walk"],
+                              "frame_algorithmic_bytes": wb + cb,
+                              "frame_achieved_GBs": (wb + cb) / (1e-3 * (result["kernel_ms"]["walk"] +
+                                                                        result["kernel_ms"]["connect"])) / 1e9}
+        result["cpu_baseline"] = {"value": total_rays / t_mt, "unit": "rays/s", "cores": cores, "kind": "port",
+                                  "sample": f"one full frame ({total_rays} rays) on {cores} threads, oracle {kind_note}; "
+                                            f"1 thread on the first {2 * sample_pairs} rays: "
+                                            f"{2 * sample_pairs / t_1t:.0f} rays/s",
+                                  "value_1_thread": 2 * sample_pairs / t_1t}
+        result["parity"] = {"max_rel_rms_per_band": max(rms), "connected_pairs": cnt["connected"],
+                            "segments": cnt["closest_rays"], "node_visits": cnt["node_visits"],
+                            "tri_tests": cnt["tri_tests"]}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,10 +95,12 @@ typedef struct fs_stats {
     uint64_t frames;             /* compute_energy_response calls */
     uint64_t rays;               /* subpaths traced by this rank */
     uint64_t pairs;              /* pairs traced by this rank */
-    double trace_kernel_ms_sum;  /* HIP-event time of the dominant kernel(s) on the context's stream */
-    double trace_kernel_ms_last;
-    double reconstruct_ms_sum;
-    uint64_t timed_frames;       /* frames contributing to *_ms_sum (profiling enabled) */
+    double walk_kernel_ms_sum;    /* HIP-event time on the context's stream, profiling enabled: walk_kernel */
+    double walk_kernel_ms_last;
+    double connect_kernel_ms_sum; /* connect_kernel */
+    double reconstruct_ms_sum;    /* reconstruct_kernel + IR publish copy */
+    uint64_t timed_frames;        /* frames contributing to walk/connect sums */
+    uint64_t timed_reconstructs;  /* reconstructs contributing to reconstruct_ms_sum */
     uint32_t bvh_nodes;
     uint32_t triangles;
     uint64_t scene_bytes;        /* device bytes of BVH + triangles + materials */

@@ -54,6 +54,8 @@ class Counters(C.Structure):
         ("connected", C.c_uint64),
         ("deposits", C.c_uint64),
         ("path_nodes", C.c_uint64),
+        ("any_node_visits", C.c_uint64),
+        ("any_tri_tests", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -430,25 +430,25 @@ int32_t fso_trace_any(const fso_scene* s, const float o[3], const float d[3], fl
     if (c) c->any_rays++;
     if (brute || s->num_nodes == 0) {
         for (int i = 0; i < s->T; ++i) {
-            if (c) c->tri_tests++;
+            if (c) { c->tri_tests++; c->any_tri_tests++; }
             if (tri_hit(&s->tris_orig[i], o, d, tmax, &t)) return 1;
         }
         return 0;
     }
     float inv[3]; ray_inv(d, inv);
     uint32_t stack[64]; int sp = 0;
-    if (c) c->node_visits++;
+    if (c) { c->node_visits++; c->any_node_visits++; }
     if (box_hit(&s->nodes[0], o, inv, tmax) != INFINITY) stack[sp++] = 0;
     while (sp > 0) {
         const fso_bnode* n = &s->nodes[stack[--sp]];
         if (n->count) {
             for (uint32_t i = n->left_first; i < n->left_first + n->count; ++i) {
-                if (c) c->tri_tests++;
+                if (c) { c->tri_tests++; c->any_tri_tests++; }
                 if (tri_hit(&s->tris[i], o, d, tmax, &t)) return 1;
             }
         } else {
             uint32_t l = n->left_first;
-            if (c) c->node_visits += 2;
+            if (c) { c->node_visits += 2; c->any_node_visits += 2; }
             float tl = box_hit(&s->nodes[l], o, inv, tmax);
             float tr_ = box_hit(&s->nodes[l + 1], o, inv, tmax);
             if (tl != INFINITY && tr_ != INFINITY) {
