@@ -1,0 +1,268 @@
+"""Pins the CPU oracle (oracle/fs_oracle.c).
+
+The reference ships no tests or golden vectors for this path ("parity unpinned", oracle/fs_oracle.h),
+so the oracle is pinned by (1) the closed-form known-answer tests of SURVEY.md A.7, each derivable by
+hand from the cited reference lines, (2) published Philox4x32-10 known answers (Random123 kat_vectors),
+(3) self-consistency: BVH == brute force, shard-invariance, determinism.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+
+# ---- RNG -------------------------------------------------------------------------------------------
+PHILOX_KAT = [  # Random123 kat_vectors: philox4x32 10 <ctr x4> <key x2> -> <out x4>
+    ((0x00000000,) * 4, (0x00000000,) * 2, (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,out", PHILOX_KAT)
+def test_philox_known_answers(oracle_mod, ctr, key, out):
+    lib = oracle_mod.load()
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib.fso_philox4x32_10(c, k, o)
+    assert tuple(o) == out
+
+
+def test_u01_range(oracle_mod):
+    lib = oracle_mod.load()
+    assert lib.fso_u01(0) == 0.0
+    assert lib.fso_u01(0xFFFFFFFF) == pytest.approx(1.0 - 2.0 ** -24, abs=0)
+    assert lib.fso_u01(0x80000000) == 0.5
+
+
+def test_sincos2pi_accuracy(oracle_mod):
+    lib = oracle_mod.load()
+    s, c = C.c_float(), C.c_float()
+    worst = 0.0
+    for u in np.linspace(0.0, 1.0, 4097, endpoint=False):
+        lib.fso_sincos2pi(float(np.float32(u)), C.byref(s), C.byref(c))
+        a = 2.0 * math.pi * float(np.float32(u))
+        worst = max(worst, abs(s.value - math.sin(a)), abs(c.value - math.cos(a)))
+    assert worst < 5e-7
+
+
+def test_sampling_maps(oracle_mod):
+    lib = oracle_mod.load()
+    rng = np.random.default_rng(1)
+    n = np.array([0.3, -0.5, 0.81], dtype=np.float32)
+    n /= np.linalg.norm(n)
+    nn = (C.c_float * 3)(*n)
+    d = (C.c_float * 3)()
+    cos_ref, cos_cos = [], []
+    for _ in range(20000):
+        U, V = float(np.float32(rng.random())), float(np.float32(rng.random()))
+        lib.fso_sample_cone(nn, U, V, 0, d)
+        v = np.array(list(d))
+        assert abs(np.linalg.norm(v) - 1.0) < 1e-5
+        cos_ref.append(float(v @ n))
+        lib.fso_sample_cone(nn, U, V, 1, d)
+        cos_cos.append(float(np.array(list(d)) @ n))
+    cos_ref, cos_cos = np.array(cos_ref), np.array(cos_cos)
+    assert cos_ref.min() > -1e-6  # hemisphere about n (ARTS.cpp:313: half angle 90 deg)
+    # VRandCone(n, 90deg): polar density (sin+cos)/2 -> E[cos] = 1/4 + pi/8
+    assert abs(cos_ref.mean() - (0.25 + math.pi / 8)) < 0.01
+    assert abs(cos_cos.mean() - 2.0 / 3.0) < 0.01  # cosine-weighted alternative
+    # sphere: unit vectors, zero mean
+    acc = np.zeros(3)
+    for i in range(5000):
+        r = (C.c_uint32 * 4)(*[int(x) for x in rng.integers(0, 2 ** 32, 4, dtype=np.uint64)])
+        lib.fso_sample_sphere(0x5EED, i, 0, 0, r, d)
+        v = np.array(list(d))
+        assert abs(np.linalg.norm(v) - 1.0) < 1e-5
+        acc += v
+    assert np.abs(acc / 5000).max() < 0.05
+
+
+# ---- A.7 known answers ------------------------------------------------------------------------------
+def _node(oracle_mod, pos, prob, material=0xFFFF):
+    n = oracle_mod.Node()
+    n.pos[:] = pos
+    n.normal[:] = (0, 0, 0)
+    n.material = material
+    n.prob = prob
+    return n
+
+
+def test_kat_evaluate_path(oracle_mod, scene_factory):
+    """A.7-1, by hand from ARTS.cpp:360-420."""
+    sc = scene_factory("shoebox", 1)
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, np.array([[0.5]], np.float32))
+    p = oracle_mod.default_params()
+    p0 = 0.9 / (4 * math.pi)
+    nodes = [_node(oracle_mod, (0, 0, 0), 1.0), _node(oracle_mod, (2000, 0, 0), p0, material=0),
+             _node(oracle_mod, (2000, 3000, 0), 0.5)]
+    gains, delay = s.evaluate_path(p, nodes)
+    e0 = 1 / (16 * math.pi) * math.exp(-0.1)
+    assert e0 == pytest.approx(0.0180011685, rel=1e-7)
+    e1 = e0 * (0.5 / math.pi) / (36 * math.pi) * math.exp(-0.15) / p0 ** 0.1
+    assert e1 == pytest.approx(2.83805637e-5, rel=1e-6)
+    assert gains[0] == pytest.approx(10 * e1, rel=2e-6)
+    assert delay == pytest.approx(5 / 343, rel=1e-6)
+    buf = np.zeros(1000, np.float32)
+    b = oracle_mod.add_energy_at_delay(buf, delay, gains[0] / 1000.0)
+    assert b == 14 and buf[14] == pytest.approx(2.83805637e-7, rel=2e-6)
+
+
+def test_kat_skip_rule(oracle_mod, scene_factory):
+    """A.7-2: all segments < 1000 cm -> E = 1 -> gain exactly 10 (ARTS.cpp:375-378, 410-413)."""
+    sc = scene_factory("shoebox", 1)
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    p = oracle_mod.default_params()
+    nodes = [_node(oracle_mod, (0, 0, 0), 1.0), _node(oracle_mod, (500, 0, 0), 0.07, 0),
+             _node(oracle_mod, (500, 900, 0), 0.2, 0), _node(oracle_mod, (100, 900, 0), 0.1)]
+    gains, delay = s.evaluate_path(p, nodes)
+    assert gains[0] == 10.0
+    assert delay == pytest.approx((0.5 + 0.9 + 0.4) / 343, rel=1e-6)
+
+
+def test_kat_bin_index(oracle_mod):
+    """A.7-3 (FSAC.h:87-91)."""
+    for delay, want in ((0.0, 0), (0.9995, 999), (1.7, 999), (-0.3, 0), (0.0145772595, 14), (0.001, 1)):
+        buf = np.zeros(1000, np.float32)
+        assert oracle_mod.add_energy_at_delay(buf, delay, 1.0) == want
+        assert buf[want] == 1.0 and buf.sum() == 1.0
+
+
+def test_kat_sizes(oracle_mod):
+    """A.7-5: NumBins = 1000, NumSamples = 48000, NumSamplesPerBin = 49 (fp32 ceil quirk, FSAC.cpp:324)."""
+    lib = oracle_mod.load()
+    assert lib.fso_num_bins(1.0, 0.001) == 1000
+    assert lib.fso_num_samples(1.0, 48000) == 48000
+    assert lib.fso_samples_per_bin(0.001, 48000) == 49
+    assert np.float32(0.001) * np.float32(48000) > 48.0
+
+
+def test_kat_reconstruct_one_hot(oracle_mod):
+    """A.7-4 (FSAC.cpp:320-380)."""
+    e = np.zeros(1000, np.float32)
+    e[10] = 0.04
+    ir = oracle_mod.reconstruct(e)
+    a10 = 0.04 / math.sqrt(0.04 * math.sqrt(4 * math.pi))
+    assert a10 == pytest.approx(0.1062251932, rel=1e-6)
+    # unfiltered: ramp up over samples 490..538, ramp down over 539..587, zero elsewhere
+    x = np.zeros(48000)
+    for s in range(49):
+        x[490 + s] = (s / 49.0) * a10
+        x[539 + s] = (1 - s / 49.0) * a10
+    y = np.zeros(48000)
+    y[0] = x[0]
+    for i in range(1, 48000):
+        y[i] = 0.25 * x[i] + 0.75 * y[i - 1]
+    assert np.abs(ir - y).max() < 2e-7
+    assert ir[:490].max() == 0.0
+    # bins >= 980 write nothing; bin 979 writes 29 samples (A.5)
+    e2 = np.zeros(1000, np.float32)
+    e2[985] = 1.0
+    assert np.all(oracle_mod.reconstruct(e2) == 0.0)
+    e3 = np.zeros(1000, np.float32)
+    e3[979] = 1.0
+    ir3 = oracle_mod.reconstruct(e3)
+    assert np.all(ir3[: 979 * 49] == 0.0) and ir3[979 * 49 + 1] > 0.0
+    # threshold 1e-6 and samples_per_bin override (compat flag j)
+    e4 = np.zeros(1000, np.float32)
+    e4[3] = 5e-7
+    assert np.all(oracle_mod.reconstruct(e4) == 0.0)
+    ir48 = oracle_mod.reconstruct(e, samples_per_bin=48)
+    assert ir48[479] == 0.0 and ir48[481] > 0.0
+
+
+# ---- ray queries: BVH == brute force -----------------------------------------------------------------
+@pytest.mark.parametrize("name", ["shoebox", "starter_room", "old_mine"])
+def test_bvh_equals_brute_force(oracle_mod, scene_factory, name):
+    sc = scene_factory(name)
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    rng = np.random.default_rng(7)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    n = 300 if name == "old_mine" else 1500
+    hits = 0
+    for i in range(n):
+        o = sc.source + rng.normal(0, 60, 3) if i % 2 else rng.uniform(lo, hi)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        a = s.trace_closest(o, d, 1e6, brute=False)
+        b = s.trace_closest(o, d, 1e6, brute=True)
+        assert a[0] == b[0]
+        if a[0]:
+            hits += 1
+            assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3])
+            assert a[3] @ d <= 0  # normal faces the ray origin side
+            tm = a[1] * rng.uniform(0.5, 1.5)
+            assert s.trace_any(o, d, tm, brute=False) == s.trace_any(o, d, tm, brute=True) == (tm >= a[1])
+    assert hits > n // 3
+
+
+# ---- GeneratePath / ConnectSubpaths / UpdateSource -----------------------------------------------------
+def test_generate_path_structure(oracle_mod, scene_factory):
+    sc = scene_factory("starter_room")
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    p = oracle_mod.default_params(depth=8)
+    seg, dup, total = 0, 0, 0
+    for pair in range(1500):
+        nodes = s.generate_path(p, pair, 0, sc.source)
+        assert 1 <= len(nodes) <= 9
+        assert nodes[0].prob == 1.0 and nodes[0].material == 0xFFFF
+        assert tuple(nodes[0].pos) == tuple(np.float32(sc.source))
+        seg += len(nodes) - 1
+        if len(nodes) > 1:
+            assert nodes[1].prob == pytest.approx(0.9 / (4 * math.pi), rel=1e-6)  # ARTS.cpp:309-310
+        for a, b in zip(nodes[:-1], nodes[1:]):
+            total += 1
+            if tuple(a.pos) == tuple(b.pos):
+                dup += 1  # a miss (open door/window): duplicate node, ARTS.cpp:296 + :339 false
+            else:
+                assert b.material != 0xFFFF and abs(np.linalg.norm(list(b.normal)) - 1) < 1e-5
+    # Russian roulette 0.9 with depth cap 8: E[segments] = sum_{k=1..8} 0.9^k = 5.13
+    assert abs(seg / 1500 - sum(0.9 ** k for k in range(1, 9))) < 0.25
+    assert 0 < dup < total // 4
+    # unbounded (reference) walk: mean 9 segments; fixed depth: exactly `depth` segments
+    pu = oracle_mod.default_params(depth=0)
+    mean = np.mean([len(s.generate_path(pu, i, 1, sc.listener)) - 1 for i in range(1500)])
+    assert abs(mean - 9.0) < 0.8
+    pf = oracle_mod.default_params(depth=6, russian_roulette=0)
+    assert all(len(s.generate_path(pf, i, 0, sc.source)) == 7 for i in range(50))
+
+
+def test_compute_energy_consistency(oracle_mod, scene_factory):
+    sc = scene_factory("starter_room")
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    p = oracle_mod.default_params(num_pairs=2048, depth=8)
+    e32, e64, c = s.compute_energy(p, sc.source, sc.listener)
+    assert c.connected == c.deposits and 0 < c.connected < 2048
+    assert c.closest_rays + 2 * 2048 == c.path_nodes or c.closest_rays <= c.path_nodes
+    # determinism
+    e32b, _, _ = s.compute_energy(p, sc.source, sc.listener)
+    assert np.array_equal(e32, e32b)
+    # brute force == BVH, bit for bit (the closest hit does not depend on the tree)
+    pb = oracle_mod.default_params(num_pairs=2048, depth=8, flags=oracle_mod.FLAG_BRUTE_FORCE)
+    e32c, _, _ = s.compute_energy(pb, sc.source, sc.listener, 0, 256)
+    e32d, _, _ = s.compute_energy(p, sc.source, sc.listener, 0, 256)
+    assert np.array_equal(e32c, e32d)
+    # shard invariance: ranges sum to the whole (global pair index keys the RNG)
+    parts = [s.compute_energy(p, sc.source, sc.listener, a, b)[1] for a, b in ((0, 700), (700, 1500), (1500, 2048))]
+    assert np.allclose(sum(parts), e64, rtol=1e-12, atol=0)
+    # quirk A.6-c: fixed normaliser 1/1000
+    pn = oracle_mod.default_params(num_pairs=2048, depth=8, flags=oracle_mod.FLAG_FIXED_NORM_1000)
+    _, e64n, _ = s.compute_energy(pn, sc.source, sc.listener)
+    assert np.allclose(e64n, e64 * 2048 / 1000, rtol=1e-6)
+    # every deposit is <= gain 10 / P per band
+    assert e64.sum(axis=1).max() <= 10.0 * c.connected / 2048 + 1e-9
+    # seeds matter
+    p2 = oracle_mod.default_params(num_pairs=2048, depth=8, seed=1234)
+    assert not np.array_equal(s.compute_energy(p2, sc.source, sc.listener)[0], e32)
+
+
+def test_multithreaded_baseline_matches(oracle_mod, scene_factory):
+    sc = scene_factory("shoebox", 2)
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    p = oracle_mod.default_params(num_pairs=3000, depth=6)
+    _, e64, c = s.compute_energy(p, sc.source, sc.listener)
+    _, e64m, cm = s.compute_energy_mt(p, sc.source, sc.listener, threads=4)
+    assert np.allclose(e64, e64m, rtol=1e-12) and c.as_dict() == cm.as_dict()
