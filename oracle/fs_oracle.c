@@ -483,7 +483,7 @@ int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair
         nd->material = mat; nd->prob = prob;
         if (c) c->path_nodes++;
         /* depth cap (build parameter; the reference loop is unbounded, quirk A.6-i) */
-        if (p->depth > 0 && (int32_t)k >= p->depth) break;
+        if ((int32_t)k >= (p->depth > 0 ? p->depth : FSO_MAX_DEPTH)) break;
         /* 1. Russian roulette ARTS.cpp:300-301 */
         uint32_t r[4];
         fso_draw(p->seed, pair, side, k, 0, r);
@@ -606,7 +606,7 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
                         uint32_t pair_begin, uint32_t pair_end, int32_t num_bins, float* energy_f32,
                         double* energy_f64, fso_counters* c) {
     int B = s->B;
-    int32_t max_nodes = p->depth > 0 ? p->depth + 1 : FSO_MAX_NODES;
+    int32_t max_nodes = (p->depth > 0 ? p->depth : FSO_MAX_DEPTH) + 1;
     fso_node* fwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes);
     fso_node* bwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes);
     fso_node* all = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes * 2);
