@@ -208,9 +208,13 @@ void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out) {
         Node64 n{};
         float lo[3], hi[3];
         child_box(b.nodes[root], lo, hi);
+        // empty second child: a degenerate far-away box no ray segment can reach (an inverted infinite
+        // box would pass the slab test: min/max of +-inf)
+        const float far = 3.0e38f;
+        (void)inf;
         n.q0 = make_float4(lo[0], lo[1], lo[2], hi[0]);
-        n.q1 = make_float4(hi[1], hi[2], inf, inf);
-        n.q2 = make_float4(inf, -inf, -inf, -inf);
+        n.q1 = make_float4(hi[1], hi[2], far, far);
+        n.q2 = make_float4(far, far, far, far);
         n.c0 = leaf_code(b.nodes[root].first, b.nodes[root].count);
         n.c1 = -1;
         out.nodes.push_back(n);

@@ -114,18 +114,22 @@ __device__ __forceinline__ void sample_cone(float nx, float ny, float nz, float 
 // ---------------------------------------------------------------------------------------------------
 struct Ray {
     float ox, oy, oz, dx, dy, dz;
-    float ix, iy, iz;  // safe reciprocals for the slab test
+    float ix, iy, iz;     // safe reciprocals for the slab test
+    float nox, noy, noz;  // -o * inv: slab distances become one fma per plane
 };
 
+// Box tests only need to be conservative (boxes are padded far beyond this error), so the hardware
+// reciprocal approximation is fine here; the triangle test uses IEEE division.
 __device__ __forceinline__ float safe_rcp(float x) {
     if (fabsf(x) < 1e-20f) x = copysignf(1e-20f, x);
-    return 1.0f / x;
+    return __builtin_amdgcn_rcpf(x);
 }
 
 __device__ __forceinline__ Ray make_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
     Ray r;
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = safe_rcp(dx); r.iy = safe_rcp(dy); r.iz = safe_rcp(dz);
+    r.nox = -(ox * r.ix); r.noy = -(oy * r.iy); r.noz = -(oz * r.iz);
     return r;
 }
 
@@ -140,16 +144,21 @@ __device__ __forceinline__ bool tri_hit(const float4 A, const float4 Bq, const f
     float pz = fmaf(r.dx, e2y, -(r.dy * e2x));
     float det = fmaf(e1x, px, fmaf(e1y, py, e1z * pz));
     if (det == 0.0f) return false;
-    float inv = 1.0f / det;
+    // barycentric tests on the un-normalised values, sign-normalised by det (exact: sign-bit xor);
+    // the one IEEE division is only paid by rays that are inside the triangle
+    const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
+    const float ad = fabsf(det);
     float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
-    float u = fmaf(sx, px, fmaf(sy, py, sz * pz)) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    float U = fmaf(sx, px, fmaf(sy, py, sz * pz));
+    float us = __uint_as_float(__float_as_uint(U) ^ sgn);
+    if (!(us >= 0.0f && us <= ad)) return false;
     float qx = fmaf(sy, e1z, -(sz * e1y));
     float qy = fmaf(sz, e1x, -(sx * e1z));
     float qz = fmaf(sx, e1y, -(sy * e1x));
-    float v = fmaf(r.dx, qx, fmaf(r.dy, qy, r.dz * qz)) * inv;
-    if (!(v >= 0.0f && (u + v) <= 1.0f)) return false;
-    float t = fmaf(e2x, qx, fmaf(e2y, qy, e2z * qz)) * inv;
+    float V = fmaf(r.dx, qx, fmaf(r.dy, qy, r.dz * qz));
+    float vs = __uint_as_float(__float_as_uint(V) ^ sgn);
+    if (!(vs >= 0.0f && (us + vs) <= ad)) return false;
+    float t = fmaf(e2x, qx, fmaf(e2y, qy, e2z * qz)) / det;
     if (!(t > 0.0f && t <= tmax)) return false;
     t_out = t;
     return true;
@@ -157,9 +166,9 @@ __device__ __forceinline__ bool tri_hit(const float4 A, const float4 Bq, const f
 
 __device__ __forceinline__ float slab(float lx, float ly, float lz, float hx, float hy, float hz, const Ray& r,
                                       float tmax, bool& hit) {
-    float t0x = (lx - r.ox) * r.ix, t1x = (hx - r.ox) * r.ix;
-    float t0y = (ly - r.oy) * r.iy, t1y = (hy - r.oy) * r.iy;
-    float t0z = (lz - r.oz) * r.iz, t1z = (hz - r.oz) * r.iz;
+    float t0x = fmaf(lx, r.ix, r.nox), t1x = fmaf(hx, r.ix, r.nox);
+    float t0y = fmaf(ly, r.iy, r.noy), t1y = fmaf(hy, r.iy, r.noy);
+    float t0z = fmaf(lz, r.iz, r.noz), t1z = fmaf(hz, r.iz, r.noz);
     float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
     hit = tn <= tf;
@@ -172,65 +181,66 @@ struct HitRec {
     uint32_t id;         // input triangle index (tie-break key)
 };
 
-// Stack-based BVH2 walk, one ray per lane.  `stack` is this lane's column of the workgroup's LDS stack
-// (element i at stack[i * kBlock]).  ANY = stop at the first hit.
+// Stack-based BVH2 walk, one ray per lane, "while-while" form: every lane first descends inner nodes
+// until it holds a leaf (or is done), THEN the wave intersects leaves together — box tests and triangle
+// tests no longer serialise against each other inside one loop body.  `stack` is this lane's column of
+// the workgroup's LDS stack (element i at stack[i * kBlock]).  ANY = stop at the first hit.
 template <bool ANY>
 __device__ __forceinline__ HitRec traverse(const DeviceScene& sc, const Ray& r, float tmax, int* stack) {
+    constexpr int kDone = (int)0x80000000;
     HitRec best;
     best.t = tmax; best.leaf_index = -1; best.id = 0xFFFFFFFFu;
     if (sc.num_nodes == 0) return best;
     int sp = 0;
-    int node = 0;  // root is always an inner node
+    int cur = 0;  // >= 0: inner node index; < 0: leaf code (~cur = first*4 + count-1) or kDone
     const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
     const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
-    while (true) {
-        // ---- inner node: fetch 64 B, test both children ----
-        const float4 q0 = nodes4[4 * node + 0];
-        const float4 q1 = nodes4[4 * node + 1];
-        const float4 q2 = nodes4[4 * node + 2];
-        const float4 q3 = nodes4[4 * node + 3];
-        bool h0, h1;
-        float t0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, best.t, h0);
-        float t1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, best.t, h1);
-        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-        int next = 0;
-        bool have = false;
-        // order the (up to two) children near-first; leaves are intersected immediately
-        int first = c0, second = c1;
-        bool hf = h0, hs = h1;
-        if (h0 && h1 && t1 < t0) { first = c1; second = c0; }
-        if (!h0) { first = c1; hf = h1; hs = false; }
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            int c = (w == 0) ? first : second;
-            bool h = (w == 0) ? hf : hs;
-            if (!h) continue;
-            if (c >= 0) {
-                if (!have) { next = c; have = true; }
-                else { stack[sp * kBlock] = c; ++sp; }
+    while (cur != kDone) {
+        // ---- phase 1: inner nodes. one 64-B fetch decides both children ----
+        while (cur >= 0) {
+            const float4 q0 = nodes4[4 * cur + 0];
+            const float4 q1 = nodes4[4 * cur + 1];
+            const float4 q2 = nodes4[4 * cur + 2];
+            const float4 q3 = nodes4[4 * cur + 3];
+            bool h0, h1;
+            float t0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, best.t, h0);
+            float t1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, best.t, h1);
+            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (h0 && h1) {
+                const bool sw = t1 < t0;
+                stack[sp * kBlock] = sw ? c0 : c1;  // far child waits
+                ++sp;
+                cur = sw ? c1 : c0;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else if (sp > 0) {
+                --sp;
+                cur = stack[sp * kBlock];
             } else {
-                int code = ~c;
-                int ft = code >> 2, cnt = (code & 3) + 1;
-                for (int i = 0; i < cnt; ++i) {
-                    const float4 A = tris4[3 * (ft + i) + 0];
-                    const float4 Bq = tris4[3 * (ft + i) + 1];
-                    const float4 Cq = tris4[3 * (ft + i) + 2];
-                    float t;
-                    if (tri_hit(A, Bq, Cq, r, best.t, t)) {
-                        if (ANY) { best.t = t; best.leaf_index = ft + i; return best; }
-                        uint32_t id = __float_as_uint(Cq.z);
-                        if (t < best.t || best.leaf_index < 0 || (t == best.t && id < best.id)) {
-                            best.t = t; best.leaf_index = ft + i; best.id = id;
-                        }
+                cur = kDone;
+            }
+        }
+        // ---- phase 2: leaf (1..4 contiguous 48-B triangle records) ----
+        if (cur != kDone) {
+            const int code = ~cur;
+            const int ft = code >> 2, cnt = (code & 3) + 1;
+            for (int i = 0; i < cnt; ++i) {
+                const float4 A = tris4[3 * (ft + i) + 0];
+                const float4 Bq = tris4[3 * (ft + i) + 1];
+                const float4 Cq = tris4[3 * (ft + i) + 2];
+                float t;
+                if (tri_hit(A, Bq, Cq, r, best.t, t)) {
+                    if (ANY) { best.t = t; best.leaf_index = ft + i; return best; }
+                    uint32_t id = __float_as_uint(Cq.z);
+                    if (t < best.t || best.leaf_index < 0 || (t == best.t && id < best.id)) {
+                        best.t = t; best.leaf_index = ft + i; best.id = id;
                     }
                 }
             }
+            if (sp > 0) { --sp; cur = stack[sp * kBlock]; } else { cur = kDone; }
         }
-        if (have) { node = next; continue; }
-        // pop until a node whose entry distance may still matter (boxes are re-tested on visit)
-        if (sp == 0) break;
-        --sp;
-        node = stack[sp * kBlock];
     }
     return best;
 }

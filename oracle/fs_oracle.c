@@ -329,16 +329,20 @@ static int tri_hit(const fso_tri* tr, const float o[3], const float d[3], float 
     float pz = fmaf(d[0], e2[1], -(d[1] * e2[0]));
     float det = fmaf(e1[0], px, fmaf(e1[1], py, e1[2] * pz));
     if (det == 0.0f) return 0;
-    float inv = 1.0f / det;
+    /* barycentric tests on the un-normalised values, sign-normalised by det (exact), so the one
+     * division is only paid by rays that are inside the triangle */
+    float ad = fabsf(det);
     float sx = o[0] - tr->v0[0], sy = o[1] - tr->v0[1], sz = o[2] - tr->v0[2];
-    float u = fmaf(sx, px, fmaf(sy, py, sz * pz)) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return 0;
+    float U = fmaf(sx, px, fmaf(sy, py, sz * pz));
+    float us = det < 0.0f ? -U : U;
+    if (!(us >= 0.0f && us <= ad)) return 0;
     float qx = fmaf(sy, e1[2], -(sz * e1[1]));
     float qy = fmaf(sz, e1[0], -(sx * e1[2]));
     float qz = fmaf(sx, e1[1], -(sy * e1[0]));
-    float v = fmaf(d[0], qx, fmaf(d[1], qy, d[2] * qz)) * inv;
-    if (!(v >= 0.0f && (u + v) <= 1.0f)) return 0;
-    float t = fmaf(e2[0], qx, fmaf(e2[1], qy, e2[2] * qz)) * inv;
+    float V = fmaf(d[0], qx, fmaf(d[1], qy, d[2] * qz));
+    float vs = det < 0.0f ? -V : V;
+    if (!(vs >= 0.0f && (us + vs) <= ad)) return 0;
+    float t = fmaf(e2[0], qx, fmaf(e2[1], qy, e2[2] * qz)) / det;
     if (!(t > 0.0f && t <= tmax)) return 0;
     *t_out = t;
     return 1;
