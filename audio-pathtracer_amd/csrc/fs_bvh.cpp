@@ -185,15 +185,25 @@ void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out) {
     for (int i = 0; i < T; ++i) {
         int t = b.order[i];
         const float* p = xyz + 9 * (size_t)t;
-        Tri48 r;
-        r.a = make_float4(p[0], p[1], p[2], p[3] - p[0]);
-        r.b = make_float4(p[4] - p[1], p[5] - p[2], p[6] - p[0], p[7] - p[1]);
+        Tri64 r;
+        const float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
+        const float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
+        r.a = make_float4(p[0], p[1], p[2], e1x);
+        r.b = make_float4(e1y, e1z, e2x, e2y);
         uint32_t m = mat ? (uint32_t)mat[t] : (uint32_t)FS_NO_MATERIAL;
         float mf, idf;
         uint32_t id = (uint32_t)t;
         std::memcpy(&mf, &m, 4);
         std::memcpy(&idf, &id, 4);
-        r.c = make_float4(p[8] - p[2], mf, idf, 0.f);
+        r.c = make_float4(e2z, mf, idf, 0.f);
+        // unit geometric normal, fixed operation order (part of the hit-normal spec; built with
+        // -ffp-contract=off, so this is the same fp32 sequence the oracle evaluates at hit time)
+        float nx = std::fmaf(e1y, e2z, -(e1z * e2y));
+        float ny = std::fmaf(e1z, e2x, -(e1x * e2z));
+        float nz = std::fmaf(e1x, e2y, -(e1y * e2x));
+        float l2 = nx * nx + ny * ny + nz * nz;
+        float inv = 1.0f / std::sqrt(l2);
+        r.d = make_float4(nx * inv, ny * inv, nz * inv, 0.f);
         out.tris[i] = r;
     }
 

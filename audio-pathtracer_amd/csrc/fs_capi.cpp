@@ -4,8 +4,10 @@
 // per-source update: AudioRayTracingSubsystem.cpp:32-53, 128-195) and of UFrequenSeeAudioComponent's
 // buffers (EnergyBuffer, ImpulseBuffer: FrequenSeeAudioComponent.h:69-91, 113, 133-143).  All compute
 // is HIP on the context's stream; there is no CPU fallback.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -54,7 +56,7 @@ struct fs_context {
     int32_t T = 0, M = 0;
     bool committed = false;
     Node64* d_nodes = nullptr;
-    Tri48* d_tris = nullptr;
+    Tri64* d_tris = nullptr;
     float* d_absorption = nullptr;
     DeviceScene scene{};
     HostBVH bvh;
@@ -65,6 +67,10 @@ struct fs_context {
     // subpath state (sized on demand)
     SubpathState st{};
     size_t cap_lanes = 0, cap_seg = 0;
+
+    // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
+    WalkLaunch walk{1, 256, 2, nullptr};
+    int refill_threshold = 16;
 
     // measurement
     bool profiling = false;
@@ -121,10 +127,10 @@ void free_scene(fs_context* ctx) {
 }
 
 void free_state(fs_context* ctx) {
-    if (ctx->st.pos_sd) (void)hipFree(ctx->st.pos_sd);
-    if (ctx->st.misc) (void)hipFree(ctx->st.misc);
-    if (ctx->st.energy) (void)hipFree(ctx->st.energy);
-    if (ctx->st.seg_nd) (void)hipFree(ctx->st.seg_nd);
+    if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
+    if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
+    if (ctx->st.seg_np) (void)hipFree(ctx->st.seg_np);
+    if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
     ctx->st = SubpathState{};
     ctx->cap_lanes = ctx->cap_seg = 0;
 }
@@ -175,25 +181,24 @@ void poll_published(Source* s) {
 }
 
 int ensure_state(fs_context* ctx, uint32_t n_local, int depth) {
-    const int B = ctx->cfg.num_bands;
     size_t lanes = 2 * (size_t)n_local;
-    size_t seg = (size_t)depth * (size_t)n_local;
+    size_t seg = (size_t)depth * lanes;
     if (lanes > ctx->cap_lanes) {
-        if (ctx->st.pos_sd) (void)hipFree(ctx->st.pos_sd);
-        if (ctx->st.misc) (void)hipFree(ctx->st.misc);
-        if (ctx->st.energy) (void)hipFree(ctx->st.energy);
-        ctx->st.pos_sd = nullptr; ctx->st.misc = nullptr; ctx->st.energy = nullptr;
+        if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
+        if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
+        ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr;
         ctx->cap_lanes = 0;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.pos_sd, sizeof(float4) * lanes));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.misc, sizeof(float4) * lanes));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.energy, sizeof(float) * lanes * (size_t)B));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * lanes));
         ctx->cap_lanes = lanes;
     }
     if (seg > ctx->cap_seg) {
-        if (ctx->st.seg_nd) (void)hipFree(ctx->st.seg_nd);
-        ctx->st.seg_nd = nullptr;
+        if (ctx->st.seg_np) (void)hipFree(ctx->st.seg_np);
+        if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
+        ctx->st.seg_np = nullptr; ctx->st.seg_mat = nullptr;
         ctx->cap_seg = 0;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_nd, sizeof(float) * seg));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_np, sizeof(float2) * seg));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_mat, sizeof(uint32_t) * seg));
         ctx->cap_seg = seg;
     }
     return FS_OK;
@@ -290,6 +295,15 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
         if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         ctx->own_stream = true;
     }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0)
+        ctx->walk.num_cus = cus;
+    if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
+    if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
+    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned));
+    if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
     ctx->device_ok = true;
     return FS_OK;
 }
@@ -303,6 +317,7 @@ int fs_context_destroy(fs_context* ctx) {
         for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
         free_scene(ctx);
         free_state(ctx);
+        if (ctx->walk.queue_head) (void)hipFree(ctx->walk.queue_head);
     }
     for (Source* s : ctx->sources) free_source(ctx, s);
     if (ctx->device_ok && ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -352,7 +367,7 @@ int fs_scene_commit(fs_context* ctx) {
     free_scene(ctx);
     build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(), ctx->T, ctx->bvh);
     if (ctx->bvh.max_depth >= kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH deeper than the traversal stack");
-    size_t nb = ctx->bvh.nodes.size() * sizeof(Node64), tb = ctx->bvh.tris.size() * sizeof(Tri48);
+    size_t nb = ctx->bvh.nodes.size() * sizeof(Node64), tb = ctx->bvh.tris.size() * sizeof(Tri64);
     size_t mb = ctx->h_absorption.size() * sizeof(float);
     if (nb) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, nb));
@@ -477,6 +492,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     std::memcpy(kp.src, s->pos, sizeof(kp.src));
     std::memcpy(kp.lis, ctx->listener, sizeof(kp.lis));
     kp.num_bins = ctx->num_bins;
+    kp.refill_threshold = ctx->refill_threshold;
 
     rc = ensure_state(ctx, kp.num_local, kp.depth);
     if (rc) return rc;
@@ -491,9 +507,9 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     // FlushEnergyBuffer ARTS.cpp:157-161
     FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
-    launch_walk(B, ctx->scene, kp, ctx->st, ctx->stream);
+    launch_walk(ctx->scene, kp, ctx->st, ctx->walk, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
-    launch_connect(B, ctx->scene, kp, ctx->st, s->d_energy, ctx->stream);
+    launch_connect(B, ctx->scene, kp, ctx->st, s->d_energy, ctx->walk.queue_head, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     if (ctx->profiling) {
         FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));

@@ -24,19 +24,21 @@ struct alignas(16) Node64 {
 };
 static_assert(sizeof(Node64) == 64, "Node64 must be 64 B");
 
-// Triangle record, 48 B, stored in leaf order:
+// Triangle record, 64 B (same size as a node, so traversal fetches either through one load sequence),
+// stored in leaf order:
 //   a = (v0.x v0.y v0.z e1.x)  b = (e1.y e1.z e2.x e2.y)  c = (e2.z, material, input index, -)
-struct alignas(16) Tri48 {
-    float4 a, b, c;
+//   d = (unit geometric normal of cross(e1, e2), -)
+struct alignas(16) Tri64 {
+    float4 a, b, c, d;
 };
-static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 B");
+static_assert(sizeof(Tri64) == 64, "Tri64 must be 64 B");
 
 constexpr int kStackDepth = 32;   // per-lane traversal stack entries (LDS); the builder caps tree depth
 constexpr int kBlock = 256;       // 4 waves of 64 lanes
 
 struct DeviceScene {
     const Node64* nodes;
-    const Tri48* tris;
+    const Tri64* tris;
     const float* absorption;  // [M][B]
     int32_t num_nodes;        // 0 = empty scene
     int32_t num_tris;
@@ -57,29 +59,40 @@ struct KParams {
     float air[FS_MAX_BANDS];
     float src[3], lis[3];
     int32_t num_bins;
+    int32_t refill_threshold;  // persistent walk: lanes waiting before the wave leaves traversal to shade/refill
 };
 
-// Subpath terminal state, SoA over 2*num_local subpaths (side-major: [0,n) source, [n,2n) listener).
+// What the walk kernels leave for connect_kernel, SoA over total = 2*num_local subpaths
+// (side-major: [0,n) source side, [n,2n) listener side).
 struct SubpathState {
-    float4* pos_sd;    // xyz = last node position, w = sum of scaled segment lengths (source side)
-    float4* misc;      // x = last node prob, y = material (bits), z = segments taken (bits), w = unused
-    float* energy;     // [B][2n] running product per band
-    float* seg_nd;     // [depth][n] listener-side scaled segment lengths, walk order
+    float4* end_pos;    // [total] xyz = last node position, w = last node probability
+    uint2* end_misc;    // [total] x = last node material, y = segments taken
+    float2* seg_np;     // [depth][total] per walk step: x = scaled segment length, y = probability of the
+                        //   node EvaluatePath pairs with the segment (departure node on the source side,
+                        //   arrival node on the listener side)
+    uint32_t* seg_mat;  // [depth][total] material of that node
 };
 
 // ---- host BVH builder ------------------------------------------------------------------------------
 struct HostBVH {
     std::vector<Node64> nodes;
-    std::vector<Tri48> tris;   // leaf order
+    std::vector<Tri64> tris;   // leaf order
     int max_depth = 0;
 };
 // xyz [T][3][3], mat [T]; binned SAH, <= 4 triangles per leaf, boxes padded conservatively.
 void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out);
 
 // ---- kernel launchers (fs_kernels.hip) -----------------------------------------------------------------
-void launch_walk(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, hipStream_t s);
+struct WalkLaunch {
+    int variant;         // 0 = one subpath per lane, 1 = persistent waves + dynamic fetch
+    int num_cus;         // compute units of the device
+    int blocks_per_cu;   // persistent grid = num_cus * blocks_per_cu workgroups (capped by the work)
+    unsigned* queue_head;  // device counter, zero at launch
+};
+void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
+                 hipStream_t s);
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    hipStream_t s);
+                    unsigned* queue_head, hipStream_t s);
 void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,
                         float* ir_bands, float* ir_mono, hipStream_t s);
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,

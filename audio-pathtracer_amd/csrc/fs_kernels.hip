@@ -1,12 +1,16 @@
 // fs_kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64) of the FrequenSee BDPT path.
 //
-//   walk_kernel        GeneratePath (AudioRayTracingSubsystem.cpp:279-355) for every source and listener
-//                      subpath, one subpath per lane, with the EvaluatePath (:360-420) segment terms applied
-//                      in-register as the walk proceeds (the path need not be stored).
-//   connect_kernel     ConnectSubpaths (:235-277) any-hit visibility ray per pair, the connection
-//                      segment's EvaluatePath term, clamp/gain (:410-413), normalisation (:164-170) and
-//                      AddEnergyAtDelay (FrequenSeeAudioComponent.h:87-91) into an LDS-privatised
-//                      [bands][bins] histogram flushed with global float atomics.
+//   walk_kernel_*      GeneratePath (AudioRayTracingSubsystem.cpp:279-355) for every source and listener
+//                      subpath.  Only geometry happens here (RNG, direction, closest hit, hit point); each
+//                      walk step leaves a 12-byte segment record (scaled length, node probability, node
+//                      material) so that EvaluatePath needs no stored path.
+//                        _persistent: waves pull subpaths from a queue and keep their lanes busy (default)
+//                        _simple:     one subpath per lane (reference variant for A/B runs)
+//   connect_kernel     ConnectSubpaths (:235-277) any-hit visibility ray per pair; for connected pairs
+//                      EvaluatePath (:360-420) over the segment records in exact path order, clamp/gain
+//                      (:410-413), normalisation (:164-170) and AddEnergyAtDelay
+//                      (FrequenSeeAudioComponent.h:87-91) into an LDS-privatised [bands][bins] histogram
+//                      flushed with global float atomics.
 //   reconstruct_kernel ReconstructImpulseResponse (FrequenSeeAudioComponent.cpp:320-380).
 //   trace_rays_kernel  the engine line trace itself (closest / any hit), for tests and tools.
 //
@@ -20,6 +24,7 @@ namespace {
 
 constexpr float kPi = 3.1415926535897932f;
 constexpr uint32_t kNoMat = FS_NO_MATERIAL;
+constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
 
 // ---------------------------------------------------------------------------------------------------
 // RNG: Philox4x32-10, counter = (pair, bounce<<1|side, block, 'FS01'), key = seed
@@ -175,90 +180,99 @@ __device__ __forceinline__ float slab(float lx, float ly, float lz, float hx, fl
     return tn;
 }
 
-struct HitRec {
-    float t;
-    int32_t leaf_index;  // index into the leaf-ordered triangle array, -1 = miss
-    uint32_t id;         // input triangle index (tie-break key)
+// ---------------------------------------------------------------------------------------------------
+// BVH traversal, one ray per lane, as a resumable single loop: every call of trav_step a busy lane
+// consumes exactly one 64-byte record — an inner node (two child boxes) OR one triangle of a pending
+// leaf — fetched through one common load sequence, so a wave never serialises "descend" against
+// "intersect" phases and a lane can be parked/resumed between any two steps (persistent kernel).
+// `stack` is this lane's column of the workgroup's LDS stack (element i at stack[i * kBlock]).
+// ---------------------------------------------------------------------------------------------------
+struct Trav {
+    int cur;        // next node: >= 0 inner index, < 0 leaf code (~cur = first*4 + count-1), kDone = none
+    int sp;         // stack entries
+    int tri_i, tri_n;  // pending triangles [tri_i, tri_n) of the current leaf
+    float t;        // closest hit so far (init: tmax)
+    int leaf_index; // hit triangle (leaf order), -1 = none
+    uint32_t id;    // its input index (tie-break key)
 };
 
-// Stack-based BVH2 walk, one ray per lane, "while-while" form: every lane first descends inner nodes
-// until it holds a leaf (or is done), THEN the wave intersects leaves together — box tests and triangle
-// tests no longer serialise against each other inside one loop body.  `stack` is this lane's column of
-// the workgroup's LDS stack (element i at stack[i * kBlock]).  ANY = stop at the first hit.
+__device__ __forceinline__ void trav_init(Trav& T, float tmax, bool scene_nonempty) {
+    T.cur = scene_nonempty ? 0 : kDone;
+    T.sp = 0; T.tri_i = 0; T.tri_n = 0;
+    T.t = tmax; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
+}
+__device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tri_n || T.cur != kDone; }
+
 template <bool ANY>
-__device__ __forceinline__ HitRec traverse(const DeviceScene& sc, const Ray& r, float tmax, int* stack) {
-    constexpr int kDone = (int)0x80000000;
-    HitRec best;
-    best.t = tmax; best.leaf_index = -1; best.id = 0xFFFFFFFFu;
-    if (sc.num_nodes == 0) return best;
-    int sp = 0;
-    int cur = 0;  // >= 0: inner node index; < 0: leaf code (~cur = first*4 + count-1) or kDone
-    const float4* nodes4 = reinterpret_cast<const float4*>(sc.nodes);
-    const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
-    while (cur != kDone) {
-        // ---- phase 1: inner nodes. one 64-B fetch decides both children ----
-        while (cur >= 0) {
-            const float4 q0 = nodes4[4 * cur + 0];
-            const float4 q1 = nodes4[4 * cur + 1];
-            const float4 q2 = nodes4[4 * cur + 2];
-            const float4 q3 = nodes4[4 * cur + 3];
-            bool h0, h1;
-            float t0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, best.t, h0);
-            float t1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, best.t, h1);
-            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            if (h0 && h1) {
-                const bool sw = t1 < t0;
-                stack[sp * kBlock] = sw ? c0 : c1;  // far child waits
-                ++sp;
-                cur = sw ? c1 : c0;
-            } else if (h0) {
-                cur = c0;
-            } else if (h1) {
-                cur = c1;
-            } else if (sp > 0) {
-                --sp;
-                cur = stack[sp * kBlock];
-            } else {
-                cur = kDone;
+__device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, Trav& T, int* stack) {
+    // a pending leaf becomes the triangle cursor and the next node is popped right away
+    if (T.tri_i >= T.tri_n && T.cur < 0 && T.cur != kDone) {
+        const int code = ~T.cur;
+        T.tri_i = code >> 2;
+        T.tri_n = T.tri_i + (code & 3) + 1;
+        if (T.sp > 0) { --T.sp; T.cur = stack[T.sp * kBlock]; } else { T.cur = kDone; }
+    }
+    const bool is_tri = T.tri_i < T.tri_n;
+    if (!is_tri && T.cur < 0) return;  // nothing left for this lane
+    const float4* rec = is_tri ? reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)T.tri_i
+                               : reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)T.cur;
+    const float4 q0 = rec[0];
+    const float4 q1 = rec[1];
+    const float4 q2 = rec[2];
+    const float4 q3 = rec[3];
+    if (is_tri) {
+        float t;
+        if (tri_hit(q0, q1, q2, r, T.t, t)) {
+            const uint32_t id = __float_as_uint(q2.z);
+            if (ANY) {
+                T.t = t; T.leaf_index = T.tri_i; T.id = id;
+                T.tri_n = T.tri_i; T.cur = kDone; T.sp = 0;  // first hit ends the query
+                return;
+            }
+            if (t < T.t || T.leaf_index < 0 || (t == T.t && id < T.id)) {
+                T.t = t; T.leaf_index = T.tri_i; T.id = id;
             }
         }
-        // ---- phase 2: leaf (1..4 contiguous 48-B triangle records) ----
-        if (cur != kDone) {
-            const int code = ~cur;
-            const int ft = code >> 2, cnt = (code & 3) + 1;
-            for (int i = 0; i < cnt; ++i) {
-                const float4 A = tris4[3 * (ft + i) + 0];
-                const float4 Bq = tris4[3 * (ft + i) + 1];
-                const float4 Cq = tris4[3 * (ft + i) + 2];
-                float t;
-                if (tri_hit(A, Bq, Cq, r, best.t, t)) {
-                    if (ANY) { best.t = t; best.leaf_index = ft + i; return best; }
-                    uint32_t id = __float_as_uint(Cq.z);
-                    if (t < best.t || best.leaf_index < 0 || (t == best.t && id < best.id)) {
-                        best.t = t; best.leaf_index = ft + i; best.id = id;
-                    }
-                }
-            }
-            if (sp > 0) { --sp; cur = stack[sp * kBlock]; } else { cur = kDone; }
+        ++T.tri_i;
+    } else {
+        bool h0, h1;
+        const float t0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, T.t, h0);
+        const float t1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, T.t, h1);
+        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+        if (h0 && h1) {
+            const bool sw = t1 < t0;
+            stack[T.sp * kBlock] = sw ? c0 : c1;  // far child waits
+            ++T.sp;
+            T.cur = sw ? c1 : c0;
+        } else if (h0) {
+            T.cur = c0;
+        } else if (h1) {
+            T.cur = c1;
+        } else if (T.sp > 0) {
+            --T.sp;
+            T.cur = stack[T.sp * kBlock];
+        } else {
+            T.cur = kDone;
         }
     }
-    return best;
 }
 
-// geometric normal of the hit triangle, unit, flipped to face the ray origin side (ImpactNormal)
-__device__ __forceinline__ void hit_normal(const float4 A, const float4 Bq, const float4 Cq, const Ray& r, float& nx,
-                                           float& ny, float& nz) {
-    const float e1x = A.w, e1y = Bq.x, e1z = Bq.y;
-    const float e2x = Bq.z, e2y = Bq.w, e2z = Cq.x;
-    float x = fmaf(e1y, e2z, -(e1z * e2y));
-    float y = fmaf(e1z, e2x, -(e1x * e2z));
-    float z = fmaf(e1x, e2y, -(e1y * e2x));
-    float l2 = x * x + y * y + z * z;
-    float inv = 1.0f / sqrtf(l2);
-    x *= inv; y *= inv; z *= inv;
+template <bool ANY>
+__device__ __forceinline__ void trav_run(const DeviceScene& sc, const Ray& r, Trav& T, int* stack) {
+    while (trav_busy(T)) trav_step<ANY>(sc, r, T, stack);
+}
+
+// ImpactNormal: the record's unit geometric normal, flipped to face the ray origin side; material of the hit
+__device__ __forceinline__ void hit_surface(const DeviceScene& sc, int leaf_index, const Ray& r, float& nx, float& ny,
+                                            float& nz, uint32_t& mat) {
+    const float4* rec = reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)leaf_index;
+    const float4 c = rec[2];
+    const float4 d = rec[3];
+    float x = d.x, y = d.y, z = d.z;
     float dn = fmaf(x, r.dx, fmaf(y, r.dy, z * r.dz));
     if (dn > 0.0f) { x = -x; y = -y; z = -z; }
     nx = x; ny = y; nz = z;
+    mat = __float_as_uint(c.y);
 }
 
 // one EvaluatePath segment term on E[b] (ARTS.cpp:381-398), in the reference's operation order
@@ -283,104 +297,220 @@ __device__ __forceinline__ void apply_segment(float (&E)[B], float nd, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// walk_kernel: GeneratePath for 2 * num_local subpaths, one per lane
+// the walk, shared by both kernel variants
 // ---------------------------------------------------------------------------------------------------
-template <int B>
-__global__ __launch_bounds__(kBlock) void walk_kernel(DeviceScene sc, KParams kp, SubpathState st) {
-    __shared__ int s_stack[kStackDepth * kBlock];
-    const uint32_t n = kp.num_local;
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= 2u * n) return;
-    const uint32_t side = g >= n ? 1u : 0u;
-    const uint32_t li = g - side * n;
-    const uint32_t pair = kp.pair_begin + li;
-    int* stack = &s_stack[threadIdx.x];
+struct Walker {          // ARTS.cpp:287-291 state + bookkeeping
+    uint32_t g, side, li, pair;
+    int k;
+    float px, py, pz, nx, ny, nz;
+    bool has_normal;
+    uint32_t mat;
+    float prob, prob_new;
+};
 
-    // state variables ARTS.cpp:287-291
-    float px = side ? kp.lis[0] : kp.src[0];
-    float py = side ? kp.lis[1] : kp.src[1];
-    float pz = side ? kp.lis[2] : kp.src[2];
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    bool has_normal = false;
-    uint32_t mat = kNoMat;
-    float prob = 1.0f;
-    float E[B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) E[b] = 1.0f;
-    float sd = 0.0f;
-    int k = 0;
-    for (; k < kp.depth; ++k) {
-        const uint32_t bs = ((uint32_t)k << 1) | side;
-        uint4 r = philox(pair, bs, 0, kp.seed_lo, kp.seed_hi);
-        if (kp.russian_roulette && !(u01(r.x) < kp.rr_prob)) break;   // ARTS.cpp:300-301, 349-353
-        float dx, dy, dz, prob_new;
-        if (!has_normal) {                                            // ARTS.cpp:306-310
-            sample_sphere(pair, bs, r, kp.seed_lo, kp.seed_hi, dx, dy, dz);
-            float pdf = 1.0f / (4.0f * kPi);
-            prob_new = pdf * kp.rr_prob;
-        } else {                                                      // ARTS.cpp:311-318
-            sample_cone(nx, ny, nz, u01(r.y), u01(r.z), kp.cosine, dx, dy, dz);
-            float cos_theta = dx * nx + dy * ny + dz * nz;
-            float pdf = cos_theta / kPi;
-            prob_new = pdf * kp.rr_prob;
-        }
-        Ray ray = make_ray(px, py, pz, dx, dy, dz);
-        HitRec h = traverse<false>(sc, ray, kp.max_trace_dist, stack);  // ARTS.cpp:339-342
-        float qx = px, qy = py, qz = pz;
-        uint32_t mat_new = mat;
-        if (h.leaf_index >= 0) {                                      // ARTS.cpp:345-347
-            const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
-            const float4 A = tris4[3 * h.leaf_index + 0];
-            const float4 Bq = tris4[3 * h.leaf_index + 1];
-            const float4 Cq = tris4[3 * h.leaf_index + 2];
-            hit_normal(A, Bq, Cq, ray, nx, ny, nz);
-            qx = fmaf(kp.surface_offset, nx, fmaf(h.t, dx, px));
-            qy = fmaf(kp.surface_offset, ny, fmaf(h.t, dy, py));
-            qz = fmaf(kp.surface_offset, nz, fmaf(h.t, dz, pz));
-            has_normal = true;
-            mat_new = __float_as_uint(Cq.y);
-        }
-        // the segment just added (zero length on a miss: the duplicate node of ARTS.cpp:296)
-        float ddx = qx - px, ddy = qy - py, ddz = qz - pz;
-        float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);        // ARTS.cpp:372
-        float nd = dist / kp.dist_divisor;                            // ARTS.cpp:373
-        if (side == 0) {
-            sd += nd;                                                 // ARTS.cpp:374, path order
-            apply_segment<B>(E, nd, mat, prob, kp, sc);               // node i = departure node
-        } else {
-            st.seg_nd[(size_t)k * n + li] = nd;                       // summed in path order by connect
-            apply_segment<B>(E, nd, mat_new, prob_new, kp, sc);       // node i = arrival node (reversed walk)
-        }
-        px = qx; py = qy; pz = qz;
-        mat = mat_new;
-        prob = prob_new;
+__device__ __forceinline__ void walker_start(Walker& w, uint32_t g, const KParams& kp) {
+    const uint32_t n = kp.num_local;
+    w.g = g;
+    w.side = g >= n ? 1u : 0u;
+    w.li = g - w.side * n;
+    w.pair = kp.pair_begin + w.li;
+    w.px = w.side ? kp.lis[0] : kp.src[0];
+    w.py = w.side ? kp.lis[1] : kp.src[1];
+    w.pz = w.side ? kp.lis[2] : kp.src[2];
+    w.nx = 0.f; w.ny = 0.f; w.nz = 0.f;
+    w.has_normal = false;
+    w.mat = kNoMat;
+    w.prob = 1.0f; w.prob_new = 1.0f;
+    w.k = 0;
+}
+
+// top of GeneratePath's loop (ARTS.cpp:294-319): depth cap, roulette, direction.  false = the walk ends.
+__device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, Ray& ray) {
+    if (w.k >= kp.depth) return false;
+    const uint32_t bs = ((uint32_t)w.k << 1) | w.side;
+    const uint4 r = philox(w.pair, bs, 0, kp.seed_lo, kp.seed_hi);
+    if (kp.russian_roulette && !(u01(r.x) < kp.rr_prob)) return false;    // ARTS.cpp:300-301, 349-353
+    float dx, dy, dz;
+    if (!w.has_normal) {                                                  // ARTS.cpp:306-310
+        sample_sphere(w.pair, bs, r, kp.seed_lo, kp.seed_hi, dx, dy, dz);
+        float pdf = 1.0f / (4.0f * kPi);
+        w.prob_new = pdf * kp.rr_prob;
+    } else {                                                              // ARTS.cpp:311-318
+        sample_cone(w.nx, w.ny, w.nz, u01(r.y), u01(r.z), kp.cosine, dx, dy, dz);
+        float cos_theta = dx * w.nx + dy * w.ny + dz * w.nz;
+        float pdf = cos_theta / kPi;
+        w.prob_new = pdf * kp.rr_prob;
     }
-    st.pos_sd[g] = make_float4(px, py, pz, sd);
-    st.misc[g] = make_float4(prob, __uint_as_float(mat), __int_as_float(k), 0.f);
-#pragma unroll
-    for (int b = 0; b < B; ++b) st.energy[(size_t)b * 2u * n + g] = E[b];
+    ray = make_ray(w.px, w.py, w.pz, dx, dy, dz);
+    return true;
+}
+
+// bottom of the loop (ARTS.cpp:339-347): apply the closest hit (or the miss) and record the segment
+__device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, const DeviceScene& sc,
+                                                 const SubpathState& st, const Ray& ray, const Trav& T) {
+    float qx = w.px, qy = w.py, qz = w.pz;
+    uint32_t mat_new = w.mat;
+    if (T.leaf_index >= 0) {                                              // ARTS.cpp:345-347
+        hit_surface(sc, T.leaf_index, ray, w.nx, w.ny, w.nz, mat_new);
+        qx = fmaf(kp.surface_offset, w.nx, fmaf(T.t, ray.dx, w.px));
+        qy = fmaf(kp.surface_offset, w.ny, fmaf(T.t, ray.dy, w.py));
+        qz = fmaf(kp.surface_offset, w.nz, fmaf(T.t, ray.dz, w.pz));
+        w.has_normal = true;
+    }
+    // the segment just added (zero length on a miss: the duplicate node of ARTS.cpp:296)
+    float ddx = qx - w.px, ddy = qy - w.py, ddz = qz - w.pz;
+    float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);                // ARTS.cpp:372
+    float nd = dist / kp.dist_divisor;                                    // ARTS.cpp:373
+    // Record for EvaluatePath (done by connect_kernel in path order): node i of the reference's loop is
+    // the DEPARTURE node on the source side and — the listener subpath being reversed in the connected
+    // path — the ARRIVAL node on the listener side.
+    const size_t slot = (size_t)w.k * (2u * (size_t)kp.num_local) + w.g;
+    st.seg_np[slot] = w.side == 0 ? make_float2(nd, w.prob) : make_float2(nd, w.prob_new);
+    st.seg_mat[slot] = w.side == 0 ? w.mat : mat_new;
+    w.px = qx; w.py = qy; w.pz = qz;
+    w.mat = mat_new;
+    w.prob = w.prob_new;
+    ++w.k;
+}
+
+__device__ __forceinline__ void walker_finish(const Walker& w, const SubpathState& st) {
+    st.end_pos[w.g] = make_float4(w.px, w.py, w.pz, w.prob);
+    st.end_misc[w.g] = make_uint2(w.mat, (uint32_t)w.k);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// connect_kernel: ConnectSubpaths + connection term + clamp/gain + deposit
+// walk_kernel_simple: one subpath per lane (reference variant)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= 2u * kp.num_local) return;
+    int* stack = &s_stack[threadIdx.x];
+    Walker w;
+    walker_start(w, g, kp);
+    Ray ray;
+    while (walker_next_ray(w, kp, ray)) {
+        Trav T;
+        trav_init(T, kp.max_trace_dist, sc.num_nodes > 0);
+        trav_run<false>(sc, ray, T, stack);
+        walker_apply_hit(w, kp, sc, st, ray, T);
+    }
+    walker_finish(w, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// walk_kernel_persistent: the same walks on persistent waves.
+//
+// One-subpath-per-lane leaves most of a wave64 idle: Russian roulette kills 10 % of the lanes per bounce
+// and the rays of a wave need very different numbers of BVH steps.  Here a lane is a worker, not a
+// subpath: waves take 64-subpath chunks from a global queue (one atomicAdd per chunk — a single shared
+// head word saturates near 88 dequeues/us on this chip) and alternate between
+//   stage A (batched: entered when >= refill_threshold lanes wait, or nothing is traversing):
+//           apply the hit of lanes whose traversal completed, hand new subpaths to lanes whose walk
+//           ended, roulette + direction sampling for the next ray;
+//   stage B: one trav_step per busy lane per iteration, left as soon as enough lanes wait.
+// Results are identical to the simple kernel: a subpath's arithmetic depends only on (seed, pair, side).
+// ---------------------------------------------------------------------------------------------------
+enum : int { PH_NEW = 0, PH_TRAV = 1, PH_SHADE = 2, PH_IDLE = 3, PH_NEXT = 4 };
+constexpr int kQueueChunk = 64;
+
+__global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc, KParams kp, SubpathState st,
+                                                                 unsigned* __restrict__ queue_head) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    int* stack = &s_stack[threadIdx.x];
+    const unsigned lane = threadIdx.x & 63u;
+    const uint32_t total = 2u * kp.num_local;
+    const int thresh = kp.refill_threshold;
+    const bool nonempty = sc.num_nodes > 0;
+
+    int phase = PH_NEW;
+    Walker w;
+    walker_start(w, 0, kp);
+    Ray ray = make_ray(0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+    Trav T;
+    trav_init(T, 0.f, false);
+    unsigned q_next = 0, q_end = 0;  // the wave's private slice of the subpath queue (wave-uniform)
+    bool drained = false;
+
+    while (true) {
+        const unsigned long long trav_m = __ballot(phase == PH_TRAV);
+        const unsigned long long wait_m = __ballot(phase == PH_NEW || phase == PH_SHADE);
+        if ((trav_m | wait_m) == 0ull) break;  // every lane idle: queue drained
+
+        // ================= stage A: apply hits / refill / sample (batched) =================
+        if (trav_m == 0ull || __popcll(wait_m) >= thresh) {
+            if (phase == PH_SHADE) {
+                walker_apply_hit(w, kp, sc, st, ray, T);
+                phase = PH_NEXT;
+            }
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long need = __ballot(phase == PH_NEW);
+                if (need != 0ull) {
+                    if (q_next == q_end && !drained) {
+                        unsigned base = 0;
+                        if (lane == 0u) base = atomicAdd(queue_head, (unsigned)kQueueChunk);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        if (base >= total) { drained = true; }
+                        else { q_next = base; q_end = min(base + (unsigned)kQueueChunk, total); }
+                    }
+                    if (phase == PH_NEW) {
+                        const unsigned my = q_next + (unsigned)__popcll(need & ((1ull << lane) - 1ull));
+                        if (my < q_end) { walker_start(w, my, kp); phase = PH_NEXT; }
+                        else if (drained) { phase = PH_IDLE; }
+                        // else: stays PH_NEW and is served from the next chunk in the following round
+                    }
+                    q_next = min(q_next + (unsigned)__popcll(need), q_end);
+                }
+                if (phase == PH_NEXT) {
+                    if (walker_next_ray(w, kp, ray)) {
+                        trav_init(T, kp.max_trace_dist, nonempty);
+                        phase = nonempty ? PH_TRAV : PH_SHADE;   // empty scene: every trace misses
+                    } else {
+                        walker_finish(w, st);
+                        phase = PH_NEW;
+                    }
+                }
+            }
+        }
+
+        // ================= stage B: BVH traversal =================
+        if (__ballot(phase == PH_TRAV) != 0ull) {
+            while (true) {
+                if (phase == PH_TRAV) {
+                    trav_step<false>(sc, ray, T, stack);
+                    if (!trav_busy(T)) phase = PH_SHADE;
+                }
+                if (__ballot(phase == PH_TRAV) == 0ull) break;
+                if (__popcll(__ballot(phase == PH_NEW || phase == PH_SHADE)) >= thresh) break;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// connect_kernel: ConnectSubpaths + EvaluatePath + clamp/gain + deposit
 // ---------------------------------------------------------------------------------------------------
 template <int B>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
-                                                         float* __restrict__ energy) {
+                                                         float* __restrict__ energy, unsigned* queue_head) {
     __shared__ int s_stack[kStackDepth * kBlock];
     extern __shared__ __attribute__((aligned(16))) float s_hist[];  // [B][num_bins]
     __shared__ int s_lo, s_hi;
     const int nb = kp.num_bins;
     for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
     if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; }
+    // the walk kernel of this frame has drained its subpath queue: rearm it for the next frame
+    if (blockIdx.x == 0 && threadIdx.x == 0) *queue_head = 0u;
     __syncthreads();
 
     const uint32_t n = kp.num_local;
+    const uint32_t total = 2u * n;
     for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < n; li += gridDim.x * kBlock) {
-        const float4 F = st.pos_sd[li];
-        const float4 Fm = st.misc[li];
-        const float4 L = st.pos_sd[n + li];
-        const float4 Lm = st.misc[n + li];
+        const float4 F = st.end_pos[li];
+        const uint2 Fm = st.end_misc[li];
+        const float4 L = st.end_pos[n + li];
+        const uint2 Lm = st.end_misc[n + li];
         // visibility F_k -> B_m - 0.1 * unit(B_m - F_k) (ARTS.cpp:252-254); visible iff NO hit
         float dx = L.x - F.x, dy = L.y - F.y, dz = L.z - F.z;
         float l2 = dx * dx + dy * dy + dz * dz;
@@ -391,23 +521,35 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
             float tmax = len - kp.connect_pullback;
             if (tmax > 0.0f) {
                 Ray ray = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
-                HitRec h = traverse<true>(sc, ray, tmax, &s_stack[threadIdx.x]);
-                visible = h.leaf_index < 0;
+                Trav T;
+                trav_init(T, tmax, sc.num_nodes > 0);
+                trav_run<true>(sc, ray, T, &s_stack[threadIdx.x]);
+                visible = T.leaf_index < 0;
             }
         }
         if (!visible) continue;
-        // connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267): connection segment uses F_k's material/prob
+        // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
         float E[B];
 #pragma unroll
-        for (int b = 0; b < B; ++b) E[b] = st.energy[(size_t)b * 2u * n + li];
-        float dist = sqrtf(l2);
-        float nd = dist / kp.dist_divisor;
-        float sd = F.w;
-        sd += nd;
-        apply_segment<B>(E, nd, __float_as_uint(Fm.y), Fm.x, kp, sc);
-        // listener-side segments in path order B_m -> ... -> B_0 (reverse of the walk)
-        const int segs = __float_as_int(Lm.z);
-        for (int j = segs - 1; j >= 0; --j) sd += st.seg_nd[(size_t)j * n + li];
+        for (int b = 0; b < B; ++b) E[b] = 1.0f;
+        float sd = 0.0f;
+        const int kf = (int)Fm.y, kl = (int)Lm.y;
+        for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
+            const float2 np = st.seg_np[(size_t)j * total + li];
+            sd += np.x;                                               // ARTS.cpp:374
+            apply_segment<B>(E, np.x, st.seg_mat[(size_t)j * total + li], np.y, kp, sc);
+        }
+        {                                                             // connection segment: F_k's material/prob
+            float dist = sqrtf(l2);
+            float nd = dist / kp.dist_divisor;
+            sd += nd;
+            apply_segment<B>(E, nd, Fm.x, F.w, kp, sc);
+        }
+        for (int j = kl - 1; j >= 0; --j) {                           // listener-side segments B_j+1 -> B_j
+            const float2 np = st.seg_np[(size_t)j * total + n + li];
+            sd += np.x;
+            apply_segment<B>(E, np.x, st.seg_mat[(size_t)j * total + n + li], np.y, kp, sc);
+        }
         float delay = sd / kp.sound_speed;                            // ARTS.cpp:419
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
         float fl = floorf(x);
@@ -416,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         atomicMax(&s_hi, bin);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
-            float e = E[b] * st.energy[(size_t)b * 2u * n + n + li];
+            float e = E[b];
             e = (e < kp.energy_clamp) ? e : kp.energy_clamp;          // FMath::Min ARTS.cpp:410
             e *= kp.energy_gain;                                      // ARTS.cpp:413
             e *= kp.norm;                                             // ARTS.cpp:164-170
@@ -438,10 +580,11 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
 // reconstruct_kernel: ReconstructImpulseResponse (FSAC.cpp:320-380)
 //   rows 0..B-1 = bands, row B = band-mean energy -> the channel view (channels are identical,
 //   FSAC.cpp:331).  The one-pole filter y[i] = 0.25 x[i] + 0.75 y[i-1] (FSAC.cpp:366-375) is evaluated
-//   per 32-sample chunk after a 160-sample warm-up: 0.75^160 ~ 1e-20 is far below fp32 resolution.
+//   per kChunk-sample chunk after a kWarm-sample warm-up: 0.75^96 ~ 1e-12 is far below fp32 resolution.
+//   The interpolated sample x[i] is produced incrementally (bin / in-bin counters), no division by spb.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kChunk = 32;
-constexpr int kWarm = 160;
+constexpr int kChunk = 16;
+constexpr int kWarm = 96;
 
 __global__ __launch_bounds__(kBlock) void reconstruct_kernel(const float* __restrict__ energy, int B, int nb,
                                                              int num_samples, int spb, float* __restrict__ ir_bands,
@@ -466,29 +609,36 @@ __global__ __launch_bounds__(kBlock) void reconstruct_kernel(const float* __rest
     const int s0 = chunk * kChunk;
     if (s0 >= num_samples) return;
     float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
-    const float inv_spb = (float)spb;
-    auto sample = [&](int i) -> float {
-        int bin = i / spb;
-        if (bin >= nb) return 0.0f;
-        int bs = i - bin * spb;
-        float cur = s_amp[bin];
-        float prev = bin == 0 ? cur : s_amp[bin - 1];             // FSAC.cpp:347-355
-        float w = (float)bs / inv_spb;                            // FSAC.cpp:359
-        float a = (1.0f - w) * prev;
-        float b = w * cur;
-        return a + b;                                             // FSAC.cpp:360
-    };
-    int w0 = s0 - kWarm;
-    float y;
-    int i;
-    if (w0 <= 0) { y = sample(0); i = 1; if (s0 == 0) out[0] = y; }  // Filtered[0] = IR[0] FSAC.cpp:371
-    else { y = 0.0f; i = w0; }
     const int s1 = min(s0 + kChunk, num_samples);
-    for (; i < s1; ++i) {
-        float a = 0.25f * sample(i);
-        float b = (1.0f - 0.25f) * y;
-        y = a + b;                                                // FSAC.cpp:374
+    const int i0 = max(s0 - kWarm, 0);
+    int bin = i0 / spb;
+    int bs = i0 - bin * spb;
+    float cur = bin < nb ? s_amp[bin] : 0.0f;
+    float prev = bin == 0 ? cur : (bin - 1 < nb ? s_amp[bin - 1] : 0.0f);   // FSAC.cpp:347-355
+    const float fspb = (float)spb;
+    float y = 0.0f;
+    for (int i = i0; i < s1; ++i) {
+        float x = 0.0f;
+        if (bin < nb) {
+            float wgt = (float)bs / fspb;                           // FSAC.cpp:359
+            float a = (1.0f - wgt) * prev;
+            float b = wgt * cur;
+            x = a + b;                                              // FSAC.cpp:360
+        }
+        if (i == 0) {
+            y = x;                                                  // Filtered[0] = IR[0] FSAC.cpp:371
+        } else {
+            float a = 0.25f * x;
+            float b = (1.0f - 0.25f) * y;
+            y = a + b;                                              // FSAC.cpp:374
+        }
         if (i >= s0) out[i] = y;
+        if (++bs == spb) {
+            bs = 0;
+            ++bin;
+            prev = cur;
+            cur = bin < nb ? s_amp[bin] : 0.0f;
+        }
     }
 }
 
@@ -503,22 +653,21 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= N) return;
     Ray r = make_ray(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    Trav T;
+    trav_init(T, tmax[i], sc.num_nodes > 0);
     if (any_hit) {
-        HitRec h = traverse<true>(sc, r, tmax[i], &s_stack[threadIdx.x]);
-        hit[i] = h.leaf_index >= 0;
+        trav_run<true>(sc, r, T, &s_stack[threadIdx.x]);
+        hit[i] = T.leaf_index >= 0;
         return;
     }
-    HitRec h = traverse<false>(sc, r, tmax[i], &s_stack[threadIdx.x]);
-    hit[i] = h.leaf_index >= 0;
-    if (h.leaf_index >= 0) {
-        const float4* tris4 = reinterpret_cast<const float4*>(sc.tris);
-        const float4 A = tris4[3 * h.leaf_index + 0];
-        const float4 Bq = tris4[3 * h.leaf_index + 1];
-        const float4 Cq = tris4[3 * h.leaf_index + 2];
+    trav_run<false>(sc, r, T, &s_stack[threadIdx.x]);
+    hit[i] = T.leaf_index >= 0;
+    if (T.leaf_index >= 0) {
         float nx, ny, nz;
-        hit_normal(A, Bq, Cq, r, nx, ny, nz);
-        t[i] = h.t;
-        tri[i] = (int32_t)h.id;
+        uint32_t mat;
+        hit_surface(sc, T.leaf_index, r, nx, ny, nz, mat);
+        t[i] = T.t;
+        tri[i] = (int32_t)T.id;
         normal[3 * i] = nx; normal[3 * i + 1] = ny; normal[3 * i + 2] = nz;
     } else {
         t[i] = tmax[i];
@@ -536,48 +685,44 @@ __global__ void add_energy_kernel(float* row, int nb, float delay, float e) {
 }
 
 template <int B>
-void launch_walk_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, hipStream_t s) {
-    uint32_t lanes = 2u * kp.num_local;
-    if (lanes == 0) return;
-    dim3 grid((lanes + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(walk_kernel<B>, grid, dim3(kBlock), 0, s, sc, kp, st);
-}
-
-template <int B>
 void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                      hipStream_t s) {
+                      unsigned* queue_head, hipStream_t s) {
     if (kp.num_local == 0) return;
     uint32_t blocks = (kp.num_local + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;
     size_t lds = sizeof(float) * (size_t)B * (size_t)kp.num_bins;
-    hipLaunchKernelGGL(connect_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy);
+    hipLaunchKernelGGL(connect_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, queue_head);
 }
 
 }  // namespace
 
-#define FS_DISPATCH_B(B, CALL)            \
-    switch (B) {                          \
-        case 1: CALL(1); break;           \
-        case 2: CALL(2); break;           \
-        case 3: CALL(3); break;           \
-        case 4: CALL(4); break;           \
-        case 5: CALL(5); break;           \
-        case 6: CALL(6); break;           \
-        case 7: CALL(7); break;           \
-        default: CALL(8); break;          \
+void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
+                 hipStream_t s) {
+    uint32_t lanes = 2u * kp.num_local;
+    if (lanes == 0) return;
+    uint32_t full = (lanes + kBlock - 1) / kBlock;
+    if (wl.variant == 0) {
+        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st);
+        return;
     }
-
-void launch_walk(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, hipStream_t s) {
-#define CALL(N) launch_walk_t<N>(sc, kp, st, s)
-    FS_DISPATCH_B(B, CALL)
-#undef CALL
+    uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;
+    if (blocks > full) blocks = full;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head);
 }
 
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    hipStream_t s) {
-#define CALL(N) launch_connect_t<N>(sc, kp, st, energy, s)
-    FS_DISPATCH_B(B, CALL)
-#undef CALL
+                    unsigned* queue_head, hipStream_t s) {
+    switch (B) {
+        case 1: launch_connect_t<1>(sc, kp, st, energy, queue_head, s); break;
+        case 2: launch_connect_t<2>(sc, kp, st, energy, queue_head, s); break;
+        case 3: launch_connect_t<3>(sc, kp, st, energy, queue_head, s); break;
+        case 4: launch_connect_t<4>(sc, kp, st, energy, queue_head, s); break;
+        case 5: launch_connect_t<5>(sc, kp, st, energy, queue_head, s); break;
+        case 6: launch_connect_t<6>(sc, kp, st, energy, queue_head, s); break;
+        case 7: launch_connect_t<7>(sc, kp, st, energy, queue_head, s); break;
+        default: launch_connect_t<8>(sc, kp, st, energy, queue_head, s); break;
+    }
 }
 
 void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,
