@@ -92,6 +92,8 @@ class Stats(C.Structure):
         ("timed_reconstructs", C.c_uint64),
         ("bvh_nodes", C.c_uint32),
         ("triangles", C.c_uint32),
+        ("bvh_stack_need", C.c_uint32),
+        ("bvh_depth", C.c_uint32),
         ("scene_bytes", C.c_uint64),
     ]
 

@@ -1,19 +1,22 @@
-// fs_bvh.cpp — host-side BVH2 construction for the HIP traversal kernels.
+// fs_bvh.cpp — host-side acceleration-structure build for the HIP traversal kernels.
 //
-// Replaces the acceleration structure behind the engine call the reference delegates to
+// Replaces the structure behind the engine call the reference delegates to
 // (UWorld::LineTraceSingleByObjectType, call sites AudioRayTracingSubsystem.cpp:252-254, 340-342).
-// Top-down binned SAH over triangle centroids, <= 4 triangles per leaf, tree depth capped at
-// kStackDepth so the per-lane LDS stack of the kernels can never overflow.  Flattened breadth-first
-// into 64-byte nodes that carry both children's boxes (one fetch per traversal step); the top of the
-// tree is therefore a contiguous prefix of the node array (staged into LDS by the kernels).
 //
-// Boxes are padded far beyond the float error of the slab and triangle tests, so the closest hit
-// found through the BVH equals the brute-force closest hit: results do not depend on the tree.
+//   1. top-down binned SAH BVH2 over triangle centroids, <= 4 triangles per leaf;
+//   2. greedy collapse to a 4-wide tree (the child with the largest surface area is opened until the node
+//      has 4 children);
+//   3. flatten breadth-first into 64-byte nodes: child boxes quantised to 8 bits per plane on a
+//      per-node power-of-two grid (rounded outwards), so one node = 4 child boxes = 4 x 16-byte loads.
+//
+// Leaf boxes are padded far beyond the float error of the slab and triangle tests and quantisation only
+// grows boxes, so the closest hit found through the tree equals the brute-force closest hit: results do
+// not depend on the tree.  The builder bounds the traversal stack: the worst-case number of pending
+// entries along any root-to-leaf path must fit kStackDepth, otherwise the BVH2 is rebuilt shallower.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
-#include <queue>
 
 #include "fs_internal.hpp"
 
@@ -53,6 +56,7 @@ struct Builder {
     std::vector<int> order;      // permutation of triangle indices
     std::vector<BuildNode> nodes;
     int max_depth = 0;
+    int depth_cap = 48;
 
     static constexpr int kBins = 32;
     static constexpr int kLeaf = 4;
@@ -75,10 +79,10 @@ struct Builder {
         max_depth = std::max(max_depth, depth);
         if (count > kLeaf) {
             int mid = -1;
-            // levels still available below this node; a balanced split needs ceil(log2(count/4)) of them
+            // levels a balanced split still needs below this node
             int need = 0;
             for (int c = count; c > kLeaf; c = (c + 1) / 2) ++need;
-            bool force_median = depth + need + 1 >= kStackDepth;
+            bool force_median = depth + need + 1 >= depth_cap;
             if (!force_median) mid = sah_split(first, count, cb);
             if (mid < 0) mid = median_split(first, count, cb);
             int l = make(first, mid - first, depth + 1);
@@ -126,7 +130,6 @@ struct Builder {
         });
         int mid = (int)(it - order.begin());
         if (mid == first || mid == first + count) return -1;
-        // keep the tree shallow enough: reject hopelessly lopsided splits near the depth cap
         return mid;
     }
 
@@ -147,12 +150,72 @@ struct Builder {
 
 inline int32_t leaf_code(int first, int count) { return ~(int32_t)(first * 4 + (count - 1)); }
 
+// 4-wide node before quantisation: children are build-node indices
+struct Wide {
+    int src;            // build node this wide node spans
+    int child[4];
+    int n;
+};
+
+void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wide, std::vector<int>& wide_of) {
+    // breadth-first so the top of the tree is a contiguous prefix of the node array
+    wide.clear();
+    wide_of.assign(bn.size(), -1);
+    std::vector<int> queue;
+    queue.push_back(root);
+    wide_of[root] = 0;
+    for (size_t h = 0; h < queue.size(); ++h) {
+        const BuildNode& n = bn[queue[h]];
+        Wide w;
+        w.src = queue[h];
+        w.n = 0;
+        if (n.left < 0) {           // a leaf root: one child
+            w.child[w.n++] = queue[h];
+        } else {
+            w.child[w.n++] = n.left;
+            w.child[w.n++] = n.right;
+            while (w.n < 4) {       // open the inner child with the largest surface area
+                int best = -1;
+                float ba = -1.f;
+                for (int i = 0; i < w.n; ++i) {
+                    const BuildNode& c = bn[w.child[i]];
+                    if (c.left >= 0 && c.box.half_area() > ba) { ba = c.box.half_area(); best = i; }
+                }
+                if (best < 0) break;
+                const BuildNode& c = bn[w.child[best]];
+                w.child[best] = c.left;
+                w.child[w.n++] = c.right;
+            }
+        }
+        for (int i = 0; i < w.n; ++i) {
+            int c = w.child[i];
+            if (bn[c].left >= 0) { wide_of[c] = (int)queue.size(); queue.push_back(c); }
+        }
+        wide.push_back(w);
+    }
+}
+
+// worst-case pending stack entries along any root-to-leaf path (every child hit at every level)
+int stack_need(const std::vector<BuildNode>& bn, const std::vector<Wide>& wide, const std::vector<int>& wide_of) {
+    std::vector<int> need(wide.size(), 0);
+    int worst = 0;
+    for (size_t i = 0; i < wide.size(); ++i) {   // BFS order: parents before children
+        const Wide& w = wide[i];
+        int here = need[i] + (w.n - 1);
+        worst = std::max(worst, here);
+        for (int c = 0; c < w.n; ++c)
+            if (bn[w.child[c]].left >= 0) need[wide_of[w.child[c]]] = here;
+    }
+    return worst;
+}
+
 }  // namespace
 
 void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out) {
     out.nodes.clear();
     out.tris.clear();
     out.max_depth = 0;
+    out.stack_need = 0;
     if (T <= 0) return;
 
     Builder b;
@@ -171,13 +234,24 @@ void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out) {
             }
         b.pbox[t] = bx;
         for (int k = 0; k < 3; ++k) b.cen[3 * t + k] = 0.5f * (bx.lo[k] + bx.hi[k]);
-        b.order[t] = t;
     }
     // conservative padding (cm): >> float error of the tests at this coordinate magnitude
     const float pad = std::max(0.01f, amax * 3.8146973e-06f);
 
-    b.nodes.reserve(2 * (size_t)T / 3 + 16);
-    int root = b.make(0, T, 0);
+    std::vector<Wide> wide;
+    std::vector<int> wide_of;
+    int root = 0;
+    for (int cap = 48; cap >= 8; cap -= 4) {   // rebuild shallower until the traversal stack bound holds
+        b.depth_cap = cap;
+        b.nodes.clear();
+        b.nodes.reserve(2 * (size_t)T / 3 + 16);
+        b.max_depth = 0;
+        for (int t = 0; t < T; ++t) b.order[t] = t;
+        root = b.make(0, T, 0);
+        collapse(b.nodes, root, wide, wide_of);
+        out.stack_need = stack_need(b.nodes, wide, wide_of);
+        if (out.stack_need <= kStackDepth) break;
+    }
     out.max_depth = b.max_depth;
 
     // triangles in leaf order
@@ -207,51 +281,51 @@ void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out) {
         out.tris[i] = r;
     }
 
-    // flatten inner nodes breadth-first; a leaf root becomes an inner node with one empty child
-    auto child_box = [&](const BuildNode& n, float lo[3], float hi[3]) {
-        for (int k = 0; k < 3; ++k) { lo[k] = n.box.lo[k] - pad; hi[k] = n.box.hi[k] + pad; }
-    };
-    const float inf = std::numeric_limits<float>::infinity();
-    std::vector<int> flat_of(b.nodes.size(), -1);
-    std::vector<int> bfs;
-    if (b.nodes[root].left < 0) {
-        Node64 n{};
-        float lo[3], hi[3];
-        child_box(b.nodes[root], lo, hi);
-        // empty second child: a degenerate far-away box no ray segment can reach (an inverted infinite
-        // box would pass the slab test: min/max of +-inf)
-        const float far = 3.0e38f;
-        (void)inf;
-        n.q0 = make_float4(lo[0], lo[1], lo[2], hi[0]);
-        n.q1 = make_float4(hi[1], hi[2], far, far);
-        n.q2 = make_float4(far, far, far, far);
-        n.c0 = leaf_code(b.nodes[root].first, b.nodes[root].count);
-        n.c1 = -1;
-        out.nodes.push_back(n);
-        return;
-    }
-    bfs.push_back(root);
-    flat_of[root] = 0;
-    for (size_t h = 0; h < bfs.size(); ++h) {
-        const BuildNode& n = b.nodes[bfs[h]];
-        for (int c : {n.left, n.right})
-            if (b.nodes[c].left >= 0) { flat_of[c] = (int)bfs.size(); bfs.push_back(c); }
-    }
-    out.nodes.resize(bfs.size());
-    for (size_t h = 0; h < bfs.size(); ++h) {
-        const BuildNode& n = b.nodes[bfs[h]];
-        const BuildNode& l = b.nodes[n.left];
-        const BuildNode& r = b.nodes[n.right];
-        float l0[3], h0[3], l1[3], h1[3];
-        child_box(l, l0, h0);
-        child_box(r, l1, h1);
-        Node64 o{};
-        o.q0 = make_float4(l0[0], l0[1], l0[2], h0[0]);
-        o.q1 = make_float4(h0[1], h0[2], l1[0], l1[1]);
-        o.q2 = make_float4(l1[2], h1[0], h1[1], h1[2]);
-        o.c0 = l.left >= 0 ? flat_of[n.left] : leaf_code(l.first, l.count);
-        o.c1 = r.left >= 0 ? flat_of[n.right] : leaf_code(r.first, r.count);
-        out.nodes[h] = o;
+    // quantise + flatten
+    out.nodes.resize(wide.size());
+    for (size_t i = 0; i < wide.size(); ++i) {
+        const Wide& w = wide[i];
+        Box nb; nb.reset();
+        for (int c = 0; c < w.n; ++c) nb.grow(b.nodes[w.child[c]].box);
+        NodeQ4 q{};
+        double origin[3], scale[3];
+        uint32_t exps = 0;
+        for (int k = 0; k < 3; ++k) {
+            origin[k] = (double)(nb.lo[k] - pad);
+            double ext = (double)(nb.hi[k] + pad) - origin[k];
+            int e = (int)std::ceil(std::log2(std::max(ext, 1e-30) / 255.0));
+            e = std::max(-100, std::min(100, e));
+            while (std::ldexp(255.0, e) < ext) ++e;     // guard the log2 rounding
+            scale[k] = std::ldexp(1.0, e);
+            exps |= (uint32_t)(e + 127) << (8 * k);
+        }
+        q.ox = (float)origin[0]; q.oy = (float)origin[1]; q.oz = (float)origin[2];
+        // the float origin may round up by half an ulp; the >= 0.01 cm padding dwarfs it
+        q.exps = exps;
+        uint32_t lo4[3] = {0, 0, 0}, hi4[3] = {0, 0, 0};
+        for (int c = 0; c < 4; ++c) {
+            for (int k = 0; k < 3; ++k) {
+                uint32_t ql = 255, qh = 0;   // empty slot: lo > hi on every axis -> can never be hit
+                if (c < w.n) {
+                    const Box& cbx = b.nodes[w.child[c]].box;
+                    double l = ((double)(cbx.lo[k] - pad) - (double)(float)origin[k]) / scale[k];
+                    double h = ((double)(cbx.hi[k] + pad) - (double)(float)origin[k]) / scale[k];
+                    ql = (uint32_t)std::max(0.0, std::min(255.0, std::floor(l)));
+                    qh = (uint32_t)std::max(0.0, std::min(255.0, std::ceil(h)));
+                }
+                lo4[k] |= ql << (8 * c);
+                hi4[k] |= qh << (8 * c);
+            }
+            if (c < w.n) {
+                const BuildNode& cn = b.nodes[w.child[c]];
+                q.child[c] = cn.left >= 0 ? wide_of[w.child[c]] : leaf_code(cn.first, cn.count);
+            } else {
+                q.child[c] = -1;
+            }
+        }
+        q.lox = lo4[0]; q.loy = lo4[1]; q.loz = lo4[2];
+        q.hix = hi4[0]; q.hiy = hi4[1]; q.hiz = hi4[2];
+        out.nodes[i] = q;
     }
 }
 

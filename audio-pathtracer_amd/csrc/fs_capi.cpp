@@ -55,7 +55,7 @@ struct fs_context {
     std::vector<float> h_absorption, h_transmission, h_scattering;
     int32_t T = 0, M = 0;
     bool committed = false;
-    Node64* d_nodes = nullptr;
+    NodeQ4* d_nodes = nullptr;
     Tri64* d_tris = nullptr;
     float* d_absorption = nullptr;
     DeviceScene scene{};
@@ -69,7 +69,7 @@ struct fs_context {
     size_t cap_lanes = 0, cap_seg = 0;
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
-    WalkLaunch walk{1, 256, 2, nullptr};
+    WalkLaunch walk{0, 256, 2, nullptr, 1, nullptr, nullptr};
     int refill_threshold = 16;
 
     // measurement
@@ -131,6 +131,9 @@ void free_state(fs_context* ctx) {
     if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
     if (ctx->st.seg_np) (void)hipFree(ctx->st.seg_np);
     if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
+    if (ctx->walk.len) (void)hipFree(ctx->walk.len);
+    if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
+    ctx->walk.len = nullptr; ctx->walk.perm = nullptr;
     ctx->st = SubpathState{};
     ctx->cap_lanes = ctx->cap_seg = 0;
 }
@@ -186,10 +189,15 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int depth) {
     if (lanes > ctx->cap_lanes) {
         if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
         if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
+        if (ctx->walk.len) (void)hipFree(ctx->walk.len);
+        if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
         ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr;
+        ctx->walk.len = nullptr; ctx->walk.perm = nullptr;
         ctx->cap_lanes = 0;
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * lanes));
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.len, lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * lanes));
         ctx->cap_lanes = lanes;
     }
     if (seg > ctx->cap_seg) {
@@ -301,8 +309,9 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
     if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
-    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned));
+    if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchWords);
+    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchWords);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
     ctx->device_ok = true;
     return FS_OK;
@@ -366,8 +375,8 @@ int fs_scene_commit(fs_context* ctx) {
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(), ctx->T, ctx->bvh);
-    if (ctx->bvh.max_depth >= kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH deeper than the traversal stack");
-    size_t nb = ctx->bvh.nodes.size() * sizeof(Node64), tb = ctx->bvh.tris.size() * sizeof(Tri64);
+    if (ctx->bvh.stack_need > kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH needs a deeper traversal stack");
+    size_t nb = ctx->bvh.nodes.size() * sizeof(NodeQ4), tb = ctx->bvh.tris.size() * sizeof(Tri64);
     size_t mb = ctx->h_absorption.size() * sizeof(float);
     if (nb) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, nb));
@@ -389,6 +398,8 @@ int fs_scene_commit(fs_context* ctx) {
     ctx->scene.num_materials = ctx->M;
     ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
     ctx->stats.triangles = (uint32_t)ctx->T;
+    ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;
+    ctx->stats.bvh_depth = (uint32_t)ctx->bvh.max_depth;
     ctx->stats.scene_bytes = nb + tb + mb;
     ctx->committed = true;
     return FS_OK;
@@ -768,6 +779,8 @@ int fs_reset_stats(fs_context* ctx) {
     ctx->stats = fs_stats{};
     ctx->stats.bvh_nodes = keep.bvh_nodes;
     ctx->stats.triangles = keep.triangles;
+    ctx->stats.bvh_stack_need = keep.bvh_stack_need;
+    ctx->stats.bvh_depth = keep.bvh_depth;
     ctx->stats.scene_bytes = keep.scene_bytes;
     return FS_OK;
 }

@@ -13,16 +13,21 @@
 namespace fs {
 
 // ---- device data layout (HBM) --------------------------------------------------------------------
-// BVH2 node, 64 B = half a 128-B cache line, holds BOTH children's boxes so one fetch decides both:
-//   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)  q2 = (lo1.z hi1.x hi1.y hi1.z)
-//   q3 = (child0, child1, -, -) as int bits; child >= 0: inner node index; child < 0: leaf,
-//   ~child = first_tri * 4 + (count - 1), count in 1..4; empty child: box lo=+inf hi=-inf, child = -1.
-struct alignas(16) Node64 {
-    float4 q0, q1, q2;
-    int32_t c0, c1;
-    uint32_t pad0, pad1;
+// 4-wide BVH node, 64 B = half a 128-B cache line = four 16-byte loads:
+//   q0 = (origin.x origin.y origin.z, exps)   exps: byte k = biased exponent of the power-of-two grid step
+//                                             of axis k (step = 2^(byte-127))
+//   q1 = (lox4 loy4 loz4 hix4)  q2 = (hiy4 hiz4 - -)   byte c of each word = child c's plane on that
+//                                             grid: box = origin + q * step, rounded outwards
+//   q3 = child[4] as int bits; child >= 0: inner node index; child < 0: leaf,
+//        ~child = first_tri * 4 + (count - 1), count in 1..4; empty slot: lo = 255 > hi = 0 (never hit).
+struct alignas(16) NodeQ4 {
+    float ox, oy, oz;
+    uint32_t exps;
+    uint32_t lox, loy, loz, hix;
+    uint32_t hiy, hiz, pad0, pad1;
+    int32_t child[4];
 };
-static_assert(sizeof(Node64) == 64, "Node64 must be 64 B");
+static_assert(sizeof(NodeQ4) == 64, "NodeQ4 must be 64 B");
 
 // Triangle record, 64 B (same size as a node, so traversal fetches either through one load sequence),
 // stored in leaf order:
@@ -37,7 +42,7 @@ constexpr int kStackDepth = 32;   // per-lane traversal stack entries (LDS); the
 constexpr int kBlock = 256;       // 4 waves of 64 lanes
 
 struct DeviceScene {
-    const Node64* nodes;
+    const NodeQ4* nodes;
     const Tri64* tris;
     const float* absorption;  // [M][B]
     int32_t num_nodes;        // 0 = empty scene
@@ -75,11 +80,12 @@ struct SubpathState {
 
 // ---- host BVH builder ------------------------------------------------------------------------------
 struct HostBVH {
-    std::vector<Node64> nodes;
+    std::vector<NodeQ4> nodes;
     std::vector<Tri64> tris;   // leaf order
-    int max_depth = 0;
+    int max_depth = 0;         // of the binary tree before the 4-wide collapse
+    int stack_need = 0;        // worst-case pending traversal-stack entries (<= kStackDepth by construction)
 };
-// xyz [T][3][3], mat [T]; binned SAH, <= 4 triangles per leaf, boxes padded conservatively.
+// xyz [T][3][3], mat [T]; binned SAH BVH2 collapsed to a quantised 4-wide tree, <= 4 triangles per leaf.
 void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out);
 
 // ---- kernel launchers (fs_kernels.hip) -----------------------------------------------------------------
@@ -87,8 +93,12 @@ struct WalkLaunch {
     int variant;         // 0 = one subpath per lane, 1 = persistent waves + dynamic fetch
     int num_cus;         // compute units of the device
     int blocks_per_cu;   // persistent grid = num_cus * blocks_per_cu workgroups (capped by the work)
-    unsigned* queue_head;  // device counter, zero at launch
+    unsigned* queue_head;  // frame scratch: [0] subpath queue head, then plan counts + cursors; zero at launch
+    int plan;            // 1 = sort subpaths by their (RNG-determined) length before walking
+    uint8_t* len;        // [total] planned length per subpath
+    uint32_t* perm;      // [total] subpath indices by descending length
 };
+constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  hipStream_t s);
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,

@@ -235,19 +235,53 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         }
         ++T.tri_i;
     } else {
-        bool h0, h1;
-        const float t0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, r, T.t, h0);
-        const float t1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, r, T.t, h1);
-        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-        if (h0 && h1) {
-            const bool sw = t1 < t0;
-            stack[T.sp * kBlock] = sw ? c0 : c1;  // far child waits
-            ++T.sp;
-            T.cur = sw ? c1 : c0;
-        } else if (h0) {
-            T.cur = c0;
-        } else if (h1) {
-            T.cur = c1;
+        // ---- 4-wide node, child boxes on the node's 8-bit grid: plane distance = fma(q, step*inv, (origin-o)*inv)
+        const uint32_t exps = __float_as_uint(q0.w);
+        const float sx = __uint_as_float((exps & 0xFFu) << 23) * r.ix;
+        const float sy = __uint_as_float(((exps >> 8) & 0xFFu) << 23) * r.iy;
+        const float sz = __uint_as_float(((exps >> 16) & 0xFFu) << 23) * r.iz;
+        const float bx = fmaf(q0.x, r.ix, r.nox);
+        const float by = fmaf(q0.y, r.iy, r.noy);
+        const float bz = fmaf(q0.z, r.iz, r.noz);
+        const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+        const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+        // the ray's direction signs pick the entry / exit plane words once per node
+        const uint32_t nxw = r.ix < 0.0f ? hix : lox, fxw = r.ix < 0.0f ? lox : hix;
+        const uint32_t nyw = r.iy < 0.0f ? hiy : loy, fyw = r.iy < 0.0f ? loy : hiy;
+        const uint32_t nzw = r.iz < 0.0f ? hiz : loz, fzw = r.iz < 0.0f ? loz : hiz;
+        uint32_t key[4];
+        int hits = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float tnx = fmaf((float)((nxw >> (8 * c)) & 0xFFu), sx, bx);
+            const float tny = fmaf((float)((nyw >> (8 * c)) & 0xFFu), sy, by);
+            const float tnz = fmaf((float)((nzw >> (8 * c)) & 0xFFu), sz, bz);
+            const float tfx = fmaf((float)((fxw >> (8 * c)) & 0xFFu), sx, bx);
+            const float tfy = fmaf((float)((fyw >> (8 * c)) & 0xFFu), sy, by);
+            const float tfz = fmaf((float)((fzw >> (8 * c)) & 0xFFu), sz, bz);
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, T.t));
+            const bool h = tn <= tf;
+            hits += h ? 1 : 0;
+            // entry distance (>= 0, so its bits order like an integer) with the slot in the low 2 bits
+            key[c] = h ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : (0xFFFFFFFCu | (uint32_t)c);
+        }
+        // sort the 4 keys (5-comparator network): nearest first
+#define FS_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+        FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
+#undef FS_CSWAP
+        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(q3.z),
+                  c3 = __float_as_int(q3.w);
+        auto ref = [&](uint32_t k) -> int {
+            const uint32_t s = k & 3u;
+            return s == 0u ? c0 : (s == 1u ? c1 : (s == 2u ? c2 : c3));
+        };
+        // far children wait on the stack, farthest pushed first
+        if (hits >= 4) { stack[T.sp * kBlock] = ref(key[3]); ++T.sp; }
+        if (hits >= 3) { stack[T.sp * kBlock] = ref(key[2]); ++T.sp; }
+        if (hits >= 2) { stack[T.sp * kBlock] = ref(key[1]); ++T.sp; }
+        if (hits >= 1) {
+            T.cur = ref(key[0]);
         } else if (T.sp > 0) {
             --T.sp;
             T.cur = stack[T.sp * kBlock];
@@ -379,12 +413,80 @@ __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathStat
 }
 
 // ---------------------------------------------------------------------------------------------------
+// plan kernels: the number of segments a subpath takes under Russian roulette depends only on the RNG
+// stream (seed, pair, side, bounce) — never on the geometry — so it is known before any ray is traced.
+// plan_count computes every subpath's length and a global length histogram; plan_scatter counting-sorts
+// the subpath indices by DESCENDING length into `perm`.  Walk waves then hold subpaths of equal length:
+// no lane idles because its neighbours' walks ended earlier.  (Order never affects results.)
+//   scratch[0] = subpath queue head (persistent walk), [1, 1+kPlanBuckets) = counts, then cursors.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPlanBuckets = FS_MAX_DEPTH + 1;
+
+__device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
+    const uint32_t n = kp.num_local;
+    const uint32_t side = g >= n ? 1u : 0u;
+    const uint32_t pair = kp.pair_begin + (g - side * n);
+    int k = 0;
+    for (; k < kp.depth; ++k) {
+        const uint4 r = philox(pair, ((uint32_t)k << 1) | side, 0, kp.seed_lo, kp.seed_hi);
+        if (!(u01(r.x) < kp.rr_prob)) break;   // ARTS.cpp:300-301
+    }
+    return k;
+}
+
+__global__ __launch_bounds__(kBlock) void plan_count_kernel(KParams kp, uint8_t* __restrict__ len,
+                                                            unsigned* __restrict__ scratch) {
+    __shared__ unsigned s_hist[kPlanBuckets];
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) s_hist[i] = 0u;
+    __syncthreads();
+    const uint32_t total = 2u * kp.num_local;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g < total) {
+        const int L = planned_length(g, kp);
+        len[g] = (uint8_t)L;
+        atomicAdd(&s_hist[L], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
+        if (s_hist[i]) atomicAdd(&scratch[1 + i], s_hist[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void plan_scatter_kernel(KParams kp, const uint8_t* __restrict__ len,
+                                                              unsigned* __restrict__ scratch,
+                                                              uint32_t* __restrict__ perm) {
+    __shared__ unsigned s_hist[kPlanBuckets];
+    __shared__ unsigned s_base[kPlanBuckets];
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) s_hist[i] = 0u;
+    __syncthreads();
+    const uint32_t total = 2u * kp.num_local;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    int L = 0;
+    unsigned rank = 0;
+    if (g < total) {
+        L = len[g];
+        rank = atomicAdd(&s_hist[L], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) {
+        if (s_hist[i]) {
+            unsigned start = 0;                      // buckets in descending length order
+            for (int j = kPlanBuckets - 1; j > i; --j) start += scratch[1 + j];
+            s_base[i] = start + atomicAdd(&scratch[1 + kPlanBuckets + i], s_hist[i]);
+        }
+    }
+    __syncthreads();
+    if (g < total) perm[s_base[L] + rank] = g;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // walk_kernel_simple: one subpath per lane (reference variant)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st) {
+__global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const uint32_t* __restrict__ perm) {
     __shared__ int s_stack[kStackDepth * kBlock];
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    if (g >= 2u * kp.num_local) return;
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= 2u * kp.num_local) return;
+    const uint32_t g = perm ? perm[slot] : slot;   // length-sorted schedule (plan kernels) or identity
     int* stack = &s_stack[threadIdx.x];
     Walker w;
     walker_start(w, g, kp);
@@ -415,7 +517,8 @@ enum : int { PH_NEW = 0, PH_TRAV = 1, PH_SHADE = 2, PH_IDLE = 3, PH_NEXT = 4 };
 constexpr int kQueueChunk = 64;
 
 __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc, KParams kp, SubpathState st,
-                                                                 unsigned* __restrict__ queue_head) {
+                                                                 unsigned* __restrict__ queue_head,
+                                                                 const uint32_t* __restrict__ perm) {
     __shared__ int s_stack[kStackDepth * kBlock];
     int* stack = &s_stack[threadIdx.x];
     const unsigned lane = threadIdx.x & 63u;
@@ -456,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
                     }
                     if (phase == PH_NEW) {
                         const unsigned my = q_next + (unsigned)__popcll(need & ((1ull << lane) - 1ull));
-                        if (my < q_end) { walker_start(w, my, kp); phase = PH_NEXT; }
+                        if (my < q_end) { walker_start(w, perm ? perm[my] : my, kp); phase = PH_NEXT; }
                         else if (drained) { phase = PH_IDLE; }
                         // else: stays PH_NEW and is served from the next chunk in the following round
                     }
@@ -500,8 +603,9 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     const int nb = kp.num_bins;
     for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
     if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; }
-    // the walk kernel of this frame has drained its subpath queue: rearm it for the next frame
-    if (blockIdx.x == 0 && threadIdx.x == 0) *queue_head = 0u;
+    // this frame's walk is over: rearm the frame scratch (queue head, plan counts and cursors) for the next one
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
     __syncthreads();
 
     const uint32_t n = kp.num_local;
@@ -701,14 +805,21 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
+    // length-sorted schedule: only meaningful when roulette can end walks early
+    const uint32_t* perm = nullptr;
+    if (wl.plan && kp.russian_roulette && kp.depth > 1 && wl.len && wl.perm) {
+        hipLaunchKernelGGL(plan_count_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head);
+        hipLaunchKernelGGL(plan_scatter_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head, wl.perm);
+        perm = wl.perm;
+    }
     if (wl.variant == 0) {
-        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st);
+        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st, perm);
         return;
     }
     uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;
     if (blocks > full) blocks = full;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head);
+    hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
 }
 
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,

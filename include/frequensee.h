@@ -103,6 +103,8 @@ typedef struct fs_stats {
     uint64_t timed_reconstructs;  /* reconstructs contributing to reconstruct_ms_sum */
     uint32_t bvh_nodes;
     uint32_t triangles;
+    uint32_t bvh_stack_need;     /* worst-case traversal stack entries of the committed tree */
+    uint32_t bvh_depth;          /* depth of the binary tree before the 4-wide collapse */
     uint64_t scene_bytes;        /* device bytes of BVH + triangles + materials */
 } fs_stats;
 
