@@ -38,7 +38,34 @@ EXPORTS = [
     "fs_copy_impulse_response", "fs_copy_band_impulse_response", "fs_get_energy_buffer", "fs_flush_energy_buffer",
     "fs_add_energy_at_delay", "fs_update_energy_buffer", "fs_num_bins", "fs_num_samples", "fs_trace_rays",
     "fs_set_profiling", "fs_get_stats", "fs_reset_stats",
+    "fs_sound_params_default", "fs_scene_set_objects", "fs_update_sound", "fs_get_occlusion_attenuation",
 ]
+
+
+class SoundParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("raycasts_per_tick", C.c_int32),
+        ("seed", C.c_uint64),
+        ("raycast_bounces", C.c_int32),
+        ("raycast_distance", C.c_float),
+        ("simulated_duration", C.c_float),
+        ("listener_radius", C.c_float),
+    ]
+
+
+class SoundResult(C.Structure):
+    _fields_ = [
+        ("total_energy", C.c_float),
+        ("occlusion_attenuation", C.c_float),
+        ("direct_energy_sum", C.c_float),
+        ("rays_reaching_listener", C.c_uint32),
+        ("direct_hits", C.c_uint32),
+        ("traces", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class Config(C.Structure):
@@ -154,6 +181,10 @@ def load():
         "fs_set_profiling": (C.c_int, [vp, i32]),
         "fs_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
         "fs_reset_stats": (C.c_int, [vp]),
+        "fs_sound_params_default": (None, [C.POINTER(SoundParams)]),
+        "fs_scene_set_objects": (C.c_int, [vp, vp, i32]),
+        "fs_update_sound": (C.c_int, [vp, i32, C.POINTER(SoundParams), C.POINTER(SoundResult)]),
+        "fs_get_occlusion_attenuation": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -169,6 +200,14 @@ def default_config(**kw) -> Config:
     for k, v in kw.items():
         setattr(c, k, v)
     return c
+
+
+def default_sound_params(**kw) -> SoundParams:
+    p = SoundParams()
+    load().fs_sound_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
 
 
 def default_params(**kw) -> Params:

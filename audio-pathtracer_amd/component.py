@@ -58,7 +58,7 @@ class Context:
             pass
 
     # ---- scene ----
-    def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None):
+    def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None, object_ids=None):
         tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
         mat = np.ascontiguousarray(material_ids, dtype=np.uint16).reshape(-1)
         if mat.shape[0] != tri.shape[0]:
@@ -74,6 +74,11 @@ class Context:
                                                    opt[0].ctypes.data if opt[0] is not None else None,
                                                    opt[1].ctypes.data if opt[1] is not None else None,
                                                    ab.shape[0], ab.shape[1]))
+        if object_ids is not None:   # actor per triangle (legacy tracer's AddIgnoredActor / pass-through logic)
+            obj = np.ascontiguousarray(object_ids, dtype=np.uint32).reshape(-1)
+            self.check(self.lib.fs_scene_set_objects(self.h, obj.ctypes.data, obj.shape[0]))
+        else:
+            self.check(self.lib.fs_scene_set_objects(self.h, None, tri.shape[0]))
         self.check(self.lib.fs_scene_commit(self.h))
 
     def set_listener(self, xyz):
@@ -150,6 +155,17 @@ class Context:
         self.check(self.lib.fs_trace_rays(self.h, o.ctypes.data, d.ctypes.data, tm.ctypes.data, n, int(any_hit),
                                           hit.ctypes.data, t.ctypes.data, tri.ctypes.data, nrm.ctypes.data))
         return hit.astype(bool), t, tri, nrm
+
+    def update_sound(self, src, params=None):
+        """legacy forward tracer UpdateSound (FSAC.cpp:283-306); returns the fs_sound_result fields"""
+        r = _capi.SoundResult()
+        self.check(self.lib.fs_update_sound(self.h, src, C.byref(params) if params is not None else None, C.byref(r)))
+        return r.as_dict()
+
+    def occlusion_attenuation(self, src):
+        v = C.c_float()
+        self.check(self.lib.fs_get_occlusion_attenuation(self.h, src, C.byref(v)))
+        return float(v.value)
 
     def set_profiling(self, on=True):
         self.check(self.lib.fs_set_profiling(self.h, int(on)))
@@ -230,6 +246,21 @@ class FrequenSeeAudioComponent:
     def GetBandImpulseResponse(self, band):
         return self._ctx().band_impulse_response(self._src, band)
 
+    # legacy per-frame forward tracer (TickComponent -> UpdateSound, FSAC.cpp:103-109, 283-306)
+    RaycastsPerTick = 1500      # FSAC.h:39
+    RaycastBounces = 10         # FSAC.h:42
+    RaycastDistance = 5000.0    # FSAC.h:45
+
+    def UpdateSound(self, seed=0x5EED, listener_radius=34.0):
+        self._subsys._commit()
+        p = _capi.default_sound_params(raycasts_per_tick=self.RaycastsPerTick, raycast_bounces=self.RaycastBounces,
+                                       raycast_distance=self.RaycastDistance, seed=seed,
+                                       listener_radius=listener_radius)
+        return self._ctx().update_sound(self._src, p)
+
+    def GetOcclusionAttenuation(self):  # FSAC.h:112
+        return self._ctx().occlusion_attenuation(self._src)
+
 
 class AudioRayTracingSubsystem:
     """UAudioRayTracingSubsystem's registries and per-source update (ARTS.h:86-196, ARTS.cpp:45-195)."""
@@ -239,7 +270,8 @@ class AudioRayTracingSubsystem:
     def __init__(self, num_bands=1, device=0, rank=0, world_size=1, stream=None):
         self.ctx = Context(num_bands=num_bands, device=device, rank=rank, world_size=world_size, stream=stream)
         self.ActiveSources = []
-        self._geom = []          # registered (triangles, material_ids)
+        self._geom = []          # registered (triangles, material_ids, actor ids)
+        self._next_actor = 0
         self._materials = None
         self._dirty = True
         self.params = _capi.default_params()
@@ -248,9 +280,16 @@ class AudioRayTracingSubsystem:
         self.ctx.close()
 
     # RegisterGeometry / UnregisterGeometry (ARTS.h:99-100): a "component" is a triangle set + material ids
-    def RegisterGeometry(self, triangles, material_ids):
-        comp = (np.asarray(triangles, dtype=np.float32).reshape(-1, 3, 3),
-                np.asarray(material_ids, dtype=np.uint16).reshape(-1))
+    def RegisterGeometry(self, triangles, material_ids, object_ids=None):
+        """one UAcousticGeometryComponent = one actor, unless per-triangle actor ids are given"""
+        tri = np.asarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
+        if object_ids is None:
+            obj = np.full(tri.shape[0], self._next_actor, dtype=np.uint32)
+            self._next_actor += 1
+        else:
+            obj = np.asarray(object_ids, dtype=np.uint32).reshape(-1)
+            self._next_actor = max(self._next_actor, int(obj.max(initial=0)) + 1)
+        comp = (tri, np.asarray(material_ids, dtype=np.uint16).reshape(-1), obj)
         self._geom.append(comp)
         self._dirty = True
         return comp
@@ -269,11 +308,12 @@ class AudioRayTracingSubsystem:
         if self._geom:
             tri = np.concatenate([g[0] for g in self._geom], axis=0)
             mat = np.concatenate([g[1] for g in self._geom], axis=0)
+            obj = np.concatenate([g[2] for g in self._geom], axis=0)
         else:
-            tri, mat = np.zeros((0, 3, 3), np.float32), np.zeros((0,), np.uint16)
+            tri, mat, obj = np.zeros((0, 3, 3), np.float32), np.zeros((0,), np.uint16), None
         ab, tr, sc = self._materials if self._materials is not None else (
             np.zeros((0, self.ctx.num_bands), np.float32), None, None)
-        self.ctx.set_scene(tri, mat, ab, tr, sc)
+        self.ctx.set_scene(tri, mat, ab, tr, sc, object_ids=obj)
         self._dirty = False
 
     def RegisterSource(self, InComp: FrequenSeeAudioComponent):  # ARTS.cpp:45-48

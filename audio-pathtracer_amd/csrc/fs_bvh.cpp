@@ -211,7 +211,7 @@ int stack_need(const std::vector<BuildNode>& bn, const std::vector<Wide>& wide, 
 
 }  // namespace
 
-void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out) {
+void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out) {
     out.nodes.clear();
     out.tris.clear();
     out.max_depth = 0;
@@ -265,11 +265,13 @@ void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out) {
         r.a = make_float4(p[0], p[1], p[2], e1x);
         r.b = make_float4(e1y, e1z, e2x, e2y);
         uint32_t m = mat ? (uint32_t)mat[t] : (uint32_t)FS_NO_MATERIAL;
-        float mf, idf;
+        float mf, idf, of;
         uint32_t id = (uint32_t)t;
+        uint32_t obj = object_id ? object_id[t] : (uint32_t)t;   // default: every triangle its own actor
         std::memcpy(&mf, &m, 4);
         std::memcpy(&idf, &id, 4);
-        r.c = make_float4(e2z, mf, idf, 0.f);
+        std::memcpy(&of, &obj, 4);
+        r.c = make_float4(e2z, mf, idf, of);
         // unit geometric normal, fixed operation order (part of the hit-normal spec; built with
         // -ffp-contract=off, so this is the same fp32 sequence the oracle evaluates at hit time)
         float nx = std::fmaf(e1y, e2z, -(e1z * e2y));

@@ -32,6 +32,7 @@ struct Source {
     uint64_t seq_of[kIrRing] = {0, 0, 0};
     uint64_t enqueued = 0;             // publishes enqueued so far
     std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
+    float occlusion = 1.0f;            // OcclusionAttenuation FSAC.h:130 (1.f until the first UpdateSound)
 };
 
 struct TimedFrame {
@@ -52,12 +53,14 @@ struct fs_context {
     // scene (host staging + device)
     std::vector<float> h_xyz;
     std::vector<uint16_t> h_mat;
+    std::vector<uint32_t> h_obj;   // actor id per triangle (empty = one actor per triangle)
     std::vector<float> h_absorption, h_transmission, h_scattering;
     int32_t T = 0, M = 0;
     bool committed = false;
     NodeQ4* d_nodes = nullptr;
     Tri64* d_tris = nullptr;
     float* d_absorption = nullptr;
+    SoundAccum* d_sound = nullptr;
     DeviceScene scene{};
     HostBVH bvh;
 
@@ -327,6 +330,7 @@ int fs_context_destroy(fs_context* ctx) {
         free_scene(ctx);
         free_state(ctx);
         if (ctx->walk.queue_head) (void)hipFree(ctx->walk.queue_head);
+        if (ctx->d_sound) (void)hipFree(ctx->d_sound);
     }
     for (Source* s : ctx->sources) free_source(ctx, s);
     if (ctx->device_ok && ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -374,7 +378,8 @@ int fs_scene_commit(fs_context* ctx) {
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
-    build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(), ctx->T, ctx->bvh);
+    build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(), ctx->h_obj.size() == (size_t)ctx->T && ctx->T > 0 ? ctx->h_obj.data() : nullptr,
+              ctx->T, ctx->bvh);
     if (ctx->bvh.stack_need > kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH needs a deeper traversal stack");
     size_t nb = ctx->bvh.nodes.size() * sizeof(NodeQ4), tb = ctx->bvh.tris.size() * sizeof(Tri64);
     size_t mb = ctx->h_absorption.size() * sizeof(float);
@@ -705,6 +710,76 @@ int fs_update_energy_buffer(fs_context* ctx, fs_source h, const float* values, i
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipMemcpyAsync(s->d_energy, values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+// ---- legacy forward tracer (a9) -----------------------------------------------------------------------------
+void fs_sound_params_default(fs_sound_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->struct_size = sizeof(fs_sound_params);
+    p->seed = 0x5EEDull;
+    p->raycasts_per_tick = 1500;   // FSAC.h:39
+    p->raycast_bounces = 10;       // FSAC.h:42
+    p->raycast_distance = 5000.f;  // FSAC.h:45
+    p->simulated_duration = 1.0f;  // FSAC.h:136
+    p->listener_radius = 34.0f;    // ADefaultPawn collision sphere (engine default, build-owned)
+}
+
+int fs_scene_set_objects(fs_context* ctx, const uint32_t* object_id, int32_t T) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (object_id && T != ctx->T) return ctx->fail(FS_ERR_SIZE_MISMATCH, "object ids: T != number of triangles");
+    if (object_id) ctx->h_obj.assign(object_id, object_id + T);
+    else ctx->h_obj.clear();
+    ctx->committed = false;
+    return FS_OK;
+}
+
+int fs_update_sound(fs_context* ctx, fs_source h, const fs_sound_params* p, fs_sound_result* out) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    fs_sound_params def;
+    if (!p) { fs_sound_params_default(&def); p = &def; }
+    if (p->struct_size != sizeof(fs_sound_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_sound_params.struct_size mismatch");
+    if (p->raycasts_per_tick < 0 || p->raycast_bounces < 0 || !(p->listener_radius >= 0.f))
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad sound params");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (!ctx->d_sound) FS_HIP(ctx, hipMalloc((void**)&ctx->d_sound, sizeof(SoundAccum)));
+    SoundKParams sp{};
+    sp.seed_lo = (uint32_t)p->seed;
+    sp.seed_hi = (uint32_t)(p->seed >> 32);
+    sp.raycasts_per_tick = p->raycasts_per_tick;
+    sp.raycast_bounces = p->raycast_bounces;
+    sp.raycast_distance = p->raycast_distance;
+    sp.simulated_duration = p->simulated_duration;
+    sp.listener_radius = p->listener_radius;
+    std::memcpy(sp.src, s->pos, sizeof(sp.src));
+    std::memcpy(sp.lis, ctx->listener, sizeof(sp.lis));
+    FS_HIP(ctx, hipMemsetAsync(ctx->d_sound, 0, sizeof(SoundAccum), ctx->stream));
+    launch_update_sound(ctx->scene, sp, ctx->d_sound, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    SoundAccum acc{};
+    FS_HIP(ctx, hipMemcpyAsync(&acc, ctx->d_sound, sizeof(acc), hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->rays_reaching_listener = acc.reaching;
+    out->direct_hits = acc.direct_hits;
+    out->direct_energy_sum = acc.direct_energy_sum;
+    out->traces = acc.traces;
+    out->occlusion_attenuation = acc.occlusion;
+    // TotalEnergy /= RaycastsPerTick (FSAC.cpp:294); every reaching ray returns Energy == 1
+    out->total_energy = p->raycasts_per_tick > 0 ? (float)acc.reaching / (float)p->raycasts_per_tick : 0.0f;
+    s->occlusion = acc.occlusion;
+    return FS_OK;
+}
+
+int fs_get_occlusion_attenuation(fs_context* ctx, fs_source h, float* out) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return FS_ERR_BAD_HANDLE;
+    *out = s->occlusion;
     return FS_OK;
 }
 

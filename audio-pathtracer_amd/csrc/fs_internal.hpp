@@ -31,7 +31,7 @@ static_assert(sizeof(NodeQ4) == 64, "NodeQ4 must be 64 B");
 
 // Triangle record, 64 B (same size as a node, so traversal fetches either through one load sequence),
 // stored in leaf order:
-//   a = (v0.x v0.y v0.z e1.x)  b = (e1.y e1.z e2.x e2.y)  c = (e2.z, material, input index, -)
+//   a = (v0.x v0.y v0.z e1.x)  b = (e1.y e1.z e2.x e2.y)  c = (e2.z, material, input index, object id)
 //   d = (unit geometric normal of cross(e1, e2), -)
 struct alignas(16) Tri64 {
     float4 a, b, c, d;
@@ -67,6 +67,19 @@ struct KParams {
     int32_t refill_threshold;  // persistent walk: lanes waiting before the wave leaves traversal to shade/refill
 };
 
+// legacy forward tracer (UpdateSound) constants and device-side accumulators
+struct SoundKParams {
+    uint32_t seed_lo, seed_hi;
+    int32_t raycasts_per_tick, raycast_bounces;
+    float raycast_distance, simulated_duration, listener_radius;
+    float src[3], lis[3];
+};
+struct SoundAccum {
+    unsigned long long traces;
+    unsigned reaching, direct_hits;
+    float direct_energy_sum, occlusion;
+};
+
 // What the walk kernels leave for connect_kernel, SoA over total = 2*num_local subpaths
 // (side-major: [0,n) source side, [n,2n) listener side).
 struct SubpathState {
@@ -86,7 +99,7 @@ struct HostBVH {
     int stack_need = 0;        // worst-case pending traversal-stack entries (<= kStackDepth by construction)
 };
 // xyz [T][3][3], mat [T]; binned SAH BVH2 collapsed to a quantised 4-wide tree, <= 4 triangles per leaf.
-void build_bvh(const float* xyz, const uint16_t* mat, int32_t T, HostBVH& out);
+void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out);
 
 // ---- kernel launchers (fs_kernels.hip) -----------------------------------------------------------------
 struct WalkLaunch {
@@ -107,6 +120,7 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
                         float* ir_bands, float* ir_mono, hipStream_t s);
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
                        int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s);
+void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, hipStream_t s);
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s);
 
 }  // namespace fs

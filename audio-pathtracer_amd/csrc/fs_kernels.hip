@@ -169,16 +169,6 @@ __device__ __forceinline__ bool tri_hit(const float4 A, const float4 Bq, const f
     return true;
 }
 
-__device__ __forceinline__ float slab(float lx, float ly, float lz, float hx, float hy, float hz, const Ray& r,
-                                      float tmax, bool& hit) {
-    float t0x = fmaf(lx, r.ix, r.nox), t1x = fmaf(hx, r.ix, r.nox);
-    float t0y = fmaf(ly, r.iy, r.noy), t1y = fmaf(hy, r.iy, r.noy);
-    float t0z = fmaf(lz, r.iz, r.noz), t1z = fmaf(hz, r.iz, r.noz);
-    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
-    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-    hit = tn <= tf;
-    return tn;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // BVH traversal, one ray per lane, as a resumable single loop: every call of trav_step a busy lane
@@ -203,8 +193,9 @@ __device__ __forceinline__ void trav_init(Trav& T, float tmax, bool scene_nonemp
 }
 __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tri_n || T.cur != kDone; }
 
-template <bool ANY>
-__device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, Trav& T, int* stack) {
+template <bool ANY, bool IGN = false>
+__device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, Trav& T, int* stack,
+                                          uint32_t ignore_object = 0xFFFFFFFFu) {
     // a pending leaf becomes the triangle cursor and the next node is popped right away
     if (T.tri_i >= T.tri_n && T.cur < 0 && T.cur != kDone) {
         const int code = ~T.cur;
@@ -222,7 +213,8 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
     const float4 q3 = rec[3];
     if (is_tri) {
         float t;
-        if (tri_hit(q0, q1, q2, r, T.t, t)) {
+        // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
+        if ((!IGN || __float_as_uint(q2.w) != ignore_object) && tri_hit(q0, q1, q2, r, T.t, t)) {
             const uint32_t id = __float_as_uint(q2.z);
             if (ANY) {
                 T.t = t; T.leaf_index = T.tri_i; T.id = id;
@@ -291,9 +283,10 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
     }
 }
 
-template <bool ANY>
-__device__ __forceinline__ void trav_run(const DeviceScene& sc, const Ray& r, Trav& T, int* stack) {
-    while (trav_busy(T)) trav_step<ANY>(sc, r, T, stack);
+template <bool ANY, bool IGN = false>
+__device__ __forceinline__ void trav_run(const DeviceScene& sc, const Ray& r, Trav& T, int* stack,
+                                         uint32_t ignore_object = 0xFFFFFFFFu) {
+    while (trav_busy(T)) trav_step<ANY, IGN>(sc, r, T, stack, ignore_object);
 }
 
 // ImpactNormal: the record's unit geometric normal, flipped to face the ray origin side; material of the hit
@@ -523,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
     int* stack = &s_stack[threadIdx.x];
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t total = 2u * kp.num_local;
-    const int thresh = kp.refill_threshold;
+    const unsigned thresh = (unsigned)kp.refill_threshold;
     const bool nonempty = sc.num_nodes > 0;
 
     int phase = PH_NEW;
@@ -780,6 +773,168 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// update_sound_kernel: the legacy per-frame forward tracer (UpdateSound FrequenSeeAudioComponent.cpp:283-306,
+// CastAudioRay :132-207, CastDirectAudioRay :209-280).  Lane i < N follows specular chain i (with the
+// listener-directed transmission ray at every bounce); lane N computes OcclusionAttenuation (:295-299).
+// Build-owned engine semantics: actors = object id per triangle, the player pawn = a sphere.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kNoObject = 0xFFFFFFFFu;
+constexpr uint32_t kPawnObject = 0xFFFFFFFEu;
+
+__device__ __forceinline__ bool sphere_hit(const Ray& r, const float c[3], float rad, float tmax, float& t_out) {
+    float ox = r.ox - c[0], oy = r.oy - c[1], oz = r.oz - c[2];
+    float b = fmaf(ox, r.dx, fmaf(oy, r.dy, oz * r.dz));
+    float cc = fmaf(ox, ox, fmaf(oy, oy, oz * oz)) - rad * rad;
+    float disc = fmaf(b, b, -cc);
+    if (!(disc >= 0.0f)) return false;
+    float sq = sqrtf(disc);
+    float t = -b - sq;
+    if (!(t > 0.0f)) t = sq - b;
+    if (!(t > 0.0f && t <= tmax)) return false;
+    t_out = t;
+    return true;
+}
+
+struct LegacyHit { float t; uint32_t object; float nx, ny, nz; };
+
+// closest blocking hit among the triangles (minus one ignored actor) and the pawn sphere
+__device__ __forceinline__ bool legacy_trace(const DeviceScene& sc, const SoundKParams& sp, const Ray& r, float tmax,
+                                             uint32_t ignore, int* stack, LegacyHit& h, unsigned long long& traces) {
+    ++traces;
+    Trav T;
+    trav_init(T, tmax, sc.num_nodes > 0);
+    trav_run<false, true>(sc, r, T, stack, ignore);
+    float ts;
+    const bool hs = sphere_hit(r, sp.lis, sp.listener_radius, tmax, ts);
+    const bool ht = T.leaf_index >= 0;
+    if (!ht && !hs) return false;
+    if (hs && (!ht || ts <= T.t)) { h.t = ts; h.object = kPawnObject; h.nx = h.ny = h.nz = 0.f; return true; }
+    uint32_t mat;
+    hit_surface(sc, T.leaf_index, r, h.nx, h.ny, h.nz, mat);
+    h.t = T.t;
+    h.object = __float_as_uint(reinterpret_cast<const float4*>(sc.tris)[4 * (size_t)T.leaf_index + 2].w);
+    return true;
+}
+
+// CastDirectAudioRay FSAC.cpp:209-280 (tail recursion as a loop)
+__device__ __forceinline__ float cast_direct(const DeviceScene& sc, const SoundKParams& sp, float dx, float dy, float dz,
+                                             float px, float py, float pz, float max_distance, int bounces,
+                                             float energy, uint32_t direct_hit_actor, int* stack,
+                                             unsigned long long& traces) {
+    while (true) {
+        if (bounces == 0 || energy <= 0.0f) return 0.0f;                  // FSAC.cpp:212
+        Ray r = make_ray(fmaf(dx, 0.1f, px), fmaf(dy, 0.1f, py), fmaf(dz, 0.1f, pz), dx, dy, dz);  // :232
+        LegacyHit h;
+        if (!legacy_trace(sc, sp, r, max_distance, direct_hit_actor, stack, h, traces)) return 0.0f;  // :279
+        if (h.object == kPawnObject) {                                    // FSAC.cpp:253-270
+            float travel = sp.raycast_distance - max_distance + h.t;
+            travel *= 0.01f;
+            float time = travel / 343.0f;
+            if (time > sp.simulated_duration) return 0.0f;
+            energy *= expf(-0.0017f * travel);
+            return energy;
+        }
+        px = fmaf(h.t, dx, r.ox); py = fmaf(h.t, dy, r.oy); pz = fmaf(h.t, dz, r.oz);   // Hit.ImpactPoint
+        max_distance = max_distance - h.t;                                // FSAC.cpp:275
+        bounces -= 1;
+        direct_hit_actor = h.object;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void update_sound_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc) {
+    __shared__ int s_stack[kStackDepth * kBlock];
+    int* stack = &s_stack[threadIdx.x];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int N = sp.raycasts_per_tick;
+    if (i > N) return;
+    unsigned long long traces = 0;
+    if (i == N) {                                                         // FSAC.cpp:295-299
+        float dx = sp.lis[0] - sp.src[0], dy = sp.lis[1] - sp.src[1], dz = sp.lis[2] - sp.src[2];
+        float l2 = dx * dx + dy * dy + dz * dz;
+        float occ = 0.0f;
+        if (l2 > 0.0f) {
+            float inv = 1.0f / sqrtf(l2);
+            occ = cast_direct(sc, sp, dx * inv, dy * inv, dz * inv, sp.src[0], sp.src[1], sp.src[2],
+                              sp.raycast_distance, 10, 1.0f, kNoObject, stack, traces);
+        }
+        acc->occlusion = occ;
+        atomicAdd(&acc->traces, traces);
+        return;
+    }
+    // initial direction: FMath::VRandCone((0,-1,0), PI, PI) FSAC.cpp:291 == theta = 2 pi U, phi = acos(2V-1)
+    float ddx, ddy, ddz;
+    {
+        uint32_t c0 = (uint32_t)i, c1 = 0u, c2 = 0u, c3 = 0x46533032u, k0 = sp.seed_lo, k1 = sp.seed_hi;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+            uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        const float U = u01(c0), V = u01(c1);
+        const float x = fmaf(V, 2.0f, -1.0f);
+        const float sphi = sqrtf(fmaxf(0.0f, fmaf(-x, x, 1.0f)));
+        float st, ct;
+        sincos2pi(U, st, ct);
+        const float nx = 0.0f, ny = -1.0f, nz = 0.0f;
+        float sg = copysignf(1.0f, nz);
+        float a = -1.0f / (sg + nz);
+        float b = nx * ny * a;
+        float t0 = fmaf(sg * nx * nx, a, 1.0f), t1 = sg * b, t2 = -sg * nx;
+        float b0 = b, b1 = fmaf(ny * ny, a, sg), b2 = -ny;
+        float lx = sphi * ct, ly = sphi * st;
+        float d0 = fmaf(lx, t0, fmaf(ly, b0, x * nx));
+        float d1 = fmaf(lx, t1, fmaf(ly, b1, x * ny));
+        float d2 = fmaf(lx, t2, fmaf(ly, b2, x * nz));
+        float l2 = d0 * d0 + d1 * d1 + d2 * d2;
+        float inv = 1.0f / sqrtf(l2);
+        ddx = d0 * inv; ddy = d1 * inv; ddz = d2 * inv;
+    }
+    // CastAudioRay FSAC.cpp:132-207 (tail recursion as a loop)
+    float px = sp.src[0], py = sp.src[1], pz = sp.src[2];
+    float max_distance = sp.raycast_distance;
+    int bounces = sp.raycast_bounces;
+    const float energy = 1.0f;
+    float result = 0.0f;
+    unsigned direct_hits = 0;
+    float direct_sum = 0.0f;
+    while (true) {
+        if (bounces == 0) break;                                          // FSAC.cpp:134
+        float l2 = ddx * ddx + ddy * ddy + ddz * ddz;                     // GetSafeNormal FSAC.cpp:141
+        float inv = 1.0f / sqrtf(l2);
+        const float dx = ddx * inv, dy = ddy * inv, dz = ddz * inv;
+        Ray r = make_ray(px, py, pz, dx, dy, dz);
+        LegacyHit h;
+        if (!legacy_trace(sc, sp, r, max_distance, kNoObject, stack, h, traces)) break;   // FSAC.cpp:192-196
+        const float ipx = fmaf(h.t, dx, px), ipy = fmaf(h.t, dy, py), ipz = fmaf(h.t, dz, pz);
+        const float left = max_distance - h.t;                            // DistanceLeft FSAC.cpp:167
+        const float tx = sp.lis[0] - ipx, ty = sp.lis[1] - ipy, tz = sp.lis[2] - ipz;
+        const float dist_to_player = sqrtf(tx * tx + ty * ty + tz * tz);
+        const float travel_time = (sp.raycast_distance - left + dist_to_player) * 0.01f / 343.0f;   // :171
+        if (travel_time > sp.simulated_duration) break;
+        if (h.object == kPawnObject) { result = energy; break; }          // FSAC.cpp:177-181
+        if (dist_to_player > 0.0f) {                                      // FSAC.cpp:184-185
+            const float invp = 1.0f / dist_to_player;
+            const float de = cast_direct(sc, sp, tx * invp, ty * invp, tz * invp, ipx, ipy, ipz, left, 1, energy,
+                                         kNoObject, stack, traces);
+            if (de > 0.0f) { ++direct_hits; direct_sum += de; }
+        }
+        const float dn = dx * h.nx + dy * h.ny + dz * h.nz;               // GetReflectionVector FSAC.cpp:186
+        ddx = fmaf(-2.0f * dn, h.nx, dx);
+        ddy = fmaf(-2.0f * dn, h.ny, dy);
+        ddz = fmaf(-2.0f * dn, h.nz, dz);
+        px = fmaf(h.nx, 0.5f, ipx); py = fmaf(h.ny, 0.5f, ipy); pz = fmaf(h.nz, 0.5f, ipz);   // FSAC.cpp:187
+        max_distance = left;
+        bounces -= 1;
+    }
+    if (result > 0.0f) atomicAdd(&acc->reaching, 1u);
+    if (direct_hits) { atomicAdd(&acc->direct_hits, direct_hits); atomicAdd(&acc->direct_energy_sum, direct_sum); }
+    atomicAdd(&acc->traces, traces);
+}
+
 // AddEnergyAtDelay on the device-resident buffer (FSAC.h:87-91)
 __global__ void add_energy_kernel(float* row, int nb, float delay, float e) {
     float x = (delay * 1000.f) / 1.0f;
@@ -850,6 +1005,11 @@ void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, co
     if (N <= 0) return;
     hipLaunchKernelGGL(trace_rays_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sc, o, d, tmax, N,
                        any_hit, hit, t, tri, normal);
+}
+
+void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, hipStream_t s) {
+    int lanes = sp.raycasts_per_tick + 1;
+    hipLaunchKernelGGL(update_sound_kernel, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sc, sp, acc);
 }
 
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s) {

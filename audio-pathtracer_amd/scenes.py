@@ -32,6 +32,7 @@ class Scene:
     listener: np.ndarray  # [3]
     material_names: list = field(default_factory=list)
     extra_sources: np.ndarray | None = None  # [S,3] for the multi-source config
+    object_ids: np.ndarray | None = None     # [T] uint32 actor per triangle (legacy tracer: ignored / passed-through actors)
 
     @property
     def num_triangles(self) -> int:
@@ -49,11 +50,18 @@ class _Mesh:
     def __init__(self):
         self.tris = []
         self.mats = []
+        self.objs = []
+        self.next_obj = 0
 
-    def add(self, tris, mat):
+    def add(self, tris, mat, obj=None):
+        """one call = one actor (a mesh with its own collision), unless obj names an existing actor"""
         tris = np.asarray(tris, dtype=np.float64).reshape(-1, 3, 3)
+        if obj is None:
+            obj = self.next_obj
+            self.next_obj += 1
         self.tris.append(tris)
         self.mats.append(np.full(tris.shape[0], mat, dtype=np.uint16))
+        self.objs.append(np.full(tris.shape[0], obj, dtype=np.uint32))
 
     def count(self):
         return int(sum(t.shape[0] for t in self.tris))
@@ -61,6 +69,7 @@ class _Mesh:
     def finish(self):
         t = np.concatenate(self.tris, axis=0).astype(np.float32)
         m = np.concatenate(self.mats, axis=0)
+        self.object_ids = np.ascontiguousarray(np.concatenate(self.objs, axis=0))
         return np.ascontiguousarray(t), np.ascontiguousarray(m)
 
 
@@ -155,7 +164,7 @@ def shoebox(bands: int = 1, reflectivity: float = 0.5) -> Scene:
     assert t.shape[0] == 12
     return Scene("shoebox", t, ids, np.full((1, bands), reflectivity, dtype=np.float32),
                  np.array([250, 200, 150], dtype=np.float32), np.array([750, 600, 120], dtype=np.float32),
-                 ["plaster"])
+                 ["plaster"], None, m.object_ids)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -210,7 +219,7 @@ def starter_room(bands: int = 4, seed: int = 0x57A7, target_tris: int = 5000) ->
     assert t.shape[0] == target_tris
     return Scene("starter_room", t, ids, _materials(rng, 4, bands),
                  np.array([300, 300, 150], dtype=np.float32), np.array([1100, 1250, 160], dtype=np.float32),
-                 ["carpet", "concrete", "glass", "wood"])
+                 ["carpet", "concrete", "glass", "wood"], None, m.object_ids)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -322,6 +331,8 @@ def old_mine(bands: int = 8, seed: int = 0x01D, target_tris: int = 100000, cell:
     m = _Mesh()
     m.tris = [np.concatenate(tris, axis=0)]
     m.mats = [np.concatenate(mats, axis=0)]
+    m.objs = [np.zeros(m.tris[0].shape[0], dtype=np.uint32)]   # the tunnel shell is one landscape actor
+    m.next_obj = 1
     lattice = m.count()
     assert lattice % 4 == 0 and lattice < target_tris - 2000, lattice
 
@@ -369,7 +380,7 @@ def old_mine(bands: int = 8, seed: int = 0x01D, target_tris: int = 100000, cell:
     extra = np.array([[*along(b, s_, 0.0), 150.0] for b, s_ in spots], dtype=np.float32)
     return Scene("old_mine", t, ids, _materials(rng, 8, bands),
                  np.array([sx, sy, 150.0], dtype=np.float32), np.array([lx, ly, 140.0], dtype=np.float32),
-                 ["dirt", "rock_a", "rock_b", "rock_c", "ceiling", "wood", "metal", "gravel"], extra)
+                 ["dirt", "rock_a", "rock_b", "rock_c", "ceiling", "wood", "metal", "gravel"], extra, m.object_ids)
 
 
 def by_name(name: str, bands: int | None = None) -> Scene:

@@ -168,6 +168,37 @@ int fs_update_energy_buffer(fs_context* ctx, fs_source src, const float* values,
 int fs_num_bins(const fs_context* ctx);    /* FSAC.h:137 */
 int fs_num_samples(const fs_context* ctx); /* FSAC.h:138 */
 
+/* ---- legacy per-frame forward tracer (row a9): UpdateSound (FSAC.cpp:283-306) = RaycastsPerTick specular
+ *      chains CastAudioRay (:132-207), each bounce firing a listener-directed CastDirectAudioRay (:209-280),
+ *      then OcclusionAttenuation (:295-299), the only live output at HEAD (OCC.cpp:43 reads it).
+ *      Engine semantics owned by the build: an actor = an object id per triangle; the player pawn = a sphere. */
+typedef struct fs_sound_params {
+    uint32_t struct_size;        /* = sizeof(fs_sound_params) */
+    int32_t raycasts_per_tick;   /* 1500  FSAC.h:39 */
+    uint64_t seed;
+    int32_t raycast_bounces;     /* 10    FSAC.h:42 */
+    float raycast_distance;      /* 5000  FSAC.h:45 */
+    float simulated_duration;    /* 1.0   FSAC.h:136 */
+    float listener_radius;       /* pawn collision sphere radius, cm */
+} fs_sound_params;
+
+typedef struct fs_sound_result {
+    float total_energy;          /* TotalEnergy / RaycastsPerTick, FSAC.cpp:294 (computed then dropped at HEAD) */
+    float occlusion_attenuation; /* FSAC.cpp:299 */
+    float direct_energy_sum;     /* sum of the per-bounce CastDirectAudioRay results (what Accumulate would get) */
+    uint32_t rays_reaching_listener;
+    uint32_t direct_hits;
+    uint64_t traces;             /* line traces issued */
+} fs_sound_result;
+
+void fs_sound_params_default(fs_sound_params* p);
+/* actor id per triangle [T] (AActor the collision belongs to); NULL = every triangle its own actor.
+ * Takes effect at the next fs_scene_commit. */
+int fs_scene_set_objects(fs_context* ctx, const uint32_t* object_id, int32_t T);
+int fs_update_sound(fs_context* ctx, fs_source src, const fs_sound_params* p, fs_sound_result* out);
+/* GetOcclusionAttenuation() FSAC.h:112: value of the last fs_update_sound (1.0 before the first) */
+int fs_get_occlusion_attenuation(fs_context* ctx, fs_source src, float* out);
+
 /* ---- engine line trace the BVH kernel replaces (UWorld::LineTraceSingleByObjectType; call sites
  *      ARTS.cpp:252-254 any-hit, :340-342 closest-hit). Batch query, host arrays. ------------------- */
 /* origins/dirs: [N][3] (dirs unit), tmax: [N]; out: hit[N] (0/1), t[N], tri[N] (input triangle index or -1),

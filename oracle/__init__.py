@@ -66,6 +66,31 @@ class Counters(C.Structure):
             setattr(self, k, getattr(self, k) + getattr(other, k))
 
 
+class SoundParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("raycasts_per_tick", C.c_int32),
+        ("raycast_bounces", C.c_int32),
+        ("raycast_distance", C.c_float),
+        ("simulated_duration", C.c_float),
+        ("listener_radius", C.c_float),
+    ]
+
+
+class SoundResult(C.Structure):
+    _fields_ = [
+        ("total_energy", C.c_float),
+        ("occlusion_attenuation", C.c_float),
+        ("direct_energy_sum", C.c_float),
+        ("rays_reaching_listener", C.c_uint32),
+        ("direct_hits", C.c_uint32),
+        ("traces", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class Node(C.Structure):
     _fields_ = [
         ("pos", C.c_float * 3),
@@ -125,8 +150,10 @@ def _bind(lib):
     lib.fso_compute_energy.argtypes = [C.c_void_p, C.POINTER(Params), _f3, _f3, C.c_uint32, C.c_uint32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.POINTER(Counters)]
     lib.fso_reconstruct.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
-    lib.fso_occlusion_attenuation.argtypes = [C.c_void_p, _f3, _f3, C.c_float, C.c_float, C.c_int32]
-    lib.fso_occlusion_attenuation.restype = C.c_float
+    lib.fso_scene_set_objects.argtypes = [C.c_void_p, C.c_void_p]
+    lib.fso_sound_params_default.argtypes = [C.POINTER(SoundParams)]
+    lib.fso_legacy_direction.argtypes = [C.c_uint64, C.c_uint32, _f3]
+    lib.fso_update_sound.argtypes = [C.c_void_p, C.POINTER(SoundParams), _f3, _f3, C.POINTER(SoundResult)]
     return lib
 
 
@@ -249,9 +276,24 @@ class Scene:
             c.add(p[2])
         return e64.astype(np.float32), e64, c
 
-    def occlusion_attenuation(self, src, lis, listener_radius=50.0, raycast_distance=5000.0, bounces=10):
-        return float(self.lib.fso_occlusion_attenuation(self.h, _vec3(src), _vec3(lis), listener_radius,
-                                                        raycast_distance, bounces))
+    def set_objects(self, object_ids):
+        """actor id per triangle (None = every triangle its own actor)"""
+        if object_ids is None:
+            self.lib.fso_scene_set_objects(self.h, None)
+        else:
+            self._obj = np.ascontiguousarray(object_ids, dtype=np.uint32)
+            assert self._obj.shape[0] == self.T
+            self.lib.fso_scene_set_objects(self.h, self._obj.ctypes.data)
+
+    def update_sound(self, src, lis, **kw):
+        """legacy forward tracer UpdateSound (FSAC.cpp:283-306)"""
+        p = SoundParams()
+        self.lib.fso_sound_params_default(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        r = SoundResult()
+        self.lib.fso_update_sound(self.h, C.byref(p), _vec3(src), _vec3(lis), C.byref(r))
+        return r.as_dict()
 
 
 def reconstruct(energy_row, sample_rate=48000, bin_duration=0.001, num_samples=48000, samples_per_bin=0, lib=None):

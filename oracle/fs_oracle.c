@@ -154,7 +154,7 @@ void fso_sample_cone(const float n[3], float U, float V, int32_t cosine, float d
 /* ------------------------------------------------------------------------------------------- */
 typedef struct fso_tri { /* 48 B record: v0, e1, e2, material */
     float v0[3]; float e1[3]; float e2[3];
-    uint32_t material; uint32_t id; uint32_t pad;
+    uint32_t material; uint32_t id; uint32_t object; /* actor the triangle belongs to */
 } fso_tri;
 
 typedef struct fso_bnode { /* 32 B */
@@ -290,6 +290,7 @@ fso_scene* fso_scene_create(const float* xyz, const uint16_t* mat_id, int32_t T,
         }
         t->material = mat_id ? mat_id[i] : FSO_NO_MATERIAL;
         t->id = (uint32_t)i;
+        t->object = (uint32_t)i; /* default: every triangle is its own actor */
         s->tris_orig[i] = *t;
     }
     /* conservative box padding: far above float error of the slab/triangle tests, so the BVH result
@@ -379,14 +380,17 @@ static void hit_normal(const fso_tri* tr, const float d[3], float n[3]) {
     n[0] = nx; n[1] = ny; n[2] = nz;
 }
 
-int32_t fso_trace_closest(const fso_scene* s, const float o[3], const float d[3], float tmax, int32_t brute,
-                          float* t_out, int32_t* tri_out, float n_out[3], fso_counters* c) {
+#define FSO_NO_OBJECT 0xFFFFFFFFu
+static int32_t closest_impl(const fso_scene* s, const float o[3], const float d[3], float tmax, int32_t brute,
+                            uint32_t ignore_object, float* t_out, int32_t* tri_out, float n_out[3],
+                            fso_counters* c) {
     float best_t = tmax; uint32_t best_id = 0xFFFFFFFFu; const fso_tri* best = NULL;
     if (c) c->closest_rays++;
     if (brute || s->num_nodes == 0) {
         for (int i = 0; i < s->T; ++i) {
             float t;
             if (c) c->tri_tests++;
+            if (s->tris_orig[i].object == ignore_object) continue;   /* AddIgnoredActor */
             if (tri_hit(&s->tris_orig[i], o, d, best_t, &t)) {
                 if (t < best_t || best == NULL) { best_t = t; best = &s->tris_orig[i]; best_id = (uint32_t)i; }
             }
@@ -402,6 +406,7 @@ int32_t fso_trace_closest(const fso_scene* s, const float o[3], const float d[3]
                 for (uint32_t i = n->left_first; i < n->left_first + n->count; ++i) {
                     float t; const fso_tri* tr = &s->tris[i];
                     if (c) c->tri_tests++;
+                    if (tr->object == ignore_object) continue;       /* AddIgnoredActor */
                     if (tri_hit(tr, o, d, best_t, &t)) {
                         if (t < best_t || best == NULL || (t == best_t && tr->id < best_id)) {
                             best_t = t; best = tr; best_id = tr->id;
@@ -426,6 +431,16 @@ int32_t fso_trace_closest(const fso_scene* s, const float o[3], const float d[3]
     if (tri_out) *tri_out = (int32_t)best_id;
     if (n_out) hit_normal(best, d, n_out);
     return 1;
+}
+
+int32_t fso_trace_closest(const fso_scene* s, const float o[3], const float d[3], float tmax, int32_t brute,
+                          float* t_out, int32_t* tri_out, float n_out[3], fso_counters* c) {
+    return closest_impl(s, o, d, tmax, brute, FSO_NO_OBJECT, t_out, tri_out, n_out, c);
+}
+
+void fso_scene_set_objects(fso_scene* s, const uint32_t* object_id) {
+    for (int i = 0; i < s->T; ++i) s->tris_orig[i].object = object_id ? object_id[i] : (uint32_t)i;
+    for (int i = 0; i < s->T; ++i) s->tris[i].object = s->tris_orig[s->tris[i].id].object;
 }
 
 int32_t fso_trace_any(const fso_scene* s, const float o[3], const float d[3], float tmax, int32_t brute,
@@ -682,53 +697,164 @@ void fso_reconstruct(const float* energy, int32_t num_bins, int32_t sample_rate,
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* Legacy occlusion scalar: UpdateSound FSAC.cpp:295-299 -> CastDirectAudioRay FSAC.cpp:209-280 */
-/* Build contract: every triangle is its own obstacle "actor" is too fine; obstacles are keyed  */
-/* by material id (one UAcousticGeometryComponent per actor); the listener is a sphere.         */
+/* Legacy per-frame forward tracer: UpdateSound FSAC.cpp:283-306, CastAudioRay :132-207,         */
+/* CastDirectAudioRay :209-280.  Engine semantics defined by the build: an "actor" is an object  */
+/* id per triangle (fso_scene_set_objects); the player pawn is a sphere of listener_radius at the */
+/* listener position; the source's own actor has no geometry.                                    */
 /* ------------------------------------------------------------------------------------------- */
 static int sphere_hit(const float o[3], const float d[3], const float c[3], float r, float tmax, float* t_out) {
     float ox = o[0] - c[0], oy = o[1] - c[1], oz = o[2] - c[2];
-    float b = ox * d[0] + oy * d[1] + oz * d[2];
-    float cc = ox * ox + oy * oy + oz * oz - r * r;
-    float disc = b * b - cc;
-    if (disc < 0.0f) return 0;
+    float b = fmaf(ox, d[0], fmaf(oy, d[1], oz * d[2]));
+    float cc = fmaf(ox, ox, fmaf(oy, oy, oz * oz)) - r * r;
+    float disc = fmaf(b, b, -cc);
+    if (!(disc >= 0.0f)) return 0;
     float sq = sqrtf(disc);
     float t = -b - sq;
-    if (t <= 0.0f) t = -b + sq;
+    if (!(t > 0.0f)) t = sq - b;
     if (!(t > 0.0f && t <= tmax)) return 0;
     *t_out = t;
     return 1;
 }
 
-float fso_occlusion_attenuation(const fso_scene* s, const float src[3], const float lis[3], float listener_radius,
-                                float raycast_distance, int32_t bounces) {
-    float dx = lis[0] - src[0], dy = lis[1] - src[1], dz = lis[2] - src[2];
-    float l2 = dx * dx + dy * dy + dz * dz;
-    if (!(l2 > 1e-8f)) return 0.0f;
-    float inv = 1.0f / sqrtf(l2);
-    float dir[3] = {dx * inv, dy * inv, dz * inv};            /* DirToPlayer.Normalize() FSAC.cpp:296 */
-    float pos[3] = {src[0], src[1], src[2]};
-    float max_dist = raycast_distance;
-    float energy = 1.0f;
-    while (bounces > 0 && energy > 0.0f) {                    /* FSAC.cpp:212 */
+#define FSO_PAWN_OBJECT 0xFFFFFFFEu
+/* closest blocking hit among the triangles (minus one ignored actor) and the pawn sphere */
+static int legacy_trace(const fso_scene* s, const float o[3], const float d[3], float tmax, uint32_t ignore,
+                        const float lis[3], float radius, float* t_out, uint32_t* obj_out, float n_out[3],
+                        fso_sound_result* res) {
+    float tt = 0.f, ts = 0.f; int32_t tri = -1; float n[3] = {0.f, 0.f, 0.f};
+    if (res) res->traces++;
+    int ht = closest_impl(s, o, d, tmax, 0, ignore, &tt, &tri, n, NULL);
+    int hs = sphere_hit(o, d, lis, radius, tmax, &ts);
+    if (!ht && !hs) return 0;
+    if (hs && (!ht || ts <= tt)) { *t_out = ts; *obj_out = FSO_PAWN_OBJECT; n_out[0] = n_out[1] = n_out[2] = 0.f; return 1; }
+    *t_out = tt; *obj_out = s->tris_orig[tri].object;
+    n_out[0] = n[0]; n_out[1] = n[1]; n_out[2] = n[2];
+    return 1;
+}
+
+/* CastDirectAudioRay FSAC.cpp:209-280 (tail recursion written as a loop) */
+static float cast_direct(const fso_scene* s, const fso_sound_params* p, const float dir[3], const float start[3],
+                         float max_distance, int bounces, float energy, uint32_t direct_hit_actor,
+                         const float lis[3], fso_sound_result* res) {
+    float pos[3] = {start[0], start[1], start[2]};
+    while (1) {
+        if (bounces == 0 || energy <= 0.0f) return 0.0f;                   /* FSAC.cpp:212 */
         float o[3];
-        for (int k = 0; k < 3; ++k) o[k] = fmaf(dir[k], 0.1f, pos[k]);   /* DirectStart FSAC.cpp:232 */
-        float tt = INFINITY, ts = INFINITY, n[3]; int32_t tri = -1;
-        int ht = fso_trace_closest(s, o, dir, max_dist, 0, &tt, &tri, n, NULL);
-        int hs = sphere_hit(o, dir, lis, listener_radius, max_dist, &ts);
-        if (!ht && !hs) return 0.0f;                          /* no hit FSAC.cpp:279 */
-        if (hs && (!ht || ts <= tt)) {                        /* hit the player FSAC.cpp:253-270 */
-            float travel = raycast_distance - max_dist + ts;
+        for (int k = 0; k < 3; ++k) o[k] = fmaf(dir[k], 0.1f, pos[k]);     /* DirectStart FSAC.cpp:232 */
+        float t, n[3]; uint32_t obj;
+        if (!legacy_trace(s, o, dir, max_distance, direct_hit_actor, lis, p->listener_radius, &t, &obj, n, res))
+            return 0.0f;                                                   /* no hit FSAC.cpp:279 */
+        if (obj == FSO_PAWN_OBJECT) {                                      /* FSAC.cpp:253-270 */
+            float travel = p->raycast_distance - max_distance + t;
             travel *= 0.01f;
             float time = travel / 343.0f;
-            if (time > 1.0f) return 0.0f;
+            if (time > p->simulated_duration) return 0.0f;
             energy *= expf(-0.0017f * travel);
             return energy;
         }
-        /* hit a different obstacle: continue through it FSAC.cpp:272-276 */
-        for (int k = 0; k < 3; ++k) pos[k] = fmaf(tt, dir[k], o[k]);
-        max_dist -= tt;
+        /* a different obstacle: continue through it, FSAC.cpp:272-276 */
+        for (int k = 0; k < 3; ++k) pos[k] = fmaf(t, dir[k], o[k]);        /* Hit.ImpactPoint */
+        max_distance = max_distance - t;
+        bounces -= 1;
+        direct_hit_actor = obj;
+    }
+}
+
+/* CastAudioRay FSAC.cpp:132-207 (tail recursion written as a loop) */
+static float cast_audio_ray(const fso_scene* s, const fso_sound_params* p, const float dir_in[3],
+                            const float start[3], const float lis[3], fso_sound_result* res) {
+    float pos[3] = {start[0], start[1], start[2]};
+    float dir[3] = {dir_in[0], dir_in[1], dir_in[2]};
+    float max_distance = p->raycast_distance;
+    int bounces = p->raycast_bounces;
+    const float energy = 1.0f;
+    while (1) {
+        if (bounces == 0 || energy <= 0.0f) return 0.0f;                   /* FSAC.cpp:134 */
+        float l2 = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];    /* GetSafeNormal FSAC.cpp:141 */
+        float inv = 1.0f / sqrtf(l2);
+        float d[3] = {dir[0] * inv, dir[1] * inv, dir[2] * inv};
+        float t, n[3]; uint32_t obj;
+        if (!legacy_trace(s, pos, d, max_distance, FSO_NO_OBJECT, lis, p->listener_radius, &t, &obj, n, res))
+            return 0.0f;                                                   /* FSAC.cpp:192-196 */
+        float ip[3];
+        for (int k = 0; k < 3; ++k) ip[k] = fmaf(t, d[k], pos[k]);
+        float left = max_distance - t;                                     /* DistanceLeft FSAC.cpp:167 */
+        float tp[3] = {lis[0] - ip[0], lis[1] - ip[1], lis[2] - ip[2]};
+        float dist_to_player = sqrtf(tp[0] * tp[0] + tp[1] * tp[1] + tp[2] * tp[2]);
+        float travel_time = (p->raycast_distance - left + dist_to_player) * 0.01f / 343.0f;  /* FSAC.cpp:171 */
+        if (travel_time > p->simulated_duration) return 0.0f;
+        if (obj == FSO_PAWN_OBJECT) return energy;                         /* FSAC.cpp:177-181 */
+        if (dist_to_player > 0.0f) {                                       /* FSAC.cpp:184-185 (result unused) */
+            float invp = 1.0f / dist_to_player;
+            float dp[3] = {tp[0] * invp, tp[1] * invp, tp[2] * invp};
+            float de = cast_direct(s, p, dp, ip, left, 1, energy, FSO_NO_OBJECT, lis, res);
+            if (de > 0.0f && res) { res->direct_hits++; res->direct_energy_sum += de; }
+        }
+        float dn = d[0] * n[0] + d[1] * n[1] + d[2] * n[2];                /* GetReflectionVector FSAC.cpp:186 */
+        for (int k = 0; k < 3; ++k) {
+            dir[k] = fmaf(-2.0f * dn, n[k], d[k]);
+            pos[k] = fmaf(n[k], 0.5f, ip[k]);                              /* FSAC.cpp:187 */
+        }
+        max_distance = left;
         bounces -= 1;
     }
-    return 0.0f;
+}
+
+void fso_sound_params_default(fso_sound_params* p) {
+    p->seed = 0x5EEDull;
+    p->raycasts_per_tick = 1500;      /* FSAC.h:39 */
+    p->raycast_bounces = 10;          /* FSAC.h:42 */
+    p->raycast_distance = 5000.0f;    /* FSAC.h:45 */
+    p->simulated_duration = 1.0f;     /* FSAC.h:136 */
+    p->listener_radius = 34.0f;       /* ADefaultPawn collision sphere (engine default, build-owned) */
+}
+
+/* the initial direction FMath::VRandCone((0,-1,0), PI, PI) FSAC.cpp:291: with both half angles PI the
+ * polar clamp is the identity, i.e. theta = 2 pi U, phi = acos(2V - 1) about the axis (0,-1,0) */
+void fso_legacy_direction(uint64_t seed, uint32_t ray, float dir[3]) {
+    uint32_t ctr[4] = {ray, 0u, 0u, 0x46533032u /* 'FS02' */};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t r[4];
+    fso_philox4x32_10(ctr, key, r);
+    float U = fso_u01(r[0]), V = fso_u01(r[1]);
+    float x = fmaf(V, 2.0f, -1.0f);
+    float sphi = sqrtf(fmaxf(0.0f, fmaf(-x, x, 1.0f)));
+    float st, ct;
+    fso_sincos2pi(U, &st, &ct);
+    const float n[3] = {0.0f, -1.0f, 0.0f};
+    float sg = copysignf(1.0f, n[2]);
+    float a = -1.0f / (sg + n[2]);
+    float b = n[0] * n[1] * a;
+    float t0 = fmaf(sg * n[0] * n[0], a, 1.0f), t1 = sg * b, t2 = -sg * n[0];
+    float b0 = b, b1 = fmaf(n[1] * n[1], a, sg), b2 = -n[1];
+    float lx = sphi * ct, ly = sphi * st;
+    float d0 = fmaf(lx, t0, fmaf(ly, b0, x * n[0]));
+    float d1 = fmaf(lx, t1, fmaf(ly, b1, x * n[1]));
+    float d2 = fmaf(lx, t2, fmaf(ly, b2, x * n[2]));
+    float l2 = d0 * d0 + d1 * d1 + d2 * d2;
+    float inv = 1.0f / sqrtf(l2);
+    dir[0] = d0 * inv; dir[1] = d1 * inv; dir[2] = d2 * inv;
+}
+
+/* UpdateSound FSAC.cpp:283-306 */
+void fso_update_sound(const fso_scene* s, const fso_sound_params* p, const float src[3], const float lis[3],
+                      fso_sound_result* res) {
+    memset(res, 0, sizeof(*res));
+    float total = 0.0f;
+    for (int32_t i = 0; i < p->raycasts_per_tick; ++i) {                   /* FSAC.cpp:289-294 */
+        float dir[3];
+        fso_legacy_direction(p->seed, (uint32_t)i, dir);
+        float e = cast_audio_ray(s, p, dir, src, lis, res);
+        total += e;
+        if (e > 0.0f) res->rays_reaching_listener++;
+    }
+    res->total_energy = p->raycasts_per_tick > 0 ? total / (float)p->raycasts_per_tick : 0.0f;  /* FSAC.cpp:294 */
+    float dx = lis[0] - src[0], dy = lis[1] - src[1], dz = lis[2] - src[2];  /* FSAC.cpp:296-297 */
+    float l2 = dx * dx + dy * dy + dz * dz;
+    if (l2 > 0.0f) {
+        float inv = 1.0f / sqrtf(l2);
+        float d[3] = {dx * inv, dy * inv, dz * inv};
+        /* 10 pass-throughs, ignoring the source's own (geometry-less) actor, FSAC.cpp:299 */
+        res->occlusion_attenuation = cast_direct(s, p, d, src, p->raycast_distance, 10, 1.0f, FSO_NO_OBJECT, lis, res);
+    }
 }

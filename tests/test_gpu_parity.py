@@ -371,3 +371,48 @@ def test_full_size_properties_cfg4(pkg, scene_factory):
         c.close()
     assert np.array_equal(acc != 0, full != 0)
     assert all(rel_rms(acc[b], full[b]) <= TIGHT_TOL for b in range(8))
+
+
+# ---- a9: legacy forward tracer ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["shoebox", "starter_room", "old_mine"])
+def test_update_sound_parity(pkg, oracle_mod, scene_factory, name):
+    """UpdateSound / CastAudioRay / CastDirectAudioRay (FSAC.cpp:132-306): counts exact, energies to fp32 ulps."""
+    sc = scene_factory(name)
+    ctx = pkg.Context(num_bands=sc.num_bands)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, object_ids=sc.object_ids)
+    ctx.set_listener(sc.listener)
+    src = ctx.create_source(sc.source)
+    assert ctx.occlusion_attenuation(src) == 1.0            # OcclusionAttenuation = 1.f (FSAC.h:130)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    osc.set_objects(sc.object_ids)
+    for kw in ({}, {"seed": 99, "raycasts_per_tick": 777, "raycast_bounces": 4, "listener_radius": 60.0},
+               {"raycast_distance": 1500.0}):
+        got = ctx.update_sound(src, pkg._capi.default_sound_params(**kw))
+        ref = osc.update_sound(sc.source, sc.listener, **kw)
+        for k in ("rays_reaching_listener", "direct_hits", "traces"):
+            assert got[k] == ref[k], (k, got, ref)
+        assert got["total_energy"] == ref["total_energy"]
+        assert got["occlusion_attenuation"] == pytest.approx(ref["occlusion_attenuation"], rel=2e-6, abs=0)
+        assert got["direct_energy_sum"] == pytest.approx(ref["direct_energy_sum"], rel=2e-5, abs=0)
+        assert ctx.occlusion_attenuation(src) == got["occlusion_attenuation"]
+    # default actors (every triangle its own) must agree as well
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    osc.set_objects(None)
+    got, ref = ctx.update_sound(src), osc.update_sound(sc.source, sc.listener)
+    assert got["traces"] == ref["traces"] and got["direct_hits"] == ref["direct_hits"]
+    assert got["occlusion_attenuation"] == pytest.approx(ref["occlusion_attenuation"], rel=2e-6, abs=0)
+    ctx.close()
+
+
+def test_component_update_sound(pkg, scene_factory):
+    sc = scene_factory("starter_room", 4)
+    sub = pkg.AudioRayTracingSubsystem(num_bands=4)
+    sub.RegisterGeometry(sc.triangles, sc.material_ids, sc.object_ids)
+    sub.SetMaterials(sc.absorption)
+    comp = pkg.FrequenSeeAudioComponent(sc.source)
+    comp.OnRegister(sub)
+    sub.SetListenerLocation(sc.listener)
+    assert comp.GetOcclusionAttenuation() == 1.0
+    r = comp.UpdateSound()
+    assert 0.0 < comp.GetOcclusionAttenuation() <= 1.0 and r["traces"] > 1500
+    sub.Deinitialize()

@@ -266,3 +266,54 @@ def test_multithreaded_baseline_matches(oracle_mod, scene_factory):
     _, e64, c = s.compute_energy(p, sc.source, sc.listener)
     _, e64m, cm = s.compute_energy_mt(p, sc.source, sc.listener, threads=4)
     assert np.allclose(e64, e64m, rtol=1e-12) and c.as_dict() == cm.as_dict()
+
+
+# ---- a9: legacy forward tracer (UpdateSound / CastAudioRay / CastDirectAudioRay) ------------------------------
+def test_kat_legacy_occlusion_closed_form(oracle_mod, scene_factory):
+    """CastDirectAudioRay FSAC.cpp:209-280: the pawn hit returns exp(-0.0017 * metres travelled)."""
+    sc = scene_factory("shoebox", 1)
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    s.set_objects(sc.object_ids)
+    r = s.update_sound(sc.source, sc.listener, listener_radius=34.0)
+    d_cm = float(np.linalg.norm(sc.listener.astype(np.float64) - sc.source.astype(np.float64))) - 34.0
+    assert r["occlusion_attenuation"] == pytest.approx(math.exp(-0.0017 * d_cm * 0.01), rel=2e-6)
+    # a wall (one actor, two faces) between source and listener is passed through once (FSAC.cpp:272-276)
+    wall = np.array([[[500, 0, 0], [500, 800, 0], [500, 800, 300]], [[500, 0, 0], [500, 800, 300], [500, 0, 300]],
+                     [[510, 0, 0], [510, 800, 0], [510, 800, 300]], [[510, 0, 0], [510, 800, 300], [510, 0, 300]]],
+                    dtype=np.float32)
+    tri = np.concatenate([sc.triangles, wall])
+    mat = np.concatenate([sc.material_ids, np.zeros(4, np.uint16)])
+    s2 = oracle_mod.Scene(tri, mat, sc.absorption)
+    s2.set_objects(np.concatenate([sc.object_ids, np.full(4, 7, np.uint32)]))
+    r2 = s2.update_sound(sc.source, sc.listener, listener_radius=34.0)
+    assert r2["occlusion_attenuation"] == pytest.approx(r["occlusion_attenuation"], rel=1e-5)
+    # every face its own actor: the wall costs two of the ten pass-throughs, still audible ...
+    s2.set_objects(None)
+    assert s2.update_sound(sc.source, sc.listener)["occlusion_attenuation"] > 0.9
+    # ... but six such walls (12 faces) exhaust them: occluded (FSAC.cpp:212)
+    walls = np.concatenate([wall + np.array([20.0 * k, 0, 0], np.float32) for k in range(6)])
+    s3 = oracle_mod.Scene(np.concatenate([sc.triangles, walls]),
+                          np.concatenate([sc.material_ids, np.zeros(24, np.uint16)]), sc.absorption)
+    assert s3.update_sound(sc.source, sc.listener)["occlusion_attenuation"] == 0.0
+    # range cull: travel time > SimulatedDuration returns 0 (FSAC.cpp:171-175 / :260-263)
+    assert s.update_sound(sc.source, sc.listener, raycast_distance=100.0)["occlusion_attenuation"] == 0.0
+
+
+def test_legacy_forward_tracer_statistics(oracle_mod, scene_factory):
+    sc = scene_factory("starter_room", 4)
+    s = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    s.set_objects(sc.object_ids)
+    r = s.update_sound(sc.source, sc.listener)
+    assert 0 < r["rays_reaching_listener"] < 1500 and r["total_energy"] == pytest.approx(r["rays_reaching_listener"] / 1500)
+    assert r["direct_hits"] > 0 and 0 < r["direct_energy_sum"] <= r["direct_hits"]
+    assert 1500 <= r["traces"] <= 1500 * 20 + 10
+    # the initial directions (VRandCone((0,-1,0), PI, PI)) are uniform on the sphere
+    lib = oracle_mod.load()
+    d = (C.c_float * 3)()
+    acc = np.zeros(3)
+    for i in range(4000):
+        lib.fso_legacy_direction(0x5EED, i, d)
+        v = np.array(list(d))
+        assert abs(np.linalg.norm(v) - 1) < 1e-5
+        acc += v
+    assert np.abs(acc / 4000).max() < 0.05
