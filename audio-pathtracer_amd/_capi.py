@@ -39,6 +39,7 @@ EXPORTS = [
     "fs_add_energy_at_delay", "fs_update_energy_buffer", "fs_num_bins", "fs_num_samples", "fs_trace_rays",
     "fs_set_profiling", "fs_get_stats", "fs_reset_stats",
     "fs_sound_params_default", "fs_scene_set_objects", "fs_update_sound", "fs_get_occlusion_attenuation",
+    "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
 ]
 
 
@@ -185,6 +186,9 @@ def load():
         "fs_scene_set_objects": (C.c_int, [vp, vp, i32]),
         "fs_update_sound": (C.c_int, [vp, i32, C.POINTER(SoundParams), C.POINTER(SoundResult)]),
         "fs_get_occlusion_attenuation": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
+        "fs_save_array_to_file": (C.c_int, [f32p, i32, C.c_char_p]),
+        "fs_load_float_array": (C.c_int, [C.c_char_p, f32p, i32, C.POINTER(i32)]),
+        "fs_save_impulse_response": (C.c_int, [vp, i32, i32, C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -220,3 +224,25 @@ def default_params(**kw) -> Params:
         else:
             setattr(p, k, v)
     return p
+
+
+def save_array_to_file(array, path):
+    """SaveArrayToFile (FSAC.cpp:492-505): one SanitizeFloat'ed value per line"""
+    import numpy as np
+    a = np.ascontiguousarray(array, dtype=np.float32).reshape(-1)
+    rc = load().fs_save_array_to_file(a.ctypes.data, a.shape[0], str(path).encode())
+    if rc != OK:
+        raise FrequenSeeError(rc, f"cannot write {path}")
+
+
+def load_float_array(path):
+    """LoadFloatArray (FSAC.cpp:454-490)"""
+    import numpy as np
+    n = C.c_int32()
+    lib = load()
+    rc = lib.fs_load_float_array(str(path).encode(), None, 0, C.byref(n))
+    if rc != OK:
+        raise FrequenSeeError(rc, f"cannot read {path}")
+    out = np.zeros(n.value, dtype=np.float32)
+    lib.fs_load_float_array(str(path).encode(), out.ctypes.data, out.shape[0], C.byref(n))
+    return out

@@ -830,6 +830,79 @@ int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, cons
     return FS_OK;
 }
 
+// ---- f1: text import / export (FSAC.cpp:454-505) ------------------------------------------------------------
+extern "C++" {
+namespace {
+// FString::SanitizeFloat(double, MinFractionalDigits = 1): "%f", trailing zeros trimmed, one fractional digit kept
+std::string sanitize_float(double v) {
+    if (v == 0.0) v = 0.0;  // strip negative zero
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "%f", v);
+    std::string t(buf);
+    bool numeric = !t.empty();
+    for (size_t i = 0; i < t.size(); ++i) {
+        char c = t[i];
+        if (!((c >= '0' && c <= '9') || c == '.' || ((c == '-' || c == '+') && i == 0))) numeric = false;
+    }
+    if (!numeric) return t;  // "nan", "inf": left alone like the engine
+    size_t dot = t.find('.');
+    if (dot == std::string::npos) return t + ".0";
+    size_t end = t.size();
+    while (end > dot + 2 && t[end - 1] == '0') --end;
+    return t.substr(0, end);
+}
+}  // namespace
+}  // extern "C++"
+
+int fs_save_array_to_file(const float* data, int32_t n, const char* path) {
+    if (!path || n < 0 || (n > 0 && !data)) return FS_ERR_INVALID_ARGUMENT;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return FS_ERR_INVALID_ARGUMENT;
+    for (int32_t i = 0; i < n; ++i) {   // FString::Join(Lines, "\n"): no trailing newline
+        std::string s = sanitize_float((double)data[i]);
+        if (i) std::fputc('\n', f);
+        std::fwrite(s.data(), 1, s.size(), f);
+    }
+    std::fclose(f);
+    return FS_OK;
+}
+
+int fs_load_float_array(const char* path, float* out, int32_t cap, int32_t* n_out) {
+    if (!path || !n_out || cap < 0) return FS_ERR_INVALID_ARGUMENT;
+    *n_out = 0;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return FS_ERR_INVALID_ARGUMENT;   // "Failed to load impulse response file" FSAC.cpp:472
+    std::string content;
+    char buf[65536];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) content.append(buf, got);
+    std::fclose(f);
+    int32_t n = 0;
+    size_t pos = 0;
+    while (pos <= content.size()) {
+        size_t nl = content.find('\n', pos);
+        if (nl == std::string::npos) nl = content.size();
+        if (nl > pos) {                   // ParseIntoArray(..., InCullEmpty = true)
+            std::string line = content.substr(pos, nl - pos);
+            float v = (float)std::atof(line.c_str());   // FCString::Atof
+            if (out && n < cap) out[n] = v;
+            ++n;
+        }
+        pos = nl + 1;
+    }
+    *n_out = n;
+    return FS_OK;
+}
+
+int fs_save_impulse_response(fs_context* ctx, fs_source h, int32_t channel, const char* path) {
+    if (!ctx || !path) return FS_ERR_INVALID_ARGUMENT;
+    const float* p = nullptr;
+    int32_t n = 0;
+    int rc = fs_get_impulse_response(ctx, h, channel, &p, &n);
+    if (rc) return rc;
+    return fs_save_array_to_file(p, n, path);
+}
+
 // ---- measurement ----------------------------------------------------------------------------------------------
 int fs_set_profiling(fs_context* ctx, int32_t enabled) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;

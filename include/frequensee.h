@@ -206,6 +206,16 @@ int fs_get_occlusion_attenuation(fs_context* ctx, fs_source src, float* out);
 int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, const float* tmax, int32_t N,
                   int32_t any_hit, int32_t* hit, float* t, int32_t* tri, float* normal);
 
+/* ---- row f1: the reference's only interchange format (one float per line) --------------------------------
+ *      SaveArrayToFile FSAC.cpp:492-505 (FString::SanitizeFloat per value, joined by '\n'),
+ *      LoadFloatArray FSAC.cpp:454-490 (split on '\n' culling empty lines, FCString::Atof per line).
+ *      Host-side utilities; they need no context and no device. */
+int fs_save_array_to_file(const float* data, int32_t n, const char* path);
+/* reads at most cap values into out (out may be NULL to count); *n_out = number of lines parsed */
+int fs_load_float_array(const char* path, float* out, int32_t cap, int32_t* n_out);
+/* "saved_ir.txt": SaveArrayToFile(ImpulseBuffer[channel]) FSAC.cpp:302 */
+int fs_save_impulse_response(fs_context* ctx, fs_source src, int32_t channel, const char* path);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 int fs_set_profiling(fs_context* ctx, int32_t enabled); /* HIP events around the kernels on the stream */
 int fs_get_stats(fs_context* ctx, fs_stats* out);

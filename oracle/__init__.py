@@ -150,6 +150,12 @@ def _bind(lib):
     lib.fso_compute_energy.argtypes = [C.c_void_p, C.POINTER(Params), _f3, _f3, C.c_uint32, C.c_uint32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.POINTER(Counters)]
     lib.fso_reconstruct.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
+    lib.fso_sanitize_float.argtypes = [C.c_double, C.c_char_p, C.c_int32]
+    lib.fso_sanitize_float.restype = C.c_int32
+    lib.fso_save_array_to_file.argtypes = [C.c_void_p, C.c_int32, C.c_char_p]
+    lib.fso_save_array_to_file.restype = C.c_int32
+    lib.fso_load_float_array.argtypes = [C.c_char_p, C.c_void_p, C.c_int32]
+    lib.fso_load_float_array.restype = C.c_int32
     lib.fso_scene_set_objects.argtypes = [C.c_void_p, C.c_void_p]
     lib.fso_sound_params_default.argtypes = [C.POINTER(SoundParams)]
     lib.fso_legacy_direction.argtypes = [C.c_uint64, C.c_uint32, _f3]

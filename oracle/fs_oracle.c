@@ -13,6 +13,7 @@
 #include "fs_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -857,4 +858,65 @@ void fso_update_sound(const fso_scene* s, const fso_sound_params* p, const float
         /* 10 pass-throughs, ignoring the source's own (geometry-less) actor, FSAC.cpp:299 */
         res->occlusion_attenuation = cast_direct(s, p, d, src, p->raycast_distance, 10, 1.0f, FSO_NO_OBJECT, lis, res);
     }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* f1: SaveArrayToFile FSAC.cpp:492-505 / LoadFloatArray FSAC.cpp:454-490                        */
+/* ------------------------------------------------------------------------------------------- */
+/* FString::SanitizeFloat(v, 1): printf("%f"), trim trailing zeros, keep one fractional digit */
+int32_t fso_sanitize_float(double v, char* out, int32_t cap) {
+    char t[512];
+    if (v == 0.0) v = 0.0;
+    snprintf(t, sizeof(t), "%f", v);
+    int numeric = t[0] != 0;
+    for (int i = 0; t[i]; ++i) {
+        char c = t[i];
+        if (!((c >= '0' && c <= '9') || c == '.' || ((c == '-' || c == '+') && i == 0))) numeric = 0;
+    }
+    int len = (int)strlen(t);
+    if (numeric) {
+        char* dot = strchr(t, '.');
+        if (!dot) { strcat(t, ".0"); len += 2; }
+        else { while (len > (int)(dot - t) + 2 && t[len - 1] == '0') t[--len] = 0; }
+    }
+    if (len + 1 > cap) return -1;
+    memcpy(out, t, (size_t)len + 1);
+    return len;
+}
+
+int32_t fso_save_array_to_file(const float* data, int32_t n, const char* path) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    char buf[512];
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t len = fso_sanitize_float((double)data[i], buf, (int32_t)sizeof(buf));
+        if (i) fputc('\n', f);
+        fwrite(buf, 1, (size_t)len, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+int32_t fso_load_float_array(const char* path, float* out, int32_t cap) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    int32_t n = 0;
+    char line[1024];
+    int len = 0, c;
+    while (1) {
+        c = fgetc(f);
+        if (c == '\n' || c == EOF) {
+            if (len > 0) {                       /* ParseIntoArray culls empty lines */
+                line[len] = 0;
+                if (n < cap) out[n] = (float)atof(line);   /* FCString::Atof */
+                ++n;
+            }
+            len = 0;
+            if (c == EOF) break;
+        } else if (len < (int)sizeof(line) - 1) {
+            line[len++] = (char)c;
+        }
+    }
+    fclose(f);
+    return n;
 }
