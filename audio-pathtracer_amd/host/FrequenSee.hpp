@@ -1,0 +1,212 @@
+// FrequenSee.hpp — C++17 host-side mirror of the reference's plugin interface, over the C ABI only
+// (include/frequensee.h; no HIP headers needed by the includer).
+//
+//   frequensee::AudioRayTracingSubsystem  <->  UAudioRayTracingSubsystem  (Public/AudioRayTracingSubsystem.h:86-196)
+//   frequensee::FrequenSeeAudioComponent  <->  UFrequenSeeAudioComponent  (Public/FrequenSeeAudioComponent.h:20-154)
+//
+// Same member names and argument meaning as the reference so a UE shim or a headless
+// harness reads like the original call sites.  check()-style aborts of the reference become
+// std::runtime_error carrying fs_last_error().
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/frequensee.h"
+
+namespace frequensee {
+
+struct FVector {
+    float X = 0, Y = 0, Z = 0;
+};
+
+class AudioRayTracingSubsystem;
+
+// UAcousticGeometryComponent (Public/AcousticGeometryComponent.h:9-22) + the owner's collision triangles
+struct AcousticGeometryComponent {
+    std::vector<float> Triangles;     // [T][3][3], cm
+    std::vector<uint16_t> MaterialId; // [T] index into the material table (UAcousticMaterial per actor)
+    uint32_t Actor = 0;               // AActor the collision belongs to
+};
+
+class FrequenSeeAudioComponent {
+public:
+    explicit FrequenSeeAudioComponent(FVector Location = {}) : Location_(Location) {}
+    FrequenSeeAudioComponent(const FrequenSeeAudioComponent&) = delete;
+    FrequenSeeAudioComponent& operator=(const FrequenSeeAudioComponent&) = delete;
+    ~FrequenSeeAudioComponent();
+
+    void OnRegister(AudioRayTracingSubsystem& SubSys);   // FrequenSeeAudioComponent.cpp:42-52
+    void OnUnregister();                                 // :54-64
+
+    FVector GetComponentLocation() const { return Location_; }
+    void SetComponentLocation(FVector L);
+
+    int NumBins() const;      // FrequenSeeAudioComponent.h:137
+    int NumSamples() const;   // :138
+
+    void FlushEnergyBuffer();                                            // .h:76-79
+    void UpdateEnergyBuffer(const std::vector<float>& NewEnergyValues);  // .h:81-85
+    void AddEnergyAtDelay(float DelaySeconds, float EnergyValue, int Band = 0);   // .h:87-91
+    std::vector<float> EnergyBuffer() const;                             // [bands][NumBins]
+    void ReconstructImpulseResponse();                                   // .cpp:320-380
+    // GetImpulseResponse()[Channel]: pointer into the published front buffer (lock-free, audio thread safe)
+    const float* GetImpulseResponse(int Channel, int* NumSamplesOut = nullptr) const;   // .h:113
+    float GetOcclusionAttenuation() const;                               // .h:112
+    fs_sound_result UpdateSound(uint64_t Seed = 0x5EED);                 // .cpp:283-306
+    void SaveImpulseResponse(const std::string& Path, int Channel = 0) const;   // SaveArrayToFile .cpp:492-505
+
+    bool bApplyReverb = true;   // .h:60
+
+private:
+    friend class AudioRayTracingSubsystem;
+    FVector Location_;
+    AudioRayTracingSubsystem* SubSys_ = nullptr;
+    fs_source Handle_ = -1;
+};
+
+class AudioRayTracingSubsystem {
+public:
+    static constexpr int USED_RAY_COUNT = 1000;   // AudioRayTracingSubsystem.h:176
+
+    explicit AudioRayTracingSubsystem(int NumBands = 1, int Device = 0, int Rank = 0, int WorldSize = 1) {   // Initialize :32-36
+        fs_config c;
+        fs_config_default(&c);
+        c.num_bands = NumBands; c.device = Device; c.rank = Rank; c.world_size = WorldSize;
+        NumBands_ = NumBands;
+        int rc = fs_context_create(&c, &Ctx_);
+        if (rc != FS_OK) {
+            std::string m = Ctx_ ? fs_last_error(Ctx_) : "fs_context_create failed";
+            if (Ctx_) fs_context_destroy(Ctx_);
+            Ctx_ = nullptr;
+            throw std::runtime_error("FrequenSee: " + m);
+        }
+        fs_params_default(&Params);
+        Params.num_rays = 2 * USED_RAY_COUNT;
+    }
+    ~AudioRayTracingSubsystem() { if (Ctx_) fs_context_destroy(Ctx_); }   // Deinitialize :38-42
+    AudioRayTracingSubsystem(const AudioRayTracingSubsystem&) = delete;
+    AudioRayTracingSubsystem& operator=(const AudioRayTracingSubsystem&) = delete;
+
+    void RegisterGeometry(const AcousticGeometryComponent* Comp) { Geometry_.push_back(Comp); Dirty_ = true; }   // .h:99
+    void UnregisterGeometry(const AcousticGeometryComponent* Comp) {                                            // .h:100
+        for (size_t i = 0; i < Geometry_.size(); ++i)
+            if (Geometry_[i] == Comp) { Geometry_.erase(Geometry_.begin() + (long)i); Dirty_ = true; break; }
+    }
+    // UAcousticMaterial table: Absorption [M][bands] (AcousticMaterial.h:22-30)
+    void SetMaterials(const std::vector<float>& Absorption, int NumMaterials) {
+        Absorption_ = Absorption; NumMaterials_ = NumMaterials; Dirty_ = true;
+    }
+    void RegisterSource(FrequenSeeAudioComponent* InComp) {      // .cpp:45-48
+        Check(fs_source_create(Ctx_, &InComp->Handle_));
+        InComp->SubSys_ = this;
+        const FVector L = InComp->Location_;
+        Check(fs_source_set_position(Ctx_, InComp->Handle_, &L.X));
+        ActiveSources.push_back(InComp);
+    }
+    void UnRegisterSource(FrequenSeeAudioComponent* InComp) {    // .cpp:50-53
+        for (size_t i = 0; i < ActiveSources.size(); ++i)
+            if (ActiveSources[i] == InComp) {
+                ActiveSources.erase(ActiveSources.begin() + (long)i);
+                fs_source_destroy(Ctx_, InComp->Handle_);
+                InComp->Handle_ = -1; InComp->SubSys_ = nullptr;
+                break;
+            }
+    }
+    void SetListenerLocation(FVector L) { Check(fs_listener_set_position(Ctx_, &L.X)); }   // PlayerPawn location :287
+
+    // UpdateSource (.cpp:128-195): trace + evaluate + flush + deposit + reconstruct
+    void UpdateSource(FrequenSeeAudioComponent& Src, std::vector<float>* EnergyOut = nullptr) {
+        Commit();
+        const int n = Src.NumBins() * NumBands();
+        if (EnergyOut) EnergyOut->resize((size_t)n);
+        Check(fs_compute_energy_response(Ctx_, Src.Handle_, &Params, EnergyOut ? EnergyOut->data() : nullptr));
+        Check(fs_reconstruct_impulse_response(Ctx_, Src.Handle_, &Params));
+    }
+    void ForceUpdateSources() { for (auto* s : ActiveSources) UpdateSource(*s); }   // .cpp:883-886
+    void Tick(float /*DeltaTime*/) { if (!ActiveSources.empty()) ForceUpdateSources(); }   // .cpp:55-85 (caller drives every frame)
+
+    int NumBands() const { return NumBands_; }
+    fs_context* Context() const { return Ctx_; }
+    void Commit() {
+        if (!Dirty_) return;
+        std::vector<float> xyz; std::vector<uint16_t> mat; std::vector<uint32_t> obj;
+        for (const auto* g : Geometry_) {
+            xyz.insert(xyz.end(), g->Triangles.begin(), g->Triangles.end());
+            mat.insert(mat.end(), g->MaterialId.begin(), g->MaterialId.end());
+            obj.insert(obj.end(), g->MaterialId.size(), g->Actor);
+        }
+        Check(fs_scene_set_triangles(Ctx_, xyz.data(), mat.data(), (int32_t)mat.size()));
+        Check(fs_scene_set_materials(Ctx_, Absorption_.data(), nullptr, nullptr, NumMaterials_,
+                                     NumMaterials_ ? (int32_t)(Absorption_.size() / (size_t)NumMaterials_) : NumBands()));
+        Check(fs_scene_set_objects(Ctx_, obj.data(), (int32_t)obj.size()));
+        Check(fs_scene_commit(Ctx_));
+        Dirty_ = false;
+    }
+    void Check(int rc) const { if (rc != FS_OK) throw std::runtime_error(std::string("FrequenSee: ") + fs_last_error(Ctx_)); }
+
+    fs_params Params;                                   // the constants of AudioRayTracingSubsystem.cpp:282-284, 362-413
+    std::vector<FrequenSeeAudioComponent*> ActiveSources;
+
+private:
+    fs_context* Ctx_ = nullptr;
+    std::vector<const AcousticGeometryComponent*> Geometry_;
+    std::vector<float> Absorption_;
+    int NumMaterials_ = 0;
+    bool Dirty_ = true;
+    int NumBands_ = 1;
+    friend class FrequenSeeAudioComponent;
+};
+
+inline FrequenSeeAudioComponent::~FrequenSeeAudioComponent() { OnUnregister(); }
+inline void FrequenSeeAudioComponent::OnRegister(AudioRayTracingSubsystem& S) { S.RegisterSource(this); }
+inline void FrequenSeeAudioComponent::OnUnregister() { if (SubSys_) SubSys_->UnRegisterSource(this); }
+inline void FrequenSeeAudioComponent::SetComponentLocation(FVector L) {
+    Location_ = L;
+    if (SubSys_) SubSys_->Check(fs_source_set_position(SubSys_->Ctx_, Handle_, &L.X));
+}
+inline int FrequenSeeAudioComponent::NumBins() const { return fs_num_bins(SubSys_->Ctx_); }
+inline int FrequenSeeAudioComponent::NumSamples() const { return fs_num_samples(SubSys_->Ctx_); }
+inline void FrequenSeeAudioComponent::FlushEnergyBuffer() { SubSys_->Check(fs_flush_energy_buffer(SubSys_->Ctx_, Handle_)); }
+inline void FrequenSeeAudioComponent::UpdateEnergyBuffer(const std::vector<float>& V) {
+    SubSys_->Check(fs_update_energy_buffer(SubSys_->Ctx_, Handle_, V.data(), (int32_t)V.size()));
+}
+inline void FrequenSeeAudioComponent::AddEnergyAtDelay(float D, float E, int Band) {
+    SubSys_->Check(fs_add_energy_at_delay(SubSys_->Ctx_, Handle_, Band, D, E));
+}
+inline std::vector<float> FrequenSeeAudioComponent::EnergyBuffer() const {
+    std::vector<float> v((size_t)NumBins() * (size_t)SubSys_->NumBands());
+    SubSys_->Check(fs_get_energy_buffer(SubSys_->Ctx_, Handle_, v.data(), (int32_t)v.size()));
+    return v;
+}
+inline void FrequenSeeAudioComponent::ReconstructImpulseResponse() {
+    SubSys_->Check(fs_reconstruct_impulse_response(SubSys_->Ctx_, Handle_, &SubSys_->Params));
+}
+inline const float* FrequenSeeAudioComponent::GetImpulseResponse(int Channel, int* N) const {
+    const float* p = nullptr;
+    int32_t n = 0;
+    SubSys_->Check(fs_get_impulse_response(SubSys_->Ctx_, Handle_, Channel, &p, &n));
+    if (N) *N = n;
+    return p;
+}
+inline float FrequenSeeAudioComponent::GetOcclusionAttenuation() const {
+    float v = 1.f;
+    SubSys_->Check(fs_get_occlusion_attenuation(SubSys_->Ctx_, Handle_, &v));
+    return v;
+}
+inline fs_sound_result FrequenSeeAudioComponent::UpdateSound(uint64_t Seed) {
+    SubSys_->Commit();
+    fs_sound_params p;
+    fs_sound_params_default(&p);
+    p.seed = Seed;
+    fs_sound_result r{};
+    SubSys_->Check(fs_update_sound(SubSys_->Ctx_, Handle_, &p, &r));
+    return r;
+}
+inline void FrequenSeeAudioComponent::SaveImpulseResponse(const std::string& Path, int Channel) const {
+    SubSys_->Check(fs_save_impulse_response(SubSys_->Ctx_, Handle_, Channel, Path.c_str()));
+}
+
+}  // namespace frequensee

@@ -416,3 +416,26 @@ def test_component_update_sound(pkg, scene_factory):
     r = comp.UpdateSound()
     assert 0.0 < comp.GetOcclusionAttenuation() <= 1.0 and r["traces"] > 1500
     sub.Deinitialize()
+
+
+# ---- C++ host side: the headless harness drives the C ABI without Python -----------------------------------------
+def test_cpp_harness_matches_oracle(pkg, oracle_mod, scene_factory, tmp_path):
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg._capi.LIB_PATH), "fs_harness")
+    out = tmp_path / "saved_ir.txt"
+    r = subprocess.run([exe, "3", "512", "4", str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout)
+    sc = scene_factory("shoebox", 1)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e0 = osc.compute_energy(oracle_mod.default_params(num_pairs=512, depth=4, seed=0x5EED), sc.source, sc.listener)[1]
+    assert j["energy_sum_first_frame"] == pytest.approx(float(e0.sum()), rel=1e-5)
+    e_last = osc.compute_energy(oracle_mod.default_params(num_pairs=512, depth=4, seed=0x5EED + 2),
+                                sc.source, sc.listener)[0]
+    ir_ref = oracle_mod.reconstruct(e_last[0])
+    ir = pkg._capi.load_float_array(out)                      # SaveArrayToFile text: six decimals
+    assert ir.shape == (48000,) and np.abs(ir - ir_ref).max() <= 6e-7 + 1e-5 * np.abs(ir_ref).max()
+    assert j["ir_peak"] == pytest.approx(float(np.abs(ir_ref).max()), rel=1e-4)
+    osc.set_objects(np.zeros(12, np.uint32))
+    assert j["occlusion_attenuation"] == pytest.approx(osc.update_sound(sc.source, sc.listener)["occlusion_attenuation"], rel=1e-5)
