@@ -112,8 +112,10 @@ struct WalkLaunch {
     uint32_t* perm;      // [total] subpath indices by descending length
 };
 constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
+// plan kernels (length-sorted schedule); returns the permutation to walk in, or nullptr for identity
+const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, hipStream_t s);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 hipStream_t s);
+                 const uint32_t* perm, hipStream_t s);
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
                     unsigned* queue_head, hipStream_t s);
 void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,

@@ -955,18 +955,21 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
 
 }  // namespace
 
+const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, hipStream_t s) {
+    uint32_t lanes = 2u * kp.num_local;
+    // length-sorted schedule: only meaningful when roulette can end walks early
+    if (lanes == 0 || !wl.plan || !kp.russian_roulette || kp.depth <= 1 || !wl.len || !wl.perm) return nullptr;
+    uint32_t full = (lanes + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(plan_count_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head);
+    hipLaunchKernelGGL(plan_scatter_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head, wl.perm);
+    return wl.perm;
+}
+
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 hipStream_t s) {
+                 const uint32_t* perm, hipStream_t s) {
     uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
-    // length-sorted schedule: only meaningful when roulette can end walks early
-    const uint32_t* perm = nullptr;
-    if (wl.plan && kp.russian_roulette && kp.depth > 1 && wl.len && wl.perm) {
-        hipLaunchKernelGGL(plan_count_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head);
-        hipLaunchKernelGGL(plan_scatter_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head, wl.perm);
-        perm = wl.perm;
-    }
     if (wl.variant == 0) {
         hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st, perm);
         return;

@@ -49,14 +49,18 @@ class _CudaArray:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def algorithmic_bytes(cnt, rays, bands, depth_segments):
-    """SURVEY.md §8(d) per-frame figure, split per kernel.  cnt = oracle counters for the frame."""
+def algorithmic_bytes(cnt, rays, bands):
+    """SURVEY.md §8(d) per-frame figure, split per kernel.  cnt = the oracle's counters for
+    the frame on its reference BVH2: 32 B per node visit, 48 B per triangle test; per subpath a 24-B terminal
+    state (written by walk, read by connect); per walk segment a 12-B record (length, probability, material)
+    written once and read once for connected pairs; a deposit = fp32 read-modify-write per band."""
     walk_nodes = cnt["node_visits"] - cnt["any_node_visits"]
     walk_tris = cnt["tri_tests"] - cnt["any_tri_tests"]
-    state = rays * (32 + 4 * bands)                       # terminal state written once ...
-    walk = 32 * walk_nodes + 48 * walk_tris + state + 4 * depth_segments
-    connect = (32 * cnt["any_node_visits"] + 48 * cnt["any_tri_tests"] + state  # ... and read once
-               + 4 * depth_segments + 4 * bands * cnt["deposits"] * 2 + 4 * bands * 1000)
+    segments = cnt["closest_rays"]
+    pairs = max(rays // 2, 1)
+    walk = 32 * walk_nodes + 48 * walk_tris + 24 * rays + 12 * segments
+    connect = (32 * cnt["any_node_visits"] + 48 * cnt["any_tri_tests"] + 24 * rays
+               + 12 * segments * cnt["connected"] // pairs + 8 * bands * cnt["deposits"] + 4 * bands * 1000)
     return walk, connect
 
 
@@ -69,6 +73,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fixed-depth", action="store_true", help="Russian roulette off: every subpath takes `depth` segments")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent frames in flight (one context + HIP stream each); 1 = strictly sequential frames")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the extra region that times the same frames with two in flight")
     args = ap.parse_args()
 
     import torch
@@ -91,21 +99,29 @@ def main():
     scene_name, bands, rays_per_gpu, depth = WORKLOADS[args.workload]
     sc = pkg.scenes.by_name(scene_name, bands)
     total_rays = rays_per_gpu * world
-    stream = torch.cuda.current_stream()
-    ctx = pkg.Context(num_bands=bands, device=local_rank, rank=rank, world_size=world, stream=stream.cuda_stream)
-    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
-    ctx.set_listener(sc.listener)
-    src = ctx.create_source(sc.source)
     p = pkg.default_params(num_rays=total_rays, depth=depth, seed=args.seed,
                            russian_roulette=0 if args.fixed_depth else 1)
-    eptr, ebytes = ctx.energy_device_ptr(src)
-    energy_t = torch.as_tensor(_CudaArray(eptr, (bands * ctx.num_bins,)), device=f"cuda:{local_rank}")
+    lanes = []   # one (stream, context, source, energy tensor) per frame in flight
+    for i in range(max(1, args.inflight)):
+        st_i = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
+        c = pkg.Context(num_bands=bands, device=local_rank, rank=rank, world_size=world, stream=st_i.cuda_stream)
+        c.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+        c.set_listener(sc.listener)
+        s_i = c.create_source(sc.source)
+        eptr, ebytes = c.energy_device_ptr(s_i)
+        e_t = torch.as_tensor(_CudaArray(eptr, (bands * c.num_bins,)), device=f"cuda:{local_rank}")
+        lanes.append((st_i, c, s_i, e_t))
+    stream, ctx, src, energy_t = lanes[0]
+    frame_no = [0]
 
     def frame():
-        ctx.compute_energy_response_async(src, p)
+        st_i, c, s_i, e_t = lanes[frame_no[0] % len(lanes)]
+        frame_no[0] += 1
+        c.compute_energy_response_async(s_i, p)
         if world > 1:
-            dist.all_reduce(energy_t)          # RCCL sum of the [bands][bins] fp32 energy buffer
-        ctx.reconstruct_impulse_response_async(src, p)
+            with torch.cuda.stream(st_i):
+                dist.all_reduce(e_t)           # RCCL sum of the [bands][bins] fp32 energy buffer
+        c.reconstruct_impulse_response_async(s_i, p)
 
     def barrier():
         if world > 1:
@@ -114,9 +130,10 @@ def main():
 
     for _ in range(args.warmup):
         frame()
-    ctx.synchronize()
-    ctx.reset_stats()
-    ctx.set_profiling(True)                    # HIP events around the kernels on the launch stream
+    for _, c, _, _ in lanes:
+        c.synchronize()
+        c.reset_stats()
+        c.set_profiling(True)                  # HIP events around the kernels on the launch stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -124,9 +141,17 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.synchronize()
-    st = ctx.stats()
-    ctx.set_profiling(False)
+    st = None
+    for _, c, _, _ in lanes:
+        c.synchronize()
+        s1 = c.stats()
+        c.set_profiling(False)
+        if st is None:
+            st = s1
+        else:
+            for k in ("walk_kernel_ms_sum", "connect_kernel_ms_sum", "reconstruct_ms_sum", "timed_frames",
+                      "timed_reconstructs"):
+                st[k] += s1[k]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,10 +185,37 @@ def main():
                                    f"(source+listener subpaths), depth {depth}, {bands} bands, "
                                    f"{'fixed depth' if args.fixed_depth else 'Russian roulette 0.9'}",
                        "rays_per_frame": total_rays, "pairs_per_frame": total_rays // 2, "depth": depth,
-                       "bands": bands, "triangles": sc.num_triangles, "sharding": f"pairs/{world}"},
+                       "bands": bands, "triangles": sc.num_triangles, "sharding": f"pairs/{world}",
+                       "frames_in_flight": len(lanes)},
             "ir_frames_per_s": args.steps / elapsed,
             "kernel_ms": {"walk": walk_ms, "connect": conn_ms, "reconstruct+publish": rec_ms},
         }
+
+    # ---- extra region (N=1): the same frames with TWO in flight on separate HIP streams — one cfg3 frame
+    #      cannot fill the chip (occupancy decays as walks end); independent frames/sources overlap ------------
+    if world == 1 and len(lanes) == 1 and not args.no_pipelined:
+        st2 = torch.cuda.Stream()
+        c2 = pkg.Context(num_bands=bands, device=local_rank, stream=st2.cuda_stream)
+        c2.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+        c2.set_listener(sc.listener)
+        s2 = c2.create_source(sc.source)
+        both = [(ctx, src), (c2, s2)]
+        k2 = max(2, args.steps)
+        for i in range(6):
+            c, s_i = both[i % 2]
+            c.compute_energy_response_async(s_i, p)
+            c.reconstruct_impulse_response_async(s_i, p)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(k2):
+            c, s_i = both[i % 2]
+            c.compute_energy_response_async(s_i, p)
+            c.reconstruct_impulse_response_async(s_i, p)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        c2.close()
+        result["pipelined"] = {"frames_in_flight": 2, "steps": k2, "value": total_rays * k2 / el2, "unit": "rays/s",
+                               "ms_per_step": 1e3 * el2 / k2, "ir_frames_per_s": k2 / el2}
 
     # ---- oracle leg (rank 0, N=1 only): parity check, algorithmic bytes, CPU baseline ---------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -195,8 +247,7 @@ def main():
                      max(np.sqrt(np.mean(e64[b] ** 2)), 1e-300)) for b in range(bands)]
         if max(rms) > 1e-3:
             raise SystemExit(f"parity failure: relative RMS per band {rms}")
-        seg_entries = cnt["closest_rays"] // 2     # listener-side segment lengths stored for the bin sum
-        wb, cb = algorithmic_bytes(cnt, total_rays, bands, seg_entries)
+        wb, cb = algorithmic_bytes(cnt, total_rays, bands)
         walk_s = 1e-3 * result["kernel_ms"]["walk"]
         achieved = wb / walk_s / 1e9
         traffic = None
@@ -223,7 +274,8 @@ def main():
                             "tri_tests": cnt["tri_tests"]}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    ctx.close()
+    for _, c, _, _ in lanes:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
