@@ -38,7 +38,8 @@ WORKLOADS = {
     # name: (scene, bands, rays per GPU per frame, depth)
     "cfg2_starter_room": ("starter_room", 4, 16384, 8),
     "cfg3_old_mine": ("old_mine", 8, 262144, 8),
-    "cfg4_old_mine_d12": ("old_mine", 8, 131072, 12),
+    "cfg4_old_mine_d12": ("old_mine", 8, 131072, 12),          # cfg4's per-GPU share at 8 GPUs
+    "cfg4_old_mine_1m_d12": ("old_mine", 8, 1048576, 12),      # all of cfg4 on one GPU
 }
 
 
