@@ -117,6 +117,7 @@ class Stats(C.Structure):
         ("connect_kernel_ms_sum", C.c_double),
         ("reconstruct_ms_sum", C.c_double),
         ("timed_frames", C.c_uint64),
+        ("timed_connects", C.c_uint64),
         ("timed_reconstructs", C.c_uint64),
         ("bvh_nodes", C.c_uint32),
         ("triangles", C.c_uint32),

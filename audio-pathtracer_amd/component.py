@@ -167,8 +167,9 @@ class Context:
         self.check(self.lib.fs_get_occlusion_attenuation(self.h, src, C.byref(v)))
         return float(v.value)
 
-    def set_profiling(self, on=True):
-        self.check(self.lib.fs_set_profiling(self.h, int(on)))
+    def set_profiling(self, level=2):
+        """0 off, 1 = HIP events around the dominant (walk) kernel only, 2 = every kernel"""
+        self.check(self.lib.fs_set_profiling(self.h, int(level)))
 
     def stats(self):
         s = _capi.Stats()

@@ -108,12 +108,13 @@ struct WalkLaunch {
     int blocks_per_cu;   // persistent grid = num_cus * blocks_per_cu workgroups (capped by the work)
     unsigned* queue_head;  // frame scratch: [0] subpath queue head, then plan counts + cursors; zero at launch
     int plan;            // 1 = sort subpaths by their (RNG-determined) length before walking
-    uint8_t* len;        // [total] planned length per subpath
-    uint32_t* perm;      // [total] subpath indices by descending length
+    uint8_t* len;        // unused (kept for layout stability)
+    uint32_t* perm;      // [depth + 1][total] subpath indices bucketed by planned length
 };
 constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
-// plan kernels (length-sorted schedule); returns the permutation to walk in, or nullptr for identity
-const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, hipStream_t s);
+// plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
+// nullptr when no plan applies (the caller then clears the energy buffer itself)
+const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words, hipStream_t s);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,

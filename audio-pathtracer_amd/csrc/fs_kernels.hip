@@ -406,12 +406,14 @@ __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathStat
 }
 
 // ---------------------------------------------------------------------------------------------------
-// plan kernels: the number of segments a subpath takes under Russian roulette depends only on the RNG
+// plan_kernel: the number of segments a subpath takes under Russian roulette depends only on the RNG
 // stream (seed, pair, side, bounce) — never on the geometry — so it is known before any ray is traced.
-// plan_count computes every subpath's length and a global length histogram; plan_scatter counting-sorts
-// the subpath indices by DESCENDING length into `perm`.  Walk waves then hold subpaths of equal length:
-// no lane idles because its neighbours' walks ended earlier.  (Order never affects results.)
-//   scratch[0] = subpath queue head (persistent walk), [1, 1+kPlanBuckets) = counts, then cursors.
+// One pass buckets the subpath indices by length: bucket L owns perm[L * total, L * total + count[L])
+// (worst-case capacity, so no prefix pass is needed); workgroups reserve their share of a bucket with one
+// atomicAdd per occupied length.  Walk lanes then read the buckets in DESCENDING length order, so every
+// wave holds walks of equal length and no lane idles because its neighbours' walks ended earlier.
+// (Order never affects results.)  The pass also performs FlushEnergyBuffer (ARTS.cpp:157-161).
+//   scratch[0] = subpath queue head (persistent walk), [1, 1 + kPlanBuckets) = bucket counts.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kPlanBuckets = FS_MAX_DEPTH + 1;
 
@@ -427,59 +429,57 @@ __device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
     return k;
 }
 
-__global__ __launch_bounds__(kBlock) void plan_count_kernel(KParams kp, uint8_t* __restrict__ len,
-                                                            unsigned* __restrict__ scratch) {
-    __shared__ unsigned s_hist[kPlanBuckets];
-    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) s_hist[i] = 0u;
-    __syncthreads();
-    const uint32_t total = 2u * kp.num_local;
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    if (g < total) {
-        const int L = planned_length(g, kp);
-        len[g] = (uint8_t)L;
-        atomicAdd(&s_hist[L], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
-        if (s_hist[i]) atomicAdd(&scratch[1 + i], s_hist[i]);
-}
-
-__global__ __launch_bounds__(kBlock) void plan_scatter_kernel(KParams kp, const uint8_t* __restrict__ len,
-                                                              unsigned* __restrict__ scratch,
-                                                              uint32_t* __restrict__ perm) {
+__global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __restrict__ scratch,
+                                                      uint32_t* __restrict__ perm, float* __restrict__ energy,
+                                                      int energy_words) {
     __shared__ unsigned s_hist[kPlanBuckets];
     __shared__ unsigned s_base[kPlanBuckets];
     for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) s_hist[i] = 0u;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) energy[i] = 0.0f;
     __syncthreads();
     const uint32_t total = 2u * kp.num_local;
     const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
     int L = 0;
     unsigned rank = 0;
     if (g < total) {
-        L = len[g];
+        L = planned_length(g, kp);
         rank = atomicAdd(&s_hist[L], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) {
-        if (s_hist[i]) {
-            unsigned start = 0;                      // buckets in descending length order
-            for (int j = kPlanBuckets - 1; j > i; --j) start += scratch[1 + j];
-            s_base[i] = start + atomicAdd(&scratch[1 + kPlanBuckets + i], s_hist[i]);
-        }
-    }
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
+        if (s_hist[i]) s_base[i] = atomicAdd(&scratch[1 + i], s_hist[i]);
     __syncthreads();
-    if (g < total) perm[s_base[L] + rank] = g;
+    if (g < total) perm[(size_t)L * total + s_base[L] + rank] = g;
+}
+
+// launch slot -> subpath index through the buckets, longest walks first.  s_cnt = bucket counts in LDS.
+__device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, uint32_t total, const unsigned* s_cnt,
+                                                    const uint32_t* __restrict__ perm) {
+    uint32_t acc = 0;
+    for (int L = depth; L > 0; --L) {
+        const uint32_t c = s_cnt[L];
+        if (slot < acc + c) return perm[(size_t)L * total + (slot - acc)];
+        acc += c;
+    }
+    return perm[slot - acc];   // bucket 0
 }
 
 // ---------------------------------------------------------------------------------------------------
 // walk_kernel_simple: one subpath per lane (reference variant)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
     __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ unsigned s_cnt[kPlanBuckets];
+    if (perm) {   // wave-uniform: bucket counts of the plan pass
+        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
+        __syncthreads();
+    }
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= 2u * kp.num_local) return;
-    const uint32_t g = perm ? perm[slot] : slot;   // length-sorted schedule (plan kernels) or identity
+    // length-sorted schedule (plan pass) or identity
+    const uint32_t g = perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot;
     int* stack = &s_stack[threadIdx.x];
     Walker w;
     walker_start(w, g, kp);
@@ -513,6 +513,11 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
                                                                  unsigned* __restrict__ queue_head,
                                                                  const uint32_t* __restrict__ perm) {
     __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ unsigned s_cnt[kPlanBuckets];
+    if (perm) {
+        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = queue_head[1 + i];
+        __syncthreads();
+    }
     int* stack = &s_stack[threadIdx.x];
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t total = 2u * kp.num_local;
@@ -552,7 +557,10 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
                     }
                     if (phase == PH_NEW) {
                         const unsigned my = q_next + (unsigned)__popcll(need & ((1ull << lane) - 1ull));
-                        if (my < q_end) { walker_start(w, perm ? perm[my] : my, kp); phase = PH_NEXT; }
+                        if (my < q_end) {
+                            walker_start(w, perm ? planned_subpath(my, kp.depth, total, s_cnt, perm) : my, kp);
+                            phase = PH_NEXT;
+                        }
                         else if (drained) { phase = PH_IDLE; }
                         // else: stays PH_NEW and is served from the next chunk in the following round
                     }
@@ -955,13 +963,13 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
 
 }  // namespace
 
-const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, hipStream_t s) {
+const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
+                            hipStream_t s) {
     uint32_t lanes = 2u * kp.num_local;
     // length-sorted schedule: only meaningful when roulette can end walks early
-    if (lanes == 0 || !wl.plan || !kp.russian_roulette || kp.depth <= 1 || !wl.len || !wl.perm) return nullptr;
+    if (lanes == 0 || !wl.plan || !kp.russian_roulette || kp.depth <= 1 || !wl.perm) return nullptr;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(plan_count_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head);
-    hipLaunchKernelGGL(plan_scatter_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.len, wl.queue_head, wl.perm);
+    hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, wl.perm, energy, energy_words);
     return wl.perm;
 }
 
@@ -971,7 +979,7 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
     if (wl.variant == 0) {
-        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st, perm);
+        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
         return;
     }
     uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;

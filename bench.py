@@ -134,7 +134,7 @@ def main():
     for _, c, _, _ in lanes:
         c.synchronize()
         c.reset_stats()
-        c.set_profiling(True)                  # HIP events around the kernels on the launch stream
+        c.set_profiling(1)                     # HIP events around the dominant kernel on its launch stream
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -146,29 +146,36 @@ def main():
     for _, c, _, _ in lanes:
         c.synchronize()
         s1 = c.stats()
-        c.set_profiling(False)
+        c.set_profiling(0)
         if st is None:
             st = s1
         else:
-            for k in ("walk_kernel_ms_sum", "connect_kernel_ms_sum", "reconstruct_ms_sum", "timed_frames",
-                      "timed_reconstructs"):
+            for k in ("walk_kernel_ms_sum", "timed_frames"):
                 st[k] += s1[k]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # untimed: the same K frames without the profiling events, to show the events' cost
     e_gpu = ctx.energy_buffer(src)
     ir = ctx.impulse_response(src, 0)
+    # untimed: a few sequential frames with events around EVERY kernel, for the per-kernel breakdown
+    ctx.reset_stats()
+    ctx.set_profiling(2)
+    for _ in range(10):
+        ctx.compute_energy_response_async(src, p)
+        ctx.reconstruct_impulse_response_async(src, p)
+    ctx.synchronize()
+    st_all = ctx.stats()
+    ctx.set_profiling(0)
 
     result = None
     if rank == 0:
         rays_s = total_rays * args.steps / elapsed
         ms_step = 1e3 * elapsed / args.steps
         walk_ms = st["walk_kernel_ms_sum"] / max(st["timed_frames"], 1)
-        conn_ms = st["connect_kernel_ms_sum"] / max(st["timed_frames"], 1)
-        rec_ms = st["reconstruct_ms_sum"] / max(st["timed_reconstructs"], 1)
+        conn_ms = st_all["connect_kernel_ms_sum"] / max(st_all["timed_connects"], 1)
+        rec_ms = st_all["reconstruct_ms_sum"] / max(st_all["timed_reconstructs"], 1)
         result = {
             "metric": "rays/sec + IR-frames/sec (1s IR, depth 8)",
             "value": rays_s,

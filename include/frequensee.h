@@ -99,7 +99,8 @@ typedef struct fs_stats {
     double walk_kernel_ms_last;
     double connect_kernel_ms_sum; /* connect_kernel */
     double reconstruct_ms_sum;    /* reconstruct_kernel + IR publish copy */
-    uint64_t timed_frames;        /* frames contributing to walk/connect sums */
+    uint64_t timed_frames;        /* frames contributing to the walk sum */
+    uint64_t timed_connects;      /* frames contributing to the connect sum (profiling level 2) */
     uint64_t timed_reconstructs;  /* reconstructs contributing to reconstruct_ms_sum */
     uint32_t bvh_nodes;
     uint32_t triangles;
@@ -217,7 +218,8 @@ int fs_load_float_array(const char* path, float* out, int32_t cap, int32_t* n_ou
 int fs_save_impulse_response(fs_context* ctx, fs_source src, int32_t channel, const char* path);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
-int fs_set_profiling(fs_context* ctx, int32_t enabled); /* HIP events around the kernels on the stream */
+/* HIP events on the context's stream: 0 = off, 1 = around the dominant (walk) kernel only, 2 = every kernel */
+int fs_set_profiling(fs_context* ctx, int32_t level);
 int fs_get_stats(fs_context* ctx, fs_stats* out);
 int fs_reset_stats(fs_context* ctx);
 
