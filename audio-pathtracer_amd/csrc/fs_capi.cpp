@@ -29,6 +29,7 @@ struct Source {
     float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
     float* h_ir[kIrRing] = {nullptr, nullptr, nullptr};  // pinned host copies of the channel view
     hipEvent_t ev[kIrRing] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_recon = nullptr;     // reconstruct kernel done -> the copy stream may read d_ir_mono
     uint64_t seq_of[kIrRing] = {0, 0, 0};
     uint64_t enqueued = 0;             // publishes enqueued so far
     std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
@@ -46,6 +47,7 @@ struct fs_context {
     fs_config cfg{};
     int num_bins = 0, num_samples = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // publishes IRs to the host off the compute stream
     bool own_stream = false;
     bool device_ok = false;
     std::string err;
@@ -116,6 +118,7 @@ void free_source(fs_context* ctx, Source* s) {
             if (s->h_ir[i]) (void)hipHostFree(s->h_ir[i]);
             if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
         }
+        if (s->ev_recon) (void)hipEventDestroy(s->ev_recon);
     }
     delete s;
 }
@@ -310,6 +313,8 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
         if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         ctx->own_stream = true;
     }
+    e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate(copy): ") + hipGetErrorString(e));
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0)
         ctx->walk.num_cus = cus;
@@ -329,6 +334,7 @@ int fs_context_destroy(fs_context* ctx) {
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->cfg.device);
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
         resolve_timings(ctx);
         for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
         free_scene(ctx);
@@ -337,6 +343,7 @@ int fs_context_destroy(fs_context* ctx) {
         if (ctx->d_sound) (void)hipFree(ctx->d_sound);
     }
     for (Source* s : ctx->sources) free_source(ctx, s);
+    if (ctx->device_ok && ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->device_ok && ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FS_OK;
@@ -441,6 +448,7 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         std::memset(s->h_ir[i], 0, ib);  // ImpulseBuffer[ch].Init(0, NumSamples) FSAC.cpp:24-28
         if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
+    if ((e = hipEventCreateWithFlags(&s->ev_recon, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     s->alive = true;
     // RegisterSource: ActiveSources.Add (ARTS.cpp:45-48); reuse a dead slot if any
     for (size_t i = 0; i < ctx->sources.size(); ++i)
@@ -454,7 +462,7 @@ int fs_source_destroy(fs_context* ctx, fs_source h) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
-    if (ctx->device_ok) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->device_ok) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_stream); }
     ctx->sources[(size_t)h] = nullptr;  // UnRegisterSource ARTS.cpp:50-53
     free_source(ctx, s);
     return FS_OK;
@@ -598,14 +606,19 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     }
     if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)  // ARTS.cpp:191 literally
         FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+    // the previous publish still reads d_ir_mono on the copy stream: order this reconstruct behind it
+    if (s->enqueued > 0) FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev[(int)(s->enqueued % kIrRing)], 0));
     launch_reconstruct(s->d_energy, B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
                        s->d_ir_mono, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     uint64_t seq = s->enqueued + 1;
     int slot = (int)(seq % kIrRing);
+    // publish off the compute stream: the next frame's kernels do not wait for the PCIe copy
+    FS_HIP(ctx, hipEventRecord(s->ev_recon, ctx->stream));
+    FS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, s->ev_recon, 0));
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
-                               hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->stream));
+                               hipMemcpyDeviceToHost, ctx->copy_stream));
+    FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->copy_stream));
     s->seq_of[slot] = seq;
     s->enqueued = seq;
     if (timed) {
@@ -621,6 +634,7 @@ int fs_synchronize(fs_context* ctx) {
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     for (Source* s : ctx->sources)
         if (s && s->alive) poll_published(s);
     resolve_timings(ctx);
