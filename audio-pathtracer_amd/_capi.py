@@ -40,7 +40,9 @@ EXPORTS = [
     "fs_set_profiling", "fs_get_stats", "fs_reset_stats",
     "fs_sound_params_default", "fs_scene_set_objects", "fs_update_sound", "fs_get_occlusion_attenuation",
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
+    "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
 ]
+REVERB_LITERAL_TAIL = 1
 
 
 class SoundParams(C.Structure):
@@ -190,6 +192,9 @@ def load():
         "fs_save_array_to_file": (C.c_int, [f32p, i32, C.c_char_p]),
         "fs_load_float_array": (C.c_int, [C.c_char_p, f32p, i32, C.POINTER(i32)]),
         "fs_save_impulse_response": (C.c_int, [vp, i32, i32, C.c_char_p]),
+        "fs_reverb_init": (C.c_int, [vp, i32, i32]),
+        "fs_reverb_process": (C.c_int, [vp, i32, f32p, f32p, i32, C.c_uint32]),
+        "fs_reverb_release": (C.c_int, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -167,6 +167,26 @@ class Context:
         self.check(self.lib.fs_get_occlusion_attenuation(self.h, src, C.byref(v)))
         return float(v.value)
 
+    # ---- row f2: reverb plugin convolution ----
+    def reverb_init(self, src, frame_size=1024):
+        self.check(self.lib.fs_reverb_init(self.h, src, frame_size))
+        self._rev_frame = getattr(self, "_rev_frame", {})
+        self._rev_frame[src] = frame_size
+
+    def reverb_process(self, src, audio_interleaved, apply_reverb=True, literal_tail=False):
+        """ProcessSourceAudio (RVB.cpp:118-170): interleaved stereo block in -> convolved block out"""
+        frame = self._rev_frame[src]
+        a = np.ascontiguousarray(audio_interleaved, dtype=np.float32).reshape(-1)
+        if a.shape[0] != 2 * frame:
+            raise ValueError("audio block must hold frame_size * 2 interleaved samples")
+        out = np.empty_like(a)
+        self.check(self.lib.fs_reverb_process(self.h, src, a.ctypes.data, out.ctypes.data, int(apply_reverb),
+                                              _capi.REVERB_LITERAL_TAIL if literal_tail else 0))
+        return out
+
+    def reverb_release(self, src):
+        self.check(self.lib.fs_reverb_release(self.h, src))
+
     def set_profiling(self, level=2):
         """0 off, 1 = HIP events around the dominant (walk) kernel only, 2 = every kernel"""
         self.check(self.lib.fs_set_profiling(self.h, int(level)))
@@ -359,3 +379,25 @@ class AudioRayTracingSubsystem:
             return False, 0.0, -1, np.zeros(3, np.float32)
         hit, t, tri, n = self.ctx.trace_rays(s[None], (d / ln)[None], ln)
         return bool(hit[0]), float(t[0]), int(tri[0]), n[0]
+
+
+class FrequenSeeAudioReverbPlugin:
+    """FFrequenSeeAudioReverbPlugin (Private/FrequenSeeAudioReverbPlugin.h:46-47, .cpp:74-213): per audio
+    callback, convolve the last IR-1 + BufferLength samples of a source with its impulse response."""
+
+    def __init__(self, subsystem: AudioRayTracingSubsystem):
+        self.ctx = subsystem.ctx
+        self.FrameSize = 1024      # AudioCallbackBufferFrameSize, Config/DefaultEngine.ini:13
+
+    def Initialize(self, BufferLength=1024):
+        self.FrameSize = int(BufferLength)
+
+    def OnInitSource(self, component: FrequenSeeAudioComponent):
+        self.ctx.reverb_init(component._src, self.FrameSize)
+
+    def OnReleaseSource(self, component: FrequenSeeAudioComponent):
+        self.ctx.reverb_release(component._src)
+
+    def ProcessSourceAudio(self, component: FrequenSeeAudioComponent, AudioBuffer, literal_tail=False):
+        return self.ctx.reverb_process(component._src, AudioBuffer, apply_reverb=component.bApplyReverb,
+                                       literal_tail=literal_tail)

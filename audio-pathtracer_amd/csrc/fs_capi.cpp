@@ -33,6 +33,9 @@ struct Source {
     uint64_t seq_of[kIrRing] = {0, 0, 0};
     uint64_t enqueued = 0;             // publishes enqueued so far
     std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
+    // reverb (row f2): history rings [2][kReverbRing], staging buffers, write head
+    float* d_ring = nullptr; float* d_rev_in = nullptr; float* d_rev_cur = nullptr; float* d_rev_out = nullptr;
+    unsigned rev_head = 0; int rev_frame = 0;
     float occlusion = 1.0f;            // OcclusionAttenuation FSAC.h:130 (1.f until the first UpdateSound)
 };
 
@@ -119,6 +122,10 @@ void free_source(fs_context* ctx, Source* s) {
             if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
         }
         if (s->ev_recon) (void)hipEventDestroy(s->ev_recon);
+        if (s->d_ring) (void)hipFree(s->d_ring);
+        if (s->d_rev_in) (void)hipFree(s->d_rev_in);
+        if (s->d_rev_cur) (void)hipFree(s->d_rev_cur);
+        if (s->d_rev_out) (void)hipFree(s->d_rev_out);
     }
     delete s;
 }
@@ -920,6 +927,62 @@ int fs_save_impulse_response(fs_context* ctx, fs_source h, int32_t channel, cons
     int rc = fs_get_impulse_response(ctx, h, channel, &p, &n);
     if (rc) return rc;
     return fs_save_array_to_file(p, n, path);
+}
+
+// ---- f2: reverb convolution (RVB.cpp:74-213) ---------------------------------------------------------------------
+int fs_reverb_init(fs_context* ctx, fs_source h, int32_t frame_size) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (frame_size < 1 || frame_size > 16384 || ctx->num_samples - 1 > kReverbRing)
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad reverb frame size / IR longer than the history ring");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->d_ring) { (void)hipFree(s->d_ring); (void)hipFree(s->d_rev_in); (void)hipFree(s->d_rev_cur); (void)hipFree(s->d_rev_out); }
+    s->d_ring = s->d_rev_in = s->d_rev_cur = s->d_rev_out = nullptr;
+    FS_HIP(ctx, hipMalloc((void**)&s->d_ring, sizeof(float) * 2 * kReverbRing));
+    FS_HIP(ctx, hipMalloc((void**)&s->d_rev_in, sizeof(float) * 2 * (size_t)frame_size));
+    FS_HIP(ctx, hipMalloc((void**)&s->d_rev_cur, sizeof(float) * 2 * (size_t)frame_size));
+    FS_HIP(ctx, hipMalloc((void**)&s->d_rev_out, sizeof(float) * 2 * (size_t)frame_size));
+    FS_HIP(ctx, hipMemsetAsync(s->d_ring, 0, sizeof(float) * 2 * kReverbRing, ctx->stream));   // SetNumZeroed
+    s->rev_head = 0;
+    s->rev_frame = frame_size;
+    return FS_OK;
+}
+
+int fs_reverb_process(fs_context* ctx, fs_source h, const float* in, float* out, int32_t apply_reverb, uint32_t flags) {
+    if (!ctx || !in || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (!s->d_ring) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_reverb_init has not been called for this source");
+    const int frame = s->rev_frame;
+    if (!apply_reverb) {   // bApplyReverb == false: RVB.cpp:128-132
+        std::memcpy(out, in, sizeof(float) * 2 * (size_t)frame);
+        return FS_OK;
+    }
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipMemcpyAsync(s->d_rev_in, in, sizeof(float) * 2 * (size_t)frame, hipMemcpyHostToDevice, ctx->stream));
+    launch_reverb(s->d_ir_mono, ctx->num_samples, s->d_ring, s->rev_head, s->d_rev_in, s->d_rev_cur, s->d_rev_out, frame,
+                  (flags & FS_REVERB_LITERAL_TAIL) ? 1 : 0, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    s->rev_head += (unsigned)frame;
+    FS_HIP(ctx, hipMemcpyAsync(out, s->d_rev_out, sizeof(float) * 2 * (size_t)frame, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+int fs_reverb_release(fs_context* ctx, fs_source h) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (s->d_ring && ctx->device_ok) {
+        FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+        FS_HIP(ctx, hipMemsetAsync(s->d_ring, 0, sizeof(float) * 2 * kReverbRing, ctx->stream));
+        s->rev_head = 0;
+    }
+    return FS_OK;
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------------

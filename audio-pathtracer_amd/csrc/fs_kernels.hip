@@ -943,6 +943,86 @@ __global__ __launch_bounds__(kBlock) void update_sound_kernel(DeviceScene sc, So
     atomicAdd(&acc->traces, traces);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Row f2 — the reverb plugin's per-callback convolution (FFrequenSeeAudioReverbPlugin::ProcessSourceAudio,
+// FrequenSeeAudioReverbPlugin.cpp:118-170, ConvolveFFT :172-213).  The reference zero-pads the last
+// 47 999 + 1 024 samples and the 48 000-tap IR to 65 536 and multiplies three KissFFT spectra; only output
+// samples [47 999, 49 023) are kept, for which the circular product equals the plain convolution
+//   out[s] = sum_k IR[k] * u[47 999 + s - k].
+// On this chip 2 x 1024 x 48 000 MACs are a few microseconds of fp32 FMA, so the kernel evaluates that sum
+// directly (no FFT, no 65 536-point scratch, deterministic order): thread t owns a contiguous 192-tap slice
+// and slides a 31-sample register window over it (47 loads per 256 FMAs), partial sums meet in LDS.
+//   u[j] = j < tail ? ring[(head - tail + j) & mask] : cur[j - tail]
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRevOut = 16;      // outputs per workgroup
+constexpr int kRevRing = 65536;  // history ring length per channel (power of two >= 47 999)
+
+__global__ void reverb_prepare_kernel(const float* __restrict__ in, float* __restrict__ cur, int frame, int literal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame) return;
+    // RVB.cpp:147-148 copies the first `frame` floats of the INTERLEAVED buffer into both mono tails
+    cur[i] = literal ? in[i] : in[2 * i];
+    cur[frame + i] = literal ? in[i] : in[2 * i + 1];
+}
+
+__global__ __launch_bounds__(kBlock) void reverb_conv_kernel(const float* __restrict__ ir, int ir_size,
+                                                             const float* __restrict__ ring, unsigned head,
+                                                             const float* __restrict__ cur, int frame,
+                                                             float* __restrict__ out_interleaved) {
+    __shared__ float s_part[kRevOut][kBlock + 1];
+    const int ch = blockIdx.y;
+    const int s0 = blockIdx.x * kRevOut;
+    const int tail = ir_size - 1;
+    const float* rg = ring + (size_t)ch * kRevRing;
+    const float* cu = cur + (size_t)ch * frame;
+    const unsigned base = head - (unsigned)tail;   // ring index of u[0]
+    const int slice = ((ir_size + kBlock - 1) / kBlock + 15) & ~15;
+    const int k0 = (int)threadIdx.x * slice;
+    const int k1 = min(k0 + slice, ir_size);
+    float acc[kRevOut];
+#pragma unroll
+    for (int o = 0; o < kRevOut; ++o) acc[o] = 0.0f;
+    for (int kb = k0; kb < k1; kb += 16) {
+        float w[31], h[16];
+        const int j0 = tail + s0 - kb - 15;   // u index of w[0]
+#pragma unroll
+        for (int i = 0; i < 31; ++i) {
+            const int j = j0 + i;
+            float v = 0.0f;
+            if (j >= 0 && j < tail + frame) v = j < tail ? rg[(base + (unsigned)j) & (unsigned)(kRevRing - 1)] : cu[j - tail];
+            w[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[i] = (kb + i) < ir_size ? ir[kb + i] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int o = 0; o < kRevOut; ++o) acc[o] = fmaf(h[i], w[15 - i + o], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < kRevOut; ++o) s_part[o][threadIdx.x] = acc[o];
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int o = 0; o < kRevOut; ++o) s_part[o][threadIdx.x] += s_part[o][threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x < kRevOut && s0 + (int)threadIdx.x < frame) {
+        float v = s_part[threadIdx.x][0];
+        v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);                 // FMath::Clamp RVB.cpp:165-167, MixAlpha = 1
+        out_interleaved[2 * (s0 + (int)threadIdx.x) + ch] = v;
+    }
+}
+
+// AudioTailBuffer{Left,Right}.AddSamples(in, frame, ch, 2)  RVB.cpp:144-145
+__global__ void reverb_push_kernel(const float* __restrict__ in, float* __restrict__ ring, unsigned head, int frame) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame) return;
+    ring[(head + (unsigned)i) & (unsigned)(kRevRing - 1)] = in[2 * i];
+    ring[kRevRing + ((head + (unsigned)i) & (unsigned)(kRevRing - 1))] = in[2 * i + 1];
+}
+
 // AddEnergyAtDelay on the device-resident buffer (FSAC.h:87-91)
 __global__ void add_energy_kernel(float* row, int nb, float delay, float e) {
     float x = (delay * 1000.f) / 1.0f;
@@ -1021,6 +1101,15 @@ void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, co
 void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, hipStream_t s) {
     int lanes = sp.raycasts_per_tick + 1;
     hipLaunchKernelGGL(update_sound_kernel, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sc, sp, acc);
+}
+
+void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
+                   int frame, int literal_tail, hipStream_t s) {
+    const int tb = 256;
+    hipLaunchKernelGGL(reverb_prepare_kernel, dim3((frame + tb - 1) / tb), dim3(tb), 0, s, in, cur, frame, literal_tail);
+    hipLaunchKernelGGL(reverb_conv_kernel, dim3((frame + kRevOut - 1) / kRevOut, 2), dim3(kBlock), 0, s, ir, ir_size,
+                       ring, head, cur, frame, out);
+    hipLaunchKernelGGL(reverb_push_kernel, dim3((frame + tb - 1) / tb), dim3(tb), 0, s, in, ring, head, frame);
 }
 
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s) {

@@ -217,6 +217,16 @@ int fs_load_float_array(const char* path, float* out, int32_t cap, int32_t* n_ou
 /* "saved_ir.txt": SaveArrayToFile(ImpulseBuffer[channel]) FSAC.cpp:302 */
 int fs_save_impulse_response(fs_context* ctx, fs_source src, int32_t channel, const char* path);
 
+/* ---- row f2: the reverb plugin's per-callback convolution (audio render thread) --------------------------
+ *      FFrequenSeeAudioReverbPlugin::Initialize/OnInitSource (RVB.cpp:74-109), ProcessSourceAudio (:118-170),
+ *      ConvolveFFT (:172-213), FCircularAudioBuffer (CircularBuffer.cpp).  RVB.cpp =
+ *      Private/FrequenSeeAudioReverbPlugin.cpp.  The source's most recent impulse response is used on the device. */
+#define FS_REVERB_LITERAL_TAIL 1u /* RVB.cpp:147-148 literally: the interleaved buffer's first `frame` floats feed both channels */
+int fs_reverb_init(fs_context* ctx, fs_source src, int32_t frame_size /* BufferLength, 1024 */);
+/* in/out: interleaved stereo [frame_size * 2]; apply_reverb == 0 is the bApplyReverb bypass (memcpy, RVB.cpp:128-132) */
+int fs_reverb_process(fs_context* ctx, fs_source src, const float* in, float* out, int32_t apply_reverb, uint32_t flags);
+int fs_reverb_release(fs_context* ctx, fs_source src); /* OnReleaseSource: ClearBuffers */
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* HIP events on the context's stream: 0 = off, 1 = around the dominant (walk) kernel only, 2 = every kernel */
 int fs_set_profiling(fs_context* ctx, int32_t level);

@@ -316,3 +316,53 @@ def add_energy_at_delay(buf, delay, e, bin_size_ms=1, lib=None):
     lib = lib or load()
     assert buf.dtype == np.float32 and buf.flags.c_contiguous
     return lib.fso_add_energy_at_delay(buf.ctypes.data, buf.shape[0], bin_size_ms, delay, e)
+
+
+# ---- row f2: reverb oracle built around the reference's own KissFFT (oracle/_ref, see oracle/Makefile) ----------
+_REF_SO = os.path.join(_HERE, "_ref", "libfs_reverb_ref.so")
+_KISS_DIR = "/root/reference/Plugins/FrequenSee/Source/FrequenSee/Private/FrequenSeeFFTConvolver/KissFFT"
+
+
+def build_ref() -> str | None:
+    """Compile oracle/_ref from the reference's KissFFT sources where they lie (only possible where
+    /root/reference exists; the GPU box uses the prebuilt .so)."""
+    if os.path.isdir(_KISS_DIR):
+        subprocess.run(["make", "-s", "-C", _HERE, "_ref"], check=True)
+    return _REF_SO if os.path.exists(_REF_SO) else None
+
+
+class ReverbRef:
+    """FFrequenSeeAudioReverbPlugin::ProcessSourceAudio restated around the reference's KissFFT."""
+
+    def __init__(self, sample_rate=48000, simulated_duration=1.0, frame_size=1024):
+        so = _REF_SO if os.path.exists(_REF_SO) else build_ref()
+        if not so:
+            raise FileNotFoundError("oracle/_ref/libfs_reverb_ref.so missing and /root/reference not present")
+        lib = C.CDLL(so)
+        lib.fso_reverb_create.restype = C.c_void_p
+        lib.fso_reverb_create.argtypes = [C.c_int32, C.c_float, C.c_int32]
+        lib.fso_reverb_destroy.argtypes = [C.c_void_p]
+        lib.fso_reverb_fft_size.argtypes = [C.c_void_p]
+        lib.fso_reverb_fft_size.restype = C.c_int32
+        lib.fso_reverb_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        self.lib = lib
+        self.frame = frame_size
+        self.h = lib.fso_reverb_create(sample_rate, simulated_duration, frame_size)
+        self.fft_size = lib.fso_reverb_fft_size(self.h)
+
+    def process(self, ir_l, ir_r, audio_interleaved, apply_reverb=True, literal_tail=False):
+        a = np.ascontiguousarray(audio_interleaved, dtype=np.float32).reshape(-1)
+        il = np.ascontiguousarray(ir_l, dtype=np.float32)
+        ir = np.ascontiguousarray(ir_r, dtype=np.float32)
+        out = np.zeros_like(a)
+        self.lib.fso_reverb_process(self.h, il.ctypes.data, ir.ctypes.data, a.ctypes.data, out.ctypes.data,
+                                    int(apply_reverb), int(literal_tail))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.fso_reverb_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
