@@ -77,7 +77,7 @@ struct fs_context {
     size_t cap_lanes = 0, cap_seg = 0;
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
-    WalkLaunch walk{0, 256, 2, nullptr, 1, nullptr, nullptr};
+    WalkLaunch walk{0, 256, 2, nullptr, 1, nullptr};
     int refill_threshold = 16;
 
     // measurement
@@ -144,9 +144,8 @@ void free_state(fs_context* ctx) {
     if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
     if (ctx->st.seg_np) (void)hipFree(ctx->st.seg_np);
     if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
-    if (ctx->walk.len) (void)hipFree(ctx->walk.len);
     if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
-    ctx->walk.len = nullptr; ctx->walk.perm = nullptr;
+    ctx->walk.perm = nullptr;
     ctx->st = SubpathState{};
     ctx->cap_lanes = ctx->cap_seg = 0;
 }
@@ -204,10 +203,9 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int depth) {
     if (lanes > ctx->cap_lanes) {
         if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
         if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
-        if (ctx->walk.len) (void)hipFree(ctx->walk.len);
         if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
         ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr;
-        ctx->walk.len = nullptr; ctx->walk.perm = nullptr;
+        ctx->walk.perm = nullptr;
         ctx->cap_lanes = 0;
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * lanes));
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * lanes));
@@ -350,8 +348,10 @@ int fs_context_destroy(fs_context* ctx) {
         if (ctx->d_sound) (void)hipFree(ctx->d_sound);
     }
     for (Source* s : ctx->sources) free_source(ctx, s);
-    if (ctx->device_ok && ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-    if (ctx->device_ok && ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    // streams exist even when a later step of fs_context_create failed (device_ok == false)
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (!ctx->device_ok && ctx->walk.queue_head) (void)hipFree(ctx->walk.queue_head);
     delete ctx;
     return FS_OK;
 }

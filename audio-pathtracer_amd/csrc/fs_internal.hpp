@@ -108,7 +108,6 @@ struct WalkLaunch {
     int blocks_per_cu;   // persistent grid = num_cus * blocks_per_cu workgroups (capped by the work)
     unsigned* queue_head;  // frame scratch: [0] subpath queue head, then plan counts + cursors; zero at launch
     int plan;            // 1 = sort subpaths by their (RNG-determined) length before walking
-    uint8_t* len;        // unused (kept for layout stability)
     uint32_t* perm;      // [depth + 1][total] subpath indices bucketed by planned length
 };
 constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);

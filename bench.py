@@ -91,10 +91,17 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    # rehearsal switches (never set by the driver): run the N>1 control flow on ONE GPU with gloo
+    backend = os.environ.get("FS_BENCH_BACKEND", "nccl")
+    if os.environ.get("FS_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = graft.load_package()
     scene_name, bands, rays_per_gpu, depth = WORKLOADS[args.workload]
