@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Row f2 timing: one audio callback (1024 stereo frames, 48 000-tap IR) through fs_reverb_process (HIP direct
 convolution, includes the 8 KB H2D/D2H round trip and the stream sync the audio thread needs) against the
-reference's own KissFFT path (oracle/_ref) on one host core.  usage: python profiles/measure_reverb.py"""
+reference's own KissFFT path (oracle/_ref) on one host core.  usage: python tests/measure_reverb.py   (lives under tests/: it loads the oracle)"""
 import json
 import os
 import sys
