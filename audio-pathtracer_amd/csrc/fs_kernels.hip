@@ -25,6 +25,9 @@ namespace {
 constexpr float kPi = 3.1415926535897932f;
 constexpr uint32_t kNoMat = FS_NO_MATERIAL;
 constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
+#ifdef FS_TRAV_STATS
+__device__ unsigned long long g_trav_stats[8];   // [0] step calls, [1] node iterations, [2] node lanes, [3] tri iterations, [4] tri lanes
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // RNG: Philox4x32-10, counter = (pair, bounce<<1|side, block, 'FS01'), key = seed
@@ -204,6 +207,16 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         if (T.sp > 0) { --T.sp; T.cur = stack[T.sp * kBlock]; } else { T.cur = kDone; }
     }
     const bool is_tri = T.tri_i < T.tri_n;
+#ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.sh): SIMD occupancy of the two step kinds
+    {
+        const unsigned long long mt = __ballot(is_tri), mn = __ballot(!is_tri && T.cur >= 0);
+        if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(true)) - 1)) {
+            atomicAdd(&g_trav_stats[0], 1ull);
+            if (mn) { atomicAdd(&g_trav_stats[1], 1ull); atomicAdd(&g_trav_stats[2], (unsigned long long)__popcll(mn)); }
+            if (mt) { atomicAdd(&g_trav_stats[3], 1ull); atomicAdd(&g_trav_stats[4], (unsigned long long)__popcll(mt)); }
+        }
+    }
+#endif
     if (!is_tri && T.cur < 0) return;  // nothing left for this lane
     const float4* rec = is_tri ? reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)T.tri_i
                                : reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)T.cur;
@@ -1111,6 +1124,13 @@ void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, con
                        ring, head, cur, frame, out);
     hipLaunchKernelGGL(reverb_push_kernel, dim3((frame + tb - 1) / tb), dim3(tb), 0, s, in, ring, head, frame);
 }
+
+#ifdef FS_TRAV_STATS
+extern "C" void fs_debug_trav_stats(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof(z)); }
+}
+#endif
 
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s) {
     hipLaunchKernelGGL(add_energy_kernel, dim3(1), dim3(1), 0, s, energy_row, num_bins, delay_s, e);
