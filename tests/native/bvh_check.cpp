@@ -1,0 +1,125 @@
+// bvh_check.cpp — host-only unit test of the product's BVH builder (audio-pathtracer_amd/csrc/fs_bvh.cpp),
+// compiled with g++ -fsanitize=address,undefined by tests/test_native_sanitizers.py.  Checks the invariants the
+// kernels rely on: stack bound, leaf sizes, every triangle referenced exactly once, and CONSERVATIVE boxes —
+// the decoded 8-bit child box of every node contains every triangle vertex below it (this is what makes the
+// closest hit independent of the tree).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../audio-pathtracer_amd/csrc/fs_internal.hpp"
+
+using namespace fs;
+
+static int fails = 0;
+#define CHECK(c, ...) do { if (!(c)) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); ++fails; } } while (0)
+
+struct Box { float lo[3], hi[3]; };
+
+static void decode(const NodeQ4& n, int c, Box& b) {
+    const uint32_t lo4[3] = {n.lox, n.loy, n.loz}, hi4[3] = {n.hix, n.hiy, n.hiz};
+    const float org[3] = {n.ox, n.oy, n.oz};
+    for (int k = 0; k < 3; ++k) {
+        int e = (int)((n.exps >> (8 * k)) & 0xFF) - 127;
+        float step = std::ldexp(1.0f, e);
+        b.lo[k] = org[k] + (float)((lo4[k] >> (8 * c)) & 0xFF) * step;
+        b.hi[k] = org[k] + (float)((hi4[k] >> (8 * c)) & 0xFF) * step;
+    }
+}
+
+// returns the tight bounds of everything below `ref`, checks containment on the way up
+static void walk(const HostBVH& bvh, int32_t ref, Box& out, std::vector<int>& seen, int depth, int& max_pending, int pending) {
+    for (int k = 0; k < 3; ++k) { out.lo[k] = INFINITY; out.hi[k] = -INFINITY; }
+    if (ref < 0) {
+        int code = ~ref, first = code >> 2, cnt = (code & 3) + 1;
+        CHECK(first >= 0 && first + cnt <= (int)bvh.tris.size(), "leaf range %d+%d", first, cnt);
+        for (int i = first; i < first + cnt && i < (int)bvh.tris.size(); ++i) {
+            seen[i]++;
+            const Tri64& t = bvh.tris[i];
+            float v[3][3] = {{t.a.x, t.a.y, t.a.z},
+                             {t.a.x + t.a.w, t.a.y + t.b.x, t.a.z + t.b.y},
+                             {t.a.x + t.b.z, t.a.y + t.b.w, t.a.z + t.c.x}};
+            for (auto& p : v) for (int k = 0; k < 3; ++k) { out.lo[k] = std::fmin(out.lo[k], p[k]); out.hi[k] = std::fmax(out.hi[k], p[k]); }
+        }
+        return;
+    }
+    CHECK(ref < (int)bvh.nodes.size(), "node index %d", ref);
+    CHECK(depth < 64, "runaway depth");
+    const NodeQ4& n = bvh.nodes[ref];
+    int nchild = 0;
+    for (int c = 0; c < 4; ++c) {
+        Box q; decode(n, c, q);
+        bool empty = q.lo[0] > q.hi[0] && q.lo[1] > q.hi[1] && q.lo[2] > q.hi[2];
+        if (empty) continue;
+        ++nchild;
+    }
+    max_pending = std::max(max_pending, pending + nchild - 1);
+    for (int c = 0; c < 4; ++c) {
+        Box q; decode(n, c, q);
+        bool empty = q.lo[0] > q.hi[0] && q.lo[1] > q.hi[1] && q.lo[2] > q.hi[2];
+        if (empty) continue;
+        Box sub;
+        walk(bvh, n.child[c], sub, seen, depth + 1, max_pending, pending + nchild - 1);
+        for (int k = 0; k < 3; ++k) {
+            CHECK(q.lo[k] <= sub.lo[k] && q.hi[k] >= sub.hi[k], "node %d child %d axis %d: box [%g,%g] does not contain [%g,%g]",
+                  ref, c, k, q.lo[k], q.hi[k], sub.lo[k], sub.hi[k]);
+            CHECK(sub.lo[k] - q.lo[k] >= 0.005f && q.hi[k] - sub.hi[k] >= 0.005f, "padding lost at node %d child %d", ref, c);
+            out.lo[k] = std::fmin(out.lo[k], sub.lo[k]); out.hi[k] = std::fmax(out.hi[k], sub.hi[k]);
+        }
+    }
+}
+
+static void run(const char* name, const std::vector<float>& xyz) {
+    int T = (int)(xyz.size() / 9);
+    std::vector<uint16_t> mat((size_t)T, 0);
+    HostBVH bvh;
+    build_bvh(xyz.data(), mat.data(), nullptr, T, bvh);
+    CHECK((int)bvh.tris.size() == T, "%s: tris %zu != %d", name, bvh.tris.size(), T);
+    if (T == 0) { CHECK(bvh.nodes.empty(), "empty scene has nodes"); return; }
+    CHECK(!bvh.nodes.empty(), "%s: no nodes", name);
+    CHECK(bvh.stack_need <= kStackDepth, "%s: stack_need %d", name, bvh.stack_need);
+    std::vector<int> seen((size_t)T, 0);
+    Box all; int max_pending = 0;
+    walk(bvh, 0, all, seen, 0, max_pending, 0);
+    for (int i = 0; i < T; ++i) CHECK(seen[i] == 1, "%s: triangle slot %d referenced %d times", name, i, seen[i]);
+    CHECK(max_pending <= bvh.stack_need, "%s: pending %d > stack_need %d", name, max_pending, bvh.stack_need);
+    std::vector<int> ids((size_t)T, 0);
+    for (const Tri64& t : bvh.tris) { uint32_t id; std::memcpy(&id, &t.c.z, 4); CHECK(id < (uint32_t)T, "id"); if (id < (uint32_t)T) ids[id]++; }
+    for (int i = 0; i < T; ++i) CHECK(ids[i] == 1, "%s: input triangle %d appears %d times", name, i, ids[i]);
+    std::printf("%-22s T=%-6d nodes=%-6zu depth=%-3d stack_need=%-3d ok\n", name, T, bvh.nodes.size(), bvh.max_depth, bvh.stack_need);
+}
+
+int main() {
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    auto soup = [&](int T, float extent, float size) {
+        std::vector<float> v;
+        for (int t = 0; t < T; ++t) {
+            float c[3] = {U(rng) * extent, U(rng) * extent, U(rng) * extent * 0.3f};
+            for (int k = 0; k < 9; ++k) v.push_back(c[k % 3] + (U(rng) - 0.5f) * size);
+        }
+        return v;
+    };
+    run("empty", {});
+    run("one", soup(1, 100, 10));
+    run("four", soup(4, 100, 10));
+    run("five", soup(5, 100, 10));
+    run("hundred", soup(100, 1000, 50));
+    run("20k clustered", soup(20000, 12000, 30));
+    run("2k huge coords", soup(2000, 900000, 500));
+    std::vector<float> same;
+    for (int t = 0; t < 300; ++t) { const float p[9] = {0, 0, 0, 10, 0, 0, 0, 10, 0}; same.insert(same.end(), p, p + 9); }
+    run("300 identical", same);
+    std::vector<float> line;   // centroids on a line, degenerate (zero-area) triangles included
+    for (int t = 0; t < 500; ++t) { float x = (float)t; const float p[9] = {x, 0, 0, x + 1, 0, 0, x + 2, 0, 0}; line.insert(line.end(), p, p + 9); }
+    run("500 colinear", line);
+    std::vector<float> chain;  // adversarial for depth: exponentially spaced sizes
+    for (int t = 0; t < 2000; ++t) { float s = std::pow(1.01f, (float)t); const float p[9] = {s, 0, 0, s, s * 0.01f, 0, s, 0, s * 0.01f}; chain.insert(chain.end(), p, p + 9); }
+    run("2000 geometric", chain);
+    if (fails) { std::printf("%d failures\n", fails); return 1; }
+    std::printf("all BVH invariants hold\n");
+    return 0;
+}

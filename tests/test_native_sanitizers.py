@@ -1,0 +1,29 @@
+"""Native code under AddressSanitizer + UBSan on the CPU build (GPU sanitizers are not available on the pool):
+the oracle's entry points, and the product's host-side BVH builder with its invariants — leaf sizes, every
+triangle referenced once, traversal-stack bound, and conservative (padded, outward-quantised) child boxes."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+
+
+def test_oracle_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "oracle_san"
+    subprocess.run(["gcc", "-O1", "-std=c11", "-ffp-contract=off", *SAN, "-o", str(exe),
+                    os.path.join(ROOT, "tests/native/oracle_san.c"), os.path.join(ROOT, "oracle/fs_oracle.c"), "-lm"],
+                   check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "connected=" in r.stdout and "runtime error" not in r.stderr
+
+
+def test_bvh_builder_invariants_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "bvh_check"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    *SAN, "-Wno-unused-result", "-o", str(exe), os.path.join(ROOT, "tests/native/bvh_check.cpp"),
+                    os.path.join(ROOT, "audio-pathtracer_amd/csrc/fs_bvh.cpp")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all BVH invariants hold" in r.stdout and "runtime error" not in r.stderr
