@@ -17,6 +17,7 @@
 // The triangle test, the hit point/normal/offset arithmetic and the sampling maps use a fixed
 // operation order with explicit fmaf and are compiled with -ffp-contract=off: the path geometry is a
 // pure function of (scene, seed, pair index) and does not depend on launch geometry or on the BVH.
+#include <cstdlib>
 #include "fs_internal.hpp"
 
 namespace fs {
@@ -151,33 +152,37 @@ __device__ __forceinline__ bool tri_hit(const float4 A, const float4 Bq, const f
     float py = fmaf(r.dz, e2x, -(r.dx * e2z));
     float pz = fmaf(r.dx, e2y, -(r.dy * e2x));
     float det = fmaf(e1x, px, fmaf(e1y, py, e1z * pz));
-    if (det == 0.0f) return false;
-    // barycentric tests on the un-normalised values, sign-normalised by det (exact: sign-bit xor);
-    // the one IEEE division is only paid by rays that are inside the triangle
+    // barycentric tests on the un-normalised values, sign-normalised by det (exact: sign-bit xor).  All of
+    // it is straight-line code behind ONE branch (bitwise &, no short-circuit exits: with a dozen lanes in
+    // the test some lane nearly always needs every term, and each early exit costs exec-mask bookkeeping);
+    // the one IEEE division is only paid by rays that are inside the triangle.
     const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
     const float ad = fabsf(det);
     float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
     float U = fmaf(sx, px, fmaf(sy, py, sz * pz));
     float us = __uint_as_float(__float_as_uint(U) ^ sgn);
-    if (!(us >= 0.0f && us <= ad)) return false;
     float qx = fmaf(sy, e1z, -(sz * e1y));
     float qy = fmaf(sz, e1x, -(sx * e1z));
     float qz = fmaf(sx, e1y, -(sy * e1x));
     float V = fmaf(r.dx, qx, fmaf(r.dy, qy, r.dz * qz));
     float vs = __uint_as_float(__float_as_uint(V) ^ sgn);
-    if (!(vs >= 0.0f && (us + vs) <= ad)) return false;
-    float t = fmaf(e2x, qx, fmaf(e2y, qy, e2z * qz)) / det;
-    if (!(t > 0.0f && t <= tmax)) return false;
+    float tn = fmaf(e2x, qx, fmaf(e2y, qy, e2z * qz));
+    const bool inside = (det != 0.0f) & (us >= 0.0f) & (us <= ad) & (vs >= 0.0f) & ((us + vs) <= ad);
+    if (!inside) return false;
+    float t = tn / det;
+    if (!((t > 0.0f) & (t <= tmax))) return false;
     t_out = t;
     return true;
 }
 
 
 // ---------------------------------------------------------------------------------------------------
-// BVH traversal, one ray per lane, as a resumable single loop: every call of trav_step a busy lane
-// consumes exactly one 64-byte record — an inner node (two child boxes) OR one triangle of a pending
-// leaf — fetched through one common load sequence, so a wave never serialises "descend" against
-// "intersect" phases and a lane can be parked/resumed between any two steps (persistent kernel).
+// BVH traversal, one ray per lane, as a resumable single loop.  Every call of trav_step a busy lane
+// advances on BOTH fronts it has work on: it tests one triangle of its pending leaf AND visits its next
+// inner node (4 child boxes).  A wave executes both code paths in most iterations anyway (its lanes are
+// in different phases), so letting one lane use both halves the iterations a ray needs — per ray about
+// max(node visits, triangle tests) instead of their sum.  The closest hit does not depend on the order
+// of the tests, so results are unchanged.  A lane can be parked/resumed between any two steps.
 // `stack` is this lane's column of the workgroup's LDS stack (element i at stack[i * kBlock]).
 // ---------------------------------------------------------------------------------------------------
 struct Trav {
@@ -206,10 +211,11 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         T.tri_n = T.tri_i + (code & 3) + 1;
         if (T.sp > 0) { --T.sp; T.cur = stack[T.sp * kBlock]; } else { T.cur = kDone; }
     }
-    const bool is_tri = T.tri_i < T.tri_n;
-#ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.sh): SIMD occupancy of the two step kinds
+    const bool has_tri = T.tri_i < T.tri_n;
+    const bool has_node = T.cur >= 0;
+#ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.py): SIMD occupancy of the two step kinds
     {
-        const unsigned long long mt = __ballot(is_tri), mn = __ballot(!is_tri && T.cur >= 0);
+        const unsigned long long mt = __ballot(has_tri), mn = __ballot(has_node);
         if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(true)) - 1)) {
             atomicAdd(&g_trav_stats[0], 1ull);
             if (mn) { atomicAdd(&g_trav_stats[1], 1ull); atomicAdd(&g_trav_stats[2], (unsigned long long)__popcll(mn)); }
@@ -217,18 +223,22 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         }
     }
 #endif
-    if (!is_tri && T.cur < 0) return;  // nothing left for this lane
-    const float4* rec = is_tri ? reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)T.tri_i
-                               : reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)T.cur;
-    const float4 q0 = rec[0];
-    const float4 q1 = rec[1];
-    const float4 q2 = rec[2];
-    const float4 q3 = rec[3];
-    if (is_tri) {
+    // both records are requested before either is used, so the two fetches overlap
+    float4 a, b, c;            // triangle: v0 | e1 | e2 (+ material, id, object)
+    float4 q0, q1, q2, q3;     // node
+    if (has_tri) {
+        const float4* rec = reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)T.tri_i;
+        a = rec[0]; b = rec[1]; c = rec[2];
+    }
+    if (has_node) {
+        const float4* rec = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)T.cur;
+        q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+    }
+    if (has_tri) {
         float t;
         // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
-        if ((!IGN || __float_as_uint(q2.w) != ignore_object) && tri_hit(q0, q1, q2, r, T.t, t)) {
-            const uint32_t id = __float_as_uint(q2.z);
+        if ((!IGN || __float_as_uint(c.w) != ignore_object) && tri_hit(a, b, c, r, T.t, t)) {
+            const uint32_t id = __float_as_uint(c.z);
             if (ANY) {
                 T.t = t; T.leaf_index = T.tri_i; T.id = id;
                 T.tri_n = T.tri_i; T.cur = kDone; T.sp = 0;  // first hit ends the query
@@ -239,7 +249,8 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
             }
         }
         ++T.tri_i;
-    } else {
+    }
+    if (has_node) {
         // ---- 4-wide node, child boxes on the node's 8-bit grid: plane distance = fma(q, step*inv, (origin-o)*inv)
         const uint32_t exps = __float_as_uint(q0.w);
         const float sx = __uint_as_float((exps & 0xFFu) << 23) * r.ix;
@@ -271,22 +282,21 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
             // entry distance (>= 0, so its bits order like an integer) with the slot in the low 2 bits
             key[c] = h ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : (0xFFFFFFFCu | (uint32_t)c);
         }
-        // sort the 4 keys (5-comparator network): nearest first
-#define FS_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]); const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+        // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free
+        int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), ref2 = __float_as_int(q3.z),
+            ref3 = __float_as_int(q3.w);
+#define FS_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t lo_ = min(key[a], key[b]); \
+                         const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; \
+                         const int ra_ = sw_ ? ref##b : ref##a; const int rb_ = sw_ ? ref##a : ref##b; \
+                         ref##a = ra_; ref##b = rb_; }
         FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
 #undef FS_CSWAP
-        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y), c2 = __float_as_int(q3.z),
-                  c3 = __float_as_int(q3.w);
-        auto ref = [&](uint32_t k) -> int {
-            const uint32_t s = k & 3u;
-            return s == 0u ? c0 : (s == 1u ? c1 : (s == 2u ? c2 : c3));
-        };
         // far children wait on the stack, farthest pushed first
-        if (hits >= 4) { stack[T.sp * kBlock] = ref(key[3]); ++T.sp; }
-        if (hits >= 3) { stack[T.sp * kBlock] = ref(key[2]); ++T.sp; }
-        if (hits >= 2) { stack[T.sp * kBlock] = ref(key[1]); ++T.sp; }
+        if (hits >= 4) { stack[T.sp * kBlock] = ref3; ++T.sp; }
+        if (hits >= 3) { stack[T.sp * kBlock] = ref2; ++T.sp; }
+        if (hits >= 2) { stack[T.sp * kBlock] = ref1; ++T.sp; }
         if (hits >= 1) {
-            T.cur = ref(key[0]);
+            T.cur = ref0;
         } else if (T.sp > 0) {
             --T.sp;
             T.cur = stack[T.sp * kBlock];
@@ -1072,7 +1082,8 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
     if (wl.variant == 0) {
-        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
+        static const int pad = std::getenv("FS_WALK_LDS_PAD") ? std::atoi(std::getenv("FS_WALK_LDS_PAD")) : 0;
+        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), (size_t)pad, s, sc, kp, st, wl.queue_head, perm);
         return;
     }
     uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;
