@@ -3,7 +3,8 @@
 // Replaces the structure behind the engine call the reference delegates to
 // (UWorld::LineTraceSingleByObjectType, call sites AudioRayTracingSubsystem.cpp:252-254, 340-342).
 //
-//   1. top-down binned SAH BVH2 over triangle centroids, <= 4 triangles per leaf;
+//   1. top-down binned SAH BVH2 over triangle centroids, <= 2 triangles per leaf (a triangle test costs about
+//      as much as 2.5 child boxes on this kernel, so small leaves win: DESIGN.md section 5);
 //   2. greedy collapse to a 4-wide tree (the child with the largest surface area is opened until the node
 //      has 4 children);
 //   3. flatten breadth-first into 64-byte nodes: child boxes quantised to 8 bits per plane on a

@@ -38,6 +38,7 @@ struct alignas(16) Tri64 {
 };
 static_assert(sizeof(Tri64) == 64, "Tri64 must be 64 B");
 
+constexpr int kStackRows = 34;    // LDS rows per lane: kStackDepth + 2 rows that absorb the unconditional pushes
 constexpr int kStackDepth = 32;   // per-lane traversal stack entries (LDS); the builder caps tree depth
 constexpr int kBlock = 256;       // 4 waves of 64 lanes
 

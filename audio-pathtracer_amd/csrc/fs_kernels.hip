@@ -17,7 +17,6 @@
 // The triangle test, the hit point/normal/offset arithmetic and the sampling maps use a fixed
 // operation order with explicit fmaf and are compiled with -ffp-contract=off: the path geometry is a
 // pure function of (scene, seed, pair index) and does not depend on launch geometry or on the BVH.
-#include <cstdlib>
 #include "fs_internal.hpp"
 
 namespace fs {
@@ -170,9 +169,8 @@ __device__ __forceinline__ bool tri_hit(const float4 A, const float4 Bq, const f
     const bool inside = (det != 0.0f) & (us >= 0.0f) & (us <= ad) & (vs >= 0.0f) & ((us + vs) <= ad);
     if (!inside) return false;
     float t = tn / det;
-    if (!((t > 0.0f) & (t <= tmax))) return false;
     t_out = t;
-    return true;
+    return (t > 0.0f) & (t <= tmax);
 }
 
 
@@ -185,6 +183,8 @@ __device__ __forceinline__ bool tri_hit(const float4 A, const float4 Bq, const f
 // of the tests, so results are unchanged.  A lane can be parked/resumed between any two steps.
 // `stack` is this lane's column of the workgroup's LDS stack (element i at stack[i * kBlock]).
 // ---------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct Trav {
     int cur;        // next node: >= 0 inner index, < 0 leaf code (~cur = first*4 + count-1), kDone = none
     int sp;         // stack entries
@@ -235,18 +235,23 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
     }
     if (has_tri) {
-        float t;
+        float t = 0.0f;
         // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
-        if ((!IGN || __float_as_uint(c.w) != ignore_object) && tri_hit(a, b, c, r, T.t, t)) {
-            const uint32_t id = __float_as_uint(c.z);
-            if (ANY) {
+        bool hit = tri_hit(a, b, c, r, T.t, t);
+        if (IGN) hit = hit & (__float_as_uint(c.w) != ignore_object);
+        const uint32_t id = __float_as_uint(c.z);
+        if (ANY) {
+            if (hit) {
                 T.t = t; T.leaf_index = T.tri_i; T.id = id;
                 T.tri_n = T.tri_i; T.cur = kDone; T.sp = 0;  // first hit ends the query
                 return;
             }
-            if (t < T.t || T.leaf_index < 0 || (t == T.t && id < T.id)) {
-                T.t = t; T.leaf_index = T.tri_i; T.id = id;
-            }
+        } else {
+            // closest hit, ties to the lower input index — as selects, not branches
+            const bool better = hit & ((t < T.t) | (T.leaf_index < 0) | ((t == T.t) & (id < T.id)));
+            T.t = better ? t : T.t;
+            T.leaf_index = better ? T.tri_i : T.leaf_index;
+            T.id = better ? id : T.id;
         }
         ++T.tri_i;
     }
@@ -265,16 +270,19 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         const uint32_t nxw = r.ix < 0.0f ? hix : lox, fxw = r.ix < 0.0f ? lox : hix;
         const uint32_t nyw = r.iy < 0.0f ? hiy : loy, fyw = r.iy < 0.0f ? loy : hiy;
         const uint32_t nzw = r.iz < 0.0f ? hiz : loz, fzw = r.iz < 0.0f ? loz : hiz;
+        const v2f sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
         uint32_t key[4];
         int hits = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float tnx = fmaf((float)((nxw >> (8 * c)) & 0xFFu), sx, bx);
-            const float tny = fmaf((float)((nyw >> (8 * c)) & 0xFFu), sy, by);
-            const float tnz = fmaf((float)((nzw >> (8 * c)) & 0xFFu), sz, bz);
-            const float tfx = fmaf((float)((fxw >> (8 * c)) & 0xFFu), sx, bx);
-            const float tfy = fmaf((float)((fyw >> (8 * c)) & 0xFFu), sy, by);
-            const float tfz = fmaf((float)((fzw >> (8 * c)) & 0xFFu), sz, bz);
+            // (entry, exit) plane distances per axis as one packed fma each (v_pk_fma_f32)
+            const v2f qx = {(float)((nxw >> (8 * c)) & 0xFFu), (float)((fxw >> (8 * c)) & 0xFFu)};
+            const v2f qy = {(float)((nyw >> (8 * c)) & 0xFFu), (float)((fyw >> (8 * c)) & 0xFFu)};
+            const v2f qz = {(float)((nzw >> (8 * c)) & 0xFFu), (float)((fzw >> (8 * c)) & 0xFFu)};
+            const v2f tx = __builtin_elementwise_fma(qx, sx2, bx2);
+            const v2f ty = __builtin_elementwise_fma(qy, sy2, by2);
+            const v2f tz = __builtin_elementwise_fma(qz, sz2, bz2);
+            const float tnx = tx.x, tfx = tx.y, tny = ty.x, tfy = ty.y, tnz = tz.x, tfz = tz.y;
             const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
             const float tf = fminf(fminf(tfx, tfy), fminf(tfz, T.t));
             const bool h = tn <= tf;
@@ -291,10 +299,16 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
                          ref##a = ra_; ref##b = rb_; }
         FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
 #undef FS_CSWAP
-        // far children wait on the stack, farthest pushed first
-        if (hits >= 4) { stack[T.sp * kBlock] = ref3; ++T.sp; }
-        if (hits >= 3) { stack[T.sp * kBlock] = ref2; ++T.sp; }
-        if (hits >= 2) { stack[T.sp * kBlock] = ref1; ++T.sp; }
+        // far children wait on the stack, farthest pushed first.  Written unconditionally: a push that does
+        // not happen lands on the free slot above the top and is overwritten by the next one (or ignored),
+        // which is cheaper than three exec-mask branches; the rows [kStackDepth, kStackRows) absorb it.
+        const int p3 = T.sp;
+        const int p2 = p3 + (hits >= 4 ? 1 : 0);
+        const int p1 = p2 + (hits >= 3 ? 1 : 0);
+        stack[p3 * kBlock] = ref3;
+        stack[p2 * kBlock] = ref2;
+        stack[p1 * kBlock] = ref1;
+        T.sp = p1 + (hits >= 2 ? 1 : 0);
         if (hits >= 1) {
             T.cur = ref0;
         } else if (T.sp > 0) {
@@ -493,7 +507,7 @@ __device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, ui
 __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackRows * kBlock];
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {   // wave-uniform: bucket counts of the plan pass
         for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
@@ -535,7 +549,7 @@ constexpr int kQueueChunk = 64;
 __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc, KParams kp, SubpathState st,
                                                                  unsigned* __restrict__ queue_head,
                                                                  const uint32_t* __restrict__ perm) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackRows * kBlock];
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {
         for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = queue_head[1 + i];
@@ -621,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
 template <int B>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy, unsigned* queue_head) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackRows * kBlock];
     extern __shared__ __attribute__((aligned(16))) float s_hist[];  // [B][num_bins]
     __shared__ int s_lo, s_hi;
     const int nb = kp.num_bins;
@@ -777,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
                                                             const float* __restrict__ d,
                                                             const float* __restrict__ tmax, int N, int any_hit,
                                                             int32_t* hit, float* t, int32_t* tri, float* normal) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackRows * kBlock];
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= N) return;
     Ray r = make_ray(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
@@ -874,7 +888,7 @@ __device__ __forceinline__ float cast_direct(const DeviceScene& sc, const SoundK
 }
 
 __global__ __launch_bounds__(kBlock) void update_sound_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc) {
-    __shared__ int s_stack[kStackDepth * kBlock];
+    __shared__ int s_stack[kStackRows * kBlock];
     int* stack = &s_stack[threadIdx.x];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int N = sp.raycasts_per_tick;
@@ -1082,8 +1096,7 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
     if (wl.variant == 0) {
-        static const int pad = std::getenv("FS_WALK_LDS_PAD") ? std::atoi(std::getenv("FS_WALK_LDS_PAD")) : 0;
-        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), (size_t)pad, s, sc, kp, st, wl.queue_head, perm);
+        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
         return;
     }
     uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;
