@@ -9,8 +9,8 @@ sharding (multi-GPU pair partition).
 from . import _capi, scenes, sharding  # noqa: F401
 from ._capi import FrequenSeeError, default_config, default_params  # noqa: F401
 from .component import (AudioRayTracingSubsystem, Context, FrequenSeeAudioComponent,  # noqa: F401
-                        FrequenSeeAudioReverbPlugin)
+                        FrequenSeeAudioReverbPlugin, MaterialAcousticProcessor)
 
-__all__ = ["AudioRayTracingSubsystem", "FrequenSeeAudioComponent", "FrequenSeeAudioReverbPlugin", "Context",
+__all__ = ["AudioRayTracingSubsystem", "FrequenSeeAudioComponent", "FrequenSeeAudioReverbPlugin", "MaterialAcousticProcessor", "Context",
            "FrequenSeeError",
            "default_config", "default_params", "scenes", "sharding"]

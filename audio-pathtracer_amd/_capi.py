@@ -41,6 +41,7 @@ EXPORTS = [
     "fs_sound_params_default", "fs_scene_set_objects", "fs_update_sound", "fs_get_occlusion_attenuation",
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
+    "fs_apply_material_fd",
 ]
 REVERB_LITERAL_TAIL = 1
 
@@ -195,6 +196,7 @@ def load():
         "fs_reverb_init": (C.c_int, [vp, i32, i32]),
         "fs_reverb_process": (C.c_int, [vp, i32, f32p, f32p, i32, C.c_uint32]),
         "fs_reverb_release": (C.c_int, [vp, i32]),
+        "fs_apply_material_fd": (C.c_int, [vp, f32p, i32, f32p, f32p, f32p, i32, f32p, f32p, f32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -187,6 +187,19 @@ class Context:
     def reverb_release(self, src):
         self.check(self.lib.fs_reverb_release(self.h, src))
 
+    def apply_material_fd(self, in_buffer, absorption, transmission, scattering):
+        """UMaterialAcousticProcessor::ApplyMaterialFD (MAP.cpp:8-107) -> (specular, diffuse, transmitted)"""
+        x = np.ascontiguousarray(in_buffer, dtype=np.float32).reshape(-1)
+        a = np.ascontiguousarray(absorption, dtype=np.float32).reshape(-1)
+        t = np.ascontiguousarray(transmission, dtype=np.float32).reshape(-1)
+        sc = np.ascontiguousarray(scattering, dtype=np.float32).reshape(-1)
+        if not (a.size == t.size == sc.size):
+            raise _capi.FrequenSeeError(_capi.ERR_SIZE_MISMATCH, "response curves differ in length")
+        outs = [np.zeros(x.size, dtype=np.float32) for _ in range(3)]
+        self.check(self.lib.fs_apply_material_fd(self.h, x.ctypes.data, x.size, a.ctypes.data, t.ctypes.data,
+                                                 sc.ctypes.data, a.size, *[o.ctypes.data for o in outs]))
+        return tuple(outs)
+
     def set_profiling(self, level=2):
         """0 off, 1 = HIP events around the dominant (walk) kernel only, 2 = every kernel"""
         self.check(self.lib.fs_set_profiling(self.h, int(level)))
@@ -401,3 +414,19 @@ class FrequenSeeAudioReverbPlugin:
     def ProcessSourceAudio(self, component: FrequenSeeAudioComponent, AudioBuffer, literal_tail=False):
         return self.ctx.reverb_process(component._src, AudioBuffer, apply_reverb=component.bApplyReverb,
                                        literal_tail=literal_tail)
+
+
+class MaterialAcousticProcessor:
+    """Mirror of UMaterialAcousticProcessor (Public/MaterialAcousticProcessor.h:55-70).  Props is any object
+    with Absorption / Transmission / Scattering response arrays (FMaterialAcousticFD, .h:24-37) or a 3-tuple."""
+
+    def __init__(self, subsystem: AudioRayTracingSubsystem):
+        self.subsystem = subsystem
+
+    def ApplyMaterialFD(self, InBuffer, Props):
+        if isinstance(Props, (tuple, list)):
+            a, t, s = Props
+        else:
+            a, t, s = Props.Absorption, Props.Transmission, Props.Scattering
+        spec, diff, trans = self.subsystem.ctx.apply_material_fd(InBuffer, a, t, s)
+        return {"Specular": spec, "Diffuse": diff, "Transmitted": trans}   # FAcousticOutputs (.h:40-53)

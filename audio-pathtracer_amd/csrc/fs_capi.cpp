@@ -67,6 +67,11 @@ struct fs_context {
     float* d_absorption = nullptr;
     SoundAccum* d_sound = nullptr;
     DeviceScene scene{};
+    // ApplyMaterialFD work buffers (row f4), sized for the largest block seen
+    int fft_n = -1;              // log2 of the size the twiddle table was built for
+    int fft_cap_n = -1, fft_cap_l = 0;
+    float2 *d_fft_x = nullptr, *d_fft_y = nullptr, *d_fft_w = nullptr;
+    float *d_fft_in = nullptr, *d_fft_resp = nullptr, *d_fft_out = nullptr;
     HostBVH bvh;
 
     float listener[3] = {0, 0, 0};
@@ -346,6 +351,9 @@ int fs_context_destroy(fs_context* ctx) {
         free_state(ctx);
         if (ctx->walk.queue_head) (void)hipFree(ctx->walk.queue_head);
         if (ctx->d_sound) (void)hipFree(ctx->d_sound);
+        for (void* p : {(void*)ctx->d_fft_x, (void*)ctx->d_fft_y, (void*)ctx->d_fft_w, (void*)ctx->d_fft_in,
+                        (void*)ctx->d_fft_resp, (void*)ctx->d_fft_out})
+            if (p) (void)hipFree(p);
     }
     for (Source* s : ctx->sources) free_source(ctx, s);
     // streams exist even when a later step of fs_context_create failed (device_ok == false)
@@ -982,6 +990,65 @@ int fs_reverb_release(fs_context* ctx, fs_source h) {
         FS_HIP(ctx, hipMemsetAsync(s->d_ring, 0, sizeof(float) * 2 * kReverbRing, ctx->stream));
         s->rev_head = 0;
     }
+    return FS_OK;
+}
+
+// ---- row f4: UMaterialAcousticProcessor::ApplyMaterialFD (MaterialAcousticProcessor.cpp:8-107) -----------------
+int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const float* absorption, const float* transmission,
+                         const float* scattering, int32_t num_responses, float* specular, float* diffuse,
+                         float* transmitted) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (L < 0 || L > (1 << 24)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "block length out of range (0 .. 2^24)");
+    if (!absorption || !transmission || !scattering) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "null response curve");
+    if (L > 0 && (!in || !specular || !diffuse || !transmitted)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "null buffer");
+    int n = 0;
+    while ((1 << n) < L) ++n;                                      // MAP.cpp:15-16: next power of two
+    const int N = 1 << n, bins = N / 2 + 1;
+    if (num_responses != bins)                                     // MAP.cpp:20-26
+        return ctx->fail(FS_ERR_SIZE_MISMATCH, "all response curves must have length " + std::to_string(bins));
+    if (L == 0) return FS_OK;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no device");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (n > ctx->fft_cap_n || L > ctx->fft_cap_l) {
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (void* p : {(void*)ctx->d_fft_x, (void*)ctx->d_fft_y, (void*)ctx->d_fft_w, (void*)ctx->d_fft_in,
+                        (void*)ctx->d_fft_resp, (void*)ctx->d_fft_out})
+            if (p) (void)hipFree(p);
+        ctx->d_fft_x = ctx->d_fft_y = ctx->d_fft_w = nullptr;
+        ctx->d_fft_in = ctx->d_fft_resp = ctx->d_fft_out = nullptr;
+        ctx->fft_cap_n = -1; ctx->fft_cap_l = 0; ctx->fft_n = -1;
+        const int cn = std::max(n, ctx->fft_cap_n);
+        const size_t CN = (size_t)1 << cn;
+        FS_HIP(ctx, hipMalloc(&ctx->d_fft_x, sizeof(float2) * CN));
+        FS_HIP(ctx, hipMalloc(&ctx->d_fft_y, sizeof(float2) * 3 * CN));
+        FS_HIP(ctx, hipMalloc(&ctx->d_fft_w, sizeof(float2) * std::max<size_t>(CN / 2, 1)));
+        FS_HIP(ctx, hipMalloc(&ctx->d_fft_in, sizeof(float) * CN));
+        FS_HIP(ctx, hipMalloc(&ctx->d_fft_resp, sizeof(float) * 3 * (CN / 2 + 1)));
+        FS_HIP(ctx, hipMalloc(&ctx->d_fft_out, sizeof(float) * 3 * CN));
+        ctx->fft_cap_n = cn; ctx->fft_cap_l = (int)CN;
+    }
+    if (ctx->fft_n != n) {   // twiddles in double precision: W[k] = exp(-2 pi i k / N)
+        std::vector<float2> w(std::max(N / 2, 1));
+        for (int k = 0; k < N / 2; ++k) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)N;
+            w[(size_t)k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        if (N < 2) w[0] = make_float2(1.f, 0.f);
+        FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_w, w.data(), sizeof(float2) * w.size(), hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // w is a stack-owned staging buffer
+        ctx->fft_n = n;
+    }
+    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_in, in, sizeof(float) * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp, absorption, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp + bins, transmission, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp + 2 * bins, scattering, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
+    launch_apply_material_fd(ctx->d_fft_in, L, n, ctx->d_fft_x, ctx->d_fft_y, ctx->d_fft_w, ctx->d_fft_resp, ctx->d_fft_out,
+                             ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    FS_HIP(ctx, hipMemcpyAsync(specular, ctx->d_fft_out, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipMemcpyAsync(diffuse, ctx->d_fft_out + L, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipMemcpyAsync(transmitted, ctx->d_fft_out + 2 * (size_t)L, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FS_OK;
 }
 

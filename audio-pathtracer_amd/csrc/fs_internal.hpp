@@ -128,5 +128,10 @@ constexpr int kReverbRing = 65536;   // per-channel history ring (floats), match
 void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
                    int frame, int literal_tail, hipStream_t s);
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s);
+// row f4 (fs_fft.hip): ApplyMaterialFD.  x [N] and y [3][N] complex work buffers, W [N/2] twiddles,
+// resp [3][N/2+1] = absorption | transmission | scattering, out [3][L] = specular | diffuse | transmitted
+constexpr int kFftChunkLog = 11;     // FFT stages with spans below 2^11 points run inside LDS
+void launch_apply_material_fd(const float* in, int L, int n, float2* x, float2* y, const float2* W, const float* resp,
+                              float* out, hipStream_t s);
 
 }  // namespace fs

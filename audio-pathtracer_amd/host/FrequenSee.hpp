@@ -3,6 +3,7 @@
 //
 //   frequensee::AudioRayTracingSubsystem  <->  UAudioRayTracingSubsystem  (Public/AudioRayTracingSubsystem.h:86-196)
 //   frequensee::FrequenSeeAudioComponent  <->  UFrequenSeeAudioComponent  (Public/FrequenSeeAudioComponent.h:20-154)
+//   frequensee::MaterialAcousticProcessor <->  UMaterialAcousticProcessor (Public/MaterialAcousticProcessor.h:55-70)
 //
 // Same member names and argument meaning as the reference so a UE shim or a headless
 // harness reads like the original call sites.  check()-style aborts of the reference become
@@ -23,6 +24,7 @@ struct FVector {
 };
 
 class AudioRayTracingSubsystem;
+class MaterialAcousticProcessor;
 
 // UAcousticGeometryComponent (Public/AcousticGeometryComponent.h:9-22) + the owner's collision triangles
 struct AcousticGeometryComponent {
@@ -158,6 +160,7 @@ private:
     bool Dirty_ = true;
     int NumBands_ = 1;
     friend class FrequenSeeAudioComponent;
+    friend class MaterialAcousticProcessor;
 };
 
 inline FrequenSeeAudioComponent::~FrequenSeeAudioComponent() { OnUnregister(); }
@@ -208,5 +211,35 @@ inline fs_sound_result FrequenSeeAudioComponent::UpdateSound(uint64_t Seed) {
 inline void FrequenSeeAudioComponent::SaveImpulseResponse(const std::string& Path, int Channel) const {
     SubSys_->Check(fs_save_impulse_response(SubSys_->Ctx_, Handle_, Channel, Path.c_str()));
 }
+
+// FMaterialAcousticFD / FAcousticOutputs (Public/MaterialAcousticProcessor.h:24-53)
+struct MaterialAcousticFD {
+    std::vector<float> Absorption, Transmission, Scattering;   // each N/2 + 1 responses
+};
+struct AcousticOutputs {
+    std::vector<float> Specular, Diffuse, Transmitted;
+};
+
+class MaterialAcousticProcessor {
+public:
+    explicit MaterialAcousticProcessor(AudioRayTracingSubsystem& SubSys) : SubSys_(&SubSys) {}
+    // ApplyMaterialFD (MaterialAcousticProcessor.cpp:8-107).  A wrong curve length logs an error and returns
+    // empty outputs in the reference (:20-26); here it throws with the same message.
+    AcousticOutputs ApplyMaterialFD(const std::vector<float>& InBuffer, const MaterialAcousticFD& Props) const {
+        AcousticOutputs Out;
+        const size_t L = InBuffer.size();
+        if (Props.Absorption.size() != Props.Transmission.size() || Props.Absorption.size() != Props.Scattering.size())
+            throw std::runtime_error("FrequenSee: response curves differ in length");
+        Out.Specular.resize(L); Out.Diffuse.resize(L); Out.Transmitted.resize(L);
+        SubSys_->Check(fs_apply_material_fd(SubSys_->Ctx_, InBuffer.data(), (int32_t)L, Props.Absorption.data(),
+                                            Props.Transmission.data(), Props.Scattering.data(),
+                                            (int32_t)Props.Absorption.size(), Out.Specular.data(), Out.Diffuse.data(),
+                                            Out.Transmitted.data()));
+        return Out;
+    }
+
+private:
+    AudioRayTracingSubsystem* SubSys_;
+};
 
 }  // namespace frequensee

@@ -58,11 +58,24 @@ int main(int argc, char** argv) {
         for (int i = 0; i < n; ++i) peak = std::fmax(peak, std::fabs(ir[i]));
         fs_sound_result snd = Comp.UpdateSound();
         Comp.SaveImpulseResponse(out);
+        // ApplyMaterialFD on the traced IR: a half-absorbing, fully diffuse wall leaves 0.5 x the block in Diffuse
+        MaterialAcousticProcessor Proc(SubSys);
+        std::vector<float> Block(ir, ir + n);
+        int fft = 1;
+        while (fft < n) fft <<= 1;
+        MaterialAcousticFD Props;
+        Props.Absorption.assign((size_t)fft / 2 + 1, 0.5f);
+        Props.Transmission.assign((size_t)fft / 2 + 1, 0.0f);
+        Props.Scattering.assign((size_t)fft / 2 + 1, 1.0f);
+        AcousticOutputs Fd = Proc.ApplyMaterialFD(Block, Props);
+        double fd_err = 0;
+        for (int i = 0; i < n; ++i) fd_err = std::fmax(fd_err, std::fabs(Fd.Diffuse[(size_t)i] - 0.5 * ir[i]));
         std::printf("{\"frames\": %d, \"pairs\": %d, \"depth\": %d, \"frames_per_s\": %.1f, \"rays_per_s\": %.0f, "
                     "\"energy_sum_first_frame\": %.6f, \"ir_samples\": %d, \"ir_peak\": %.6f, "
-                    "\"occlusion_attenuation\": %.6f, \"legacy_rays_reaching\": %u, \"saved\": \"%s\"}\n",
+                    "\"occlusion_attenuation\": %.6f, \"legacy_rays_reaching\": %u, \"material_fd_max_err\": %.3g, "
+                    "\"saved\": \"%s\"}\n",
                     frames, pairs, depth, frames / s, 2.0 * pairs * frames / s, e, n, peak,
-                    snd.occlusion_attenuation, snd.rays_reaching_listener, out.c_str());
+                    snd.occlusion_attenuation, snd.rays_reaching_listener, fd_err, out.c_str());
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "fs_harness: %s\n", ex.what());
         return 1;

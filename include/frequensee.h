@@ -227,6 +227,18 @@ int fs_reverb_init(fs_context* ctx, fs_source src, int32_t frame_size /* BufferL
 int fs_reverb_process(fs_context* ctx, fs_source src, const float* in, float* out, int32_t apply_reverb, uint32_t flags);
 int fs_reverb_release(fs_context* ctx, fs_source src); /* OnReleaseSource: ClearBuffers */
 
+/* ---- row f4: frequency-dependent material response of one audio block ------------------------------------
+ *      UMaterialAcousticProcessor::ApplyMaterialFD (Private/MaterialAcousticProcessor.cpp:8-107, MAP.cpp):
+ *      N = next power of two >= L (:15-16); forward real FFT of the zero-padded block (:29-47); per bin
+ *      Refl = 1 - absorption, transmission clamped so Refl + tau <= 1, specular = Refl*(1 - scattering),
+ *      diffuse = Refl*scattering, transmitted = tau (:51-72); three inverse FFTs scaled by 1/N (:75-92).
+ *      The three response curves (FMaterialAcousticFD, MaterialAcousticProcessor.h:24-37) must each hold
+ *      num_responses == N/2 + 1 values, otherwise FS_ERR_SIZE_MISMATCH (the reference logs the error and
+ *      returns empty outputs, :20-26).  in and the three outputs are host arrays of L floats. */
+int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const float* absorption, const float* transmission,
+                         const float* scattering, int32_t num_responses, float* specular, float* diffuse,
+                         float* transmitted);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* HIP events on the context's stream: 0 = off, 1 = around the dominant (walk) kernel only, 2 = every kernel */
 int fs_set_profiling(fs_context* ctx, int32_t level);

@@ -366,3 +366,45 @@ class ReverbRef:
                 self.h = None
         except Exception:
             pass
+
+
+def apply_material_fd(in_buffer, absorption, transmission, scattering):
+    """UMaterialAcousticProcessor::ApplyMaterialFD restated around the reference's KissFFT (oracle/_ref).
+    Returns (specular, diffuse, transmitted), or None where the reference returns empty outputs
+    (response curves not N/2+1 long, MAP.cpp:20-26)."""
+    so = _REF_SO if os.path.exists(_REF_SO) else build_ref()
+    if not so:
+        raise FileNotFoundError("oracle/_ref/libfs_reverb_ref.so missing and /root/reference not present")
+    lib = C.CDLL(so)
+    vp = C.c_void_p
+    lib.fso_apply_material_fd.argtypes = [vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp]
+    lib.fso_apply_material_fd.restype = C.c_int32
+    x = np.ascontiguousarray(in_buffer, dtype=np.float32).reshape(-1)
+    a = np.ascontiguousarray(absorption, dtype=np.float32).reshape(-1)
+    t = np.ascontiguousarray(transmission, dtype=np.float32).reshape(-1)
+    s = np.ascontiguousarray(scattering, dtype=np.float32).reshape(-1)
+    if not (a.size == t.size == s.size):
+        return None
+    outs = [np.zeros(x.size, dtype=np.float32) for _ in range(3)]
+    rc = lib.fso_apply_material_fd(x.ctypes.data, x.size, a.ctypes.data, t.ctypes.data, s.ctypes.data, a.size,
+                                   *[o.ctypes.data for o in outs])
+    return None if rc != 0 else tuple(outs)
+
+
+def apply_material_fd_numpy(in_buffer, absorption, transmission, scattering):
+    """The same block filter in float64 numpy (independent of any FFT library of the reference): a second
+    opinion for the tolerance of the fp32 transforms."""
+    x = np.asarray(in_buffer, dtype=np.float64).reshape(-1)
+    L = x.size
+    N = 1
+    while N < L:
+        N <<= 1
+    a = np.asarray(absorption, dtype=np.float32)
+    t = np.asarray(transmission, dtype=np.float32).copy()
+    s = np.asarray(scattering, dtype=np.float32)
+    refl = np.float32(1.0) - a
+    over = (refl + t) > np.float32(1.0)
+    t[over] = (np.float32(1.0) - refl)[over]
+    X = np.fft.rfft(x, N)
+    gains = (refl * (np.float32(1.0) - s), refl * s, t)
+    return tuple(np.fft.irfft(X * g.astype(np.float64), N)[:L] for g in gains)

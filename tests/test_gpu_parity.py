@@ -314,7 +314,7 @@ def test_shard_invariance_on_device(pkg, scene_factory, world):
 
 
 # ---- golden fixtures -------------------------------------------------------------------------------------------
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg*.npz")))   # frame fixtures
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
@@ -439,3 +439,4 @@ def test_cpp_harness_matches_oracle(pkg, oracle_mod, scene_factory, tmp_path):
     assert j["ir_peak"] == pytest.approx(float(np.abs(ir_ref).max()), rel=1e-4)
     osc.set_objects(np.zeros(12, np.uint32))
     assert j["occlusion_attenuation"] == pytest.approx(osc.update_sound(sc.source, sc.listener)["occlusion_attenuation"], rel=1e-5)
+    assert j["material_fd_max_err"] <= 1e-5 * max(j["ir_peak"], 1e-3)   # MaterialAcousticProcessor through the C++ mirror
