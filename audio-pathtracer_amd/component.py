@@ -121,6 +121,13 @@ class Context:
         self.check(self.lib.fs_energy_device_ptr(self.h, src, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def energy_handoff(self, src):
+        """(device pointer, bytes, tail stream handle): the current frame's energy buffer, handed over to the
+        tail stream on which the caller's all-reduce and the reconstruct run (include/frequensee.h)"""
+        p, n, st = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        self.check(self.lib.fs_energy_handoff(self.h, src, C.byref(p), C.byref(n), C.byref(st)))
+        return p.value, n.value, st.value
+
     def impulse_response(self, src, channel=0):
         """copy of the published channel IR (GetImpulseResponse()[channel])"""
         out = np.empty(self.num_samples, dtype=np.float32)

@@ -24,12 +24,21 @@ constexpr int kIrRing = 3;  // published IR ring: a returned pointer stays valid
 struct Source {
     bool alive = false;
     float pos[3] = {0, 0, 0};
-    float* d_energy = nullptr;    // [B][bins]
+    // Two energy buffers [B][bins], alternating per frame: while the tail stream still reduces /
+    // reconstructs frame f from one of them, the compute stream already traces frame f+1 into the other.
+    float* d_energy[2] = {nullptr, nullptr};
+    int cur = 0;                       // buffer of the current frame (rotates in fs_compute_energy_response*)
+    hipEvent_t ev_dep = nullptr;       // compute stream: everything that writes the current buffer is enqueued
+    hipEvent_t ev_rec[2] = {nullptr, nullptr};   // tail stream: the reconstruct that read buffer i is done
+    bool rec_recorded[2] = {false, false};
+    int last_rec = -1;                 // buffer the newest reconstruct read (its event also guards d_ir_*)
+    hipEvent_t ev_rev = nullptr;       // compute stream: the newest reverb callback has read d_ir_mono
+    bool rev_recorded = false;
+    float* energy() const { return d_energy[cur]; }
     float* d_ir_bands = nullptr;  // [B][samples]
     float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
     float* h_ir[kIrRing] = {nullptr, nullptr, nullptr};  // pinned host copies of the channel view
     hipEvent_t ev[kIrRing] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_recon = nullptr;     // reconstruct kernel done -> the copy stream may read d_ir_mono
     uint64_t seq_of[kIrRing] = {0, 0, 0};
     uint64_t enqueued = 0;             // publishes enqueued so far
     std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
@@ -50,7 +59,9 @@ struct fs_context {
     fs_config cfg{};
     int num_bins = 0, num_samples = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;   // publishes IRs to the host off the compute stream
+    // "tail" stream: [caller's all-reduce] -> reconstruct -> publish of frame f, concurrent with the tracing of
+    // frame f+1 on `stream`
+    hipStream_t copy_stream = nullptr;
     bool own_stream = false;
     bool device_ok = false;
     std::string err;
@@ -115,18 +126,36 @@ Source* get_source(fs_context* ctx, fs_source h) {
     return (s && s->alive) ? s : nullptr;
 }
 
+// Before the compute stream writes the current energy buffer: the tail-stream reconstruct that last read it
+// must be done (two frames back in steady state, i.e. long finished).
+hipError_t wait_energy_readers(fs_context* ctx, Source* s) {
+    if (!s->rec_recorded[s->cur]) return hipSuccess;
+    return hipStreamWaitEvent(ctx->stream, s->ev_rec[s->cur], 0);
+}
+// Hand the current energy buffer over to the tail stream: what the compute stream has enqueued so far
+// completes before anything enqueued on the tail stream from now on.
+hipError_t handoff_energy(fs_context* ctx, Source* s) {
+    hipError_t e = hipEventRecord(s->ev_dep, ctx->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamWaitEvent(ctx->copy_stream, s->ev_dep, 0);
+}
+
 void free_source(fs_context* ctx, Source* s) {
     if (!s) return;
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->cfg.device);
-        if (s->d_energy) (void)hipFree(s->d_energy);
+        for (int i = 0; i < 2; ++i) {
+            if (s->d_energy[i]) (void)hipFree(s->d_energy[i]);
+            if (s->ev_rec[i]) (void)hipEventDestroy(s->ev_rec[i]);
+        }
+        if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
+        if (s->ev_rev) (void)hipEventDestroy(s->ev_rev);
         if (s->d_ir_bands) (void)hipFree(s->d_ir_bands);
         if (s->d_ir_mono) (void)hipFree(s->d_ir_mono);
         for (int i = 0; i < kIrRing; ++i) {
             if (s->h_ir[i]) (void)hipHostFree(s->h_ir[i]);
             if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
         }
-        if (s->ev_recon) (void)hipEventDestroy(s->ev_recon);
         if (s->d_ring) (void)hipFree(s->d_ring);
         if (s->d_rev_in) (void)hipFree(s->d_rev_in);
         if (s->d_rev_cur) (void)hipFree(s->d_rev_cur);
@@ -452,10 +481,13 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         return rc;
     };
     hipError_t e;
-    if ((e = hipMalloc((void**)&s->d_energy, eb)) != hipSuccess) return bail(e, "hipMalloc(energy)");
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipMalloc((void**)&s->d_energy[i], eb)) != hipSuccess) return bail(e, "hipMalloc(energy)");
+        if ((e = hipMemsetAsync(s->d_energy[i], 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+        if ((e = hipEventCreateWithFlags(&s->ev_rec[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
     if ((e = hipMalloc((void**)&s->d_ir_bands, ib * (size_t)ctx->cfg.num_bands)) != hipSuccess) return bail(e, "hipMalloc(ir_bands)");
     if ((e = hipMalloc((void**)&s->d_ir_mono, ib)) != hipSuccess) return bail(e, "hipMalloc(ir_mono)");
-    if ((e = hipMemsetAsync(s->d_energy, 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     if ((e = hipMemsetAsync(s->d_ir_bands, 0, ib * (size_t)ctx->cfg.num_bands, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     if ((e = hipMemsetAsync(s->d_ir_mono, 0, ib, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     for (int i = 0; i < kIrRing; ++i) {
@@ -463,7 +495,10 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         std::memset(s->h_ir[i], 0, ib);  // ImpulseBuffer[ch].Init(0, NumSamples) FSAC.cpp:24-28
         if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
-    if ((e = hipEventCreateWithFlags(&s->ev_recon, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&s->ev_rev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    // the initial fills above ran on the compute stream; the first reconstruct runs on the tail stream
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     s->alive = true;
     // RegisterSource: ActiveSources.Add (ARTS.cpp:45-48); reuse a dead slot if any
     for (size_t i = 0; i < ctx->sources.size(); ++i)
@@ -547,13 +582,15 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
         tf.e[1] = take_event(ctx);
         if (ctx->profiling >= 2) tf.e[2] = take_event(ctx);
     }
+    s->cur ^= 1;   // this frame deposits into the other buffer; the tail may still be busy with the last one
+    FS_HIP(ctx, wait_energy_readers(ctx, s));
     // FlushEnergyBuffer ARTS.cpp:157-161 is folded into the plan pass (one launch); plain memset otherwise
-    const uint32_t* perm = launch_plan(kp, ctx->walk, s->d_energy, B * ctx->num_bins, ctx->stream);
-    if (!perm) FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+    const uint32_t* perm = launch_plan(kp, ctx->walk, s->energy(), B * ctx->num_bins, ctx->stream);
+    if (!perm) FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     launch_walk(ctx->scene, kp, ctx->st, ctx->walk, perm, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
-    launch_connect(B, ctx->scene, kp, ctx->st, s->d_energy, ctx->walk.queue_head, ctx->stream);
+    launch_connect(B, ctx->scene, kp, ctx->st, s->energy(), ctx->walk.queue_head, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     if (ctx->profiling) {
         if (tf.e[2]) FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
@@ -571,12 +608,15 @@ int fs_compute_energy_response(fs_context* ctx, fs_source h, const fs_params* p,
     if (rc) return rc;
     Source* s = get_source(ctx, h);
     if (energy_out) {
-        FS_HIP(ctx, hipMemcpyAsync(energy_out, s->d_energy,
+        FS_HIP(ctx, hipMemcpyAsync(energy_out, s->energy(),
                                    sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
                                    hipMemcpyDeviceToHost, ctx->stream));
     }
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    resolve_timings(ctx);
+    if (!ctx->pending.empty()) {
+        FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // reconstruct timings live on the tail stream
+        resolve_timings(ctx);
+    }
     return FS_OK;
 }
 
@@ -584,8 +624,21 @@ int fs_energy_device_ptr(fs_context* ctx, fs_source h, void** dptr, size_t* byte
     if (!ctx || !dptr) return FS_ERR_INVALID_ARGUMENT;
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
-    *dptr = s->d_energy;
+    *dptr = s->energy();
     if (bytes) *bytes = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    return FS_OK;
+}
+
+int fs_energy_handoff(fs_context* ctx, fs_source h, void** dptr, size_t* bytes, void** tail_stream) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, handoff_energy(ctx, s));
+    if (dptr) *dptr = s->energy();
+    if (bytes) *bytes = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    if (tail_stream) *tail_stream = (void*)ctx->copy_stream;
     return FS_OK;
 }
 
@@ -617,27 +670,33 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
         for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
         tf.e[3] = take_event(ctx);
         tf.e[4] = take_event(ctx);
-        FS_HIP(ctx, hipEventRecord(tf.e[3], ctx->stream));
     }
-    if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)  // ARTS.cpp:191 literally
-        FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
-    // the previous publish still reads d_ir_mono on the copy stream: order this reconstruct behind it
-    if (s->enqueued > 0) FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev[(int)(s->enqueued % kIrRing)], 0));
-    launch_reconstruct(s->d_energy, B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
-                       s->d_ir_mono, ctx->stream);
+    if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) {  // ARTS.cpp:191 literally
+        FS_HIP(ctx, wait_energy_readers(ctx, s));
+        FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+    }
+    // The tail stream takes over: it waits for this frame's deposit (and runs behind any collective the caller
+    // put there after fs_energy_handoff), reconstructs and publishes while the compute stream goes on to the
+    // next frame.  Reconstructs and publishes of one source are ordered among themselves by the tail stream.
+    FS_HIP(ctx, handoff_energy(ctx, s));
+    hipStream_t tail = ctx->copy_stream;
+    if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
+    if (timed) FS_HIP(ctx, hipEventRecord(tf.e[3], tail));
+    launch_reconstruct(s->energy(), B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
+                       s->d_ir_mono, tail);
     FS_HIP(ctx, hipGetLastError());
+    FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], tail));
+    s->rec_recorded[s->cur] = true;
+    s->last_rec = s->cur;
     uint64_t seq = s->enqueued + 1;
     int slot = (int)(seq % kIrRing);
-    // publish off the compute stream: the next frame's kernels do not wait for the PCIe copy
-    FS_HIP(ctx, hipEventRecord(s->ev_recon, ctx->stream));
-    FS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, s->ev_recon, 0));
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
-                               hipMemcpyDeviceToHost, ctx->copy_stream));
-    FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->copy_stream));
+                               hipMemcpyDeviceToHost, tail));
+    FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
     s->seq_of[slot] = seq;
     s->enqueued = seq;
     if (timed) {
-        FS_HIP(ctx, hipEventRecord(tf.e[4], ctx->stream));
+        FS_HIP(ctx, hipEventRecord(tf.e[4], tail));
         tf.has_recon = true;
         ctx->pending.push_back(tf);
     }
@@ -691,6 +750,7 @@ int fs_copy_band_impulse_response(fs_context* ctx, fs_source h, int32_t band, fl
     if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
     if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // the reconstruct runs on the tail stream
     FS_HIP(ctx, hipMemcpyAsync(out, s->d_ir_bands + (size_t)band * (size_t)ctx->num_samples, sizeof(float) * (size_t)n,
                                hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -705,7 +765,8 @@ int fs_get_energy_buffer(fs_context* ctx, fs_source h, float* out, int32_t n) {
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    FS_HIP(ctx, hipMemcpyAsync(out, s->d_energy, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // a collective on the tail stream may still be summing it
+    FS_HIP(ctx, hipMemcpyAsync(out, s->energy(), sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FS_OK;
 }
@@ -716,7 +777,8 @@ int fs_flush_energy_buffer(fs_context* ctx, fs_source h) {
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    FS_HIP(ctx, hipMemsetAsync(s->d_energy, 0, sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
+    FS_HIP(ctx, wait_energy_readers(ctx, s));
+    FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
                                ctx->stream));
     return FS_OK;
 }
@@ -728,7 +790,8 @@ int fs_add_energy_at_delay(fs_context* ctx, fs_source h, int32_t band, float del
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    launch_add_energy(s->d_energy + (size_t)band * (size_t)ctx->num_bins, ctx->num_bins, delay_seconds, energy,
+    FS_HIP(ctx, wait_energy_readers(ctx, s));
+    launch_add_energy(s->energy() + (size_t)band * (size_t)ctx->num_bins, ctx->num_bins, delay_seconds, energy,
                       ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     return FS_OK;
@@ -742,7 +805,8 @@ int fs_update_energy_buffer(fs_context* ctx, fs_source h, const float* values, i
     // check(NewEnergyValues.Num() == NumBins) FSAC.h:83 -> status instead of abort
     if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    FS_HIP(ctx, hipMemcpyAsync(s->d_energy, values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx, wait_energy_readers(ctx, s));
+    FS_HIP(ctx, hipMemcpyAsync(s->energy(), values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FS_OK;
 }
@@ -971,10 +1035,15 @@ int fs_reverb_process(fs_context* ctx, fs_source h, const float* in, float* out,
         return FS_OK;
     }
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    // the device-resident IR is written by reconstructs on the tail stream: read it behind the newest one, and
+    // make the next one wait for this read (ev_rev)
+    if (s->last_rec >= 0) FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_rec[s->last_rec], 0));
     FS_HIP(ctx, hipMemcpyAsync(s->d_rev_in, in, sizeof(float) * 2 * (size_t)frame, hipMemcpyHostToDevice, ctx->stream));
     launch_reverb(s->d_ir_mono, ctx->num_samples, s->d_ring, s->rev_head, s->d_rev_in, s->d_rev_cur, s->d_rev_out, frame,
                   (flags & FS_REVERB_LITERAL_TAIL) ? 1 : 0, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
+    FS_HIP(ctx, hipEventRecord(s->ev_rev, ctx->stream));
+    s->rev_recorded = true;
     s->rev_head += (unsigned)frame;
     FS_HIP(ctx, hipMemcpyAsync(out, s->d_rev_out, sizeof(float) * 2 * (size_t)frame, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1064,6 +1133,7 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
     if (ctx->device_ok && !ctx->pending.empty()) {
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
         resolve_timings(ctx);
     }
     *out = ctx->stats;

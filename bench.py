@@ -109,26 +109,33 @@ def main():
     total_rays = rays_per_gpu * world
     p = pkg.default_params(num_rays=total_rays, depth=depth, seed=args.seed,
                            russian_roulette=0 if args.fixed_depth else 1)
-    lanes = []   # one (stream, context, source, energy tensor) per frame in flight
+    lanes = []   # one (stream, context, source) per frame in flight
     for i in range(max(1, args.inflight)):
         st_i = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
         c = pkg.Context(num_bands=bands, device=local_rank, rank=rank, world_size=world, stream=st_i.cuda_stream)
         c.set_scene(sc.triangles, sc.material_ids, sc.absorption)
         c.set_listener(sc.listener)
         s_i = c.create_source(sc.source)
-        eptr, ebytes = c.energy_device_ptr(s_i)
-        e_t = torch.as_tensor(_CudaArray(eptr, (bands * c.num_bins,)), device=f"cuda:{local_rank}")
-        lanes.append((st_i, c, s_i, e_t))
-    stream, ctx, src, energy_t = lanes[0]
+        lanes.append((st_i, c, s_i))
+    stream, ctx, src = lanes[0]
     frame_no = [0]
+    tensors = {}      # device pointer -> torch view of that energy buffer (a source alternates between two)
+    tails = {}        # tail stream handle -> torch stream object
 
     def frame():
-        st_i, c, s_i, e_t = lanes[frame_no[0] % len(lanes)]
+        st_i, c, s_i = lanes[frame_no[0] % len(lanes)]
         frame_no[0] += 1
         c.compute_energy_response_async(s_i, p)
         if world > 1:
-            with torch.cuda.stream(st_i):
-                dist.all_reduce(e_t)           # RCCL sum of the [bands][bins] fp32 energy buffer
+            # RCCL sum of the [bands][bins] fp32 energy buffer on the context's tail stream: it and the
+            # reconstruct behind it overlap the next frame's tracing on the compute stream
+            eptr, _, tail = c.energy_handoff(s_i)
+            if eptr not in tensors:
+                tensors[eptr] = torch.as_tensor(_CudaArray(eptr, (bands * c.num_bins,)), device=f"cuda:{local_rank}")
+            if tail not in tails:
+                tails[tail] = torch.cuda.ExternalStream(tail, device=f"cuda:{local_rank}")
+            with torch.cuda.stream(tails[tail]):
+                dist.all_reduce(tensors[eptr])
         c.reconstruct_impulse_response_async(s_i, p)
 
     def barrier():
@@ -138,7 +145,7 @@ def main():
 
     for _ in range(args.warmup):
         frame()
-    for _, c, _, _ in lanes:
+    for _, c, _ in lanes:
         c.synchronize()
         c.reset_stats()
         c.set_profiling(1)                     # HIP events around the dominant kernel on its launch stream
@@ -150,7 +157,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st = None
-    for _, c, _, _ in lanes:
+    for _, c, _ in lanes:
         c.synchronize()
         s1 = c.stats()
         c.set_profiling(0)
@@ -298,7 +305,7 @@ def main():
                             "tri_tests": cnt["tri_tests"]}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    for _, c, _, _ in lanes:
+    for _, c, _ in lanes:
         c.close()
     if world > 1:
         dist.destroy_process_group()

@@ -142,9 +142,17 @@ int fs_listener_set_position(fs_context* ctx, const float xyz[3]);
 int fs_compute_energy_response(fs_context* ctx, fs_source src, const fs_params* params, float* energy_out);
 /* Same, enqueue only (no host sync). */
 int fs_compute_energy_response_async(fs_context* ctx, fs_source src, const fs_params* params);
-/* Device pointer of the source's energy buffer [B][num_bins] fp32 — the hook for a multi-GPU
- * sum-reduce between compute and reconstruct (RCCL all-reduce on the same stream). */
+/* Device pointer of the energy buffer [B][num_bins] fp32 the source's CURRENT frame deposits into.  A source
+ * owns two such buffers and every fs_compute_energy_response* switches to the other one, so that the tail of
+ * frame f (reduce, reconstruct, publish) overlaps the tracing of frame f+1: query the pointer per frame. */
 int fs_energy_device_ptr(fs_context* ctx, fs_source src, void** dptr, size_t* bytes);
+/* Multi-GPU hook (one sum all-reduce of [B][1000] fp32 between ARTS.cpp:173 and :192).  Hands
+ * the current frame's energy buffer over to the context's tail stream: every deposit enqueued so far completes
+ * before anything enqueued on *tail_stream after this call.  The caller issues its collective there
+ * (ncclAllReduce(dptr, dptr, B*1000, ncclFloat, ncclSum, comm, (hipStream_t)*tail_stream)) and then calls
+ * fs_reconstruct_impulse_response_async, which runs behind it on the same stream — all of it concurrent with
+ * the next frame's tracing on the compute stream.  Any of the three out-pointers may be NULL. */
+int fs_energy_handoff(fs_context* ctx, fs_source src, void** dptr, size_t* bytes, void** tail_stream);
 
 /* ReconstructImpulseResponse (FSAC.cpp:320-380, called at ARTS.cpp:192): energy -> per-band IR
  * [B][num_samples] and the num_channels-channel view (both channels identical, FSAC.cpp:331) built
