@@ -40,7 +40,11 @@ WORKLOADS = {
     "cfg3_old_mine": ("old_mine", 8, 262144, 8),
     "cfg4_old_mine_d12": ("old_mine", 8, 131072, 12),          # cfg4's per-GPU share at 8 GPUs
     "cfg4_old_mine_1m_d12": ("old_mine", 8, 1048576, 12),      # all of cfg4 on one GPU
+    # cfg5: 8 sources x 131 072 rays, 1 listener; sources are dealt round-robin to the ranks (one per GPU at
+    # N = 8), each on its own context/stream, no reduce; total work is fixed => strong scaling
+    "cfg5_multi_source": ("old_mine", 8, 131072, 8),
 }
+MULTI_SOURCE = {"cfg5_multi_source": 8}
 
 
 class _CudaArray:
@@ -74,7 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fixed-depth", action="store_true", help="Russian roulette off: every subpath takes `depth` segments")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="independent frames in flight (one context + HIP stream each); 1 = strictly sequential frames")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra region that times the same frames with two in flight")
@@ -106,23 +110,53 @@ def main():
     pkg = graft.load_package()
     scene_name, bands, rays_per_gpu, depth = WORKLOADS[args.workload]
     sc = pkg.scenes.by_name(scene_name, bands)
-    total_rays = rays_per_gpu * world
-    p = pkg.default_params(num_rays=total_rays, depth=depth, seed=args.seed,
-                           russian_roulette=0 if args.fixed_depth else 1)
-    lanes = []   # one (stream, context, source) per frame in flight
-    for i in range(max(1, args.inflight)):
+    n_sources = MULTI_SOURCE.get(args.workload, 0)
+    if n_sources:
+        # independent sources: rank r owns sources r, r+N, ...; every source traces all of its pairs here
+        my_sources = [i for i in range(n_sources) if i % world == rank]
+        total_rays = rays_per_gpu * n_sources            # per step, over all ranks
+        p = pkg.default_params(num_rays=rays_per_gpu, depth=depth, seed=args.seed,
+                               russian_roulette=0 if args.fixed_depth else 1)
+        positions = [np.asarray(x, np.float32) for x in sc.extra_sources]   # 8 spots on a ~15 m spacing
+        assert len(positions) >= n_sources
+    else:
+        my_sources = []
+        total_rays = rays_per_gpu * world
+        p = pkg.default_params(num_rays=total_rays, depth=depth, seed=args.seed,
+                               russian_roulette=0 if args.fixed_depth else 1)
+    lanes = []   # one (stream, context, source) per frame in flight; multi-source: one per source of this rank,
+    #              the sources dealt round-robin to `--inflight` contexts (each context = one compute + one tail stream)
+    ctxs = []
+    if args.inflight is None:
+        args.inflight = len(my_sources) if n_sources else 1   # independent sources: all in flight (measured best)
+    n_ctx = max(1, args.inflight) if not n_sources else max(1, min(args.inflight, len(my_sources)))
+    for i in range(n_ctx):
         st_i = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
-        c = pkg.Context(num_bands=bands, device=local_rank, rank=rank, world_size=world, stream=st_i.cuda_stream)
+        if n_sources:
+            c = pkg.Context(num_bands=bands, device=local_rank, stream=st_i.cuda_stream)
+        else:
+            c = pkg.Context(num_bands=bands, device=local_rank, rank=rank, world_size=world, stream=st_i.cuda_stream)
         c.set_scene(sc.triangles, sc.material_ids, sc.absorption)
         c.set_listener(sc.listener)
-        s_i = c.create_source(sc.source)
-        lanes.append((st_i, c, s_i))
+        ctxs.append((st_i, c))
+    if n_sources:
+        for j, si in enumerate(my_sources):
+            st_i, c = ctxs[j % n_ctx]
+            lanes.append((st_i, c, c.create_source(positions[si])))
+    else:
+        for st_i, c in ctxs:
+            lanes.append((st_i, c, c.create_source(sc.source)))
     stream, ctx, src = lanes[0]
     frame_no = [0]
     tensors = {}      # device pointer -> torch view of that energy buffer (a source alternates between two)
     tails = {}        # tail stream handle -> torch stream object
 
     def frame():
+        if n_sources:   # one step = one update of every source (this rank's share), all in flight together
+            for _, c, s_i in lanes:
+                c.compute_energy_response_async(s_i, p)
+                c.reconstruct_impulse_response_async(s_i, p)
+            return
         st_i, c, s_i = lanes[frame_no[0] % len(lanes)]
         frame_no[0] += 1
         c.compute_energy_response_async(s_i, p)
@@ -145,7 +179,7 @@ def main():
 
     for _ in range(args.warmup):
         frame()
-    for _, c, _ in lanes:
+    for _, c in ctxs:
         c.synchronize()
         c.reset_stats()
         c.set_profiling(1)                     # HIP events around the dominant kernel on its launch stream
@@ -157,7 +191,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st = None
-    for _, c, _ in lanes:
+    for _, c in ctxs:
         c.synchronize()
         s1 = c.stats()
         c.set_profiling(0)
@@ -199,7 +233,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if n_sources else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -207,15 +241,16 @@ def main():
                                    f"(source+listener subpaths), depth {depth}, {bands} bands, "
                                    f"{'fixed depth' if args.fixed_depth else 'Russian roulette 0.9'}",
                        "rays_per_frame": total_rays, "pairs_per_frame": total_rays // 2, "depth": depth,
-                       "bands": bands, "triangles": sc.num_triangles, "sharding": f"pairs/{world}",
-                       "frames_in_flight": len(lanes)},
+                       "bands": bands, "triangles": sc.num_triangles,
+                       "sharding": f"{n_sources} sources round-robin over {world} ranks" if n_sources else f"pairs/{world}",
+                       "frames_in_flight": len(ctxs)},
             "ir_frames_per_s": args.steps / elapsed,
             "kernel_ms": {"walk": walk_ms, "connect": conn_ms, "reconstruct+publish": rec_ms},
         }
 
     # ---- extra region (N=1): the same frames with TWO in flight on separate HIP streams — one cfg3 frame
     #      cannot fill the chip (occupancy decays as walks end); independent frames/sources overlap ------------
-    if world == 1 and len(lanes) == 1 and not args.no_pipelined:
+    if world == 1 and len(lanes) == 1 and not n_sources and not args.no_pipelined:
         st2 = torch.cuda.Stream()
         c2 = pkg.Context(num_bands=bands, device=local_rank, stream=st2.cuda_stream)
         c2.set_scene(sc.triangles, sc.material_ids, sc.absorption)
@@ -240,7 +275,7 @@ def main():
                                "ms_per_step": 1e3 * el2 / k2, "ir_frames_per_s": k2 / el2}
 
     # ---- oracle leg (rank 0, N=1 only): parity check, algorithmic bytes, CPU baseline ---------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not n_sources and not args.no_cpu_baseline:
         import oracle  # checker / CPU baseline only
 
         lib = None
@@ -305,7 +340,7 @@ def main():
                             "tri_tests": cnt["tri_tests"]}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    for _, c, _ in lanes:
+    for _, c in ctxs:
         c.close()
     if world > 1:
         dist.destroy_process_group()
