@@ -81,6 +81,14 @@ class Context:
             self.check(self.lib.fs_scene_set_objects(self.h, None, tri.shape[0]))
         self.check(self.lib.fs_scene_commit(self.h))
 
+    def update_triangles(self, first, triangles):
+        """move committed triangles [first, first + n) (row f4: dynamic props); the refit runs before the next trace"""
+        t = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
+        self.check(self.lib.fs_scene_update_triangles(self.h, int(first), t.shape[0], t.ctypes.data))
+
+    def refit(self):
+        self.check(self.lib.fs_scene_refit(self.h))
+
     def set_listener(self, xyz):
         self.check(self.lib.fs_listener_set_position(self.h, _f3(xyz)))
 
@@ -356,6 +364,17 @@ class AudioRayTracingSubsystem:
             np.zeros((0, self.ctx.num_bands), np.float32), None, None)
         self.ctx.set_scene(tri, mat, ab, tr, sc, object_ids=obj)
         self._dirty = False
+
+    def GeometryMoved(self, comp_index, triangles):
+        """A registered geometry component (index in registration order) moved: same triangle count, new
+        world-space positions.  Rewritten in place + device refit before the next trace (no rebuild)."""
+        self._commit()
+        first = sum(g[0].shape[0] for g in self._geom[:comp_index])
+        tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
+        if tri.shape[0] != self._geom[comp_index][0].shape[0]:
+            raise ValueError("a moved component keeps its triangle count")
+        self._geom[comp_index] = (tri, *self._geom[comp_index][1:])
+        self.ctx.update_triangles(first, tri)
 
     def RegisterSource(self, InComp: FrequenSeeAudioComponent):  # ARTS.cpp:45-48
         InComp._subsys = self

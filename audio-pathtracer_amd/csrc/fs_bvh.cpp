@@ -159,13 +159,15 @@ struct Wide {
     int n;
 };
 
-void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wide, std::vector<int>& wide_of) {
+void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wide, std::vector<int>& wide_of,
+              std::vector<int>& level) {
     // breadth-first so the top of the tree is a contiguous prefix of the node array
     wide.clear();
     wide_of.assign(bn.size(), -1);
     std::vector<int> queue;
     queue.push_back(root);
     wide_of[root] = 0;
+    level.assign(1, 0);   // depth of every wide node; breadth-first order keeps each level contiguous
     for (size_t h = 0; h < queue.size(); ++h) {
         const BuildNode& n = bn[queue[h]];
         Wide w;
@@ -191,7 +193,7 @@ void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wid
         }
         for (int i = 0; i < w.n; ++i) {
             int c = w.child[i];
-            if (bn[c].left >= 0) { wide_of[c] = (int)queue.size(); queue.push_back(c); }
+            if (bn[c].left >= 0) { wide_of[c] = (int)queue.size(); queue.push_back(c); level.push_back(level[h] + 1); }
         }
         wide.push_back(w);
     }
@@ -218,6 +220,9 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
     out.tris.clear();
     out.max_depth = 0;
     out.stack_need = 0;
+    out.leaf_pos.clear();
+    out.level_begin.clear();
+    out.pad = 0.01f;
     if (T <= 0) return;
 
     Builder b;
@@ -243,6 +248,7 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
 
     std::vector<Wide> wide;
     std::vector<int> wide_of;
+    std::vector<int> level;
     int root = 0;
     for (int cap = 48; cap >= 8; cap -= 4) {   // rebuild shallower until the traversal stack bound holds
         b.depth_cap = cap;
@@ -251,11 +257,19 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
         b.max_depth = 0;
         for (int t = 0; t < T; ++t) b.order[t] = t;
         root = b.make(0, T, 0);
-        collapse(b.nodes, root, wide, wide_of);
+        collapse(b.nodes, root, wide, wide_of, level);
         out.stack_need = stack_need(b.nodes, wide, wide_of);
         if (out.stack_need <= kStackDepth) break;
     }
     out.max_depth = b.max_depth;
+    out.pad = pad;
+    // refit support: where each input triangle sits in leaf order, and the node range of every tree level
+    out.leaf_pos.resize(T);
+    for (int i = 0; i < T; ++i) out.leaf_pos[(size_t)b.order[i]] = (uint32_t)i;
+    out.level_begin.clear();
+    for (size_t i = 0; i < level.size(); ++i)
+        if (i == 0 || level[i] != level[i - 1]) out.level_begin.push_back((int32_t)i);
+    out.level_begin.push_back((int32_t)level.size());
 
     // triangles in leaf order
     out.tris.resize(T);

@@ -77,6 +77,13 @@ struct fs_context {
     Tri64* d_tris = nullptr;
     float* d_absorption = nullptr;
     SoundAccum* d_sound = nullptr;
+    // refit support (row f4, fs_refit.hip)
+    uint32_t* d_leaf_pos = nullptr;   // input triangle -> leaf-order position
+    float4* d_node_box = nullptr;     // [nodes][2] fp32 bounds scratch
+    float* d_move = nullptr;          // staging for moved triangles
+    size_t move_cap = 0;              // in triangles
+    float amax = 0.f;                 // largest |coordinate| seen (sets the box padding)
+    bool refit_pending = false;
     DeviceScene scene{};
     // ApplyMaterialFD work buffers (row f4), sized for the largest block seen
     int fft_n = -1;              // log2 of the size the twiddle table was built for
@@ -168,6 +175,12 @@ void free_scene(fs_context* ctx) {
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_tris) (void)hipFree(ctx->d_tris);
     if (ctx->d_absorption) (void)hipFree(ctx->d_absorption);
+    if (ctx->d_leaf_pos) (void)hipFree(ctx->d_leaf_pos);
+    if (ctx->d_node_box) (void)hipFree(ctx->d_node_box);
+    if (ctx->d_move) (void)hipFree(ctx->d_move);
+    ctx->d_leaf_pos = nullptr; ctx->d_node_box = nullptr; ctx->d_move = nullptr;
+    ctx->move_cap = 0;
+    ctx->refit_pending = false;
     ctx->d_nodes = nullptr; ctx->d_tris = nullptr; ctx->d_absorption = nullptr;
     ctx->scene = DeviceScene{};
     ctx->committed = false;
@@ -450,6 +463,14 @@ int fs_scene_commit(fs_context* ctx) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_absorption, mb));
         FS_HIP(ctx, hipMemcpy(ctx->d_absorption, ctx->h_absorption.data(), mb, hipMemcpyHostToDevice));
     }
+    if (tb) {   // refit support: leaf positions and the bounds scratch
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_pos, sizeof(uint32_t) * ctx->bvh.leaf_pos.size()));
+        FS_HIP(ctx, hipMemcpy(ctx->d_leaf_pos, ctx->bvh.leaf_pos.data(), sizeof(uint32_t) * ctx->bvh.leaf_pos.size(),
+                              hipMemcpyHostToDevice));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_node_box, sizeof(float4) * 2 * std::max<size_t>(ctx->bvh.nodes.size(), 1)));
+    }
+    ctx->amax = 0.f;
+    for (float v : ctx->h_xyz) ctx->amax = std::max(ctx->amax, std::fabs(v));
     ctx->scene.nodes = ctx->d_nodes;
     ctx->scene.tris = ctx->d_tris;
     ctx->scene.absorption = ctx->d_absorption;
@@ -462,6 +483,49 @@ int fs_scene_commit(fs_context* ctx) {
     ctx->stats.bvh_depth = (uint32_t)ctx->bvh.max_depth;
     ctx->stats.scene_bytes = nb + tb + mb;
     ctx->committed = true;
+    return FS_OK;
+}
+
+// ---- moving geometry (row f4): ECC_WorldDynamic movers are seen by the next trace (ARTS.cpp:333-336) -------------
+int fs_scene_update_triangles(fs_context* ctx, int32_t first, int32_t count, const float* xyz) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    if (first < 0 || count < 0 || (int64_t)first + count > ctx->T || (count > 0 && !xyz))
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "triangle range outside the committed scene");
+    if (count == 0) return FS_OK;
+    for (size_t i = 0; i < 9 * (size_t)count; ++i)
+        if (!std::isfinite(xyz[i])) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "non-finite vertex coordinate");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if ((size_t)count > ctx->move_cap) {
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_move) (void)hipFree(ctx->d_move);
+        ctx->d_move = nullptr; ctx->move_cap = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_move, sizeof(float) * 9 * (size_t)count));
+        ctx->move_cap = (size_t)count;
+    }
+    std::memcpy(ctx->h_xyz.data() + 9 * (size_t)first, xyz, sizeof(float) * 9 * (size_t)count);   // a later commit stays consistent
+    for (size_t i = 0; i < 9 * (size_t)count; ++i) ctx->amax = std::max(ctx->amax, std::fabs(xyz[i]));
+    // the staging buffer may still be read by the previous update's kernel: same stream, so ordered
+    FS_HIP(ctx, hipMemcpyAsync(ctx->d_move, xyz, sizeof(float) * 9 * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    launch_update_triangles(ctx->d_tris, ctx->d_leaf_pos, first, count, ctx->d_move, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // xyz is the caller's memory
+    ctx->refit_pending = true;
+    return FS_OK;
+}
+
+int fs_scene_refit(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    ctx->refit_pending = false;
+    if (ctx->bvh.nodes.empty()) return FS_OK;
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const float pad = std::max(std::max(0.01f, ctx->amax * 3.8146973e-06f), ctx->bvh.pad);   // as fs_bvh.cpp; never shrinks
+    launch_refit(ctx->d_nodes, ctx->d_tris, ctx->d_node_box, ctx->bvh.level_begin.data(),
+                 (int)ctx->bvh.level_begin.size() - 1, pad, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
     return FS_OK;
 }
 
@@ -539,6 +603,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     int rc = check_params(ctx, p);
     if (rc) return rc;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
@@ -839,6 +904,7 @@ int fs_update_sound(fs_context* ctx, fs_source h, const fs_sound_params* p, fs_s
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     fs_sound_params def;
     if (!p) { fs_sound_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_sound_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_sound_params.struct_size mismatch");
@@ -887,6 +953,7 @@ int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, cons
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     if (N < 0 || (N > 0 && (!origins || !dirs || !tmax || !hit))) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad ray arrays");
     if (!any_hit && N > 0 && (!t || !tri || !normal)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "closest-hit outputs required");
     if (N == 0) return FS_OK;

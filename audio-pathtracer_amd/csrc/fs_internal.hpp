@@ -98,6 +98,11 @@ struct HostBVH {
     std::vector<Tri64> tris;   // leaf order
     int max_depth = 0;         // of the binary tree before the 4-wide collapse
     int stack_need = 0;        // worst-case pending traversal-stack entries (<= kStackDepth by construction)
+    // refit support (fs_refit.hip): input triangle -> leaf-order position; node range [level_begin[l],
+    // level_begin[l+1]) of every tree level (breadth-first layout); box padding used by the build
+    std::vector<uint32_t> leaf_pos;
+    std::vector<int32_t> level_begin;
+    float pad = 0.01f;
 };
 // xyz [T][3][3], mat [T]; binned SAH BVH2 collapsed to a quantised 4-wide tree, <= 4 triangles per leaf.
 void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out);
@@ -128,6 +133,12 @@ constexpr int kReverbRing = 65536;   // per-channel history ring (floats), match
 void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
                    int frame, int literal_tail, hipStream_t s);
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s);
+// row f4 (fs_refit.hip): moving geometry without a rebuild.  xyz = `count` new triangles [count][3][3] on the
+// device, written to the leaf-order records through leaf_pos; then one refit launch per tree level, deepest
+// first (node_box = scratch [num_nodes][2] float4 holding each node's fp32 bounds).
+void launch_update_triangles(Tri64* tris, const uint32_t* leaf_pos, int first, int count, const float* xyz, hipStream_t s);
+void launch_refit(NodeQ4* nodes, const Tri64* tris, float4* node_box, const int32_t* level_begin, int levels, float pad,
+                  hipStream_t s);
 // row f4 (fs_fft.hip): ApplyMaterialFD.  x [N] and y [3][N] complex work buffers, W [N/2] twiddles,
 // resp [3][N/2+1] = absorption | transmission | scattering, out [3][L] = specular | diffuse | transmitted
 constexpr int kFftChunkLog = 11;     // FFT stages with spans below 2^11 points run inside LDS

@@ -1,0 +1,144 @@
+// fs_refit.hip — moving geometry without a rebuild (row f4: dynamic props).
+//
+// The reference's line traces run against the live physics scene and include ECC_WorldDynamic objects
+// (AudioRayTracingSubsystem.cpp:333-336, FrequenSeeAudioComponent.cpp:229-232), so a moved prop is seen by
+// the next frame.  The host SAH build takes ~180 ms for 100 000 triangles; a moved subset is instead written
+// straight into the leaf-order triangle records and the 4-wide tree is refitted bottom-up on the device:
+// same topology, new boxes.  Results stay a function of ray and triangles only (boxes are conservative:
+// padded and quantised outwards exactly as in fs_bvh.cpp), so they equal a fresh build's bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "fs_internal.hpp"
+
+namespace fs {
+namespace {
+
+constexpr int kRefitBlock = 256;
+
+// new vertex positions -> Tri64 {v0, e1, e2, unit normal}; material, input index and actor id are kept.
+// Same fp32 operation order as the host build (fs_bvh.cpp) — the normal is part of the hit-normal spec.
+__global__ __launch_bounds__(kRefitBlock) void update_tris_kernel(Tri64* __restrict__ tris,
+                                                                  const uint32_t* __restrict__ leaf_pos, int first,
+                                                                  int count, const float* __restrict__ xyz) {
+    const int i = blockIdx.x * kRefitBlock + threadIdx.x;
+    if (i >= count) return;
+    const float* p = xyz + 9 * (size_t)i;
+    Tri64& r = tris[leaf_pos[first + i]];
+    const float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
+    const float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
+    r.a = make_float4(p[0], p[1], p[2], e1x);
+    r.b = make_float4(e1y, e1z, e2x, e2y);
+    r.c.x = e2z;
+    const float nx = fmaf(e1y, e2z, -(e1z * e2y));
+    const float ny = fmaf(e1z, e2x, -(e1x * e2z));
+    const float nz = fmaf(e1x, e2y, -(e1y * e2x));
+    const float l2 = nx * nx + ny * ny + nz * nz;
+    const float inv = 1.0f / sqrtf(l2);
+    r.d = make_float4(nx * inv, ny * inv, nz * inv, 0.f);
+}
+
+struct Box3 {
+    float lo[3], hi[3];
+};
+
+__device__ __forceinline__ void box_point(Box3& b, float x, float y, float z) {
+    b.lo[0] = fminf(b.lo[0], x); b.hi[0] = fmaxf(b.hi[0], x);
+    b.lo[1] = fminf(b.lo[1], y); b.hi[1] = fmaxf(b.hi[1], y);
+    b.lo[2] = fminf(b.lo[2], z); b.hi[2] = fmaxf(b.hi[2], z);
+}
+
+// one thread per node of one tree level: child boxes (leaves from their triangles, inner children from the
+// level below), own bounds, outward 8-bit quantisation on the node's power-of-two grid (as fs_bvh.cpp)
+__global__ __launch_bounds__(kRefitBlock) void refit_level_kernel(NodeQ4* __restrict__ nodes,
+                                                                  const Tri64* __restrict__ tris,
+                                                                  float4* __restrict__ node_box, int begin, int end,
+                                                                  float pad) {
+    const int i = begin + blockIdx.x * kRefitBlock + threadIdx.x;
+    if (i >= end) return;
+    NodeQ4 q = nodes[i];
+    const float inf = __builtin_inff();
+    Box3 cb[4];
+    bool used[4];
+    Box3 nb;
+    for (int k = 0; k < 3; ++k) { nb.lo[k] = inf; nb.hi[k] = -inf; }
+    for (int c = 0; c < 4; ++c) {
+        // an empty slot carries lo = 255 > hi = 0 on every axis
+        used[c] = ((q.lox >> (8 * c)) & 0xFFu) <= ((q.hix >> (8 * c)) & 0xFFu);
+        for (int k = 0; k < 3; ++k) { cb[c].lo[k] = inf; cb[c].hi[k] = -inf; }
+        if (!used[c]) continue;
+        const int32_t link = q.child[c];
+        if (link >= 0) {
+            const float4 lo = node_box[2 * (size_t)link], hi = node_box[2 * (size_t)link + 1];
+            cb[c].lo[0] = lo.x; cb[c].lo[1] = lo.y; cb[c].lo[2] = lo.z;
+            cb[c].hi[0] = hi.x; cb[c].hi[1] = hi.y; cb[c].hi[2] = hi.z;
+        } else {
+            const int code = ~link;
+            const int first = code >> 2, n = (code & 3) + 1;
+            for (int t = first; t < first + n; ++t) {
+                const float4 a = tris[t].a, b = tris[t].b;
+                const float e2z = tris[t].c.x;
+                box_point(cb[c], a.x, a.y, a.z);
+                box_point(cb[c], a.x + a.w, a.y + b.x, a.z + b.y);      // v0 + e1 (half an ulp off the input
+                box_point(cb[c], a.x + b.z, a.y + b.w, a.z + e2z);      // vertex at most; pad >= 0.01 cm)
+            }
+        }
+        for (int k = 0; k < 3; ++k) { nb.lo[k] = fminf(nb.lo[k], cb[c].lo[k]); nb.hi[k] = fmaxf(nb.hi[k], cb[c].hi[k]); }
+    }
+    node_box[2 * (size_t)i] = make_float4(nb.lo[0], nb.lo[1], nb.lo[2], 0.f);
+    node_box[2 * (size_t)i + 1] = make_float4(nb.hi[0], nb.hi[1], nb.hi[2], 0.f);
+
+    double origin[3], scale[3];
+    float originf[3];
+    uint32_t exps = 0;
+    for (int k = 0; k < 3; ++k) {
+        origin[k] = (double)(nb.lo[k] - pad);
+        const double ext = (double)(nb.hi[k] + pad) - origin[k];
+        int e = (int)ceil(log2(fmax(ext, 1e-30) / 255.0));
+        e = max(-100, min(100, e));
+        while (ldexp(255.0, e) < ext) ++e;     // guard the log2 rounding
+        scale[k] = ldexp(1.0, e);
+        exps |= (uint32_t)(e + 127) << (8 * k);
+        originf[k] = (float)origin[k];
+    }
+    uint32_t lo4[3] = {0, 0, 0}, hi4[3] = {0, 0, 0};
+    for (int c = 0; c < 4; ++c)
+        for (int k = 0; k < 3; ++k) {
+            uint32_t ql = 255, qh = 0;
+            if (used[c]) {
+                const double l = ((double)(cb[c].lo[k] - pad) - (double)originf[k]) / scale[k];
+                const double h = ((double)(cb[c].hi[k] + pad) - (double)originf[k]) / scale[k];
+                ql = (uint32_t)fmax(0.0, fmin(255.0, floor(l)));
+                qh = (uint32_t)fmax(0.0, fmin(255.0, ceil(h)));
+            }
+            lo4[k] |= ql << (8 * c);
+            hi4[k] |= qh << (8 * c);
+        }
+    q.ox = originf[0]; q.oy = originf[1]; q.oz = originf[2];
+    q.exps = exps;
+    q.lox = lo4[0]; q.loy = lo4[1]; q.loz = lo4[2];
+    q.hix = hi4[0]; q.hiy = hi4[1]; q.hiz = hi4[2];
+    nodes[i] = q;
+}
+
+}  // namespace
+
+void launch_update_triangles(Tri64* tris, const uint32_t* leaf_pos, int first, int count, const float* xyz,
+                             hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(update_tris_kernel, dim3((unsigned)((count + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock),
+                       0, s, tris, leaf_pos, first, count, xyz);
+}
+
+void launch_refit(NodeQ4* nodes, const Tri64* tris, float4* node_box, const int32_t* level_begin, int levels, float pad,
+                  hipStream_t s) {
+    for (int l = levels - 1; l >= 0; --l) {   // deepest level first: a node reads its children's bounds
+        const int begin = level_begin[l], end = level_begin[l + 1];
+        if (end <= begin) continue;
+        hipLaunchKernelGGL(refit_level_kernel, dim3((unsigned)((end - begin + kRefitBlock - 1) / kRefitBlock)),
+                           dim3(kRefitBlock), 0, s, nodes, tris, node_box, begin, end, pad);
+    }
+}
+
+}  // namespace fs

@@ -147,6 +147,21 @@ public:
         Check(fs_scene_commit(Ctx_));
         Dirty_ = false;
     }
+    // A registered geometry component moved (ECC_WorldDynamic prop): its triangles are rewritten in place and the
+    // acceleration structure is refitted on the device before the next trace — no rebuild.  `Comp->Triangles`
+    // already holds the new world-space positions; the triangle count must not change.
+    void GeometryMoved(const AcousticGeometryComponent* Comp) {
+        Commit();
+        size_t first = 0;
+        for (const auto* g : Geometry_) {
+            if (g == Comp) {
+                Check(fs_scene_update_triangles(Ctx_, (int32_t)first, (int32_t)g->MaterialId.size(), g->Triangles.data()));
+                return;
+            }
+            first += g->MaterialId.size();
+        }
+        throw std::runtime_error("FrequenSee: geometry component is not registered");
+    }
     void Check(int rc) const { if (rc != FS_OK) throw std::runtime_error(std::string("FrequenSee: ") + fs_last_error(Ctx_)); }
 
     fs_params Params;                                   // the constants of AudioRayTracingSubsystem.cpp:282-284, 362-413

@@ -125,6 +125,14 @@ int fs_scene_set_triangles(fs_context* ctx, const float* xyz, const uint16_t* ma
 int fs_scene_set_materials(fs_context* ctx, const float* absorption, const float* transmission,
                            const float* scattering, int32_t M, int32_t B);
 int fs_scene_commit(fs_context* ctx); /* builds the flattened BVH and uploads it */
+/* Moving geometry without a rebuild (row f4).  The reference's line traces run against the live physics scene and
+ * include ECC_WorldDynamic objects (ARTS.cpp:333-336, FSAC.cpp:229-232): a prop that moved is seen by the next
+ * frame.  fs_scene_update_triangles overwrites `count` committed triangles starting at input index `first` with new
+ * vertex positions (layout of fs_scene_set_triangles; materials and actor ids are kept); fs_scene_refit recomputes
+ * the boxes of the acceleration structure bottom-up on the device (same topology).  A pending refit is also run
+ * automatically by the next trace.  Results equal those of a fresh fs_scene_commit of the moved geometry. */
+int fs_scene_update_triangles(fs_context* ctx, int32_t first, int32_t count, const float* xyz /* [count][3][3] */);
+int fs_scene_refit(fs_context* ctx);
 
 /* ---- sources and listener: RegisterSource/UnRegisterSource (ARTS.h:103-104, ARTS.cpp:45-53),
  *      GetActorLocation of the source owner / the player pawn (ARTS.cpp:287) ------------------------- */

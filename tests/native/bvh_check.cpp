@@ -89,6 +89,29 @@ static void run(const char* name, const std::vector<float>& xyz) {
     std::vector<int> ids((size_t)T, 0);
     for (const Tri64& t : bvh.tris) { uint32_t id; std::memcpy(&id, &t.c.z, 4); CHECK(id < (uint32_t)T, "id"); if (id < (uint32_t)T) ids[id]++; }
     for (int i = 0; i < T; ++i) CHECK(ids[i] == 1, "%s: input triangle %d appears %d times", name, i, ids[i]);
+    // refit support: leaf_pos inverts the leaf order; level ranges tile the node array and every inner child
+    // of a node lies exactly one level below it (so a bottom-up, level-by-level refit sees finished children)
+    CHECK((int)bvh.leaf_pos.size() == T, "%s: leaf_pos size", name);
+    for (int i = 0; i < T && i < (int)bvh.leaf_pos.size(); ++i) {
+        uint32_t id = 0xFFFFFFFFu;
+        if (bvh.leaf_pos[(size_t)i] < (uint32_t)T) std::memcpy(&id, &bvh.tris[bvh.leaf_pos[(size_t)i]].c.z, 4);
+        CHECK(id == (uint32_t)i, "%s: leaf_pos[%d] points at input triangle %u", name, i, id);
+    }
+    CHECK(bvh.level_begin.size() >= 2 && bvh.level_begin.front() == 0 && bvh.level_begin.back() == (int)bvh.nodes.size(),
+          "%s: level ranges do not tile the nodes", name);
+    std::vector<int> lvl(bvh.nodes.size(), -1);
+    for (size_t l = 0; l + 1 < bvh.level_begin.size(); ++l) {
+        CHECK(bvh.level_begin[l] < bvh.level_begin[l + 1], "%s: empty level %zu", name, l);
+        for (int i = bvh.level_begin[l]; i < bvh.level_begin[l + 1] && i < (int)bvh.nodes.size(); ++i) lvl[(size_t)i] = (int)l;
+    }
+    for (size_t i = 0; i < bvh.nodes.size(); ++i)
+        for (int c = 0; c < 4; ++c) {
+            const NodeQ4& q = bvh.nodes[i];
+            const bool used = ((q.lox >> (8 * c)) & 0xFFu) <= ((q.hix >> (8 * c)) & 0xFFu);
+            if (used && q.child[c] >= 0)
+                CHECK(lvl[(size_t)q.child[c]] == lvl[i] + 1, "%s: node %zu (level %d) has child %d on level %d", name, i,
+                      lvl[i], q.child[c], lvl[(size_t)q.child[c]]);
+        }
     std::printf("%-22s T=%-6d nodes=%-6zu depth=%-3d stack_need=%-3d ok\n", name, T, bvh.nodes.size(), bvh.max_depth, bvh.stack_need);
 }
 

@@ -363,6 +363,65 @@ def test_tail_stream_overlap_and_handoff(pkg, oracle_mod, scene_factory):
     ref_ctx.close()
 
 
+# ---- row f4: moving geometry, device refit instead of a rebuild ------------------------------------------------
+def test_moving_geometry_refit(pkg, oracle_mod, scene_factory):
+    """fs_scene_update_triangles + refit: after props move (also far outside the original bounds, and back)
+    every result equals what the oracle computes on a FRESH structure over the moved triangles — closest hits
+    bit for bit, energies as for any frame."""
+    sc = scene_factory("starter_room", 4)
+    tri0 = sc.triangles.copy()
+    T = tri0.shape[0]
+    ctx, src = make_ctx(pkg, sc)
+    p = pkg.default_params(num_rays=8192, depth=8, seed=11)
+    rng = np.random.default_rng(8)
+
+    def check(tris, tag):
+        osc = oracle_mod.Scene(tris, sc.material_ids, sc.absorption)
+        e_gpu = ctx.compute_energy_response(src, p)          # a pending refit runs before the trace
+        e32, e64, _ = osc.compute_energy(oracle_mod.default_params(num_pairs=4096, depth=8, seed=11), sc.source, sc.listener)
+        check_energy(e_gpu, e32, e64, 4)
+        n = 400
+        o = (sc.source + rng.normal(0, 80, (n, 3))).astype(np.float32)
+        d = rng.normal(size=(n, 3))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        hit, t, tri, nrm = ctx.trace_rays(o, d, 1e6)
+        for i in range(n):
+            h, tt, ti, nn = osc.trace_closest(o[i], d[i], 1e6, brute=True)
+            assert bool(hit[i]) == h, (tag, i)
+            if h:
+                assert t[i] == np.float32(tt) and tri[i] == ti and np.array_equal(nrm[i], nn), (tag, i)
+        return e_gpu
+
+    e0 = check(tri0, "committed")
+    # 1. a block of props slides across the room
+    a, b = T - 900, T - 300
+    moved = tri0.copy()
+    moved[a:b] += np.array([140.0, -75.0, 12.0], np.float32)
+    ctx.update_triangles(a, moved[a:b])
+    e1 = check(moved, "slide")
+    assert not np.array_equal(e1, e0)
+    # 2. a second, overlapping update: scaled about its centroid and lifted; explicit refit call
+    c, d_ = T - 1200, T - 700
+    cen = moved[c:d_].reshape(-1, 3).mean(axis=0)
+    moved[c:d_] = ((moved[c:d_] - cen) * np.array([1.6, 0.7, 1.2], np.float32) + cen + np.array([0, 0, 30.0], np.float32)).astype(np.float32)
+    ctx.update_triangles(c, moved[c:d_])
+    ctx.refit()
+    check(moved, "scale")
+    # 3. far outside the committed bounds: every ancestor box up to the root has to grow
+    far = moved.copy()
+    far[a:a + 200] += np.array([9000.0, 4000.0, 500.0], np.float32)
+    ctx.update_triangles(a, far[a:a + 200])
+    check(far, "far")
+    # 4. everything back where it was: the committed frame again (same path set, same bins)
+    ctx.update_triangles(c, tri0[c:b])
+    e_back = check(tri0, "back")
+    assert np.array_equal(e_back != 0, e0 != 0) and max(rel_rms(e_back[k], e0[k]) for k in range(4)) <= TIGHT_TOL
+    # errors: range outside the scene, update before commit
+    with pytest.raises(pkg.FrequenSeeError):
+        ctx.update_triangles(T - 1, tri0[:2])
+    ctx.close()
+
+
 # ---- golden fixtures -------------------------------------------------------------------------------------------
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg*.npz")))   # frame fixtures
 
