@@ -35,6 +35,10 @@ struct Source {
     hipEvent_t ev_rev = nullptr;       // compute stream: the newest reverb callback has read d_ir_mono
     bool rev_recorded = false;
     float* energy() const { return d_energy[cur]; }
+    // deterministic mode (FS_FLAG_DETERMINISTIC): u64 fixed-point histograms [B][bins], allocated on first use,
+    // alternating like the energy buffers; cur_fixed = the current frame deposited into d_fixed[cur]
+    unsigned long long* d_fixed[2] = {nullptr, nullptr};
+    bool cur_fixed = false;
     float* d_ir_bands = nullptr;  // [B][samples]
     float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
     float* h_ir[kIrRing] = {nullptr, nullptr, nullptr};  // pinned host copies of the channel view
@@ -153,6 +157,7 @@ void free_source(fs_context* ctx, Source* s) {
         (void)hipSetDevice(ctx->cfg.device);
         for (int i = 0; i < 2; ++i) {
             if (s->d_energy[i]) (void)hipFree(s->d_energy[i]);
+            if (s->d_fixed[i]) (void)hipFree(s->d_fixed[i]);
             if (s->ev_rec[i]) (void)hipEventDestroy(s->ev_rec[i]);
         }
         if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
@@ -647,15 +652,26 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
         tf.e[1] = take_event(ctx);
         if (ctx->profiling >= 2) tf.e[2] = take_event(ctx);
     }
+    const bool fixed = (p->flags & FS_FLAG_DETERMINISTIC) != 0;
+    if (fixed && !s->d_fixed[0]) {
+        for (int i = 0; i < 2; ++i)
+            FS_HIP(ctx, hipMalloc((void**)&s->d_fixed[i], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
+    }
     s->cur ^= 1;   // this frame deposits into the other buffer; the tail may still be busy with the last one
+    s->cur_fixed = fixed;
     FS_HIP(ctx, wait_energy_readers(ctx, s));
-    // FlushEnergyBuffer ARTS.cpp:157-161 is folded into the plan pass (one launch); plain memset otherwise
-    const uint32_t* perm = launch_plan(kp, ctx->walk, s->energy(), B * ctx->num_bins, ctx->stream);
-    if (!perm) FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+    // FlushEnergyBuffer ARTS.cpp:157-161 is folded into the plan pass (one launch); plain memset otherwise.
+    // Deterministic mode zeroes the fixed-point histogram instead (the fp32 buffer is rewritten from it).
+    float* zero_ptr = fixed ? reinterpret_cast<float*>(s->d_fixed[s->cur]) : s->energy();
+    const int zero_words = (fixed ? 2 : 1) * B * ctx->num_bins;
+    const uint32_t* perm = launch_plan(kp, ctx->walk, zero_ptr, zero_words, ctx->stream);
+    if (!perm) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     launch_walk(ctx->scene, kp, ctx->st, ctx->walk, perm, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
-    launch_connect(B, ctx->scene, kp, ctx->st, s->energy(), ctx->walk.queue_head, ctx->stream);
+    launch_connect(B, ctx->scene, kp, ctx->st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
+                   ctx->stream);
+    if (fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     if (ctx->profiling) {
         if (tf.e[2]) FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
@@ -701,8 +717,9 @@ int fs_energy_handoff(fs_context* ctx, fs_source h, void** dptr, size_t* bytes, 
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, handoff_energy(ctx, s));
-    if (dptr) *dptr = s->energy();
-    if (bytes) *bytes = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    if (dptr) *dptr = s->cur_fixed ? (void*)s->d_fixed[s->cur] : (void*)s->energy();
+    if (bytes) *bytes = (s->cur_fixed ? sizeof(unsigned long long) : sizeof(float)) * words;
     if (tail_stream) *tail_stream = (void*)ctx->copy_stream;
     return FS_OK;
 }
@@ -747,6 +764,8 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     hipStream_t tail = ctx->copy_stream;
     if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
     if (timed) FS_HIP(ctx, hipEventRecord(tf.e[3], tail));
+    // deterministic mode: the caller's collective summed the fixed-point histogram; round it to fp32 once, now
+    if (s->cur_fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
     launch_reconstruct(s->energy(), B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
                        s->d_ir_mono, tail);
     FS_HIP(ctx, hipGetLastError());

@@ -122,8 +122,10 @@ constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words, hipStream_t s);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
+// fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    unsigned* queue_head, hipStream_t s);
+                    unsigned long long* fixed, unsigned* queue_head, hipStream_t s);
+void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int words, hipStream_t s);
 void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,
                         float* ir_bands, float* ir_mono, hipStream_t s);
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,

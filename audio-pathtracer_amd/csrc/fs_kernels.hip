@@ -25,6 +25,7 @@ namespace {
 constexpr float kPi = 3.1415926535897932f;
 constexpr uint32_t kNoMat = FS_NO_MATERIAL;
 constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
+constexpr double kFixedScale = 1099511627776.0;   // 2^40: quantum of the deterministic (fixed-point) energy sum
 #ifdef FS_TRAV_STATS
 __device__ unsigned long long g_trav_stats[8];   // [0] step calls, [1] node iterations, [2] node lanes, [3] tri iterations, [4] tri lanes
 #endif
@@ -634,7 +635,8 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
 // ---------------------------------------------------------------------------------------------------
 template <int B>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
-                                                         float* __restrict__ energy, unsigned* queue_head) {
+                                                         float* __restrict__ energy,
+                                                         unsigned long long* __restrict__ fixed, unsigned* queue_head) {
     __shared__ int s_stack[kStackRows * kBlock];
     extern __shared__ __attribute__((aligned(16))) float s_hist[];  // [B][num_bins]
     __shared__ int s_lo, s_hi;
@@ -696,15 +698,20 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
         float fl = floorf(x);
         int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
-        atomicMin(&s_lo, bin);
-        atomicMax(&s_hi, bin);
+        if (!fixed) {
+            atomicMin(&s_lo, bin);
+            atomicMax(&s_hi, bin);
+        }
 #pragma unroll
         for (int b = 0; b < B; ++b) {
             float e = E[b];
             e = (e < kp.energy_clamp) ? e : kp.energy_clamp;          // FMath::Min ARTS.cpp:410
             e *= kp.energy_gain;                                      // ARTS.cpp:413
             e *= kp.norm;                                             // ARTS.cpp:164-170
-            atomicAdd(&s_hist[b * nb + bin], e);                      // ds_add_f32
+            if (fixed)   // deterministic mode: integer sum of 2^-40 quanta — exact, so order- and shard-independent
+                atomicAdd(&fixed[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
+            else
+                atomicAdd(&s_hist[b * nb + bin], e);                  // ds_add_f32
         }
     }
     __syncthreads();
@@ -716,6 +723,13 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         float v = s_hist[b * nb + bin];
         if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);           // global_atomic_add_f32
     }
+}
+
+// deterministic mode: fixed-point histogram -> the fp32 energy buffer (one rounding per bin, after all sums)
+__global__ __launch_bounds__(kBlock) void fixed_to_energy_kernel(const unsigned long long* __restrict__ fixed,
+                                                                 float* __restrict__ energy, int words) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < words) energy[i] = (float)((double)fixed[i] * (1.0 / kFixedScale));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1070,12 +1084,12 @@ __global__ void add_energy_kernel(float* row, int nb, float delay, float e) {
 
 template <int B>
 void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                      unsigned* queue_head, hipStream_t s) {
+                      unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
     if (kp.num_local == 0) return;
     uint32_t blocks = (kp.num_local + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;
     size_t lds = sizeof(float) * (size_t)B * (size_t)kp.num_bins;
-    hipLaunchKernelGGL(connect_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, queue_head);
+    hipLaunchKernelGGL(connect_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
 }
 
 }  // namespace
@@ -1105,17 +1119,23 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
 }
 
+void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int words, hipStream_t s) {
+    if (words <= 0) return;
+    hipLaunchKernelGGL(fixed_to_energy_kernel, dim3((unsigned)((words + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, fixed,
+                       energy, words);
+}
+
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    unsigned* queue_head, hipStream_t s) {
+                    unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
     switch (B) {
-        case 1: launch_connect_t<1>(sc, kp, st, energy, queue_head, s); break;
-        case 2: launch_connect_t<2>(sc, kp, st, energy, queue_head, s); break;
-        case 3: launch_connect_t<3>(sc, kp, st, energy, queue_head, s); break;
-        case 4: launch_connect_t<4>(sc, kp, st, energy, queue_head, s); break;
-        case 5: launch_connect_t<5>(sc, kp, st, energy, queue_head, s); break;
-        case 6: launch_connect_t<6>(sc, kp, st, energy, queue_head, s); break;
-        case 7: launch_connect_t<7>(sc, kp, st, energy, queue_head, s); break;
-        default: launch_connect_t<8>(sc, kp, st, energy, queue_head, s); break;
+        case 1: launch_connect_t<1>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 2: launch_connect_t<2>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 3: launch_connect_t<3>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 4: launch_connect_t<4>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 5: launch_connect_t<5>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 6: launch_connect_t<6>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 7: launch_connect_t<7>(sc, kp, st, energy, fixed, queue_head, s); break;
+        default: launch_connect_t<8>(sc, kp, st, energy, fixed, queue_head, s); break;
     }
 }
 

@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--inflight", type=int, default=None,
                     help="independent frames in flight (one context + HIP stream each); 1 = strictly sequential frames")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="FS_FLAG_DETERMINISTIC: u64 fixed-point deposits, integer all-reduce (bit-identical for any N)")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra region that times the same frames with two in flight")
     args = ap.parse_args()
@@ -124,6 +126,8 @@ def main():
         total_rays = rays_per_gpu * world
         p = pkg.default_params(num_rays=total_rays, depth=depth, seed=args.seed,
                                russian_roulette=0 if args.fixed_depth else 1)
+    if args.deterministic:
+        p.flags |= pkg._capi.FLAG_DETERMINISTIC
     lanes = []   # one (stream, context, source) per frame in flight; multi-source: one per source of this rank,
     #              the sources dealt round-robin to `--inflight` contexts (each context = one compute + one tail stream)
     ctxs = []
@@ -163,9 +167,11 @@ def main():
         if world > 1:
             # RCCL sum of the [bands][bins] fp32 energy buffer on the context's tail stream: it and the
             # reconstruct behind it overlap the next frame's tracing on the compute stream
-            eptr, _, tail = c.energy_handoff(s_i)
-            if eptr not in tensors:
-                tensors[eptr] = torch.as_tensor(_CudaArray(eptr, (bands * c.num_bins,)), device=f"cuda:{local_rank}")
+            eptr, ebytes, tail = c.energy_handoff(s_i)
+            if eptr not in tensors:   # fp32 energy, or the i64 fixed-point histogram in deterministic mode
+                tensors[eptr] = torch.as_tensor(_CudaArray(eptr, (bands * c.num_bins,),
+                                                           "<i8" if ebytes == 8 * bands * c.num_bins else "<f4"),
+                                                device=f"cuda:{local_rank}")
             if tail not in tails:
                 tails[tail] = torch.cuda.ExternalStream(tail, device=f"cuda:{local_rank}")
             with torch.cuda.stream(tails[tail]):

@@ -50,6 +50,10 @@ enum {
 #define FS_FLAG_FIXED_NORM_1000 1u          /* ARTS.cpp:164 normaliser 1/USED_RAY_COUNT whatever NumRays is */
 #define FS_FLAG_FLUSH_BEFORE_RECONSTRUCT 2u /* ARTS.cpp:191 second FlushEnergyBuffer (IR becomes all zero) */
 #define FS_FLAG_COSINE_SAMPLING 4u          /* cosine-weighted bounce instead of VRandCone(n, 90 deg) */
+#define FS_FLAG_DETERMINISTIC 8u            /* deposits are summed as 64-bit integers of 2^-40 energy quanta: the
+                                             * histogram no longer depends on the order of the atomics, so it is bit-identical
+                                             * from run to run and for every split of the pairs over GPUs (sum-reduce the u64
+                                             * buffer fs_energy_handoff returns; it is rounded to fp32 once, after the reduce) */
 
 typedef struct fs_context fs_context;
 typedef int32_t fs_source; /* handle of one registered UFrequenSeeAudioComponent */
@@ -159,7 +163,9 @@ int fs_energy_device_ptr(fs_context* ctx, fs_source src, void** dptr, size_t* by
  * before anything enqueued on *tail_stream after this call.  The caller issues its collective there
  * (ncclAllReduce(dptr, dptr, B*1000, ncclFloat, ncclSum, comm, (hipStream_t)*tail_stream)) and then calls
  * fs_reconstruct_impulse_response_async, which runs behind it on the same stream — all of it concurrent with
- * the next frame's tracing on the compute stream.  Any of the three out-pointers may be NULL. */
+ * the next frame's tracing on the compute stream.  Any of the three out-pointers may be NULL.
+ * If the frame was computed with FS_FLAG_DETERMINISTIC, *dptr is the [B][num_bins] uint64 fixed-point histogram
+ * and *bytes = 8 * B * num_bins: reduce it with an integer sum (ncclUint64 / ncclSum); the reconstruct converts it. */
 int fs_energy_handoff(fs_context* ctx, fs_source src, void** dptr, size_t* bytes, void** tail_stream);
 
 /* ReconstructImpulseResponse (FSAC.cpp:320-380, called at ARTS.cpp:192): energy -> per-band IR

@@ -363,6 +363,64 @@ def test_tail_stream_overlap_and_handoff(pkg, oracle_mod, scene_factory):
     ref_ctx.close()
 
 
+# ---- deterministic (fixed-point) accumulation ------------------------------------------------------
+def test_deterministic_mode_is_bit_reproducible_and_shard_invariant(pkg, oracle_mod, scene_factory):
+    """FS_FLAG_DETERMINISTIC: deposits are summed as u64 counts of 2^-40 quanta.  The histogram is then (i) within
+    the usual tolerance of the oracle, (ii) bit-identical from run to run (the fp32 atomics are not), and (iii)
+    bit-identical for every split of the pairs over ranks once the u64 buffers are integer-summed — the quantity a
+    multi-GPU all-reduce sees through fs_energy_handoff."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    sc = scene_factory("starter_room", 4)
+    det = pkg._capi.FLAG_DETERMINISTIC
+    p = pkg.default_params(num_rays=16384, depth=8, seed=21, flags=det)
+    nb = 4 * 1000
+
+    def fixed_hist(ctx, src):
+        ctx.compute_energy_response_async(src, p)
+        ptr, nbytes, _ = ctx.energy_handoff(src)
+        assert nbytes == 8 * nb                                   # u64 histogram, not the fp32 buffer
+        ctx.synchronize()
+        h = np.zeros(nb, np.uint64)
+        assert hip.hipMemcpy(h.ctypes.data, ptr, nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return h
+
+    ctx, src = make_ctx(pkg, sc)
+    runs = [ctx.compute_energy_response(src, p).copy() for _ in range(3)]
+    assert all(np.array_equal(r, runs[0]) for r in runs[1:])      # (ii)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, _ = osc.compute_energy(oracle_mod.default_params(num_pairs=8192, depth=8, seed=21), sc.source, sc.listener)
+    # (i) a deposit is rounded to the nearest 2^-40 (9e-13; the reconstruct ignores bins below 1e-6), so a bin
+    #     may differ from the exact sum by half a quantum per deposit
+    for b in range(4):
+        assert rel_rms(runs[0][b], e64[b]) <= TIGHT_TOL
+    assert np.abs(runs[0] - e64).max() <= 1e-9 + TIGHT_TOL * np.abs(e64).max()
+    full = fixed_hist(ctx, src)
+    assert np.array_equal((full.astype(np.float64) * 2.0 ** -40).astype(np.float32).reshape(4, 1000), runs[0])
+    # the reconstruct of a deterministic frame uses the (reduced) fixed-point histogram
+    ctx.reconstruct_impulse_response(src, p)
+    mean = (runs[0].sum(axis=0, dtype=np.float32) / np.float32(4)).astype(np.float32)
+    want = oracle_mod.reconstruct(mean)
+    assert np.abs(ctx.impulse_response(src, 0) - want).max() <= IR_TOL * np.abs(want).max()
+    ctx.close()
+    for world in (2, 3, 5):                                       # (iii)
+        acc = np.zeros(nb, np.uint64)
+        for r in range(world):
+            c, s_ = make_ctx(pkg, sc, rank=r, world_size=world)
+            acc += fixed_hist(c, s_)
+            c.close()
+        assert np.array_equal(acc, full), world
+    # the default fp32 path is untouched by the flag's existence
+    ctx, src = make_ctx(pkg, sc)
+    e = ctx.compute_energy_response(src, pkg.default_params(num_rays=16384, depth=8, seed=21))
+    check_energy(e, e32, e64, 4)
+    assert np.abs(e - runs[0]).max() <= 1e-9 + TIGHT_TOL * np.abs(e64).max()
+    _, nbytes, _ = ctx.energy_handoff(src)
+    assert nbytes == 4 * nb
+    ctx.close()
+
+
 # ---- row f4: moving geometry, device refit instead of a rebuild ------------------------------------------------
 def test_moving_geometry_refit(pkg, oracle_mod, scene_factory):
     """fs_scene_update_triangles + refit: after props move (also far outside the original bounds, and back)
