@@ -102,6 +102,8 @@ struct fs_context {
     // subpath state (sized on demand)
     SubpathState st{};
     size_t cap_lanes = 0, cap_seg = 0;
+    float4* d_seg_pos = nullptr;   // node positions per walk step, all-connections mode only (row f3)
+    size_t cap_pos = 0;
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
     WalkLaunch walk{0, 256, 2, nullptr, 1, nullptr};
@@ -196,6 +198,8 @@ void free_state(fs_context* ctx) {
     if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
     if (ctx->st.seg_np) (void)hipFree(ctx->st.seg_np);
     if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
+    if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
+    ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
     if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
     ctx->walk.perm = nullptr;
     ctx->st = SubpathState{};
@@ -249,9 +253,15 @@ void poll_published(Source* s) {
     s->front.store(f, std::memory_order_release);
 }
 
-int ensure_state(fs_context* ctx, uint32_t n_local, int depth) {
+int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positions) {
     size_t lanes = 2 * (size_t)n_local;
     size_t seg = (size_t)depth * lanes;
+    if (want_positions && seg > ctx->cap_pos) {
+        if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
+        ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_seg_pos, sizeof(float4) * std::max<size_t>(seg, 1)));
+        ctx->cap_pos = seg;
+    }
     if (lanes > ctx->cap_lanes) {
         if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
         if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
@@ -642,8 +652,11 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     kp.num_bins = ctx->num_bins;
     kp.refill_threshold = ctx->refill_threshold;
 
-    rc = ensure_state(ctx, kp.num_local, kp.depth);
+    const bool all_conn = (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
+    rc = ensure_state(ctx, kp.num_local, kp.depth, all_conn);
     if (rc) return rc;
+    SubpathState st = ctx->st;
+    st.seg_pos = all_conn ? ctx->d_seg_pos : nullptr;
 
     TimedFrame tf{};
     if (ctx->profiling) {
@@ -667,10 +680,14 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     const uint32_t* perm = launch_plan(kp, ctx->walk, zero_ptr, zero_words, ctx->stream);
     if (!perm) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
-    launch_walk(ctx->scene, kp, ctx->st, ctx->walk, perm, ctx->stream);
+    launch_walk(ctx->scene, kp, st, ctx->walk, perm, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
-    launch_connect(B, ctx->scene, kp, ctx->st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
-                   ctx->stream);
+    if (all_conn)
+        launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
+                           ctx->stream);
+    else
+        launch_connect(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
+                       ctx->stream);
     if (fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     if (ctx->profiling) {

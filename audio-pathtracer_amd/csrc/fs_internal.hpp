@@ -90,6 +90,8 @@ struct SubpathState {
                         //   node EvaluatePath pairs with the segment (departure node on the source side,
                         //   arrival node on the listener side)
     uint32_t* seg_mat;  // [depth][total] material of that node
+    float4* seg_pos;    // [depth][total] xyz = position of the node a walk step arrives at; only written (and only
+                        //   non-null) in all-connections mode, which connects interior nodes too (row f3)
 };
 
 // ---- host BVH builder ------------------------------------------------------------------------------
@@ -125,6 +127,9 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
                     unsigned long long* fixed, unsigned* queue_head, hipStream_t s);
+// row f3: every forward prefix x every backward prefix of each pair (one wave per pair), uniform MIS weights
+void launch_connect_all(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
+                        unsigned long long* fixed, unsigned* queue_head, hipStream_t s);
 void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int words, hipStream_t s);
 void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,
                         float* ir_bands, float* ir_mono, hipStream_t s);

@@ -432,6 +432,7 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
     const size_t slot = (size_t)w.k * (2u * (size_t)kp.num_local) + w.g;
     st.seg_np[slot] = w.side == 0 ? make_float2(nd, w.prob) : make_float2(nd, w.prob_new);
     st.seg_mat[slot] = w.side == 0 ? w.mat : mat_new;
+    if (st.seg_pos) st.seg_pos[slot] = make_float4(qx, qy, qz, 0.0f);   // all-connections mode (wave-uniform)
     w.px = qx; w.py = qy; w.pz = qz;
     w.mat = mat_new;
     w.prob = w.prob_new;
@@ -722,6 +723,120 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         int b = i / span, bin = lo + (i - b * span);
         float v = s_hist[b * nb + bin];
         if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);           // global_atomic_add_f32
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// connect_all_kernel (row f3): the reference's unfinished "naive connections" (Is_NaiveConnections,
+// ARTS.cpp:518-546: every bounce of the forward sample x every bounce of the backward sample, "Equation 12").
+// For pair p with forward nodes F0..Fk and backward nodes B0..Bm every (i, j) in [0,k] x [0,m] is a
+// candidate path F0..Fi, Bj..B0: ConnectSubpaths' visibility test Fi -> Bj, EvaluatePath over the stored
+// segment records in path order, uniform multiple-importance weight 1 / N(i + j) with N(t) = number of
+// (i', j') in [0, D]^2, i' + j' = t (D = depth cap).  One WAVE per pair, one lane per (i, j): the up to
+// (D+1)^2 visibility rays of a pair start and end at neighbouring nodes, so the wave traverses coherently.
+// ---------------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KParams kp, SubpathState st,
+                                                             float* __restrict__ energy,
+                                                             unsigned long long* __restrict__ fixed,
+                                                             unsigned* queue_head) {
+    __shared__ int s_stack[kStackRows * kBlock];
+    extern __shared__ __attribute__((aligned(16))) float s_hist[];  // [B][num_bins]
+    __shared__ int s_lo, s_hi;
+    const int nb = kp.num_bins;
+    for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
+    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
+    __syncthreads();
+
+    const uint32_t n = kp.num_local;
+    const uint32_t total = 2u * n;
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t wave = threadIdx.x >> 6, waves = kBlock / 64;
+    for (uint32_t li = blockIdx.x * waves + wave; li < n; li += gridDim.x * waves) {
+        const uint2 Fm = st.end_misc[li];
+        const uint2 Lm = st.end_misc[n + li];
+        const int kf = (int)Fm.y, kl = (int)Lm.y;
+        const int combos = (kf + 1) * (kl + 1);
+        for (int c = lane; c < combos; c += 64) {
+            const int i = c / (kl + 1), j = c - i * (kl + 1);
+            // node Fi (position, material, probability) and node Bj (position)
+            float fx = kp.src[0], fy = kp.src[1], fz = kp.src[2];
+            if (i > 0) { const float4 q = st.seg_pos[(size_t)(i - 1) * total + li]; fx = q.x; fy = q.y; fz = q.z; }
+            float bx = kp.lis[0], by = kp.lis[1], bz = kp.lis[2];
+            if (j > 0) { const float4 q = st.seg_pos[(size_t)(j - 1) * total + n + li]; bx = q.x; by = q.y; bz = q.z; }
+            uint32_t fmat; float fprob;
+            if (i < kf) { fmat = st.seg_mat[(size_t)i * total + li]; fprob = st.seg_np[(size_t)i * total + li].y; }
+            else { fmat = Fm.x; fprob = st.end_pos[li].w; }
+            float dx = bx - fx, dy = by - fy, dz = bz - fz;
+            float l2 = dx * dx + dy * dy + dz * dz;
+            bool visible = true;
+            if (l2 > 1e-8f) {
+                float len = sqrtf(l2);
+                float inv = 1.0f / len;
+                float tmax = len - kp.connect_pullback;
+                if (tmax > 0.0f) {
+                    Ray ray = make_ray(fx, fy, fz, dx * inv, dy * inv, dz * inv);
+                    Trav T;
+                    trav_init(T, tmax, sc.num_nodes > 0);
+                    trav_run<true>(sc, ray, T, &s_stack[threadIdx.x]);
+                    visible = T.leaf_index < 0;
+                }
+            }
+            if (!visible) continue;
+            float E[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) E[b] = 1.0f;
+            float sd = 0.0f;
+            for (int a = 0; a < i; ++a) {                                 // F_a -> F_a+1
+                const float2 np = st.seg_np[(size_t)a * total + li];
+                sd += np.x;
+                apply_segment<B>(E, np.x, st.seg_mat[(size_t)a * total + li], np.y, kp, sc);
+            }
+            {                                                             // Fi -> Bj
+                float nd = sqrtf(l2) / kp.dist_divisor;
+                sd += nd;
+                apply_segment<B>(E, nd, fmat, fprob, kp, sc);
+            }
+            for (int a = j - 1; a >= 0; --a) {                            // B_a+1 -> B_a
+                const float2 np = st.seg_np[(size_t)a * total + n + li];
+                sd += np.x;
+                apply_segment<B>(E, np.x, st.seg_mat[(size_t)a * total + n + li], np.y, kp, sc);
+            }
+            const int t = i + j, D = kp.depth;
+            const int lo_t = t - D > 0 ? t - D : 0, hi_t = t < D ? t : D;
+            const float w = 1.0f / (float)(hi_t - lo_t + 1);
+            float delay = sd / kp.sound_speed;
+            float x = (delay * 1000.f) / 1.0f;
+            float fl = floorf(x);
+            int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
+            if (!fixed) {
+                atomicMin(&s_lo, bin);
+                atomicMax(&s_hi, bin);
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                float e = E[b];
+                e = (e < kp.energy_clamp) ? e : kp.energy_clamp;
+                e *= kp.energy_gain;
+                e *= kp.norm;
+                e *= w;
+                if (fixed)
+                    atomicAdd(&fixed[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
+                else
+                    atomicAdd(&s_hist[b * nb + bin], e);
+            }
+        }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    if (hi < lo) return;
+    const int span = hi - lo + 1;
+    for (int i = threadIdx.x; i < B * span; i += kBlock) {
+        int b = i / span, bin = lo + (i - b * span);
+        float v = s_hist[b * nb + bin];
+        if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);
     }
 }
 
@@ -1117,6 +1232,30 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     if (blocks > full) blocks = full;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
+}
+
+template <int B>
+void launch_connect_all_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
+                          unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
+    if (kp.num_local == 0) return;
+    uint32_t blocks = (kp.num_local + 3) / 4;   // one wave per pair, 4 waves per workgroup
+    if (blocks > 4096) blocks = 4096;
+    size_t lds = sizeof(float) * (size_t)B * (size_t)kp.num_bins;
+    hipLaunchKernelGGL(connect_all_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
+}
+
+void launch_connect_all(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
+                        unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
+    switch (B) {
+        case 1: launch_connect_all_t<1>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 2: launch_connect_all_t<2>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 3: launch_connect_all_t<3>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 4: launch_connect_all_t<4>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 5: launch_connect_all_t<5>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 6: launch_connect_all_t<6>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 7: launch_connect_all_t<7>(sc, kp, st, energy, fixed, queue_head, s); break;
+        default: launch_connect_all_t<8>(sc, kp, st, energy, fixed, queue_head, s); break;
+    }
 }
 
 void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int words, hipStream_t s) {

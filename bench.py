@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--inflight", type=int, default=None,
                     help="independent frames in flight (one context + HIP stream each); 1 = strictly sequential frames")
+    ap.add_argument("--all-connections", action="store_true",
+                    help="FS_FLAG_ALL_CONNECTIONS (row f3): every forward prefix x every backward prefix per pair")
     ap.add_argument("--deterministic", action="store_true",
                     help="FS_FLAG_DETERMINISTIC: u64 fixed-point deposits, integer all-reduce (bit-identical for any N)")
     ap.add_argument("--no-pipelined", action="store_true",
@@ -128,6 +130,8 @@ def main():
                                russian_roulette=0 if args.fixed_depth else 1)
     if args.deterministic:
         p.flags |= pkg._capi.FLAG_DETERMINISTIC
+    if args.all_connections:
+        p.flags |= pkg._capi.FLAG_ALL_CONNECTIONS
     lanes = []   # one (stream, context, source) per frame in flight; multi-source: one per source of this rank,
     #              the sources dealt round-robin to `--inflight` contexts (each context = one compute + one tail stream)
     ctxs = []
@@ -293,7 +297,8 @@ def main():
         except Exception:
             lib = oracle.load()
         osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption, lib=lib)
-        op = oracle.default_params(num_pairs=total_rays // 2, depth=depth, seed=args.seed,
+        oflags = oracle.FLAG_ALL_CONNECTIONS if args.all_connections else 0
+        op = oracle.default_params(num_pairs=total_rays // 2, depth=depth, seed=args.seed, flags=oflags,
                                    russian_roulette=0 if args.fixed_depth else 1)
         # 1 thread on a bounded sample (the first 1/8 of the frame's pairs)
         sample_pairs = max(1, (total_rays // 2) // 8)
@@ -309,7 +314,7 @@ def main():
         extra_frames = int(max(0, min(15, round(12.0 / max(t_first * cores, 1e-3)) - 1)))
         t1 = time.perf_counter()
         for i in range(extra_frames):
-            op_i = oracle.default_params(num_pairs=total_rays // 2, depth=depth, seed=args.seed + 1 + i,
+            op_i = oracle.default_params(num_pairs=total_rays // 2, depth=depth, seed=args.seed + 1 + i, flags=oflags,
                                          russian_roulette=0 if args.fixed_depth else 1)
             osc.compute_energy_mt(op_i, sc.source, sc.listener, cores)
         t_mt = (t_first + (time.perf_counter() - t1)) / (1 + extra_frames)
@@ -342,6 +347,7 @@ def main():
                                             f"{2 * sample_pairs / t_1t:.0f} rays/s",
                                   "value_1_thread": 2 * sample_pairs / t_1t}
         result["parity"] = {"max_rel_rms_per_band": max(rms), "connected_pairs": cnt["connected"],
+                            "connections_tested": cnt["any_rays"],
                             "segments": cnt["closest_rays"], "node_visits": cnt["node_visits"],
                             "tri_tests": cnt["tri_tests"]}
     if rank == 0:

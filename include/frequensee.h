@@ -50,6 +50,10 @@ enum {
 #define FS_FLAG_FIXED_NORM_1000 1u          /* ARTS.cpp:164 normaliser 1/USED_RAY_COUNT whatever NumRays is */
 #define FS_FLAG_FLUSH_BEFORE_RECONSTRUCT 2u /* ARTS.cpp:191 second FlushEnergyBuffer (IR becomes all zero) */
 #define FS_FLAG_COSINE_SAMPLING 4u          /* cosine-weighted bounce instead of VRandCone(n, 90 deg) */
+#define FS_FLAG_ALL_CONNECTIONS 16u          /* row f3, the reference's unfinished draft (Is_NaiveConnections, ARTS.cpp:518-546): connect every
+                                             * forward prefix F0..Fi with every backward prefix B0..Bj of a pair (visibility test and
+                                             * EvaluatePath as for the end-to-end connection) and combine the (i, j) that give the same
+                                             * path length with uniform weights 1/N(i+j); ~(k+1)(m+1) contributions per pair instead of 1 */
 #define FS_FLAG_DETERMINISTIC 8u            /* deposits are summed as 64-bit integers of 2^-40 energy quanta: the
                                              * histogram no longer depends on the order of the atomics, so it is bit-identical
                                              * from run to run and for every split of the pairs over GPUs (sum-reduce the u64

@@ -22,6 +22,7 @@ FLAG_FIXED_NORM_1000 = 1
 FLAG_FLUSH_BEFORE_RECONSTRUCT = 2
 FLAG_COSINE_SAMPLING = 4
 FLAG_BRUTE_FORCE = 8
+FLAG_ALL_CONNECTIONS = 16
 
 
 class Params(C.Structure):

@@ -639,6 +639,38 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
         int32_t nf = fso_generate_path(s, p, i, 0, src, fwd, max_nodes, c);
         int32_t nb = fso_generate_path(s, p, i, 1, lis, bwd, max_nodes, c);
         if (nf == 0 || nb == 0) continue;                  /* ARTS.cpp:237 */
+        if (p->flags & FSO_FLAG_ALL_CONNECTIONS) {
+            /* Row f3 — the reference's unfinished "naive connections" draft (Is_NaiveConnections, ARTS.cpp:518-546:
+             * "connect every bounce of every sample in forward dir with every bounce in backward dir, Equation
+             * 12"), restated for one pair: forward prefix F0..Fi (i = 0..k) x backward prefix B0..Bj (j = 0..m),
+             * each connected by ConnectSubpaths' visibility test and evaluated by EvaluatePath on the path
+             * F0..Fi, Bj..B0.  Several (i, j) produce paths with the same number of segments i + j + 1; they are
+             * combined with uniform multiple-importance weights 1 / N(i + j), N(t) = number of (i', j') in
+             * [0, D]^2 with i' + j' = t (D = depth cap) — the weights of one path length sum to 1. */
+            int32_t D = p->depth > 0 ? p->depth : FSO_MAX_DEPTH;
+            for (int32_t fi = 0; fi < nf; ++fi)
+                for (int32_t bj = 0; bj < nb; ++bj) {
+                    if (!fso_connect(s, p, &fwd[fi], &bwd[bj], c)) continue;
+                    if (c) c->connected++;
+                    memcpy(all, fwd, sizeof(fso_node) * (size_t)(fi + 1));
+                    for (int32_t j = 0; j <= bj; ++j) all[fi + 1 + j] = bwd[bj - j];
+                    float gains[FSO_MAX_BANDS], delay;
+                    fso_evaluate_path(s, p, all, fi + bj + 2, gains, &delay);
+                    int32_t t = fi + bj;
+                    int32_t lo = t - D > 0 ? t - D : 0, hi = t < D ? t : D;
+                    float w = 1.0f / (float)(hi - lo + 1);
+                    int32_t bin = 0;
+                    for (int b = 0; b < B; ++b) {
+                        float e = gains[b];
+                        e *= norm;
+                        e *= w;
+                        bin = fso_add_energy_at_delay(energy_f32 + (size_t)b * (size_t)num_bins, num_bins, 1, delay, e);
+                        if (energy_f64) energy_f64[(size_t)b * (size_t)num_bins + (size_t)bin] += (double)e;
+                    }
+                    if (c) c->deposits++;
+                }
+            continue;
+        }
         if (!fso_connect(s, p, &fwd[nf - 1], &bwd[nb - 1], c)) continue;
         if (c) c->connected++;
         /* node order F0..Fk, Bm..B0 ARTS.cpp:262-267 */

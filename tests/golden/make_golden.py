@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates the committed golden fixtures from the CPU oracle (run in the build container):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case names ...]
 
 The reference has no golden vectors of its own and cannot run here, so these pin the
 ORACLE (a later change to oracle/fs_oracle.c that alters any output fails tests/test_golden.py) and give
@@ -28,12 +28,18 @@ CASES = [
     ("cfg2_starter_room_metres", "starter_room", 4, 4096, 8, 77, {"dist_divisor": 100.0}),
     ("cfg2_starter_room_fixed_depth", "starter_room", 4, 2048, 6, 5, {"russian_roulette": 0}),
     ("cfg3_old_mine", "old_mine", 8, 131072, 8, 0x5EED, {}),
+    # row f3 (FS_FLAG_ALL_CONNECTIONS == FSO_FLAG_ALL_CONNECTIONS == 16)
+    ("cfg1_shoebox_all_connections", "shoebox", 1, 512, 4, 0x5EED, {"flags": 16}),
+    ("cfg2_starter_room_all_connections", "starter_room", 4, 2048, 8, 9, {"flags": 16}),
 ]
 
 
 def main():
     pkg = graft.load_package()
+    only = set(sys.argv[1:])   # optional: regenerate just the named cases
     for name, scene, bands, pairs, depth, seed, extra in CASES:
+        if only and name not in only:
+            continue
         sc = pkg.scenes.by_name(scene, bands)
         osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption)
         p = oracle.default_params(num_pairs=pairs, depth=depth, seed=seed, **extra)

@@ -110,6 +110,13 @@ VARIANTS = [
     ("min_seg_zero", "shoebox", 1, 1024, 4, {"min_seg": 0.0, "dist_divisor": 100.0},
      {"min_seg": 0.0, "dist_divisor": 100.0}),
     ("one_pair", "shoebox", 1, 2, 8, {}, {}),
+    # row f3: every forward prefix x every backward prefix, uniform MIS weights (flag 16 on both sides)
+    ("all_connections_cfg1", "shoebox", 1, 1024, 4, {"flags": 16}, {"flags": 16}),
+    ("all_connections_cfg2", "starter_room", 4, 8192, 8, {"flags": 16}, {"flags": 16}),
+    ("all_connections_mine_no_rr", "old_mine", 8, 4096, 5, {"flags": 16, "russian_roulette": 0, "dist_divisor": 200.0},
+     {"flags": 16, "russian_roulette": 0, "dist_divisor": 200.0}),
+    ("all_connections_unbounded", "shoebox", 2, 600, 0, {"flags": 16}, {"flags": 16}),
+    ("all_connections_one_pair", "shoebox", 1, 2, 8, {"flags": 16}, {"flags": 16}),
 ]
 
 
@@ -363,6 +370,37 @@ def test_tail_stream_overlap_and_handoff(pkg, oracle_mod, scene_factory):
     ref_ctx.close()
 
 
+# ---- row f3: all-prefix connections ----------------------------------------------------------------------------
+def test_all_connections_properties_full_size(pkg, oracle_mod, scene_factory):
+    """cfg3 size (262 144 rays, depth 8, 100 000 triangles) in all-connections mode: oracle parity on a pair
+    subset through sharding (rank 0 of 16 traces the first 8 192 pairs with the full frame's normaliser), and
+    size-independent properties of the whole frame: shard invariance, and the i = k, j = m strategy alone
+    (weight 1/N) is contained in it, so energy(all) >= energy(end-to-end) / (D + 1) bin by bin."""
+    sc = scene_factory("old_mine", 8)
+    flags = pkg._capi.FLAG_ALL_CONNECTIONS
+    p_all = pkg.default_params(num_rays=262144, depth=8, seed=0x5EED, flags=flags)
+    ctx, src = make_ctx(pkg, sc)
+    e_all = ctx.compute_energy_response(src, p_all).astype(np.float64)
+    e_end = ctx.compute_energy_response(src, pkg.default_params(num_rays=262144, depth=8, seed=0x5EED)).astype(np.float64)
+    ctx.close()
+    assert e_all.sum() > e_end.sum() > 0
+    assert np.all(e_all * (1 + 1e-4) + 1e-12 >= e_end / 9.0)
+    acc = np.zeros_like(e_all)
+    for r in range(2):
+        c, s_ = make_ctx(pkg, sc, rank=r, world_size=2)
+        acc += c.compute_energy_response(s_, p_all)
+        c.close()
+    assert np.array_equal(acc != 0, e_all != 0) and max(rel_rms(acc[b], e_all[b]) for b in range(8)) <= TIGHT_TOL
+    c, s_ = make_ctx(pkg, sc, rank=0, world_size=16)
+    e_r0 = c.compute_energy_response(s_, p_all)
+    c.close()
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    op = oracle_mod.default_params(num_pairs=131072, depth=8, seed=0x5EED, flags=oracle_mod.FLAG_ALL_CONNECTIONS)
+    e32, e64, cnt = osc.compute_energy(op, sc.source, sc.listener, pair_begin=0, pair_end=8192)
+    assert cnt.connected > 8192                                   # more than one connection per pair on average
+    check_energy(e_r0, e32, e64, 8)
+
+
 # ---- SURVEY.md 8e: deterministic (fixed-point) accumulation ------------------------------------------------------
 def test_deterministic_mode_is_bit_reproducible_and_shard_invariant(pkg, oracle_mod, scene_factory):
     """FS_FLAG_DETERMINISTIC: deposits are summed as u64 counts of 2^-40 quanta.  The histogram is then (i) within
@@ -488,8 +526,9 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "cfg
 def test_gpu_matches_golden(pkg, scene_factory, path):
     z = np.load(path)
     extra = {str(k): float(v) for k, v in zip(z["extra_keys"], z["extra_vals"])}
-    if "russian_roulette" in extra:
-        extra["russian_roulette"] = int(extra["russian_roulette"])
+    for key in ("russian_roulette", "flags"):
+        if key in extra:
+            extra[key] = int(extra[key])
     bands = int(z["bands"])
     sc = scene_factory(str(z["scene"]), bands)
     ctx, src = make_ctx(pkg, sc)

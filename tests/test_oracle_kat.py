@@ -317,3 +317,33 @@ def test_legacy_forward_tracer_statistics(oracle_mod, scene_factory):
         assert abs(np.linalg.norm(v) - 1) < 1e-5
         acc += v
     assert np.abs(acc / 4000).max() < 0.05
+
+
+def test_kat_all_connections_open_space(oracle_mod):
+    """Row f3 by hand.  Nothing is ever hit (one speck of a triangle far away), Russian roulette off, D = 2:
+    every walk step misses, so F0..F2 all sit at the source and B0..B2 at the listener (the duplicate nodes of
+    ARTS.cpp:296) and all 9 (i, j) connections are visible.  Path (i, j): i zero-length segments (skipped,
+    ARTS.cpp:375-378), the connection of d = 3, j zero-length segments => E = 1/(4 pi d^2) exp(-0.05 d) / P(Fi)^0.1
+    with P(F0) = 1, P(Fi>0) = 0.9/(4 pi) (sphere pdf x roulette, ARTS.cpp:306-310); weight 1/N(i+j) with
+    N(0..4) = 1, 2, 3, 2, 1; everything lands in bin floor(3/343 s / 1 ms) = 8."""
+    far = np.array([[[1e5, 1e5, 1e5], [1e5 + 1e-3, 1e5, 1e5], [1e5, 1e5 + 1e-3, 1e5]]], np.float32)
+    s = oracle_mod.Scene(far, np.zeros(1, np.uint16), np.array([[0.5]], np.float32))
+    pairs = 4
+    p = oracle_mod.default_params(num_pairs=pairs, depth=2, russian_roulette=0, flags=oracle_mod.FLAG_ALL_CONNECTIONS)
+    e32, e64, c = s.compute_energy(p, (0, 0, 0), (3000, 0, 0))
+    assert c.connected == 9 * pairs and c.deposits == 9 * pairs and c.any_rays == 9 * pairs
+    base = 1.0 / (4 * math.pi * 9.0) * math.exp(-0.15)
+    gain = [10.0 * min(1.0, base), 10.0 * min(1.0, base / (0.9 / (4 * math.pi)) ** 0.1)]
+    weight = {0: 1.0, 1: 0.5, 2: 1.0 / 3.0, 3: 0.5, 4: 1.0}
+    want = sum(gain[min(i, 1)] * weight[i + j] for i in range(3) for j in range(3))   # x pairs x norm (1/pairs)
+    assert np.count_nonzero(e64) == 1 and e64[0, 8] == pytest.approx(want, rel=2e-6)
+    assert e32[0, 8] == pytest.approx(want, rel=1e-5)
+    # the end-to-end strategy alone (default mode) is the (2, 2) term with weight 1
+    p1 = oracle_mod.default_params(num_pairs=pairs, depth=2, russian_roulette=0)
+    _, e64b, c1 = s.compute_energy(p1, (0, 0, 0), (3000, 0, 0))
+    assert c1.connected == pairs and e64b[0, 8] == pytest.approx(gain[1], rel=2e-6)
+    # weights of one path length sum to 1 for any depth cap
+    for D in (1, 2, 5, 8):
+        for t in range(2 * D + 1):
+            n = sum(1 for i in range(D + 1) for j in range(D + 1) if i + j == t)
+            assert n == min(t, D) - max(0, t - D) + 1
