@@ -43,7 +43,7 @@ EXPORTS = [
     "fs_sound_params_default", "fs_scene_set_objects", "fs_update_sound", "fs_get_occlusion_attenuation",
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
-    "fs_apply_material_fd", "fs_energy_handoff", "fs_scene_update_triangles", "fs_scene_refit",
+    "fs_apply_material_fd", "fs_energy_handoff", "fs_scene_update_triangles", "fs_scene_refit", "fs_set_impulse_response",
 ]
 REVERB_LITERAL_TAIL = 1
 
@@ -174,6 +174,7 @@ def load():
         "fs_energy_device_ptr": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "fs_scene_update_triangles": (C.c_int, [vp, i32, i32, f32p]),
         "fs_scene_refit": (C.c_int, [vp]),
+        "fs_set_impulse_response": (C.c_int, [vp, i32, f32p, i32]),
         "fs_energy_handoff": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]),
         "fs_reconstruct_impulse_response": (C.c_int, [vp, i32, C.POINTER(Params)]),
         "fs_reconstruct_impulse_response_async": (C.c_int, [vp, i32, C.POINTER(Params)]),

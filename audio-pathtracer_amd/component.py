@@ -142,6 +142,11 @@ class Context:
         self.check(self.lib.fs_copy_impulse_response(self.h, src, channel, out.ctypes.data, out.shape[0]))
         return out
 
+    def set_impulse_response(self, src, ir):
+        """install an IR of the caller's own (GetImpulseResponse() is a mutable reference, FSAC.h:113)"""
+        a = np.ascontiguousarray(ir, dtype=np.float32).reshape(-1)
+        self.check(self.lib.fs_set_impulse_response(self.h, src, a.ctypes.data, a.shape[0]))
+
     def impulse_response_view(self, src, channel=0):
         """zero-copy view of the published front buffer (valid until the second-next publish)"""
         p, n = C.POINTER(C.c_float)(), C.c_int32()
@@ -291,6 +296,17 @@ class FrequenSeeAudioComponent:
     def GetImpulseResponse(self):  # FSAC.h:113 -> [NumChannels][NumSamples]
         c = self._ctx()
         return [c.impulse_response_view(self._src, ch) for ch in range(c.cfg.num_channels)]
+
+    def SetImpulseResponse(self, ir):
+        """write through the mutable reference GetImpulseResponse() returns (FSAC.h:113)"""
+        self._ctx().set_impulse_response(self._src, ir)
+
+    def GenerateDummyImpulseResponse(self):  # FSAC.cpp:408-452 as it ends up: a delta at samples 0 and N-1
+        ir = np.zeros(self.NumSamples, np.float32)
+        ir[0] = 1.0
+        ir[-1] = 1.0
+        self.SetImpulseResponse(ir)
+        return ir
 
     def GetBandImpulseResponse(self, band):
         return self._ctx().band_impulse_response(self._src, band)

@@ -804,6 +804,42 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     return FS_OK;
 }
 
+int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32_t n) {
+    if (!ctx || !ir) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    poll_published(s);
+    if (s->enqueued >= 2) {   // never overwrite the front buffer: at most two publishes in flight
+        int slot = (int)((s->enqueued - 1) % kIrRing);
+        if (s->seq_of[slot] == s->enqueued - 1 && s->front.load(std::memory_order_relaxed) < s->enqueued - 1) {
+            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
+            poll_published(s);
+        }
+    }
+    hipStream_t tail = ctx->copy_stream;   // ordered with reconstructs and publishes of this source
+    if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));
+    const size_t bytes = sizeof(float) * (size_t)n;
+    FS_HIP(ctx, hipMemcpyAsync(s->d_ir_mono, ir, bytes, hipMemcpyHostToDevice, tail));
+    for (int b = 0; b < ctx->cfg.num_bands; ++b)
+        FS_HIP(ctx, hipMemcpyAsync(s->d_ir_bands + (size_t)b * (size_t)n, s->d_ir_mono, bytes, hipMemcpyDeviceToDevice, tail));
+    const int cur = s->last_rec >= 0 ? s->last_rec : s->cur;
+    FS_HIP(ctx, hipEventRecord(s->ev_rec[cur], tail));   // the reverb waits on this before reading d_ir_mono
+    s->rec_recorded[cur] = true;
+    s->last_rec = cur;
+    uint64_t seq = s->enqueued + 1;
+    int slot = (int)(seq % kIrRing);
+    FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, bytes, hipMemcpyDeviceToHost, tail));
+    FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
+    s->seq_of[slot] = seq;
+    s->enqueued = seq;
+    FS_HIP(ctx, hipStreamSynchronize(tail));   // `ir` is the caller's memory
+    poll_published(s);
+    return FS_OK;
+}
+
 int fs_synchronize(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");

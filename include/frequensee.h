@@ -184,6 +184,11 @@ int fs_synchronize(fs_context* ctx);
 int fs_get_impulse_response(fs_context* ctx, fs_source src, int32_t channel, const float** data, int32_t* n);
 int fs_copy_impulse_response(fs_context* ctx, fs_source src, int32_t channel, float* out, int32_t n);
 int fs_copy_band_impulse_response(fs_context* ctx, fs_source src, int32_t band, float* out, int32_t n);
+/* GetImpulseResponse() returns a MUTABLE reference in the reference (FSAC.h:113): consumers may install an IR of their
+ * own (the authors' convolver checks used synthetic and downloaded IRs: GenerateDummyImpulseResponse FSAC.cpp:408-452,
+ * a delta at samples 0 and N-1; LoadFloatArray :454-490).  Replaces the source's published IR (all channels and
+ * bands) with ir[num_samples]; the reverb callback and fs_get_impulse_response see it until the next reconstruct. */
+int fs_set_impulse_response(fs_context* ctx, fs_source src, const float* ir, int32_t n);
 
 /* ---- energy-buffer helpers of the component (FSAC.h:72-91), so a UE shim or a test can drive the
  *      same sequence as ARTS.cpp:157-192 ------------------------------------------------------------ */

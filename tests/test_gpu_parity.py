@@ -401,6 +401,33 @@ def test_all_connections_properties_full_size(pkg, oracle_mod, scene_factory):
     check_energy(e_r0, e32, e64, 8)
 
 
+def test_physical_sanity_direct_sound(pkg, scene_factory):
+    """Not a parity gate ("statistical tests"): nothing can arrive before the direct sound,
+    and in all-connections mode the (i = 0, j = 0) strategy deposits exactly the direct path of every pair into
+    the direct-sound bin: gain 10 * min(1, 1/(4 pi d^2) * exp(-0.05 d)) with d in the path's length unit."""
+    sc = scene_factory("shoebox", 1)
+    ctx, src = make_ctx(pkg, sc)
+    dist_cm = float(np.linalg.norm(sc.listener.astype(np.float64) - sc.source.astype(np.float64)))
+    for div in (1000.0, 100.0):                                    # reference scale (ARTS.cpp:373) and metres
+        d = dist_cm / div
+        direct_bin = int(np.floor(d / 343.0 * 1000.0))
+        e = ctx.compute_energy_response(src, pkg.default_params(num_rays=8192, depth=6, seed=3, dist_divisor=div))
+        occupied = np.flatnonzero(e[0])
+        assert occupied.size > 0 and occupied.min() >= direct_bin
+        e_all = ctx.compute_energy_response(src, pkg.default_params(num_rays=8192, depth=6, seed=3, dist_divisor=div,
+                                                                    flags=pkg._capi.FLAG_ALL_CONNECTIONS))
+        assert np.flatnonzero(e_all[0]).min() == direct_bin
+        direct = 10.0 * min(1.0, 1.0 / (4 * np.pi * d * d) * np.exp(-0.05 * d)) if d >= 1.0 else 10.0
+        # every pair contributes the direct path once with weight 1 (norm = 1 / pairs); longer paths may share the bin
+        assert e_all[0, direct_bin] >= direct * (1 - 1e-5)
+        assert e_all[0, :direct_bin].sum() == 0
+        # the histogram decays: the second half of the occupied range holds less energy than the first
+        occ = np.flatnonzero(e_all[0])
+        mid = (occ.min() + occ.max()) // 2
+        assert e_all[0, mid + 1:].sum() < e_all[0, :mid + 1].sum()
+    ctx.close()
+
+
 # ---- SURVEY.md 8e: deterministic (fixed-point) accumulation ------------------------------------------------------
 def test_deterministic_mode_is_bit_reproducible_and_shard_invariant(pkg, oracle_mod, scene_factory):
     """FS_FLAG_DETERMINISTIC: deposits are summed as u64 counts of 2^-40 quanta.  The histogram is then (i) within

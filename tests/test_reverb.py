@@ -80,3 +80,42 @@ def test_gpu_reverb_matches_reference_kissfft(pkg, oracle_mod, scene_factory):
     b = blocks(rng, 1)[0]
     assert np.array_equal(plug.ProcessSourceAudio(comp, b), b)
     sub.Deinitialize()
+
+
+@pytest.mark.gpu
+def test_gpu_reverb_with_installed_impulse_response(pkg, oracle_mod, tmp_path):
+    """The authors' convolver check (README "works with a known IR"): GenerateDummyImpulseResponse
+    (FSAC.cpp:408-452: a delta at samples 0 and N-1) and an IR loaded from a one-float-per-line text file
+    (LoadFloatArray :454-490), installed through the mutable GetImpulseResponse() reference (FSAC.h:113)."""
+    sub = pkg.AudioRayTracingSubsystem(num_bands=2)
+    comp = pkg.FrequenSeeAudioComponent((0.0, 0.0, 0.0))
+    comp.OnRegister(sub)
+    plug = pkg.FrequenSeeAudioReverbPlugin(sub)
+    plug.Initialize(BufferLength=FRAME)
+    plug.OnInitSource(comp)
+    rng = np.random.default_rng(5)
+    dummy = comp.GenerateDummyImpulseResponse()
+    assert dummy[0] == 1.0 and dummy[-1] == 1.0 and dummy.sum() == 2.0
+    got_ir = comp.GetImpulseResponse()
+    assert np.array_equal(got_ir[0], dummy) and np.array_equal(got_ir[1], dummy)
+    assert np.array_equal(comp.GetBandImpulseResponse(1), dummy)
+    ref = oracle_mod.ReverbRef()
+    for b in blocks(rng, 4):
+        want = ref.process(dummy, dummy, b)
+        got = plug.ProcessSourceAudio(comp, b)
+        assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-3)
+    # an exponentially decaying noise IR written and read back as text (six decimals, FSAC.cpp:492-505)
+    ir = (rng.normal(0, 1, 48000) * np.exp(-np.arange(48000) / 5000.0) * 0.05).astype(np.float32)
+    path = tmp_path / "loaded_ir.txt"
+    pkg._capi.save_array_to_file(ir, path)
+    loaded = pkg._capi.load_float_array(path)
+    comp.SetImpulseResponse(loaded)
+    plug.OnReleaseSource(comp)
+    ref = oracle_mod.ReverbRef()
+    for b in blocks(rng, 3):
+        want = ref.process(loaded, loaded, b)
+        got = plug.ProcessSourceAudio(comp, b)
+        assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-3)
+    with pytest.raises(pkg.FrequenSeeError):
+        comp.SetImpulseResponse(np.zeros(100, np.float32))           # wrong length
+    sub.Deinitialize()
