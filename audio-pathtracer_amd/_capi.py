@@ -129,6 +129,9 @@ class Stats(C.Structure):
         ("bvh_stack_need", C.c_uint32),
         ("bvh_depth", C.c_uint32),
         ("scene_bytes", C.c_uint64),
+        ("segments", C.c_uint64),
+        ("connections_tested", C.c_uint64),
+        ("deposits", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -389,8 +389,8 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
     if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
-    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchWords);
-    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchWords);
+    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchAllocWords);
+    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchAllocWords);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
     ctx->device_ok = true;
     return FS_OK;
@@ -1275,6 +1275,15 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
         resolve_timings(ctx);
     }
+    if (ctx->device_ok && ctx->walk.queue_head) {   // work counters kept on the device since the last reset
+        unsigned long long c[kNumCounters] = {0, 0, 0, 0};
+        FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+        FS_HIP(ctx, hipMemcpyAsync(c, ctx->walk.queue_head + kCounterWord, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stats.segments = c[0];
+        ctx->stats.connections_tested = c[1];
+        ctx->stats.deposits = c[2];
+    }
     *out = ctx->stats;
     return FS_OK;
 }
@@ -1288,6 +1297,10 @@ int fs_reset_stats(fs_context* ctx) {
     ctx->stats.bvh_stack_need = keep.bvh_stack_need;
     ctx->stats.bvh_depth = keep.bvh_depth;
     ctx->stats.scene_bytes = keep.scene_bytes;
+    if (ctx->device_ok && ctx->walk.queue_head) {
+        FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+        FS_HIP(ctx, hipMemsetAsync(ctx->walk.queue_head + kCounterWord, 0, sizeof(unsigned long long) * kNumCounters, ctx->stream));
+    }
     return FS_OK;
 }
 

@@ -119,6 +119,11 @@ struct WalkLaunch {
     uint32_t* perm;      // [depth + 1][total] subpath indices bucketed by planned length
 };
 constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
+// frame scratch allocation: kScratchWords rearmed every frame, then (8-byte aligned) kNumCounters u64 work
+// counters that accumulate until fs_reset_stats: walk segments, connections tested, deposits
+constexpr int kCounterWord = (kScratchWords + 1) & ~1;
+constexpr int kNumCounters = 4;
+constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
 // nullptr when no plan applies (the caller then clears the energy buffer itself)
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words, hipStream_t s);

@@ -489,6 +489,10 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
         if (s_hist[i]) s_base[i] = atomicAdd(&scratch[1 + i], s_hist[i]);
     __syncthreads();
     if (g < total) perm[(size_t)L * total + s_base[L] + rank] = g;
+    // work counter: walk segments of this frame (a walk of length L traces L rays)
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
+        if (i > 0 && s_hist[i])
+            atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), (unsigned long long)i * s_hist[i]);
 }
 
 // launch slot -> subpath index through the buckets, longest walks first.  s_cnt = bucket counts in LDS.
@@ -651,6 +655,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
 
     const uint32_t n = kp.num_local;
     const uint32_t total = 2u * n;
+    unsigned my_deposits = 0;
     for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < n; li += gridDim.x * kBlock) {
         const float4 F = st.end_pos[li];
         const uint2 Fm = st.end_misc[li];
@@ -673,6 +678,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
             }
         }
         if (!visible) continue;
+        ++my_deposits;
         // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
         float E[B];
 #pragma unroll
@@ -715,6 +721,13 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
                 atomicAdd(&s_hist[b * nb + bin], e);                  // ds_add_f32
         }
     }
+    {   // work counters: one atomic per wave
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
+        unsigned d = my_deposits;
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+        if ((threadIdx.x & 63u) == 0u && d) atomicAdd(&counters[2], (unsigned long long)d);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
+    }
     __syncthreads();
     const int lo = s_lo, hi = s_hi;
     if (hi < lo) return;
@@ -754,12 +767,14 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
     const uint32_t total = 2u * n;
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t wave = threadIdx.x >> 6, waves = kBlock / 64;
+    unsigned my_deposits = 0, my_tests = 0;
     for (uint32_t li = blockIdx.x * waves + wave; li < n; li += gridDim.x * waves) {
         const uint2 Fm = st.end_misc[li];
         const uint2 Lm = st.end_misc[n + li];
         const int kf = (int)Fm.y, kl = (int)Lm.y;
         const int combos = (kf + 1) * (kl + 1);
         for (int c = lane; c < combos; c += 64) {
+            ++my_tests;
             const int i = c / (kl + 1), j = c - i * (kl + 1);
             // node Fi (position, material, probability) and node Bj (position)
             float fx = kp.src[0], fy = kp.src[1], fz = kp.src[2];
@@ -785,6 +800,7 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
                 }
             }
             if (!visible) continue;
+            ++my_deposits;
             float E[B];
 #pragma unroll
             for (int b = 0; b < B; ++b) E[b] = 1.0f;
@@ -827,6 +843,15 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
                 else
                     atomicAdd(&s_hist[b * nb + bin], e);
             }
+        }
+    }
+    {   // work counters: one atomic per wave
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
+        unsigned d = my_deposits, t = my_tests;
+        for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); t += __shfl_down(t, o); }
+        if (lane == 0) {
+            if (d) atomicAdd(&counters[2], (unsigned long long)d);
+            if (t) atomicAdd(&counters[1], (unsigned long long)t);
         }
     }
     __syncthreads();

@@ -208,12 +208,16 @@ def main():
         if st is None:
             st = s1
         else:
-            for k in ("walk_kernel_ms_sum", "timed_frames"):
+            for k in ("walk_kernel_ms_sum", "timed_frames", "segments", "connections_tested", "deposits"):
                 st[k] += s1[k]
+    work = [float(st["segments"]), float(st["connections_tested"]), float(st["deposits"])]   # device-side counters
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        w = torch.tensor(work, dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(w)
+        work = [float(x) for x in w.tolist()]
 
     e_gpu = ctx.energy_buffer(src)
     ir = ctx.impulse_response(src, 0)
@@ -255,6 +259,10 @@ def main():
                        "sharding": f"{n_sources} sources round-robin over {world} ranks" if n_sources else f"pairs/{world}",
                        "frames_in_flight": len(ctxs)},
             "ir_frames_per_s": args.steps / elapsed,
+            # the same rate in the other units one might mean by "rays" (device-side counters)
+            "pairs_per_s": total_rays / 2 * args.steps / elapsed,
+            "segments_per_s": (work[0] + work[1]) / elapsed,            # closest-hit + any-hit queries
+            "contributions_per_s": work[2] / elapsed,                  # unobstructed connections deposited
             "kernel_ms": {"walk": walk_ms, "connect": conn_ms, "reconstruct+publish": rec_ms},
         }
 

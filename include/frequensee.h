@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 1
+#define FS_ABI_VERSION 2
 #define FS_MAX_BANDS 8
 #define FS_NO_MATERIAL 0xFFFFu /* actor without UAcousticGeometryComponent / Material (ARTS.cpp:383) */
 #define FS_MAX_DEPTH 64        /* hard cap on segments per subpath when depth == 0 ("unbounded") */
@@ -115,6 +115,10 @@ typedef struct fs_stats {
     uint32_t bvh_stack_need;     /* worst-case traversal stack entries of the committed tree */
     uint32_t bvh_depth;          /* depth of the binary tree before the 4-wide collapse */
     uint64_t scene_bytes;        /* device bytes of BVH + triangles + materials */
+    /* work counters kept on the device since the last fs_reset_stats */
+    uint64_t segments;           /* walk segments = closest-hit queries (counted by the length plan; 0 when it is off) */
+    uint64_t connections_tested; /* any-hit queries: one per pair, or one per (i, j) in all-connections mode */
+    uint64_t deposits;           /* unobstructed connections = paths evaluated and deposited */
 } fs_stats;
 
 /* ---- lifecycle: UAudioRayTracingSubsystem::Initialize/Deinitialize (ARTS.cpp:32-42) ------------- */

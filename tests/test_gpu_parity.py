@@ -87,6 +87,8 @@ def test_energy_parity_baseline_configs(pkg, oracle_mod, scene_factory, name, ba
     e32, e64, cnt = osc.compute_energy_mt(op, sc.source, sc.listener, 8) if rays > 100000 else \
         osc.compute_energy(op, sc.source, sc.listener)
     assert cnt.connected > 0
+    st = ctx.stats()                                  # device-side work counters == the oracle's, exactly
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
     if rays > 100000:
         assert np.array_equal(e_gpu != 0, e64 != 0)
         for b in range(bands):
@@ -399,6 +401,13 @@ def test_all_connections_properties_full_size(pkg, oracle_mod, scene_factory):
     e32, e64, cnt = osc.compute_energy(op, sc.source, sc.listener, pair_begin=0, pair_end=8192)
     assert cnt.connected > 8192                                   # more than one connection per pair on average
     check_energy(e_r0, e32, e64, 8)
+    c, s_ = make_ctx(pkg, sc, rank=0, world_size=16)
+    c.compute_energy_response(s_, p_all)
+    st = c.stats()
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+    c.reset_stats()
+    assert c.stats()["deposits"] == 0
+    c.close()
 
 
 def test_physical_sanity_direct_sound(pkg, scene_factory):
