@@ -28,6 +28,7 @@ constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
 constexpr double kFixedScale = 1099511627776.0;   // 2^40: quantum of the deterministic (fixed-point) energy sum
 #ifdef FS_TRAV_STATS
 __device__ unsigned long long g_trav_stats[8];   // [0] step calls, [1] node iterations, [2] node lanes, [3] tri iterations, [4] tri lanes
+__device__ unsigned short* g_step_buf;           // optional [depth][2P]: traversal iterations of every walk segment
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -530,7 +531,13 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
     while (walker_next_ray(w, kp, ray)) {
         Trav T;
         trav_init(T, kp.max_trace_dist, sc.num_nodes > 0);
+#ifdef FS_TRAV_STATS
+        unsigned steps = 0;
+        while (trav_busy(T)) { trav_step<false>(sc, ray, T, stack); ++steps; }
+        if (g_step_buf) g_step_buf[(size_t)w.k * (2u * (size_t)kp.num_local) + w.g] = (unsigned short)steps;
+#else
         trav_run<false>(sc, ray, T, stack);
+#endif
         walker_apply_hit(w, kp, sc, st, ray, T);
     }
     walker_finish(w, st);
@@ -1335,8 +1342,11 @@ void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, con
 
 #ifdef FS_TRAV_STATS
 extern "C" void fs_debug_trav_stats(unsigned long long* out, int reset) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof(z)); }
+}
+extern "C" void fs_debug_step_buffer(unsigned short* device_ptr) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_buf), &device_ptr, sizeof(device_ptr));
 }
 #endif
 

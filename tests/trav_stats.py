@@ -16,7 +16,8 @@ src = os.path.join(ROOT, "audio-pathtracer_amd", "csrc")
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                 "-munsafe-fp-atomics", "--offload-arch=gfx950", "-DFS_TRAV_STATS", "-shared", "-o",
                 os.path.join(out, "libfrequensee.so"), "-x", "hip", os.path.join(src, "fs_capi.cpp"),
-                os.path.join(src, "fs_bvh.cpp"), os.path.join(src, "fs_kernels.hip")], check=True)
+                os.path.join(src, "fs_bvh.cpp"), os.path.join(src, "fs_kernels.hip"), os.path.join(src, "fs_fft.hip"),
+                os.path.join(src, "fs_refit.hip")], check=True)
 import __graft_entry__ as graft  # noqa: E402
 pkg = graft.load_package()
 pkg._capi.LIB_PATH = os.path.join(out, "libfrequensee.so")
@@ -37,4 +38,40 @@ for plan in (1,):
     v = list(buf)
     res = {"wave_step_calls": v[0], "node_iterations": v[1], "node_lane_steps": v[2], "tri_iterations": v[3],
            "tri_lane_steps": v[4], "node_lanes_per_iteration": v[2] / max(v[1], 1), "tri_lanes_per_iteration": v[4] / max(v[3], 1)}
+# per-segment iteration counts: how much of a wave's time is waiting for its slowest ray, and how well the
+# cost of a subpath's next segment could be predicted from its previous one
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+import numpy as np  # noqa: E402
+D, R = 8, 262144
+dptr = C.c_void_p()
+assert hip.hipMalloc(C.byref(dptr), 2 * D * R) == 0
+hip.hipMemset(dptr, 0, 2 * D * R)
+lib.fs_debug_step_buffer.argtypes = [C.c_void_p]
+lib.fs_debug_step_buffer(dptr)
+ctx.compute_energy_response(s, p)
+steps = np.zeros((D, R), np.uint16)
+assert hip.hipMemcpy(steps.ctypes.data, dptr, steps.nbytes, 2) == 0
+lib.fs_debug_step_buffer(None)
+length = (steps > 0).sum(axis=0)
+res["segments_recorded"] = int((steps > 0).sum())
+res["mean_steps_per_segment"] = float(steps[steps > 0].mean())
+res["p50_p90_p99_max"] = [float(np.percentile(steps[steps > 0], q)) for q in (50, 90, 99, 100)]
+full = steps[:, length == D].astype(np.float64)            # the walks that take all 8 segments
+res["corr_consecutive_segments"] = float(np.mean([np.corrcoef(full[k], full[k + 1])[0, 1] for k in range(D - 1)]))
+rng = np.random.default_rng(0)
+n = full.shape[1] // 64 * 64
+def wave_steps(order):   # per bounce the wave waits for its slowest lane (walks of equal length grouped, as the plan does)
+    return float(sum(full[k, order[k]][:n].reshape(-1, 64).max(axis=1).sum() for k in range(D)))
+ident = [np.arange(full.shape[1])] * D
+res["ideal_over_actual_wave_steps"] = float(full[:, :n].sum() / 64.0 / wave_steps(ident))
+# regroup every bounce by the previous segment's cost (what an in-block re-sort between bounces could do at best)
+by_prev = [np.arange(full.shape[1])] + [np.argsort(full[k - 1], kind="stable") for k in range(1, D)]
+res["wave_steps_sorted_by_previous_cost_over_actual"] = wave_steps(by_prev) / wave_steps(ident)
+# two walks per lane, traced back to back in each bounce
+pair_cost = full[:, :n // 128 * 128].reshape(D, -1, 2).sum(axis=2)
+res["two_walks_per_lane_over_actual"] = float(sum(pair_cost[k].reshape(-1, 64).max(axis=1).sum() for k in range(D)) /
+                                              wave_steps([np.arange(full.shape[1])[:n // 128 * 128]] * D)) if n >= 128 else None
 print(json.dumps(res))
