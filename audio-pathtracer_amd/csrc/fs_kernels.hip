@@ -225,17 +225,15 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         }
     }
 #endif
-    // both records are requested before either is used, so the two fetches overlap
-    float4 a, b, c;            // triangle: v0 | e1 | e2 (+ material, id, object)
-    float4 q0, q1, q2, q3;     // node
-    if (has_tri) {
-        const float4* rec = reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)T.tri_i;
-        a = rec[0]; b = rec[1]; c = rec[2];
-    }
-    if (has_node) {
-        const float4* rec = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)T.cur;
-        q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
-    }
+    // Both records are requested before either is used, so the two fetches overlap.  The loads are NOT
+    // conditional: a lane without a pending triangle (or node) fetches record 0 instead (an L1 hit).  Inside
+    // `if (has_node)` / `if (has_tri)` blocks the compiler sinks the first arithmetic on the loaded words into
+    // the block of the loads, i.e. waits for one record before it requests the other — a full L2 latency
+    // per iteration, serialised.
+    const float4* trec = reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)(has_tri ? T.tri_i : 0);
+    const float4* nrec = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)(has_node ? T.cur : 0);
+    const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2], q3 = nrec[3];   // node
+    const float4 a = trec[0], b = trec[1], c = trec[2];                    // triangle: v0 | e1 | e2 (+ material, id, object)
     if (has_tri) {
         float t = 0.0f;
         // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
