@@ -88,6 +88,16 @@ def main():
                     help="skip the extra region that times the same frames with two in flight")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: libraries that print banners to fd 1 (RCCL does at
+    # communicator creation) are sent to stderr for the lifetime of the process
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    # A context overlaps frame f's tail (reduce, reconstruct, publish) with frame f+1's tracing on two HIP streams.
+    # The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); with RCCL's own streams
+    # in the process the two land on one queue and serialise (measured 0.64 vs 0.57 ms per frame).  Must be set
+    # before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
     import torch
     import torch.distributed as dist
 
@@ -104,7 +114,10 @@ def main():
     if os.environ.get("FS_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # rehearsal switch (never set by the driver): take the RCCL all-reduce path with a single rank
+    force_reduce = os.environ.get("FS_BENCH_FORCE_REDUCE") == "1"
+    if world > 1 or force_reduce:
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -168,7 +181,7 @@ def main():
         st_i, c, s_i = lanes[frame_no[0] % len(lanes)]
         frame_no[0] += 1
         c.compute_energy_response_async(s_i, p)
-        if world > 1:
+        if (world > 1 or force_reduce) and os.environ.get("FS_BENCH_SKIP_REDUCE") != "2":
             # RCCL sum of the [bands][bins] fp32 energy buffer on the context's tail stream: it and the
             # reconstruct behind it overlap the next frame's tracing on the compute stream
             eptr, ebytes, tail = c.energy_handoff(s_i)
@@ -178,12 +191,13 @@ def main():
                                                 device=f"cuda:{local_rank}")
             if tail not in tails:
                 tails[tail] = torch.cuda.ExternalStream(tail, device=f"cuda:{local_rank}")
-            with torch.cuda.stream(tails[tail]):
-                dist.all_reduce(tensors[eptr])
+            if os.environ.get("FS_BENCH_SKIP_REDUCE") != "1":   # rehearsal switch: everything but the collective
+                with torch.cuda.stream(tails[tail]):
+                    dist.all_reduce(tensors[eptr])
         c.reconstruct_impulse_response_async(s_i, p)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_reduce:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -359,10 +373,11 @@ def main():
                             "segments": cnt["closest_rays"], "node_visits": cnt["node_visits"],
                             "tri_tests": cnt["tri_tests"]}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        result_out.write(json.dumps(result) + "\n")
+        result_out.flush()
     for _, c in ctxs:
         c.close()
-    if world > 1:
+    if world > 1 or force_reduce:
         dist.destroy_process_group()
 
 
