@@ -68,6 +68,87 @@ def test_line_trace_matches_brute_force(pkg, oracle_mod, scene_factory, name):
     ctx.close()
 
 
+SOUPS = ["uniform", "slivers", "duplicates", "huge_coordinates", "coplanar_grid", "one_triangle", "tiny_and_big"]
+
+
+@pytest.mark.parametrize("kind", SOUPS)
+def test_line_trace_fuzz_soups(pkg, oracle_mod, kind):
+    """Random triangle soups that stress the builder and the tests at their edges: needle triangles, exact
+    duplicates (ties broken by input index), coordinates around 1e6 cm, a coplanar grid (rays in the plane, rays
+    through shared edges and vertices), a single triangle, four orders of magnitude of triangle sizes.  Closest
+    hits must equal the oracle's brute-force scan bit for bit, any-hits must agree."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))   # stable across processes (str hashes are salted)
+    if kind == "uniform":
+        c = rng.uniform(-2000, 2000, (3000, 1, 3))
+        tri = c + rng.normal(0, 60, (3000, 3, 3))
+    elif kind == "slivers":
+        c = rng.uniform(-1500, 1500, (2000, 1, 3))
+        d = rng.normal(size=(2000, 1, 3))
+        t = np.array([0.0, 1.0, 0.5]).reshape(1, 3, 1)
+        tri = c + d * t * rng.uniform(50, 900, (2000, 1, 1)) + rng.normal(0, 0.02, (2000, 3, 3))
+    elif kind == "duplicates":
+        base = rng.uniform(-800, 800, (400, 1, 3)) + rng.normal(0, 80, (400, 3, 3))
+        tri = np.concatenate([base, base, base[::2]], axis=0)
+    elif kind == "huge_coordinates":
+        c = rng.uniform(-300, 300, (1500, 1, 3)) + np.array([9.0e5, -7.5e5, 4.0e5])
+        tri = c + rng.normal(0, 40, (1500, 3, 3))
+    elif kind == "coplanar_grid":
+        n = 24
+        xs, ys = np.meshgrid(np.arange(n) * 50.0, np.arange(n) * 50.0, indexing="ij")
+        p00 = np.stack([xs, ys, np.zeros_like(xs)], -1)[:-1, :-1]
+        p10 = np.stack([xs, ys, np.zeros_like(xs)], -1)[1:, :-1]
+        p01 = np.stack([xs, ys, np.zeros_like(xs)], -1)[:-1, 1:]
+        p11 = np.stack([xs, ys, np.zeros_like(xs)], -1)[1:, 1:]
+        tri = np.concatenate([np.stack([p00, p10, p11], -2).reshape(-1, 3, 3),
+                              np.stack([p00, p11, p01], -2).reshape(-1, 3, 3)], axis=0)
+    elif kind == "one_triangle":
+        tri = np.array([[[0, 0, 0], [100, 0, 0], [0, 100, 0]]], dtype=np.float64)
+    else:
+        c = rng.uniform(-1000, 1000, (2500, 1, 3))
+        size = 10.0 ** rng.uniform(-1.5, 2.5, (2500, 1, 1))
+        tri = c + rng.normal(0, 1, (2500, 3, 3)) * size
+    tri = tri.astype(np.float32)
+    T = tri.shape[0]
+    mat = np.zeros(T, np.uint16)
+    absorption = np.full((1, 1), 0.5, np.float32)
+    ctx = pkg.Context(num_bands=1)
+    ctx.set_scene(tri, mat, absorption)
+    osc = oracle_mod.Scene(tri, mat, absorption)
+    lo, hi = tri.min(axis=(0, 1)).astype(np.float64), tri.max(axis=(0, 1)).astype(np.float64)
+    ext = np.maximum(hi - lo, 1.0)
+    n = 600
+    o = rng.uniform(lo - 0.3 * ext, hi + 0.3 * ext, (n, 3))
+    d = rng.normal(size=(n, 3))
+    # a third of the rays aim at triangle vertices / edge midpoints / centroids: the borderline cases
+    pick = rng.integers(0, T, n)
+    w = rng.dirichlet((1, 1, 1), n)
+    w[: n // 9] = np.array([1.0, 0.0, 0.0])
+    w[n // 9: 2 * n // 9] = np.array([0.5, 0.5, 0.0])
+    target = (tri[pick].astype(np.float64) * w[:, :, None]).sum(axis=1)
+    aimed = np.arange(n) < n // 3
+    d[aimed] = target[aimed] - o[aimed]
+    if kind == "coplanar_grid":
+        o[n // 3: n // 2, 2] = 0.0                                    # rays inside the plane of the grid
+        d[n // 3: n // 2, 2] = 0.0
+    o = o.astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    hit, t, idx, nrm = ctx.trace_rays(o, d, 1e7)
+    tm = np.empty(n, np.float32)
+    for i in range(n):
+        h, tt, ti, nn = osc.trace_closest(o[i], d[i], 1e7, brute=True)
+        assert bool(hit[i]) == h, (kind, i)
+        if h:
+            assert t[i] == np.float32(tt) and idx[i] == ti and np.array_equal(nrm[i], nn), (kind, i, t[i], tt, idx[i], ti)
+        tm[i] = (tt if h else 1000.0) * rng.uniform(0.5, 1.5)
+    any_hit, *_ = ctx.trace_rays(o, d, tm, any_hit=True)
+    for i in range(n):
+        assert bool(any_hit[i]) == osc.trace_any(o[i], d[i], float(tm[i]), brute=True), (kind, i)
+    st = ctx.stats()
+    assert st["bvh_stack_need"] <= 32 and st["triangles"] == T
+    ctx.close()
+
+
 # ---- a1-a5: ComputeEnergyResponse ----------------------------------------------------------------------------
 CFGS = [  # BASELINE.json configs[0..2]: name, bands, rays, depth
     ("shoebox", 1, 1024, 4),
