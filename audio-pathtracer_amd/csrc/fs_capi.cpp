@@ -94,6 +94,12 @@ struct fs_context {
     int fft_cap_n = -1, fft_cap_l = 0;
     float2 *d_fft_x = nullptr, *d_fft_y = nullptr, *d_fft_w = nullptr;
     float *d_fft_in = nullptr, *d_fft_resp = nullptr, *d_fft_out = nullptr;
+    // the 2 copies + up to 2 log2(N) - 20 launches of one block size are captured once into a hipGraph and replayed:
+    // the sequence is launch-bound (16 launches for a 48 000-sample block)
+    float* h_fft_stage = nullptr;      // pinned: in [L] | curves [3][bins] | out [3][L]
+    size_t fft_stage_floats = 0;
+    hipGraphExec_t fft_graph = nullptr;
+    int fft_graph_n = -1, fft_graph_l = -1;
     HostBVH bvh;
 
     float listener[3] = {0, 0, 0};
@@ -411,6 +417,8 @@ int fs_context_destroy(fs_context* ctx) {
         for (void* p : {(void*)ctx->d_fft_x, (void*)ctx->d_fft_y, (void*)ctx->d_fft_w, (void*)ctx->d_fft_in,
                         (void*)ctx->d_fft_resp, (void*)ctx->d_fft_out})
             if (p) (void)hipFree(p);
+        if (ctx->fft_graph) (void)hipGraphExecDestroy(ctx->fft_graph);
+        if (ctx->h_fft_stage) (void)hipHostFree(ctx->h_fft_stage);
     }
     for (Source* s : ctx->sources) free_source(ctx, s);
     // streams exist even when a later step of fs_context_create failed (device_ok == false)
@@ -1225,6 +1233,8 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
         ctx->d_fft_x = ctx->d_fft_y = ctx->d_fft_w = nullptr;
         ctx->d_fft_in = ctx->d_fft_resp = ctx->d_fft_out = nullptr;
         ctx->fft_cap_n = -1; ctx->fft_cap_l = 0; ctx->fft_n = -1;
+        if (ctx->fft_graph) { (void)hipGraphExecDestroy(ctx->fft_graph); ctx->fft_graph = nullptr; }   // captured the old buffers
+        ctx->fft_graph_n = -1;
         const int cn = std::max(n, ctx->fft_cap_n);
         const size_t CN = (size_t)1 << cn;
         FS_HIP(ctx, hipMalloc(&ctx->d_fft_x, sizeof(float2) * CN));
@@ -1246,17 +1256,71 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // w is a stack-owned staging buffer
         ctx->fft_n = n;
     }
-    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_in, in, sizeof(float) * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp, absorption, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp + bins, transmission, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
-    FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp + 2 * bins, scattering, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
-    launch_apply_material_fd(ctx->d_fft_in, L, n, ctx->d_fft_x, ctx->d_fft_y, ctx->d_fft_w, ctx->d_fft_resp, ctx->d_fft_out,
-                             ctx->stream);
+    if (L > (1 << 17)) {   // large blocks are copy-bound, not launch-bound: straight from / to the caller's memory
+        FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_in, in, sizeof(float) * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp, absorption, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp + bins, transmission, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(ctx, hipMemcpyAsync(ctx->d_fft_resp + 2 * bins, scattering, sizeof(float) * bins, hipMemcpyHostToDevice, ctx->stream));
+        launch_apply_material_fd(ctx->d_fft_in, L, n, ctx->d_fft_x, ctx->d_fft_y, ctx->d_fft_w, ctx->d_fft_resp, ctx->d_fft_out,
+                                 ctx->stream);
+        FS_HIP(ctx, hipGetLastError());
+        FS_HIP(ctx, hipMemcpyAsync(specular, ctx->d_fft_out, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(ctx, hipMemcpyAsync(diffuse, ctx->d_fft_out + L, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(ctx, hipMemcpyAsync(transmitted, ctx->d_fft_out + 2 * (size_t)L, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FS_OK;
+    }
+    // pinned staging so that the captured copies always use the same addresses
+    const size_t stage_floats = (size_t)L + 3 * (size_t)bins + 3 * (size_t)L;
+    if (stage_floats > ctx->fft_stage_floats) {
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->fft_graph) { (void)hipGraphExecDestroy(ctx->fft_graph); ctx->fft_graph = nullptr; ctx->fft_graph_n = -1; }
+        if (ctx->h_fft_stage) (void)hipHostFree(ctx->h_fft_stage);
+        ctx->h_fft_stage = nullptr; ctx->fft_stage_floats = 0;
+        FS_HIP(ctx, hipHostMalloc((void**)&ctx->h_fft_stage, sizeof(float) * stage_floats, hipHostMallocDefault));
+        ctx->fft_stage_floats = stage_floats;
+    }
+    float* h_in = ctx->h_fft_stage;
+    float* h_resp = h_in + L;
+    float* h_out = h_resp + 3 * (size_t)bins;
+    std::memcpy(h_in, in, sizeof(float) * (size_t)L);
+    std::memcpy(h_resp, absorption, sizeof(float) * (size_t)bins);
+    std::memcpy(h_resp + bins, transmission, sizeof(float) * (size_t)bins);
+    std::memcpy(h_resp + 2 * (size_t)bins, scattering, sizeof(float) * (size_t)bins);
+    auto enqueue = [&](hipStream_t st) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(ctx->d_fft_in, h_in, sizeof(float) * (size_t)L, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(ctx->d_fft_resp, h_resp, sizeof(float) * 3 * (size_t)bins, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        launch_apply_material_fd(ctx->d_fft_in, L, n, ctx->d_fft_x, ctx->d_fft_y, ctx->d_fft_w, ctx->d_fft_resp,
+                                 ctx->d_fft_out, st);
+        return hipMemcpyAsync(h_out, ctx->d_fft_out, sizeof(float) * 3 * (size_t)L, hipMemcpyDeviceToHost, st);
+    };
+    if (ctx->fft_graph_n != n || ctx->fft_graph_l != L) {   // (re)capture for this block size
+        if (ctx->fft_graph) { (void)hipGraphExecDestroy(ctx->fft_graph); ctx->fft_graph = nullptr; }
+        ctx->fft_graph_n = -1;
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            hipError_t e = enqueue(ctx->stream);
+            hipError_t e2 = hipStreamEndCapture(ctx->stream, &g);
+            if (e == hipSuccess && e2 == hipSuccess && g &&
+                hipGraphInstantiate(&ctx->fft_graph, g, nullptr, nullptr, 0) == hipSuccess) {
+                ctx->fft_graph_n = n; ctx->fft_graph_l = L;
+            } else {
+                ctx->fft_graph = nullptr;
+            }
+            if (g) (void)hipGraphDestroy(g);
+        }
+        (void)hipGetLastError();
+    }
+    if (ctx->fft_graph) FS_HIP(ctx, hipGraphLaunch(ctx->fft_graph, ctx->stream));
+    else FS_HIP(ctx, enqueue(ctx->stream));   // capture unavailable: the same sequence, launched one by one
     FS_HIP(ctx, hipGetLastError());
-    FS_HIP(ctx, hipMemcpyAsync(specular, ctx->d_fft_out, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(ctx, hipMemcpyAsync(diffuse, ctx->d_fft_out + L, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(ctx, hipMemcpyAsync(transmitted, ctx->d_fft_out + 2 * (size_t)L, sizeof(float) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(specular, h_out, sizeof(float) * (size_t)L);
+    std::memcpy(diffuse, h_out + L, sizeof(float) * (size_t)L);
+    std::memcpy(transmitted, h_out + 2 * (size_t)L, sizeof(float) * (size_t)L);
     return FS_OK;
 }
 
