@@ -119,3 +119,29 @@ def test_gpu_reverb_with_installed_impulse_response(pkg, oracle_mod, tmp_path):
     with pytest.raises(pkg.FrequenSeeError):
         comp.SetImpulseResponse(np.zeros(100, np.float32))           # wrong length
     sub.Deinitialize()
+
+
+@pytest.mark.gpu
+def test_offline_audition_tool(pkg, tmp_path):
+    """tools/convolve_ir.py: saved_ir.txt + input_audio.txt -> output_audio.txt (the reference's bGenerateReverb
+    round trip, FSAC.cpp:300-305) equals numpy's convolution, clamped to [-1, 1] like the plugin output."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("convolve_ir", os.path.join(root, "tools", "convolve_ir.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    rng = np.random.default_rng(11)
+    ir = (rng.normal(0, 1, 6000) * np.exp(-np.arange(6000) / 900.0) * 0.05).astype(np.float32)
+    audio = np.clip(rng.normal(0, 0.2, 5000), -1, 1).astype(np.float32)
+    pkg._capi.save_array_to_file(ir, tmp_path / "saved_ir.txt")
+    pkg._capi.save_array_to_file(audio, tmp_path / "input_audio.txt")
+    assert tool.main(["convolve_ir.py", str(tmp_path / "saved_ir.txt"), str(tmp_path / "input_audio.txt"),
+                      str(tmp_path / "output_audio.txt")]) == 0
+    got = pkg._capi.load_float_array(tmp_path / "output_audio.txt")
+    ir_txt = pkg._capi.load_float_array(tmp_path / "saved_ir.txt")          # six decimals, as the tool saw them
+    audio_txt = pkg._capi.load_float_array(tmp_path / "input_audio.txt")
+    want = np.clip(np.convolve(audio_txt.astype(np.float64), ir_txt.astype(np.float64)), -1, 1)
+    assert got.size == audio.size + 48000 - 1
+    assert np.abs(got[: want.size] - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-3) + 1e-6   # + text rounding
+    assert np.abs(got[want.size:]).max() <= 1e-6
