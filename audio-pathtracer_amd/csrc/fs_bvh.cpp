@@ -12,8 +12,9 @@
 //
 // Leaf boxes are padded far beyond the float error of the slab and triangle tests and quantisation only
 // grows boxes, so the closest hit found through the tree equals the brute-force closest hit: results do
-// not depend on the tree.  The builder bounds the traversal stack: the worst-case number of pending
-// entries along any root-to-leaf path must fit kStackDepth, otherwise the BVH2 is rebuilt shallower.
+// not depend on the tree.  The builder reports the traversal stack the tree needs (worst-case number of pending
+// entries along any root-to-leaf path; the kernels size their LDS stack from it) and rebuilds the BVH2 shallower
+// only if that exceeds kStackDepth.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

@@ -500,6 +500,7 @@ int fs_scene_commit(fs_context* ctx) {
     ctx->scene.num_nodes = (int32_t)ctx->bvh.nodes.size();
     ctx->scene.num_tris = ctx->T;
     ctx->scene.num_materials = ctx->M;
+    ctx->scene.stack_rows = std::max(ctx->bvh.stack_need, 2) + kStackSlack;
     ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
     ctx->stats.triangles = (uint32_t)ctx->T;
     ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;

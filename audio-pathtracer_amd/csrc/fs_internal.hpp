@@ -38,8 +38,10 @@ struct alignas(16) Tri64 {
 };
 static_assert(sizeof(Tri64) == 64, "Tri64 must be 64 B");
 
-constexpr int kStackRows = 34;    // LDS rows per lane: kStackDepth + 2 rows that absorb the unconditional pushes
-constexpr int kStackDepth = 32;   // per-lane traversal stack entries (LDS); the builder caps tree depth
+// Per-lane traversal stack in LDS: DeviceScene.stack_rows rows of kBlock ints, sized at run time from the committed
+// tree (its worst-case need + 2 rows that absorb the unconditional pushes), passed as dynamic shared memory.
+constexpr int kStackDepth = 64;   // largest worst-case stack need the builder accepts before it rebuilds shallower
+constexpr int kStackSlack = 2;
 constexpr int kBlock = 256;       // 4 waves of 64 lanes
 
 struct DeviceScene {
@@ -49,6 +51,7 @@ struct DeviceScene {
     int32_t num_nodes;        // 0 = empty scene
     int32_t num_tris;
     int32_t num_materials;
+    int32_t stack_rows;       // LDS stack rows per lane for this tree (see kStackDepth)
 };
 
 // per-update constants handed to the kernels by value

@@ -301,7 +301,7 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
 #undef FS_CSWAP
         // far children wait on the stack, farthest pushed first.  Written unconditionally: a push that does
         // not happen lands on the free slot above the top and is overwritten by the next one (or ignored),
-        // which is cheaper than three exec-mask branches; the rows [kStackDepth, kStackRows) absorb it.
+        // which is cheaper than three exec-mask branches; the two rows above the tree's worst-case need absorb it.
         const int p3 = T.sp;
         const int p2 = p3 + (hits >= 4 ? 1 : 0);
         const int p1 = p2 + (hits >= 3 ? 1 : 0);
@@ -512,7 +512,8 @@ __device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, ui
 __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
-    __shared__ int s_stack[kStackRows * kBlock];
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
+    int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {   // wave-uniform: bucket counts of the plan pass
         for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
@@ -560,7 +561,8 @@ constexpr int kQueueChunk = 64;
 __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc, KParams kp, SubpathState st,
                                                                  unsigned* __restrict__ queue_head,
                                                                  const uint32_t* __restrict__ perm) {
-    __shared__ int s_stack[kStackRows * kBlock];
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
+    int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {
         for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = queue_head[1 + i];
@@ -647,8 +649,9 @@ template <int B>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head) {
-    __shared__ int s_stack[kStackRows * kBlock];
-    extern __shared__ __attribute__((aligned(16))) float s_hist[];  // [B][num_bins]
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
+    int* s_stack = s_dyn;
+    float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
     __shared__ int s_lo, s_hi;
     const int nb = kp.num_bins;
     for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
@@ -758,8 +761,9 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
                                                              float* __restrict__ energy,
                                                              unsigned long long* __restrict__ fixed,
                                                              unsigned* queue_head) {
-    __shared__ int s_stack[kStackRows * kBlock];
-    extern __shared__ __attribute__((aligned(16))) float s_hist[];  // [B][num_bins]
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
+    int* s_stack = s_dyn;
+    float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
     __shared__ int s_lo, s_hi;
     const int nb = kp.num_bins;
     for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
@@ -950,7 +954,8 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
                                                             const float* __restrict__ d,
                                                             const float* __restrict__ tmax, int N, int any_hit,
                                                             int32_t* hit, float* t, int32_t* tri, float* normal) {
-    __shared__ int s_stack[kStackRows * kBlock];
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
+    int* s_stack = s_dyn;
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= N) return;
     Ray r = make_ray(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
@@ -1047,7 +1052,8 @@ __device__ __forceinline__ float cast_direct(const DeviceScene& sc, const SoundK
 }
 
 __global__ __launch_bounds__(kBlock) void update_sound_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc) {
-    __shared__ int s_stack[kStackRows * kBlock];
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
+    int* s_stack = s_dyn;
     int* stack = &s_stack[threadIdx.x];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int N = sp.raycasts_per_tick;
@@ -1227,13 +1233,26 @@ __global__ void add_energy_kernel(float* row, int nb, float delay, float e) {
     row[bin] += e;
 }
 
+// dynamic LDS of a traversal kernel: the scene's stack rows (+ extra bytes behind them).  Sizes above the default
+// 64 KB limit are announced to the runtime once per kernel.
+inline size_t stack_bytes(const DeviceScene& sc) { return sizeof(int) * (size_t)sc.stack_rows * (size_t)kBlock; }
+template <typename K>
+inline void allow_lds(K kernel, size_t bytes) {
+    static size_t allowed = 48 * 1024;   // per kernel instantiation
+    if (bytes > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        allowed = bytes;
+    }
+}
+
 template <int B>
 void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
                       unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
     if (kp.num_local == 0) return;
     uint32_t blocks = (kp.num_local + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;
-    size_t lds = sizeof(float) * (size_t)B * (size_t)kp.num_bins;
+    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins;
+    allow_lds(connect_kernel<B>, lds);
     hipLaunchKernelGGL(connect_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
 }
 
@@ -1255,13 +1274,15 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
     if (wl.variant == 0) {
-        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
+        allow_lds(walk_kernel_simple, stack_bytes(sc));
+        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
         return;
     }
     uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;
     if (blocks > full) blocks = full;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), 0, s, sc, kp, st, wl.queue_head, perm);
+    allow_lds(walk_kernel_persistent, stack_bytes(sc));
+    hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
 }
 
 template <int B>
@@ -1270,7 +1291,8 @@ void launch_connect_all_t(const DeviceScene& sc, const KParams& kp, const Subpat
     if (kp.num_local == 0) return;
     uint32_t blocks = (kp.num_local + 3) / 4;   // one wave per pair, 4 waves per workgroup
     if (blocks > 4096) blocks = 4096;
-    size_t lds = sizeof(float) * (size_t)B * (size_t)kp.num_bins;
+    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins;
+    allow_lds(connect_all_kernel<B>, lds);
     hipLaunchKernelGGL(connect_all_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
 }
 
@@ -1320,13 +1342,15 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
                        int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s) {
     if (N <= 0) return;
-    hipLaunchKernelGGL(trace_rays_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sc, o, d, tmax, N,
+    allow_lds(trace_rays_kernel, stack_bytes(sc));
+    hipLaunchKernelGGL(trace_rays_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(sc), s, sc, o, d, tmax, N,
                        any_hit, hit, t, tri, normal);
 }
 
 void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, hipStream_t s) {
     int lanes = sp.raycasts_per_tick + 1;
-    hipLaunchKernelGGL(update_sound_kernel, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sc, sp, acc);
+    allow_lds(update_sound_kernel, stack_bytes(sc));
+    hipLaunchKernelGGL(update_sound_kernel, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(sc), s, sc, sp, acc);
 }
 
 void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
