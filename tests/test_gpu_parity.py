@@ -560,6 +560,52 @@ def test_physical_sanity_direct_sound(pkg, scene_factory):
     ctx.close()
 
 
+def test_audio_thread_reads_while_frames_are_produced(pkg, scene_factory):
+    """The unguarded race of the reference (game thread rewrites ImpulseBuffer while the audio thread reads it,
+    FSAC.cpp:330-378 vs RVB.cpp:136) is what the published-IR ring removes.  A reader thread hammers the lock-free
+    fs_get_impulse_response pointer while the producer publishes 300 frames alternating two parameter sets; in
+    deterministic mode each set has one bit-exact IR, so every read must equal one of the two (or the initial
+    zeros) — a torn or half-written buffer would match neither."""
+    import threading
+    sc = scene_factory("starter_room", 4)
+    ctx, src = make_ctx(pkg, sc)
+    det = pkg._capi.FLAG_DETERMINISTIC
+    params = [pkg.default_params(num_rays=8192, depth=8, seed=s_, dist_divisor=100.0, flags=det) for s_ in (5, 6)]
+    irs = []
+    for p in params:
+        ctx.compute_energy_response(src, p)
+        ctx.reconstruct_impulse_response(src, p)
+        irs.append(ctx.impulse_response(src, 0).copy())
+    assert not np.array_equal(irs[0], irs[1]) and irs[0].any()
+    stop = threading.Event()
+    seen = {"reads": 0, "bad": 0, "a": 0, "b": 0}
+
+    def reader():
+        while not stop.is_set():
+            v = ctx.impulse_response_view(src, 0).copy()           # ctypes call + memcpy, both without the GIL held long
+            seen["reads"] += 1
+            if np.array_equal(v, irs[0]):
+                seen["a"] += 1
+            elif np.array_equal(v, irs[1]):
+                seen["b"] += 1
+            else:
+                seen["bad"] += 1
+
+    th = threading.Thread(target=reader)
+    th.start()
+    try:
+        for f in range(300):
+            ctx.compute_energy_response_async(src, params[f & 1])
+            ctx.reconstruct_impulse_response_async(src, params[f & 1])
+        ctx.synchronize()
+    finally:
+        stop.set()
+        th.join()
+    assert seen["bad"] == 0 and seen["reads"] > 20 and seen["a"] > 0 and seen["b"] > 0, seen
+    assert np.array_equal(ctx.impulse_response(src, 0), irs[1])     # frame 299 used the second set
+    ctx.close()
+
+
 # ---- SURVEY.md 8e: deterministic (fixed-point) accumulation ------------------------------------------------------
 def test_deterministic_mode_is_bit_reproducible_and_shard_invariant(pkg, oracle_mod, scene_factory):
     """FS_FLAG_DETERMINISTIC: deposits are summed as u64 counts of 2^-40 quanta.  The histogram is then (i) within
