@@ -11,8 +11,10 @@
  *
  * Conventions: extern "C", POD only, every call returns an int status (FS_OK == 0), no exception
  * crosses the boundary, output buffers are caller-allocated, handles are opaque.  Positions are
- * Unreal units (cm).  One context drives one HIP device; all GPU work of a context is ordered on
- * one HIP stream (its own, or the caller's via fs_config.stream).  A context is not re-entrant:
+ * Unreal units (cm).  One context drives one HIP device.  Its tracing is ordered on one HIP stream (the
+ * "compute" stream: its own, or the caller's via fs_config.stream); the tail of a frame — a caller's
+ * multi-GPU reduce, the reconstruct and the publish of the impulse response — runs on a second stream of
+ * the context, concurrently with the next frame's tracing (fs_energy_handoff).  A context is not re-entrant:
  * one producer thread calls compute/reconstruct; any number of threads may read published
  * impulse responses (fs_get_impulse_response) concurrently with the producer.
  *
@@ -50,7 +52,7 @@ enum {
 #define FS_FLAG_FIXED_NORM_1000 1u          /* ARTS.cpp:164 normaliser 1/USED_RAY_COUNT whatever NumRays is */
 #define FS_FLAG_FLUSH_BEFORE_RECONSTRUCT 2u /* ARTS.cpp:191 second FlushEnergyBuffer (IR becomes all zero) */
 #define FS_FLAG_COSINE_SAMPLING 4u          /* cosine-weighted bounce instead of VRandCone(n, 90 deg) */
-#define FS_FLAG_ALL_CONNECTIONS 16u          /* row f3, the reference's unfinished draft (Is_NaiveConnections, ARTS.cpp:518-546): connect every
+#define FS_FLAG_ALL_CONNECTIONS 16u         /* row f3, the reference's unfinished draft (Is_NaiveConnections, ARTS.cpp:518-546): connect every
                                              * forward prefix F0..Fi with every backward prefix B0..Bj of a pair (visibility test and
                                              * EvaluatePath as for the end-to-end connection) and combine the (i, j) that give the same
                                              * path length with uniform weights 1/N(i+j); ~(k+1)(m+1) contributions per pair instead of 1 */
