@@ -16,10 +16,12 @@
 // entries along any root-to-leaf path; the kernels size their LDS stack from it) and rebuilds the BVH2 shallower
 // only if that exceeds kStackDepth.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 #include "fs_internal.hpp"
 
@@ -53,13 +55,31 @@ struct BuildNode {
     int depth = 0;
 };
 
+// One record per triangle, permuted in place by the splits, so every pass over a node streams through
+// contiguous memory (gathering boxes through an index array made the build cache-bound and kept worker
+// threads from scaling).  Worker threads own disjoint ranges.
+struct Prim {
+    Box box;
+    float cen[3];
+    int idx;      // input triangle
+};
+
+struct BuildInput {
+    std::vector<Prim> prims;
+};
+
 struct Builder {
-    std::vector<Box> pbox;       // per input triangle
-    std::vector<float> cen;      // centroids [T][3]
-    std::vector<int> order;      // permutation of triangle indices
+    BuildInput& in;
+    std::vector<Prim>& prims;
     std::vector<BuildNode> nodes;
     int max_depth = 0;
     int depth_cap = 48;
+    // parallel build: nodes with at most `defer_below` triangles (below the root) are left unsplit and listed in
+    // `deferred`; worker threads build their subtrees with private builders, spliced in afterwards
+    int defer_below = 0;
+    std::vector<int> deferred;
+
+    explicit Builder(BuildInput& i) : in(i), prims(i.prims) {}
 
     static constexpr int kBins = 32;
     int kLeaf = 2;   // measured: a triangle test costs about as much as 2.5 child boxes, small leaves win
@@ -72,14 +92,19 @@ struct Builder {
         n.box.reset();
         Box cb; cb.reset();
         for (int i = first; i < first + count; ++i) {
-            int t = order[i];
-            n.box.grow(pbox[t]);
+            const Prim& p = prims[(size_t)i];
+            n.box.grow(p.box);
             for (int k = 0; k < 3; ++k) {
-                cb.lo[k] = std::min(cb.lo[k], cen[3 * t + k]);
-                cb.hi[k] = std::max(cb.hi[k], cen[3 * t + k]);
+                cb.lo[k] = std::min(cb.lo[k], p.cen[k]);
+                cb.hi[k] = std::max(cb.hi[k], p.cen[k]);
             }
         }
         max_depth = std::max(max_depth, depth);
+        if (count > kLeaf && defer_below > 0 && depth > 0 && count <= defer_below) {
+            deferred.push_back(id);
+            nodes[id] = n;
+            return id;
+        }
         if (count > kLeaf) {
             int mid = -1;
             // levels a balanced split still needs below this node
@@ -106,9 +131,9 @@ struct Builder {
             for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
             float scale = kBins / ext;
             for (int i = first; i < first + count; ++i) {
-                int t = order[i];
-                int b = std::min(kBins - 1, std::max(0, (int)((cen[3 * t + ax] - cb.lo[ax]) * scale)));
-                bb[b].grow(pbox[t]); bc[b]++;
+                const Prim& p = prims[(size_t)i];
+                int b = std::min(kBins - 1, std::max(0, (int)((p.cen[ax] - cb.lo[ax]) * scale)));
+                bb[b].grow(p.box); bc[b]++;
             }
             float ra[kBins]; int rc[kBins];
             Box acc; acc.reset(); int c = 0;
@@ -127,11 +152,12 @@ struct Builder {
         if (best_axis < 0) return -1;
         float ext = cb.hi[best_axis] - cb.lo[best_axis];
         float scale = kBins / ext;
-        auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](int t) {
-            int b = std::min(kBins - 1, std::max(0, (int)((cen[3 * t + best_axis] - cb.lo[best_axis]) * scale)));
+        const float lo = cb.lo[best_axis];
+        auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& p) {
+            int b = std::min(kBins - 1, std::max(0, (int)((p.cen[best_axis] - lo) * scale)));
             return b <= best_bin;
         });
-        int mid = (int)(it - order.begin());
+        int mid = (int)(it - prims.begin());
         if (mid == first || mid == first + count) return -1;
         return mid;
     }
@@ -142,10 +168,9 @@ struct Builder {
         for (int k = 0; k < 3; ++k)
             if (cb.hi[k] - cb.lo[k] > e) { e = cb.hi[k] - cb.lo[k]; ax = k; }
         int mid = first + count / 2;
-        std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
-                         [&](int a, int b) {
-                             float ca = cen[3 * a + ax], cb2 = cen[3 * b + ax];
-                             return ca < cb2 || (ca == cb2 && a < b);
+        std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                         [&](const Prim& a, const Prim& b) {
+                             return a.cen[ax] < b.cen[ax] || (a.cen[ax] == b.cen[ax] && a.idx < b.idx);
                          });
         return mid;
     }
@@ -226,11 +251,12 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
     out.pad = 0.01f;
     if (T <= 0) return;
 
-    Builder b;
+    BuildInput input;
+    Builder b(input);
     if (const char* v = std::getenv("FS_BVH_LEAF")) b.kLeaf = std::max(1, std::min(4, std::atoi(v)));
-    b.pbox.resize(T);
-    b.cen.resize(3 * (size_t)T);
-    b.order.resize(T);
+    int threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* v = std::getenv("FS_BVH_THREADS")) threads = std::max(1, std::min(64, std::atoi(v)));
+    std::vector<Prim> prims0((size_t)T);   // input order, copied into the working array before every (re)build
     float amax = 0.f;
     for (int t = 0; t < T; ++t) {
         const float* p = xyz + 9 * (size_t)t;
@@ -241,8 +267,10 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
                 bx.hi[k] = std::max(bx.hi[k], p[3 * v + k]);
                 amax = std::max(amax, std::fabs(p[3 * v + k]));
             }
-        b.pbox[t] = bx;
-        for (int k = 0; k < 3; ++k) b.cen[3 * t + k] = 0.5f * (bx.lo[k] + bx.hi[k]);
+        Prim& q = prims0[(size_t)t];
+        q.box = bx;
+        for (int k = 0; k < 3; ++k) q.cen[k] = 0.5f * (bx.lo[k] + bx.hi[k]);
+        q.idx = t;
     }
     // conservative padding (cm): >> float error of the tests at this coordinate magnitude
     const float pad = std::max(0.01f, amax * 3.8146973e-06f);
@@ -256,8 +284,47 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
         b.nodes.clear();
         b.nodes.reserve(2 * (size_t)T / 3 + 16);
         b.max_depth = 0;
-        for (int t = 0; t < T; ++t) b.order[t] = t;
+        input.prims = prims0;
+        b.deferred.clear();
+        b.defer_below = (threads > 1 && T >= 20000) ? std::max(1024, T / (4 * threads)) : 0;
         root = b.make(0, T, 0);
+        if (!b.deferred.empty()) {
+            // Worker threads split the deferred nodes.  A subtree depends only on its own triangle range, so the
+            // tree is the one a serial build produces; only the order of the build-node array differs, and the
+            // flattened output (breadth-first from the root) does not depend on that.
+            const std::vector<int> tasks = b.deferred;
+            std::vector<std::vector<BuildNode>> sub(tasks.size());
+            std::vector<int> sub_depth(tasks.size(), 0);
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
+                    const BuildNode& ph = b.nodes[(size_t)tasks[k]];
+                    Builder lb(input);
+                    lb.kLeaf = b.kLeaf;
+                    lb.depth_cap = b.depth_cap;
+                    lb.nodes.reserve(2 * (size_t)ph.count / 3 + 16);
+                    lb.make(ph.first, ph.count, ph.depth);
+                    sub[k] = std::move(lb.nodes);
+                    sub_depth[k] = lb.max_depth;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int w = 1; w < threads; ++w) pool.emplace_back(work);
+            work();
+            for (std::thread& th : pool) th.join();
+            for (size_t k = 0; k < tasks.size(); ++k) {   // splice: local node 0 replaces the placeholder
+                const int ph = tasks[k];
+                const int base = (int)b.nodes.size() - 1;   // local j >= 1 -> base + j
+                auto remap = [&](int c) { return c < 0 ? c : (c == 0 ? ph : base + c); };
+                for (size_t j = 0; j < sub[k].size(); ++j) {
+                    BuildNode n = sub[k][j];
+                    n.left = remap(n.left);
+                    n.right = remap(n.right);
+                    if (j == 0) b.nodes[(size_t)ph] = n; else b.nodes.push_back(n);
+                }
+                b.max_depth = std::max(b.max_depth, sub_depth[k]);
+            }
+        }
         collapse(b.nodes, root, wide, wide_of, level);
         out.stack_need = stack_need(b.nodes, wide, wide_of);
         if (out.stack_need <= kStackDepth) break;
@@ -266,7 +333,7 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
     out.pad = pad;
     // refit support: where each input triangle sits in leaf order, and the node range of every tree level
     out.leaf_pos.resize(T);
-    for (int i = 0; i < T; ++i) out.leaf_pos[(size_t)b.order[i]] = (uint32_t)i;
+    for (int i = 0; i < T; ++i) out.leaf_pos[(size_t)input.prims[(size_t)i].idx] = (uint32_t)i;
     out.level_begin.clear();
     for (size_t i = 0; i < level.size(); ++i)
         if (i == 0 || level[i] != level[i - 1]) out.level_begin.push_back((int32_t)i);
@@ -275,7 +342,7 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
     // triangles in leaf order
     out.tris.resize(T);
     for (int i = 0; i < T; ++i) {
-        int t = b.order[i];
+        int t = input.prims[(size_t)i].idx;
         const float* p = xyz + 9 * (size_t)t;
         Tri64 r;
         const float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];

@@ -142,6 +142,25 @@ int main() {
     std::vector<float> chain;  // adversarial for depth: exponentially spaced sizes
     for (int t = 0; t < 2000; ++t) { float s = std::pow(1.01f, (float)t); const float p[9] = {s, 0, 0, s, s * 0.01f, 0, s, 0, s * 0.01f}; chain.insert(chain.end(), p, p + 9); }
     run("2000 geometric", chain);
+    {   // worker threads build the same tree as the serial builder, byte for byte (60 000 triangles: above the
+        // threshold at which subtrees are handed to threads)
+        const std::vector<float> big = soup(60000, 20000, 40);
+        HostBVH a, b;
+        setenv("FS_BVH_THREADS", "1", 1);
+        build_bvh(big.data(), nullptr, nullptr, 60000, a);
+        setenv("FS_BVH_THREADS", "6", 1);
+        build_bvh(big.data(), nullptr, nullptr, 60000, b);
+        unsetenv("FS_BVH_THREADS");
+        CHECK(a.nodes.size() == b.nodes.size() && a.tris.size() == b.tris.size(), "threaded build: sizes differ");
+        CHECK(a.nodes.size() == b.nodes.size() &&
+                  std::memcmp(a.nodes.data(), b.nodes.data(), a.nodes.size() * sizeof(NodeQ4)) == 0,
+              "threaded build: nodes differ");
+        CHECK(a.tris.size() == b.tris.size() && std::memcmp(a.tris.data(), b.tris.data(), a.tris.size() * sizeof(Tri64)) == 0,
+              "threaded build: triangle order differs");
+        CHECK(a.leaf_pos == b.leaf_pos && a.level_begin == b.level_begin && a.stack_need == b.stack_need,
+              "threaded build: metadata differs");
+        run("60k threaded", big);
+    }
     if (fails) { std::printf("%d failures\n", fails); return 1; }
     std::printf("all BVH invariants hold\n");
     return 0;

@@ -21,7 +21,7 @@ def test_oracle_under_asan_ubsan(tmp_path):
 
 def test_bvh_builder_invariants_under_asan_ubsan(tmp_path):
     exe = tmp_path / "bvh_check"
-    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                     *SAN, "-Wno-unused-result", "-o", str(exe), os.path.join(ROOT, "tests/native/bvh_check.cpp"),
                     os.path.join(ROOT, "audio-pathtracer_amd/csrc/fs_bvh.cpp")], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV, timeout=600)
