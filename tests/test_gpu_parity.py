@@ -319,6 +319,17 @@ def test_empty_scene_and_zero_rays(pkg, scene_factory):
         ctx.compute_energy_response(src, pkg.default_params(num_rays=7, depth=4))     # odd
     with pytest.raises(pkg.FrequenSeeError):
         ctx.compute_energy_response(src, pkg.default_params(num_rays=8, depth=65))    # > FS_MAX_DEPTH
+    with pytest.raises(pkg.FrequenSeeError):
+        ctx.compute_energy_response(src, pkg.default_params(num_rays=(1 << 30) + 2, depth=4))   # 32-bit subpath indices
+    with pytest.raises(pkg.FrequenSeeError):
+        ctx.compute_energy_response(src, pkg.default_params(num_rays=8, depth=4, dist_divisor=0.0))
+    bad = pkg.default_params(num_rays=8, depth=4)
+    bad.struct_size = 12
+    with pytest.raises(pkg.FrequenSeeError):
+        ctx.compute_energy_response(src, bad)
+    with pytest.raises(pkg.FrequenSeeError):                                          # non-finite vertex
+        ctx.set_scene(np.full((1, 3, 3), np.nan, np.float32), np.zeros(1, np.uint16), np.zeros((1, 2), np.float32))
+    assert "non-finite" in ctx.lib.fs_last_error(ctx.h).decode()
     ctx.close()
 
 
