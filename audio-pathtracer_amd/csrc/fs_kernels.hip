@@ -1,18 +1,27 @@
 // fs_kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64) of the FrequenSee BDPT path.
 //
+//   plan_kernel        the length of a subpath under Russian roulette depends only on the RNG stream: bucket the
+//                      subpaths by length before tracing, so that every walk wave holds equal-length walks;
+//                      also FlushEnergyBuffer (:157-161).
 //   walk_kernel_*      GeneratePath (AudioRayTracingSubsystem.cpp:279-355) for every source and listener
 //                      subpath.  Only geometry happens here (RNG, direction, closest hit, hit point); each
 //                      walk step leaves a 12-byte segment record (scaled length, node probability, node
 //                      material) so that EvaluatePath needs no stored path.
-//                        _persistent: waves pull subpaths from a queue and keep their lanes busy (default)
-//                        _simple:     one subpath per lane (reference variant for A/B runs)
+//                        _simple:     one subpath per lane, length-sorted schedule (default)
+//                        _persistent: waves pull subpaths from a queue and refill their lanes (opt-in,
+//                                     FS_WALK_VARIANT=1; measured no faster at the BASELINE frame sizes)
 //   connect_kernel     ConnectSubpaths (:235-277) any-hit visibility ray per pair; for connected pairs
 //                      EvaluatePath (:360-420) over the segment records in exact path order, clamp/gain
 //                      (:410-413), normalisation (:164-170) and AddEnergyAtDelay
 //                      (FrequenSeeAudioComponent.h:87-91) into an LDS-privatised [bands][bins] histogram
-//                      flushed with global float atomics.
+//                      flushed with global float atomics (or a u64 fixed-point histogram, deterministic mode).
+//   connect_all_kernel the same for every forward prefix x backward prefix of a pair (draft :518-546, row f3).
 //   reconstruct_kernel ReconstructImpulseResponse (FrequenSeeAudioComponent.cpp:320-380).
+//   update_sound_kernel legacy forward tracer UpdateSound/CastAudioRay/CastDirectAudioRay (:132-306 of
+//                      FrequenSeeAudioComponent.cpp), reverb_*_kernel the reverb plugin's per-callback convolution
+//                      (FrequenSeeAudioReverbPlugin.cpp:118-213).
 //   trace_rays_kernel  the engine line trace itself (closest / any hit), for tests and tools.
+//   (fs_fft.hip: ApplyMaterialFD; fs_refit.hip: moving geometry.)
 //
 // The triangle test, the hit point/normal/offset arithmetic and the sampling maps use a fixed
 // operation order with explicit fmaf and are compiled with -ffp-contract=off: the path geometry is a
