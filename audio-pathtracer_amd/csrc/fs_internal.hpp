@@ -19,7 +19,7 @@ namespace fs {
 //   q1 = (lox4 loy4 loz4 hix4)  q2 = (hiy4 hiz4 - -)   byte c of each word = child c's plane on that
 //                                             grid: box = origin + q * step, rounded outwards
 //   q3 = child[4] as int bits; child >= 0: inner node index; child < 0: leaf,
-//        ~child = first_tri * 4 + (count - 1), count in 1..4; empty slot: lo = 255 > hi = 0 (never hit).
+//        ~child = first_tri * 4 + (count - 1), count in 1..4 (the builder makes 1..2); empty slot: lo = 255 > hi = 0 (never hit).
 struct alignas(16) NodeQ4 {
     float ox, oy, oz;
     uint32_t exps;
@@ -29,7 +29,7 @@ struct alignas(16) NodeQ4 {
 };
 static_assert(sizeof(NodeQ4) == 64, "NodeQ4 must be 64 B");
 
-// Triangle record, 64 B (same size as a node, so traversal fetches either through one load sequence),
+// Triangle record, 64 B (the intersection test reads the first 48 B, the hit shading the last 16 B),
 // stored in leaf order:
 //   a = (v0.x v0.y v0.z e1.x)  b = (e1.y e1.z e2.x e2.y)  c = (e2.z, material, input index, object id)
 //   d = (unit geometric normal of cross(e1, e2), -)
@@ -109,7 +109,7 @@ struct HostBVH {
     std::vector<int32_t> level_begin;
     float pad = 0.01f;
 };
-// xyz [T][3][3], mat [T]; binned SAH BVH2 collapsed to a quantised 4-wide tree, <= 4 triangles per leaf.
+// xyz [T][3][3], mat [T]; binned SAH BVH2 collapsed to a quantised 4-wide tree, <= 2 triangles per leaf.
 void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out);
 
 // ---- kernel launchers (fs_kernels.hip) -----------------------------------------------------------------
