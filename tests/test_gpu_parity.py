@@ -235,6 +235,18 @@ VARIANTS = [
     ("min_seg_zero", "shoebox", 1, 1024, 4, {"min_seg": 0.0, "dist_divisor": 100.0},
      {"min_seg": 0.0, "dist_divisor": 100.0}),
     ("one_pair", "shoebox", 1, 2, 8, {}, {}),
+    # parameter extremes
+    ("roulette_half", "starter_room", 4, 8192, 8, {"rr_prob": 0.5}, {"rr_prob": 0.5}),
+    ("roulette_099_depth_32", "starter_room", 2, 2048, 32, {"rr_prob": 0.99}, {"rr_prob": 0.99}),
+    ("no_offset_no_pullback", "starter_room", 4, 4096, 6, {"surface_offset": 0.0, "connect_pullback": 0.0},
+     {"surface_offset": 0.0, "connect_pullback": 0.0}),
+    ("short_traces", "starter_room", 4, 4096, 8, {"max_trace_dist": 300.0, "dist_divisor": 100.0},
+     {"max_trace_dist": 300.0, "dist_divisor": 100.0}),
+    ("clamp_and_gain", "shoebox", 1, 2048, 6, {"energy_clamp": 0.001, "energy_gain": 3.0, "prob_exponent": 1.0, "dist_divisor": 100.0},
+     {"energy_clamp": 0.001, "energy_gain": 3.0, "prob_exponent": 1.0, "dist_divisor": 100.0}),
+    ("slow_sound_late_bins", "old_mine", 8, 4096, 8, {"sound_speed": 30.0, "dist_divisor": 100.0},
+     {"sound_speed": 30.0, "dist_divisor": 100.0}),
+    ("reference_defaults_2000_rays", "starter_room", 1, 2000, 0, {"flags": 1}, {"flags": 1}),
     # row f3: every forward prefix x every backward prefix, uniform MIS weights (flag 16 on both sides)
     ("all_connections_cfg1", "shoebox", 1, 1024, 4, {"flags": 16}, {"flags": 16}),
     ("all_connections_cfg2", "starter_room", 4, 8192, 8, {"flags": 16}, {"flags": 16}),
@@ -330,6 +342,43 @@ def test_empty_scene_and_zero_rays(pkg, scene_factory):
     with pytest.raises(pkg.FrequenSeeError):                                          # non-finite vertex
         ctx.set_scene(np.full((1, 3, 3), np.nan, np.float32), np.zeros(1, np.uint16), np.zeros((1, 2), np.float32))
     assert "non-finite" in ctx.lib.fs_last_error(ctx.h).decode()
+    ctx.close()
+
+
+PLACEMENTS = [
+    # id, source, listener (cm) in the starter room (2000 x 1600 x 400)
+    ("same_point", (900.0, 700.0, 150.0), (900.0, 700.0, 150.0)),
+    ("one_millimetre_apart", (900.0, 700.0, 150.0), (900.1, 700.0, 150.0)),
+    ("source_outside_the_room", (-800.0, 700.0, 150.0), (900.0, 700.0, 150.0)),
+    ("both_outside", (-800.0, 700.0, 150.0), (3000.0, -500.0, 900.0)),
+    ("source_on_the_floor", (500.0, 500.0, 0.0), (1500.0, 1100.0, 160.0)),
+    ("far_away_coordinates", (2.0e5, 3.0e5, 150.0), (900.0, 700.0, 150.0)),
+]
+
+
+@pytest.mark.parametrize("pid,spos,lpos", PLACEMENTS, ids=[p[0] for p in PLACEMENTS])
+def test_energy_parity_unusual_placements(pkg, oracle_mod, scene_factory, pid, spos, lpos):
+    """Source and listener where a level designer would not put them: coincident, outside the geometry, on a
+    surface, hundreds of metres away.  The reference has no guards for any of these (ARTS.cpp:287-355 just
+    walks); whatever the oracle does with them, the HIP path does the same."""
+    sc = scene_factory("starter_room", 4)
+    ctx = pkg.Context(num_bands=4)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx.set_listener(lpos)
+    src = ctx.create_source(spos)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    for flags in (0, 16):
+        p = pkg.default_params(num_rays=4096, depth=6, seed=17, dist_divisor=100.0, flags=flags)
+        e_gpu = ctx.compute_energy_response(src, p)
+        e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=2048, depth=6, seed=17, dist_divisor=100.0, flags=flags),
+                                           np.array(spos, np.float32), np.array(lpos, np.float32))
+        assert np.all(np.isfinite(e_gpu))
+        st = ctx.stats()
+        if cnt.connected == 0:
+            assert not e_gpu.any(), (pid, flags)
+        else:
+            check_energy(e_gpu, e32, e64, 4)
+        ctx.reset_stats()
     ctx.close()
 
 
