@@ -875,6 +875,26 @@ def test_update_sound_parity(pkg, oracle_mod, scene_factory, name):
     ctx.close()
 
 
+def test_update_sound_matches_golden(pkg, scene_factory):
+    """the same against the committed fixture (no oracle at run time)"""
+    import json
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "legacy_update_sound.json")))
+    for c in cases:
+        sc = scene_factory(c["scene"])
+        ctx = pkg.Context(num_bands=sc.num_bands)
+        ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, object_ids=sc.object_ids)
+        ctx.set_listener(sc.listener)
+        src = ctx.create_source(sc.source)
+        got = ctx.update_sound(src, pkg._capi.default_sound_params(**c["params"]))
+        want = c["result"]
+        for k in ("rays_reaching_listener", "direct_hits", "traces"):
+            assert got[k] == want[k], (c["scene"], k)
+        assert got["total_energy"] == want["total_energy"]
+        assert got["occlusion_attenuation"] == pytest.approx(want["occlusion_attenuation"], rel=2e-6, abs=0)
+        assert got["direct_energy_sum"] == pytest.approx(want["direct_energy_sum"], rel=2e-5, abs=0)
+        ctx.close()
+
+
 def test_component_update_sound(pkg, scene_factory):
     sc = scene_factory("starter_room", 4)
     sub = pkg.AudioRayTracingSubsystem(num_bands=4)
