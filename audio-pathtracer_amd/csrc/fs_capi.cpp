@@ -223,27 +223,45 @@ hipEvent_t take_event(fs_context* ctx) {
     return e;
 }
 
-// fold finished timed frames into the stats (call only after the stream has been synchronised)
-void resolve_timings(fs_context* ctx) {
-    for (TimedFrame& f : ctx->pending) {
-        float ms = 0.f, ms2 = 0.f;
-        if (f.has_trace && hipEventElapsedTime(&ms, f.e[0], f.e[1]) == hipSuccess) {
-            ctx->stats.walk_kernel_ms_sum += ms;
-            ctx->stats.walk_kernel_ms_last = ms;
-            ctx->stats.timed_frames++;
-            if (f.e[2] && hipEventElapsedTime(&ms2, f.e[1], f.e[2]) == hipSuccess) {
-                ctx->stats.connect_kernel_ms_sum += ms2;
-                ctx->stats.timed_connects++;
-            }
+// fold one finished timed frame into the stats and recycle its events
+void fold_timed_frame(fs_context* ctx, TimedFrame& f) {
+    float ms = 0.f, ms2 = 0.f;
+    if (f.has_trace && hipEventElapsedTime(&ms, f.e[0], f.e[1]) == hipSuccess) {
+        ctx->stats.walk_kernel_ms_sum += ms;
+        ctx->stats.walk_kernel_ms_last = ms;
+        ctx->stats.timed_frames++;
+        if (f.e[2] && hipEventElapsedTime(&ms2, f.e[1], f.e[2]) == hipSuccess) {
+            ctx->stats.connect_kernel_ms_sum += ms2;
+            ctx->stats.timed_connects++;
         }
-        if (f.has_recon && hipEventElapsedTime(&ms, f.e[3], f.e[4]) == hipSuccess) {
-            ctx->stats.reconstruct_ms_sum += ms;
-            ctx->stats.timed_reconstructs++;
-        }
-        for (int i = 0; i < 5; ++i)
-            if (f.e[i]) ctx->free_events.push_back(f.e[i]);
     }
+    if (f.has_recon && hipEventElapsedTime(&ms, f.e[3], f.e[4]) == hipSuccess) {
+        ctx->stats.reconstruct_ms_sum += ms;
+        ctx->stats.timed_reconstructs++;
+    }
+    for (int i = 0; i < 5; ++i)
+        if (f.e[i]) ctx->free_events.push_back(f.e[i]);
+}
+
+// fold finished timed frames into the stats (call only after the streams have been synchronised)
+void resolve_timings(fs_context* ctx) {
+    for (TimedFrame& f : ctx->pending) fold_timed_frame(ctx, f);
     ctx->pending.clear();
+}
+
+// A caller that leaves profiling on and never asks for the stats must not accumulate events without bound:
+// once enough frames are pending, the ones whose last event has completed are folded in as they go.
+void resolve_completed_timings(fs_context* ctx) {
+    if (ctx->pending.size() < 64) return;
+    size_t done = 0;
+    for (TimedFrame& f : ctx->pending) {
+        hipEvent_t last = f.has_recon ? f.e[4] : (f.e[2] ? f.e[2] : f.e[1]);
+        if (!last || hipEventQuery(last) != hipSuccess) break;
+        fold_timed_frame(ctx, f);
+        ++done;
+    }
+    (void)hipGetLastError();   // hipErrorNotReady from the query is not an error
+    if (done) ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + (long)done);
 }
 
 // advance `front` over publishes whose D2H copy has completed (producer thread only)
@@ -670,6 +688,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
 
     TimedFrame tf{};
     if (ctx->profiling) {
+        resolve_completed_timings(ctx);
         for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
         tf.e[0] = take_event(ctx);
         tf.e[1] = take_event(ctx);
