@@ -59,6 +59,10 @@ public:
     float GetOcclusionAttenuation() const;                               // .h:112
     fs_sound_result UpdateSound(uint64_t Seed = 0x5EED);                 // .cpp:283-306
     void SaveImpulseResponse(const std::string& Path, int Channel = 0) const;   // SaveArrayToFile .cpp:492-505
+    // GetImpulseResponse() is a mutable reference in the reference (.h:113): install an IR of the caller's own
+    void SetImpulseResponse(const std::vector<float>& IR);
+    // GenerateDummyImpulseResponse (.cpp:408-452) as it ends up: a delta at samples 0 and N-1
+    std::vector<float> GenerateDummyImpulseResponse();
 
     bool bApplyReverb = true;   // .h:60
 
@@ -222,6 +226,15 @@ inline fs_sound_result FrequenSeeAudioComponent::UpdateSound(uint64_t Seed) {
     fs_sound_result r{};
     SubSys_->Check(fs_update_sound(SubSys_->Ctx_, Handle_, &p, &r));
     return r;
+}
+inline void FrequenSeeAudioComponent::SetImpulseResponse(const std::vector<float>& IR) {
+    SubSys_->Check(fs_set_impulse_response(SubSys_->Ctx_, Handle_, IR.data(), (int32_t)IR.size()));
+}
+inline std::vector<float> FrequenSeeAudioComponent::GenerateDummyImpulseResponse() {
+    std::vector<float> IR((size_t)fs_num_samples(SubSys_->Ctx_), 0.0f);
+    if (!IR.empty()) { IR.front() = 1.0f; IR.back() = 1.0f; }
+    SetImpulseResponse(IR);
+    return IR;
 }
 inline void FrequenSeeAudioComponent::SaveImpulseResponse(const std::string& Path, int Channel) const {
     SubSys_->Check(fs_save_impulse_response(SubSys_->Ctx_, Handle_, Channel, Path.c_str()));
