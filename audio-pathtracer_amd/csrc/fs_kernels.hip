@@ -463,6 +463,7 @@ __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathStat
 //   scratch[0] = subpath queue head (persistent walk), [1, 1 + kPlanBuckets) = bucket counts.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kPlanBuckets = FS_MAX_DEPTH + 1;
+constexpr int kPlanItems = 4;   // subpaths per plan-kernel thread
 
 __device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
     const uint32_t n = kp.num_local;
@@ -485,22 +486,34 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) energy[i] = 0.0f;
     __syncthreads();
     const uint32_t total = 2u * kp.num_local;
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    int L = 0;
-    unsigned rank = 0;
-    if (g < total) {
-        L = planned_length(g, kp);
-        rank = atomicAdd(&s_hist[L], 1u);
+    // kPlanItems subpaths per thread: the bucket counters are a handful of hot addresses, and every workgroup
+    // pays one global atomic per occupied length — fewer, larger workgroup batches mean fewer of them
+    int L[kPlanItems];
+    unsigned rank[kPlanItems];
+#pragma unroll
+    for (int it = 0; it < kPlanItems; ++it) {
+        const uint32_t g = (blockIdx.x * kPlanItems + it) * kBlock + threadIdx.x;
+        L[it] = 0; rank[it] = 0;
+        if (g < total) {
+            L[it] = planned_length(g, kp);
+            rank[it] = atomicAdd(&s_hist[L[it]], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
         if (s_hist[i]) s_base[i] = atomicAdd(&scratch[1 + i], s_hist[i]);
     __syncthreads();
-    if (g < total) perm[(size_t)L * total + s_base[L] + rank] = g;
-    // work counter: walk segments of this frame (a walk of length L traces L rays)
-    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
-        if (i > 0 && s_hist[i])
-            atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), (unsigned long long)i * s_hist[i]);
+#pragma unroll
+    for (int it = 0; it < kPlanItems; ++it) {
+        const uint32_t g = (blockIdx.x * kPlanItems + it) * kBlock + threadIdx.x;
+        if (g < total) perm[(size_t)L[it] * total + s_base[L[it]] + rank[it]] = g;
+    }
+    // work counter: walk segments of this frame (a walk of length L traces L rays), one atomic per workgroup
+    if (threadIdx.x == 0) {
+        unsigned long long seg = 0;
+        for (int i = 1; i < kPlanBuckets; ++i) seg += (unsigned long long)i * s_hist[i];
+        if (seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), seg);
+    }
 }
 
 // launch slot -> subpath index through the buckets, longest walks first.  s_cnt = bucket counts in LDS.
@@ -1272,7 +1285,7 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
     uint32_t lanes = 2u * kp.num_local;
     // length-sorted schedule: only meaningful when roulette can end walks early
     if (lanes == 0 || !wl.plan || !kp.russian_roulette || kp.depth <= 1 || !wl.perm) return nullptr;
-    uint32_t full = (lanes + kBlock - 1) / kBlock;
+    uint32_t full = (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
     hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, wl.perm, energy, energy_words);
     return wl.perm;
 }
