@@ -84,6 +84,9 @@ def main():
                     help="FS_FLAG_ALL_CONNECTIONS (row f3): every forward prefix x every backward prefix per pair")
     ap.add_argument("--deterministic", action="store_true",
                     help="FS_FLAG_DETERMINISTIC: u64 fixed-point deposits, integer all-reduce (bit-identical for any N)")
+    ap.add_argument("--fixed-seed", action="store_true",
+                    help="every frame traces the same sample set (default: a new RNG seed every frame, as an application "
+                         "does; the frame checked against the oracle uses --seed itself)")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra region that times the same frames with two in flight")
     args = ap.parse_args()
@@ -174,12 +177,17 @@ def main():
 
     def frame():
         if n_sources:   # one step = one update of every source (this rank's share), all in flight together
+            frame_no[0] += 1
+            if not args.fixed_seed:
+                p.seed = args.seed + frame_no[0]
             for _, c, s_i in lanes:
                 c.compute_energy_response_async(s_i, p)
                 c.reconstruct_impulse_response_async(s_i, p)
             return
         st_i, c, s_i = lanes[frame_no[0] % len(lanes)]
         frame_no[0] += 1
+        if not args.fixed_seed:
+            p.seed = args.seed + frame_no[0]
         c.compute_energy_response_async(s_i, p)
         if (world > 1 or force_reduce) and os.environ.get("FS_BENCH_SKIP_REDUCE") != "2":
             # RCCL sum of the [bands][bins] fp32 energy buffer on the context's tail stream: it and the
@@ -233,15 +241,23 @@ def main():
         dist.all_reduce(w)
         work = [float(x) for x in w.tolist()]
 
+    # untimed: the frame the oracle leg checks (seed = --seed), then a few sequential frames with events around
+    # EVERY kernel for the per-kernel breakdown
+    p.seed = args.seed
+    ctx.compute_energy_response_async(src, p)
+    ctx.reconstruct_impulse_response_async(src, p)
+    ctx.synchronize()
     e_gpu = ctx.energy_buffer(src)
     ir = ctx.impulse_response(src, 0)
-    # untimed: a few sequential frames with events around EVERY kernel, for the per-kernel breakdown
     ctx.reset_stats()
     ctx.set_profiling(2)
-    for _ in range(10):
+    for i in range(10):
+        if not args.fixed_seed:
+            p.seed = args.seed + 1000003 + i
         ctx.compute_energy_response_async(src, p)
         ctx.reconstruct_impulse_response_async(src, p)
     ctx.synchronize()
+    p.seed = args.seed
     st_all = ctx.stats()
     ctx.set_profiling(0)
 
@@ -264,7 +280,7 @@ def main():
             "scaling": "strong" if n_sources else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + ("" if not args.fixed_seed else " (same sample set every frame)"),
             "config": {"workload": f"{args.workload}: {scene_name} {sc.num_triangles} tris, {rays_per_gpu} rays/frame/GPU "
                                    f"(source+listener subpaths), depth {depth}, {bands} bands, "
                                    f"{'fixed depth' if args.fixed_depth else 'Russian roulette 0.9'}",
@@ -298,10 +314,13 @@ def main():
         t1 = time.perf_counter()
         for i in range(k2):
             c, s_i = both[i % 2]
+            if not args.fixed_seed:
+                p.seed = args.seed + 2000003 + i
             c.compute_energy_response_async(s_i, p)
             c.reconstruct_impulse_response_async(s_i, p)
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t1
+        p.seed = args.seed
         c2.close()
         result["pipelined"] = {"frames_in_flight": 2, "steps": k2, "value": total_rays * k2 / el2, "unit": "rays/s",
                                "ms_per_step": 1e3 * el2 / k2, "ir_frames_per_s": k2 / el2}
