@@ -74,4 +74,31 @@ res["wave_steps_sorted_by_previous_cost_over_actual"] = wave_steps(by_prev) / wa
 pair_cost = full[:, :n // 128 * 128].reshape(D, -1, 2).sum(axis=2)
 res["two_walks_per_lane_over_actual"] = float(sum(pair_cost[k].reshape(-1, 64).max(axis=1).sum() for k in range(D)) /
                                               wave_steps([np.arange(full.shape[1])[:n // 128 * 128]] * D)) if n >= 128 else None
+# bounce 0: all rays of a side leave one point — would grouping them by direction shorten the waves' waits?
+import oracle  # noqa: E402  (diagnostic script under tests/: may use the oracle)
+olib = oracle.load()
+P = R // 2
+dirs = np.zeros((R, 3), np.float32)
+ctr = (C.c_uint32 * 4)(); key = (C.c_uint32 * 2)(p.seed & 0xFFFFFFFF, p.seed >> 32); out4 = (C.c_uint32 * 4)(); d3 = (C.c_float * 3)()
+sub = np.arange(0, R, 8)                                   # every 8th subpath is plenty for the estimate
+for g in sub:
+    side = 1 if g >= P else 0
+    pair = g - side * P
+    ctr[0], ctr[1], ctr[2], ctr[3] = pair, side, 0, 0x46533031
+    olib.fso_philox4x32_10(ctr, key, out4)
+    olib.fso_sample_sphere(p.seed, pair, side, 0, out4, d3)
+    dirs[g] = (d3[0], d3[1], d3[2])
+s0 = steps[0, sub].astype(np.float64)
+alive = s0 > 0
+octant = ((dirs[sub, 0] > 0).astype(int) | ((dirs[sub, 1] > 0).astype(int) << 1) | ((dirs[sub, 2] > 0).astype(int) << 2)) + 8 * (sub >= P)
+def waves(order):
+    v = s0[alive][order]
+    m = v.size // 64 * 64
+    return float(v[:m].reshape(-1, 64).max(axis=1).sum())
+base = waves(np.arange(alive.sum()))
+az = np.arctan2(dirs[sub, 1], dirs[sub, 0])[alive]
+res["bounce0_wave_steps_sorted_by_octant_over_unsorted"] = waves(np.argsort(octant[alive], kind="stable")) / base
+res["bounce0_wave_steps_sorted_by_side_azimuth_over_unsorted"] = waves(np.lexsort((az, (sub >= P)[alive]))) / base
+res["bounce0_wave_steps_sorted_by_cost_over_unsorted"] = waves(np.argsort(s0[alive])) / base
+res["bounce0_share_of_all_segments"] = float((steps[0] > 0).sum() / (steps > 0).sum())
 print(json.dumps(res))
