@@ -931,3 +931,14 @@ def test_cpp_harness_matches_oracle(pkg, oracle_mod, scene_factory, tmp_path):
     osc.set_objects(np.zeros(12, np.uint32))
     assert j["occlusion_attenuation"] == pytest.approx(osc.update_sound(sc.source, sc.listener)["occlusion_attenuation"], rel=1e-5)
     assert j["material_fd_max_err"] <= 1e-5 * max(j["ir_peak"], 1e-3)   # MaterialAcousticProcessor through the C++ mirror
+
+
+def test_api_state_machine_stress():
+    """tools/stress.py: a random sequence of frames in all modes, moving geometry, energy helpers, installed IRs,
+    reverb callbacks and stats on one context, with checkpoints against a second, synchronous context."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fs_stress", os.path.join(root, "tools", "stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(400, 7) == 0
