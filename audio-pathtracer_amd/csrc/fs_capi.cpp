@@ -326,6 +326,13 @@ int check_params(fs_context* ctx, const fs_params* p) {
 
 }  // namespace
 
+// A context overlaps the tail of a frame with the next frame's tracing on two HIP streams.  The runtime multiplexes
+// streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); with other libraries' streams in the process (RCCL)
+// the two can land on one queue and serialise (measured 0.64 vs 0.57 ms per frame).  Ask for 16 queues unless the
+// process environment already says otherwise; it only takes effect if the HIP runtime has not initialised yet
+// (INTEGRATION.md), which is why bench.py also sets it itself.
+__attribute__((constructor)) static void fs_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+
 extern "C" {
 
 int fs_abi_version(void) { return FS_ABI_VERSION; }
