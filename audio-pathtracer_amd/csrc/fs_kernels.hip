@@ -308,6 +308,9 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
                          ref##a = ra_; ref##b = rb_; }
         FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
 #undef FS_CSWAP
+#ifdef FS_TRAV_STATS
+        atomicAdd(&g_trav_stats[5 + (hits > 2 ? 2 : hits)], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
+#endif
         // far children wait on the stack, farthest pushed first.  Written unconditionally: a push that does
         // not happen lands on the free slot above the top and is overwritten by the next one (or ignored),
         // which is cheaper than three exec-mask branches; the two rows above the tree's worst-case need absorb it.
