@@ -317,9 +317,11 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         const int p3 = T.sp;
         const int p2 = p3 + (hits >= 4 ? 1 : 0);
         const int p1 = p2 + (hits >= 3 ? 1 : 0);
-        stack[p3 * kBlock] = ref3;
-        stack[p2 * kBlock] = ref2;
-        stack[p1 * kBlock] = ref1;
+        if (hits >= 2) {   // 3 of 4 visits hit at most one child and push nothing
+            stack[p3 * kBlock] = ref3;
+            stack[p2 * kBlock] = ref2;
+            stack[p1 * kBlock] = ref1;
+        }
         T.sp = p1 + (hits >= 2 ? 1 : 0);
         if (hits >= 1) {
             T.cur = ref0;
