@@ -112,7 +112,7 @@ struct fs_context {
     size_t cap_pos = 0;
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
-    WalkLaunch walk{0, 256, 2, nullptr, 1, nullptr};
+    WalkLaunch walk{2, 256, 2, nullptr, 1, nullptr};   // variant 2 = wave work sharing (default), 0 = one subpath per lane, 1 = persistent
     int refill_threshold = 16;
 
     // measurement
@@ -417,7 +417,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0)
         ctx->walk.num_cus = cus;
-    if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
     if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;

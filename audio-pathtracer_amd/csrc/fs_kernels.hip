@@ -198,7 +198,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct Trav {
     int cur;        // next node: >= 0 inner index, < 0 leaf code (~cur = first*4 + count-1), kDone = none
-    int sp;         // stack entries
+    int sp;         // stack top (entries live in [sb, sp))
+    int sb;         // stack bottom: 0 unless entries were given away from the bottom (wave work sharing)
     int tri_i, tri_n;  // pending triangles [tri_i, tri_n) of the current leaf
     float t;        // closest hit so far (init: tmax)
     int leaf_index; // hit triangle (leaf order), -1 = none
@@ -207,7 +208,7 @@ struct Trav {
 
 __device__ __forceinline__ void trav_init(Trav& T, float tmax, bool scene_nonempty) {
     T.cur = scene_nonempty ? 0 : kDone;
-    T.sp = 0; T.tri_i = 0; T.tri_n = 0;
+    T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
     T.t = tmax; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
 }
 __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tri_n || T.cur != kDone; }
@@ -220,7 +221,7 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         const int code = ~T.cur;
         T.tri_i = code >> 2;
         T.tri_n = T.tri_i + (code & 3) + 1;
-        if (T.sp > 0) { --T.sp; T.cur = stack[T.sp * kBlock]; } else { T.cur = kDone; }
+        if (T.sp > T.sb) { --T.sp; T.cur = stack[T.sp * kBlock]; } else { T.cur = kDone; }
     }
     const bool has_tri = T.tri_i < T.tri_n;
     const bool has_node = T.cur >= 0;
@@ -252,7 +253,7 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         if (ANY) {
             if (hit) {
                 T.t = t; T.leaf_index = T.tri_i; T.id = id;
-                T.tri_n = T.tri_i; T.cur = kDone; T.sp = 0;  // first hit ends the query
+                T.tri_n = T.tri_i; T.cur = kDone; T.sp = T.sb;  // first hit ends the query
                 return;
             }
         } else {
@@ -325,7 +326,7 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         T.sp = p1 + (hits >= 2 ? 1 : 0);
         if (hits >= 1) {
             T.cur = ref0;
-        } else if (T.sp > 0) {
+        } else if (T.sp > T.sb) {
             --T.sp;
             T.cur = stack[T.sp * kBlock];
         } else {
@@ -564,6 +565,122 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
 #else
         trav_run<false>(sc, ray, T, stack);
 #endif
+        walker_apply_hit(w, kp, sc, st, ray, T);
+    }
+    walker_finish(w, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Wave work sharing for closest-hit queries.
+//
+// The rays of a wave need very different numbers of traversal steps (median 19, p99 40) and the wave waits for
+// its slowest ray in every bounce.  A closest-hit query parallelises: disjoint subtrees can be searched by
+// different lanes and the answers merged by min (t, triangle id) — exactly the order a single traversal applies.
+// So a lane that has finished its own ray takes the OLDEST pending subtree (bottom of the stack: the one its
+// owner would reach last) from a lane that still has pending entries, traverses it with that lane's ray and the
+// closest hit the owner knew at that moment as bound, and reports into the owner's mailbox.  All of it happens
+// inside one wave (lock-step), through LDS, without atomics on the stacks.
+//   LDS behind the stack rows: ray store [12][kBlock] | result key [kBlock] u64 | result leaf [kBlock] |
+//   donation boxes: ref, owner, bound [kBlock] each.
+// ---------------------------------------------------------------------------------------------------
+constexpr size_t kShareLdsBytes = (size_t)kBlock * (12 * 4 + 8 + 4 + 3 * 4);
+
+__device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray& own, Trav& T, int* stack, int* s_dyn,
+                                                float tmax) {
+    float* rs = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
+    unsigned long long* rkey = reinterpret_cast<unsigned long long*>(rs + 12 * kBlock);
+    int* rleaf = reinterpret_cast<int*>(rkey + kBlock);
+    int* dref = rleaf + kBlock;
+    int* down = dref + kBlock;
+    float* dbound = reinterpret_cast<float*>(down + kBlock);
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // publish this lane's ray and clear its mailbox
+    rs[0 * kBlock + tid] = own.ox;  rs[1 * kBlock + tid] = own.oy;  rs[2 * kBlock + tid] = own.oz;
+    rs[3 * kBlock + tid] = own.dx;  rs[4 * kBlock + tid] = own.dy;  rs[5 * kBlock + tid] = own.dz;
+    rs[6 * kBlock + tid] = own.ix;  rs[7 * kBlock + tid] = own.iy;  rs[8 * kBlock + tid] = own.iz;
+    rs[9 * kBlock + tid] = own.nox; rs[10 * kBlock + tid] = own.noy; rs[11 * kBlock + tid] = own.noz;
+    rkey[tid] = ~0ull;
+    rleaf[tid] = -1;
+    unsigned owner = tid;   // block-local lane whose ray this lane is working on
+    Ray wr = own;
+    trav_init(T, tmax, sc.num_nodes > 0);
+    while (true) {
+        if (trav_busy(T)) {
+            trav_step<false>(sc, wr, T, stack);
+            if (!trav_busy(T) && T.leaf_index >= 0) {   // this (sub)traversal is over: report to the owner of the ray
+                const unsigned long long key = ((unsigned long long)__float_as_uint(T.t) << 32) | (unsigned long long)T.id;
+                atomicMin(&rkey[owner], key);
+                if (rkey[owner] == key) rleaf[owner] = T.leaf_index;
+            }
+        }
+        const bool idle = !trav_busy(T);
+        const unsigned long long busy_m = __ballot(!idle);
+        if (busy_m == 0ull) break;                      // nothing left anywhere in the wave
+        const unsigned long long idle_m = __ballot(idle);
+        const bool can_give = !idle && T.sp > T.sb;
+        const unsigned long long give_m = __ballot(can_give);
+        if (idle_m != 0ull && give_m != 0ull) {
+            const int n = min(__popcll(idle_m), __popcll(give_m));
+            if (can_give) {
+                const int r = __popcll(give_m & lt);
+                if (r < n) {
+                    dref[wbase + r] = stack[T.sb * kBlock];
+                    down[wbase + r] = (int)owner;
+                    dbound[wbase + r] = T.t;
+                    ++T.sb;
+                    if (T.sb == T.sp) { T.sb = 0; T.sp = 0; }
+                }
+            }
+            if (idle) {
+                const int r = __popcll(idle_m & lt);
+                if (r < n) {
+                    const int e = dref[wbase + r];
+                    owner = (unsigned)down[wbase + r];
+                    const float bound = dbound[wbase + r];
+                    wr.ox = rs[0 * kBlock + owner];  wr.oy = rs[1 * kBlock + owner];  wr.oz = rs[2 * kBlock + owner];
+                    wr.dx = rs[3 * kBlock + owner];  wr.dy = rs[4 * kBlock + owner];  wr.dz = rs[5 * kBlock + owner];
+                    wr.ix = rs[6 * kBlock + owner];  wr.iy = rs[7 * kBlock + owner];  wr.iz = rs[8 * kBlock + owner];
+                    wr.nox = rs[9 * kBlock + owner]; wr.noy = rs[10 * kBlock + owner]; wr.noz = rs[11 * kBlock + owner];
+                    T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
+                    T.t = bound; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
+                }
+            }
+        }
+    }
+    // everything searched: the mailbox holds the closest hit of this lane's own ray
+    const unsigned long long key = rkey[tid];
+    if (key != ~0ull) {
+        T.t = __uint_as_float((uint32_t)(key >> 32));
+        T.id = (uint32_t)key;
+        T.leaf_index = rleaf[tid];
+    } else {
+        T.t = tmax;
+        T.leaf_index = -1;
+        T.id = 0xFFFFFFFFu;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
+                                                             const uint32_t* __restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
+    int* s_stack = s_dyn;
+    __shared__ unsigned s_cnt[kPlanBuckets];
+    if (perm) {
+        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
+        __syncthreads();
+    }
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= 2u * kp.num_local) return;
+    const uint32_t g = perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot;
+    int* stack = &s_stack[threadIdx.x];
+    Walker w;
+    walker_start(w, g, kp);
+    Ray ray;
+    while (walker_next_ray(w, kp, ray)) {
+        Trav T;
+        trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist);
         walker_apply_hit(w, kp, sc, st, ray, T);
     }
     walker_finish(w, st);
@@ -1300,6 +1417,12 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
+    if (wl.variant == 2) {
+        allow_lds(walk_kernel_shared, stack_bytes(sc) + kShareLdsBytes);
+        hipLaunchKernelGGL(walk_kernel_shared, dim3(full), dim3(kBlock), stack_bytes(sc) + kShareLdsBytes, s, sc, kp, st,
+                           wl.queue_head, perm);
+        return;
+    }
     if (wl.variant == 0) {
         allow_lds(walk_kernel_simple, stack_bytes(sc));
         hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
