@@ -637,7 +637,9 @@ __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray
                 if (r < n) {
                     const int e = dref[wbase + r];
                     owner = (unsigned)down[wbase + r];
-                    const float bound = dbound[wbase + r];
+                    // the owner's mailbox may already hold a closer hit than the donor knew of
+                    const float bound = __uint_as_float(min(__float_as_uint(dbound[wbase + r]),
+                                                            (uint32_t)(rkey[owner] >> 32)));
                     wr.ox = rs[0 * kBlock + owner];  wr.oy = rs[1 * kBlock + owner];  wr.oz = rs[2 * kBlock + owner];
                     wr.dx = rs[3 * kBlock + owner];  wr.dy = rs[4 * kBlock + owner];  wr.dz = rs[5 * kBlock + owner];
                     wr.ix = rs[6 * kBlock + owner];  wr.iy = rs[7 * kBlock + owner];  wr.iz = rs[8 * kBlock + owner];

@@ -39,6 +39,9 @@ for plan in (1,):
     res = {"wave_step_calls": v[0], "node_iterations": v[1], "node_lane_steps": v[2], "tri_iterations": v[3],
            "tri_lane_steps": v[4], "node_lanes_per_iteration": v[2] / max(v[1], 1), "tri_lanes_per_iteration": v[4] / max(v[3], 1),
            "node_visits_by_children_hit_0_1_2plus": [v[5], v[6], v[7]]}
+if os.environ.get("FS_WALK_VARIANT", "2") != "0":   # the per-segment counts below are recorded by the one-subpath-per-lane
+    print(json.dumps(res))                           # kernel only: FS_WALK_VARIANT=0 python tests/trav_stats.py
+    sys.exit(0)
 # per-segment iteration counts: how much of a wave's time is waiting for its slowest ray, and how well the
 # cost of a subpath's next segment could be predicted from its previous one
 hip = C.CDLL("libamdhip64.so")
