@@ -277,14 +277,15 @@ void poll_published(Source* s) {
     s->front.store(f, std::memory_order_release);
 }
 
-int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positions) {
+int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positions, bool want_normals) {
     size_t lanes = 2 * (size_t)n_local;
     size_t seg = (size_t)depth * lanes;
-    if (want_positions && seg > ctx->cap_pos) {
+    const size_t want = want_positions ? seg * (want_normals ? 2 : 1) : 0;   // positions, then normals
+    if (want > ctx->cap_pos) {
         if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
         ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->d_seg_pos, sizeof(float4) * std::max<size_t>(seg, 1)));
-        ctx->cap_pos = seg;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_seg_pos, sizeof(float4) * std::max<size_t>(want, 1)));
+        ctx->cap_pos = want;
     }
     if (lanes > ctx->cap_lanes) {
         if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
@@ -687,11 +688,14 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     kp.num_bins = ctx->num_bins;
     kp.refill_threshold = ctx->refill_threshold;
 
-    const bool all_conn = (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
-    rc = ensure_state(ctx, kp.num_local, kp.depth, all_conn);
+    const bool mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
+    const bool all_conn = mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
+    kp.mis = mis ? 1 : 0;
+    rc = ensure_state(ctx, kp.num_local, kp.depth, all_conn, mis);
     if (rc) return rc;
     SubpathState st = ctx->st;
     st.seg_pos = all_conn ? ctx->d_seg_pos : nullptr;
+    st.seg_nrm = mis ? ctx->d_seg_pos + (size_t)kp.depth * 2 * (size_t)kp.num_local : nullptr;
 
     TimedFrame tf{};
     if (ctx->profiling) {

@@ -62,6 +62,7 @@ struct KParams {
     int32_t depth;         // max segments per subpath (1..FS_MAX_DEPTH)
     int32_t russian_roulette;
     int32_t cosine;
+    int32_t mis;           // all-connections mode: 1 = balance-heuristic weights, 0 = uniform
     float rr_prob, max_trace_dist, surface_offset, connect_pullback;
     float dist_divisor, min_seg, prob_exponent, energy_clamp, energy_gain, sound_speed;
     float norm;            // 1/P or 1/1000 (ARTS.cpp:164)
@@ -95,6 +96,7 @@ struct SubpathState {
     uint32_t* seg_mat;  // [depth][total] material of that node
     float4* seg_pos;    // [depth][total] xyz = position of the node a walk step arrives at; only written (and only
                         //   non-null) in all-connections mode, which connects interior nodes too (row f3)
+    float4* seg_nrm;    // [depth][total] xyz = normal of that node; only with balance-heuristic weights
 };
 
 // ---- host BVH builder ------------------------------------------------------------------------------

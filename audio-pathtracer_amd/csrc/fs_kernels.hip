@@ -447,6 +447,7 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
     st.seg_np[slot] = w.side == 0 ? make_float2(nd, w.prob) : make_float2(nd, w.prob_new);
     st.seg_mat[slot] = w.side == 0 ? w.mat : mat_new;
     if (st.seg_pos) st.seg_pos[slot] = make_float4(qx, qy, qz, 0.0f);   // all-connections mode (wave-uniform)
+    if (st.seg_nrm) st.seg_nrm[slot] = make_float4(w.nx, w.ny, w.nz, 0.0f);   // balance-heuristic weights only
     w.px = qx; w.py = qy; w.pz = qz;
     w.mat = mat_new;
     w.prob = w.prob_new;
@@ -902,6 +903,63 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
 // (i', j') in [0, D]^2, i' + j' = t (D = depth cap).  One WAVE per pair, one lane per (i, j): the up to
 // (D+1)^2 visibility rays of a pair start and end at neighbouring nodes, so the wave traverses coherently.
 // ---------------------------------------------------------------------------------------------------
+// Balance-heuristic weight of strategy i (vertices y_1..y_i generated from the source, y_t..y_{i+1} from the
+// listener, t = i + j) among the strategies [max(0, t-D), min(t, D)] that give the same path — the intent of the
+// draft's MISEnergy (ARTS.cpp:571-597); build-owned definition, DESIGN.md section 8: forward density of y_{k+1}
+// given y_k  pf_k = Pf(k) |n_{k+1}.d_k| / L_k^2 with Pf(0) = 1/4pi, Pf(k) = max(0, n_k.d_k)/pi; backward density of
+// y_k given y_{k+1}  pb_k = Pb(k+1) |n_k.d_k| / L_k^2 with Pb(t+1) = 1/4pi, Pb(k) = max(0, -n_k.d_{k-1})/pi;
+// p_s = prod_{k<s} pf_k prod_{k>s} pb_k, w_i = p_i / sum_s p_s.  One pass over the t + 1 segments in double:
+// T_k = T_{k-1} pb_k + [lo <= k <= hi] PF_k ends as sum_s p_s, Q likewise as p_i; uniform weight when a segment
+// is degenerate or the ratio is not finite and positive.
+// Vertex k of the connected path: 0 = source, 1..i = forward nodes, i+1..t = backward nodes j..1, t+1 = listener.
+struct MisVertex { double x, y, z, nx, ny, nz; };
+__device__ __forceinline__ MisVertex mis_vertex(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t n,
+                                                uint32_t li, int i, int t, int k) {
+    MisVertex v;
+    if (k == 0) { v.x = kp.src[0]; v.y = kp.src[1]; v.z = kp.src[2]; v.nx = v.ny = v.nz = 0.0; return v; }
+    if (k == t + 1) { v.x = kp.lis[0]; v.y = kp.lis[1]; v.z = kp.lis[2]; v.nx = v.ny = v.nz = 0.0; return v; }
+    const size_t slot = k <= i ? (size_t)(k - 1) * total + li : (size_t)(t - k) * total + n + li;
+    const float4 q = st.seg_pos[slot], m = st.seg_nrm[slot];
+    v.x = q.x; v.y = q.y; v.z = q.z; v.nx = m.x; v.ny = m.y; v.nz = m.z;
+    return v;
+}
+__device__ float mis_weight(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t n, uint32_t li, int i,
+                            int j) {
+    const int t = i + j, D = kp.depth;
+    const int lo = t - D > 0 ? t - D : 0, hi = t < D ? t : D;
+    const double uniform = 1.0 / (double)(hi - lo + 1);
+    if (t <= 0) return (float)uniform;
+    const double inv4pi = 1.0 / (4.0 * 3.14159265358979323846), invpi = 1.0 / 3.14159265358979323846;
+    double PF = 1.0, T = 0.0, Q = 0.0;
+    MisVertex a = mis_vertex(kp, st, total, n, li, i, t, 0);
+    for (int k = 0; k <= t; ++k) {
+        const MisVertex b = mis_vertex(kp, st, total, n, li, i, t, k + 1);
+        double dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+        const double l2 = dx * dx + dy * dy + dz * dz;
+        if (!(l2 > 1e-8)) return (float)uniform;
+        const double inv = 1.0 / sqrt(l2);
+        dx *= inv; dy *= inv; dz *= inv;
+        const double ca = k > 0 ? a.nx * dx + a.ny * dy + a.nz * dz : 0.0;
+        const double cb = k < t ? b.nx * dx + b.ny * dy + b.nz * dz : 0.0;
+        if (k >= 1) {
+            const double Pb = k == t ? inv4pi : (cb < 0.0 ? -cb : 0.0) * invpi;
+            const double pb = Pb * fabs(ca) / l2;
+            T *= pb;
+            if (k > i) Q *= pb;
+        }
+        if (k >= lo && k <= hi) T += PF;
+        if (k == i) Q = PF;
+        if (k < t) {
+            const double Pf = k == 0 ? inv4pi : (ca > 0.0 ? ca : 0.0) * invpi;
+            PF *= Pf * fabs(cb) / l2;
+        }
+        a = b;
+    }
+    const double w = Q / T;
+    if (!(Q > 0.0) || !(T > 0.0) || !(w <= 1.0)) return (float)uniform;
+    return (float)w;
+}
+
 template <int B>
 __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                              float* __restrict__ energy,
@@ -977,7 +1035,8 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             }
             const int t = i + j, D = kp.depth;
             const int lo_t = t - D > 0 ? t - D : 0, hi_t = t < D ? t : D;
-            const float w = 1.0f / (float)(hi_t - lo_t + 1);
+            float w = 1.0f / (float)(hi_t - lo_t + 1);
+            if (kp.mis) w = mis_weight(kp, st, total, n, li, i, j);
             float delay = sd / kp.sound_speed;
             float x = (delay * 1000.f) / 1.0f;
             float fl = floorf(x);

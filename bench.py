@@ -82,6 +82,8 @@ def main():
                     help="independent frames in flight (one context + HIP stream each); 1 = strictly sequential frames")
     ap.add_argument("--all-connections", action="store_true",
                     help="FS_FLAG_ALL_CONNECTIONS (row f3): every forward prefix x every backward prefix per pair")
+    ap.add_argument("--mis-balance", action="store_true",
+                    help="FS_FLAG_MIS_BALANCE (row f3): all-connections mode with balance-heuristic weights")
     ap.add_argument("--deterministic", action="store_true",
                     help="FS_FLAG_DETERMINISTIC: u64 fixed-point deposits, integer all-reduce (bit-identical for any N)")
     ap.add_argument("--fixed-seed", action="store_true",
@@ -148,6 +150,8 @@ def main():
         p.flags |= pkg._capi.FLAG_DETERMINISTIC
     if args.all_connections:
         p.flags |= pkg._capi.FLAG_ALL_CONNECTIONS
+    if args.mis_balance:
+        p.flags |= pkg._capi.FLAG_MIS_BALANCE
     lanes = []   # one (stream, context, source) per frame in flight; multi-source: one per source of this rank,
     #              the sources dealt round-robin to `--inflight` contexts (each context = one compute + one tail stream)
     ctxs = []
@@ -338,7 +342,8 @@ def main():
         except Exception:
             lib = oracle.load()
         osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption, lib=lib)
-        oflags = oracle.FLAG_ALL_CONNECTIONS if args.all_connections else 0
+        oflags = (oracle.FLAG_ALL_CONNECTIONS if args.all_connections else 0) | \
+            (oracle.FLAG_MIS_BALANCE if args.mis_balance else 0)
         op = oracle.default_params(num_pairs=total_rays // 2, depth=depth, seed=args.seed, flags=oflags,
                                    russian_roulette=0 if args.fixed_depth else 1)
         # 1 thread on a bounded sample (the first 1/8 of the frame's pairs)

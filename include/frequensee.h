@@ -56,6 +56,12 @@ enum {
                                              * forward prefix F0..Fi with every backward prefix B0..Bj of a pair (visibility test and
                                              * EvaluatePath as for the end-to-end connection) and combine the (i, j) that give the same
                                              * path length with uniform weights 1/N(i+j); ~(k+1)(m+1) contributions per pair instead of 1 */
+#define FS_FLAG_MIS_BALANCE 32u             /* row f3: balance-heuristic weights for the all-connections mode (implies it) — the intent of
+                                             * the draft's MISEnergy / getExpectedWeight, ARTS.cpp:548-597 ("the weight considers other
+                                             * strategies that could have produced the same path"): weight of the (i, j) that produced a
+                                             * path = its sampling density / the sum over all (i', j') of the same path length, with the
+                                             * densities the walk uses (1/4pi at the end points, CosTheta/PI at surfaces, ARTS.cpp:306-318)
+                                             * in area measure; uniform weight when a segment is degenerate */
 #define FS_FLAG_DETERMINISTIC 8u            /* deposits are summed as 64-bit integers of 2^-40 energy quanta: the
                                              * histogram no longer depends on the order of the atomics, so it is bit-identical
                                              * from run to run and for every split of the pairs over GPUs (sum-reduce the u64

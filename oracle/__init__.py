@@ -23,6 +23,7 @@ FLAG_FLUSH_BEFORE_RECONSTRUCT = 2
 FLAG_COSINE_SAMPLING = 4
 FLAG_BRUTE_FORCE = 8
 FLAG_ALL_CONNECTIONS = 16
+FLAG_MIS_BALANCE = 32
 
 
 class Params(C.Structure):
@@ -140,6 +141,8 @@ def _bind(lib):
     lib.fso_connect.restype = C.c_int32
     lib.fso_evaluate_path.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Node), C.c_int32,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.fso_mis_weight.argtypes = [C.POINTER(Node), C.c_int32, C.c_int32, C.c_int32]
+    lib.fso_mis_weight.restype = C.c_double
     lib.fso_add_energy_at_delay.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]
     lib.fso_add_energy_at_delay.restype = C.c_int32
     lib.fso_num_bins.argtypes = [C.c_float, C.c_float]
@@ -311,6 +314,22 @@ def reconstruct(energy_row, sample_rate=48000, bin_duration=0.001, num_samples=4
     lib.fso_reconstruct(e.ctypes.data, e.shape[0], sample_rate, bin_duration, num_samples, samples_per_bin,
                         out.ctypes.data)
     return out
+
+
+def mis_weight(nodes, s, depth, lib=None):
+    """Balance-heuristic weight of strategy s for the connected path `nodes` (list of Node), depth cap `depth`."""
+    lib = lib or load()
+    arr = (Node * len(nodes))(*nodes)
+    return float(lib.fso_mis_weight(arr, len(nodes), s, depth))
+
+
+def make_node(pos, normal=(0.0, 0.0, 0.0), material=0xFFFFFFFF, prob=1.0):
+    nd = Node()
+    nd.pos[:] = [float(x) for x in pos]
+    nd.normal[:] = [float(x) for x in normal]
+    nd.material = material
+    nd.prob = prob
+    return nd
 
 
 def add_energy_at_delay(buf, delay, e, bin_size_ms=1, lib=None):

@@ -596,6 +596,61 @@ void fso_evaluate_path(const fso_scene* s, const fso_params* p, const fso_node* 
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* Balance-heuristic weights for the all-connections mode (row f3).                            */
+/* The reference's draft (getExpectedWeight / MISEnergy, ARTS.cpp:548-597) weights a sample by  */
+/* "Cj * prob" — its sampling density relative to the other strategies "that could have         */
+/* produced the same path" — but is unfinished (getPdf returns 0.9, integer divisions); this   */
+/* is that intent with the densities the walk actually uses (ARTS.cpp:306-318), build-owned:   */
+/*   path y_0 (source), y_1..y_t (surface vertices, stored normal n_k), y_{t+1} (listener);    */
+/*   d_k = unit(y_{k+1} - y_k), L_k = |y_{k+1} - y_k|, k = 0..t.                               */
+/*   forward density of y_{k+1} given y_k   pf_k = Pf(k) |n_{k+1} . d_k| / L_k^2,  k = 0..t-1,  */
+/*       Pf(0) = 1/(4 pi) (VRand), Pf(k) = max(0, n_k . d_k) / pi (the walk's CosTheta / PI);   */
+/*   backward density of y_k given y_{k+1}  pb_k = Pb(k+1) |n_k . d_k| / L_k^2,    k = 1..t,    */
+/*       Pb(t+1) = 1/(4 pi), Pb(k) = max(0, -n_k . d_{k-1}) / pi;                               */
+/*   strategy s generates y_1..y_s from the source and y_t..y_{s+1} from the listener:         */
+/*       p_s = prod_{k<s} pf_k * prod_{k>s} pb_k;   w_s = p_s / sum_{s'} p_s'.                  */
+/* (The roulette factor rr^t is common to all strategies of one path and cancels.)  Evaluated   */
+/* in ONE pass over the segments, in double: T_k = T_{k-1} pb_k + [lo <= k <= hi] PF_k gives    */
+/* T_t = sum_s p_s, Q the same for s alone; PF_k = prod_{m<k} pf_m.  The HIP kernel follows     */
+/* the same sequence of operations.                                                            */
+/* ------------------------------------------------------------------------------------------- */
+double fso_mis_weight(const fso_node* nodes, int32_t n, int32_t s, int32_t D) {
+    const int32_t t = n - 2;
+    const int32_t lo = t - D > 0 ? t - D : 0, hi = t < D ? t : D;
+    const double uniform = 1.0 / (double)(hi - lo + 1);
+    if (t <= 0) return uniform;
+    const double inv4pi = 1.0 / (4.0 * 3.14159265358979323846), invpi = 1.0 / 3.14159265358979323846;
+    double PF = 1.0, T = 0.0, Q = 0.0;
+    for (int32_t k = 0; k <= t; ++k) {
+        const fso_node* a = &nodes[k]; const fso_node* b = &nodes[k + 1];
+        double dx = (double)b->pos[0] - (double)a->pos[0], dy = (double)b->pos[1] - (double)a->pos[1],
+               dz = (double)b->pos[2] - (double)a->pos[2];
+        double l2 = dx * dx + dy * dy + dz * dz;
+        if (!(l2 > 1e-8)) return uniform;
+        double inv = 1.0 / sqrt(l2);
+        dx *= inv; dy *= inv; dz *= inv;
+        /* cosines of the segment with the normals at its two ends (the end points have none) */
+        double ca = k > 0 ? (double)a->normal[0] * dx + (double)a->normal[1] * dy + (double)a->normal[2] * dz : 0.0;
+        double cb = k < t ? (double)b->normal[0] * dx + (double)b->normal[1] * dy + (double)b->normal[2] * dz : 0.0;
+        if (k >= 1) {
+            double Pb = k == t ? inv4pi : (cb < 0.0 ? -cb : 0.0) * invpi;
+            double pb = Pb * fabs(ca) / l2;
+            T *= pb;
+            if (k > s) Q *= pb;
+        }
+        if (k >= lo && k <= hi) T += PF;
+        if (k == s) Q = PF;
+        if (k < t) {
+            double Pf = k == 0 ? inv4pi : (ca > 0.0 ? ca : 0.0) * invpi;
+            PF *= Pf * fabs(cb) / l2;
+        }
+    }
+    double w = Q / T;
+    if (!(Q > 0.0) || !(T > 0.0) || !(w <= 1.0)) return uniform;   /* also NaN / inf */
+    return w;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* energy buffer  FSAC.h:72-91,133-139                                                         */
 /* ------------------------------------------------------------------------------------------- */
 int32_t fso_num_bins(float simulated_duration, float bin_duration) {
@@ -639,7 +694,7 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
         int32_t nf = fso_generate_path(s, p, i, 0, src, fwd, max_nodes, c);
         int32_t nb = fso_generate_path(s, p, i, 1, lis, bwd, max_nodes, c);
         if (nf == 0 || nb == 0) continue;                  /* ARTS.cpp:237 */
-        if (p->flags & FSO_FLAG_ALL_CONNECTIONS) {
+        if (p->flags & (FSO_FLAG_ALL_CONNECTIONS | FSO_FLAG_MIS_BALANCE)) {
             /* Row f3 — the reference's unfinished "naive connections" draft (Is_NaiveConnections, ARTS.cpp:518-546:
              * "connect every bounce of every sample in forward dir with every bounce in backward dir, Equation
              * 12"), restated for one pair: forward prefix F0..Fi (i = 0..k) x backward prefix B0..Bj (j = 0..m),
@@ -659,6 +714,7 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
                     int32_t t = fi + bj;
                     int32_t lo = t - D > 0 ? t - D : 0, hi = t < D ? t : D;
                     float w = 1.0f / (float)(hi - lo + 1);
+                    if (p->flags & FSO_FLAG_MIS_BALANCE) w = (float)fso_mis_weight(all, fi + bj + 2, fi, D);
                     int32_t bin = 0;
                     for (int b = 0; b < B; ++b) {
                         float e = gains[b];

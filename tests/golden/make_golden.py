@@ -31,6 +31,9 @@ CASES = [
     # row f3 (FS_FLAG_ALL_CONNECTIONS == FSO_FLAG_ALL_CONNECTIONS == 16)
     ("cfg1_shoebox_all_connections", "shoebox", 1, 512, 4, 0x5EED, {"flags": 16}),
     ("cfg2_starter_room_all_connections", "starter_room", 4, 2048, 8, 9, {"flags": 16}),
+    # row f3 with balance-heuristic weights (FS_FLAG_MIS_BALANCE == FSO_FLAG_MIS_BALANCE == 32)
+    ("cfg1_shoebox_mis_balance", "shoebox", 1, 512, 4, 0x5EED, {"flags": 32}),
+    ("cfg2_starter_room_mis_balance", "starter_room", 4, 2048, 8, 9, {"flags": 32}),
 ]
 
 

@@ -254,6 +254,15 @@ VARIANTS = [
      {"flags": 16, "russian_roulette": 0, "dist_divisor": 200.0}),
     ("all_connections_unbounded", "shoebox", 2, 600, 0, {"flags": 16}, {"flags": 16}),
     ("all_connections_one_pair", "shoebox", 1, 2, 8, {"flags": 16}, {"flags": 16}),
+    # row f3 with balance-heuristic weights (flag 32 on both sides; implies 16)
+    ("mis_balance_cfg1", "shoebox", 1, 1024, 4, {"flags": 32}, {"flags": 32}),
+    ("mis_balance_cfg2", "starter_room", 4, 8192, 8, {"flags": 32}, {"flags": 32}),
+    ("mis_balance_mine_no_rr", "old_mine", 8, 4096, 5, {"flags": 32, "russian_roulette": 0, "dist_divisor": 200.0},
+     {"flags": 32, "russian_roulette": 0, "dist_divisor": 200.0}),
+    ("mis_balance_unbounded_cosine", "shoebox", 2, 600, 0, {"flags": 32 | 4}, {"flags": 32 | 4}),
+    ("mis_balance_one_pair", "shoebox", 1, 2, 8, {"flags": 48}, {"flags": 48}),
+    ("mis_balance_no_offset", "starter_room", 4, 2048, 6, {"flags": 32, "surface_offset": 0.0, "connect_pullback": 0.0},
+     {"flags": 32, "surface_offset": 0.0, "connect_pullback": 0.0}),
 ]
 
 
@@ -591,6 +600,60 @@ def test_all_connections_properties_full_size(pkg, oracle_mod, scene_factory):
     c.reset_stats()
     assert c.stats()["deposits"] == 0
     c.close()
+
+
+def test_mis_balance_full_size(pkg, oracle_mod, scene_factory):
+    """cfg3 size with balance-heuristic weights (FS_FLAG_MIS_BALANCE): oracle parity on the first 8 192 pairs
+    (rank 0 of 16), work counters equal to the oracle's, and frame-level properties: the same paths are deposited as
+    with uniform weights (identical occupied bins and counters, different energies), shard invariance, and the
+    deterministic accumulation mode composes with it (bit-identical across shard counts)."""
+    sc = scene_factory("old_mine", 8)
+    mis, allc, det = pkg._capi.FLAG_MIS_BALANCE, pkg._capi.FLAG_ALL_CONNECTIONS, pkg._capi.FLAG_DETERMINISTIC
+    p_mis = pkg.default_params(num_rays=262144, depth=8, seed=0x5EED, flags=mis)
+    ctx, src = make_ctx(pkg, sc)
+    e_mis = ctx.compute_energy_response(src, p_mis).astype(np.float64)
+    st_mis = ctx.stats()
+    ctx.reset_stats()
+    e_uni = ctx.compute_energy_response(src, pkg.default_params(num_rays=262144, depth=8, seed=0x5EED, flags=allc)).astype(np.float64)
+    st_uni = ctx.stats()
+    ctx.reset_stats()
+    e_det = ctx.compute_energy_response(src, pkg.default_params(num_rays=262144, depth=8, seed=0x5EED, flags=mis | det))
+    ctx.close()
+    assert np.array_equal(e_mis != 0, e_uni != 0)
+    assert all(st_mis[k] == st_uni[k] for k in ("segments", "connections_tested", "deposits"))
+    assert max(rel_rms(e_mis[b], e_uni[b]) for b in range(8)) > 1e-2           # the weights do differ
+    assert max(rel_rms(e_det[b].astype(np.float64), e_mis[b]) for b in range(8)) <= TIGHT_TOL
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    p_det = pkg.default_params(num_rays=262144, depth=8, seed=0x5EED, flags=mis | det)
+
+    def fixed_hist(c, s_):
+        c.compute_energy_response_async(s_, p_det)
+        ptr, nbytes, _ = c.energy_handoff(s_)
+        c.synchronize()
+        h = np.zeros(8 * 1000, np.uint64)
+        assert nbytes == h.nbytes and hip.hipMemcpy(h.ctypes.data, ptr, nbytes, 2) == 0
+        return h
+
+    acc = np.zeros_like(e_mis)
+    acc_det = np.zeros(8 * 1000, np.uint64)
+    for r in range(2):
+        c, s_ = make_ctx(pkg, sc, rank=r, world_size=2)
+        acc += c.compute_energy_response(s_, p_mis)
+        acc_det += fixed_hist(c, s_)
+        c.close()
+    assert np.array_equal(acc != 0, e_mis != 0) and max(rel_rms(acc[b], e_mis[b]) for b in range(8)) <= TIGHT_TOL
+    assert np.array_equal((acc_det.astype(np.float64) * 2.0 ** -40).astype(np.float32).reshape(8, 1000), e_det)
+    c, s_ = make_ctx(pkg, sc, rank=0, world_size=16)
+    e_r0 = c.compute_energy_response(s_, p_mis)
+    st = c.stats()
+    c.close()
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    op = oracle_mod.default_params(num_pairs=131072, depth=8, seed=0x5EED, flags=oracle_mod.FLAG_MIS_BALANCE)
+    e32, e64, cnt = osc.compute_energy(op, sc.source, sc.listener, pair_begin=0, pair_end=8192)
+    check_energy(e_r0, e32, e64, 8)
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
 
 
 def test_physical_sanity_direct_sound(pkg, scene_factory):

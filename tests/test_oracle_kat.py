@@ -347,3 +347,116 @@ def test_kat_all_connections_open_space(oracle_mod):
         for t in range(2 * D + 1):
             n = sum(1 for i in range(D + 1) for j in range(D + 1) if i + j == t)
             assert n == min(t, D) - max(0, t - D) + 1
+
+
+# ---- row f3: balance-heuristic weights -------------------------------------------------------------------------
+def _mis_by_definition(pos, nrm, s, D):
+    """p_s = prod_{k<s} pf_k * prod_{k>s} pb_k written out strategy by strategy in float64 (the oracle evaluates the
+    same sum in one pass).  pos[0] = source, pos[-1] = listener, nrm[k] = stored normal of surface vertex k."""
+    t = len(pos) - 2
+    lo, hi = max(0, t - D), min(t, D)
+    seg = []
+    for k in range(t + 1):
+        d = pos[k + 1] - pos[k]
+        l2 = float(d @ d)
+        seg.append((d / math.sqrt(l2), l2))
+
+    def pf(k):      # density of y_{k+1} generated from y_k, area measure
+        d, l2 = seg[k]
+        P = 1 / (4 * math.pi) if k == 0 else max(0.0, float(nrm[k] @ d)) / math.pi
+        return P * abs(float(nrm[k + 1] @ d)) / l2
+
+    def pb(k):      # density of y_k generated from y_{k+1}
+        d, l2 = seg[k]
+        P = 1 / (4 * math.pi) if k == t else max(0.0, -float(nrm[k + 1] @ d)) / math.pi
+        return P * abs(float(nrm[k] @ d)) / l2
+
+    def p(sp):
+        v = 1.0
+        for k in range(sp):
+            v *= pf(k)
+        for k in range(sp + 1, t + 1):
+            v *= pb(k)
+        return v
+
+    return p(s) / sum(p(sp) for sp in range(lo, hi + 1))
+
+
+def test_kat_mis_weight_one_bounce_by_hand(oracle_mod):
+    """t = 1 by hand: floor z = -100 (normal +z), source (0,0,0), vertex (50,0,-100), listener (200,0,0).
+    Generated from the source: p_1 = 1/(4 pi) cos1 / L0^2 with cos1 = 100/L0, L0^2 = 12500; from the listener:
+    p_0 = 1/(4 pi) cos1' / L1^2 with cos1' = 100/L1, L1^2 = 32500.  w_1 = p_1 / (p_0 + p_1) = L1^3 / (L0^3 + L1^3)."""
+    mk = oracle_mod.make_node
+    nodes = [mk((0, 0, 0)), mk((50, 0, -100), (0, 0, 1)), mk((200, 0, 0))]
+    L0, L1 = math.sqrt(12500.0), math.sqrt(32500.0)
+    w1 = L1 ** 3 / (L0 ** 3 + L1 ** 3)
+    assert oracle_mod.mis_weight(nodes, 1, 8) == pytest.approx(w1, rel=1e-14)
+    assert oracle_mod.mis_weight(nodes, 0, 8) == pytest.approx(1 - w1, rel=1e-14)
+    # direct path: one strategy, weight 1; depth cap 1 leaves both strategies of t = 1
+    assert oracle_mod.mis_weight([mk((0, 0, 0)), mk((200, 0, 0))], 0, 8) == 1.0
+    assert oracle_mod.mis_weight(nodes, 1, 1) == pytest.approx(w1, rel=1e-14)
+
+
+def test_mis_weight_matches_definition_and_sums_to_one(oracle_mod):
+    """Random reflection paths inside a unit-ish box: the one-pass evaluation equals the strategy-by-strategy
+    definition, the weights of all strategies of one path sum to 1 (also when the depth cap removes some), a
+    strategy that would have to leave a surface backwards has weight 0, degenerate segments give the uniform weight."""
+    rng = np.random.default_rng(7)
+    mk = oracle_mod.make_node
+    for trial in range(200):
+        t = int(rng.integers(1, 9))
+        D = int(rng.integers(max(1, (t + 1) // 2), 9))
+        pos = rng.uniform(-500, 500, (t + 2, 3))
+        nrm = np.zeros((t + 2, 3))
+        for k in range(1, t + 1):
+            # a normal with both neighbours on its side (a reflection), as the walk produces
+            a = (pos[k - 1] - pos[k]) / np.linalg.norm(pos[k - 1] - pos[k])
+            b = (pos[k + 1] - pos[k]) / np.linalg.norm(pos[k + 1] - pos[k])
+            n = a + b + rng.normal(0, 0.05, 3)
+            if np.linalg.norm(a + b) < 0.2:        # nearly straight through: tilt the normal off the path
+                n = np.cross(a, rng.normal(size=3)) + 0.3 * (a + b)
+            nrm[k] = n / np.linalg.norm(n)
+            if min(nrm[k] @ a, nrm[k] @ b) < 0.02:
+                nrm[k] = np.cross(np.cross(a, b), a - b)      # bisector plane normal: equal, positive cosines
+                nrm[k] /= np.linalg.norm(nrm[k])
+                if nrm[k] @ a < 0:
+                    nrm[k] = -nrm[k]
+        pos32, nrm32 = pos.astype(np.float32), nrm.astype(np.float32)
+        nodes = [mk(pos32[k], nrm32[k]) for k in range(t + 2)]
+        lo, hi = max(0, t - D), min(t, D)
+        ws = [oracle_mod.mis_weight(nodes, s, D) for s in range(lo, hi + 1)]
+        for s, w in zip(range(lo, hi + 1), ws):
+            assert w == pytest.approx(_mis_by_definition(pos32.astype(np.float64), nrm32.astype(np.float64), s, D),
+                                      rel=1e-11, abs=1e-300)
+        assert sum(ws) == pytest.approx(1.0, rel=1e-12)
+    # vertex 1 faces away from the listener side: it cannot have been left towards vertex 2 by the forward walk,
+    # so every strategy that generates vertex 2 from the source (s = 2) has density 0
+    nodes = [mk((0, 0, 0)), mk((100, 0, -100), (0, 0, 1)), mk((200, 0, -200), (0, 0, 1)), mk((300, 0, 0))]
+    assert oracle_mod.mis_weight(nodes, 2, 8) == pytest.approx(1.0 / 3.0)          # its own density is 0: uniform fallback
+    assert oracle_mod.mis_weight(nodes, 0, 8) + oracle_mod.mis_weight(nodes, 1, 8) == pytest.approx(1.0)
+    # a duplicate node (a walk step that missed, ARTS.cpp:296): uniform weight 1 / N(t)
+    nodes = [mk((0, 0, 0)), mk((50, 0, -100), (0, 0, 1)), mk((50, 0, -100), (0, 0, 1)), mk((200, 0, 0))]
+    assert oracle_mod.mis_weight(nodes, 1, 8) == pytest.approx(1.0 / 3.0)
+    assert oracle_mod.mis_weight(nodes, 1, 1) == pytest.approx(1.0)                # t = 2, D = 1: only s = 1 is left
+
+
+def test_mis_frame_properties(oracle_mod, scene_factory):
+    """Frame level (cfg1): the balance heuristic reweights the same connected paths, so occupied bins, connection
+    and deposit counts equal the uniform-weight mode's; the direct path (one strategy) is untouched; the flag
+    implies all-connections."""
+    sc = scene_factory("shoebox", 1)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    pu = oracle_mod.default_params(num_pairs=256, depth=4, seed=11, flags=oracle_mod.FLAG_ALL_CONNECTIONS)
+    pm = oracle_mod.default_params(num_pairs=256, depth=4, seed=11, flags=oracle_mod.FLAG_MIS_BALANCE)
+    pb = oracle_mod.default_params(num_pairs=256, depth=4, seed=11,
+                                   flags=oracle_mod.FLAG_MIS_BALANCE | oracle_mod.FLAG_ALL_CONNECTIONS)
+    eu, eu64, cu = osc.compute_energy(pu, sc.source, sc.listener)
+    em, em64, cm = osc.compute_energy(pm, sc.source, sc.listener)
+    eb, _, _ = osc.compute_energy(pb, sc.source, sc.listener)
+    assert np.array_equal(em, eb)
+    assert (cu.connected, cu.deposits, cu.any_rays) == (cm.connected, cm.deposits, cm.any_rays)
+    assert np.array_equal(eu != 0, em != 0)
+    assert not np.allclose(eu64, em64, rtol=1e-3)
+    d = float(np.linalg.norm(sc.listener.astype(np.float64) - sc.source.astype(np.float64))) / 1000.0
+    direct_bin = int(np.floor(d / 343.0 * 1000.0))
+    assert np.flatnonzero(em[0]).min() == direct_bin
