@@ -30,6 +30,7 @@ FLAG_COSINE_SAMPLING = 4
 FLAG_DETERMINISTIC = 8
 FLAG_ALL_CONNECTIONS = 16
 FLAG_MIS_BALANCE = 32
+FLAG_MATERIAL_LOBES = 64
 
 # every symbol include/frequensee.h declares (tests check the library exports all of them)
 EXPORTS = [

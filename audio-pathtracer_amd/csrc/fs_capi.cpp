@@ -110,6 +110,7 @@ struct fs_context {
     size_t cap_lanes = 0, cap_seg = 0;
     float4* d_seg_pos = nullptr;   // node positions per walk step, all-connections mode only (row f3)
     size_t cap_pos = 0;
+    unsigned long long host_segments = 0;   // walk segments of frames without a plan pass (roulette off), since the last reset
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
     WalkLaunch walk{2, 256, 2, nullptr, 1, nullptr};   // variant 2 = wave work sharing (default), 0 = one subpath per lane, 1 = persistent
@@ -320,6 +321,8 @@ int check_params(fs_context* ctx, const fs_params* p) {
     if (p->depth < 0 || p->depth > FS_MAX_DEPTH) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "depth out of range");
     if (p->num_rays & 1u) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "num_rays must be even (source + listener subpaths)");
     if (p->num_rays > (1u << 30)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "num_rays above 2^30 per frame (32-bit subpath indices)");
+    if ((p->flags & FS_FLAG_MATERIAL_LOBES) && (p->flags & FS_FLAG_MIS_BALANCE))
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "FS_FLAG_MATERIAL_LOBES and FS_FLAG_MIS_BALANCE cannot be combined");
     if (!(p->dist_divisor > 0.f) || !(p->sound_speed > 0.f))
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "dist_divisor and sound_speed must be positive");
     return FS_OK;
@@ -510,8 +513,37 @@ int fs_scene_commit(fs_context* ctx) {
         FS_HIP(ctx, hipMemcpy(ctx->d_tris, ctx->bvh.tris.data(), tb, hipMemcpyHostToDevice));
     }
     if (mb) {
-        FS_HIP(ctx, hipMalloc((void**)&ctx->d_absorption, mb));
-        FS_HIP(ctx, hipMemcpy(ctx->d_absorption, ctx->h_absorption.data(), mb, hipMemcpyHostToDevice));
+        // absorption [M][B] | lobe gains [M][3][B] | lobe probabilities [M][3] (FS_FLAG_MATERIAL_LOBES).  The split is
+        // the per-bin rule of ApplyMaterialFD (MaterialAcousticProcessor.cpp:51-72) per band: Refl = 1 - alpha, tau
+        // clamped to Refl + tau <= 1, diffuse Refl sigma, specular Refl (1 - sigma), transmitted tau; a lobe is
+        // picked with the band mean of its gain over the sum of the three.  No arrays: tau = 0, sigma = 1.
+        const int B = ctx->cfg.num_bands, M = ctx->M;
+        std::vector<float> table(ctx->h_absorption);
+        table.resize((size_t)M * B + (size_t)M * 3 * B + (size_t)M * 3, 0.f);
+        float* gain = table.data() + (size_t)M * B;
+        float* prob = gain + (size_t)M * 3 * B;
+        const bool has_t = ctx->h_transmission.size() == (size_t)M * B, has_s = ctx->h_scattering.size() == (size_t)M * B;
+        for (int m = 0; m < M; ++m) {
+            float sum[3] = {0.f, 0.f, 0.f};
+            for (int b = 0; b < B; ++b) {
+                const float alpha = ctx->h_absorption[(size_t)m * B + b];
+                float tau = has_t ? ctx->h_transmission[(size_t)m * B + b] : 0.0f;
+                const float sigma = has_s ? ctx->h_scattering[(size_t)m * B + b] : 1.0f;
+                const float refl = 1.0f - alpha;
+                if (refl + tau > 1.0f) tau = 1.0f - refl;
+                float g[3] = {refl * sigma, refl * (1.0f - sigma), tau};
+                for (int l = 0; l < 3; ++l) {
+                    if (!(g[l] > 0.0f)) g[l] = 0.0f;
+                    gain[((size_t)m * 3 + l) * B + b] = g[l];
+                    sum[l] += g[l];
+                }
+            }
+            float mean[3], tot = 0.0f;
+            for (int l = 0; l < 3; ++l) { mean[l] = sum[l] / (float)B; tot += mean[l]; }
+            for (int l = 0; l < 3; ++l) prob[(size_t)m * 3 + l] = tot > 0.0f ? mean[l] / tot : (l == 0 ? 1.0f : 0.0f);
+        }
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_absorption, table.size() * sizeof(float)));
+        FS_HIP(ctx, hipMemcpy(ctx->d_absorption, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (tb) {   // refit support: leaf positions and the bounds scratch
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_pos, sizeof(uint32_t) * ctx->bvh.leaf_pos.size()));
@@ -524,6 +556,8 @@ int fs_scene_commit(fs_context* ctx) {
     ctx->scene.nodes = ctx->d_nodes;
     ctx->scene.tris = ctx->d_tris;
     ctx->scene.absorption = ctx->d_absorption;
+    ctx->scene.lobe_gain = ctx->d_absorption ? ctx->d_absorption + (size_t)ctx->M * ctx->cfg.num_bands : nullptr;
+    ctx->scene.lobe_prob = ctx->d_absorption ? ctx->scene.lobe_gain + (size_t)ctx->M * 3 * ctx->cfg.num_bands : nullptr;
     ctx->scene.num_nodes = (int32_t)ctx->bvh.nodes.size();
     ctx->scene.num_tris = ctx->T;
     ctx->scene.num_materials = ctx->M;
@@ -688,6 +722,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     kp.num_bins = ctx->num_bins;
     kp.refill_threshold = ctx->refill_threshold;
 
+    kp.lobes = (p->flags & FS_FLAG_MATERIAL_LOBES) ? 1 : 0;
     const bool mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
     const bool all_conn = mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
     kp.mis = mis ? 1 : 0;
@@ -719,6 +754,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     const int zero_words = (fixed ? 2 : 1) * B * ctx->num_bins;
     const uint32_t* perm = launch_plan(kp, ctx->walk, zero_ptr, zero_words, ctx->stream);
     if (!perm) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+    if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     launch_walk(ctx->scene, kp, st, ctx->walk, perm, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
@@ -1376,7 +1412,7 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
         FS_HIP(ctx, hipMemcpyAsync(c, ctx->walk.queue_head + kCounterWord, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->stats.segments = c[0];
+        ctx->stats.segments = c[0] + ctx->host_segments;
         ctx->stats.connections_tested = c[1];
         ctx->stats.deposits = c[2];
     }
@@ -1388,6 +1424,7 @@ int fs_reset_stats(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     fs_stats keep = ctx->stats;
     ctx->stats = fs_stats{};
+    ctx->host_segments = 0;
     ctx->stats.bvh_nodes = keep.bvh_nodes;
     ctx->stats.triangles = keep.triangles;
     ctx->stats.bvh_stack_need = keep.bvh_stack_need;

@@ -48,6 +48,8 @@ struct DeviceScene {
     const NodeQ4* nodes;
     const Tri64* tris;
     const float* absorption;  // [M][B]
+    const float* lobe_gain;   // [M][3][B] diffuse / specular / transmitted gains (FS_FLAG_MATERIAL_LOBES)
+    const float* lobe_prob;   // [M][3] probability of each lobe
     int32_t num_nodes;        // 0 = empty scene
     int32_t num_tris;
     int32_t num_materials;
@@ -62,6 +64,7 @@ struct KParams {
     int32_t depth;         // max segments per subpath (1..FS_MAX_DEPTH)
     int32_t russian_roulette;
     int32_t cosine;
+    int32_t lobes;         // 1 = FS_FLAG_MATERIAL_LOBES: the walk picks a specular / diffuse / transmitted lobe per vertex
     int32_t mis;           // all-connections mode: 1 = balance-heuristic weights, 0 = uniform
     float rr_prob, max_trace_dist, surface_offset, connect_pullback;
     float dist_divisor, min_seg, prob_exponent, energy_clamp, energy_gain, sound_speed;

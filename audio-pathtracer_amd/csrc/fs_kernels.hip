@@ -33,6 +33,8 @@ namespace {
 
 constexpr float kPi = 3.1415926535897932f;
 constexpr uint32_t kNoMat = FS_NO_MATERIAL;
+constexpr uint32_t kLobeDiffuse = 0u, kLobeSpecular = 1u, kLobeTransmit = 2u;
+constexpr int kLobeShift = 16;   // segment record: material id | lobe << 16
 constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
 constexpr double kFixedScale = 1099511627776.0;   // 2^40: quantum of the deterministic (fixed-point) energy sum
 #ifdef FS_TRAV_STATS
@@ -355,17 +357,26 @@ __device__ __forceinline__ void hit_surface(const DeviceScene& sc, int leaf_inde
 }
 
 // one EvaluatePath segment term on E[b] (ARTS.cpp:381-398), in the reference's operation order
-template <int B>
+// LOBES: 0 / 1 = FS_FLAG_MATERIAL_LOBES known at compile time (the default connect kernel), -1 = read kp.lobes
+template <int B, int LOBES = -1>
 __device__ __forceinline__ void apply_segment(float (&E)[B], float nd, uint32_t mat, float prob, const KParams& kp,
                                               const DeviceScene& sc) {
+    const bool lobes = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
     if (nd < kp.min_seg) return;  // ARTS.cpp:375-378
     float nd2 = nd * nd;
     float geo = 1.0f / (4 * kPi * nd2);            // ARTS.cpp:391
     float pw = powf(prob, kp.prob_exponent);       // ARTS.cpp:398
+    // FS_FLAG_MATERIAL_LOBES (row f4): bits 16-17 of the record = lobe the walk took at this vertex (0 = diffuse,
+    // also at a connection vertex); its gain replaces Absorption (the diffuse one still over pi)
+    const uint32_t lobe = (lobes && mat != kNoMat) ? ((mat >> kLobeShift) & 3u) : 0u;
+    if (lobes && mat != kNoMat) mat &= 0xFFFFu;
     bool has = (mat != kNoMat) && ((int32_t)mat < sc.num_materials);
+    const float* coeff = lobes ? sc.lobe_gain + ((size_t)mat * 3 + lobe) * B : sc.absorption + (size_t)mat * B;
+    const bool over_pi = !lobes || lobe == kLobeDiffuse;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        float bsdf = has ? sc.absorption[mat * B + b] / kPi : 1.0f;   // ARTS.cpp:382-386
+        float bsdf = 1.0f;                                            // ARTS.cpp:382-386
+        if (has) bsdf = over_pi ? coeff[b] / kPi : coeff[b];
         float e = E[b];
         e *= bsdf;
         e *= geo;
@@ -383,7 +394,9 @@ struct Walker {          // ARTS.cpp:287-291 state + bookkeeping
     int k;
     float px, py, pz, nx, ny, nz;
     bool has_normal;
+    bool arrived;      // the current vertex was reached by a hit (lobes are picked only then)
     uint32_t mat;
+    uint32_t lobe;     // lobe picked at the current vertex << kLobeShift (FS_FLAG_MATERIAL_LOBES), else 0
     float prob, prob_new;
 };
 
@@ -398,13 +411,20 @@ __device__ __forceinline__ void walker_start(Walker& w, uint32_t g, const KParam
     w.pz = w.side ? kp.lis[2] : kp.src[2];
     w.nx = 0.f; w.ny = 0.f; w.nz = 0.f;
     w.has_normal = false;
+    w.arrived = false;
+    w.lobe = 0u;
     w.mat = kNoMat;
     w.prob = 1.0f; w.prob_new = 1.0f;
     w.k = 0;
 }
 
 // top of GeneratePath's loop (ARTS.cpp:294-319): depth cap, roulette, direction.  false = the walk ends.
-__device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, Ray& ray) {
+// `ray` still holds the previous segment's ray on entry: its direction is the arrival direction at this vertex.
+// LOBES: 0 / 1 = FS_FLAG_MATERIAL_LOBES known at compile time, -1 = read kp.lobes.
+template <int LOBES = -1>
+__device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, const DeviceScene& sc,
+                                                const SubpathState& st, Ray& ray) {
+    const bool lobes_on = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
     if (w.k >= kp.depth) return false;
     const uint32_t bs = ((uint32_t)w.k << 1) | w.side;
     const uint4 r = philox(w.pair, bs, 0, kp.seed_lo, kp.seed_hi);
@@ -415,10 +435,44 @@ __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, Ra
         float pdf = 1.0f / (4.0f * kPi);
         w.prob_new = pdf * kp.rr_prob;
     } else {                                                              // ARTS.cpp:311-318
-        sample_cone(w.nx, w.ny, w.nz, u01(r.y), u01(r.z), kp.cosine, dx, dy, dz);
-        float cos_theta = dx * w.nx + dy * w.ny + dz * w.nz;
-        float pdf = cos_theta / kPi;
-        w.prob_new = pdf * kp.rr_prob;
+        // FS_FLAG_MATERIAL_LOBES (row f4, build-owned): one lobe per vertex, picked with the Philox word the diffuse
+        // walk leaves unused, probabilities = band means of the lobe gains (table built at commit)
+        uint32_t lobe = kLobeDiffuse;
+        float plobe = 1.0f;
+        const bool pick = lobes_on && w.arrived && w.mat != kNoMat && (int32_t)w.mat < sc.num_materials;
+        if (pick) {
+            const float* pr = sc.lobe_prob + 3 * (size_t)w.mat;
+            const float p0 = pr[0], p1 = pr[1], p2 = pr[2];
+            const float u = u01(r.w);
+            const float c1 = p0, c2 = p0 + p1;
+            lobe = u < c1 ? kLobeDiffuse : (u < c2 ? kLobeSpecular : kLobeTransmit);
+            if (lobe == kLobeTransmit && !(p2 > 0.0f)) lobe = p1 > 0.0f ? kLobeSpecular : kLobeDiffuse;
+            plobe = lobe == kLobeDiffuse ? p0 : (lobe == kLobeSpecular ? p1 : p2);
+            // the listener side pairs a segment with its ARRIVAL vertex: the record of the previous step describes
+            // this vertex and learns its lobe now
+            if (w.side) st.seg_mat[(size_t)(w.k - 1) * (2u * (size_t)kp.num_local) + w.g] = w.mat | (lobe << kLobeShift);
+        }
+        w.lobe = pick ? lobe << kLobeShift : 0u;
+        float ox = w.px, oy = w.py, oz = w.pz;
+        if (lobe == kLobeDiffuse) {
+            sample_cone(w.nx, w.ny, w.nz, u01(r.y), u01(r.z), kp.cosine, dx, dy, dz);
+            float cos_theta = dx * w.nx + dy * w.ny + dz * w.nz;
+            float pdf = cos_theta / kPi;
+            w.prob_new = pdf * kp.rr_prob;
+        } else if (lobe == kLobeSpecular) {                               // mirror direction of the arriving ray
+            float dn = ray.dx * w.nx + ray.dy * w.ny + ray.dz * w.nz;
+            float k2 = 2.0f * dn;
+            dx = fmaf(-k2, w.nx, ray.dx); dy = fmaf(-k2, w.ny, ray.dy); dz = fmaf(-k2, w.nz, ray.dz);
+            w.prob_new = kp.rr_prob;
+        } else {                                                          // straight on, from the far side of the surface
+            dx = ray.dx; dy = ray.dy; dz = ray.dz;
+            w.prob_new = kp.rr_prob;
+            float back = -2.0f * kp.surface_offset;
+            ox = fmaf(back, w.nx, w.px); oy = fmaf(back, w.ny, w.py); oz = fmaf(back, w.nz, w.pz);
+        }
+        if (pick) w.prob_new = w.prob_new * plobe;
+        ray = make_ray(ox, oy, oz, dx, dy, dz);
+        return true;
     }
     ray = make_ray(w.px, w.py, w.pz, dx, dy, dz);
     return true;
@@ -431,11 +485,12 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
     uint32_t mat_new = w.mat;
     if (T.leaf_index >= 0) {                                              // ARTS.cpp:345-347
         hit_surface(sc, T.leaf_index, ray, w.nx, w.ny, w.nz, mat_new);
-        qx = fmaf(kp.surface_offset, w.nx, fmaf(T.t, ray.dx, w.px));
-        qy = fmaf(kp.surface_offset, w.ny, fmaf(T.t, ray.dy, w.py));
-        qz = fmaf(kp.surface_offset, w.nz, fmaf(T.t, ray.dz, w.pz));
+        qx = fmaf(kp.surface_offset, w.nx, fmaf(T.t, ray.dx, ray.ox));   // ray origin = node position, except behind
+        qy = fmaf(kp.surface_offset, w.ny, fmaf(T.t, ray.dy, ray.oy));   // the surface for a transmitted segment
+        qz = fmaf(kp.surface_offset, w.nz, fmaf(T.t, ray.dz, ray.oz));
         w.has_normal = true;
     }
+    w.arrived = T.leaf_index >= 0;
     // the segment just added (zero length on a miss: the duplicate node of ARTS.cpp:296)
     float ddx = qx - w.px, ddy = qy - w.py, ddz = qz - w.pz;
     float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);                // ARTS.cpp:372
@@ -445,7 +500,7 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
     // path — the ARRIVAL node on the listener side.
     const size_t slot = (size_t)w.k * (2u * (size_t)kp.num_local) + w.g;
     st.seg_np[slot] = w.side == 0 ? make_float2(nd, w.prob) : make_float2(nd, w.prob_new);
-    st.seg_mat[slot] = w.side == 0 ? w.mat : mat_new;
+    st.seg_mat[slot] = w.side == 0 ? (w.mat | w.lobe) : mat_new;   // w.lobe: 0 unless FS_FLAG_MATERIAL_LOBES picked one here
     if (st.seg_pos) st.seg_pos[slot] = make_float4(qx, qy, qz, 0.0f);   // all-connections mode (wave-uniform)
     if (st.seg_nrm) st.seg_nrm[slot] = make_float4(w.nx, w.ny, w.nz, 0.0f);   // balance-heuristic weights only
     w.px = qx; w.py = qy; w.pz = qz;
@@ -513,7 +568,7 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
 #pragma unroll
     for (int it = 0; it < kPlanItems; ++it) {
         const uint32_t g = (blockIdx.x * kPlanItems + it) * kBlock + threadIdx.x;
-        if (g < total) perm[(size_t)L[it] * total + s_base[L[it]] + rank[it]] = g;
+        if (perm && g < total) perm[(size_t)L[it] * total + s_base[L[it]] + rank[it]] = g;
     }
     // work counter: walk segments of this frame (a walk of length L traces L rays), one atomic per workgroup
     if (threadIdx.x == 0) {
@@ -538,6 +593,7 @@ __device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, ui
 // ---------------------------------------------------------------------------------------------------
 // walk_kernel_simple: one subpath per lane (reference variant)
 // ---------------------------------------------------------------------------------------------------
+template <int LOBES>
 __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
@@ -556,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
     Walker w;
     walker_start(w, g, kp);
     Ray ray;
-    while (walker_next_ray(w, kp, ray)) {
+    while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
         Trav T;
         trav_init(T, kp.max_trace_dist, sc.num_nodes > 0);
 #ifdef FS_TRAV_STATS
@@ -664,6 +720,7 @@ __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray
     }
 }
 
+template <int LOBES>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
@@ -681,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
     Walker w;
     walker_start(w, g, kp);
     Ray ray;
-    while (walker_next_ray(w, kp, ray)) {
+    while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
         Trav T;
         trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist);
         walker_apply_hit(w, kp, sc, st, ray, T);
@@ -764,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
                     q_next = min(q_next + (unsigned)__popcll(need), q_end);
                 }
                 if (phase == PH_NEXT) {
-                    if (walker_next_ray(w, kp, ray)) {
+                    if (walker_next_ray(w, kp, sc, st, ray)) {
                         trav_init(T, kp.max_trace_dist, nonempty);
                         phase = nonempty ? PH_TRAV : PH_SHADE;   // empty scene: every trace misses
                     } else {
@@ -792,7 +849,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
 // ---------------------------------------------------------------------------------------------------
 // connect_kernel: ConnectSubpaths + EvaluatePath + clamp/gain + deposit
 // ---------------------------------------------------------------------------------------------------
-template <int B>
+template <int B, int LOBES>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head) {
@@ -800,9 +857,10 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
     __shared__ int s_lo, s_hi;
+    __shared__ unsigned s_dep;
     const int nb = kp.num_bins;
     for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
-    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; }
+    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; }
     // this frame's walk is over: rearm the frame scratch (queue head, plan counts and cursors) for the next one
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
@@ -843,18 +901,18 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
             const float2 np = st.seg_np[(size_t)j * total + li];
             sd += np.x;                                               // ARTS.cpp:374
-            apply_segment<B>(E, np.x, st.seg_mat[(size_t)j * total + li], np.y, kp, sc);
+            apply_segment<B, LOBES>(E, np.x, st.seg_mat[(size_t)j * total + li], np.y, kp, sc);
         }
         {                                                             // connection segment: F_k's material/prob
             float dist = sqrtf(l2);
             float nd = dist / kp.dist_divisor;
             sd += nd;
-            apply_segment<B>(E, nd, Fm.x, F.w, kp, sc);
+            apply_segment<B, LOBES>(E, nd, Fm.x, F.w, kp, sc);
         }
         for (int j = kl - 1; j >= 0; --j) {                           // listener-side segments B_j+1 -> B_j
             const float2 np = st.seg_np[(size_t)j * total + n + li];
             sd += np.x;
-            apply_segment<B>(E, np.x, st.seg_mat[(size_t)j * total + n + li], np.y, kp, sc);
+            apply_segment<B, LOBES>(E, np.x, st.seg_mat[(size_t)j * total + n + li], np.y, kp, sc);
         }
         float delay = sd / kp.sound_speed;                            // ARTS.cpp:419
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
@@ -876,14 +934,18 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
                 atomicAdd(&s_hist[b * nb + bin], e);                  // ds_add_f32
         }
     }
-    {   // work counters: one atomic per wave
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
+    {   // work counters: summed per wave, then per workgroup in LDS — one global atomic per workgroup (thousands of
+        // atomics on one address cost the kernel ~10 %)
         unsigned d = my_deposits;
         for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
-        if ((threadIdx.x & 63u) == 0u && d) atomicAdd(&counters[2], (unsigned long long)d);
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
+        if ((threadIdx.x & 63u) == 0u && d) atomicAdd(&s_dep, d);
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
+        if (s_dep) atomicAdd(&counters[2], (unsigned long long)s_dep);
+        if (blockIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
+    }
     const int lo = s_lo, hi = s_hi;
     if (hi < lo) return;
     const int span = hi - lo + 1;
@@ -997,6 +1059,7 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             uint32_t fmat; float fprob;
             if (i < kf) { fmat = st.seg_mat[(size_t)i * total + li]; fprob = st.seg_np[(size_t)i * total + li].y; }
             else { fmat = Fm.x; fprob = st.end_pos[li].w; }
+            fmat &= 0xFFFFu;   // a connection vertex scatters diffusely whatever lobe the walk took there later (row f4)
             float dx = bx - fx, dy = by - fy, dz = bz - fz;
             float l2 = dx * dx + dy * dy + dz * dz;
             bool visible = true;
@@ -1031,7 +1094,9 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             for (int a = j - 1; a >= 0; --a) {                            // B_a+1 -> B_a
                 const float2 np = st.seg_np[(size_t)a * total + n + li];
                 sd += np.x;
-                apply_segment<B>(E, np.x, st.seg_mat[(size_t)a * total + n + li], np.y, kp, sc);
+                uint32_t bmat = st.seg_mat[(size_t)a * total + n + li];
+                if (a == j - 1) bmat &= 0xFFFFu;                          // Bj is the other connection vertex
+                apply_segment<B>(E, np.x, bmat, np.y, kp, sc);
             }
             const int t = i + j, D = kp.depth;
             const int lo_t = t - D > 0 ? t - D : 0, hi_t = t < D ? t : D;
@@ -1457,8 +1522,13 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
     uint32_t blocks = (kp.num_local + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;
     size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins;
-    allow_lds(connect_kernel<B>, lds);
-    hipLaunchKernelGGL(connect_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
+    if (kp.lobes) {
+        allow_lds(connect_kernel<B, 1>, lds);
+        hipLaunchKernelGGL((connect_kernel<B, 1>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
+    } else {
+        allow_lds(connect_kernel<B, 0>, lds);
+        hipLaunchKernelGGL((connect_kernel<B, 0>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
+    }
 }
 
 }  // namespace
@@ -1466,11 +1536,15 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
                             hipStream_t s) {
     uint32_t lanes = 2u * kp.num_local;
-    // length-sorted schedule: only meaningful when roulette can end walks early
-    if (lanes == 0 || !wl.plan || !kp.russian_roulette || kp.depth <= 1 || !wl.perm) return nullptr;
+    // Without roulette every walk takes kp.depth segments: nothing to sort, and the caller counts the segments on
+    // the host.  With roulette the pass always runs — it is also what counts the frame's walk segments — but it
+    // only produces the length-sorted schedule when that is enabled and can matter.
+    if (lanes == 0 || !kp.russian_roulette) return nullptr;
+    const bool sort = wl.plan && kp.depth > 1 && wl.perm;
     uint32_t full = (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
-    hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, wl.perm, energy, energy_words);
-    return wl.perm;
+    hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, sort ? wl.perm : nullptr, energy,
+                       energy_words);
+    return sort ? wl.perm : nullptr;
 }
 
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
@@ -1478,15 +1552,25 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
-    if (wl.variant == 2) {
-        allow_lds(walk_kernel_shared, stack_bytes(sc) + kShareLdsBytes);
-        hipLaunchKernelGGL(walk_kernel_shared, dim3(full), dim3(kBlock), stack_bytes(sc) + kShareLdsBytes, s, sc, kp, st,
-                           wl.queue_head, perm);
+    if (wl.variant == 2) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
+        if (kp.lobes) {
+            allow_lds(walk_kernel_shared<1>, lds);
+            hipLaunchKernelGGL(walk_kernel_shared<1>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm);
+        } else {
+            allow_lds(walk_kernel_shared<0>, lds);
+            hipLaunchKernelGGL(walk_kernel_shared<0>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm);
+        }
         return;
     }
     if (wl.variant == 0) {
-        allow_lds(walk_kernel_simple, stack_bytes(sc));
-        hipLaunchKernelGGL(walk_kernel_simple, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
+        if (kp.lobes) {
+            allow_lds(walk_kernel_simple<1>, stack_bytes(sc));
+            hipLaunchKernelGGL(walk_kernel_simple<1>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
+        } else {
+            allow_lds(walk_kernel_simple<0>, stack_bytes(sc));
+            hipLaunchKernelGGL(walk_kernel_simple<0>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
+        }
         return;
     }
     uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;

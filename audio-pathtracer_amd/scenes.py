@@ -391,3 +391,14 @@ def by_name(name: str, bands: int | None = None) -> Scene:
     if name == "old_mine":
         return old_mine(bands or 8)
     raise KeyError(name)
+
+
+def material_lobes(scene: Scene, seed: int = 0x10BE, max_transmission: float = 0.3):
+    """Synthetic UAcousticMaterial::Transmission / Scattering arrays (MAT.h:26-30) for a scene's materials, [M][B]
+    float32 each: transmission uniform in [0, max_transmission], scattering uniform in [0.1, 0.9] (seeded).  The
+    generated scenes carry absorption only; these feed FS_FLAG_MATERIAL_LOBES in tests and bench."""
+    rng = np.random.default_rng(seed)
+    shape = np.asarray(scene.absorption).shape
+    transmission = rng.uniform(0.0, max_transmission, shape).astype(np.float32)
+    scattering = rng.uniform(0.1, 0.9, shape).astype(np.float32)
+    return transmission, scattering

@@ -62,6 +62,14 @@ enum {
                                              * path = its sampling density / the sum over all (i', j') of the same path length, with the
                                              * densities the walk uses (1/4pi at the end points, CosTheta/PI at surfaces, ARTS.cpp:306-318)
                                              * in area measure; uniform weight when a segment is degenerate */
+#define FS_FLAG_MATERIAL_LOBES 64u          /* row f4: a walk vertex reached by a hit picks ONE of three lobes from the material's
+                                             * Absorption / Transmission / Scattering arrays (MAT.h:22-30), split as ApplyMaterialFD does
+                                             * per bin (MaterialAcousticProcessor.cpp:51-72: Refl = 1 - alpha, tau clamped to Refl + tau
+                                             * <= 1, specular Refl (1 - sigma), diffuse Refl sigma, transmitted tau): diffuse = the
+                                             * reference's cone sample, specular = mirror direction, transmitted = straight on from the
+                                             * far side; EvaluatePath then uses that lobe's gain (diffuse / pi at a connection vertex)
+                                             * instead of Absorption / pi.  The reference's walk is diffuse only ("FIXME assuming
+                                             * diffuse", ARTS.cpp:304).  Not combinable with FS_FLAG_MIS_BALANCE. */
 #define FS_FLAG_DETERMINISTIC 8u            /* deposits are summed as 64-bit integers of 2^-40 energy quanta: the
                                              * histogram no longer depends on the order of the atomics, so it is bit-identical
                                              * from run to run and for every split of the pairs over GPUs (sum-reduce the u64

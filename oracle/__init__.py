@@ -24,6 +24,9 @@ FLAG_COSINE_SAMPLING = 4
 FLAG_BRUTE_FORCE = 8
 FLAG_ALL_CONNECTIONS = 16
 FLAG_MIS_BALANCE = 32
+FLAG_MATERIAL_LOBES = 64
+LOBE_DIFFUSE, LOBE_SPECULAR, LOBE_TRANSMIT = 0, 1, 2
+LOBE_SHIFT = 16
 
 
 class Params(C.Structure):
@@ -141,6 +144,10 @@ def _bind(lib):
     lib.fso_connect.restype = C.c_int32
     lib.fso_evaluate_path.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Node), C.c_int32,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.fso_scene_set_lobes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fso_scene_set_lobes.restype = None
+    lib.fso_scene_lobe_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.fso_scene_lobe_table.restype = None
     lib.fso_mis_weight.argtypes = [C.POINTER(Node), C.c_int32, C.c_int32, C.c_int32]
     lib.fso_mis_weight.restype = C.c_double
     lib.fso_add_energy_at_delay.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float]
@@ -204,7 +211,7 @@ def default_params(**kw) -> Params:
 class Scene:
     """Triangle soup + per-band material table (what RegisterGeometry + UAcousticMaterial provide)."""
 
-    def __init__(self, tri_xyz, mat_id, absorption, lib=None):
+    def __init__(self, tri_xyz, mat_id, absorption, lib=None, transmission=None, scattering=None):
         self.lib = lib or load()
         self.tri = np.ascontiguousarray(tri_xyz, dtype=np.float32).reshape(-1, 3, 3)
         self.mat = np.ascontiguousarray(mat_id, dtype=np.uint16).reshape(-1)
@@ -218,6 +225,27 @@ class Scene:
                                            self.absorption.ctypes.data, self.M, self.B)
         if not self.h:
             raise ValueError("fso_scene_create failed")
+        if transmission is not None or scattering is not None:
+            self.set_lobes(transmission, scattering)
+
+    def set_lobes(self, transmission=None, scattering=None):
+        """UAcousticMaterial::Transmission / Scattering, [M][B] each (None = 0 / 1): tables of FLAG_MATERIAL_LOBES."""
+        arrs = []
+        for a in (transmission, scattering):
+            if a is None:
+                arrs.append(None)
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float32).reshape(self.M, self.B)
+                arrs.append(a)
+        self._lobe_inputs = arrs        # keep alive during the call
+        self.lib.fso_scene_set_lobes(self.h, None if arrs[0] is None else arrs[0].ctypes.data,
+                                     None if arrs[1] is None else arrs[1].ctypes.data)
+
+    def lobe_table(self, m):
+        gains = np.zeros((3, self.B), np.float32)
+        prob = np.zeros(3, np.float32)
+        self.lib.fso_scene_lobe_table(self.h, m, gains.ctypes.data, prob.ctypes.data)
+        return gains, prob
 
     def __del__(self):
         try:
@@ -323,7 +351,7 @@ def mis_weight(nodes, s, depth, lib=None):
     return float(lib.fso_mis_weight(arr, len(nodes), s, depth))
 
 
-def make_node(pos, normal=(0.0, 0.0, 0.0), material=0xFFFFFFFF, prob=1.0):
+def make_node(pos, normal=(0.0, 0.0, 0.0), material=NO_MATERIAL, prob=1.0):
     nd = Node()
     nd.pos[:] = [float(x) for x in pos]
     nd.normal[:] = [float(x) for x in normal]

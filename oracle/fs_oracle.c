@@ -169,6 +169,8 @@ struct fso_scene {
     fso_tri* tris;       /* leaf order */
     fso_tri* tris_orig;  /* input order (brute force scans ids ascending) */
     float* absorption;   /* [M][B] */
+    float* lobe_gain;    /* [M][3][B] diffuse, specular, transmitted (FSO_FLAG_MATERIAL_LOBES) */
+    float* lobe_prob;    /* [M][3] probability of picking each lobe (band means of the gains, normalised) */
     fso_bnode* nodes;
     int32_t num_nodes;
     float pad;
@@ -281,6 +283,9 @@ fso_scene* fso_scene_create(const float* xyz, const uint16_t* mat_id, int32_t T,
     s->tris_orig = (fso_tri*)calloc((size_t)(T > 0 ? T : 1), sizeof(fso_tri));
     s->absorption = (float*)calloc((size_t)(M > 0 ? M * B : 1), sizeof(float));
     if (M > 0) memcpy(s->absorption, absorption, sizeof(float) * (size_t)M * (size_t)B);
+    s->lobe_gain = (float*)calloc((size_t)(M > 0 ? M * 3 * B : 1), sizeof(float));
+    s->lobe_prob = (float*)calloc((size_t)(M > 0 ? M * 3 : 1), sizeof(float));
+    fso_scene_set_lobes(s, NULL, NULL);
     float amax = 0.0f;
     for (int i = 0; i < T; ++i) {
         fso_tri* t = &s->tris[i];
@@ -314,9 +319,46 @@ fso_scene* fso_scene_create(const float* xyz, const uint16_t* mat_id, int32_t T,
     return s;
 }
 
+/* Lobe tables of FSO_FLAG_MATERIAL_LOBES.  The split is the per-bin rule of UMaterialAcousticProcessor::ApplyMaterialFD
+ * (MaterialAcousticProcessor.cpp:51-72) applied per band: Refl = 1 - alpha; tau clamped so that Refl + tau <= 1;
+ * specular Refl (1 - sigma), diffuse Refl sigma, transmitted tau.  The walk picks ONE lobe per surface vertex with
+ * probabilities proportional to the band means of the three gains (build-owned: the reference's walk is diffuse
+ * only, "FIXME assuming diffuse", ARTS.cpp:304).  Without Transmission / Scattering arrays: tau = 0, sigma = 1. */
+void fso_scene_set_lobes(fso_scene* s, const float* transmission, const float* scattering) {
+    const int B = s->B;
+    for (int m = 0; m < s->M; ++m) {
+        float sum[3] = {0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            float alpha = s->absorption[(size_t)m * B + b];
+            float tau = transmission ? transmission[(size_t)m * B + b] : 0.0f;
+            float sigma = scattering ? scattering[(size_t)m * B + b] : 1.0f;
+            float refl = 1.0f - alpha;
+            if (refl + tau > 1.0f) tau = 1.0f - refl;
+            float g[3];
+            g[FSO_LOBE_DIFFUSE] = refl * sigma;
+            g[FSO_LOBE_SPECULAR] = refl * (1.0f - sigma);
+            g[FSO_LOBE_TRANSMIT] = tau;
+            for (int l = 0; l < 3; ++l) {
+                if (!(g[l] > 0.0f)) g[l] = 0.0f;       /* also NaN; curves outside [0, 1] give no negative energy */
+                s->lobe_gain[((size_t)m * 3 + l) * B + b] = g[l];
+                sum[l] += g[l];
+            }
+        }
+        float mean[3], tot = 0.0f;
+        for (int l = 0; l < 3; ++l) { mean[l] = sum[l] / (float)B; tot += mean[l]; }
+        /* a material that reflects and transmits nothing keeps the diffuse lobe (gain 0): walk lengths stay a
+         * function of the random stream alone */
+        for (int l = 0; l < 3; ++l) s->lobe_prob[(size_t)m * 3 + l] = tot > 0.0f ? mean[l] / tot : (l == 0 ? 1.0f : 0.0f);
+    }
+}
+void fso_scene_lobe_table(const fso_scene* s, int32_t m, float* gains, float prob[3]) {
+    memcpy(gains, s->lobe_gain + (size_t)m * 3 * s->B, sizeof(float) * 3 * (size_t)s->B);
+    memcpy(prob, s->lobe_prob + (size_t)m * 3, sizeof(float) * 3);
+}
+
 void fso_scene_destroy(fso_scene* s) {
     if (!s) return;
-    free(s->tris); free(s->tris_orig); free(s->absorption); free(s->nodes); free(s);
+    free(s->tris); free(s->tris_orig); free(s->absorption); free(s->lobe_gain); free(s->lobe_prob); free(s->nodes); free(s);
 }
 int32_t fso_scene_num_nodes(const fso_scene* s) { return s->num_nodes; }
 
@@ -494,6 +536,14 @@ int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair
     int has_normal = 0;
     int brute = (p->flags & FSO_FLAG_BRUTE_FORCE) != 0;
     int cosine = (p->flags & FSO_FLAG_COSINE_SAMPLING) != 0;
+    /* FSO_FLAG_MATERIAL_LOBES (row f4, build-owned): a vertex reached by a hit on a material picks one lobe with
+     * the Philox word the diffuse walk leaves unused (r[3]); diffuse = the reference's cone sample, specular =
+     * mirror direction of the arriving ray, transmitted = the arriving direction continued from the far side of the
+     * surface (origin pos - 2 offset n).  The node keeps the lobe in material bits 16-17 for EvaluatePath; its
+     * probability multiplies the node probability. */
+    int lobes = (p->flags & FSO_FLAG_MATERIAL_LOBES) != 0;
+    float din[3] = {0.f, 0.f, 0.f};
+    int arrived = 0;
     int32_t n = 0;
     for (uint32_t k = 0;; ++k) {
         /* 0. push node ARTS.cpp:296-297 */
@@ -509,28 +559,62 @@ int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair
         fso_draw(p->seed, pair, side, k, 0, r);
         if (p->russian_roulette && !(fso_u01(r[0]) < p->rr_prob)) break; /* ARTS.cpp:349-353 */
         /* 2. direction + probability ARTS.cpp:304-319 */
-        float dir[3];
+        float dir[3], org[3];
+        int shifted = 0;
         if (!has_normal) {                               /* CurrentNormal.IsNearlyZero() */
             fso_sample_sphere(p->seed, pair, side, k, r, dir);
             float pdf = 1.0f / (4.0f * FSO_PI);
             prob = pdf * p->rr_prob;
         } else {
-            fso_sample_cone(nrm, fso_u01(r[1]), fso_u01(r[2]), cosine, dir);
-            float cos_theta = dir[0] * nrm[0] + dir[1] * nrm[1] + dir[2] * nrm[2];
-            float pdf = cos_theta / FSO_PI;
-            prob = pdf * p->rr_prob;
+            uint32_t lobe = FSO_LOBE_DIFFUSE;
+            float plobe = 1.0f;
+            int pick = lobes && arrived && mat != FSO_NO_MATERIAL && (int32_t)mat < s->M;
+            if (pick) {
+                const float* pr = s->lobe_prob + 3 * (size_t)mat;
+                float u = fso_u01(r[3]);
+                float c1 = pr[0], c2 = pr[0] + pr[1];
+                lobe = u < c1 ? FSO_LOBE_DIFFUSE : (u < c2 ? FSO_LOBE_SPECULAR : FSO_LOBE_TRANSMIT);
+                if (lobe == FSO_LOBE_TRANSMIT && !(pr[2] > 0.0f)) lobe = pr[1] > 0.0f ? FSO_LOBE_SPECULAR : FSO_LOBE_DIFFUSE;
+                plobe = pr[lobe];
+                nd->material = mat | (lobe << FSO_LOBE_SHIFT);
+            }
+            if (lobe == FSO_LOBE_DIFFUSE) {
+                fso_sample_cone(nrm, fso_u01(r[1]), fso_u01(r[2]), cosine, dir);
+                float cos_theta = dir[0] * nrm[0] + dir[1] * nrm[1] + dir[2] * nrm[2];
+                float pdf = cos_theta / FSO_PI;
+                prob = pdf * p->rr_prob;
+            } else if (lobe == FSO_LOBE_SPECULAR) {
+                float dn = din[0] * nrm[0] + din[1] * nrm[1] + din[2] * nrm[2];
+                float k2 = 2.0f * dn;
+                for (int q = 0; q < 3; ++q) dir[q] = fmaf(-k2, nrm[q], din[q]);
+                prob = p->rr_prob;
+            } else {
+                for (int q = 0; q < 3; ++q) dir[q] = din[q];
+                prob = p->rr_prob;
+            }
+            if (pick) prob = prob * plobe;
+            if (lobe == FSO_LOBE_TRANSMIT) {
+                float back = -2.0f * p->surface_offset;
+                for (int q = 0; q < 3; ++q) org[q] = fmaf(back, nrm[q], pos[q]);
+                shifted = 1;
+            }
         }
         /* 3. closest hit on [pos, pos + dir * MAX_RAYCAST_DIST] ARTS.cpp:339-342 */
         float t, hn[3]; int32_t tri;
-        if (fso_trace_closest(s, pos, dir, p->max_trace_dist, brute, &t, &tri, hn, c)) {
+        if (!shifted) memcpy(org, pos, sizeof(org));
+        if (fso_trace_closest(s, org, dir, p->max_trace_dist, brute, &t, &tri, hn, c)) {
             /* 4. ARTS.cpp:345-347 */
             for (int q = 0; q < 3; ++q) {
-                float ip = fmaf(t, dir[q], pos[q]);
+                float ip = fmaf(t, dir[q], org[q]);
                 pos[q] = fmaf(p->surface_offset, hn[q], ip);
                 nrm[q] = hn[q];
+                din[q] = dir[q];
             }
             has_normal = 1;
+            arrived = 1;
             mat = s->tris_orig[tri].material;
+        } else {
+            arrived = 0;
         }
         /* on miss the state is unchanged and the loop continues (duplicate node, new prob) */
     }
@@ -575,10 +659,19 @@ void fso_evaluate_path(const fso_scene* s, const fso_params* p, const fso_node* 
         float nd2 = nd * nd;
         float geo = 1.0f / (4 * FSO_PI * nd2);                /* ARTS.cpp:391 */
         float pw = powf(a->prob, p->prob_exponent);           /* ARTS.cpp:398 */
+        const int lobes = (p->flags & FSO_FLAG_MATERIAL_LOBES) != 0;
+        const uint32_t mid = lobes && a->material != FSO_NO_MATERIAL ? (a->material & 0xFFFFu) : a->material;
+        const uint32_t lobe = lobes && a->material != FSO_NO_MATERIAL ? ((a->material >> FSO_LOBE_SHIFT) & 3u) : 0u;
         for (int b = 0; b < B; ++b) {
             float bsdf = 1.0f;                                /* ARTS.cpp:382-386 */
-            if (a->material != FSO_NO_MATERIAL && (int32_t)a->material < s->M)
-                bsdf = s->absorption[(size_t)a->material * (size_t)B + (size_t)b] / FSO_PI;
+            if (mid != FSO_NO_MATERIAL && (int32_t)mid < s->M) {
+                if (!lobes) {
+                    bsdf = s->absorption[(size_t)mid * (size_t)B + (size_t)b] / FSO_PI;
+                } else {   /* row f4: gain of the lobe the walk took at this vertex (diffuse at a connection vertex) */
+                    float g = s->lobe_gain[((size_t)mid * 3 + lobe) * (size_t)B + (size_t)b];
+                    bsdf = lobe == FSO_LOBE_DIFFUSE ? g / FSO_PI : g;
+                }
+            }
             float e = E[b];
             e *= bsdf;                                        /* ARTS.cpp:392 */
             e *= geo;                                         /* ARTS.cpp:393 */
@@ -709,6 +802,9 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
                     if (c) c->connected++;
                     memcpy(all, fwd, sizeof(fso_node) * (size_t)(fi + 1));
                     for (int32_t j = 0; j <= bj; ++j) all[fi + 1 + j] = bwd[bj - j];
+                    /* the two connection vertices scatter diffusely whatever lobe the walk took there later */
+                    if (all[fi].material != FSO_NO_MATERIAL) all[fi].material &= 0xFFFFu;
+                    if (all[fi + 1].material != FSO_NO_MATERIAL) all[fi + 1].material &= 0xFFFFu;
                     float gains[FSO_MAX_BANDS], delay;
                     fso_evaluate_path(s, p, all, fi + bj + 2, gains, &delay);
                     int32_t t = fi + bj;

@@ -34,6 +34,10 @@ CASES = [
     # row f3 with balance-heuristic weights (FS_FLAG_MIS_BALANCE == FSO_FLAG_MIS_BALANCE == 32)
     ("cfg1_shoebox_mis_balance", "shoebox", 1, 512, 4, 0x5EED, {"flags": 32}),
     ("cfg2_starter_room_mis_balance", "starter_room", 4, 2048, 8, 9, {"flags": 32}),
+    # row f4: lobes in the walk (FS_FLAG_MATERIAL_LOBES == FSO_FLAG_MATERIAL_LOBES == 64), Transmission / Scattering
+    # arrays from scenes.material_lobes(scene) ("lobes": 1 is a fixture key, not a parameter)
+    ("cfg1_shoebox_material_lobes", "shoebox", 1, 512, 6, 0x5EED, {"flags": 64, "lobes": 1}),
+    ("cfg2_starter_room_material_lobes", "starter_room", 4, 2048, 8, 9, {"flags": 64, "lobes": 1}),
 ]
 
 
@@ -44,8 +48,9 @@ def main():
         if only and name not in only:
             continue
         sc = pkg.scenes.by_name(scene, bands)
-        osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption)
-        p = oracle.default_params(num_pairs=pairs, depth=depth, seed=seed, **extra)
+        tau, sigma = pkg.scenes.material_lobes(sc) if extra.get("lobes") else (None, None)
+        osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
+        p = oracle.default_params(num_pairs=pairs, depth=depth, seed=seed, **{k: v for k, v in extra.items() if k != "lobes"})
         e32, e64, cnt = osc.compute_energy_mt(p, sc.source, sc.listener, threads=8) if pairs > 20000 else \
             osc.compute_energy(p, sc.source, sc.listener)
         if pairs > 20000:  # the literal sequential-f32 histogram needs the single-threaded order

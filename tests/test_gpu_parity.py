@@ -656,6 +656,73 @@ def test_mis_balance_full_size(pkg, oracle_mod, scene_factory):
     assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
 
 
+# ---- row f4: specular / diffuse / transmitted lobes in the walk -------------------------------------------------------
+LOBE_CASES = [
+    # id, scene, bands, rays, depth, lobe arrays ("seeded" / "default" / (tau, sigma) constants), extra params
+    ("cfg1_half_specular", "shoebox", 1, 2048, 6, (0.1, 0.5), {}),
+    ("cfg2_seeded", "starter_room", 4, 8192, 8, "seeded", {}),
+    ("cfg2_no_arrays", "starter_room", 4, 4096, 8, "default", {}),
+    ("mine_no_rr", "old_mine", 8, 4096, 5, "seeded", {"russian_roulette": 0, "dist_divisor": 200.0}),
+    ("mirror_room", "shoebox", 2, 2048, 8, (0.0, 0.0), {"dist_divisor": 100.0}),
+    ("glass_room", "starter_room", 4, 4096, 8, (1.0, 0.5), {}),
+    ("all_connections", "starter_room", 4, 2048, 6, "seeded", {"flags": 16}),
+    ("cosine_unbounded", "shoebox", 1, 600, 0, (0.2, 0.7), {"flags": 4}),
+    ("deterministic", "starter_room", 4, 4096, 8, "seeded", {"flags": 8}),
+]
+
+
+def lobe_arrays(pkg, sc, spec):
+    if spec == "default":
+        return None, None
+    if spec == "seeded":
+        return pkg.scenes.material_lobes(sc)
+    tau, sigma = spec
+    return np.full_like(sc.absorption, tau), np.full_like(sc.absorption, sigma)
+
+
+@pytest.mark.parametrize("cid,name,bands,rays,depth,spec,extra", LOBE_CASES, ids=[c[0] for c in LOBE_CASES])
+def test_material_lobes_parity(pkg, oracle_mod, scene_factory, cid, name, bands, rays, depth, spec, extra):
+    """FS_FLAG_MATERIAL_LOBES against the oracle: identical path set (occupied bins, segment / connection / deposit
+    counters) and energies within the usual tolerance, for mixed, purely specular, strongly transmitting and absent
+    Transmission / Scattering arrays, alone and combined with the other modes."""
+    sc = scene_factory(name, bands)
+    tau, sigma = lobe_arrays(pkg, sc, spec)
+    ctx = pkg.Context(num_bands=bands)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
+    ctx.set_listener(sc.listener)
+    src = ctx.create_source(sc.source)
+    extra = dict(extra)
+    gflags = extra.pop("flags", 0) | pkg._capi.FLAG_MATERIAL_LOBES
+    oflags = (gflags & ~pkg._capi.FLAG_DETERMINISTIC)              # the oracle's 8 is its brute-force switch
+    e_gpu = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=0x5EED, flags=gflags, **extra))
+    st = ctx.stats()
+    e_off = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=0x5EED,
+                                                                flags=gflags & ~pkg._capi.FLAG_MATERIAL_LOBES, **extra))
+    ctx.close()
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
+    op = oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=0x5EED, flags=oflags, **extra)
+    e32, e64, cnt = osc.compute_energy(op, sc.source, sc.listener)
+    assert cnt.connected > 0
+    if gflags & pkg._capi.FLAG_DETERMINISTIC:
+        for b in range(bands):
+            assert rel_rms(e_gpu[b], e64[b]) <= TIGHT_TOL
+        assert np.abs(e_gpu - e64).max() <= 1e-9 + TIGHT_TOL * np.abs(e64).max()
+    else:
+        check_energy(e_gpu, e32, e64, bands)
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+    assert not np.array_equal(e_gpu, e_off)                         # the mode does change the result
+
+
+def test_material_lobes_rejects_mis(pkg, scene_factory):
+    sc = scene_factory("shoebox", 1)
+    ctx, src = make_ctx(pkg, sc)
+    with pytest.raises(pkg.FrequenSeeError) as ei:
+        ctx.compute_energy_response(src, pkg.default_params(num_rays=64, depth=4, flags=pkg._capi.FLAG_MATERIAL_LOBES |
+                                                            pkg._capi.FLAG_MIS_BALANCE))
+    assert ei.value.code == pkg._capi.ERR_INVALID_ARGUMENT
+    ctx.close()
+
+
 def test_physical_sanity_direct_sound(pkg, scene_factory):
     """Not a parity gate ("statistical tests"): nothing can arrive before the direct sound,
     and in all-connections mode the (i = 0, j = 0) strategy deposits exactly the direct path of every pair into
@@ -860,6 +927,9 @@ def test_gpu_matches_golden(pkg, scene_factory, path):
     bands = int(z["bands"])
     sc = scene_factory(str(z["scene"]), bands)
     ctx, src = make_ctx(pkg, sc)
+    if extra.pop("lobes", 0):      # fixture key: seeded Transmission / Scattering arrays on the scene (row f4)
+        tau, sigma = pkg.scenes.material_lobes(sc)
+        ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
     p = pkg.default_params(num_rays=2 * int(z["pairs"]), depth=int(z["depth"]), seed=int(z["seed"]), **extra)
     e = ctx.compute_energy_response(src, p)
     assert np.array_equal(e != 0, z["energy_f32"] != 0)

@@ -460,3 +460,94 @@ def test_mis_frame_properties(oracle_mod, scene_factory):
     d = float(np.linalg.norm(sc.listener.astype(np.float64) - sc.source.astype(np.float64))) / 1000.0
     direct_bin = int(np.floor(d / 343.0 * 1000.0))
     assert np.flatnonzero(em[0]).min() == direct_bin
+
+
+# ---- row f4: specular / diffuse / transmitted lobes in the walk ---------------------------------------------------
+def _two_floors(z0=0.0, z1=300.0, half=1e5):
+    """two huge horizontal quads (4 triangles): z = z0 (material 0) and z = z1 (material 1)"""
+    def quad(z):
+        a, b, c, d = (-half, -half, z), (half, -half, z), (half, half, z), (-half, half, z)
+        return [[a, b, c], [a, c, d]]
+    tri = np.array(quad(z0) + quad(z1), np.float32)
+    return tri, np.array([0, 0, 1, 1], np.uint16)
+
+
+def test_kat_lobe_table_by_hand(oracle_mod):
+    """MaterialAcousticProcessor.cpp:51-72 per band: alpha = 0.4 -> Refl = 0.6; tau = 0.5 is clamped to 0.4 (Refl + tau
+    <= 1); sigma = 0.25 -> specular 0.45, diffuse 0.15, transmitted 0.4; the gains sum to 1, so they are the
+    selection probabilities too.  Second band alpha = 1: nothing reflected, tau = 0.2 kept."""
+    tri, mat = _two_floors()
+    s = oracle_mod.Scene(tri, mat, np.array([[0.4, 1.0], [0.3, 0.3]], np.float32),
+                         transmission=np.array([[0.5, 0.2], [0.0, 0.0]], np.float32),
+                         scattering=np.array([[0.25, 0.5], [1.0, 1.0]], np.float32))
+    g, p = s.lobe_table(0)
+    assert np.allclose(g[:, 0], [0.15, 0.45, 0.4], rtol=1e-6) and np.allclose(g[:, 1], [0.0, 0.0, 0.2], atol=1e-7)
+    mean = g.mean(axis=1)
+    assert np.allclose(p, mean / mean.sum(), rtol=1e-6)
+    g1, p1 = s.lobe_table(1)                    # sigma = 1, tau = 0: the reference's purely diffuse walk
+    assert np.allclose(g1[0], 0.7, rtol=1e-6) and not g1[1:].any() and np.array_equal(p1, [1.0, 0.0, 0.0])
+    # without arrays: tau = 0, sigma = 1 for every material
+    s0 = oracle_mod.Scene(tri, mat, np.array([[0.4, 1.0], [0.3, 0.3]], np.float32))
+    g0, p0 = s0.lobe_table(0)
+    assert np.allclose(g0[0], [0.6, 0.0], atol=1e-7) and not g0[1:].any() and np.array_equal(p0, [1.0, 0.0, 0.0])
+
+
+def test_kat_specular_and_transmitted_directions(oracle_mod):
+    """Mirror floor (sigma = 0, tau = 0): the walk leaves the floor in the mirror direction, so source -> floor ->
+    ceiling keeps its horizontal velocity.  Fully transmitting floor (alpha = 1, tau = 1): it goes straight on to
+    the plane below.  The lobe sits in material bits 16-17 of the vertex, its probability (1 here) times the
+    roulette probability is the next node's probability."""
+    src = (0.0, 0.0, 100.0)
+    L = oracle_mod.FLAG_MATERIAL_LOBES
+    tri, mat = _two_floors(0.0, 300.0)
+    mirror = oracle_mod.Scene(tri, mat, np.array([[0.2], [0.2]], np.float32),
+                              transmission=np.zeros((2, 1), np.float32), scattering=np.zeros((2, 1), np.float32))
+    p = oracle_mod.default_params(num_pairs=64, depth=2, russian_roulette=0, flags=L)
+    seen = 0
+    for pair in range(64):
+        nodes = mirror.generate_path(p, pair, 0, src)
+        if len(nodes) < 3 or nodes[1].pos[2] > 1.0:          # first segment went up: the ceiling is a mirror too
+            continue
+        seen += 1
+        n0, n1, n2 = (np.array(n.pos[:], np.float64) for n in nodes[:3])
+        assert nodes[1].material == (0 | (oracle_mod.LOBE_SPECULAR << oracle_mod.LOBE_SHIFT))
+        assert nodes[2].material == 1 and abs(n2[2] - 299.9) < 1e-3
+        assert nodes[2].prob == pytest.approx(0.9)             # roulette probability x lobe probability 1
+        slope_in = (n1[:2] - n0[:2]) / (n0[2] - 0.0)           # horizontal travel per unit of height, down
+        slope_out = (n2[:2] - n1[:2]) / (300.0 - 0.0)          # and up again after the mirror
+        assert np.allclose(slope_in, slope_out, rtol=2e-3, atol=2e-3)
+    assert seen > 10
+    tri, mat = _two_floors(0.0, -200.0)
+    glass = oracle_mod.Scene(tri, mat, np.array([[1.0], [0.5]], np.float32),
+                             transmission=np.ones((2, 1), np.float32), scattering=np.full((2, 1), 0.5, np.float32))
+    seen = 0
+    for pair in range(64):
+        nodes = glass.generate_path(p, pair, 0, src)
+        if len(nodes) < 3 or nodes[1].pos[2] > 1.0 or nodes[1].pos[2] < -1.0:
+            continue
+        seen += 1
+        n0, n1, n2 = (np.array(n.pos[:], np.float64) for n in nodes[:3])
+        assert nodes[1].material == (0 | (oracle_mod.LOBE_TRANSMIT << oracle_mod.LOBE_SHIFT))
+        assert abs(n2[2] - (-199.9)) < 1e-3                    # stopped above the lower plane, coming from above
+        assert np.allclose((n1[:2] - n0[:2]) / 100.0, (n2[:2] - n1[:2]) / 200.0, rtol=2e-3, atol=2e-3)
+    assert seen > 10
+
+
+def test_kat_lobe_gain_in_evaluate_path(oracle_mod):
+    """EvaluatePath with the flag: the vertex factor is the gain of its lobe — diffuse over pi, specular and
+    transmitted as they are — instead of Absorption / pi (ARTS.cpp:382-386)."""
+    tri, mat = _two_floors()
+    s = oracle_mod.Scene(tri, mat, np.array([[0.4], [0.3]], np.float32),
+                         transmission=np.array([[0.5], [0.0]], np.float32), scattering=np.array([[0.25], [1.0]], np.float32))
+    mk = oracle_mod.make_node
+    p_on = oracle_mod.default_params(num_pairs=1, flags=oracle_mod.FLAG_MATERIAL_LOBES, energy_clamp=1e30)
+    p_off = oracle_mod.default_params(num_pairs=1, energy_clamp=1e30)
+
+    def gain(lobe, params):
+        nodes = [mk((0, 0, 0)), mk((2000, 0, 0), (0, 0, 1), material=0 | (lobe << 16), prob=0.5), mk((2000, 3000, 0))]
+        return float(s.evaluate_path(params, nodes)[0][0])
+
+    base = gain(0, p_off) / (0.4 / math.pi)                   # everything but the vertex factor
+    assert gain(0, p_on) == pytest.approx(base * 0.15 / math.pi, rel=1e-5)
+    assert gain(1, p_on) == pytest.approx(base * 0.45, rel=1e-5)
+    assert gain(2, p_on) == pytest.approx(base * 0.4, rel=1e-5)
