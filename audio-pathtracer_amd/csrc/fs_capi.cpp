@@ -309,7 +309,9 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positio
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_mat, sizeof(uint32_t) * seg));
         if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
         ctx->walk.perm = nullptr;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * (seg + lanes)));   // [depth + 1][lanes]
+        // [depth + 1][lanes] for every later frame shape that fits the two capacities without a reallocation:
+        // depth' * lanes' <= cap_seg and lanes' <= cap_lanes  =>  (depth' + 1) * lanes' <= seg + cap_lanes
+        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * (seg + ctx->cap_lanes)));
         ctx->cap_seg = seg;
     }
     return FS_OK;

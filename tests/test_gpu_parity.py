@@ -323,6 +323,24 @@ def test_two_sources_one_context(pkg, oracle_mod, scene_factory):
     ctx.close()
 
 
+def test_frame_shapes_reuse_the_subpath_state(pkg, oracle_mod, scene_factory):
+    """One context, frames of changing shape (rays x depth): the subpath state and the length-plan buckets are sized
+    by two capacities (subpaths, subpaths x depth) and reused; every shape that fits them must still be exact —
+    in particular many shallow walks after few deep ones (the plan needs (depth + 1) x subpaths slots)."""
+    sc = scene_factory("starter_room", 2)
+    ctx, src = make_ctx(pkg, sc)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    for rays, depth in ((4000, 1), (400, 20), (4000, 2), (128, 31), (3968, 2), (4000, 1), (2, 64), (4000, 3)):
+        e = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=rays + depth, rr_prob=0.97))
+        e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=rays + depth,
+                                                                    rr_prob=0.97), sc.source, sc.listener)
+        if cnt.connected:
+            check_energy(e, e32, e64, 2)
+        else:
+            assert not e.any()
+    ctx.close()
+
+
 def test_empty_scene_and_zero_rays(pkg, scene_factory):
     ctx = pkg.Context(num_bands=2)
     with pytest.raises(pkg.FrequenSeeError) as ei:          # not committed
