@@ -720,6 +720,70 @@ __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray
     }
 }
 
+// The same scheme for any-hit (visibility) queries: most connection rays are blocked and end at their first hit,
+// the unobstructed ones must search every box along the segment, so a wave waits for a few long traversals
+// while most of its lanes idle.  Idle lanes take the oldest pending subtree of a busy lane; any hit anywhere
+// settles the ray (flag in the owner's mailbox), and lanes still searching for a settled ray drop their work.
+//   LDS behind `share`: ray store [7][kBlock] (origin, direction, tmax) | blocked flag [kBlock] | donation
+//   boxes ref, owner [kBlock] each — 40 B per lane, so two workgroups still fit a CU next to the histogram.
+// Every lane of the wave must call it (has_ray = false: nothing of its own to search, helps from the start).
+constexpr size_t kShareAnyLdsBytes = (size_t)kBlock * (7 * 4 + 4 + 2 * 4);
+
+__device__ __forceinline__ bool trav_any_shared(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
+                                                int* stack, int* share) {
+    float* rs = reinterpret_cast<float*>(share);
+    int* blocked = share + 7 * kBlock;
+    int* dref = blocked + kBlock;
+    int* down = dref + kBlock;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    rs[0 * kBlock + tid] = own.ox;  rs[1 * kBlock + tid] = own.oy;  rs[2 * kBlock + tid] = own.oz;
+    rs[3 * kBlock + tid] = own.dx;  rs[4 * kBlock + tid] = own.dy;  rs[5 * kBlock + tid] = own.dz;
+    rs[6 * kBlock + tid] = tmax;
+    blocked[tid] = 0;
+    unsigned owner = tid;
+    Ray wr = own;
+    Trav T;
+    trav_init(T, tmax, has_ray && sc.num_nodes > 0);
+    while (true) {
+        if (trav_busy(T)) {
+            trav_step<true>(sc, wr, T, stack);
+            if (T.leaf_index >= 0) { blocked[owner] = 1; T.leaf_index = -1; }   // first hit ends the query (T is idle now)
+            else if (blocked[owner]) { T.cur = kDone; T.sp = 0; T.sb = 0; T.tri_n = T.tri_i; }   // settled by another lane
+        }
+        const bool idle = !trav_busy(T);
+        const unsigned long long busy_m = __ballot(!idle);
+        if (busy_m == 0ull) break;
+        const unsigned long long idle_m = __ballot(idle);
+        const bool can_give = !idle && T.sp > T.sb;
+        const unsigned long long give_m = __ballot(can_give);
+        if (idle_m != 0ull && give_m != 0ull) {
+            const int n = min(__popcll(idle_m), __popcll(give_m));
+            if (can_give) {
+                const int r = __popcll(give_m & lt);
+                if (r < n) {
+                    dref[wbase + r] = stack[T.sb * kBlock];
+                    down[wbase + r] = (int)owner;
+                    ++T.sb;
+                    if (T.sb == T.sp) { T.sb = 0; T.sp = 0; }
+                }
+            }
+            if (idle) {
+                const int r = __popcll(idle_m & lt);
+                if (r < n) {
+                    const int e = dref[wbase + r];
+                    owner = (unsigned)down[wbase + r];
+                    wr = make_ray(rs[0 * kBlock + owner], rs[1 * kBlock + owner], rs[2 * kBlock + owner],
+                                  rs[3 * kBlock + owner], rs[4 * kBlock + owner], rs[5 * kBlock + owner]);
+                    T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
+                    T.t = rs[6 * kBlock + owner]; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
+                }
+            }
+        }
+    }
+    return blocked[tid] != 0;
+}
+
 template <int LOBES>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
@@ -856,6 +920,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
+    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * kp.num_bins);   // work-sharing area of trav_any_shared
     __shared__ int s_lo, s_hi;
     __shared__ unsigned s_dep;
     const int nb = kp.num_bins;
@@ -869,28 +934,26 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     const uint32_t n = kp.num_local;
     const uint32_t total = 2u * n;
     unsigned my_deposits = 0;
-    for (uint32_t li = blockIdx.x * kBlock + threadIdx.x; li < n; li += gridDim.x * kBlock) {
-        const float4 F = st.end_pos[li];
-        const uint2 Fm = st.end_misc[li];
-        const float4 L = st.end_pos[n + li];
-        const uint2 Lm = st.end_misc[n + li];
+    // whole workgroups step through the pairs: every lane of a wave takes part in the shared visibility queries,
+    // also the ones without a pair or without a segment to test
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t li = base + threadIdx.x;
+        const bool active = li < n;
+        const uint32_t lc = active ? li : 0u;
+        const float4 F = st.end_pos[lc];
+        const uint2 Fm = st.end_misc[lc];
+        const float4 L = st.end_pos[n + lc];
+        const uint2 Lm = st.end_misc[n + lc];
         // visibility F_k -> B_m - 0.1 * unit(B_m - F_k) (ARTS.cpp:252-254); visible iff NO hit
         float dx = L.x - F.x, dy = L.y - F.y, dz = L.z - F.z;
         float l2 = dx * dx + dy * dy + dz * dz;
-        bool visible = true;
-        if (l2 > 1e-8f) {
-            float len = sqrtf(l2);
-            float inv = 1.0f / len;
-            float tmax = len - kp.connect_pullback;
-            if (tmax > 0.0f) {
-                Ray ray = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
-                Trav T;
-                trav_init(T, tmax, sc.num_nodes > 0);
-                trav_run<true>(sc, ray, T, &s_stack[threadIdx.x]);
-                visible = T.leaf_index < 0;
-            }
-        }
-        if (!visible) continue;
+        float len = sqrtf(l2);
+        float inv = 1.0f / len;
+        float tmax = len - kp.connect_pullback;
+        const bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
+        Ray ray = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
+        const bool hit = trav_any_shared(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share);
+        if (!active || hit) continue;
         ++my_deposits;
         // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
         float E[B];
@@ -1030,6 +1093,7 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
+    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * kp.num_bins);   // work-sharing area of trav_any_shared
     __shared__ int s_lo, s_hi;
     const int nb = kp.num_bins;
     for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
@@ -1048,8 +1112,10 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
         const uint2 Lm = st.end_misc[n + li];
         const int kf = (int)Fm.y, kl = (int)Lm.y;
         const int combos = (kf + 1) * (kl + 1);
-        for (int c = lane; c < combos; c += 64) {
-            ++my_tests;
+        for (int c0 = 0; c0 < combos; c0 += 64) {   // wave-uniform trip count: all lanes share the visibility queries
+            const bool active = c0 + lane < combos;
+            const int c = active ? c0 + lane : 0;
+            if (active) ++my_tests;
             const int i = c / (kl + 1), j = c - i * (kl + 1);
             // node Fi (position, material, probability) and node Bj (position)
             float fx = kp.src[0], fy = kp.src[1], fz = kp.src[2];
@@ -1062,20 +1128,13 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             fmat &= 0xFFFFu;   // a connection vertex scatters diffusely whatever lobe the walk took there later (row f4)
             float dx = bx - fx, dy = by - fy, dz = bz - fz;
             float l2 = dx * dx + dy * dy + dz * dz;
-            bool visible = true;
-            if (l2 > 1e-8f) {
-                float len = sqrtf(l2);
-                float inv = 1.0f / len;
-                float tmax = len - kp.connect_pullback;
-                if (tmax > 0.0f) {
-                    Ray ray = make_ray(fx, fy, fz, dx * inv, dy * inv, dz * inv);
-                    Trav T;
-                    trav_init(T, tmax, sc.num_nodes > 0);
-                    trav_run<true>(sc, ray, T, &s_stack[threadIdx.x]);
-                    visible = T.leaf_index < 0;
-                }
-            }
-            if (!visible) continue;
+            float len = sqrtf(l2);
+            float inv = 1.0f / len;
+            float tmax = len - kp.connect_pullback;
+            const bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
+            Ray ray = make_ray(fx, fy, fz, dx * inv, dy * inv, dz * inv);
+            const bool hit = trav_any_shared(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share);
+            if (!active || hit) continue;
             ++my_deposits;
             float E[B];
 #pragma unroll
@@ -1521,7 +1580,7 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
     if (kp.num_local == 0) return;
     uint32_t blocks = (kp.num_local + kBlock - 1) / kBlock;
     if (blocks > 1024) blocks = 1024;
-    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins;
+    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins + kShareAnyLdsBytes;
     if (kp.lobes) {
         allow_lds(connect_kernel<B, 1>, lds);
         hipLaunchKernelGGL((connect_kernel<B, 1>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
@@ -1586,7 +1645,7 @@ void launch_connect_all_t(const DeviceScene& sc, const KParams& kp, const Subpat
     if (kp.num_local == 0) return;
     uint32_t blocks = (kp.num_local + 3) / 4;   // one wave per pair, 4 waves per workgroup
     if (blocks > 4096) blocks = 4096;
-    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins;
+    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins + kShareAnyLdsBytes;
     allow_lds(connect_all_kernel<B>, lds);
     hipLaunchKernelGGL(connect_all_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
 }
