@@ -115,6 +115,7 @@ struct fs_context {
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
     WalkLaunch walk{2, 256, 2, nullptr, 1, nullptr};   // variant 2 = wave work sharing (default), 0 = one subpath per lane, 1 = persistent
     int refill_threshold = 16;
+    int sound_rays_per_wave = 4;   // legacy tracer: rays per wave, the other lanes help (FS_SOUND_RAYS_PER_WAVE; 64 = no sharing)
 
     // measurement
     int profiling = 0;   // 0 off, 1 = HIP events around the dominant (walk) kernel only, 2 = every kernel
@@ -427,6 +428,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
     if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
     e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchAllocWords);
     if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchAllocWords);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
@@ -1073,7 +1075,7 @@ int fs_update_sound(fs_context* ctx, fs_source h, const fs_sound_params* p, fs_s
     std::memcpy(sp.src, s->pos, sizeof(sp.src));
     std::memcpy(sp.lis, ctx->listener, sizeof(sp.lis));
     FS_HIP(ctx, hipMemsetAsync(ctx->d_sound, 0, sizeof(SoundAccum), ctx->stream));
-    launch_update_sound(ctx->scene, sp, ctx->d_sound, ctx->stream);
+    launch_update_sound(ctx->scene, sp, ctx->d_sound, ctx->sound_rays_per_wave, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     SoundAccum acc{};
     FS_HIP(ctx, hipMemcpyAsync(&acc, ctx->d_sound, sizeof(acc), hipMemcpyDeviceToHost, ctx->stream));

@@ -148,7 +148,8 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
                         float* ir_bands, float* ir_mono, hipStream_t s);
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
                        int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s);
-void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, hipStream_t s);
+// rays_per_wave < 64: sparse waves whose other lanes help with every closest-hit query; 64 = one ray per lane
+void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, int rays_per_wave, hipStream_t s);
 constexpr int kReverbRing = 65536;   // per-channel history ring (floats), matches kRevRing in the kernels
 void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
                    int frame, int literal_tail, hipStream_t s);

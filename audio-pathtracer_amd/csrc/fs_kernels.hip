@@ -1380,6 +1380,271 @@ __device__ __forceinline__ float cast_direct(const DeviceScene& sc, const SoundK
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The legacy tracer on sparse waves.  UpdateSound is 1501 rays, each a CHAIN of up to ~20 dependent closest-hit
+// queries: on one lane per ray that is 24 waves on a 1024-SIMD chip and the call takes the latency of the longest
+// chain (0.9 ms at 100 000 triangles).  update_sound_shared_kernel gives every wave only `rays_per_wave` rays and
+// lets the other lanes help: every query of the wave is searched by all 64 lanes (the wave work sharing of
+// trav_run_shared, here with the per-ray ignored actor), so a query takes about as many steps as its deepest
+// root-to-leaf descent instead of its total node count.  Each lane runs CastAudioRay / CastDirectAudioRay as a
+// small state machine (main trace | direct trace | done) so that the whole wave meets at every query; the
+// arithmetic and therefore every result is that of update_sound_kernel.
+//   LDS behind the stack rows: ray store [12][kBlock] | ignored actor [kBlock] | result key [kBlock] u64 |
+//   result leaf [kBlock] | donation boxes ref, owner, bound [kBlock] each.
+// ---------------------------------------------------------------------------------------------------
+constexpr size_t kShareIgnLdsBytes = (size_t)kBlock * (12 * 4 + 4 + 8 + 4 + 3 * 4);
+
+__device__ __forceinline__ void trav_closest_shared_ign(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
+                                                        uint32_t ignore, Trav& T, int* stack, int* share) {
+    float* rs = reinterpret_cast<float*>(share);
+    uint32_t* rign = reinterpret_cast<uint32_t*>(rs + 12 * kBlock);
+    unsigned long long* rkey = reinterpret_cast<unsigned long long*>(rign + kBlock);
+    int* rleaf = reinterpret_cast<int*>(rkey + kBlock);
+    int* dref = rleaf + kBlock;
+    int* down = dref + kBlock;
+    float* dbound = reinterpret_cast<float*>(down + kBlock);
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    rs[0 * kBlock + tid] = own.ox;  rs[1 * kBlock + tid] = own.oy;  rs[2 * kBlock + tid] = own.oz;
+    rs[3 * kBlock + tid] = own.dx;  rs[4 * kBlock + tid] = own.dy;  rs[5 * kBlock + tid] = own.dz;
+    rs[6 * kBlock + tid] = own.ix;  rs[7 * kBlock + tid] = own.iy;  rs[8 * kBlock + tid] = own.iz;
+    rs[9 * kBlock + tid] = own.nox; rs[10 * kBlock + tid] = own.noy; rs[11 * kBlock + tid] = own.noz;
+    rign[tid] = ignore;
+    rkey[tid] = ~0ull;
+    rleaf[tid] = -1;
+    unsigned owner = tid;
+    uint32_t wign = ignore;
+    Ray wr = own;
+    trav_init(T, tmax, has_ray && sc.num_nodes > 0);
+    while (true) {
+        if (trav_busy(T)) {
+            trav_step<false, true>(sc, wr, T, stack, wign);
+            if (!trav_busy(T) && T.leaf_index >= 0) {
+                const unsigned long long key = ((unsigned long long)__float_as_uint(T.t) << 32) | (unsigned long long)T.id;
+                atomicMin(&rkey[owner], key);
+                if (rkey[owner] == key) rleaf[owner] = T.leaf_index;
+            }
+        }
+        const bool idle = !trav_busy(T);
+        const unsigned long long busy_m = __ballot(!idle);
+        if (busy_m == 0ull) break;
+        const unsigned long long idle_m = __ballot(idle);
+        const bool can_give = !idle && T.sp > T.sb;
+        const unsigned long long give_m = __ballot(can_give);
+        if (idle_m != 0ull && give_m != 0ull) {
+            const int n = min(__popcll(idle_m), __popcll(give_m));
+            if (can_give) {
+                const int r = __popcll(give_m & lt);
+                if (r < n) {
+                    dref[wbase + r] = stack[T.sb * kBlock];
+                    down[wbase + r] = (int)owner;
+                    dbound[wbase + r] = T.t;
+                    ++T.sb;
+                    if (T.sb == T.sp) { T.sb = 0; T.sp = 0; }
+                }
+            }
+            if (idle) {
+                const int r = __popcll(idle_m & lt);
+                if (r < n) {
+                    const int e = dref[wbase + r];
+                    owner = (unsigned)down[wbase + r];
+                    const float bound = __uint_as_float(min(__float_as_uint(dbound[wbase + r]),
+                                                            (uint32_t)(rkey[owner] >> 32)));
+                    wr.ox = rs[0 * kBlock + owner];  wr.oy = rs[1 * kBlock + owner];  wr.oz = rs[2 * kBlock + owner];
+                    wr.dx = rs[3 * kBlock + owner];  wr.dy = rs[4 * kBlock + owner];  wr.dz = rs[5 * kBlock + owner];
+                    wr.ix = rs[6 * kBlock + owner];  wr.iy = rs[7 * kBlock + owner];  wr.iz = rs[8 * kBlock + owner];
+                    wr.nox = rs[9 * kBlock + owner]; wr.noy = rs[10 * kBlock + owner]; wr.noz = rs[11 * kBlock + owner];
+                    wign = rign[owner];
+                    T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
+                    T.t = bound; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
+                }
+            }
+        }
+    }
+    const unsigned long long key = rkey[tid];
+    if (key != ~0ull) {
+        T.t = __uint_as_float((uint32_t)(key >> 32));
+        T.id = (uint32_t)key;
+        T.leaf_index = rleaf[tid];
+    } else {
+        T.t = tmax;
+        T.leaf_index = -1;
+        T.id = 0xFFFFFFFFu;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void update_sound_shared_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc,
+                                                                     int rays_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | share area
+    int* stack = &s_dyn[threadIdx.x];
+    int* share = s_dyn + (size_t)sc.stack_rows * kBlock;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = (int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    const int N = sp.raycasts_per_tick;
+    const int i = wave * rays_per_wave + lane;
+    const bool mine = lane < rays_per_wave && i <= N;
+    enum { MAIN = 0, DIRECT = 1, DONE = 2 };
+    int mode = DONE;
+    bool is_occl = false;
+    unsigned long long traces = 0;
+    // CastAudioRay state (FSAC.cpp:132-207)
+    float px = 0.f, py = 0.f, pz = 0.f, ddx = 0.f, ddy = 0.f, ddz = 0.f;
+    float max_distance = sp.raycast_distance;
+    int bounces = sp.raycast_bounces;
+    const float energy = 1.0f;
+    float result = 0.0f, direct_sum = 0.0f;
+    unsigned direct_hits = 0;
+    // CastDirectAudioRay state (FSAC.cpp:209-280)
+    float qx = 0.f, qy = 0.f, qz = 0.f, ex = 0.f, ey = 0.f, ez = 0.f, dmax = 0.f, denergy = 0.f;
+    int dbounces = 0;
+    uint32_t dactor = kNoObject;
+
+    if (mine && i == N) {                                                  // FSAC.cpp:295-299
+        is_occl = true;
+        float dx = sp.lis[0] - sp.src[0], dy = sp.lis[1] - sp.src[1], dz = sp.lis[2] - sp.src[2];
+        float l2 = dx * dx + dy * dy + dz * dz;
+        if (l2 > 0.0f) {
+            float inv = 1.0f / sqrtf(l2);
+            ex = dx * inv; ey = dy * inv; ez = dz * inv;
+            qx = sp.src[0]; qy = sp.src[1]; qz = sp.src[2];
+            dmax = sp.raycast_distance; dbounces = 10; denergy = 1.0f; dactor = kNoObject;
+            mode = DIRECT;
+        } else {
+            acc->occlusion = 0.0f;
+        }
+    } else if (mine) {
+        // initial direction: FMath::VRandCone((0,-1,0), PI, PI) FSAC.cpp:291 == theta = 2 pi U, phi = acos(2V-1)
+        uint32_t c0 = (uint32_t)i, c1 = 0u, c2 = 0u, c3 = 0x46533032u, k0 = sp.seed_lo, k1 = sp.seed_hi;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+            uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        const float U = u01(c0), V = u01(c1);
+        const float x = fmaf(V, 2.0f, -1.0f);
+        const float sphi = sqrtf(fmaxf(0.0f, fmaf(-x, x, 1.0f)));
+        float st, ct;
+        sincos2pi(U, st, ct);
+        const float nx = 0.0f, ny = -1.0f, nz = 0.0f;
+        float sg = copysignf(1.0f, nz);
+        float a = -1.0f / (sg + nz);
+        float b = nx * ny * a;
+        float t0 = fmaf(sg * nx * nx, a, 1.0f), t1 = sg * b, t2 = -sg * nx;
+        float b0 = b, b1 = fmaf(ny * ny, a, sg), b2 = -ny;
+        float lx = sphi * ct, ly = sphi * st;
+        float d0 = fmaf(lx, t0, fmaf(ly, b0, x * nx));
+        float d1 = fmaf(lx, t1, fmaf(ly, b1, x * ny));
+        float d2 = fmaf(lx, t2, fmaf(ly, b2, x * nz));
+        float l2 = d0 * d0 + d1 * d1 + d2 * d2;
+        float inv = 1.0f / sqrtf(l2);
+        ddx = d0 * inv; ddy = d1 * inv; ddz = d2 * inv;
+        px = sp.src[0]; py = sp.src[1]; pz = sp.src[2];
+        mode = MAIN;
+    }
+
+    while (true) {
+        // settle everything that needs no trace: a finished direct ray returns to its caller, a walk out of bounces ends
+        for (int guard = 0; guard < 2; ++guard) {
+            if (mode == DIRECT && (dbounces == 0 || denergy <= 0.0f)) {   // FSAC.cpp:212: the direct ray died
+                if (is_occl) { acc->occlusion = 0.0f; mode = DONE; } else { mode = MAIN; }
+            }
+            if (mode == MAIN && bounces == 0) mode = DONE;                // FSAC.cpp:134
+        }
+        const bool has = mode != DONE;
+        if (__ballot(has) == 0ull) break;
+        // the next query of this lane
+        Ray r;
+        float tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+        uint32_t ign = kNoObject;
+        if (mode == MAIN) {
+            float l2 = ddx * ddx + ddy * ddy + ddz * ddz;                 // GetSafeNormal FSAC.cpp:141
+            float inv = 1.0f / sqrtf(l2);
+            dx = ddx * inv; dy = ddy * inv; dz = ddz * inv;
+            r = make_ray(px, py, pz, dx, dy, dz);
+            tmax = max_distance;
+        } else {
+            dx = ex; dy = ey; dz = ez;
+            r = make_ray(fmaf(ex, 0.1f, qx), fmaf(ey, 0.1f, qy), fmaf(ez, 0.1f, qz), ex, ey, ez);   // FSAC.cpp:232
+            tmax = dmax;
+            ign = dactor;
+        }
+        Trav T;
+        trav_closest_shared_ign(sc, has, r, tmax, ign, T, stack, share);
+        if (!has) continue;
+        // legacy_trace: closest of the triangles and the pawn sphere
+        ++traces;
+        LegacyHit h;
+        bool hit;
+        {
+            float ts;
+            const bool hs = sphere_hit(r, sp.lis, sp.listener_radius, tmax, ts);
+            const bool ht = T.leaf_index >= 0;
+            hit = ht || hs;
+            if (hs && (!ht || ts <= T.t)) { h.t = ts; h.object = kPawnObject; h.nx = h.ny = h.nz = 0.f; }
+            else if (ht) {
+                uint32_t mat;
+                hit_surface(sc, T.leaf_index, r, h.nx, h.ny, h.nz, mat);
+                h.t = T.t;
+                h.object = __float_as_uint(reinterpret_cast<const float4*>(sc.tris)[4 * (size_t)T.leaf_index + 2].w);
+            }
+        }
+        if (mode == MAIN) {
+            if (!hit) { mode = DONE; continue; }                          // FSAC.cpp:192-196
+            const float ipx = fmaf(h.t, dx, px), ipy = fmaf(h.t, dy, py), ipz = fmaf(h.t, dz, pz);
+            const float left = max_distance - h.t;                        // DistanceLeft FSAC.cpp:167
+            const float tx = sp.lis[0] - ipx, ty = sp.lis[1] - ipy, tz = sp.lis[2] - ipz;
+            const float dist_to_player = sqrtf(tx * tx + ty * ty + tz * tz);
+            const float travel_time = (sp.raycast_distance - left + dist_to_player) * 0.01f / 343.0f;   // :171
+            if (travel_time > sp.simulated_duration) { mode = DONE; continue; }
+            if (h.object == kPawnObject) { result = energy; mode = DONE; continue; }   // FSAC.cpp:177-181
+            // the reflection (FSAC.cpp:186-187) does not depend on the direct ray: set the next main segment up now
+            const float dn = dx * h.nx + dy * h.ny + dz * h.nz;
+            ddx = fmaf(-2.0f * dn, h.nx, dx);
+            ddy = fmaf(-2.0f * dn, h.ny, dy);
+            ddz = fmaf(-2.0f * dn, h.nz, dz);
+            px = fmaf(h.nx, 0.5f, ipx); py = fmaf(h.ny, 0.5f, ipy); pz = fmaf(h.nz, 0.5f, ipz);
+            max_distance = left;
+            bounces -= 1;
+            if (dist_to_player > 0.0f) {                                  // FSAC.cpp:184-185: one direct ray to the listener
+                const float invp = 1.0f / dist_to_player;
+                ex = tx * invp; ey = ty * invp; ez = tz * invp;
+                qx = ipx; qy = ipy; qz = ipz;
+                dmax = left; dbounces = 1; denergy = energy; dactor = kNoObject;
+                mode = DIRECT;
+            }
+        } else {                                                          // CastDirectAudioRay FSAC.cpp:209-280
+            float de = 0.0f;
+            bool finished = true;
+            if (hit) {
+                if (h.object == kPawnObject) {                            // FSAC.cpp:253-270
+                    float travel = sp.raycast_distance - dmax + h.t;
+                    travel *= 0.01f;
+                    float time = travel / 343.0f;
+                    if (!(time > sp.simulated_duration)) de = denergy * expf(-0.0017f * travel);
+                } else {                                                  // through the obstacle, FSAC.cpp:272-276
+                    qx = fmaf(h.t, ex, r.ox); qy = fmaf(h.t, ey, r.oy); qz = fmaf(h.t, ez, r.oz);
+                    dmax = dmax - h.t;
+                    dbounces -= 1;
+                    dactor = h.object;
+                    finished = false;
+                }
+            }
+            if (finished) {
+                if (is_occl) { acc->occlusion = de; mode = DONE; }
+                else { if (de > 0.0f) { ++direct_hits; direct_sum += de; } mode = MAIN; }
+            }
+        }
+    }
+    if (mine && !is_occl) {
+        if (result > 0.0f) atomicAdd(&acc->reaching, 1u);
+        if (direct_hits) { atomicAdd(&acc->direct_hits, direct_hits); atomicAdd(&acc->direct_energy_sum, direct_sum); }
+    }
+    if (traces) atomicAdd(&acc->traces, traces);
+}
+
 __global__ __launch_bounds__(kBlock) void update_sound_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
     int* s_stack = s_dyn;
@@ -1701,10 +1966,18 @@ void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, co
                        any_hit, hit, t, tri, normal);
 }
 
-void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, hipStream_t s) {
+void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, int rays_per_wave, hipStream_t s) {
     int lanes = sp.raycasts_per_tick + 1;
-    allow_lds(update_sound_kernel, stack_bytes(sc));
-    hipLaunchKernelGGL(update_sound_kernel, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(sc), s, sc, sp, acc);
+    if (rays_per_wave >= 64 || rays_per_wave <= 0) {   // one ray per lane, no sharing (FS_SOUND_RAYS_PER_WAVE=64)
+        allow_lds(update_sound_kernel, stack_bytes(sc));
+        hipLaunchKernelGGL(update_sound_kernel, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(sc), s, sc, sp, acc);
+        return;
+    }
+    const int waves = (lanes + rays_per_wave - 1) / rays_per_wave;
+    const size_t lds = stack_bytes(sc) + kShareIgnLdsBytes;
+    allow_lds(update_sound_shared_kernel, lds);
+    hipLaunchKernelGGL(update_sound_shared_kernel, dim3((waves + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), lds, s, sc, sp,
+                       acc, rays_per_wave);
 }
 
 void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
