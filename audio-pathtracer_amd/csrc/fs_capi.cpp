@@ -115,6 +115,7 @@ struct fs_context {
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
     WalkLaunch walk{2, 256, 2, nullptr, 1, nullptr};   // variant 2 = wave work sharing (default), 0 = one subpath per lane, 1 = persistent
     int refill_threshold = 16;
+    int walk_rays_per_wave = 0;    // BDPT walk: subpaths per wave, 0 = by frame size (FS_WALK_RAYS_PER_WAVE; 64 = dense waves)
     int sound_rays_per_wave = 4;   // legacy tracer: rays per wave, the other lanes help (FS_SOUND_RAYS_PER_WAVE; 64 = no sharing)
 
     // measurement
@@ -318,6 +319,21 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positio
     return FS_OK;
 }
 
+// Subpaths per wave of the walk kernel.  A large frame fills the chip with dense waves; a small one is a few waves
+// and takes the latency of its longest chain of closest-hit queries, which shrinks when the idle lanes of sparse
+// waves help with every query (walk_kernel_sparse).  Thresholds measured on MI355X
+// (tools/sparse_sweep.py, tools/sparse_check.py, profiles/r01_sparse_waves.json).  Frames of shallow walks do best at
+// about 2048 waves (16 384 subpaths at depth 8: 0.33 -> 0.19 ms with 8 per wave; from 131 072 subpaths on dense
+// waves win).  Walks deeper than 16 segments (the reference's unbounded default) leave long chains of a few
+// survivors and do best at about 16 384 waves at every size measured (262 144 subpaths, unbounded depth, 5 000
+// triangles: 1.29 -> 0.82 ms with 16 per wave; 1 048 576: dense again).
+int auto_rays_per_wave(unsigned long long lanes, int depth) {
+    const unsigned long long target_waves = depth > 16 ? 16384ull : 2048ull;
+    int rpw = 4;
+    while (rpw < 64 && (unsigned long long)rpw * 2 * target_waves <= lanes) rpw *= 2;   // largest power of two <= lanes / target
+    return rpw;
+}
+
 int check_params(fs_context* ctx, const fs_params* p) {
     if (!p) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "params is NULL");
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
@@ -428,6 +444,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
     if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
     e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchAllocWords);
     if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchAllocWords);
@@ -760,7 +777,9 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     if (!perm) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
     if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
-    launch_walk(ctx->scene, kp, st, ctx->walk, perm, ctx->stream);
+    WalkLaunch wl = ctx->walk;
+    wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
+    launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
     if (all_conn)
         launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,

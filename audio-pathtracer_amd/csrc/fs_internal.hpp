@@ -125,6 +125,7 @@ struct WalkLaunch {
     unsigned* queue_head;  // frame scratch: [0] subpath queue head, then plan counts + cursors; zero at launch
     int plan;            // 1 = sort subpaths by their (RNG-determined) length before walking
     uint32_t* perm;      // [depth + 1][total] subpath indices bucketed by planned length
+    int rays_per_wave = 64;   // < 64: sparse waves for small frames (variant 2): a wave owns this many subpaths, the other lanes help
 };
 constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
 // frame scratch allocation: kScratchWords rearmed every frame, then (8-byte aligned) kNumCounters u64 work

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
 constexpr size_t kShareLdsBytes = (size_t)kBlock * (12 * 4 + 8 + 4 + 3 * 4);
 
 __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray& own, Trav& T, int* stack, int* s_dyn,
-                                                float tmax) {
+                                                float tmax, bool has_ray = true) {
     float* rs = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
     unsigned long long* rkey = reinterpret_cast<unsigned long long*>(rs + 12 * kBlock);
     int* rleaf = reinterpret_cast<int*>(rkey + kBlock);
@@ -661,7 +661,7 @@ __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray
     rleaf[tid] = -1;
     unsigned owner = tid;   // block-local lane whose ray this lane is working on
     Ray wr = own;
-    trav_init(T, tmax, sc.num_nodes > 0);
+    trav_init(T, tmax, has_ray && sc.num_nodes > 0);   // has_ray = false: a helper lane of a sparse wave
     while (true) {
         if (trav_busy(T)) {
             trav_step<false>(sc, wr, T, stack);
@@ -808,6 +808,39 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
         walker_apply_hit(w, kp, sc, st, ray, T);
     }
     walker_finish(w, st);
+}
+
+// Small frames on sparse waves: a frame of a few thousand subpaths is a handful of waves and takes the latency of
+// its longest chain of closest-hit queries.  Here a wave owns only `rays_per_wave` subpaths (its first lanes) and
+// the other lanes help with every query — the legacy tracer's scheme (update_sound_shared_kernel).  The loop is
+// wave-uniform: lanes whose walk has ended (or that never had one) keep calling the shared traversal as helpers.
+template <int LOBES>
+__global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
+                                                             const uint32_t* __restrict__ perm, int rays_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
+    int* s_stack = s_dyn;
+    __shared__ unsigned s_cnt[kPlanBuckets];
+    if (perm) {
+        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
+    bool alive = lane < (uint32_t)rays_per_wave && slot < 2u * kp.num_local;
+    int* stack = &s_stack[threadIdx.x];
+    Walker w;
+    walker_start(w, alive ? (perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot) : 0u, kp);
+    Ray ray;
+    while (true) {
+        const bool go = alive && walker_next_ray<LOBES>(w, kp, sc, st, ray);
+        if (alive && !go) { walker_finish(w, st); alive = false; }
+        if (__ballot(go) == 0ull) break;
+        Trav T;
+        trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
+        if (go) walker_apply_hit(w, kp, sc, st, ray, T);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1876,6 +1909,21 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
+    if (wl.variant == 2 && wl.rays_per_wave > 0 && wl.rays_per_wave < 64) {   // small frame: sparse waves, idle lanes help
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
+        const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
+        const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
+        if (kp.lobes) {
+            allow_lds(walk_kernel_sparse<1>, lds);
+            hipLaunchKernelGGL(walk_kernel_sparse<1>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm,
+                               wl.rays_per_wave);
+        } else {
+            allow_lds(walk_kernel_sparse<0>, lds);
+            hipLaunchKernelGGL(walk_kernel_sparse<0>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm,
+                               wl.rays_per_wave);
+        }
+        return;
+    }
     if (wl.variant == 2) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
         if (kp.lobes) {
