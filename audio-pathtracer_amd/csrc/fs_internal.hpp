@@ -140,7 +140,7 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
                  const uint32_t* perm, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    unsigned long long* fixed, unsigned* queue_head, hipStream_t s);
+                    unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, hipStream_t s);
 // row f3: every forward prefix x every backward prefix of each pair (one wave per pair), uniform MIS weights
 void launch_connect_all(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
                         unsigned long long* fixed, unsigned* queue_head, hipStream_t s);

@@ -946,10 +946,14 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
 // ---------------------------------------------------------------------------------------------------
 // connect_kernel: ConnectSubpaths + EvaluatePath + clamp/gain + deposit
 // ---------------------------------------------------------------------------------------------------
+// pairs_per_wave < 64: sparse waves for small frames — a wave owns that many pairs (its first lanes), the other
+// lanes only help with the shared visibility queries (a frame of a few thousand pairs is otherwise a few waves
+// waiting for their longest traversal).
 template <int B, int LOBES>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
-                                                         unsigned long long* __restrict__ fixed, unsigned* queue_head) {
+                                                         unsigned long long* __restrict__ fixed, unsigned* queue_head,
+                                                         int pairs_per_wave) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
@@ -969,9 +973,11 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     unsigned my_deposits = 0;
     // whole workgroups step through the pairs: every lane of a wave takes part in the shared visibility queries,
     // also the ones without a pair or without a segment to test
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t li = base + threadIdx.x;
-        const bool active = li < n;
+    const uint32_t ppw = (uint32_t)pairs_per_wave, per_block = ppw * (kBlock / 64);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
+        const uint32_t li = base + wave * ppw + lane;
+        const bool active = lane < ppw && li < n;
         const uint32_t lc = active ? li : 0u;
         const float4 F = st.end_pos[lc];
         const uint2 Fm = st.end_misc[lc];
@@ -1874,17 +1880,21 @@ inline void allow_lds(K kernel, size_t bytes) {
 
 template <int B>
 void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                      unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
+                      unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, hipStream_t s) {
     if (kp.num_local == 0) return;
-    uint32_t blocks = (kp.num_local + kBlock - 1) / kBlock;
+    if (pairs_per_wave < 1 || pairs_per_wave > 64) pairs_per_wave = 64;
+    const uint32_t per_block = (uint32_t)pairs_per_wave * (kBlock / 64);
+    uint32_t blocks = (kp.num_local + per_block - 1) / per_block;
     if (blocks > 1024) blocks = 1024;
     size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins + kShareAnyLdsBytes;
     if (kp.lobes) {
         allow_lds(connect_kernel<B, 1>, lds);
-        hipLaunchKernelGGL((connect_kernel<B, 1>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
+        hipLaunchKernelGGL((connect_kernel<B, 1>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head,
+                           pairs_per_wave);
     } else {
         allow_lds(connect_kernel<B, 0>, lds);
-        hipLaunchKernelGGL((connect_kernel<B, 0>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
+        hipLaunchKernelGGL((connect_kernel<B, 0>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head,
+                           pairs_per_wave);
     }
 }
 
@@ -1984,16 +1994,16 @@ void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int 
 }
 
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
+                    unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, hipStream_t s) {
     switch (B) {
-        case 1: launch_connect_t<1>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 2: launch_connect_t<2>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 3: launch_connect_t<3>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 4: launch_connect_t<4>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 5: launch_connect_t<5>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 6: launch_connect_t<6>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 7: launch_connect_t<7>(sc, kp, st, energy, fixed, queue_head, s); break;
-        default: launch_connect_t<8>(sc, kp, st, energy, fixed, queue_head, s); break;
+        case 1: launch_connect_t<1>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        case 2: launch_connect_t<2>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        case 3: launch_connect_t<3>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        case 4: launch_connect_t<4>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        case 5: launch_connect_t<5>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        case 6: launch_connect_t<6>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        case 7: launch_connect_t<7>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        default: launch_connect_t<8>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
     }
 }
 
