@@ -385,7 +385,11 @@ def main():
                               "algorithmic_bytes_per_launch": wb, "avg_launch_ms": result["kernel_ms"]["walk"],
                               "frame_algorithmic_bytes": wb + cb,
                               "frame_achieved_GBs": (wb + cb) / (1e-3 * (result["kernel_ms"]["walk"] +
-                                                                        result["kernel_ms"]["connect"])) / 1e9}
+                                                                        result["kernel_ms"]["connect"])) / 1e9,
+                              "note": "achieved = SURVEY 8(d) algorithmic bytes (oracle BVH2 node/triangle fetches) / "
+                                      "launch time; the tree is served from L2 / Infinity Cache, so frac can exceed 1 — "
+                                      "`traffic` is the HBM traffic measured by PMC (profiles/traffic.json); the "
+                                      "kernel is bound by VALU issue, DESIGN.md section 5"}
         result["cpu_baseline"] = {"value": total_rays / t_mt, "unit": "rays/s", "cores": cores, "kind": "port",
                                   "sample": f"{1 + extra_frames} full frames ({total_rays} rays each) on {cores} threads "
                                             f"(~{t_mt * (1 + extra_frames) * cores:.0f} s of CPU work), oracle {kind_note}; "
