@@ -1,7 +1,7 @@
 """Latency of the legacy per-frame forward tracer (row a9: UpdateSound, FSAC.cpp:283-306 — 1500 rays x up to 10
 bounces, a listener-directed transmission ray per bounce; the only tracing the reference does every frame at HEAD)
 through fs_update_sound, against the CPU oracle on one core.  Run on the GPU box:
-    python tools/measure_update_sound.py > gpurun_out/update_sound.json"""
+    python tests/measure_update_sound.py > gpurun_out/update_sound.json"""
 import json
 import os
 import sys
