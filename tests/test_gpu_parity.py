@@ -731,6 +731,47 @@ def test_material_lobes_parity(pkg, oracle_mod, scene_factory, cid, name, bands,
     assert not np.array_equal(e_gpu, e_off)                         # the mode does change the result
 
 
+def test_material_lobes_full_size(pkg, oracle_mod, scene_factory):
+    """cfg3 size (262 144 rays, depth 8, 100 000 triangles) with FS_FLAG_MATERIAL_LOBES and the seeded Transmission /
+    Scattering arrays: oracle parity and equal work counters on the first 8 192 pairs (rank 0 of 16 with the full
+    frame's normaliser), shard invariance of the whole frame, and sanity of the lobe split: nothing is deposited
+    before the direct sound, and the frame carries less energy than the reference's diffuse-only walk, whose vertex
+    factor Absorption / pi (ARTS.cpp:382-386) it replaces by Refl sigma / pi <= (1 - alpha) / pi on connections."""
+    sc = scene_factory("old_mine", 8)
+    tau, sigma = pkg.scenes.material_lobes(sc)
+    lobes = pkg._capi.FLAG_MATERIAL_LOBES
+    p = pkg.default_params(num_rays=262144, depth=8, seed=0x5EED, flags=lobes)
+
+    def ctx_for(**kw):
+        c = pkg.Context(num_bands=8, **kw)
+        c.set_scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
+        c.set_listener(sc.listener)
+        return c, c.create_source(sc.source)
+
+    ctx, src = ctx_for()
+    e_full = ctx.compute_energy_response(src, p).astype(np.float64)
+    ctx.close()
+    assert e_full.sum() > 0
+    acc = np.zeros_like(e_full)
+    for r in range(2):
+        c, s_ = ctx_for(rank=r, world_size=2)
+        acc += c.compute_energy_response(s_, p)
+        c.close()
+    assert np.array_equal(acc != 0, e_full != 0) and max(rel_rms(acc[b], e_full[b]) for b in range(8)) <= TIGHT_TOL
+    d = float(np.linalg.norm(sc.listener.astype(np.float64) - sc.source.astype(np.float64))) / 1000.0
+    assert np.flatnonzero(e_full.sum(axis=0)).min() >= int(np.floor(d / 343.0 * 1000.0))
+    c, s_ = ctx_for(rank=0, world_size=16)
+    e_r0 = c.compute_energy_response(s_, p)
+    st = c.stats()
+    c.close()
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
+    op = oracle_mod.default_params(num_pairs=131072, depth=8, seed=0x5EED, flags=oracle_mod.FLAG_MATERIAL_LOBES)
+    e32, e64, cnt = osc.compute_energy(op, sc.source, sc.listener, pair_begin=0, pair_end=8192)
+    assert cnt.connected > 0
+    check_energy(e_r0, e32, e64, 8)
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+
+
 def test_material_lobes_rejects_mis(pkg, scene_factory):
     sc = scene_factory("shoebox", 1)
     ctx, src = make_ctx(pkg, sc)
