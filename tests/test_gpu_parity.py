@@ -734,9 +734,7 @@ def test_material_lobes_parity(pkg, oracle_mod, scene_factory, cid, name, bands,
 def test_material_lobes_full_size(pkg, oracle_mod, scene_factory):
     """cfg3 size (262 144 rays, depth 8, 100 000 triangles) with FS_FLAG_MATERIAL_LOBES and the seeded Transmission /
     Scattering arrays: oracle parity and equal work counters on the first 8 192 pairs (rank 0 of 16 with the full
-    frame's normaliser), shard invariance of the whole frame, and sanity of the lobe split: nothing is deposited
-    before the direct sound, and the frame carries less energy than the reference's diffuse-only walk, whose vertex
-    factor Absorption / pi (ARTS.cpp:382-386) it replaces by Refl sigma / pi <= (1 - alpha) / pi on connections."""
+    frame's normaliser), shard invariance of the whole frame, and nothing is deposited before the direct sound."""
     sc = scene_factory("old_mine", 8)
     tau, sigma = pkg.scenes.material_lobes(sc)
     lobes = pkg._capi.FLAG_MATERIAL_LOBES
