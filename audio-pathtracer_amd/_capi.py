@@ -37,7 +37,7 @@ EXPORTS = [
     "fs_config_default", "fs_params_default", "fs_abi_version", "fs_context_create", "fs_context_destroy",
     "fs_last_error", "fs_scene_set_triangles", "fs_scene_set_materials", "fs_scene_commit", "fs_source_create",
     "fs_source_destroy", "fs_source_set_position", "fs_listener_set_position", "fs_compute_energy_response",
-    "fs_compute_energy_response_async", "fs_energy_device_ptr", "fs_reconstruct_impulse_response",
+    "fs_compute_energy_response_async", "fs_compute_energy_response_batch_async", "fs_energy_device_ptr", "fs_reconstruct_impulse_response",
     "fs_reconstruct_impulse_response_async", "fs_synchronize", "fs_get_impulse_response",
     "fs_copy_impulse_response", "fs_copy_band_impulse_response", "fs_get_energy_buffer", "fs_flush_energy_buffer",
     "fs_add_energy_at_delay", "fs_update_energy_buffer", "fs_num_bins", "fs_num_samples", "fs_trace_rays",
@@ -176,6 +176,7 @@ def load():
         "fs_listener_set_position": (C.c_int, [vp, C.POINTER(C.c_float)]),
         "fs_compute_energy_response": (C.c_int, [vp, i32, C.POINTER(Params), f32p]),
         "fs_compute_energy_response_async": (C.c_int, [vp, i32, C.POINTER(Params)]),
+        "fs_compute_energy_response_batch_async": (C.c_int, [vp, C.POINTER(C.c_int32), i32, C.POINTER(Params)]),
         "fs_energy_device_ptr": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "fs_scene_update_triangles": (C.c_int, [vp, i32, i32, f32p]),
         "fs_scene_refit": (C.c_int, [vp]),

@@ -115,6 +115,11 @@ class Context:
     def compute_energy_response_async(self, src, params):
         self.check(self.lib.fs_compute_energy_response_async(self.h, src, C.byref(params)))
 
+    def compute_energy_response_batch_async(self, sources, params):
+        """several sources in one traced frame (UpdateSource over ActiveSources): same result per source as separate calls"""
+        arr = (C.c_int32 * len(sources))(*[int(x) for x in sources])
+        self.check(self.lib.fs_compute_energy_response_batch_async(self.h, arr, len(sources), C.byref(params)))
+
     def reconstruct_impulse_response(self, src, params=None):
         self.check(self.lib.fs_reconstruct_impulse_response(self.h, src, C.byref(params) if params else None))
 
@@ -415,9 +420,15 @@ class AudioRayTracingSubsystem:
         self.ctx.reconstruct_impulse_response(Src._src, p)
         return e
 
-    def ForceUpdateSources(self):  # ARTS.cpp:883-886
-        for s in list(self.ActiveSources):
-            self.UpdateSource(s)
+    def ForceUpdateSources(self):  # ARTS.cpp:883-886 — all active sources in one batched frame
+        srcs = list(self.ActiveSources)
+        if not srcs:
+            return
+        self._commit()
+        self.ctx.compute_energy_response_batch_async([s._src for s in srcs], self.params)
+        for s in srcs:
+            self.ctx.reconstruct_impulse_response_async(s._src, self.params)
+        self.ctx.synchronize()
 
     def Tick(self, DeltaTime):  # ARTS.cpp:55-85 without the 1 s warm-up: the caller drives every frame
         if not self.ActiveSources:

@@ -110,6 +110,12 @@ struct fs_context {
     size_t cap_lanes = 0, cap_seg = 0;
     float4* d_seg_pos = nullptr;   // node positions per walk step, all-connections mode only (row f3)
     size_t cap_pos = 0;
+    // batched frames (fs_compute_energy_response_batch_async): per-frame tables of pointers and source positions
+    static constexpr int kBatchSlots = 4;   // frames the host may run ahead of the table copies
+    char* d_batch = nullptr; char* h_batch = nullptr; size_t batch_cap = 0;   // kBatchSlots blocks of batch_cap bytes
+    hipEvent_t ev_batch[kBatchSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool batch_pending[kBatchSlots] = {false, false, false, false};
+    unsigned batch_frame = 0;
     unsigned long long host_segments = 0;   // walk segments of frames without a plan pass (roulette off), since the last reset
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
@@ -481,6 +487,9 @@ int fs_context_destroy(fs_context* ctx) {
             if (p) (void)hipFree(p);
         if (ctx->fft_graph) (void)hipGraphExecDestroy(ctx->fft_graph);
         if (ctx->h_fft_stage) (void)hipHostFree(ctx->h_fft_stage);
+        if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+        if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+        for (hipEvent_t e : ctx->ev_batch) if (e) (void)hipEventDestroy(e);
     }
     for (Source* s : ctx->sources) free_source(ctx, s);
     // streams exist even when a later step of fs_context_create failed (device_ok == false)
@@ -714,12 +723,12 @@ int fs_listener_set_position(fs_context* ctx, const float xyz[3]) {
 }
 
 // ---- hot path ------------------------------------------------------------------------------------------
-int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_params* p) {
-    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
-    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
-    Source* s = get_source(ctx, h);
-    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
-    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+// One traced frame for `count` sources (count == 1: the plain call).  A batch lays the sources' pairs end to end in one
+// plan / walk / connect sequence: every source gets exactly the pairs, random streams and therefore results of its own
+// fs_compute_energy_response_async call, but the chip sees one large frame instead of `count` small ones.
+static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
+    Source* s = srcs[0];
+    const bool batch = count > 1;
     if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     int rc = check_params(ctx, p);
     if (rc) return rc;
@@ -733,7 +742,9 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     kp.seed_lo = (uint32_t)p->seed;
     kp.seed_hi = (uint32_t)(p->seed >> 32);
     kp.pair_begin = (uint32_t)p0;
-    kp.num_local = (uint32_t)(p1 - p0);
+    kp.pairs_per_source = (uint32_t)(p1 - p0);
+    kp.num_local = kp.pairs_per_source * (uint32_t)count;
+    kp.src_table = nullptr;
     kp.depth = p->depth > 0 ? p->depth : FS_MAX_DEPTH;
     kp.russian_roulette = p->russian_roulette;
     kp.cosine = (p->flags & FS_FLAG_COSINE_SAMPLING) ? 1 : 0;
@@ -773,19 +784,66 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
         if (ctx->profiling >= 2) tf.e[2] = take_event(ctx);
     }
     const bool fixed = (p->flags & FS_FLAG_DETERMINISTIC) != 0;
-    if (fixed && !s->d_fixed[0]) {
-        for (int i = 0; i < 2; ++i)
-            FS_HIP(ctx, hipMalloc((void**)&s->d_fixed[i], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
+    for (int i = 0; i < count; ++i) {
+        Source* si = srcs[i];
+        if (fixed && !si->d_fixed[0]) {
+            for (int k = 0; k < 2; ++k)
+                FS_HIP(ctx, hipMalloc((void**)&si->d_fixed[k], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
+        }
+        si->cur ^= 1;   // this frame deposits into the other buffer; the tail may still be busy with the last one
+        si->cur_fixed = fixed;
+        FS_HIP(ctx, wait_energy_readers(ctx, si));
     }
-    s->cur ^= 1;   // this frame deposits into the other buffer; the tail may still be busy with the last one
-    s->cur_fixed = fixed;
-    FS_HIP(ctx, wait_energy_readers(ctx, s));
     // FlushEnergyBuffer ARTS.cpp:157-161 is folded into the plan pass (one launch); plain memset otherwise.
     // Deterministic mode zeroes the fixed-point histogram instead (the fp32 buffer is rewritten from it).
     float* zero_ptr = fixed ? reinterpret_cast<float*>(s->d_fixed[s->cur]) : s->energy();
     const int zero_words = (fixed ? 2 : 1) * B * ctx->num_bins;
-    const uint32_t* perm = launch_plan(kp, ctx->walk, zero_ptr, zero_words, ctx->stream);
-    if (!perm) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+    float* const* energy_tab = nullptr;
+    unsigned long long* const* fixed_tab = nullptr;
+    if (batch) {
+        // per-frame tables in one pinned staging block: energy pointers [count] | fixed-point buffer pointers [count] |
+        // source positions [count][3].  The block is rewritten only after the previous frame's copy has left it.
+        const size_t bytes = 2 * (size_t)count * sizeof(void*) + (size_t)count * 3 * sizeof(float);
+        if (bytes > ctx->batch_cap) {
+            FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+            if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+            ctx->d_batch = nullptr; ctx->h_batch = nullptr; ctx->batch_cap = 0;
+            const size_t cap = (bytes + 255) & ~(size_t)255;
+            FS_HIP(ctx, hipMalloc((void**)&ctx->d_batch, cap * fs_context::kBatchSlots));
+            FS_HIP(ctx, hipHostMalloc((void**)&ctx->h_batch, cap * fs_context::kBatchSlots, hipHostMallocDefault));
+            ctx->batch_cap = cap;
+            for (int k = 0; k < fs_context::kBatchSlots; ++k) {
+                if (!ctx->ev_batch[k]) FS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_batch[k], hipEventDisableTiming));
+                ctx->batch_pending[k] = false;
+            }
+        }
+        const int slot = (int)(ctx->batch_frame++ % fs_context::kBatchSlots);
+        if (ctx->batch_pending[slot]) FS_HIP(ctx, hipEventSynchronize(ctx->ev_batch[slot]));   // its last copy has left the block
+        char* hb = ctx->h_batch + (size_t)slot * ctx->batch_cap;
+        char* db = ctx->d_batch + (size_t)slot * ctx->batch_cap;
+        void** h_en = reinterpret_cast<void**>(hb);
+        void** h_fx = h_en + count;
+        float* h_pos = reinterpret_cast<float*>(h_fx + count);
+        for (int i = 0; i < count; ++i) {
+            h_en[i] = srcs[i]->energy();
+            h_fx[i] = fixed ? (void*)srcs[i]->d_fixed[srcs[i]->cur] : nullptr;
+            std::memcpy(h_pos + 3 * i, srcs[i]->pos, sizeof(float) * 3);
+        }
+        FS_HIP(ctx, hipMemcpyAsync(db, hb, bytes, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(ctx, hipEventRecord(ctx->ev_batch[slot], ctx->stream));
+        ctx->batch_pending[slot] = true;
+        energy_tab = reinterpret_cast<float* const*>(db);
+        fixed_tab = fixed ? reinterpret_cast<unsigned long long* const*>(db + (size_t)count * sizeof(void*)) : nullptr;
+        kp.src_table = reinterpret_cast<const float*>(db + 2 * (size_t)count * sizeof(void*));
+        for (int i = 0; i < count; ++i) {
+            float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[srcs[i]->cur]) : srcs[i]->energy();
+            FS_HIP(ctx, hipMemsetAsync(zp, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+        }
+        zero_ptr = nullptr;
+    }
+    const uint32_t* perm = launch_plan(kp, ctx->walk, zero_ptr, zero_ptr ? zero_words : 0, ctx->stream);
+    if (!perm && zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
     if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     WalkLaunch wl = ctx->walk;
@@ -798,8 +856,10 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     else
         launch_connect(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
                        ctx->connect_pairs_per_wave > 0 ? ctx->connect_pairs_per_wave : auto_pairs_per_wave(kp.num_local),
-                       ctx->stream);
-    if (fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, ctx->stream);
+                       energy_tab, fixed_tab, ctx->stream);
+    if (fixed)
+        for (int i = 0; i < count; ++i)
+            launch_fixed_to_energy(srcs[i]->d_fixed[srcs[i]->cur], srcs[i]->energy(), B * ctx->num_bins, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     if (ctx->profiling) {
         if (tf.e[2]) FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
@@ -809,6 +869,41 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     ctx->stats.frames++;
     ctx->stats.pairs += kp.num_local;
     ctx->stats.rays += 2ull * kp.num_local;
+    return FS_OK;
+}
+
+int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    return trace_sources(ctx, &s, 1, p);
+}
+
+int fs_compute_energy_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (count < 0 || (count > 0 && !sources)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad source list");
+    if (count == 0) return FS_OK;
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    std::vector<Source*> srcs((size_t)count);
+    for (int32_t i = 0; i < count; ++i) {
+        srcs[(size_t)i] = get_source(ctx, sources[i]);
+        if (!srcs[(size_t)i]) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+        for (int32_t k = 0; k < i; ++k)
+            if (sources[k] == sources[i]) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a source appears twice in the batch");
+    }
+    // One launch sequence for all sources when the frame fits 32-bit subpath indices and the mode is the default
+    // connection strategy; the all-connections modes (one wave per pair already) and oversized batches go source by source
+    const uint64_t P = p ? p->num_rays / 2 : 0;
+    const bool one_launch = p && !(p->flags & (FS_FLAG_ALL_CONNECTIONS | FS_FLAG_MIS_BALANCE)) &&
+                            (uint64_t)count * P <= (1ull << 29);
+    if (one_launch) return trace_sources(ctx, srcs.data(), count, p);
+    for (int32_t i = 0; i < count; ++i) {
+        int rc = trace_sources(ctx, &srcs[(size_t)i], 1, p);
+        if (rc) return rc;
+    }
     return FS_OK;
 }
 

@@ -60,7 +60,10 @@ struct DeviceScene {
 struct KParams {
     uint32_t seed_lo, seed_hi;
     uint32_t pair_begin;   // first global pair index of this rank
-    uint32_t num_local;    // pairs traced by this rank
+    uint32_t num_local;    // pairs traced by this rank (all sources of a batched frame together)
+    uint32_t pairs_per_source;   // == num_local for one source; a batched frame lays its sources' pairs end to end:
+                                 // pair li belongs to source li / pairs_per_source, RNG pair index li % pairs_per_source
+    const float* src_table;      // [sources][3] source positions of a batched frame (device), else null (kp.src)
     int32_t depth;         // max segments per subpath (1..FS_MAX_DEPTH)
     int32_t russian_roulette;
     int32_t cosine;
@@ -139,8 +142,11 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
+// energy_tab / fixed_tab: per-source buffers of a batched frame (device arrays of kp.num_local / kp.pairs_per_source
+// pointers), null for one source (`energy` / `fixed` are used)
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, hipStream_t s);
+                    unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, float* const* energy_tab,
+                    unsigned long long* const* fixed_tab, hipStream_t s);
 // row f3: every forward prefix x every backward prefix of each pair (one wave per pair), uniform MIS weights
 void launch_connect_all(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
                         unsigned long long* fixed, unsigned* queue_head, hipStream_t s);

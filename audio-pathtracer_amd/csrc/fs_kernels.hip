@@ -409,6 +409,11 @@ __device__ __forceinline__ void walker_start(Walker& w, uint32_t g, const KParam
     w.px = w.side ? kp.lis[0] : kp.src[0];
     w.py = w.side ? kp.lis[1] : kp.src[1];
     w.pz = w.side ? kp.lis[2] : kp.src[2];
+    if (kp.src_table) {   // batched frame (wave-uniform): several sources' pairs end to end, same RNG pairs for each
+        const uint32_t sid = w.li / kp.pairs_per_source;
+        w.pair = kp.pair_begin + (w.li - sid * kp.pairs_per_source);
+        if (!w.side) { w.px = kp.src_table[3 * sid]; w.py = kp.src_table[3 * sid + 1]; w.pz = kp.src_table[3 * sid + 2]; }
+    }
     w.nx = 0.f; w.ny = 0.f; w.nz = 0.f;
     w.has_normal = false;
     w.arrived = false;
@@ -530,7 +535,7 @@ constexpr int kPlanItems = 4;   // subpaths per plan-kernel thread
 __device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
     const uint32_t n = kp.num_local;
     const uint32_t side = g >= n ? 1u : 0u;
-    const uint32_t pair = kp.pair_begin + (g - side * n);
+    const uint32_t pair = kp.pair_begin + (g - side * n) % kp.pairs_per_source;   // batched frame: per-source pair index
     int k = 0;
     for (; k < kp.depth; ++k) {
         const uint4 r = philox(pair, ((uint32_t)k << 1) | side, 0, kp.seed_lo, kp.seed_hi);
@@ -949,11 +954,15 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc,
 // pairs_per_wave < 64: sparse waves for small frames — a wave owns that many pairs (its first lanes), the other
 // lanes only help with the shared visibility queries (a frame of a few thousand pairs is otherwise a few waves
 // waiting for their longest traversal).
-template <int B, int LOBES>
+// BATCH: a batched frame (fs_compute_energy_response_batch): the pairs of several sources lie end to end
+// (kp.pairs_per_source each) and every source has its own energy buffer (energy_tab / fixed_tab); a workgroup
+// takes (source, chunk) items and flushes its LDS histogram whenever the source changes.
+template <int B, int LOBES, bool BATCH>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head,
-                                                         int pairs_per_wave) {
+                                                         int pairs_per_wave, float* const* __restrict__ energy_tab,
+                                                         unsigned long long* const* __restrict__ fixed_tab) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
@@ -975,9 +984,11 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     // also the ones without a pair or without a segment to test
     const uint32_t ppw = (uint32_t)pairs_per_wave, per_block = ppw * (kBlock / 64);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
-        const uint32_t li = base + wave * ppw + lane;
-        const bool active = lane < ppw && li < n;
+
+    // one chunk of per_block pairs [first, first + per_block) clipped to `end`, deposits into s_hist / fixed_dst
+    auto chunk = [&](uint32_t first, uint32_t end, unsigned long long* fixed_dst) {
+        const uint32_t li = first + wave * ppw + lane;
+        const bool active = lane < ppw && li < end;
         const uint32_t lc = active ? li : 0u;
         const float4 F = st.end_pos[lc];
         const uint2 Fm = st.end_misc[lc];
@@ -992,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         const bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
         Ray ray = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
         const bool hit = trav_any_shared(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share);
-        if (!active || hit) continue;
+        if (!active || hit) return;
         ++my_deposits;
         // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
         float E[B];
@@ -1020,7 +1031,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
         float fl = floorf(x);
         int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
-        if (!fixed) {
+        if (!fixed_dst) {
             atomicMin(&s_lo, bin);
             atomicMax(&s_hi, bin);
         }
@@ -1030,11 +1041,47 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
             e = (e < kp.energy_clamp) ? e : kp.energy_clamp;          // FMath::Min ARTS.cpp:410
             e *= kp.energy_gain;                                      // ARTS.cpp:413
             e *= kp.norm;                                             // ARTS.cpp:164-170
-            if (fixed)   // deterministic mode: integer sum of 2^-40 quanta — exact, so order- and shard-independent
-                atomicAdd(&fixed[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
+            if (fixed_dst)   // deterministic mode: integer sum of 2^-40 quanta — exact, so order- and shard-independent
+                atomicAdd(&fixed_dst[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
             else
                 atomicAdd(&s_hist[b * nb + bin], e);                  // ds_add_f32
         }
+    };
+    // LDS histogram -> one source's energy buffer (touched bin range only); clear = rearm it for the next source
+    auto flush = [&](float* dst, bool clear) {
+        __syncthreads();
+        const int lo = s_lo, hi = s_hi;
+        if (hi >= lo) {
+            const int span = hi - lo + 1;
+            for (int i = threadIdx.x; i < B * span; i += kBlock) {
+                int b = i / span, bin = lo + (i - b * span);
+                float v = s_hist[b * nb + bin];
+                if (v != 0.0f) atomicAdd(&dst[b * nb + bin], v);      // global_atomic_add_f32
+                if (clear) s_hist[b * nb + bin] = 0.0f;
+            }
+        }
+        if (clear) {
+            __syncthreads();
+            if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; }
+            __syncthreads();
+        }
+    };
+
+    if (BATCH) {
+        const uint32_t nps = kp.pairs_per_source, sources = n / nps;
+        const uint32_t chunks = (nps + per_block - 1) / per_block;   // per source
+        int cur = -1;
+        for (uint32_t it = blockIdx.x; it < chunks * sources; it += gridDim.x) {
+            const uint32_t sid = it / chunks;
+            if ((int)sid != cur) {
+                if (cur >= 0 && !fixed_tab) flush(energy_tab[cur], true);
+                cur = (int)sid;
+            }
+            chunk(sid * nps + (it - sid * chunks) * per_block, (sid + 1) * nps, fixed_tab ? fixed_tab[sid] : nullptr);
+        }
+        if (cur >= 0 && !fixed_tab) flush(energy_tab[cur], false);
+    } else {
+        for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) chunk(base, n, fixed);
     }
     {   // work counters: summed per wave, then per workgroup in LDS — one global atomic per workgroup (thousands of
         // atomics on one address cost the kernel ~10 %)
@@ -1048,13 +1095,15 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         if (s_dep) atomicAdd(&counters[2], (unsigned long long)s_dep);
         if (blockIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
     }
-    const int lo = s_lo, hi = s_hi;
-    if (hi < lo) return;
-    const int span = hi - lo + 1;
-    for (int i = threadIdx.x; i < B * span; i += kBlock) {
-        int b = i / span, bin = lo + (i - b * span);
-        float v = s_hist[b * nb + bin];
-        if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);           // global_atomic_add_f32
+    if (!BATCH) {
+        const int lo = s_lo, hi = s_hi;
+        if (hi < lo) return;
+        const int span = hi - lo + 1;
+        for (int i = threadIdx.x; i < B * span; i += kBlock) {
+            int b = i / span, bin = lo + (i - b * span);
+            float v = s_hist[b * nb + bin];
+            if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);       // global_atomic_add_f32
+        }
     }
 }
 
@@ -1880,22 +1929,25 @@ inline void allow_lds(K kernel, size_t bytes) {
 
 template <int B>
 void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                      unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, hipStream_t s) {
+                      unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, float* const* energy_tab,
+                      unsigned long long* const* fixed_tab, hipStream_t s) {
     if (kp.num_local == 0) return;
     if (pairs_per_wave < 1 || pairs_per_wave > 64) pairs_per_wave = 64;
     const uint32_t per_block = (uint32_t)pairs_per_wave * (kBlock / 64);
-    uint32_t blocks = (kp.num_local + per_block - 1) / per_block;
+    const bool batch = energy_tab != nullptr;
+    uint32_t blocks = batch ? (kp.num_local / kp.pairs_per_source) * ((kp.pairs_per_source + per_block - 1) / per_block)
+                            : (kp.num_local + per_block - 1) / per_block;
     if (blocks > 1024) blocks = 1024;
     size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins + kShareAnyLdsBytes;
-    if (kp.lobes) {
-        allow_lds(connect_kernel<B, 1>, lds);
-        hipLaunchKernelGGL((connect_kernel<B, 1>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head,
-                           pairs_per_wave);
-    } else {
-        allow_lds(connect_kernel<B, 0>, lds);
-        hipLaunchKernelGGL((connect_kernel<B, 0>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head,
-                           pairs_per_wave);
-    }
+#define FS_LAUNCH_CONNECT(L, BT)                                                                                     \
+    do {                                                                                                             \
+        allow_lds(connect_kernel<B, L, BT>, lds);                                                                    \
+        hipLaunchKernelGGL((connect_kernel<B, L, BT>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, \
+                           queue_head, pairs_per_wave, energy_tab, fixed_tab);                                       \
+    } while (0)
+    if (batch) { if (kp.lobes) FS_LAUNCH_CONNECT(1, true); else FS_LAUNCH_CONNECT(0, true); }
+    else { if (kp.lobes) FS_LAUNCH_CONNECT(1, false); else FS_LAUNCH_CONNECT(0, false); }
+#undef FS_LAUNCH_CONNECT
 }
 
 }  // namespace
@@ -1994,16 +2046,17 @@ void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int 
 }
 
 void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, hipStream_t s) {
+                    unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, float* const* energy_tab,
+                    unsigned long long* const* fixed_tab, hipStream_t s) {
     switch (B) {
-        case 1: launch_connect_t<1>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
-        case 2: launch_connect_t<2>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
-        case 3: launch_connect_t<3>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
-        case 4: launch_connect_t<4>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
-        case 5: launch_connect_t<5>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
-        case 6: launch_connect_t<6>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
-        case 7: launch_connect_t<7>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
-        default: launch_connect_t<8>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, s); break;
+        case 1: launch_connect_t<1>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
+        case 2: launch_connect_t<2>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
+        case 3: launch_connect_t<3>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
+        case 4: launch_connect_t<4>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
+        case 5: launch_connect_t<5>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
+        case 6: launch_connect_t<6>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
+        case 7: launch_connect_t<7>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
+        default: launch_connect_t<8>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
     }
 }
 

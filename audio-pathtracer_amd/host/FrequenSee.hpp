@@ -131,7 +131,16 @@ public:
         Check(fs_compute_energy_response(Ctx_, Src.Handle_, &Params, EnergyOut ? EnergyOut->data() : nullptr));
         Check(fs_reconstruct_impulse_response(Ctx_, Src.Handle_, &Params));
     }
-    void ForceUpdateSources() { for (auto* s : ActiveSources) UpdateSource(*s); }   // .cpp:883-886
+    // .cpp:883-886 — every active source; one batched frame on the device (fs_compute_energy_response_batch_async)
+    void ForceUpdateSources() {
+        if (ActiveSources.empty()) return;
+        Commit();
+        std::vector<fs_source> H;
+        for (auto* s : ActiveSources) H.push_back(s->Handle_);
+        Check(fs_compute_energy_response_batch_async(Ctx_, H.data(), (int32_t)H.size(), &Params));
+        for (auto* s : ActiveSources) Check(fs_reconstruct_impulse_response_async(Ctx_, s->Handle_, &Params));
+        Check(fs_synchronize(Ctx_));
+    }
     void Tick(float /*DeltaTime*/) { if (!ActiveSources.empty()) ForceUpdateSources(); }   // .cpp:55-85 (caller drives every frame)
 
     int NumBands() const { return NumBands_; }

@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--fixed-seed", action="store_true",
                     help="every frame traces the same sample set (default: a new RNG seed every frame, as an application "
                          "does; the frame checked against the oracle uses --seed itself)")
+    ap.add_argument("--no-batch", action="store_true",
+                    help="multi-source workloads: one context and one frame per source, all in flight, instead of one "
+                         "batched frame over this rank's sources (fs_compute_energy_response_batch_async)")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the extra region that times the same frames with two in flight")
     args = ap.parse_args()
@@ -155,8 +158,10 @@ def main():
     lanes = []   # one (stream, context, source) per frame in flight; multi-source: one per source of this rank,
     #              the sources dealt round-robin to `--inflight` contexts (each context = one compute + one tail stream)
     ctxs = []
+    batch_sources = bool(n_sources) and not args.no_batch and len(my_sources) > 1
     if args.inflight is None:
-        args.inflight = len(my_sources) if n_sources else 1   # independent sources: all in flight (measured best)
+        # independent sources: one batched frame on one context (measured best), else all sources in flight
+        args.inflight = (1 if batch_sources else len(my_sources)) if n_sources else 1
     n_ctx = max(1, args.inflight) if not n_sources else max(1, min(args.inflight, len(my_sources)))
     for i in range(n_ctx):
         st_i = torch.cuda.current_stream() if i == 0 else torch.cuda.Stream()
@@ -184,6 +189,11 @@ def main():
             frame_no[0] += 1
             if not args.fixed_seed:
                 p.seed = args.seed + frame_no[0]
+            if batch_sources and len(ctxs) == 1:   # all of this rank's sources in one traced frame
+                lanes[0][1].compute_energy_response_batch_async([s_i for _, _, s_i in lanes], p)
+                for _, c, s_i in lanes:
+                    c.reconstruct_impulse_response_async(s_i, p)
+                return
             for _, c, s_i in lanes:
                 c.compute_energy_response_async(s_i, p)
                 c.reconstruct_impulse_response_async(s_i, p)
@@ -291,7 +301,8 @@ def main():
                        "rays_per_frame": total_rays, "pairs_per_frame": total_rays // 2, "depth": depth,
                        "bands": bands, "triangles": sc.num_triangles,
                        "sharding": f"{n_sources} sources round-robin over {world} ranks" if n_sources else f"pairs/{world}",
-                       "frames_in_flight": len(ctxs)},
+                       "frames_in_flight": len(ctxs),
+                       **({"sources_per_batched_frame": len(lanes)} if batch_sources and len(ctxs) == 1 else {})},
             "ir_frames_per_s": args.steps / elapsed,
             # the same rate in the other units one might mean by "rays" (device-side counters)
             "pairs_per_s": total_rays / 2 * args.steps / elapsed,

@@ -178,6 +178,13 @@ int fs_listener_set_position(fs_context* ctx, const float xyz[3]);
 int fs_compute_energy_response(fs_context* ctx, fs_source src, const fs_params* params, float* energy_out);
 /* Same, enqueue only (no host sync). */
 int fs_compute_energy_response_async(fs_context* ctx, fs_source src, const fs_params* params);
+/* Several sources in ONE traced frame — UpdateSource over ActiveSources (ForceUpdateSources, ARTS.cpp:60-68, :128-195).
+ * Every listed source gets exactly the result of its own fs_compute_energy_response_async(ctx, src, params) call (same
+ * pairs, same random streams), but the device runs one plan / walk / connect sequence over all of them: many small
+ * frames become one large one (8 sources x 131 072 rays: 1.9x the rays/s of eight separate frames).  Afterwards each
+ * source is reconstructed as usual.  The all-connections modes fall back to one frame per source.  A source may appear
+ * only once in the list. */
+int fs_compute_energy_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 /* Device pointer of the energy buffer [B][num_bins] fp32 the source's CURRENT frame deposits into.  A source
  * owns two such buffers and every fs_compute_energy_response* switches to the other one, so that the tail of
  * frame f (reduce, reconstruct, publish) overlaps the tracing of frame f+1: query the pointer per frame. */

@@ -341,6 +341,69 @@ def test_frame_shapes_reuse_the_subpath_state(pkg, oracle_mod, scene_factory):
     ctx.close()
 
 
+BATCH_CASES = [
+    # id, scene, bands, rays per source, depth, sources, extra params
+    ("three_sources_ragged", "starter_room", 4, 2 * 777, 8, 3, {}),
+    ("eight_sources_mine", "old_mine", 8, 8192, 8, 8, {}),
+    ("two_sources_dense", "old_mine", 8, 131072, 6, 2, {}),
+    ("deterministic", "starter_room", 4, 4096, 8, 3, {"flags": 8}),
+    ("lobes_no_rr", "starter_room", 4, 2048, 5, 4, {"flags": 64, "russian_roulette": 0}),
+    ("all_connections_fallback", "shoebox", 1, 512, 4, 3, {"flags": 16}),
+    ("one_source", "shoebox", 1, 1024, 6, 1, {}),
+]
+
+
+@pytest.mark.parametrize("cid,name,bands,rays,depth,nsrc,extra", BATCH_CASES, ids=[c[0] for c in BATCH_CASES])
+def test_batched_sources_equal_separate_frames(pkg, oracle_mod, scene_factory, cid, name, bands, rays, depth, nsrc, extra):
+    """fs_compute_energy_response_batch_async (UpdateSource over ActiveSources in one traced frame): every source gets
+    the result of its own call — identical occupied bins, energies within the atomics' rounding (bit-identical in
+    deterministic mode), the same work counters in total — and matches the oracle run per source position."""
+    sc = scene_factory(name, bands)
+    ctx, src0 = make_ctx(pkg, sc)
+    rng = np.random.default_rng(nsrc)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    positions = [sc.source] + [(sc.source + rng.uniform(-0.1, 0.1, 3) * (hi - lo)).astype(np.float32) for _ in range(nsrc - 1)]
+    srcs = [src0] + [ctx.create_source(pos) for pos in positions[1:]]
+    p = pkg.default_params(num_rays=rays, depth=depth, seed=77, **extra)
+    separate = []
+    ctx.reset_stats()
+    for s_ in srcs:
+        separate.append(ctx.compute_energy_response(s_, p).copy())
+    st_sep = ctx.stats()
+    ctx.reset_stats()
+    ctx.compute_energy_response_batch_async(srcs, p)
+    for s_ in srcs:
+        ctx.reconstruct_impulse_response_async(s_, p)
+    ctx.synchronize()
+    st_bat = ctx.stats()
+    batched = [ctx.energy_buffer(s_).copy() for s_ in srcs]
+    irs = [ctx.impulse_response(s_, 0).copy() for s_ in srcs]
+    assert all(st_sep[k] == st_bat[k] for k in ("segments", "connections_tested", "deposits"))
+    oflags = extra.get("flags", 0) & ~8
+    okw = {k: v for k, v in extra.items() if k != "flags"}
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    for i, s_ in enumerate(srcs):
+        assert np.array_equal(batched[i] != 0, separate[i] != 0), i
+        if extra.get("flags", 0) & 8:
+            assert np.array_equal(batched[i], separate[i]), i
+        else:
+            assert max(rel_rms(batched[i][b], separate[i][b].astype(np.float64)) for b in range(bands)) <= TIGHT_TOL
+        e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=77, flags=oflags, **okw),
+                                           positions[i], sc.listener)
+        if cnt.connected:
+            for b in range(bands):
+                assert rel_rms(batched[i][b], e64[b]) <= TIGHT_TOL, (i, b)
+        # the per-source reconstruct behind the batch: IR of the band-mean energy
+        mean = (batched[i].sum(axis=0, dtype=np.float32) / np.float32(bands)).astype(np.float32) if bands > 1 else batched[i][0]
+        want = oracle_mod.reconstruct(mean)
+        assert np.abs(irs[i] - want).max() <= IR_TOL * max(np.abs(want).max(), 1e-30)
+    if nsrc > 1:
+        assert not np.array_equal(batched[0], batched[1])            # different positions, different results
+    with pytest.raises(pkg.FrequenSeeError):
+        ctx.compute_energy_response_batch_async([srcs[0], srcs[0]], p)
+    ctx.close()
+
+
 def test_empty_scene_and_zero_rays(pkg, scene_factory):
     ctx = pkg.Context(num_bands=2)
     with pytest.raises(pkg.FrequenSeeError) as ei:          # not committed
