@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""API state-machine stress (product path only): a random sequence of frames in all modes, moving geometry, energy
+"""API state-machine stress (product path only): a random sequence of frames in all modes (also batched over three
+sources), moving geometry, energy
 helpers, installed IRs, reverb callbacks and stats on one context, with checkpoints where the energy of a frame is
 compared with the same frame computed synchronously on a second, freshly synchronised context that saw the same
 geometry.  usage: python tools/stress.py [iterations=400] [seed=1]"""
@@ -24,20 +25,43 @@ def main(iters=400, seed=1):
     tri = sc.triangles.copy()
     T = tri.shape[0]
     ctxs = []
+    tau, sigma = pkg.scenes.material_lobes(sc)
     for _ in range(2):
         c = pkg.Context(num_bands=4)
-        c.set_scene(tri, sc.material_ids, sc.absorption, object_ids=sc.object_ids)
+        c.set_scene(tri, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma, object_ids=sc.object_ids)
         c.set_listener(sc.listener)
         ctxs.append((c, c.create_source(sc.source)))
     (a, sa), (b, sb) = ctxs
+    # two more sources on both contexts: batched frames on `a` against one-by-one frames on `b`
+    extra_pos = [sc.source + np.array([150, -80, 20], np.float32), sc.source + np.array([-200, 120, -30], np.float32)]
+    extra_a = [a.create_source(q) for q in extra_pos]
+    extra_b = [b.create_source(q) for q in extra_pos]
     a.reverb_init(sa, 1024)
-    flags_pool = [0, 0, 0, pkg._capi.FLAG_DETERMINISTIC, pkg._capi.FLAG_ALL_CONNECTIONS,
-                  pkg._capi.FLAG_ALL_CONNECTIONS | pkg._capi.FLAG_DETERMINISTIC, pkg._capi.FLAG_COSINE_SAMPLING]
+    F = pkg._capi
+    flags_pool = [0, 0, 0, F.FLAG_DETERMINISTIC, F.FLAG_ALL_CONNECTIONS, F.FLAG_ALL_CONNECTIONS | F.FLAG_DETERMINISTIC,
+                  F.FLAG_COSINE_SAMPLING, F.FLAG_MIS_BALANCE, F.FLAG_MATERIAL_LOBES, F.FLAG_MATERIAL_LOBES | F.FLAG_ALL_CONNECTIONS,
+                  F.FLAG_MATERIAL_LOBES | F.FLAG_DETERMINISTIC]
     checks = 0
     last = None
     for it in range(iters):
-        op = rng.integers(0, 10)
-        if op <= 4:                                             # a frame, asynchronously
+        op = rng.integers(0, 11)
+        if op == 10:                                            # a batched frame over three sources, checked at once
+            p = pkg.default_params(num_rays=int(rng.choice([2, 1554, 4096, 32768])), depth=int(rng.choice([1, 4, 8])),
+                                   seed=int(rng.integers(1, 1 << 40)), dist_divisor=100.0, flags=int(rng.choice(flags_pool)),
+                                   russian_roulette=int(rng.random() < 0.85))
+            group_a, group_b = [sa] + extra_a, [sb] + extra_b
+            a.compute_energy_response_batch_async(group_a, p)
+            for h in group_a:
+                a.reconstruct_impulse_response_async(h, p)
+            for ha, hb in zip(group_a, group_b):
+                got = a.energy_buffer(ha)
+                want = b.compute_energy_response(hb, p)
+                for k in range(4):
+                    if want[k].any():
+                        assert rel_rms(got[k], want[k]) <= 2e-5, (it, "batch", k, rel_rms(got[k], want[k]))
+            checks += 1
+            last = None
+        elif op <= 4:                                           # a frame, asynchronously
             p = pkg.default_params(num_rays=int(rng.choice([2, 512, 4096, 16384])), depth=int(rng.choice([1, 4, 8, 0])),
                                    seed=int(rng.integers(1, 1 << 40)), dist_divisor=100.0, flags=int(rng.choice(flags_pool)),
                                    russian_roulette=int(rng.random() < 0.85))
