@@ -121,6 +121,9 @@ struct fs_context {
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
     WalkLaunch walk{2, 256, 2, nullptr, 1, nullptr};   // variant 2 = wave work sharing (default), 0 = one subpath per lane, 1 = persistent
     int refill_threshold = 16;
+    int fuse_connect = 0;          // FS_FUSE_CONNECT=1: walk + connect as one kernel (experiment, slower: see walk_connect_kernel)
+    unsigned* d_pair_done = nullptr;   // per-pair arrival counters of the fused kernel (parity, never reset)
+    uint32_t cap_pairs_done = 0;
     int walk_rays_per_wave = 0;    // BDPT walk: subpaths per wave, 0 = by frame size (FS_WALK_RAYS_PER_WAVE; 64 = dense waves)
     int connect_pairs_per_wave = 0;   // connect kernel: pairs per wave, 0 = by frame size (FS_CONNECT_PAIRS_PER_WAVE; 64 = dense)
     int sound_rays_per_wave = 4;   // legacy tracer: rays per wave, the other lanes help (FS_SOUND_RAYS_PER_WAVE; 64 = no sharing)
@@ -460,6 +463,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
     if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_FUSE_CONNECT")) ctx->fuse_connect = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_CONNECT_PAIRS_PER_WAVE")) ctx->connect_pairs_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
@@ -487,6 +491,7 @@ int fs_context_destroy(fs_context* ctx) {
             if (p) (void)hipFree(p);
         if (ctx->fft_graph) (void)hipGraphExecDestroy(ctx->fft_graph);
         if (ctx->h_fft_stage) (void)hipHostFree(ctx->h_fft_stage);
+        if (ctx->d_pair_done) (void)hipFree(ctx->d_pair_done);
         if (ctx->d_batch) (void)hipFree(ctx->d_batch);
         if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
         for (hipEvent_t e : ctx->ev_batch) if (e) (void)hipEventDestroy(e);
@@ -848,9 +853,25 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     WalkLaunch wl = ctx->walk;
     wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
-    launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+    // Opt-in experiment (FS_FUSE_CONNECT=1; default connection strategy, one source, dense waves): walk and connect as
+    // ONE kernel, the later subpath of a pair connects it.  Measured slower (0.68 vs 0.46 ms per frame), see the kernel.
+    bool fused = false;
+    if (ctx->fuse_connect && !all_conn && !batch && wl.variant == 2 && wl.rays_per_wave >= 64) {
+        if (kp.num_local > ctx->cap_pairs_done) {
+            if (ctx->d_pair_done) (void)hipFree(ctx->d_pair_done);
+            ctx->d_pair_done = nullptr; ctx->cap_pairs_done = 0;
+            FS_HIP(ctx, hipMalloc((void**)&ctx->d_pair_done, sizeof(unsigned) * (size_t)kp.num_local));
+            FS_HIP(ctx, hipMemsetAsync(ctx->d_pair_done, 0, sizeof(unsigned) * (size_t)kp.num_local, ctx->stream));
+            ctx->cap_pairs_done = kp.num_local;
+        }
+        fused = launch_walk_connect(B, ctx->scene, kp, st, wl, perm, ctx->d_pair_done, s->energy(),
+                                    fixed ? s->d_fixed[s->cur] : nullptr, ctx->stream);
+    }
+    if (!fused) launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
-    if (all_conn)
+    if (fused) {
+        // connected inside the walk kernel
+    } else if (all_conn)
         launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
                            ctx->stream);
     else

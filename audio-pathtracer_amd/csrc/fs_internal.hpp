@@ -139,6 +139,10 @@ constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
 // nullptr when no plan applies (the caller then clears the energy buffer itself)
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words, hipStream_t s);
+// walk + connect in one kernel (default connection strategy, one source, dense waves): the later subpath of a pair
+// connects it; pair_done = per-pair arrival counters (never reset).  false = not applicable, nothing launched.
+bool launch_walk_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
+                         const uint32_t* perm, unsigned* pair_done, float* energy, unsigned long long* fixed, hipStream_t s);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead

@@ -815,6 +815,174 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
     walker_finish(w, st);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// walk_connect_kernel: the walk with ConnectSubpaths + EvaluatePath + deposit fused behind it.
+// A separate connect kernel starts only after the last walk has ended, runs as one thin round of waves and is
+// followed by a launch gap.  Here the subpath that ends LATER connects its pair right away, inside the walk
+// kernel: every subpath publishes its end state, then increments its pair's arrival counter (release); the second
+// arrival (acquire) reads the partner's records and runs the visibility query — shared by the whole wave like any
+// other query — EvaluatePath and the deposit (global atomics: a wave deposits a few dozen values, spread over the
+// kernel's duration).  The arrival counter is never reset: every frame adds exactly 2 per pair, so an odd old
+// value marks the second arrival.  The last workgroup to finish rearms the frame scratch (the connect kernel's
+// other duty).  Same paths, same arithmetic, same sums as the two-kernel sequence (parity suite passes with it).
+// Bands are a run-time loop here (one instantiation per LOBES value instead of eight more).
+// NOT the default (FS_FUSE_CONNECT=1): measured 0.655 ms against 0.362 + 0.074 ms for the two kernels.  The partner's
+// records may sit dirty in ANOTHER XCD's L2 (the eight L2s are not coherent with each other inside a kernel), so the
+// release / acquire pair below costs every wave an L2 write-back and invalidate — which the kernel boundary of the
+// two-kernel sequence provides once, for free: with the two fences compiled out (results then unreliable) the kernel
+// takes 0.453 ms, and that is still no faster than the two kernels, because two thirds of the connections fall to the
+// longest walks and lengthen exactly the waves the kernel waits for.
+// ---------------------------------------------------------------------------------------------------
+template <int LOBES>
+__device__ __forceinline__ void apply_segment_rt(float (&E)[FS_MAX_BANDS], int B, float nd, uint32_t mat, float prob,
+                                                 const KParams& kp, const DeviceScene& sc) {
+    if (nd < kp.min_seg) return;  // ARTS.cpp:375-378
+    float nd2 = nd * nd;
+    float geo = 1.0f / (4 * kPi * nd2);            // ARTS.cpp:391
+    float pw = powf(prob, kp.prob_exponent);       // ARTS.cpp:398
+    const bool lobes = LOBES != 0;
+    const uint32_t lobe = (lobes && mat != kNoMat) ? ((mat >> kLobeShift) & 3u) : 0u;
+    if (lobes && mat != kNoMat) mat &= 0xFFFFu;
+    bool has = (mat != kNoMat) && ((int32_t)mat < sc.num_materials);
+    const float* coeff = lobes ? sc.lobe_gain + ((size_t)mat * 3 + lobe) * B : sc.absorption + (size_t)mat * B;
+    const bool over_pi = !lobes || lobe == kLobeDiffuse;
+#pragma unroll
+    for (int b = 0; b < FS_MAX_BANDS; ++b) {
+        if (b < B) {
+            float bsdf = 1.0f;                                            // ARTS.cpp:382-386
+            if (has) bsdf = over_pi ? coeff[b] / kPi : coeff[b];
+            float e = E[b];
+            e *= bsdf;
+            e *= geo;
+            e *= expf(-kp.air[b] * nd);                // ARTS.cpp:395-397
+            e /= pw;
+            E[b] = e;
+        }
+    }
+}
+
+template <int LOBES>
+__global__ __launch_bounds__(kBlock) void walk_connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
+                                                              unsigned* __restrict__ scratch,
+                                                              const uint32_t* __restrict__ perm,
+                                                              unsigned* __restrict__ pair_done, int B,
+                                                              float* __restrict__ energy,
+                                                              unsigned long long* __restrict__ fixed) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
+    int* s_stack = s_dyn;
+    __shared__ unsigned s_cnt[kPlanBuckets];
+    __shared__ unsigned s_dep;
+    if (threadIdx.x == 0) s_dep = 0u;
+    if (perm) {
+        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
+    }
+    __syncthreads();
+    const uint32_t n = kp.num_local, total = 2u * n;
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const bool mine = slot < total;
+    int* stack = &s_stack[threadIdx.x];
+    unsigned my_deposits = 0;
+    // ---- the walk (as walk_kernel_shared; lanes beyond the frame only help)
+    Walker w;
+    walker_start(w, mine ? (perm ? planned_subpath(slot, kp.depth, total, s_cnt, perm) : slot) : 0u, kp);
+    Ray ray;
+    bool alive = mine;
+    while (true) {
+        const bool go = alive && walker_next_ray<LOBES>(w, kp, sc, st, ray);
+        if (alive && !go) { walker_finish(w, st); alive = false; }
+        if (__ballot(go) == 0ull) break;
+        Trav T;
+        trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
+        if (go) walker_apply_hit(w, kp, sc, st, ray, T);
+    }
+    // ---- arrival: the later of a pair's two subpaths connects them
+    bool second = false;
+    if (mine) {
+        __threadfence();                                   // release: end state and segment records before the counter
+        second = (atomicAdd(&pair_done[w.li], 1u) & 1u) != 0u;
+        if (second) __threadfence();                       // acquire: the partner's records
+    }
+    {
+        const uint32_t li = w.li;
+        const uint32_t lc = second ? li : 0u;
+        const float4 F = st.end_pos[lc];
+        const uint2 Fm = st.end_misc[lc];
+        const float4 L = st.end_pos[n + lc];
+        const uint2 Lm = st.end_misc[n + lc];
+        // visibility F_k -> B_m - 0.1 * unit(B_m - F_k) (ARTS.cpp:252-254); visible iff NO hit
+        float dx = L.x - F.x, dy = L.y - F.y, dz = L.z - F.z;
+        float l2 = dx * dx + dy * dy + dz * dz;
+        float len = sqrtf(l2);
+        float inv = 1.0f / len;
+        float tmax = len - kp.connect_pullback;
+        const bool has_ray = second && (l2 > 1e-8f) && (tmax > 0.0f);
+        Ray cr = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
+        const bool hit = trav_any_shared(sc, has_ray, cr, tmax, stack, s_dyn + (size_t)sc.stack_rows * kBlock);
+        if (second && !hit) {
+            ++my_deposits;
+            // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
+            float E[FS_MAX_BANDS];
+#pragma unroll
+            for (int b = 0; b < FS_MAX_BANDS; ++b) E[b] = 1.0f;
+            float sd = 0.0f;
+            const int kf = (int)Fm.y, kl = (int)Lm.y;
+            for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
+                const float2 np = st.seg_np[(size_t)j * total + li];
+                sd += np.x;                                               // ARTS.cpp:374
+                apply_segment_rt<LOBES>(E, B, np.x, st.seg_mat[(size_t)j * total + li], np.y, kp, sc);
+            }
+            {                                                             // connection segment: F_k's material/prob
+                float dist = sqrtf(l2);
+                float nd = dist / kp.dist_divisor;
+                sd += nd;
+                apply_segment_rt<LOBES>(E, B, nd, Fm.x, F.w, kp, sc);
+            }
+            for (int j = kl - 1; j >= 0; --j) {                           // listener-side segments B_j+1 -> B_j
+                const float2 np = st.seg_np[(size_t)j * total + n + li];
+                sd += np.x;
+                apply_segment_rt<LOBES>(E, B, np.x, st.seg_mat[(size_t)j * total + n + li], np.y, kp, sc);
+            }
+            float delay = sd / kp.sound_speed;                            // ARTS.cpp:419
+            float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
+            float fl = floorf(x);
+            const int nb = kp.num_bins;
+            int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
+#pragma unroll
+            for (int b = 0; b < FS_MAX_BANDS; ++b) {
+                if (b < B) {
+                    float e = E[b];
+                    e = (e < kp.energy_clamp) ? e : kp.energy_clamp;      // FMath::Min ARTS.cpp:410
+                    e *= kp.energy_gain;                                  // ARTS.cpp:413
+                    e *= kp.norm;                                         // ARTS.cpp:164-170
+                    if (fixed)
+                        atomicAdd(&fixed[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
+                    else
+                        atomicAdd(&energy[b * nb + bin], e);              // global_atomic_add_f32
+                }
+            }
+        }
+    }
+    // ---- work counters, and the last workgroup rearms the frame scratch for the next frame
+    {
+        unsigned d = my_deposits;
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+        if ((threadIdx.x & 63u) == 0u && d) atomicAdd(&s_dep, d);
+    }
+    __syncthreads();
+    __shared__ unsigned s_last;
+    if (threadIdx.x == 0) {
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(scratch + kCounterWord);
+        if (s_dep) atomicAdd(&counters[2], (unsigned long long)s_dep);
+        if (blockIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
+        unsigned* wg_done = scratch + kCounterWord + 6;      // the unused fourth counter doubles as the arrival count
+        s_last = atomicAdd(wg_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+        if (s_last) *wg_done = 0u;
+    }
+    __syncthreads();
+    if (s_last)
+        for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) scratch[i] = 0u;
+}
+
 // Small frames on sparse waves: a frame of a few thousand subpaths is a handful of waves and takes the latency of
 // its longest chain of closest-hit queries.  Here a wave owns only `rays_per_wave` subpaths (its first lanes) and
 // the other lanes help with every query — the legacy tracer's scheme (update_sound_shared_kernel).  The loop is
@@ -1964,6 +2132,24 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
     hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, sort ? wl.perm : nullptr, energy,
                        energy_words);
     return sort ? wl.perm : nullptr;
+}
+
+bool launch_walk_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
+                         const uint32_t* perm, unsigned* pair_done, float* energy, unsigned long long* fixed, hipStream_t s) {
+    const uint32_t lanes = 2u * kp.num_local;
+    if (lanes == 0 || wl.variant != 2 || !pair_done) return false;
+    const uint32_t full = (lanes + kBlock - 1) / kBlock;
+    const size_t lds = stack_bytes(sc) + kShareLdsBytes;   // the visibility query reuses the share area (needs less)
+    if (kp.lobes) {
+        allow_lds(walk_connect_kernel<1>, lds);
+        hipLaunchKernelGGL(walk_connect_kernel<1>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm, pair_done,
+                           B, energy, fixed);
+    } else {
+        allow_lds(walk_connect_kernel<0>, lds);
+        hipLaunchKernelGGL(walk_connect_kernel<0>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm, pair_done,
+                           B, energy, fixed);
+    }
+    return true;
 }
 
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
