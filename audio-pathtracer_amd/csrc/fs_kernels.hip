@@ -259,8 +259,12 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
                 return;
             }
         } else {
-            // closest hit, ties to the lower input index — as selects, not branches
-            const bool better = hit & ((t < T.t) | (T.leaf_index < 0) | ((t == T.t) & (id < T.id)));
+            // closest hit, ties to the lower input index — as selects, not branches.  (t, id) compares as ONE 64-bit
+            // key: t > 0, so its bits order like an integer, and a traversal without a hit yet carries id = ~0
+            // (equivalent to t < T.t | no hit yet | (t == T.t & id < T.id); one v_cmp_lt_u64 instead of five compares)
+            const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | id;
+            const unsigned long long cur = ((unsigned long long)__float_as_uint(T.t) << 32) | T.id;
+            const bool better = hit & (key < cur);
             T.t = better ? t : T.t;
             T.leaf_index = better ? T.tri_i : T.leaf_index;
             T.id = better ? id : T.id;
