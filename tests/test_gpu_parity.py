@@ -341,6 +341,32 @@ def test_frame_shapes_reuse_the_subpath_state(pkg, oracle_mod, scene_factory):
     ctx.close()
 
 
+def test_force_update_sources_batches_all_active_sources(pkg, oracle_mod, scene_factory):
+    """ForceUpdateSources / Tick of the mirrored subsystem (ARTS.cpp:55-85, 883-886) update every active source — here as
+    one batched frame: each component ends up with the energy and IR of its own UpdateSource."""
+    sc = scene_factory("starter_room", 4)
+    sub = pkg.AudioRayTracingSubsystem(num_bands=4)
+    sub.RegisterGeometry(sc.triangles, sc.material_ids)
+    sub.SetMaterials(sc.absorption)
+    sub.SetListenerLocation(sc.listener)
+    comps = []
+    for off in ((0, 0, 0), (180, -60, 30), (-250, 140, -20)):
+        c = pkg.FrequenSeeAudioComponent(sc.source + np.array(off, np.float32))
+        c.OnRegister(sub)
+        comps.append(c)
+    sub.params = pkg.default_params(num_rays=4096, depth=8, seed=5)
+    one_by_one = [sub.UpdateSource(c, sub.params).copy() for c in comps]
+    irs = [c.GetImpulseResponse()[0].copy() for c in comps]
+    for c in comps:
+        c.FlushEnergyBuffer()
+    sub.Tick(0.016)
+    for c, e, ir in zip(comps, one_by_one, irs):
+        got = c.EnergyBuffer.reshape(e.shape)
+        assert np.array_equal(got != 0, e != 0) and max(rel_rms(got[b], e[b].astype(np.float64)) for b in range(4)) <= TIGHT_TOL
+        assert np.abs(c.GetImpulseResponse()[0] - ir).max() <= IR_TOL * max(np.abs(ir).max(), 1e-30)
+    assert not np.array_equal(one_by_one[0], one_by_one[1])
+
+
 def test_fused_walk_connect_kernel_matches(pkg, oracle_mod, scene_factory, monkeypatch):
     """The opt-in one-kernel walk + connect (FS_FUSE_CONNECT=1; not the default, it is slower) deposits the same paths:
     oracle parity and identical counters, also across frames of changing size (the per-pair arrival counters are
