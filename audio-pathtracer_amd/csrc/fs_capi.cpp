@@ -119,11 +119,8 @@ struct fs_context {
     unsigned long long host_segments = 0;   // walk segments of frames without a plan pass (roulette off), since the last reset
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
-    WalkLaunch walk{2, 256, 2, nullptr, 1, nullptr};   // variant 2 = wave work sharing (default), 0 = one subpath per lane, 1 = persistent
-    int refill_threshold = 16;
-    int fuse_connect = 0;          // FS_FUSE_CONNECT=1: walk + connect as one kernel (experiment, slower: see walk_connect_kernel)
-    unsigned* d_pair_done = nullptr;   // per-pair arrival counters of the fused kernel (parity, never reset)
-    uint32_t cap_pairs_done = 0;
+    WalkLaunch walk{2, 256, nullptr, 1, nullptr};   // variant 2 = wave work sharing
+    size_t lds_limit = 64 * 1024;  // dynamic LDS a workgroup may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int walk_rays_per_wave = 0;    // BDPT walk: subpaths per wave, 0 = by frame size (FS_WALK_RAYS_PER_WAVE; 64 = dense waves)
     int connect_pairs_per_wave = 0;   // connect kernel: pairs per wave, 0 = by frame size (FS_CONNECT_PAIRS_PER_WAVE; 64 = dense)
     int sound_rays_per_wave = 4;   // legacy tracer: rays per wave, the other lanes help (FS_SOUND_RAYS_PER_WAVE; 64 = no sharing)
@@ -459,11 +456,13 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0)
         ctx->walk.num_cus = cus;
-    if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::max(0, std::min(2, std::atoi(v)));
-    if (const char* v = std::getenv("FS_WALK_BLOCKS_PER_CU")) ctx->walk.blocks_per_cu = std::max(1, std::min(5, std::atoi(v)));
-    if (const char* v = std::getenv("FS_REFILL_THRESHOLD")) ctx->refill_threshold = std::max(1, std::min(64, std::atoi(v)));
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c.device) == hipSuccess && lds > 0)
+        ctx->lds_limit = (size_t)lds;
+#ifdef FS_EXPERIMENTS
+    if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
+#endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
-    if (const char* v = std::getenv("FS_FUSE_CONNECT")) ctx->fuse_connect = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_CONNECT_PAIRS_PER_WAVE")) ctx->connect_pairs_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
@@ -491,7 +490,6 @@ int fs_context_destroy(fs_context* ctx) {
             if (p) (void)hipFree(p);
         if (ctx->fft_graph) (void)hipGraphExecDestroy(ctx->fft_graph);
         if (ctx->h_fft_stage) (void)hipHostFree(ctx->h_fft_stage);
-        if (ctx->d_pair_done) (void)hipFree(ctx->d_pair_done);
         if (ctx->d_batch) (void)hipFree(ctx->d_batch);
         if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
         for (hipEvent_t e : ctx->ev_batch) if (e) (void)hipEventDestroy(e);
@@ -548,6 +546,14 @@ int fs_scene_commit(fs_context* ctx) {
     build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(), ctx->h_obj.size() == (size_t)ctx->T && ctx->T > 0 ? ctx->h_obj.data() : nullptr,
               ctx->T, ctx->bvh);
     if (ctx->bvh.stack_need > kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH needs a deeper traversal stack");
+    {   // the traversal kernels keep stack + [bands][bins] histogram + work-sharing area in LDS: fail here, with a
+        // message, rather than with a launch error on every frame
+        const size_t need = traversal_lds_bytes(std::max(ctx->bvh.stack_need, 2) + kStackSlack, ctx->cfg.num_bands, ctx->num_bins);
+        if (need > ctx->lds_limit)
+            return ctx->fail(FS_ERR_INVALID_ARGUMENT, "scene + energy histogram need " + std::to_string(need) +
+                             " B of LDS per workgroup, the device offers " + std::to_string(ctx->lds_limit) +
+                             " (fewer bins: a longer bin_duration / shorter simulated_duration, or fewer bands)");
+    }
     size_t nb = ctx->bvh.nodes.size() * sizeof(NodeQ4), tb = ctx->bvh.tris.size() * sizeof(Tri64);
     size_t mb = ctx->h_absorption.size() * sizeof(float);
     if (nb) {
@@ -608,6 +614,9 @@ int fs_scene_commit(fs_context* ctx) {
     ctx->scene.num_tris = ctx->T;
     ctx->scene.num_materials = ctx->M;
     ctx->scene.stack_rows = std::max(ctx->bvh.stack_need, 2) + kStackSlack;
+#ifdef FS_EXPERIMENTS   // occupancy experiments only: fewer rows than the tree's worst case (an overflowing lane corrupts the share area)
+    if (const char* v = std::getenv("FS_UNSAFE_STACK_ROWS")) ctx->scene.stack_rows = std::max(4, std::atoi(v));
+#endif
     ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
     ctx->stats.triangles = (uint32_t)ctx->T;
     ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;
@@ -768,7 +777,6 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     std::memcpy(kp.src, s->pos, sizeof(kp.src));
     std::memcpy(kp.lis, ctx->listener, sizeof(kp.lis));
     kp.num_bins = ctx->num_bins;
-    kp.refill_threshold = ctx->refill_threshold;
 
     kp.lobes = (p->flags & FS_FLAG_MATERIAL_LOBES) ? 1 : 0;
     const bool mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
@@ -853,25 +861,9 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     WalkLaunch wl = ctx->walk;
     wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
-    // Opt-in experiment (FS_FUSE_CONNECT=1; default connection strategy, one source, dense waves): walk and connect as
-    // ONE kernel, the later subpath of a pair connects it.  Measured slower (0.68 vs 0.46 ms per frame), see the kernel.
-    bool fused = false;
-    if (ctx->fuse_connect && !all_conn && !batch && wl.variant == 2 && wl.rays_per_wave >= 64) {
-        if (kp.num_local > ctx->cap_pairs_done) {
-            if (ctx->d_pair_done) (void)hipFree(ctx->d_pair_done);
-            ctx->d_pair_done = nullptr; ctx->cap_pairs_done = 0;
-            FS_HIP(ctx, hipMalloc((void**)&ctx->d_pair_done, sizeof(unsigned) * (size_t)kp.num_local));
-            FS_HIP(ctx, hipMemsetAsync(ctx->d_pair_done, 0, sizeof(unsigned) * (size_t)kp.num_local, ctx->stream));
-            ctx->cap_pairs_done = kp.num_local;
-        }
-        fused = launch_walk_connect(B, ctx->scene, kp, st, wl, perm, ctx->d_pair_done, s->energy(),
-                                    fixed ? s->d_fixed[s->cur] : nullptr, ctx->stream);
-    }
-    if (!fused) launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+    launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
-    if (fused) {
-        // connected inside the walk kernel
-    } else if (all_conn)
+    if (all_conn)
         launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
                            ctx->stream);
     else

@@ -10,6 +10,10 @@
 
 #include "../../include/frequensee.h"
 
+#if defined(FS_TRAV_STATS) && !defined(FS_EXPERIMENTS)
+#define FS_EXPERIMENTS   // the traversal statistics are recorded by the one-subpath-per-lane walk kernel
+#endif
+
 namespace fs {
 
 // ---- device data layout (HBM) --------------------------------------------------------------------
@@ -39,9 +43,13 @@ struct alignas(16) Tri64 {
 static_assert(sizeof(Tri64) == 64, "Tri64 must be 64 B");
 
 // Per-lane traversal stack in LDS: DeviceScene.stack_rows rows of kBlock ints, sized at run time from the committed
-// tree (its worst-case need + 2 rows that absorb the unconditional pushes), passed as dynamic shared memory.
+// tree (its worst-case need + kStackSlack), passed as dynamic shared memory.  A node visit that pushes writes its
+// three candidate entries at sp .. sp + hits - 2 — never above the new top — so the worst-case need itself would do;
+// one spare row is kept.  LDS size matters beyond occupancy: the walk workgroups of frame f+1 share the CUs with the
+// reconstruct workgroups of frame f (tail stream, 4 KB of LDS each), and 3 x walk + 1 x reconstruct must fit the CU's
+// 160 KB or the third walk workgroup waits (measured: 52 224 B of dynamic LDS 0.356 ms, 51 200 B 0.315 ms).
 constexpr int kStackDepth = 64;   // largest worst-case stack need the builder accepts before it rebuilds shallower
-constexpr int kStackSlack = 2;
+constexpr int kStackSlack = 1;
 constexpr int kBlock = 256;       // 4 waves of 64 lanes
 
 struct DeviceScene {
@@ -54,6 +62,8 @@ struct DeviceScene {
     int32_t num_tris;
     int32_t num_materials;
     int32_t stack_rows;       // LDS stack rows per lane for this tree (see kStackDepth)
+    const float4* top = nullptr;   // kernel-side only: LDS copy of the first top_nodes nodes (FS_LDS_TOP experiment)
+    int32_t top_nodes = 0;
 };
 
 // per-update constants handed to the kernels by value
@@ -75,7 +85,6 @@ struct KParams {
     float air[FS_MAX_BANDS];
     float src[3], lis[3];
     int32_t num_bins;
-    int32_t refill_threshold;  // persistent walk: lanes waiting before the wave leaves traversal to shade/refill
 };
 
 // legacy forward tracer (UpdateSound) constants and device-side accumulators
@@ -122,10 +131,9 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
 
 // ---- kernel launchers (fs_kernels.hip) -----------------------------------------------------------------
 struct WalkLaunch {
-    int variant;         // 0 = one subpath per lane, 1 = persistent waves + dynamic fetch
+    int variant;         // 2 = wave work sharing (the only one in a default build); 0 = one subpath per lane (FS_EXPERIMENTS)
     int num_cus;         // compute units of the device
-    int blocks_per_cu;   // persistent grid = num_cus * blocks_per_cu workgroups (capped by the work)
-    unsigned* queue_head;  // frame scratch: [0] subpath queue head, then plan counts + cursors; zero at launch
+    unsigned* queue_head;  // frame scratch: [0] unused, then plan counts + cursors; zero at launch
     int plan;            // 1 = sort subpaths by their (RNG-determined) length before walking
     uint32_t* perm;      // [depth + 1][total] subpath indices bucketed by planned length
     int rays_per_wave = 64;   // < 64: sparse waves for small frames (variant 2): a wave owns this many subpaths, the other lanes help
@@ -139,10 +147,6 @@ constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
 // nullptr when no plan applies (the caller then clears the energy buffer itself)
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words, hipStream_t s);
-// walk + connect in one kernel (default connection strategy, one source, dense waves): the later subpath of a pair
-// connects it; pair_done = per-pair arrival counters (never reset).  false = not applicable, nothing launched.
-bool launch_walk_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                         const uint32_t* perm, unsigned* pair_done, float* energy, unsigned long long* fixed, hipStream_t s);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
@@ -165,6 +169,9 @@ constexpr int kReverbRing = 65536;   // per-channel history ring (floats), match
 void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
                    int frame, int literal_tail, hipStream_t s);
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s);
+// dynamic LDS the traversal kernels of a frame need for a tree with `stack_rows` stack rows: the larger of the walk
+// kernel (stack + work-sharing area) and the connect kernels (stack + [bands][bins] histogram + work-sharing area)
+size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins);
 // row f4 (fs_refit.hip): moving geometry without a rebuild.  xyz = `count` new triangles [count][3][3] on the
 // device, written to the leaf-order records through leaf_pos; then one refit launch per tree level, deepest
 // first (node_box = scratch [num_nodes][2] float4 holding each node's fp32 bounds).

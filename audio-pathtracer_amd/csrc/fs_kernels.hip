@@ -7,9 +7,10 @@
 //                      subpath.  Only geometry happens here (RNG, direction, closest hit, hit point); each
 //                      walk step leaves a 12-byte segment record (scaled length, node probability, node
 //                      material) so that EvaluatePath needs no stored path.
-//                        _simple:     one subpath per lane, length-sorted schedule (default)
-//                        _persistent: waves pull subpaths from a queue and refill their lanes (opt-in,
-//                                     FS_WALK_VARIANT=1; measured no faster at the BASELINE frame sizes)
+//                        _shared: one subpath per lane, length-sorted schedule, closest-hit queries shared within
+//                                 the wave (default);  _sparse: the same on waves that own only a few subpaths
+//                                 (small frames).  Round 1's slower variants (persistent waves, fused walk + connect,
+//                                 no sharing) are measured in DESIGN.md section 5 and no longer built.
 //   connect_kernel     ConnectSubpaths (:235-277) any-hit visibility ray per pair; for connected pairs
 //                      EvaluatePath (:360-420) over the segment records in exact path order, clamp/gain
 //                      (:410-413), normalisation (:164-170) and AddEnergyAtDelay
@@ -17,7 +18,7 @@
 //                      flushed with global float atomics (or a u64 fixed-point histogram, deterministic mode).
 //   connect_all_kernel the same for every forward prefix x backward prefix of a pair (draft :518-546, row f3).
 //   reconstruct_kernel ReconstructImpulseResponse (FrequenSeeAudioComponent.cpp:320-380).
-//   update_sound_kernel legacy forward tracer UpdateSound/CastAudioRay/CastDirectAudioRay (:132-306 of
+//   update_sound_shared_kernel legacy forward tracer UpdateSound/CastAudioRay/CastDirectAudioRay (:132-306 of
 //                      FrequenSeeAudioComponent.cpp), reverb_*_kernel the reverb plugin's per-callback convolution
 //                      (FrequenSeeAudioReverbPlugin.cpp:118-213).
 //   trace_rays_kernel  the engine line trace itself (closest / any hit), for tests and tools.
@@ -26,6 +27,9 @@
 // The triangle test, the hit point/normal/offset arithmetic and the sampling maps use a fixed
 // operation order with explicit fmaf and are compiled with -ffp-contract=off: the path geometry is a
 // pure function of (scene, seed, pair index) and does not depend on launch geometry or on the BVH.
+#include <algorithm>
+#include <atomic>
+
 #include "fs_internal.hpp"
 
 namespace fs {
@@ -36,7 +40,29 @@ constexpr uint32_t kNoMat = FS_NO_MATERIAL;
 constexpr uint32_t kLobeDiffuse = 0u, kLobeSpecular = 1u, kLobeTransmit = 2u;
 constexpr int kLobeShift = 16;   // segment record: material id | lobe << 16
 constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
+#ifndef FS_CHILD_ORDER
+#define FS_CHILD_ORDER 0   // closest-hit traversal: 0 = children fully sorted near-first, 1 = nearest first + rest in slot order
+#endif
+#ifndef FS_MASKED_LOADS
+#define FS_MASKED_LOADS 0  // traversal record fetches: 1 = exec-masked inline-asm loads, 0 = every lane loads (dummy record 0)
+#endif
+#ifndef FS_LDS_TOP
+#define FS_LDS_TOP 0       // walk_kernel_shared: number of top-of-tree nodes staged in LDS per workgroup (experiment), 0 = none
+#endif
+#ifndef FS_PREFETCH
+#define FS_PREFETCH 0      // trav_shared: request the next step's records before the work-sharing round (needs FS_MASKED_LOADS)
+#endif
+#if FS_PREFETCH && !FS_MASKED_LOADS
+#error "FS_PREFETCH needs FS_MASKED_LOADS"
+#endif
+#ifndef FS_ANY_ORDER
+#define FS_ANY_ORDER 0     // any-hit traversal: 0 = sorted, 1 = nearest first, 2 = first hit slot (no ordering at all)
+#endif
 constexpr double kFixedScale = 1099511627776.0;   // 2^40: quantum of the deterministic (fixed-point) energy sum
+#ifdef FS_WAVE_TIMELINE   // diagnostic build only (tools/wave_timeline.py): when every walk wave ran and what it spent its cycles on
+__device__ unsigned long long* g_wave_buf;       // [waves][8]: start, end (100 MHz), cycles in traversal, cycles in all, iterations, segments, hw id, slot
+__device__ unsigned long long g_tl_iter;         // scratch the shared traversal loop adds its iteration count to (per lane 0 of a wave)
+#endif
 #ifdef FS_TRAV_STATS
 __device__ unsigned long long g_trav_stats[8];   // [0] step calls, [1] node iterations, [2] node lanes, [3] tri iterations, [4] tri lanes
 __device__ unsigned short* g_step_buf;           // optional [depth][2P]: traversal iterations of every walk segment
@@ -45,8 +71,10 @@ __device__ unsigned short* g_step_buf;           // optional [depth][2P]: traver
 // ---------------------------------------------------------------------------------------------------
 // RNG: Philox4x32-10, counter = (pair, bounce<<1|side, block, 'FS01'), key = seed
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox(uint32_t pair, uint32_t bs, uint32_t block, uint32_t k0, uint32_t k1) {
-    uint32_t c0 = pair, c1 = bs, c2 = block, c3 = 0x46533031u;
+// (legacy tracer: counter = (ray, 0, 0, 'FS02'))
+__device__ __forceinline__ uint4 philox(uint32_t pair, uint32_t bs, uint32_t block, uint32_t k0, uint32_t k1,
+                                        uint32_t domain = 0x46533031u) {
+    uint32_t c0 = pair, c1 = bs, c2 = block, c3 = domain;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
@@ -215,18 +243,84 @@ __device__ __forceinline__ void trav_init(Trav& T, float tmax, bool scene_nonemp
 }
 __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tri_n || T.cur != kDone; }
 
-template <bool ANY, bool IGN = false>
-__device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, Trav& T, int* stack,
-                                          uint32_t ignore_object = 0xFFFFFFFFu) {
-    // a pending leaf becomes the triangle cursor and the next node is popped right away
+// The step in four pieces, so that a caller can put other work between the request and the use of the records:
+//   trav_settle   a pending leaf becomes the triangle cursor and the next node is popped right away
+//   trav_issue    request the node and / or triangle record the lane needs next
+//   trav_wait     the records have arrived
+//   trav_consume  triangle test, node test, pushes, next node
+// FS_MASKED_LOADS = 1: the loads are inline asm under the lanes' own exec mask, waited for once behind both groups —
+// a lane without a pending triangle (or node) requests nothing, and the request may be issued long before the use
+// (FS_PREFETCH: trav_shared issues it before the work-sharing round).  FS_MASKED_LOADS = 0 (round 1's form): plain
+// loads in trav_consume, every lane fetches (a dummy record 0 when it needs none), no branches around the loads:
+// inside `if (has_node)` / `if (has_tri)` blocks the compiler sinks the first arithmetic on the loaded words into the
+// block of the loads, i.e. waits for one record before it requests the other.
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct TravRegs { v4f q0, q1, q2, q3, a, b, c; };
+
+__device__ __forceinline__ void trav_settle(Trav& T, int* stack) {
     if (T.tri_i >= T.tri_n && T.cur < 0 && T.cur != kDone) {
         const int code = ~T.cur;
         T.tri_i = code >> 2;
         T.tri_n = T.tri_i + (code & 3) + 1;
         if (T.sp > T.sb) { --T.sp; T.cur = stack[T.sp * kBlock]; } else { T.cur = kDone; }
     }
+}
+
+__device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T, TravRegs& R) {
+#if FS_MASKED_LOADS
+#if FS_LDS_TOP
+    // experiment (north_star: "nodes ... staged through LDS"): the first FS_LDS_TOP nodes of the breadth-first array —
+    // the top levels of the tree — are read from a per-workgroup LDS copy
+    if (T.cur >= 0 && T.cur < sc.top_nodes) {
+        const v4f* lp = reinterpret_cast<const v4f*>(sc.top) + 4 * T.cur;
+        R.q0 = lp[0]; R.q1 = lp[1]; R.q2 = lp[2]; R.q3 = lp[3];
+    }
+    if (T.cur >= sc.top_nodes) {
+#else
+    if (T.cur >= 0) {
+#endif
+        const NodeQ4* np = sc.nodes + T.cur;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                     : "=&v"(R.q0), "=&v"(R.q1), "=&v"(R.q2), "=&v"(R.q3) : "v"(np) : "memory");
+    }
+    if (T.tri_i < T.tri_n) {
+        const Tri64* tp = sc.tris + T.tri_i;
+        asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %3, off offset:32"
+                     : "=&v"(R.a), "=&v"(R.b), "=&v"(R.c) : "v"(tp) : "memory");
+    }
+#endif
+}
+
+__device__ __forceinline__ void trav_wait(TravRegs& R) {
+#if FS_MASKED_LOADS
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R.q0), "+v"(R.q1), "+v"(R.q2), "+v"(R.q3), "+v"(R.a), "+v"(R.b), "+v"(R.c));
+#endif
+}
+
+template <bool ANY, bool IGN = false>
+__device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r, Trav& T, int* stack, const TravRegs& R,
+                                             uint32_t ignore_object = 0xFFFFFFFFu) {
     const bool has_tri = T.tri_i < T.tri_n;
     const bool has_node = T.cur >= 0;
+#if defined(FS_DUMMY_VALU) || defined(FS_DUMMY_SALU)   // sensitivity experiment: what does one more instruction per step cost?
+    {
+        float d0 = r.ox, d1 = r.oy;
+#ifdef FS_DUMMY_VALU
+#pragma unroll
+        for (int i = 0; i < FS_DUMMY_VALU / 2; ++i) {
+            asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(d0) : "v"(r.dx));
+            asm volatile("v_max_f32 %0, %0, %1" : "+v"(d1) : "v"(r.dy));
+        }
+#endif
+#ifdef FS_DUMMY_SALU
+#pragma unroll
+        for (int i = 0; i < FS_DUMMY_SALU; ++i) asm volatile("s_add_u32 s4, s4, 1" ::: "s4");
+#endif
+        asm volatile("" : : "v"(d0), "v"(d1));
+    }
+#endif
 #ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.py): SIMD occupancy of the two step kinds
     {
         const unsigned long long mt = __ballot(has_tri), mn = __ballot(has_node);
@@ -237,15 +331,17 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
         }
     }
 #endif
-    // Both records are requested before either is used, so the two fetches overlap.  The loads are NOT
-    // conditional: a lane without a pending triangle (or node) fetches record 0 instead (an L1 hit).  Inside
-    // `if (has_node)` / `if (has_tri)` blocks the compiler sinks the first arithmetic on the loaded words into
-    // the block of the loads, i.e. waits for one record before it requests the other — a full L2 latency
-    // per iteration, serialised.
+#if FS_MASKED_LOADS
+    const float4 q0 = make_float4(R.q0.x, R.q0.y, R.q0.z, R.q0.w), q1 = make_float4(R.q1.x, R.q1.y, R.q1.z, R.q1.w),
+                 q2 = make_float4(R.q2.x, R.q2.y, R.q2.z, R.q2.w), q3 = make_float4(R.q3.x, R.q3.y, R.q3.z, R.q3.w);
+    const float4 a = make_float4(R.a.x, R.a.y, R.a.z, R.a.w), b = make_float4(R.b.x, R.b.y, R.b.z, R.b.w),
+                 c = make_float4(R.c.x, R.c.y, R.c.z, R.c.w);
+#else
     const float4* trec = reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)(has_tri ? T.tri_i : 0);
     const float4* nrec = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)(has_node ? T.cur : 0);
     const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2], q3 = nrec[3];   // node
     const float4 a = trec[0], b = trec[1], c = trec[2];                    // triangle: v0 | e1 | e2 (+ material, id, object)
+#endif
     if (has_tri) {
         float t = 0.0f;
         // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
@@ -306,28 +402,56 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
             // entry distance (>= 0, so its bits order like an integer) with the slot in the low 2 bits
             key[c] = h ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : (0xFFFFFFFCu | (uint32_t)c);
         }
-        // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free
         int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), ref2 = __float_as_int(q3.z),
             ref3 = __float_as_int(q3.w);
+#ifdef FS_TRAV_STATS
+        atomicAdd(&g_trav_stats[5 + (hits > 2 ? 2 : hits)], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
+#endif
+        constexpr int kOrder = ANY ? FS_ANY_ORDER : FS_CHILD_ORDER;
+        int p1;
+        if (kOrder == 0) {
+            // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free
 #define FS_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t lo_ = min(key[a], key[b]); \
                          const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; \
                          const int ra_ = sw_ ? ref##b : ref##a; const int rb_ = sw_ ? ref##a : ref##b; \
                          ref##a = ra_; ref##b = rb_; }
-        FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
+            FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
 #undef FS_CSWAP
-#ifdef FS_TRAV_STATS
-        atomicAdd(&g_trav_stats[5 + (hits > 2 ? 2 : hits)], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
-#endif
-        // far children wait on the stack, farthest pushed first.  Written unconditionally: a push that does
-        // not happen lands on the free slot above the top and is overwritten by the next one (or ignored),
-        // which is cheaper than three exec-mask branches; the two rows above the tree's worst-case need absorb it.
-        const int p3 = T.sp;
-        const int p2 = p3 + (hits >= 4 ? 1 : 0);
-        const int p1 = p2 + (hits >= 3 ? 1 : 0);
-        if (hits >= 2) {   // 3 of 4 visits hit at most one child and push nothing
-            stack[p3 * kBlock] = ref3;
-            stack[p2 * kBlock] = ref2;
-            stack[p1 * kBlock] = ref1;
+            // far children wait on the stack, farthest pushed first.  Written unconditionally: a push that does
+            // not happen lands on the free slot above the top and is overwritten by the next one (or ignored),
+            // which is cheaper than three exec-mask branches; the two rows above the tree's worst-case need absorb it.
+            const int p3 = T.sp;
+            const int p2 = p3 + (hits >= 4 ? 1 : 0);
+            p1 = p2 + (hits >= 3 ? 1 : 0);
+            if (hits >= 2) {   // 3 of 4 visits hit at most one child and push nothing
+                stack[p3 * kBlock] = ref3;
+                stack[p2 * kBlock] = ref2;
+                stack[p1 * kBlock] = ref1;
+            }
+        } else {
+            // only the child to descend into is chosen (kOrder 1: the nearest; 2: the first hit slot — a visibility
+            // ray does not care); the other hit children are pushed in slot order.  Every slot writes at
+            // sp + (#pushes before it): a slot that is not pushed is overwritten by the next push or lands on the
+            // free slot above the new top.
+            uint32_t k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3];
+            if (kOrder == 2) {   // entry distance dropped from the key: min = first hit slot
+                k0 = k0 < 0xFFFFFFFCu ? 0u : k0; k1 = k1 < 0xFFFFFFFCu ? 1u : k1;
+                k2 = k2 < 0xFFFFFFFCu ? 2u : k2; k3 = k3 < 0xFFFFFFFCu ? 3u : k3;
+            }
+            const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+            const uint32_t first = kmin & 3u;
+            const int push0 = (key[0] < 0xFFFFFFFCu) & (first != 0u), push1 = (key[1] < 0xFFFFFFFCu) & (first != 1u),
+                      push2 = (key[2] < 0xFFFFFFFCu) & (first != 2u);
+            const int rfirst = first == 0u ? ref0 : (first == 1u ? ref1 : (first == 2u ? ref2 : ref3));
+            const int q0p = T.sp, q1p = q0p + push0, q2p = q1p + push1, q3p = q2p + push2;
+            if (hits >= 2) {
+                stack[q0p * kBlock] = ref0;
+                stack[q1p * kBlock] = ref1;
+                stack[q2p * kBlock] = ref2;
+                stack[q3p * kBlock] = ref3;
+            }
+            p1 = T.sp + (hits >= 2 ? hits - 2 : 0);   // hits >= 2: new top = sp + hits - 1 (the line below adds the 1)
+            ref0 = rfirst;
         }
         T.sp = p1 + (hits >= 2 ? 1 : 0);
         if (hits >= 1) {
@@ -339,6 +463,16 @@ __device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, T
             T.cur = kDone;
         }
     }
+}
+
+template <bool ANY, bool IGN = false>
+__device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, Trav& T, int* stack,
+                                          uint32_t ignore_object = 0xFFFFFFFFu) {
+    TravRegs R;
+    trav_settle(T, stack);
+    trav_issue(sc, T, R);
+    trav_wait(R);
+    trav_consume<ANY, IGN>(sc, r, T, stack, R, ignore_object);
 }
 
 template <bool ANY, bool IGN = false>
@@ -599,6 +733,7 @@ __device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, ui
     return perm[slot - acc];   // bucket 0
 }
 
+#ifdef FS_EXPERIMENTS   // diagnostic builds only (-DFS_TRAV_STATS, tests/trav_stats.py): no work sharing, per-lane step counts
 // ---------------------------------------------------------------------------------------------------
 // walk_kernel_simple: one subpath per lane (reference variant)
 // ---------------------------------------------------------------------------------------------------
@@ -635,50 +770,103 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
     }
     walker_finish(w, st);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------
-// Wave work sharing for closest-hit queries.
+// Wave work sharing for closest-hit AND any-hit queries (one implementation, three instantiations).
 //
 // The rays of a wave need very different numbers of traversal steps (median 19, p99 40) and the wave waits for
-// its slowest ray in every bounce.  A closest-hit query parallelises: disjoint subtrees can be searched by
-// different lanes and the answers merged by min (t, triangle id) — exactly the order a single traversal applies.
+// its slowest ray in every bounce.  A query parallelises: disjoint subtrees can be searched by different lanes.
 // So a lane that has finished its own ray takes the OLDEST pending subtree (bottom of the stack: the one its
-// owner would reach last) from a lane that still has pending entries, traverses it with that lane's ray and the
-// closest hit the owner knew at that moment as bound, and reports into the owner's mailbox.  All of it happens
-// inside one wave (lock-step), through LDS, without atomics on the stacks.
-//   LDS behind the stack rows: ray store [12][kBlock] | result key [kBlock] u64 | result leaf [kBlock] |
-//   donation boxes: ref, owner, bound [kBlock] each.
+// owner would reach last) from a lane that still has pending entries, traverses it with that lane's ray and
+// reports into the owner's LDS mailbox.  All of it happens inside one wave (lock-step), without atomics on the stacks.
+//   closest hit (ANY = false): the partial answers merge by atomicMin on the 64-bit key (t bits << 32 | triangle
+//     id) — exactly the (t, id) order a single traversal applies, so the result does not depend on who searched
+//     what; a taken subtree starts from min(donor's bound, owner's mailbox).
+//   any hit (ANY = true): most connection rays are blocked and end at their first hit, the unobstructed ones must
+//     search every box along the segment; a hit anywhere settles the ray (flag in the owner's mailbox) and lanes
+//     still searching for a settled ray drop their work.
+//   IGN: FCollisionQueryParams::AddIgnoredActor per ray (legacy tracer).
+// LDS rows of kBlock words: rays (closest: origin, direction, reciprocals = 9 rows, the thief recomputes -o*inv;
+// any: origin, direction, tmax = 7 rows — the thief recomputes the reciprocals too, 40 B per lane keep two connect
+// workgroups on a CU next to the histogram) | [ignored actor] | mailbox (closest: u64 key + leaf; any: blocked flag) | donation boxes ref,
+// owner [, bound].  Every lane of the wave must call it (has_ray = false: nothing of its own, helps from the start).
 // ---------------------------------------------------------------------------------------------------
-constexpr size_t kShareLdsBytes = (size_t)kBlock * (12 * 4 + 8 + 4 + 3 * 4);
+template <bool ANY, bool IGN>
+struct ShareArea {
+    static constexpr int kRayRows = ANY ? 7 : 9;
+    static constexpr int kRows = kRayRows + (IGN ? 1 : 0) + (ANY ? 1 : 3) + 2 + (ANY ? 0 : 1);
+    static constexpr size_t kBytes = (size_t)kBlock * 4 * kRows;
+    float* rs; uint32_t* rign; unsigned long long* rkey; int* rleaf; int* blocked; int* dref; int* down; float* dbound;
+    __device__ __forceinline__ explicit ShareArea(int* base) {
+        rs = reinterpret_cast<float*>(base);
+        int* p = base + kRayRows * kBlock;
+        rign = reinterpret_cast<uint32_t*>(p); if (IGN) p += kBlock;
+        rkey = reinterpret_cast<unsigned long long*>(p); blocked = p; rleaf = p + 2 * kBlock;
+        p += (ANY ? 1 : 3) * kBlock;
+        dref = p; down = p + kBlock; dbound = reinterpret_cast<float*>(p + 2 * kBlock);
+    }
+};
+constexpr size_t kShareLdsBytes = ShareArea<false, false>::kBytes;      // 60 B per lane
+constexpr size_t kShareAnyLdsBytes = ShareArea<true, false>::kBytes;    // 40 B per lane
+constexpr size_t kShareIgnLdsBytes = ShareArea<false, true>::kBytes;    // 64 B per lane
 
-__device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray& own, Trav& T, int* stack, int* s_dyn,
-                                                float tmax, bool has_ray = true) {
-    float* rs = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
-    unsigned long long* rkey = reinterpret_cast<unsigned long long*>(rs + 12 * kBlock);
-    int* rleaf = reinterpret_cast<int*>(rkey + kBlock);
-    int* dref = rleaf + kBlock;
-    int* down = dref + kBlock;
-    float* dbound = reinterpret_cast<float*>(down + kBlock);
+// returns: ANY — the ray is blocked; closest — a hit was found (T.t, T.id, T.leaf_index describe it)
+template <bool ANY, bool IGN>
+__device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
+                                            uint32_t ignore, Trav& T, int* stack, int* share) {
+    const ShareArea<ANY, IGN> A(share);
+    float* rs = A.rs;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
     // publish this lane's ray and clear its mailbox
     rs[0 * kBlock + tid] = own.ox;  rs[1 * kBlock + tid] = own.oy;  rs[2 * kBlock + tid] = own.oz;
     rs[3 * kBlock + tid] = own.dx;  rs[4 * kBlock + tid] = own.dy;  rs[5 * kBlock + tid] = own.dz;
-    rs[6 * kBlock + tid] = own.ix;  rs[7 * kBlock + tid] = own.iy;  rs[8 * kBlock + tid] = own.iz;
-    rs[9 * kBlock + tid] = own.nox; rs[10 * kBlock + tid] = own.noy; rs[11 * kBlock + tid] = own.noz;
-    rkey[tid] = ~0ull;
-    rleaf[tid] = -1;
+    if (ANY) {
+        rs[6 * kBlock + tid] = tmax;
+        A.blocked[tid] = 0;
+    } else {
+        rs[6 * kBlock + tid] = own.ix;  rs[7 * kBlock + tid] = own.iy;  rs[8 * kBlock + tid] = own.iz;
+        A.rkey[tid] = ~0ull;
+        A.rleaf[tid] = -1;
+    }
+    if (IGN) A.rign[tid] = ignore;
     unsigned owner = tid;   // block-local lane whose ray this lane is working on
+    uint32_t wign = ignore;
     Ray wr = own;
-    trav_init(T, tmax, has_ray && sc.num_nodes > 0);   // has_ray = false: a helper lane of a sparse wave
+    trav_init(T, tmax, has_ray && sc.num_nodes > 0);
+#if FS_PREFETCH
+    // The records of the NEXT step are requested as soon as this step has decided what they are — before the
+    // work-sharing round below (ballots, donation boxes, mailboxes: half a dozen LDS round trips), which then runs
+    // in the shadow of the fetch.  A wave in the thin tail of the frame runs alone on its SIMD and nothing else
+    // hides that latency.  Lanes that take work in the round request theirs at its end; a busy lane's (cur, tri
+    // cursor) does not change between its request and trav_consume.
+    TravRegs R;
+    trav_settle(T, stack);
+    trav_issue(sc, T, R);
+#endif
     while (true) {
+#if FS_PREFETCH
+        trav_wait(R);
+#endif
         if (trav_busy(T)) {
-            trav_step<false>(sc, wr, T, stack);
-            if (!trav_busy(T) && T.leaf_index >= 0) {   // this (sub)traversal is over: report to the owner of the ray
+#if FS_PREFETCH
+            trav_consume<ANY, IGN>(sc, wr, T, stack, R, wign);
+#else
+            trav_step<ANY, IGN>(sc, wr, T, stack, wign);
+#endif
+            if (ANY) {
+                if (T.leaf_index >= 0) { A.blocked[owner] = 1; T.leaf_index = -1; }   // first hit ends the query (T is idle now)
+                else if (A.blocked[owner]) { T.cur = kDone; T.sp = 0; T.sb = 0; T.tri_n = T.tri_i; }   // settled by another lane
+            } else if (!trav_busy(T) && T.leaf_index >= 0) {   // this (sub)traversal is over: report to the owner of the ray
                 const unsigned long long key = ((unsigned long long)__float_as_uint(T.t) << 32) | (unsigned long long)T.id;
-                atomicMin(&rkey[owner], key);
-                if (rkey[owner] == key) rleaf[owner] = T.leaf_index;
+                atomicMin(&A.rkey[owner], key);
+                if (A.rkey[owner] == key) A.rleaf[owner] = T.leaf_index;
             }
+#if FS_PREFETCH
+            trav_settle(T, stack);
+            trav_issue(sc, T, R);
+#endif
         }
         const bool idle = !trav_busy(T);
         const unsigned long long busy_m = __ballot(!idle);
@@ -691,9 +879,9 @@ __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray
             if (can_give) {
                 const int r = __popcll(give_m & lt);
                 if (r < n) {
-                    dref[wbase + r] = stack[T.sb * kBlock];
-                    down[wbase + r] = (int)owner;
-                    dbound[wbase + r] = T.t;
+                    A.dref[wbase + r] = stack[T.sb * kBlock];
+                    A.down[wbase + r] = (int)owner;
+                    if (!ANY) A.dbound[wbase + r] = T.t;
                     ++T.sb;
                     if (T.sb == T.sp) { T.sb = 0; T.sp = 0; }
                 }
@@ -701,109 +889,78 @@ __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray
             if (idle) {
                 const int r = __popcll(idle_m & lt);
                 if (r < n) {
-                    const int e = dref[wbase + r];
-                    owner = (unsigned)down[wbase + r];
-                    // the owner's mailbox may already hold a closer hit than the donor knew of
-                    const float bound = __uint_as_float(min(__float_as_uint(dbound[wbase + r]),
-                                                            (uint32_t)(rkey[owner] >> 32)));
-                    wr.ox = rs[0 * kBlock + owner];  wr.oy = rs[1 * kBlock + owner];  wr.oz = rs[2 * kBlock + owner];
-                    wr.dx = rs[3 * kBlock + owner];  wr.dy = rs[4 * kBlock + owner];  wr.dz = rs[5 * kBlock + owner];
-                    wr.ix = rs[6 * kBlock + owner];  wr.iy = rs[7 * kBlock + owner];  wr.iz = rs[8 * kBlock + owner];
-                    wr.nox = rs[9 * kBlock + owner]; wr.noy = rs[10 * kBlock + owner]; wr.noz = rs[11 * kBlock + owner];
+                    const int e = A.dref[wbase + r];
+                    owner = (unsigned)A.down[wbase + r];
+                    float bound;
+                    if (ANY) {
+                        wr = make_ray(rs[0 * kBlock + owner], rs[1 * kBlock + owner], rs[2 * kBlock + owner],
+                                      rs[3 * kBlock + owner], rs[4 * kBlock + owner], rs[5 * kBlock + owner]);
+                        bound = rs[6 * kBlock + owner];
+                    } else {
+                        // the owner's mailbox may already hold a closer hit than the donor knew of
+                        bound = __uint_as_float(min(__float_as_uint(A.dbound[wbase + r]), (uint32_t)(A.rkey[owner] >> 32)));
+                        wr.ox = rs[0 * kBlock + owner];  wr.oy = rs[1 * kBlock + owner];  wr.oz = rs[2 * kBlock + owner];
+                        wr.dx = rs[3 * kBlock + owner];  wr.dy = rs[4 * kBlock + owner];  wr.dz = rs[5 * kBlock + owner];
+                        wr.ix = rs[6 * kBlock + owner];  wr.iy = rs[7 * kBlock + owner];  wr.iz = rs[8 * kBlock + owner];
+                        wr.nox = -(wr.ox * wr.ix); wr.noy = -(wr.oy * wr.iy); wr.noz = -(wr.oz * wr.iz);   // as make_ray
+                    }
+                    if (IGN) wign = A.rign[owner];
                     T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
                     T.t = bound; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
+#if FS_PREFETCH
+                    trav_settle(T, stack);
+                    trav_issue(sc, T, R);
+#endif
                 }
             }
         }
     }
+    if (ANY) return A.blocked[tid] != 0;
     // everything searched: the mailbox holds the closest hit of this lane's own ray
-    const unsigned long long key = rkey[tid];
+    const unsigned long long key = A.rkey[tid];
     if (key != ~0ull) {
         T.t = __uint_as_float((uint32_t)(key >> 32));
         T.id = (uint32_t)key;
-        T.leaf_index = rleaf[tid];
-    } else {
-        T.t = tmax;
-        T.leaf_index = -1;
-        T.id = 0xFFFFFFFFu;
+        T.leaf_index = A.rleaf[tid];
+        return true;
     }
+    T.t = tmax;
+    T.leaf_index = -1;
+    T.id = 0xFFFFFFFFu;
+    return false;
 }
-
-// The same scheme for any-hit (visibility) queries: most connection rays are blocked and end at their first hit,
-// the unobstructed ones must search every box along the segment, so a wave waits for a few long traversals
-// while most of its lanes idle.  Idle lanes take the oldest pending subtree of a busy lane; any hit anywhere
-// settles the ray (flag in the owner's mailbox), and lanes still searching for a settled ray drop their work.
-//   LDS behind `share`: ray store [7][kBlock] (origin, direction, tmax) | blocked flag [kBlock] | donation
-//   boxes ref, owner [kBlock] each — 40 B per lane, so two workgroups still fit a CU next to the histogram.
-// Every lane of the wave must call it (has_ray = false: nothing of its own to search, helps from the start).
-constexpr size_t kShareAnyLdsBytes = (size_t)kBlock * (7 * 4 + 4 + 2 * 4);
-
+// the three uses: BDPT walk, ConnectSubpaths' visibility ray, legacy tracer
+__device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray& own, Trav& T, int* stack, int* s_dyn,
+                                                float tmax, bool has_ray = true) {
+    trav_shared<false, false>(sc, has_ray, own, tmax, 0xFFFFFFFFu, T, stack, s_dyn + (size_t)sc.stack_rows * kBlock);
+}
 __device__ __forceinline__ bool trav_any_shared(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
                                                 int* stack, int* share) {
-    float* rs = reinterpret_cast<float*>(share);
-    int* blocked = share + 7 * kBlock;
-    int* dref = blocked + kBlock;
-    int* down = dref + kBlock;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    rs[0 * kBlock + tid] = own.ox;  rs[1 * kBlock + tid] = own.oy;  rs[2 * kBlock + tid] = own.oz;
-    rs[3 * kBlock + tid] = own.dx;  rs[4 * kBlock + tid] = own.dy;  rs[5 * kBlock + tid] = own.dz;
-    rs[6 * kBlock + tid] = tmax;
-    blocked[tid] = 0;
-    unsigned owner = tid;
-    Ray wr = own;
     Trav T;
-    trav_init(T, tmax, has_ray && sc.num_nodes > 0);
-    while (true) {
-        if (trav_busy(T)) {
-            trav_step<true>(sc, wr, T, stack);
-            if (T.leaf_index >= 0) { blocked[owner] = 1; T.leaf_index = -1; }   // first hit ends the query (T is idle now)
-            else if (blocked[owner]) { T.cur = kDone; T.sp = 0; T.sb = 0; T.tri_n = T.tri_i; }   // settled by another lane
-        }
-        const bool idle = !trav_busy(T);
-        const unsigned long long busy_m = __ballot(!idle);
-        if (busy_m == 0ull) break;
-        const unsigned long long idle_m = __ballot(idle);
-        const bool can_give = !idle && T.sp > T.sb;
-        const unsigned long long give_m = __ballot(can_give);
-        if (idle_m != 0ull && give_m != 0ull) {
-            const int n = min(__popcll(idle_m), __popcll(give_m));
-            if (can_give) {
-                const int r = __popcll(give_m & lt);
-                if (r < n) {
-                    dref[wbase + r] = stack[T.sb * kBlock];
-                    down[wbase + r] = (int)owner;
-                    ++T.sb;
-                    if (T.sb == T.sp) { T.sb = 0; T.sp = 0; }
-                }
-            }
-            if (idle) {
-                const int r = __popcll(idle_m & lt);
-                if (r < n) {
-                    const int e = dref[wbase + r];
-                    owner = (unsigned)down[wbase + r];
-                    wr = make_ray(rs[0 * kBlock + owner], rs[1 * kBlock + owner], rs[2 * kBlock + owner],
-                                  rs[3 * kBlock + owner], rs[4 * kBlock + owner], rs[5 * kBlock + owner]);
-                    T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
-                    T.t = rs[6 * kBlock + owner]; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
-                }
-            }
-        }
-    }
-    return blocked[tid] != 0;
+    return trav_shared<true, false>(sc, has_ray, own, tmax, 0xFFFFFFFFu, T, stack, share);
 }
 
 template <int LOBES>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area [| tree top]
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
+#if FS_LDS_TOP
+    {
+        int4* top = reinterpret_cast<int4*>(reinterpret_cast<char*>(s_dyn) + sizeof(int) * (size_t)sc.stack_rows * kBlock + kShareLdsBytes);
+        const int n = min(FS_LDS_TOP, sc.num_nodes);
+        const int4* src = reinterpret_cast<const int4*>(sc.nodes);
+        for (int i = threadIdx.x; i < 4 * n; i += kBlock) top[i] = src[i];
+        sc.top = reinterpret_cast<const float4*>(top);
+        sc.top_nodes = n;
+    }
+#endif
     if (perm) {
         for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
-        __syncthreads();
     }
+    if (perm || FS_LDS_TOP) __syncthreads();
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= 2u * kp.num_local) return;
     const uint32_t g = perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot;
@@ -811,180 +968,40 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
     Walker w;
     walker_start(w, g, kp);
     Ray ray;
+#ifdef FS_WAVE_TIMELINE
+    const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tl_trav = 0, tl_seg = 0;
+#endif
     while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
         Trav T;
+#ifdef FS_WAVE_TIMELINE
+        const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
+#endif
         trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist);
+#ifdef FS_WAVE_TIMELINE
+        tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
+        ++tl_seg;
+#endif
         walker_apply_hit(w, kp, sc, st, ray, T);
     }
     walker_finish(w, st);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// walk_connect_kernel: the walk with ConnectSubpaths + EvaluatePath + deposit fused behind it.
-// A separate connect kernel starts only after the last walk has ended, runs as one thin round of waves and is
-// followed by a launch gap.  Here the subpath that ends LATER connects its pair right away, inside the walk
-// kernel: every subpath publishes its end state, then increments its pair's arrival counter (release); the second
-// arrival (acquire) reads the partner's records and runs the visibility query — shared by the whole wave like any
-// other query — EvaluatePath and the deposit (global atomics: a wave deposits a few dozen values, spread over the
-// kernel's duration).  The arrival counter is never reset: every frame adds exactly 2 per pair, so an odd old
-// value marks the second arrival.  The last workgroup to finish rearms the frame scratch (the connect kernel's
-// other duty).  Same paths, same arithmetic, same sums as the two-kernel sequence (parity suite passes with it).
-// Bands are a run-time loop here (one instantiation per LOBES value instead of eight more).
-// NOT the default (FS_FUSE_CONNECT=1): measured 0.655 ms against 0.362 + 0.074 ms for the two kernels.  The partner's
-// records may sit dirty in ANOTHER XCD's L2 (the eight L2s are not coherent with each other inside a kernel), so the
-// release / acquire pair below costs every wave an L2 write-back and invalidate — which the kernel boundary of the
-// two-kernel sequence provides once, for free: with the two fences compiled out (results then unreliable) the kernel
-// takes 0.453 ms, and that is still no faster than the two kernels, because two thirds of the connections fall to the
-// longest walks and lengthen exactly the waves the kernel waits for.
-// ---------------------------------------------------------------------------------------------------
-template <int LOBES>
-__device__ __forceinline__ void apply_segment_rt(float (&E)[FS_MAX_BANDS], int B, float nd, uint32_t mat, float prob,
-                                                 const KParams& kp, const DeviceScene& sc) {
-    if (nd < kp.min_seg) return;  // ARTS.cpp:375-378
-    float nd2 = nd * nd;
-    float geo = 1.0f / (4 * kPi * nd2);            // ARTS.cpp:391
-    float pw = powf(prob, kp.prob_exponent);       // ARTS.cpp:398
-    const bool lobes = LOBES != 0;
-    const uint32_t lobe = (lobes && mat != kNoMat) ? ((mat >> kLobeShift) & 3u) : 0u;
-    if (lobes && mat != kNoMat) mat &= 0xFFFFu;
-    bool has = (mat != kNoMat) && ((int32_t)mat < sc.num_materials);
-    const float* coeff = lobes ? sc.lobe_gain + ((size_t)mat * 3 + lobe) * B : sc.absorption + (size_t)mat * B;
-    const bool over_pi = !lobes || lobe == kLobeDiffuse;
-#pragma unroll
-    for (int b = 0; b < FS_MAX_BANDS; ++b) {
-        if (b < B) {
-            float bsdf = 1.0f;                                            // ARTS.cpp:382-386
-            if (has) bsdf = over_pi ? coeff[b] / kPi : coeff[b];
-            float e = E[b];
-            e *= bsdf;
-            e *= geo;
-            e *= expf(-kp.air[b] * nd);                // ARTS.cpp:395-397
-            e /= pw;
-            E[b] = e;
+#ifdef FS_WAVE_TIMELINE
+    {
+        unsigned long long seg_max = tl_seg, trav_max = tl_trav;   // lanes of a wave leave the loop at different bounces
+        for (int o = 32; o > 0; o >>= 1) {
+            seg_max = max(seg_max, (unsigned long long)__shfl_xor((long long)seg_max, o));
+            trav_max = max(trav_max, (unsigned long long)__shfl_xor((long long)trav_max, o));
+        }
+        if ((threadIdx.x & 63u) == 0u && g_wave_buf) {
+            unsigned long long* o = g_wave_buf + 8ull * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+            o[0] = tl_r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = trav_max;
+            o[3] = __builtin_amdgcn_s_memtime() - tl_c0; o[4] = 0; o[5] = seg_max;
+            o[6] = __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 4)            // HW_REG_HW_ID bits [7:0]
+                   | ((unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 32);   // HW_REG_XCC_ID
+            o[7] = slot;
         }
     }
-}
-
-template <int LOBES>
-__global__ __launch_bounds__(kBlock) void walk_connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
-                                                              unsigned* __restrict__ scratch,
-                                                              const uint32_t* __restrict__ perm,
-                                                              unsigned* __restrict__ pair_done, int B,
-                                                              float* __restrict__ energy,
-                                                              unsigned long long* __restrict__ fixed) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
-    int* s_stack = s_dyn;
-    __shared__ unsigned s_cnt[kPlanBuckets];
-    __shared__ unsigned s_dep;
-    if (threadIdx.x == 0) s_dep = 0u;
-    if (perm) {
-        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
-    }
-    __syncthreads();
-    const uint32_t n = kp.num_local, total = 2u * n;
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    const bool mine = slot < total;
-    int* stack = &s_stack[threadIdx.x];
-    unsigned my_deposits = 0;
-    // ---- the walk (as walk_kernel_shared; lanes beyond the frame only help)
-    Walker w;
-    walker_start(w, mine ? (perm ? planned_subpath(slot, kp.depth, total, s_cnt, perm) : slot) : 0u, kp);
-    Ray ray;
-    bool alive = mine;
-    while (true) {
-        const bool go = alive && walker_next_ray<LOBES>(w, kp, sc, st, ray);
-        if (alive && !go) { walker_finish(w, st); alive = false; }
-        if (__ballot(go) == 0ull) break;
-        Trav T;
-        trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
-        if (go) walker_apply_hit(w, kp, sc, st, ray, T);
-    }
-    // ---- arrival: the later of a pair's two subpaths connects them
-    bool second = false;
-    if (mine) {
-        __threadfence();                                   // release: end state and segment records before the counter
-        second = (atomicAdd(&pair_done[w.li], 1u) & 1u) != 0u;
-        if (second) __threadfence();                       // acquire: the partner's records
-    }
-    {
-        const uint32_t li = w.li;
-        const uint32_t lc = second ? li : 0u;
-        const float4 F = st.end_pos[lc];
-        const uint2 Fm = st.end_misc[lc];
-        const float4 L = st.end_pos[n + lc];
-        const uint2 Lm = st.end_misc[n + lc];
-        // visibility F_k -> B_m - 0.1 * unit(B_m - F_k) (ARTS.cpp:252-254); visible iff NO hit
-        float dx = L.x - F.x, dy = L.y - F.y, dz = L.z - F.z;
-        float l2 = dx * dx + dy * dy + dz * dz;
-        float len = sqrtf(l2);
-        float inv = 1.0f / len;
-        float tmax = len - kp.connect_pullback;
-        const bool has_ray = second && (l2 > 1e-8f) && (tmax > 0.0f);
-        Ray cr = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
-        const bool hit = trav_any_shared(sc, has_ray, cr, tmax, stack, s_dyn + (size_t)sc.stack_rows * kBlock);
-        if (second && !hit) {
-            ++my_deposits;
-            // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
-            float E[FS_MAX_BANDS];
-#pragma unroll
-            for (int b = 0; b < FS_MAX_BANDS; ++b) E[b] = 1.0f;
-            float sd = 0.0f;
-            const int kf = (int)Fm.y, kl = (int)Lm.y;
-            for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
-                const float2 np = st.seg_np[(size_t)j * total + li];
-                sd += np.x;                                               // ARTS.cpp:374
-                apply_segment_rt<LOBES>(E, B, np.x, st.seg_mat[(size_t)j * total + li], np.y, kp, sc);
-            }
-            {                                                             // connection segment: F_k's material/prob
-                float dist = sqrtf(l2);
-                float nd = dist / kp.dist_divisor;
-                sd += nd;
-                apply_segment_rt<LOBES>(E, B, nd, Fm.x, F.w, kp, sc);
-            }
-            for (int j = kl - 1; j >= 0; --j) {                           // listener-side segments B_j+1 -> B_j
-                const float2 np = st.seg_np[(size_t)j * total + n + li];
-                sd += np.x;
-                apply_segment_rt<LOBES>(E, B, np.x, st.seg_mat[(size_t)j * total + n + li], np.y, kp, sc);
-            }
-            float delay = sd / kp.sound_speed;                            // ARTS.cpp:419
-            float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
-            float fl = floorf(x);
-            const int nb = kp.num_bins;
-            int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
-#pragma unroll
-            for (int b = 0; b < FS_MAX_BANDS; ++b) {
-                if (b < B) {
-                    float e = E[b];
-                    e = (e < kp.energy_clamp) ? e : kp.energy_clamp;      // FMath::Min ARTS.cpp:410
-                    e *= kp.energy_gain;                                  // ARTS.cpp:413
-                    e *= kp.norm;                                         // ARTS.cpp:164-170
-                    if (fixed)
-                        atomicAdd(&fixed[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
-                    else
-                        atomicAdd(&energy[b * nb + bin], e);              // global_atomic_add_f32
-                }
-            }
-        }
-    }
-    // ---- work counters, and the last workgroup rearms the frame scratch for the next frame
-    {
-        unsigned d = my_deposits;
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
-        if ((threadIdx.x & 63u) == 0u && d) atomicAdd(&s_dep, d);
-    }
-    __syncthreads();
-    __shared__ unsigned s_last;
-    if (threadIdx.x == 0) {
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(scratch + kCounterWord);
-        if (s_dep) atomicAdd(&counters[2], (unsigned long long)s_dep);
-        if (blockIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
-        unsigned* wg_done = scratch + kCounterWord + 6;      // the unused fourth counter doubles as the arrival count
-        s_last = atomicAdd(wg_done, 1u) == gridDim.x - 1u ? 1u : 0u;
-        if (s_last) *wg_done = 0u;
-    }
-    __syncthreads();
-    if (s_last)
-        for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) scratch[i] = 0u;
+#endif
 }
 
 // Small frames on sparse waves: a frame of a few thousand subpaths is a handful of waves and takes the latency of
@@ -1017,106 +1034,6 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
         Trav T;
         trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
         if (go) walker_apply_hit(w, kp, sc, st, ray, T);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// walk_kernel_persistent: the same walks on persistent waves.
-//
-// One-subpath-per-lane leaves most of a wave64 idle: Russian roulette kills 10 % of the lanes per bounce
-// and the rays of a wave need very different numbers of BVH steps.  Here a lane is a worker, not a
-// subpath: waves take 64-subpath chunks from a global queue (one atomicAdd per chunk — a single shared
-// head word saturates near 88 dequeues/us on this chip) and alternate between
-//   stage A (batched: entered when >= refill_threshold lanes wait, or nothing is traversing):
-//           apply the hit of lanes whose traversal completed, hand new subpaths to lanes whose walk
-//           ended, roulette + direction sampling for the next ray;
-//   stage B: one trav_step per busy lane per iteration, left as soon as enough lanes wait.
-// Results are identical to the simple kernel: a subpath's arithmetic depends only on (seed, pair, side).
-// ---------------------------------------------------------------------------------------------------
-enum : int { PH_NEW = 0, PH_TRAV = 1, PH_SHADE = 2, PH_IDLE = 3, PH_NEXT = 4 };
-constexpr int kQueueChunk = 64;
-
-__global__ __launch_bounds__(kBlock) void walk_kernel_persistent(DeviceScene sc, KParams kp, SubpathState st,
-                                                                 unsigned* __restrict__ queue_head,
-                                                                 const uint32_t* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
-    int* s_stack = s_dyn;
-    __shared__ unsigned s_cnt[kPlanBuckets];
-    if (perm) {
-        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = queue_head[1 + i];
-        __syncthreads();
-    }
-    int* stack = &s_stack[threadIdx.x];
-    const unsigned lane = threadIdx.x & 63u;
-    const uint32_t total = 2u * kp.num_local;
-    const unsigned thresh = (unsigned)kp.refill_threshold;
-    const bool nonempty = sc.num_nodes > 0;
-
-    int phase = PH_NEW;
-    Walker w;
-    walker_start(w, 0, kp);
-    Ray ray = make_ray(0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
-    Trav T;
-    trav_init(T, 0.f, false);
-    unsigned q_next = 0, q_end = 0;  // the wave's private slice of the subpath queue (wave-uniform)
-    bool drained = false;
-
-    while (true) {
-        const unsigned long long trav_m = __ballot(phase == PH_TRAV);
-        const unsigned long long wait_m = __ballot(phase == PH_NEW || phase == PH_SHADE);
-        if ((trav_m | wait_m) == 0ull) break;  // every lane idle: queue drained
-
-        // ================= stage A: apply hits / refill / sample (batched) =================
-        if (trav_m == 0ull || __popcll(wait_m) >= thresh) {
-            if (phase == PH_SHADE) {
-                walker_apply_hit(w, kp, sc, st, ray, T);
-                phase = PH_NEXT;
-            }
-#pragma unroll 1
-            for (int round = 0; round < 2; ++round) {
-                const unsigned long long need = __ballot(phase == PH_NEW);
-                if (need != 0ull) {
-                    if (q_next == q_end && !drained) {
-                        unsigned base = 0;
-                        if (lane == 0u) base = atomicAdd(queue_head, (unsigned)kQueueChunk);
-                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                        if (base >= total) { drained = true; }
-                        else { q_next = base; q_end = min(base + (unsigned)kQueueChunk, total); }
-                    }
-                    if (phase == PH_NEW) {
-                        const unsigned my = q_next + (unsigned)__popcll(need & ((1ull << lane) - 1ull));
-                        if (my < q_end) {
-                            walker_start(w, perm ? planned_subpath(my, kp.depth, total, s_cnt, perm) : my, kp);
-                            phase = PH_NEXT;
-                        }
-                        else if (drained) { phase = PH_IDLE; }
-                        // else: stays PH_NEW and is served from the next chunk in the following round
-                    }
-                    q_next = min(q_next + (unsigned)__popcll(need), q_end);
-                }
-                if (phase == PH_NEXT) {
-                    if (walker_next_ray(w, kp, sc, st, ray)) {
-                        trav_init(T, kp.max_trace_dist, nonempty);
-                        phase = nonempty ? PH_TRAV : PH_SHADE;   // empty scene: every trace misses
-                    } else {
-                        walker_finish(w, st);
-                        phase = PH_NEW;
-                    }
-                }
-            }
-        }
-
-        // ================= stage B: BVH traversal =================
-        if (__ballot(phase == PH_TRAV) != 0ull) {
-            while (true) {
-                if (phase == PH_TRAV) {
-                    trav_step<false>(sc, ray, T, stack);
-                    if (!trav_busy(T)) phase = PH_SHADE;
-                }
-                if (__ballot(phase == PH_TRAV) == 0ull) break;
-                if (__popcll(__ballot(phase == PH_NEW || phase == PH_SHADE)) >= thresh) break;
-            }
-        }
     }
 }
 
@@ -1572,9 +1489,9 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
-// update_sound_kernel: the legacy per-frame forward tracer (UpdateSound FrequenSeeAudioComponent.cpp:283-306,
-// CastAudioRay :132-207, CastDirectAudioRay :209-280).  Lane i < N follows specular chain i (with the
-// listener-directed transmission ray at every bounce); lane N computes OcclusionAttenuation (:295-299).
+// update_sound_shared_kernel: the legacy per-frame forward tracer (UpdateSound FrequenSeeAudioComponent.cpp:283-306,
+// CastAudioRay :132-207, CastDirectAudioRay :209-280).  Ray i < N follows specular chain i (with the
+// listener-directed transmission ray at every bounce); ray N computes OcclusionAttenuation (:295-299).
 // Build-owned engine semantics: actors = object id per triangle, the player pawn = a sphere.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kNoObject = 0xFFFFFFFFu;
@@ -1596,50 +1513,6 @@ __device__ __forceinline__ bool sphere_hit(const Ray& r, const float c[3], float
 
 struct LegacyHit { float t; uint32_t object; float nx, ny, nz; };
 
-// closest blocking hit among the triangles (minus one ignored actor) and the pawn sphere
-__device__ __forceinline__ bool legacy_trace(const DeviceScene& sc, const SoundKParams& sp, const Ray& r, float tmax,
-                                             uint32_t ignore, int* stack, LegacyHit& h, unsigned long long& traces) {
-    ++traces;
-    Trav T;
-    trav_init(T, tmax, sc.num_nodes > 0);
-    trav_run<false, true>(sc, r, T, stack, ignore);
-    float ts;
-    const bool hs = sphere_hit(r, sp.lis, sp.listener_radius, tmax, ts);
-    const bool ht = T.leaf_index >= 0;
-    if (!ht && !hs) return false;
-    if (hs && (!ht || ts <= T.t)) { h.t = ts; h.object = kPawnObject; h.nx = h.ny = h.nz = 0.f; return true; }
-    uint32_t mat;
-    hit_surface(sc, T.leaf_index, r, h.nx, h.ny, h.nz, mat);
-    h.t = T.t;
-    h.object = __float_as_uint(reinterpret_cast<const float4*>(sc.tris)[4 * (size_t)T.leaf_index + 2].w);
-    return true;
-}
-
-// CastDirectAudioRay FSAC.cpp:209-280 (tail recursion as a loop)
-__device__ __forceinline__ float cast_direct(const DeviceScene& sc, const SoundKParams& sp, float dx, float dy, float dz,
-                                             float px, float py, float pz, float max_distance, int bounces,
-                                             float energy, uint32_t direct_hit_actor, int* stack,
-                                             unsigned long long& traces) {
-    while (true) {
-        if (bounces == 0 || energy <= 0.0f) return 0.0f;                  // FSAC.cpp:212
-        Ray r = make_ray(fmaf(dx, 0.1f, px), fmaf(dy, 0.1f, py), fmaf(dz, 0.1f, pz), dx, dy, dz);  // :232
-        LegacyHit h;
-        if (!legacy_trace(sc, sp, r, max_distance, direct_hit_actor, stack, h, traces)) return 0.0f;  // :279
-        if (h.object == kPawnObject) {                                    // FSAC.cpp:253-270
-            float travel = sp.raycast_distance - max_distance + h.t;
-            travel *= 0.01f;
-            float time = travel / 343.0f;
-            if (time > sp.simulated_duration) return 0.0f;
-            energy *= expf(-0.0017f * travel);
-            return energy;
-        }
-        px = fmaf(h.t, dx, r.ox); py = fmaf(h.t, dy, r.oy); pz = fmaf(h.t, dz, r.oz);   // Hit.ImpactPoint
-        max_distance = max_distance - h.t;                                // FSAC.cpp:275
-        bounces -= 1;
-        direct_hit_actor = h.object;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // The legacy tracer on sparse waves.  UpdateSound is 1501 rays, each a CHAIN of up to ~20 dependent closest-hit
 // queries: on one lane per ray that is 24 waves on a 1024-SIMD chip and the call takes the latency of the longest
@@ -1647,92 +1520,9 @@ __device__ __forceinline__ float cast_direct(const DeviceScene& sc, const SoundK
 // lets the other lanes help: every query of the wave is searched by all 64 lanes (the wave work sharing of
 // trav_run_shared, here with the per-ray ignored actor), so a query takes about as many steps as its deepest
 // root-to-leaf descent instead of its total node count.  Each lane runs CastAudioRay / CastDirectAudioRay as a
-// small state machine (main trace | direct trace | done) so that the whole wave meets at every query; the
-// arithmetic and therefore every result is that of update_sound_kernel.
-//   LDS behind the stack rows: ray store [12][kBlock] | ignored actor [kBlock] | result key [kBlock] u64 |
-//   result leaf [kBlock] | donation boxes ref, owner, bound [kBlock] each.
+// small state machine (main trace | direct trace | done) so that the whole wave meets at every query.
+//   LDS behind the stack rows: ShareArea<false, true>.
 // ---------------------------------------------------------------------------------------------------
-constexpr size_t kShareIgnLdsBytes = (size_t)kBlock * (12 * 4 + 4 + 8 + 4 + 3 * 4);
-
-__device__ __forceinline__ void trav_closest_shared_ign(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
-                                                        uint32_t ignore, Trav& T, int* stack, int* share) {
-    float* rs = reinterpret_cast<float*>(share);
-    uint32_t* rign = reinterpret_cast<uint32_t*>(rs + 12 * kBlock);
-    unsigned long long* rkey = reinterpret_cast<unsigned long long*>(rign + kBlock);
-    int* rleaf = reinterpret_cast<int*>(rkey + kBlock);
-    int* dref = rleaf + kBlock;
-    int* down = dref + kBlock;
-    float* dbound = reinterpret_cast<float*>(down + kBlock);
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    rs[0 * kBlock + tid] = own.ox;  rs[1 * kBlock + tid] = own.oy;  rs[2 * kBlock + tid] = own.oz;
-    rs[3 * kBlock + tid] = own.dx;  rs[4 * kBlock + tid] = own.dy;  rs[5 * kBlock + tid] = own.dz;
-    rs[6 * kBlock + tid] = own.ix;  rs[7 * kBlock + tid] = own.iy;  rs[8 * kBlock + tid] = own.iz;
-    rs[9 * kBlock + tid] = own.nox; rs[10 * kBlock + tid] = own.noy; rs[11 * kBlock + tid] = own.noz;
-    rign[tid] = ignore;
-    rkey[tid] = ~0ull;
-    rleaf[tid] = -1;
-    unsigned owner = tid;
-    uint32_t wign = ignore;
-    Ray wr = own;
-    trav_init(T, tmax, has_ray && sc.num_nodes > 0);
-    while (true) {
-        if (trav_busy(T)) {
-            trav_step<false, true>(sc, wr, T, stack, wign);
-            if (!trav_busy(T) && T.leaf_index >= 0) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(T.t) << 32) | (unsigned long long)T.id;
-                atomicMin(&rkey[owner], key);
-                if (rkey[owner] == key) rleaf[owner] = T.leaf_index;
-            }
-        }
-        const bool idle = !trav_busy(T);
-        const unsigned long long busy_m = __ballot(!idle);
-        if (busy_m == 0ull) break;
-        const unsigned long long idle_m = __ballot(idle);
-        const bool can_give = !idle && T.sp > T.sb;
-        const unsigned long long give_m = __ballot(can_give);
-        if (idle_m != 0ull && give_m != 0ull) {
-            const int n = min(__popcll(idle_m), __popcll(give_m));
-            if (can_give) {
-                const int r = __popcll(give_m & lt);
-                if (r < n) {
-                    dref[wbase + r] = stack[T.sb * kBlock];
-                    down[wbase + r] = (int)owner;
-                    dbound[wbase + r] = T.t;
-                    ++T.sb;
-                    if (T.sb == T.sp) { T.sb = 0; T.sp = 0; }
-                }
-            }
-            if (idle) {
-                const int r = __popcll(idle_m & lt);
-                if (r < n) {
-                    const int e = dref[wbase + r];
-                    owner = (unsigned)down[wbase + r];
-                    const float bound = __uint_as_float(min(__float_as_uint(dbound[wbase + r]),
-                                                            (uint32_t)(rkey[owner] >> 32)));
-                    wr.ox = rs[0 * kBlock + owner];  wr.oy = rs[1 * kBlock + owner];  wr.oz = rs[2 * kBlock + owner];
-                    wr.dx = rs[3 * kBlock + owner];  wr.dy = rs[4 * kBlock + owner];  wr.dz = rs[5 * kBlock + owner];
-                    wr.ix = rs[6 * kBlock + owner];  wr.iy = rs[7 * kBlock + owner];  wr.iz = rs[8 * kBlock + owner];
-                    wr.nox = rs[9 * kBlock + owner]; wr.noy = rs[10 * kBlock + owner]; wr.noz = rs[11 * kBlock + owner];
-                    wign = rign[owner];
-                    T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
-                    T.t = bound; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
-                }
-            }
-        }
-    }
-    const unsigned long long key = rkey[tid];
-    if (key != ~0ull) {
-        T.t = __uint_as_float((uint32_t)(key >> 32));
-        T.id = (uint32_t)key;
-        T.leaf_index = rleaf[tid];
-    } else {
-        T.t = tmax;
-        T.leaf_index = -1;
-        T.id = 0xFFFFFFFFu;
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void update_sound_shared_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc,
                                                                      int rays_per_wave) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | share area
@@ -1774,16 +1564,8 @@ __global__ __launch_bounds__(kBlock) void update_sound_shared_kernel(DeviceScene
         }
     } else if (mine) {
         // initial direction: FMath::VRandCone((0,-1,0), PI, PI) FSAC.cpp:291 == theta = 2 pi U, phi = acos(2V-1)
-        uint32_t c0 = (uint32_t)i, c1 = 0u, c2 = 0u, c3 = 0x46533032u, k0 = sp.seed_lo, k1 = sp.seed_hi;
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-            uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-        const float U = u01(c0), V = u01(c1);
+        const uint4 rnd = philox((uint32_t)i, 0u, 0u, sp.seed_lo, sp.seed_hi, 0x46533032u);
+        const float U = u01(rnd.x), V = u01(rnd.y);
         const float x = fmaf(V, 2.0f, -1.0f);
         const float sphi = sqrtf(fmaxf(0.0f, fmaf(-x, x, 1.0f)));
         float st, ct;
@@ -1832,7 +1614,7 @@ __global__ __launch_bounds__(kBlock) void update_sound_shared_kernel(DeviceScene
             ign = dactor;
         }
         Trav T;
-        trav_closest_shared_ign(sc, has, r, tmax, ign, T, stack, share);
+        trav_shared<false, true>(sc, has, r, tmax, ign, T, stack, share);
         if (!has) continue;
         // legacy_trace: closest of the triangles and the pawn sphere
         ++traces;
@@ -1903,100 +1685,6 @@ __global__ __launch_bounds__(kBlock) void update_sound_shared_kernel(DeviceScene
         if (direct_hits) { atomicAdd(&acc->direct_hits, direct_hits); atomicAdd(&acc->direct_energy_sum, direct_sum); }
     }
     if (traces) atomicAdd(&acc->traces, traces);
-}
-
-__global__ __launch_bounds__(kBlock) void update_sound_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
-    int* s_stack = s_dyn;
-    int* stack = &s_stack[threadIdx.x];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int N = sp.raycasts_per_tick;
-    if (i > N) return;
-    unsigned long long traces = 0;
-    if (i == N) {                                                         // FSAC.cpp:295-299
-        float dx = sp.lis[0] - sp.src[0], dy = sp.lis[1] - sp.src[1], dz = sp.lis[2] - sp.src[2];
-        float l2 = dx * dx + dy * dy + dz * dz;
-        float occ = 0.0f;
-        if (l2 > 0.0f) {
-            float inv = 1.0f / sqrtf(l2);
-            occ = cast_direct(sc, sp, dx * inv, dy * inv, dz * inv, sp.src[0], sp.src[1], sp.src[2],
-                              sp.raycast_distance, 10, 1.0f, kNoObject, stack, traces);
-        }
-        acc->occlusion = occ;
-        atomicAdd(&acc->traces, traces);
-        return;
-    }
-    // initial direction: FMath::VRandCone((0,-1,0), PI, PI) FSAC.cpp:291 == theta = 2 pi U, phi = acos(2V-1)
-    float ddx, ddy, ddz;
-    {
-        uint32_t c0 = (uint32_t)i, c1 = 0u, c2 = 0u, c3 = 0x46533032u, k0 = sp.seed_lo, k1 = sp.seed_hi;
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-            uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-        const float U = u01(c0), V = u01(c1);
-        const float x = fmaf(V, 2.0f, -1.0f);
-        const float sphi = sqrtf(fmaxf(0.0f, fmaf(-x, x, 1.0f)));
-        float st, ct;
-        sincos2pi(U, st, ct);
-        const float nx = 0.0f, ny = -1.0f, nz = 0.0f;
-        float sg = copysignf(1.0f, nz);
-        float a = -1.0f / (sg + nz);
-        float b = nx * ny * a;
-        float t0 = fmaf(sg * nx * nx, a, 1.0f), t1 = sg * b, t2 = -sg * nx;
-        float b0 = b, b1 = fmaf(ny * ny, a, sg), b2 = -ny;
-        float lx = sphi * ct, ly = sphi * st;
-        float d0 = fmaf(lx, t0, fmaf(ly, b0, x * nx));
-        float d1 = fmaf(lx, t1, fmaf(ly, b1, x * ny));
-        float d2 = fmaf(lx, t2, fmaf(ly, b2, x * nz));
-        float l2 = d0 * d0 + d1 * d1 + d2 * d2;
-        float inv = 1.0f / sqrtf(l2);
-        ddx = d0 * inv; ddy = d1 * inv; ddz = d2 * inv;
-    }
-    // CastAudioRay FSAC.cpp:132-207 (tail recursion as a loop)
-    float px = sp.src[0], py = sp.src[1], pz = sp.src[2];
-    float max_distance = sp.raycast_distance;
-    int bounces = sp.raycast_bounces;
-    const float energy = 1.0f;
-    float result = 0.0f;
-    unsigned direct_hits = 0;
-    float direct_sum = 0.0f;
-    while (true) {
-        if (bounces == 0) break;                                          // FSAC.cpp:134
-        float l2 = ddx * ddx + ddy * ddy + ddz * ddz;                     // GetSafeNormal FSAC.cpp:141
-        float inv = 1.0f / sqrtf(l2);
-        const float dx = ddx * inv, dy = ddy * inv, dz = ddz * inv;
-        Ray r = make_ray(px, py, pz, dx, dy, dz);
-        LegacyHit h;
-        if (!legacy_trace(sc, sp, r, max_distance, kNoObject, stack, h, traces)) break;   // FSAC.cpp:192-196
-        const float ipx = fmaf(h.t, dx, px), ipy = fmaf(h.t, dy, py), ipz = fmaf(h.t, dz, pz);
-        const float left = max_distance - h.t;                            // DistanceLeft FSAC.cpp:167
-        const float tx = sp.lis[0] - ipx, ty = sp.lis[1] - ipy, tz = sp.lis[2] - ipz;
-        const float dist_to_player = sqrtf(tx * tx + ty * ty + tz * tz);
-        const float travel_time = (sp.raycast_distance - left + dist_to_player) * 0.01f / 343.0f;   // :171
-        if (travel_time > sp.simulated_duration) break;
-        if (h.object == kPawnObject) { result = energy; break; }          // FSAC.cpp:177-181
-        if (dist_to_player > 0.0f) {                                      // FSAC.cpp:184-185
-            const float invp = 1.0f / dist_to_player;
-            const float de = cast_direct(sc, sp, tx * invp, ty * invp, tz * invp, ipx, ipy, ipz, left, 1, energy,
-                                         kNoObject, stack, traces);
-            if (de > 0.0f) { ++direct_hits; direct_sum += de; }
-        }
-        const float dn = dx * h.nx + dy * h.ny + dz * h.nz;               // GetReflectionVector FSAC.cpp:186
-        ddx = fmaf(-2.0f * dn, h.nx, dx);
-        ddy = fmaf(-2.0f * dn, h.ny, dy);
-        ddz = fmaf(-2.0f * dn, h.nz, dz);
-        px = fmaf(h.nx, 0.5f, ipx); py = fmaf(h.ny, 0.5f, ipy); pz = fmaf(h.nz, 0.5f, ipz);   // FSAC.cpp:187
-        max_distance = left;
-        bounces -= 1;
-    }
-    if (result > 0.0f) atomicAdd(&acc->reaching, 1u);
-    if (direct_hits) { atomicAdd(&acc->direct_hits, direct_hits); atomicAdd(&acc->direct_energy_sum, direct_sum); }
-    atomicAdd(&acc->traces, traces);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2088,15 +1776,25 @@ __global__ void add_energy_kernel(float* row, int nb, float delay, float e) {
 }
 
 // dynamic LDS of a traversal kernel: the scene's stack rows (+ extra bytes behind them).  Sizes above the default
-// 64 KB limit are announced to the runtime once per kernel.
+// 48 KB limit are announced to the runtime once per (kernel instantiation, device); the host side has already
+// checked the worst case against the device's LDS (fs_capi.cpp: lds_budget_ok), so a failure here is unexpected
+// and is left for the launch's own error to report.
+#ifdef FS_EXPERIMENTS
+#define FS_SHARED_WALK(wl) ((wl).variant == 2)
+#else
+#define FS_SHARED_WALK(wl) true
+#endif
 inline size_t stack_bytes(const DeviceScene& sc) { return sizeof(int) * (size_t)sc.stack_rows * (size_t)kBlock; }
+constexpr int kMaxDevices = 64;
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
-    static size_t allowed = 48 * 1024;   // per kernel instantiation
-    if (bytes > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        allowed = bytes;
-    }
+    static std::atomic<size_t> allowed[kMaxDevices];   // per kernel instantiation; 0 = the default limit
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    const size_t have = std::max<size_t>(allowed[dev].load(std::memory_order_relaxed), 48 * 1024);
+    if (bytes > have &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess)
+        allowed[dev].store(bytes, std::memory_order_relaxed);
 }
 
 template <int B>
@@ -2138,30 +1836,13 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
     return sort ? wl.perm : nullptr;
 }
 
-bool launch_walk_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                         const uint32_t* perm, unsigned* pair_done, float* energy, unsigned long long* fixed, hipStream_t s) {
-    const uint32_t lanes = 2u * kp.num_local;
-    if (lanes == 0 || wl.variant != 2 || !pair_done) return false;
-    const uint32_t full = (lanes + kBlock - 1) / kBlock;
-    const size_t lds = stack_bytes(sc) + kShareLdsBytes;   // the visibility query reuses the share area (needs less)
-    if (kp.lobes) {
-        allow_lds(walk_connect_kernel<1>, lds);
-        hipLaunchKernelGGL(walk_connect_kernel<1>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm, pair_done,
-                           B, energy, fixed);
-    } else {
-        allow_lds(walk_connect_kernel<0>, lds);
-        hipLaunchKernelGGL(walk_connect_kernel<0>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm, pair_done,
-                           B, energy, fixed);
-    }
-    return true;
-}
-
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s) {
     uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
-    if (wl.variant == 2 && wl.rays_per_wave > 0 && wl.rays_per_wave < 64) {   // small frame: sparse waves, idle lanes help
+    const bool shared = FS_SHARED_WALK(wl);
+    if (shared && wl.rays_per_wave > 0 && wl.rays_per_wave < 64) {   // small frame: sparse waves, idle lanes help
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
@@ -2176,8 +1857,8 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
         }
         return;
     }
-    if (wl.variant == 2) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
-        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
+    if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes + (size_t)FS_LDS_TOP * sizeof(NodeQ4);
         if (kp.lobes) {
             allow_lds(walk_kernel_shared<1>, lds);
             hipLaunchKernelGGL(walk_kernel_shared<1>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm);
@@ -2187,21 +1868,15 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
         }
         return;
     }
-    if (wl.variant == 0) {
-        if (kp.lobes) {
-            allow_lds(walk_kernel_simple<1>, stack_bytes(sc));
-            hipLaunchKernelGGL(walk_kernel_simple<1>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
-        } else {
-            allow_lds(walk_kernel_simple<0>, stack_bytes(sc));
-            hipLaunchKernelGGL(walk_kernel_simple<0>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
-        }
-        return;
+#ifdef FS_EXPERIMENTS
+    if (kp.lobes) {
+        allow_lds(walk_kernel_simple<1>, stack_bytes(sc));
+        hipLaunchKernelGGL(walk_kernel_simple<1>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
+    } else {
+        allow_lds(walk_kernel_simple<0>, stack_bytes(sc));
+        hipLaunchKernelGGL(walk_kernel_simple<0>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
     }
-    uint32_t blocks = (uint32_t)wl.num_cus * (uint32_t)wl.blocks_per_cu;
-    if (blocks > full) blocks = full;
-    if (blocks == 0) blocks = 1;
-    allow_lds(walk_kernel_persistent, stack_bytes(sc));
-    hipLaunchKernelGGL(walk_kernel_persistent, dim3(blocks), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
+#endif
 }
 
 template <int B>
@@ -2269,11 +1944,7 @@ void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, co
 
 void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, int rays_per_wave, hipStream_t s) {
     int lanes = sp.raycasts_per_tick + 1;
-    if (rays_per_wave >= 64 || rays_per_wave <= 0) {   // one ray per lane, no sharing (FS_SOUND_RAYS_PER_WAVE=64)
-        allow_lds(update_sound_kernel, stack_bytes(sc));
-        hipLaunchKernelGGL(update_sound_kernel, dim3((lanes + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(sc), s, sc, sp, acc);
-        return;
-    }
+    if (rays_per_wave > 64 || rays_per_wave <= 0) rays_per_wave = 64;   // 64 = one ray per lane (finished lanes still help)
     const int waves = (lanes + rays_per_wave - 1) / rays_per_wave;
     const size_t lds = stack_bytes(sc) + kShareIgnLdsBytes;
     allow_lds(update_sound_shared_kernel, lds);
@@ -2290,6 +1961,11 @@ void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, con
     hipLaunchKernelGGL(reverb_push_kernel, dim3((frame + tb - 1) / tb), dim3(tb), 0, s, in, ring, head, frame);
 }
 
+#ifdef FS_WAVE_TIMELINE
+extern "C" void fs_debug_wave_buffer(unsigned long long* device_ptr) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_buf), &device_ptr, sizeof(device_ptr));
+}
+#endif
 #ifdef FS_TRAV_STATS
 extern "C" void fs_debug_trav_stats(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 8);
@@ -2299,6 +1975,13 @@ extern "C" void fs_debug_step_buffer(unsigned short* device_ptr) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_buf), &device_ptr, sizeof(device_ptr));
 }
 #endif
+
+size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins) {
+    const size_t stack = sizeof(int) * (size_t)stack_rows * (size_t)kBlock;
+    const size_t walk = stack + std::max(kShareLdsBytes, kShareIgnLdsBytes);
+    const size_t connect = stack + sizeof(float) * (size_t)bands * (size_t)num_bins + kShareAnyLdsBytes;
+    return std::max(walk, connect) + 1024;   // + the kernels' small static arrays
+}
 
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s) {
     hipLaunchKernelGGL(add_energy_kernel, dim3(1), dim3(1), 0, s, energy_row, num_bins, delay_s, e);

@@ -367,29 +367,6 @@ def test_force_update_sources_batches_all_active_sources(pkg, oracle_mod, scene_
     assert not np.array_equal(one_by_one[0], one_by_one[1])
 
 
-def test_fused_walk_connect_kernel_matches(pkg, oracle_mod, scene_factory, monkeypatch):
-    """The opt-in one-kernel walk + connect (FS_FUSE_CONNECT=1; not the default, it is slower) deposits the same paths:
-    oracle parity and identical counters, also across frames of changing size (the per-pair arrival counters are
-    never reset) and in deterministic mode."""
-    monkeypatch.setenv("FS_FUSE_CONNECT", "1")
-    monkeypatch.setenv("FS_WALK_RAYS_PER_WAVE", "64")           # dense waves also for the small frames here
-    sc = scene_factory("starter_room", 4)
-    ctx, src = make_ctx(pkg, sc)
-    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
-    for rays, depth, flags in ((8192, 8, 0), (2 * 777, 6, 0), (16384, 8, 0), (4096, 8, 8), (8192, 8, 0)):
-        ctx.reset_stats()
-        e = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=rays, flags=flags))
-        st = ctx.stats()
-        e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=rays),
-                                           sc.source, sc.listener)
-        if flags & 8:
-            assert max(rel_rms(e[b], e64[b]) for b in range(4)) <= TIGHT_TOL
-        else:
-            check_energy(e, e32, e64, 4)
-        assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
-    ctx.close()
-
-
 BATCH_CASES = [
     # id, scene, bands, rays per source, depth, sources, extra params
     ("three_sources_ragged", "starter_room", 4, 2 * 777, 8, 3, {}),
