@@ -120,6 +120,7 @@ struct fs_context {
 
     // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
     WalkLaunch walk{2, 256, nullptr, 1, nullptr};   // variant 2 = wave work sharing
+    int hist_window = kHistWindow; // FS_HIST_WINDOW
     size_t lds_limit = 64 * 1024;  // dynamic LDS a workgroup may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int walk_rays_per_wave = 0;    // BDPT walk: subpaths per wave, 0 = by frame size (FS_WALK_RAYS_PER_WAVE; 64 = dense waves)
     int connect_pairs_per_wave = 0;   // connect kernel: pairs per wave, 0 = by frame size (FS_CONNECT_PAIRS_PER_WAVE; 64 = dense)
@@ -463,6 +464,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_HIST_WINDOW")) ctx->hist_window = std::max(1, std::min(4096, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_CONNECT_PAIRS_PER_WAVE")) ctx->connect_pairs_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
@@ -777,6 +779,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     std::memcpy(kp.src, s->pos, sizeof(kp.src));
     std::memcpy(kp.lis, ctx->listener, sizeof(kp.lis));
     kp.num_bins = ctx->num_bins;
+    kp.hist_window = std::min(ctx->num_bins, ctx->hist_window);
 
     kp.lobes = (p->flags & FS_FLAG_MATERIAL_LOBES) ? 1 : 0;
     const bool mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;

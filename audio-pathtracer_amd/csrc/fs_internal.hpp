@@ -51,6 +51,11 @@ static_assert(sizeof(Tri64) == 64, "Tri64 must be 64 B");
 constexpr int kStackDepth = 64;   // largest worst-case stack need the builder accepts before it rebuilds shallower
 constexpr int kStackSlack = 1;
 constexpr int kBlock = 256;       // 4 waves of 64 lanes
+// LDS-privatised part of the [bands][bins] energy histogram in the connect kernels.  With the reference's distance
+// scale (cm / 1000, ARTS.cpp:373) bin = path length in metres / 3.43: 256 bins cover 878 m, and a 262 144-ray frame
+// at cfg3 touches bins 0..60.  All 1000 bins cost 32 KB per workgroup at 8 bands — the 8 KB window keeps three
+// connect workgroups on a CU instead of two.  FS_HIST_WINDOW overrides it (tests exercise the far path with 16).
+constexpr int kHistWindow = 256;
 
 struct DeviceScene {
     const NodeQ4* nodes;
@@ -62,8 +67,6 @@ struct DeviceScene {
     int32_t num_tris;
     int32_t num_materials;
     int32_t stack_rows;       // LDS stack rows per lane for this tree (see kStackDepth)
-    const float4* top = nullptr;   // kernel-side only: LDS copy of the first top_nodes nodes (FS_LDS_TOP experiment)
-    int32_t top_nodes = 0;
 };
 
 // per-update constants handed to the kernels by value
@@ -85,6 +88,8 @@ struct KParams {
     float air[FS_MAX_BANDS];
     float src[3], lis[3];
     int32_t num_bins;
+    int32_t hist_window;   // the connect kernels privatise bins [0, hist_window) of every band in LDS; deposits beyond go
+                           // straight to the energy buffer with global atomics (kHistWindow, or all bins if fewer)
 };
 
 // legacy forward tracer (UpdateSound) constants and device-side accumulators

@@ -40,28 +40,10 @@ constexpr uint32_t kNoMat = FS_NO_MATERIAL;
 constexpr uint32_t kLobeDiffuse = 0u, kLobeSpecular = 1u, kLobeTransmit = 2u;
 constexpr int kLobeShift = 16;   // segment record: material id | lobe << 16
 constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
-#ifndef FS_CHILD_ORDER
-#define FS_CHILD_ORDER 0   // closest-hit traversal: 0 = children fully sorted near-first, 1 = nearest first + rest in slot order
-#endif
-#ifndef FS_MASKED_LOADS
-#define FS_MASKED_LOADS 0  // traversal record fetches: 1 = exec-masked inline-asm loads, 0 = every lane loads (dummy record 0)
-#endif
-#ifndef FS_LDS_TOP
-#define FS_LDS_TOP 0       // walk_kernel_shared: number of top-of-tree nodes staged in LDS per workgroup (experiment), 0 = none
-#endif
-#ifndef FS_PREFETCH
-#define FS_PREFETCH 0      // trav_shared: request the next step's records before the work-sharing round (needs FS_MASKED_LOADS)
-#endif
-#if FS_PREFETCH && !FS_MASKED_LOADS
-#error "FS_PREFETCH needs FS_MASKED_LOADS"
-#endif
-#ifndef FS_ANY_ORDER
-#define FS_ANY_ORDER 0     // any-hit traversal: 0 = sorted, 1 = nearest first, 2 = first hit slot (no ordering at all)
-#endif
 constexpr double kFixedScale = 1099511627776.0;   // 2^40: quantum of the deterministic (fixed-point) energy sum
 #ifdef FS_WAVE_TIMELINE   // diagnostic build only (tools/wave_timeline.py): when every walk wave ran and what it spent its cycles on
 __device__ unsigned long long* g_wave_buf;       // [waves][8]: start, end (100 MHz), cycles in traversal, cycles in all, iterations, segments, hw id, slot
-__device__ unsigned long long g_tl_iter;         // scratch the shared traversal loop adds its iteration count to (per lane 0 of a wave)
+__device__ unsigned long long* g_conn_buf;       // [waves][8]: connect kernel: start, set-up done, visibility done, evaluated, end (100 MHz), lane-0 deposits
 #endif
 #ifdef FS_TRAV_STATS
 __device__ unsigned long long g_trav_stats[8];   // [0] step calls, [1] node iterations, [2] node lanes, [3] tri iterations, [4] tri lanes
@@ -248,12 +230,12 @@ __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tr
 //   trav_issue    request the node and / or triangle record the lane needs next
 //   trav_wait     the records have arrived
 //   trav_consume  triangle test, node test, pushes, next node
-// FS_MASKED_LOADS = 1: the loads are inline asm under the lanes' own exec mask, waited for once behind both groups —
-// a lane without a pending triangle (or node) requests nothing, and the request may be issued long before the use
-// (FS_PREFETCH: trav_shared issues it before the work-sharing round).  FS_MASKED_LOADS = 0 (round 1's form): plain
-// loads in trav_consume, every lane fetches (a dummy record 0 when it needs none), no branches around the loads:
-// inside `if (has_node)` / `if (has_tri)` blocks the compiler sinks the first arithmetic on the loaded words into the
-// block of the loads, i.e. waits for one record before it requests the other.
+// The loads are inline asm under the lanes' own exec mask, waited for once behind both groups: a lane without a
+// pending triangle (or node) requests nothing, both records of a lane are in flight together, and the request may be
+// issued long before the use — trav_shared issues it before the work-sharing round.  (Round 1 let every lane fetch a
+// dummy record 0 with plain loads instead, because inside `if (has_node)` / `if (has_tri)` blocks the compiler sinks
+// the first arithmetic on the loaded words into the block of the loads, i.e. waits for one record before it requests
+// the other: 448 lane-loads per wave iteration for 207 useful ones, the CU's vector memory return path 79 % busy.)
 typedef float v4f __attribute__((ext_vector_type(4)));
 struct TravRegs { v4f q0, q1, q2, q3, a, b, c; };
 
@@ -267,18 +249,7 @@ __device__ __forceinline__ void trav_settle(Trav& T, int* stack) {
 }
 
 __device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T, TravRegs& R) {
-#if FS_MASKED_LOADS
-#if FS_LDS_TOP
-    // experiment (north_star: "nodes ... staged through LDS"): the first FS_LDS_TOP nodes of the breadth-first array —
-    // the top levels of the tree — are read from a per-workgroup LDS copy
-    if (T.cur >= 0 && T.cur < sc.top_nodes) {
-        const v4f* lp = reinterpret_cast<const v4f*>(sc.top) + 4 * T.cur;
-        R.q0 = lp[0]; R.q1 = lp[1]; R.q2 = lp[2]; R.q3 = lp[3];
-    }
-    if (T.cur >= sc.top_nodes) {
-#else
     if (T.cur >= 0) {
-#endif
         const NodeQ4* np = sc.nodes + T.cur;
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
                      "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
@@ -290,13 +261,10 @@ __device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T,
                      "global_load_dwordx4 %2, %3, off offset:32"
                      : "=&v"(R.a), "=&v"(R.b), "=&v"(R.c) : "v"(tp) : "memory");
     }
-#endif
 }
 
 __device__ __forceinline__ void trav_wait(TravRegs& R) {
-#if FS_MASKED_LOADS
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(R.q0), "+v"(R.q1), "+v"(R.q2), "+v"(R.q3), "+v"(R.a), "+v"(R.b), "+v"(R.c));
-#endif
 }
 
 template <bool ANY, bool IGN = false>
@@ -304,23 +272,6 @@ __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r
                                              uint32_t ignore_object = 0xFFFFFFFFu) {
     const bool has_tri = T.tri_i < T.tri_n;
     const bool has_node = T.cur >= 0;
-#if defined(FS_DUMMY_VALU) || defined(FS_DUMMY_SALU)   // sensitivity experiment: what does one more instruction per step cost?
-    {
-        float d0 = r.ox, d1 = r.oy;
-#ifdef FS_DUMMY_VALU
-#pragma unroll
-        for (int i = 0; i < FS_DUMMY_VALU / 2; ++i) {
-            asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(d0) : "v"(r.dx));
-            asm volatile("v_max_f32 %0, %0, %1" : "+v"(d1) : "v"(r.dy));
-        }
-#endif
-#ifdef FS_DUMMY_SALU
-#pragma unroll
-        for (int i = 0; i < FS_DUMMY_SALU; ++i) asm volatile("s_add_u32 s4, s4, 1" ::: "s4");
-#endif
-        asm volatile("" : : "v"(d0), "v"(d1));
-    }
-#endif
 #ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.py): SIMD occupancy of the two step kinds
     {
         const unsigned long long mt = __ballot(has_tri), mn = __ballot(has_node);
@@ -331,17 +282,10 @@ __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r
         }
     }
 #endif
-#if FS_MASKED_LOADS
     const float4 q0 = make_float4(R.q0.x, R.q0.y, R.q0.z, R.q0.w), q1 = make_float4(R.q1.x, R.q1.y, R.q1.z, R.q1.w),
-                 q2 = make_float4(R.q2.x, R.q2.y, R.q2.z, R.q2.w), q3 = make_float4(R.q3.x, R.q3.y, R.q3.z, R.q3.w);
+                 q2 = make_float4(R.q2.x, R.q2.y, R.q2.z, R.q2.w), q3 = make_float4(R.q3.x, R.q3.y, R.q3.z, R.q3.w);   // node
     const float4 a = make_float4(R.a.x, R.a.y, R.a.z, R.a.w), b = make_float4(R.b.x, R.b.y, R.b.z, R.b.w),
-                 c = make_float4(R.c.x, R.c.y, R.c.z, R.c.w);
-#else
-    const float4* trec = reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)(has_tri ? T.tri_i : 0);
-    const float4* nrec = reinterpret_cast<const float4*>(sc.nodes) + 4 * (size_t)(has_node ? T.cur : 0);
-    const float4 q0 = nrec[0], q1 = nrec[1], q2 = nrec[2], q3 = nrec[3];   // node
-    const float4 a = trec[0], b = trec[1], c = trec[2];                    // triangle: v0 | e1 | e2 (+ material, id, object)
-#endif
+                 c = make_float4(R.c.x, R.c.y, R.c.z, R.c.w);   // triangle: v0 | e1 | e2 (+ material, id, object)
     if (has_tri) {
         float t = 0.0f;
         // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
@@ -407,51 +351,26 @@ __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r
 #ifdef FS_TRAV_STATS
         atomicAdd(&g_trav_stats[5 + (hits > 2 ? 2 : hits)], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
 #endif
-        constexpr int kOrder = ANY ? FS_ANY_ORDER : FS_CHILD_ORDER;
-        int p1;
-        if (kOrder == 0) {
-            // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free
+        // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free.  (Measured in
+        // round 2: choosing only the nearest child and pushing the rest in slot order — also no ordering at all for
+        // visibility rays — saves a dozen instructions per visit and costs as much in extra visits: walk 0.356 ->
+        // 0.361 ms, connect 0.075 -> 0.078 ms.)
 #define FS_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t lo_ = min(key[a], key[b]); \
                          const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; \
                          const int ra_ = sw_ ? ref##b : ref##a; const int rb_ = sw_ ? ref##a : ref##b; \
                          ref##a = ra_; ref##b = rb_; }
-            FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
+        FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
 #undef FS_CSWAP
-            // far children wait on the stack, farthest pushed first.  Written unconditionally: a push that does
-            // not happen lands on the free slot above the top and is overwritten by the next one (or ignored),
-            // which is cheaper than three exec-mask branches; the two rows above the tree's worst-case need absorb it.
-            const int p3 = T.sp;
-            const int p2 = p3 + (hits >= 4 ? 1 : 0);
-            p1 = p2 + (hits >= 3 ? 1 : 0);
-            if (hits >= 2) {   // 3 of 4 visits hit at most one child and push nothing
-                stack[p3 * kBlock] = ref3;
-                stack[p2 * kBlock] = ref2;
-                stack[p1 * kBlock] = ref1;
-            }
-        } else {
-            // only the child to descend into is chosen (kOrder 1: the nearest; 2: the first hit slot — a visibility
-            // ray does not care); the other hit children are pushed in slot order.  Every slot writes at
-            // sp + (#pushes before it): a slot that is not pushed is overwritten by the next push or lands on the
-            // free slot above the new top.
-            uint32_t k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3];
-            if (kOrder == 2) {   // entry distance dropped from the key: min = first hit slot
-                k0 = k0 < 0xFFFFFFFCu ? 0u : k0; k1 = k1 < 0xFFFFFFFCu ? 1u : k1;
-                k2 = k2 < 0xFFFFFFFCu ? 2u : k2; k3 = k3 < 0xFFFFFFFCu ? 3u : k3;
-            }
-            const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-            const uint32_t first = kmin & 3u;
-            const int push0 = (key[0] < 0xFFFFFFFCu) & (first != 0u), push1 = (key[1] < 0xFFFFFFFCu) & (first != 1u),
-                      push2 = (key[2] < 0xFFFFFFFCu) & (first != 2u);
-            const int rfirst = first == 0u ? ref0 : (first == 1u ? ref1 : (first == 2u ? ref2 : ref3));
-            const int q0p = T.sp, q1p = q0p + push0, q2p = q1p + push1, q3p = q2p + push2;
-            if (hits >= 2) {
-                stack[q0p * kBlock] = ref0;
-                stack[q1p * kBlock] = ref1;
-                stack[q2p * kBlock] = ref2;
-                stack[q3p * kBlock] = ref3;
-            }
-            p1 = T.sp + (hits >= 2 ? hits - 2 : 0);   // hits >= 2: new top = sp + hits - 1 (the line below adds the 1)
-            ref0 = rfirst;
+        // far children wait on the stack, farthest pushed first, at sp .. sp + hits - 2: with two hits all three stores
+        // land on sp and the last one (the second nearest) stays, with three hits the first two share sp — no store
+        // goes above the new top, so the stack needs exactly the tree's worst-case number of rows.
+        const int p3 = T.sp;
+        const int p2 = p3 + (hits >= 4 ? 1 : 0);
+        const int p1 = p2 + (hits >= 3 ? 1 : 0);
+        if (hits >= 2) {   // 3 of 4 visits hit at most one child and push nothing
+            stack[p3 * kBlock] = ref3;
+            stack[p2 * kBlock] = ref2;
+            stack[p1 * kBlock] = ref1;
         }
         T.sp = p1 + (hits >= 2 ? 1 : 0);
         if (hits >= 1) {
@@ -835,7 +754,6 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     uint32_t wign = ignore;
     Ray wr = own;
     trav_init(T, tmax, has_ray && sc.num_nodes > 0);
-#if FS_PREFETCH
     // The records of the NEXT step are requested as soon as this step has decided what they are — before the
     // work-sharing round below (ballots, donation boxes, mailboxes: half a dozen LDS round trips), which then runs
     // in the shadow of the fetch.  A wave in the thin tail of the frame runs alone on its SIMD and nothing else
@@ -844,17 +762,10 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     TravRegs R;
     trav_settle(T, stack);
     trav_issue(sc, T, R);
-#endif
     while (true) {
-#if FS_PREFETCH
         trav_wait(R);
-#endif
         if (trav_busy(T)) {
-#if FS_PREFETCH
             trav_consume<ANY, IGN>(sc, wr, T, stack, R, wign);
-#else
-            trav_step<ANY, IGN>(sc, wr, T, stack, wign);
-#endif
             if (ANY) {
                 if (T.leaf_index >= 0) { A.blocked[owner] = 1; T.leaf_index = -1; }   // first hit ends the query (T is idle now)
                 else if (A.blocked[owner]) { T.cur = kDone; T.sp = 0; T.sb = 0; T.tri_n = T.tri_i; }   // settled by another lane
@@ -863,10 +774,8 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
                 atomicMin(&A.rkey[owner], key);
                 if (A.rkey[owner] == key) A.rleaf[owner] = T.leaf_index;
             }
-#if FS_PREFETCH
             trav_settle(T, stack);
             trav_issue(sc, T, R);
-#endif
         }
         const bool idle = !trav_busy(T);
         const unsigned long long busy_m = __ballot(!idle);
@@ -907,10 +816,8 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
                     if (IGN) wign = A.rign[owner];
                     T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
                     T.t = bound; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
-#if FS_PREFETCH
                     trav_settle(T, stack);
                     trav_issue(sc, T, R);
-#endif
                 }
             }
         }
@@ -944,23 +851,13 @@ template <int LOBES>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area [| tree top]
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
-#if FS_LDS_TOP
-    {
-        int4* top = reinterpret_cast<int4*>(reinterpret_cast<char*>(s_dyn) + sizeof(int) * (size_t)sc.stack_rows * kBlock + kShareLdsBytes);
-        const int n = min(FS_LDS_TOP, sc.num_nodes);
-        const int4* src = reinterpret_cast<const int4*>(sc.nodes);
-        for (int i = threadIdx.x; i < 4 * n; i += kBlock) top[i] = src[i];
-        sc.top = reinterpret_cast<const float4*>(top);
-        sc.top_nodes = n;
-    }
-#endif
     if (perm) {
         for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
     }
-    if (perm || FS_LDS_TOP) __syncthreads();
+    if (perm) __syncthreads();
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= 2u * kp.num_local) return;
     const uint32_t g = perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot;
@@ -1052,14 +949,17 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head,
                                                          int pairs_per_wave, float* const* __restrict__ energy_tab,
                                                          unsigned long long* const* __restrict__ fixed_tab) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][hist_window] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
-    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * kp.num_bins);   // work-sharing area of trav_any_shared
+    const int nb = kp.num_bins, W = kp.hist_window;   // LDS histogram = the first W bins of every band (see KParams)
+    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * W);   // work-sharing area of trav_any_shared
     __shared__ int s_lo, s_hi;
     __shared__ unsigned s_dep;
-    const int nb = kp.num_bins;
-    for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
+#ifdef FS_WAVE_TIMELINE
+    unsigned long long tl[6] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0};
+#endif
+    for (int i = threadIdx.x; i < B * W; i += kBlock) s_hist[i] = 0.0f;
     if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; }
     // this frame's walk is over: rearm the frame scratch (queue head, plan counts and cursors) for the next one
     if (blockIdx.x == 0)
@@ -1075,7 +975,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 
     // one chunk of per_block pairs [first, first + per_block) clipped to `end`, deposits into s_hist / fixed_dst
-    auto chunk = [&](uint32_t first, uint32_t end, unsigned long long* fixed_dst) {
+    auto chunk = [&](uint32_t first, uint32_t end, unsigned long long* fixed_dst, float* far_dst) {
         const uint32_t li = first + wave * ppw + lane;
         const bool active = lane < ppw && li < end;
         const uint32_t lc = active ? li : 0u;
@@ -1091,7 +991,13 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         float tmax = len - kp.connect_pullback;
         const bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
         Ray ray = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
+#ifdef FS_WAVE_TIMELINE
+        if (!tl[1]) tl[1] = __builtin_amdgcn_s_memrealtime();   // first chunk: set-up and end-state loads done
+#endif
         const bool hit = trav_any_shared(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share);
+#ifdef FS_WAVE_TIMELINE
+        if (!tl[2]) tl[2] = __builtin_amdgcn_s_memrealtime();   // first chunk: visibility queries done
+#endif
         if (!active || hit) return;
         ++my_deposits;
         // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
@@ -1120,7 +1026,8 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
         float fl = floorf(x);
         int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
-        if (!fixed_dst) {
+        const bool near = bin < W;
+        if (!fixed_dst && near) {
             atomicMin(&s_lo, bin);
             atomicMax(&s_hi, bin);
         }
@@ -1132,8 +1039,10 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
             e *= kp.norm;                                             // ARTS.cpp:164-170
             if (fixed_dst)   // deterministic mode: integer sum of 2^-40 quanta — exact, so order- and shard-independent
                 atomicAdd(&fixed_dst[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
+            else if (near)
+                atomicAdd(&s_hist[b * W + bin], e);                   // ds_add_f32
             else
-                atomicAdd(&s_hist[b * nb + bin], e);                  // ds_add_f32
+                atomicAdd(&far_dst[b * nb + bin], e);                 // beyond the LDS window: global_atomic_add_f32
         }
     };
     // LDS histogram -> one source's energy buffer (touched bin range only); clear = rearm it for the next source
@@ -1144,9 +1053,9 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
             const int span = hi - lo + 1;
             for (int i = threadIdx.x; i < B * span; i += kBlock) {
                 int b = i / span, bin = lo + (i - b * span);
-                float v = s_hist[b * nb + bin];
+                float v = s_hist[b * W + bin];
                 if (v != 0.0f) atomicAdd(&dst[b * nb + bin], v);      // global_atomic_add_f32
-                if (clear) s_hist[b * nb + bin] = 0.0f;
+                if (clear) s_hist[b * W + bin] = 0.0f;
             }
         }
         if (clear) {
@@ -1166,12 +1075,16 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
                 if (cur >= 0 && !fixed_tab) flush(energy_tab[cur], true);
                 cur = (int)sid;
             }
-            chunk(sid * nps + (it - sid * chunks) * per_block, (sid + 1) * nps, fixed_tab ? fixed_tab[sid] : nullptr);
+            chunk(sid * nps + (it - sid * chunks) * per_block, (sid + 1) * nps, fixed_tab ? fixed_tab[sid] : nullptr,
+                  energy_tab[sid]);
         }
         if (cur >= 0 && !fixed_tab) flush(energy_tab[cur], false);
     } else {
-        for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) chunk(base, n, fixed);
+        for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) chunk(base, n, fixed, energy);
     }
+#ifdef FS_WAVE_TIMELINE
+    tl[3] = __builtin_amdgcn_s_memrealtime();   // all chunks evaluated and deposited into LDS
+#endif
     {   // work counters: summed per wave, then per workgroup in LDS — one global atomic per workgroup (thousands of
         // atomics on one address cost the kernel ~10 %)
         unsigned d = my_deposits;
@@ -1186,14 +1099,22 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     }
     if (!BATCH) {
         const int lo = s_lo, hi = s_hi;
-        if (hi < lo) return;
-        const int span = hi - lo + 1;
-        for (int i = threadIdx.x; i < B * span; i += kBlock) {
-            int b = i / span, bin = lo + (i - b * span);
-            float v = s_hist[b * nb + bin];
-            if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);       // global_atomic_add_f32
+        if (hi >= lo) {
+            const int span = hi - lo + 1;
+            for (int i = threadIdx.x; i < B * span; i += kBlock) {
+                int b = i / span, bin = lo + (i - b * span);
+                float v = s_hist[b * W + bin];
+                if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);       // global_atomic_add_f32
+            }
         }
     }
+#ifdef FS_WAVE_TIMELINE
+    if ((threadIdx.x & 63u) == 0u && g_conn_buf) {
+        unsigned long long* o = g_conn_buf + 8ull * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+        o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = tl[3]; o[4] = __builtin_amdgcn_s_memrealtime();
+        o[5] = my_deposits; o[6] = 0; o[7] = 0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1267,13 +1188,13 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
                                                              float* __restrict__ energy,
                                                              unsigned long long* __restrict__ fixed,
                                                              unsigned* queue_head) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][num_bins] histogram
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][hist_window] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
-    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * kp.num_bins);   // work-sharing area of trav_any_shared
+    const int nb = kp.num_bins, W = kp.hist_window;
+    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * W);   // work-sharing area of trav_any_shared
     __shared__ int s_lo, s_hi;
-    const int nb = kp.num_bins;
-    for (int i = threadIdx.x; i < B * nb; i += kBlock) s_hist[i] = 0.0f;
+    for (int i = threadIdx.x; i < B * W; i += kBlock) s_hist[i] = 0.0f;
     if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; }
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
@@ -1342,7 +1263,8 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             float x = (delay * 1000.f) / 1.0f;
             float fl = floorf(x);
             int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
-            if (!fixed) {
+            const bool near = bin < W;
+            if (!fixed && near) {
                 atomicMin(&s_lo, bin);
                 atomicMax(&s_hi, bin);
             }
@@ -1355,8 +1277,10 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
                 e *= w;
                 if (fixed)
                     atomicAdd(&fixed[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
-                else
-                    atomicAdd(&s_hist[b * nb + bin], e);
+                else if (near)
+                    atomicAdd(&s_hist[b * W + bin], e);   // ds_add_f32.  (Summing the equal-bin deposits of a wave first —
+                else                                      // ballot per distinct bin + butterfly per band — measured slower:
+                    atomicAdd(&energy[b * nb + bin], e);  // 2.12 -> 2.47 ms at cfg3; a pair's paths rarely share a bin.)
             }
         }
     }
@@ -1375,7 +1299,7 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
     const int span = hi - lo + 1;
     for (int i = threadIdx.x; i < B * span; i += kBlock) {
         int b = i / span, bin = lo + (i - b * span);
-        float v = s_hist[b * nb + bin];
+        float v = s_hist[b * W + bin];
         if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);
     }
 }
@@ -1808,7 +1732,7 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
     uint32_t blocks = batch ? (kp.num_local / kp.pairs_per_source) * ((kp.pairs_per_source + per_block - 1) / per_block)
                             : (kp.num_local + per_block - 1) / per_block;
     if (blocks > 1024) blocks = 1024;
-    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins + kShareAnyLdsBytes;
+    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.hist_window + kShareAnyLdsBytes;
 #define FS_LAUNCH_CONNECT(L, BT)                                                                                     \
     do {                                                                                                             \
         allow_lds(connect_kernel<B, L, BT>, lds);                                                                    \
@@ -1858,7 +1782,7 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
         return;
     }
     if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
-        const size_t lds = stack_bytes(sc) + kShareLdsBytes + (size_t)FS_LDS_TOP * sizeof(NodeQ4);
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
         if (kp.lobes) {
             allow_lds(walk_kernel_shared<1>, lds);
             hipLaunchKernelGGL(walk_kernel_shared<1>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm);
@@ -1885,7 +1809,7 @@ void launch_connect_all_t(const DeviceScene& sc, const KParams& kp, const Subpat
     if (kp.num_local == 0) return;
     uint32_t blocks = (kp.num_local + 3) / 4;   // one wave per pair, 4 waves per workgroup
     if (blocks > 4096) blocks = 4096;
-    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.num_bins + kShareAnyLdsBytes;
+    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.hist_window + kShareAnyLdsBytes;
     allow_lds(connect_all_kernel<B>, lds);
     hipLaunchKernelGGL(connect_all_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
 }
@@ -1965,6 +1889,9 @@ void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, con
 extern "C" void fs_debug_wave_buffer(unsigned long long* device_ptr) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_buf), &device_ptr, sizeof(device_ptr));
 }
+extern "C" void fs_debug_connect_buffer(unsigned long long* device_ptr) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conn_buf), &device_ptr, sizeof(device_ptr));
+}
 #endif
 #ifdef FS_TRAV_STATS
 extern "C" void fs_debug_trav_stats(unsigned long long* out, int reset) {
@@ -1979,7 +1906,7 @@ extern "C" void fs_debug_step_buffer(unsigned short* device_ptr) {
 size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins) {
     const size_t stack = sizeof(int) * (size_t)stack_rows * (size_t)kBlock;
     const size_t walk = stack + std::max(kShareLdsBytes, kShareIgnLdsBytes);
-    const size_t connect = stack + sizeof(float) * (size_t)bands * (size_t)num_bins + kShareAnyLdsBytes;
+    const size_t connect = stack + sizeof(float) * (size_t)bands * (size_t)std::min(num_bins, kHistWindow) + kShareAnyLdsBytes;
     return std::max(walk, connect) + 1024;   // + the kernels' small static arrays
 }
 

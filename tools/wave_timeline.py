@@ -45,11 +45,20 @@ for i in range(5):   # warm
     ctx.compute_energy_response(s, p)
 hip.hipMemset(dptr, 0, 8 * 8 * W)
 lib.fs_debug_wave_buffer(dptr)
+cptr = C.c_void_p()
+CW = 4096   # connect waves (grid is capped at 1024 workgroups)
+assert hip.hipMalloc(C.byref(cptr), 8 * 8 * CW) == 0
+hip.hipMemset(cptr, 0, 8 * 8 * CW)
+lib.fs_debug_connect_buffer.argtypes = [C.c_void_p]
+lib.fs_debug_connect_buffer(cptr)
 p.seed = 0x5EED
 ctx.compute_energy_response(s, p)
 buf = np.zeros((W, 8), np.uint64)
 assert hip.hipMemcpy(buf.ctypes.data, dptr, buf.nbytes, 2) == 0
 lib.fs_debug_wave_buffer(None)
+cbuf = np.zeros((CW, 8), np.uint64)
+assert hip.hipMemcpy(cbuf.ctypes.data, cptr, cbuf.nbytes, 2) == 0
+lib.fs_debug_connect_buffer(None)
 live = buf[:, 1] > 0
 b = buf[live].astype(np.float64)
 t0 = b[:, 0].min()
@@ -77,4 +86,13 @@ if m8.sum():
     key = xcc[m8] * 100000 + cu[m8]
     _, counts = np.unique(key, return_counts=True)
     res["len8_waves_per_hw_slot_hist"] = {int(k): int(v) for k, v in zip(*np.unique(counts, return_counts=True))}
+cl = cbuf[cbuf[:, 4] > 0].astype(np.float64)
+if len(cl):
+    c0 = cl[:, 0].min()
+    ph = lambda a, b: {"p50": float(np.median((cl[:, b] - cl[:, a]) / 100.0)), "p90": float(np.percentile((cl[:, b] - cl[:, a]) / 100.0, 90)),
+                       "max": float(((cl[:, b] - cl[:, a]) / 100.0).max())}
+    res["connect"] = {"waves": int(len(cl)), "span_us": float((cl[:, 4].max() - c0) / 100.0),
+                      "start_us_max": float((cl[:, 0].max() - c0) / 100.0),
+                      "gap_after_walk_us": float((c0 - t0) / 100.0 - end.max()),
+                      "setup_us": ph(0, 1), "visibility_us": ph(1, 2), "evaluate_us": ph(2, 3), "flush_us": ph(3, 4), "wave_us": ph(0, 4)}
 print(json.dumps(res))
