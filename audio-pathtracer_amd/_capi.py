@@ -46,7 +46,10 @@ EXPORTS = [
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
     "fs_apply_material_fd", "fs_energy_handoff", "fs_scene_update_triangles", "fs_scene_refit", "fs_set_impulse_response",
+    "fs_comm_unique_id", "fs_comm_init", "fs_comm_attach", "fs_comm_detach", "fs_shard_range",
 ]
+COMM_ID_BYTES = 128
+ERR_COMM = 8
 REVERB_LITERAL_TAIL = 1
 
 
@@ -134,6 +137,10 @@ class Stats(C.Structure):
         ("segments", C.c_uint64),
         ("connections_tested", C.c_uint64),
         ("deposits", C.c_uint64),
+        ("walk_node_fetches", C.c_uint64),
+        ("walk_tri_fetches", C.c_uint64),
+        ("any_node_fetches", C.c_uint64),
+        ("any_tri_fetches", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -209,6 +216,11 @@ def load():
         "fs_reverb_process": (C.c_int, [vp, i32, f32p, f32p, i32, C.c_uint32]),
         "fs_reverb_release": (C.c_int, [vp, i32]),
         "fs_apply_material_fd": (C.c_int, [vp, f32p, i32, f32p, f32p, f32p, i32, f32p, f32p, f32p]),
+        "fs_comm_unique_id": (C.c_int, [vp, C.c_size_t]),
+        "fs_comm_init": (C.c_int, [vp, vp, C.c_size_t]),
+        "fs_comm_attach": (C.c_int, [vp, vp]),
+        "fs_comm_detach": (C.c_int, [vp]),
+        "fs_shard_range": (C.c_int, [C.c_uint32, i32, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

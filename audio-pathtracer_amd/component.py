@@ -57,6 +57,30 @@ class Context:
         except Exception:
             pass
 
+    # ---- multi-GPU: the library's own RCCL communicator (include/frequensee.h) ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: the 128-byte id every rank passes to comm_init (ship it with any host-side transport)"""
+        buf = (C.c_char * _capi.COMM_ID_BYTES)()
+        rc = _capi.load().fs_comm_unique_id(buf, _capi.COMM_ID_BYTES)
+        if rc != _capi.OK:
+            raise FrequenSeeError(rc, "fs_comm_unique_id failed (librccl not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes):
+        """collective over the world_size ranks: from now on every frame's energy buffer is summed over the ranks on
+        the tail stream, and set_scene lets rank 0 build the acceleration structure for all"""
+        if len(unique_id) != _capi.COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = (C.c_char * _capi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self.check(self.lib.fs_comm_init(self.h, buf, _capi.COMM_ID_BYTES))
+
+    def comm_attach(self, nccl_comm: int):
+        self.check(self.lib.fs_comm_attach(self.h, C.c_void_p(int(nccl_comm))))
+
+    def comm_detach(self):
+        self.check(self.lib.fs_comm_detach(self.h))
+
     # ---- scene ----
     def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None, object_ids=None):
         tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
@@ -337,8 +361,12 @@ class AudioRayTracingSubsystem:
 
     USED_RAY_COUNT = 1000  # ARTS.h:176
 
-    def __init__(self, num_bands=1, device=0, rank=0, world_size=1, stream=None):
+    def __init__(self, num_bands=1, device=0, rank=0, world_size=1, stream=None, comm_id=None):
+        """comm_id: the 128 bytes of Context.comm_unique_id() (made by rank 0, shipped to all ranks): the subsystem of
+        a sharded run (world_size > 1) then sums every frame's energy buffer over the ranks inside the library"""
         self.ctx = Context(num_bands=num_bands, device=device, rank=rank, world_size=world_size, stream=stream)
+        if comm_id is not None:
+            self.ctx.comm_init(comm_id)
         self.ActiveSources = []
         self._geom = []          # registered (triangles, material_ids, actor ids)
         self._next_actor = 0
@@ -434,6 +462,8 @@ class AudioRayTracingSubsystem:
         if not self.ActiveSources:
             return
         self.ForceUpdateSources()
+        # the reference draws from the engine's global rand() stream: every frame sees fresh samples
+        self.params.seed = (self.params.seed + 1) & 0xFFFFFFFFFFFFFFFF
 
     def LineTraceSingle(self, start, end):
         """closest hit on the segment [start, end] (UWorld::LineTraceSingleByObjectType contract)"""

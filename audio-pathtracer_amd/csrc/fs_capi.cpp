@@ -13,6 +13,9 @@
 #include <mutex>
 #include <new>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is opened at run time (fs_comm_*), never linked
+
 #include "fs_internal.hpp"
 
 using namespace fs;
@@ -35,6 +38,11 @@ struct Source {
     hipEvent_t ev_rev = nullptr;       // compute stream: the newest reverb callback has read d_ir_mono
     bool rev_recorded = false;
     float* energy() const { return d_energy[cur]; }
+    // multi-GPU: the frame in the current buffer has been summed over the ranks (library collective), or handed to the
+    // caller's collective (fs_energy_handoff); a world_size > 1 context refuses to reconstruct a frame that is neither
+    bool reduced = false, handed_off = false;
+    hipEvent_t ev_red[2] = {nullptr, nullptr};   // tail stream: the library's all-reduce of buffer i is done
+    bool red_recorded[2] = {false, false};
     // deterministic mode (FS_FLAG_DETERMINISTIC): u64 fixed-point histograms [B][bins], allocated on first use,
     // alternating like the energy buffers; cur_fixed = the current frame deposited into d_fixed[cur]
     unsigned long long* d_fixed[2] = {nullptr, nullptr};
@@ -105,6 +113,10 @@ struct fs_context {
     float listener[3] = {0, 0, 0};
     std::vector<Source*> sources;
 
+    // multi-GPU: RCCL communicator over the ranks that share the pairs of every frame
+    ncclComm_t comm = nullptr;
+    bool comm_owned = false;           // created by fs_comm_init (destroyed with the context) vs attached by the caller
+
     // subpath state (sized on demand)
     SubpathState st{};
     size_t cap_lanes = 0, cap_seg = 0;
@@ -159,6 +171,10 @@ Source* get_source(fs_context* ctx, fs_source h) {
 // Before the compute stream writes the current energy buffer: the tail-stream reconstruct that last read it
 // must be done (two frames back in steady state, i.e. long finished).
 hipError_t wait_energy_readers(fs_context* ctx, Source* s) {
+    if (s->red_recorded[s->cur]) {   // the tail stream may still be summing this buffer over the ranks
+        hipError_t e = hipStreamWaitEvent(ctx->stream, s->ev_red[s->cur], 0);
+        if (e != hipSuccess) return e;
+    }
     if (!s->rec_recorded[s->cur]) return hipSuccess;
     return hipStreamWaitEvent(ctx->stream, s->ev_rec[s->cur], 0);
 }
@@ -180,6 +196,7 @@ void free_source(fs_context* ctx, Source* s) {
             if (s->ev_rec[i]) (void)hipEventDestroy(s->ev_rec[i]);
         }
         if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
+        for (int i = 0; i < 2; ++i) if (s->ev_red[i]) (void)hipEventDestroy(s->ev_red[i]);
         if (s->ev_rev) (void)hipEventDestroy(s->ev_rev);
         if (s->d_ir_bands) (void)hipFree(s->d_ir_bands);
         if (s->d_ir_mono) (void)hipFree(s->d_ir_mono);
@@ -482,6 +499,7 @@ int fs_context_destroy(fs_context* ctx) {
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
         resolve_timings(ctx);
+        (void)fs_comm_detach(ctx);
         for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
         free_scene(ctx);
         free_state(ctx);
@@ -508,6 +526,163 @@ int fs_context_destroy(fs_context* ctx) {
 const char* fs_last_error(const fs_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int fs_num_bins(const fs_context* ctx) { return ctx ? ctx->num_bins : 0; }
 int fs_num_samples(const fs_context* ctx) { return ctx ? ctx->num_samples : 0; }
+
+}  // extern "C" (reopened below)
+
+// ---- multi-GPU: RCCL over xGMI behind the C ABI ---------------------------------------------------
+// The pairs of a frame are sharded over world_size ranks (one process per GPU); what the ranks exchange is
+//   * one sum all-reduce of the [B][bins] energy histogram per source and frame (fp32, or the u64 fixed-point
+//     histogram of FS_FLAG_DETERMINISTIC), on the tail stream, concurrent with the next frame's tracing;
+//   * one broadcast of the acceleration structure at fs_scene_commit (rank 0 builds it, the others receive nodes,
+//     triangle records and the refit tables).
+// librccl is opened at run time — an already loaded copy first (a host process that uses torch.distributed has its
+// own), then FS_RCCL_LIB, then the system's — so single-GPU users need no RCCL at all.
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;   // why loading failed
+};
+
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = std::getenv("FS_RCCL_LIB");
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy the process already has
+        if (!api.handle && env && *env) api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) { const char* e = dlerror(); api.why = std::string("librccl not found: ") + (e ? e : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(api.handle, n); if (!p && api.why.empty()) api.why = std::string("librccl lacks ") + n; return p; };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!api.why.empty()) api.handle = nullptr;
+    });
+    return api.handle ? &api : nullptr;
+}
+
+int nccl_fail(fs_context* ctx, ncclResult_t r, const char* what) {
+    RcclApi* a = rccl();
+    return ctx->fail(FS_ERR_COMM, std::string(what) + ": " + (a && a->GetErrorString ? a->GetErrorString(r) : "RCCL error"));
+}
+#define FS_NCCL(ctx, call)                                          \
+    do {                                                            \
+        ncclResult_t r_ = (call);                                   \
+        if (r_ != ncclSuccess) return nccl_fail((ctx), r_, #call);  \
+    } while (0)
+
+// Sum the source's current energy buffer over the ranks, on the tail stream, behind everything the compute stream
+// has enqueued so far.  No-op without a communicator or when the frame has been summed already.
+int reduce_energy(fs_context* ctx, Source* s) {
+    if (!ctx->comm || s->reduced) return FS_OK;
+    RcclApi* a = rccl();
+    if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
+    FS_HIP(ctx, handoff_energy(ctx, s));
+    const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    if (s->cur_fixed) {   // deterministic mode: integer sum of the fixed-point histogram, rounded to fp32 once, behind it
+        FS_NCCL(ctx, a->AllReduce(s->d_fixed[s->cur], s->d_fixed[s->cur], words, ncclUint64, ncclSum, ctx->comm, ctx->copy_stream));
+        launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), (int)words, ctx->copy_stream);
+    } else
+        FS_NCCL(ctx, a->AllReduce(s->energy(), s->energy(), words, ncclFloat32, ncclSum, ctx->comm, ctx->copy_stream));
+    FS_HIP(ctx, hipEventRecord(s->ev_red[s->cur], ctx->copy_stream));
+    s->red_recorded[s->cur] = true;
+    s->reduced = true;
+    return FS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t* pair_begin, uint32_t* pair_count) {
+    if (world_size < 1 || rank < 0 || rank >= world_size || (num_rays & 1u)) return FS_ERR_INVALID_ARGUMENT;
+    const uint64_t P = num_rays / 2, W = (uint64_t)world_size, R = (uint64_t)rank;
+    const uint64_t p0 = P * R / W, p1 = P * (R + 1) / W;
+    if (pair_begin) *pair_begin = (uint32_t)p0;
+    if (pair_count) *pair_count = (uint32_t)(p1 - p0);
+    return FS_OK;
+}
+
+int fs_comm_unique_id(void* id_out, size_t bytes) {
+    if (!id_out || bytes != FS_COMM_ID_BYTES) return FS_ERR_INVALID_ARGUMENT;
+    RcclApi* a = rccl();
+    if (!a) return FS_ERR_COMM;
+    ncclUniqueId id;
+    if (a->GetUniqueId(&id) != ncclSuccess) return FS_ERR_COMM;
+    static_assert(sizeof(ncclUniqueId) == FS_COMM_ID_BYTES, "FS_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+    std::memcpy(id_out, &id, sizeof(id));
+    return FS_OK;
+}
+
+int fs_comm_init(fs_context* ctx, const void* unique_id, size_t bytes) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!unique_id || bytes != FS_COMM_ID_BYTES) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "unique id must be FS_COMM_ID_BYTES bytes");
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (ctx->comm) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a communicator is already attached");
+    RcclApi* a = rccl();
+    if (!a) return ctx->fail(FS_ERR_COMM, rccl() ? "" : "librccl is not loadable (set FS_RCCL_LIB)");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    FS_NCCL(ctx, a->CommInitRank(&ctx->comm, ctx->cfg.world_size, id, ctx->cfg.rank));
+    ctx->comm_owned = true;
+    return FS_OK;
+}
+
+int fs_comm_attach(fs_context* ctx, void* nccl_comm) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!nccl_comm) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "null communicator");
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (ctx->comm) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a communicator is already attached");
+    RcclApi* a = rccl();
+    if (!a) return ctx->fail(FS_ERR_COMM, "librccl is not loadable (set FS_RCCL_LIB)");
+    int n = 0, r = -1;
+    FS_NCCL(ctx, a->CommCount((ncclComm_t)nccl_comm, &n));
+    FS_NCCL(ctx, a->CommUserRank((ncclComm_t)nccl_comm, &r));
+    if (n != ctx->cfg.world_size || r != ctx->cfg.rank)
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "communicator size / rank differ from fs_config.world_size / rank");
+    ctx->comm = (ncclComm_t)nccl_comm;
+    ctx->comm_owned = false;
+    return FS_OK;
+}
+
+int fs_comm_detach(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->comm) return FS_OK;
+    if (ctx->device_ok) {
+        (void)hipSetDevice(ctx->cfg.device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->copy_stream);
+    }
+    RcclApi* a = rccl();
+    if (ctx->comm_owned && a) (void)a->CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_owned = false;
+    return FS_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- scene -----------------------------------------------------------------------------------------
 int fs_scene_set_triangles(fs_context* ctx, const float* xyz, const uint16_t* mat_id, int32_t T) {
@@ -545,27 +720,63 @@ int fs_scene_commit(fs_context* ctx) {
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
-    build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(), ctx->h_obj.size() == (size_t)ctx->T && ctx->T > 0 ? ctx->h_obj.data() : nullptr,
-              ctx->T, ctx->bvh);
+    // With a communicator attached rank 0 alone builds the acceleration structure and broadcasts it; the
+    // other ranks only hold the triangles for later fs_scene_update_triangles bookkeeping.
+    RcclApi* ra = ctx->comm ? rccl() : nullptr;
+    if (ctx->comm && !ra) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
+    const bool bcast = ra != nullptr;
+    const bool root = !bcast || ctx->cfg.rank == 0;
+    size_t n_nodes = 0, n_tris = 0, n_leaf = 0, n_lvl = 0;
+    if (root) {
+        build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(),
+                  ctx->h_obj.size() == (size_t)ctx->T && ctx->T > 0 ? ctx->h_obj.data() : nullptr, ctx->T, ctx->bvh);
+        n_nodes = ctx->bvh.nodes.size(); n_tris = ctx->bvh.tris.size();
+        n_leaf = ctx->bvh.leaf_pos.size(); n_lvl = ctx->bvh.level_begin.size();
+    }
+    if (bcast) {   // header first: sizes, stack bound, box padding
+        int32_t hdr[8] = {(int32_t)n_nodes, (int32_t)n_tris, (int32_t)n_leaf, (int32_t)n_lvl, ctx->bvh.stack_need,
+                          ctx->bvh.max_depth, 0, ctx->T};
+        std::memcpy(&hdr[6], &ctx->bvh.pad, sizeof(float));
+        int32_t* d_hdr = nullptr;
+        FS_HIP(ctx, hipMalloc((void**)&d_hdr, sizeof(hdr)));
+        if (root) FS_HIP(ctx, hipMemcpyAsync(d_hdr, hdr, sizeof(hdr), hipMemcpyHostToDevice, ctx->stream));
+        ncclResult_t r = ra->Broadcast(d_hdr, d_hdr, 8, ncclInt32, 0, ctx->comm, ctx->stream);
+        hipError_t e = hipMemcpyAsync(hdr, d_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_hdr);
+        if (r != ncclSuccess) return nccl_fail(ctx, r, "ncclBroadcast(scene header)");
+        if (e != hipSuccess) return ctx->hip_fail(e, "scene header");
+        if (hdr[7] != ctx->T) return ctx->fail(FS_ERR_SIZE_MISMATCH, "fs_scene_commit: rank 0 committed a different number of triangles");
+        if (!root) {
+            n_nodes = (size_t)hdr[0]; n_tris = (size_t)hdr[1]; n_leaf = (size_t)hdr[2]; n_lvl = (size_t)hdr[3];
+            ctx->bvh = HostBVH{};
+            ctx->bvh.stack_need = hdr[4]; ctx->bvh.max_depth = hdr[5];
+            std::memcpy(&ctx->bvh.pad, &hdr[6], sizeof(float));
+            ctx->bvh.nodes.resize(n_nodes); ctx->bvh.tris.resize(n_tris);   // sizes only; the records live on the device
+            ctx->bvh.level_begin.assign(n_lvl, 0);
+        }
+    }
     if (ctx->bvh.stack_need > kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH needs a deeper traversal stack");
-    {   // the traversal kernels keep stack + [bands][bins] histogram + work-sharing area in LDS: fail here, with a
+    {   // the traversal kernels keep stack + energy histogram window + work-sharing area in LDS: fail here, with a
         // message, rather than with a launch error on every frame
         const size_t need = traversal_lds_bytes(std::max(ctx->bvh.stack_need, 2) + kStackSlack, ctx->cfg.num_bands, ctx->num_bins);
         if (need > ctx->lds_limit)
             return ctx->fail(FS_ERR_INVALID_ARGUMENT, "scene + energy histogram need " + std::to_string(need) +
-                             " B of LDS per workgroup, the device offers " + std::to_string(ctx->lds_limit) +
-                             " (fewer bins: a longer bin_duration / shorter simulated_duration, or fewer bands)");
+                             " B of LDS per workgroup, the device offers " + std::to_string(ctx->lds_limit));
     }
-    size_t nb = ctx->bvh.nodes.size() * sizeof(NodeQ4), tb = ctx->bvh.tris.size() * sizeof(Tri64);
+    size_t nb = n_nodes * sizeof(NodeQ4), tb = n_tris * sizeof(Tri64);
     size_t mb = ctx->h_absorption.size() * sizeof(float);
     if (nb) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, nb));
-        FS_HIP(ctx, hipMemcpy(ctx->d_nodes, ctx->bvh.nodes.data(), nb, hipMemcpyHostToDevice));
+        if (root) FS_HIP(ctx, hipMemcpyAsync(ctx->d_nodes, ctx->bvh.nodes.data(), nb, hipMemcpyHostToDevice, ctx->stream));
+        if (bcast) FS_NCCL(ctx, ra->Broadcast(ctx->d_nodes, ctx->d_nodes, nb, ncclUint8, 0, ctx->comm, ctx->stream));
     }
     if (tb) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_tris, tb));
-        FS_HIP(ctx, hipMemcpy(ctx->d_tris, ctx->bvh.tris.data(), tb, hipMemcpyHostToDevice));
+        if (root) FS_HIP(ctx, hipMemcpyAsync(ctx->d_tris, ctx->bvh.tris.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+        if (bcast) FS_NCCL(ctx, ra->Broadcast(ctx->d_tris, ctx->d_tris, tb, ncclUint8, 0, ctx->comm, ctx->stream));
     }
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (mb) {
         // absorption [M][B] | lobe gains [M][3][B] | lobe probabilities [M][3] (FS_FLAG_MATERIAL_LOBES).  The split is
         // the per-bin rule of ApplyMaterialFD (MaterialAcousticProcessor.cpp:51-72) per band: Refl = 1 - alpha, tau
@@ -599,11 +810,25 @@ int fs_scene_commit(fs_context* ctx) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_absorption, table.size() * sizeof(float)));
         FS_HIP(ctx, hipMemcpy(ctx->d_absorption, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (tb) {   // refit support: leaf positions and the bounds scratch
-        FS_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_pos, sizeof(uint32_t) * ctx->bvh.leaf_pos.size()));
-        FS_HIP(ctx, hipMemcpy(ctx->d_leaf_pos, ctx->bvh.leaf_pos.data(), sizeof(uint32_t) * ctx->bvh.leaf_pos.size(),
-                              hipMemcpyHostToDevice));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->d_node_box, sizeof(float4) * 2 * std::max<size_t>(ctx->bvh.nodes.size(), 1)));
+    if (tb) {   // refit support: leaf positions, level table and the bounds scratch
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_pos, sizeof(uint32_t) * std::max<size_t>(n_leaf, 1)));
+        if (root) FS_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_pos, ctx->bvh.leaf_pos.data(), sizeof(uint32_t) * n_leaf,
+                                             hipMemcpyHostToDevice, ctx->stream));
+        if (bcast) {
+            FS_NCCL(ctx, ra->Broadcast(ctx->d_leaf_pos, ctx->d_leaf_pos, n_leaf, ncclUint32, 0, ctx->comm, ctx->stream));
+            int32_t* d_lvl = nullptr;   // the level table is host data (one refit launch per level): through a device bounce buffer
+            FS_HIP(ctx, hipMalloc((void**)&d_lvl, sizeof(int32_t) * std::max<size_t>(n_lvl, 1)));
+            if (root) FS_HIP(ctx, hipMemcpyAsync(d_lvl, ctx->bvh.level_begin.data(), sizeof(int32_t) * n_lvl, hipMemcpyHostToDevice, ctx->stream));
+            ncclResult_t r = ra->Broadcast(d_lvl, d_lvl, n_lvl, ncclInt32, 0, ctx->comm, ctx->stream);
+            hipError_t e = hipSuccess;
+            if (!root) e = hipMemcpyAsync(ctx->bvh.level_begin.data(), d_lvl, sizeof(int32_t) * n_lvl, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(d_lvl);
+            if (r != ncclSuccess) return nccl_fail(ctx, r, "ncclBroadcast(level table)");
+            if (e != hipSuccess) return ctx->hip_fail(e, "level table");
+        }
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_node_box, sizeof(float4) * 2 * std::max<size_t>(n_nodes, 1)));
     }
     ctx->amax = 0.f;
     for (float v : ctx->h_xyz) ctx->amax = std::max(ctx->amax, std::fabs(v));
@@ -702,6 +927,8 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
     if ((e = hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (int i = 0; i < 2; ++i)
+        if ((e = hipEventCreateWithFlags(&s->ev_red[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&s->ev_rev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     // the initial fills above ran on the compute stream; the first reconstruct runs on the tail stream
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -752,13 +979,13 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
 
     const int B = ctx->cfg.num_bands;
     const uint64_t P = p->num_rays / 2;
-    const uint64_t W = (uint64_t)ctx->cfg.world_size, R = (uint64_t)ctx->cfg.rank;
-    const uint64_t p0 = P * R / W, p1 = P * (R + 1) / W;
+    uint32_t p0 = 0, pn = 0;
+    (void)fs_shard_range(p->num_rays, ctx->cfg.rank, ctx->cfg.world_size, &p0, &pn);   // validated by check_params / create
     KParams kp{};
     kp.seed_lo = (uint32_t)p->seed;
     kp.seed_hi = (uint32_t)(p->seed >> 32);
-    kp.pair_begin = (uint32_t)p0;
-    kp.pairs_per_source = (uint32_t)(p1 - p0);
+    kp.pair_begin = p0;
+    kp.pairs_per_source = pn;
     kp.num_local = kp.pairs_per_source * (uint32_t)count;
     kp.src_table = nullptr;
     kp.depth = p->depth > 0 ? p->depth : FS_MAX_DEPTH;
@@ -778,6 +1005,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     for (int b = 0; b < FS_MAX_BANDS; ++b) kp.air[b] = p->air_absorption[b];
     std::memcpy(kp.src, s->pos, sizeof(kp.src));
     std::memcpy(kp.lis, ctx->listener, sizeof(kp.lis));
+    kp.count = ctx->profiling >= 3 ? 1 : 0;
     kp.num_bins = ctx->num_bins;
     kp.hist_window = std::min(ctx->num_bins, ctx->hist_window);
 
@@ -808,6 +1036,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         }
         si->cur ^= 1;   // this frame deposits into the other buffer; the tail may still be busy with the last one
         si->cur_fixed = fixed;
+        si->reduced = false; si->handed_off = false;
         FS_HIP(ctx, wait_energy_readers(ctx, si));
     }
     // FlushEnergyBuffer ARTS.cpp:157-161 is folded into the plan pass (one launch); plain memset otherwise.
@@ -885,6 +1114,10 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     ctx->stats.frames++;
     ctx->stats.pairs += kp.num_local;
     ctx->stats.rays += 2ull * kp.num_local;
+    // multi-GPU: the sum over the ranks (ARTS.cpp:164-173 deposits ALL pairs into the one buffer) runs on the tail
+    // stream right behind the deposit, concurrently with whatever the compute stream traces next
+    if (ctx->comm)
+        for (int i = 0; i < count; ++i) { int rr = reduce_energy(ctx, srcs[i]); if (rr) return rr; }
     return FS_OK;
 }
 
@@ -956,6 +1189,7 @@ int fs_energy_handoff(fs_context* ctx, fs_source h, void** dptr, size_t* bytes, 
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, handoff_energy(ctx, s));
+    s->handed_off = true;
     const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
     if (dptr) *dptr = s->cur_fixed ? (void*)s->d_fixed[s->cur] : (void*)s->energy();
     if (bytes) *bytes = (s->cur_fixed ? sizeof(unsigned long long) : sizeof(float)) * words;
@@ -971,6 +1205,12 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     fs_params def;
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    // ReconstructImpulseResponse is not linear in the energy (a = e / sqrt(e * Pi4)): the IR of a rank's PARTIAL
+    // histogram is not a partial IR.  A sharded context only reconstructs a frame that was summed over the ranks — by
+    // the library (fs_comm_init / fs_comm_attach) or by the caller's collective on the tail stream (fs_energy_handoff).
+    if (ctx->cfg.world_size > 1 && !s->reduced && !s->handed_off)
+        return ctx->fail(FS_ERR_COMM, "world_size > 1: the energy buffer holds this rank's partial sums only — attach a "
+                                      "communicator (fs_comm_init) or reduce it behind fs_energy_handoff before reconstructing");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     const int B = ctx->cfg.num_bands;
     int spb = p->samples_per_bin > 0 ? p->samples_per_bin
@@ -1136,6 +1376,8 @@ int fs_flush_energy_buffer(fs_context* ctx, fs_source h) {
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
+    s->handed_off = true;   // the caller owns the content now
     FS_HIP(ctx, wait_energy_readers(ctx, s));
     FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
                                ctx->stream));
@@ -1149,6 +1391,8 @@ int fs_add_energy_at_delay(fs_context* ctx, fs_source h, int32_t band, float del
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
+    s->handed_off = true;   // the caller owns the content now
     FS_HIP(ctx, wait_energy_readers(ctx, s));
     launch_add_energy(s->energy() + (size_t)band * (size_t)ctx->num_bins, ctx->num_bins, delay_seconds, energy,
                       ctx->stream);
@@ -1164,6 +1408,8 @@ int fs_update_energy_buffer(fs_context* ctx, fs_source h, const float* values, i
     // check(NewEnergyValues.Num() == NumBins) FSAC.h:83 -> status instead of abort
     if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
+    s->handed_off = true;   // the caller owns the content now
     FS_HIP(ctx, wait_energy_readers(ctx, s));
     FS_HIP(ctx, hipMemcpyAsync(s->energy(), values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1541,7 +1787,7 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
 // ---- measurement ----------------------------------------------------------------------------------------------
 int fs_set_profiling(fs_context* ctx, int32_t enabled) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
-    ctx->profiling = enabled < 0 ? 0 : (enabled > 2 ? 2 : enabled);
+    ctx->profiling = enabled < 0 ? 0 : (enabled > 3 ? 3 : enabled);
     return FS_OK;
 }
 
@@ -1554,13 +1800,17 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         resolve_timings(ctx);
     }
     if (ctx->device_ok && ctx->walk.queue_head) {   // work counters kept on the device since the last reset
-        unsigned long long c[kNumCounters] = {0, 0, 0, 0};
+        unsigned long long c[kNumCounters] = {0};
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
         FS_HIP(ctx, hipMemcpyAsync(c, ctx->walk.queue_head + kCounterWord, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->stats.segments = c[0] + ctx->host_segments;
         ctx->stats.connections_tested = c[1];
         ctx->stats.deposits = c[2];
+        ctx->stats.walk_node_fetches = c[3];
+        ctx->stats.walk_tri_fetches = c[4];
+        ctx->stats.any_node_fetches = c[5];
+        ctx->stats.any_tri_fetches = c[6];
     }
     *out = ctx->stats;
     return FS_OK;

@@ -87,6 +87,7 @@ struct KParams {
     float norm;            // 1/P or 1/1000 (ARTS.cpp:164)
     float air[FS_MAX_BANDS];
     float src[3], lis[3];
+    int32_t count;         // 1 = COUNT instantiations: the kernels also count the records they fetch (fs_set_profiling level 3)
     int32_t num_bins;
     int32_t hist_window;   // the connect kernels privatise bins [0, hist_window) of every band in LDS; deposits beyond go
                            // straight to the energy buffer with global atomics (kHistWindow, or all bins if fewer)
@@ -147,7 +148,7 @@ constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
 // frame scratch allocation: kScratchWords rearmed every frame, then (8-byte aligned) kNumCounters u64 work
 // counters that accumulate until fs_reset_stats: walk segments, connections tested, deposits
 constexpr int kCounterWord = (kScratchWords + 1) & ~1;
-constexpr int kNumCounters = 4;
+constexpr int kNumCounters = 8;   // walk segments, connections tested, deposits | level 3: walk node / triangle records, any-hit node / triangle records | spare
 constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
 // nullptr when no plan applies (the caller then clears the energy buffer itself)

@@ -216,12 +216,14 @@ struct Trav {
     float t;        // closest hit so far (init: tmax)
     int leaf_index; // hit triangle (leaf order), -1 = none
     uint32_t id;    // its input index (tie-break key)
+    uint32_t nv, nt;   // COUNT instantiations only (fs_set_profiling level 3): node records / triangle records this lane fetched
 };
 
 __device__ __forceinline__ void trav_init(Trav& T, float tmax, bool scene_nonempty) {
     T.cur = scene_nonempty ? 0 : kDone;
     T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
     T.t = tmax; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
+    T.nv = 0u; T.nt = 0u;
 }
 __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tri_n || T.cur != kDone; }
 
@@ -267,11 +269,12 @@ __device__ __forceinline__ void trav_wait(TravRegs& R) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(R.q0), "+v"(R.q1), "+v"(R.q2), "+v"(R.q3), "+v"(R.a), "+v"(R.b), "+v"(R.c));
 }
 
-template <bool ANY, bool IGN = false>
+template <bool ANY, bool IGN = false, bool COUNT = false>
 __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r, Trav& T, int* stack, const TravRegs& R,
                                              uint32_t ignore_object = 0xFFFFFFFFu) {
     const bool has_tri = T.tri_i < T.tri_n;
     const bool has_node = T.cur >= 0;
+    if (COUNT) { T.nv += has_node ? 1u : 0u; T.nt += has_tri ? 1u : 0u; }
 #ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.py): SIMD occupancy of the two step kinds
     {
         const unsigned long long mt = __ballot(has_tri), mn = __ballot(has_node);
@@ -731,7 +734,7 @@ constexpr size_t kShareAnyLdsBytes = ShareArea<true, false>::kBytes;    // 40 B 
 constexpr size_t kShareIgnLdsBytes = ShareArea<false, true>::kBytes;    // 64 B per lane
 
 // returns: ANY — the ray is blocked; closest — a hit was found (T.t, T.id, T.leaf_index describe it)
-template <bool ANY, bool IGN>
+template <bool ANY, bool IGN, bool COUNT = false>
 __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
                                             uint32_t ignore, Trav& T, int* stack, int* share) {
     const ShareArea<ANY, IGN> A(share);
@@ -765,7 +768,7 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     while (true) {
         trav_wait(R);
         if (trav_busy(T)) {
-            trav_consume<ANY, IGN>(sc, wr, T, stack, R, wign);
+            trav_consume<ANY, IGN, COUNT>(sc, wr, T, stack, R, wign);
             if (ANY) {
                 if (T.leaf_index >= 0) { A.blocked[owner] = 1; T.leaf_index = -1; }   // first hit ends the query (T is idle now)
                 else if (A.blocked[owner]) { T.cur = kDone; T.sp = 0; T.sb = 0; T.tri_n = T.tri_i; }   // settled by another lane
@@ -837,17 +840,28 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     return false;
 }
 // the three uses: BDPT walk, ConnectSubpaths' visibility ray, legacy tracer
+template <bool COUNT = false>
 __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray& own, Trav& T, int* stack, int* s_dyn,
                                                 float tmax, bool has_ray = true) {
-    trav_shared<false, false>(sc, has_ray, own, tmax, 0xFFFFFFFFu, T, stack, s_dyn + (size_t)sc.stack_rows * kBlock);
+    trav_shared<false, false, COUNT>(sc, has_ray, own, tmax, 0xFFFFFFFFu, T, stack, s_dyn + (size_t)sc.stack_rows * kBlock);
 }
+template <bool COUNT = false>
 __device__ __forceinline__ bool trav_any_shared(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
-                                                int* stack, int* share) {
+                                                int* stack, int* share, uint32_t* nv = nullptr, uint32_t* nt = nullptr) {
     Trav T;
-    return trav_shared<true, false>(sc, has_ray, own, tmax, 0xFFFFFFFFu, T, stack, share);
+    const bool blocked = trav_shared<true, false, COUNT>(sc, has_ray, own, tmax, 0xFFFFFFFFu, T, stack, share);
+    if (COUNT) { *nv += T.nv; *nt += T.nt; }
+    return blocked;
+}
+// COUNT instantiations: this lane's record fetches -> the frame scratch's work counters (one atomic per lane: the
+// counting frames are not timed)
+__device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_counter, uint32_t nv, uint32_t nt) {
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(scratch + kCounterWord);
+    if (nv) atomicAdd(&counters[first_counter], (unsigned long long)nv);
+    if (nt) atomicAdd(&counters[first_counter + 1], (unsigned long long)nt);
 }
 
-template <int LOBES>
+template <int LOBES, bool COUNT>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm) {
@@ -865,6 +879,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
     Walker w;
     walker_start(w, g, kp);
     Ray ray;
+    uint32_t cnt_nv = 0u, cnt_nt = 0u;
 #ifdef FS_WAVE_TIMELINE
     const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
     unsigned long long tl_trav = 0, tl_seg = 0;
@@ -874,14 +889,16 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
 #ifdef FS_WAVE_TIMELINE
         const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
 #endif
-        trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist);
+        trav_run_shared<COUNT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist);
 #ifdef FS_WAVE_TIMELINE
         tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
         ++tl_seg;
 #endif
+        if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         walker_apply_hit(w, kp, sc, st, ray, T);
     }
     walker_finish(w, st);
+    if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 #ifdef FS_WAVE_TIMELINE
     {
         unsigned long long seg_max = tl_seg, trav_max = tl_trav;   // lanes of a wave leave the loop at different bounces
@@ -905,7 +922,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
 // its longest chain of closest-hit queries.  Here a wave owns only `rays_per_wave` subpaths (its first lanes) and
 // the other lanes help with every query — the legacy tracer's scheme (update_sound_shared_kernel).  The loop is
 // wave-uniform: lanes whose walk has ended (or that never had one) keep calling the shared traversal as helpers.
-template <int LOBES>
+template <int LOBES, bool COUNT>
 __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm, int rays_per_wave) {
@@ -924,14 +941,17 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
     Walker w;
     walker_start(w, alive ? (perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot) : 0u, kp);
     Ray ray;
+    uint32_t cnt_nv = 0u, cnt_nt = 0u;
     while (true) {
         const bool go = alive && walker_next_ray<LOBES>(w, kp, sc, st, ray);
         if (alive && !go) { walker_finish(w, st); alive = false; }
         if (__ballot(go) == 0ull) break;
         Trav T;
-        trav_run_shared(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
+        trav_run_shared<COUNT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
+        if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         if (go) walker_apply_hit(w, kp, sc, st, ray, T);
     }
+    if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -943,7 +963,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
 // BATCH: a batched frame (fs_compute_energy_response_batch): the pairs of several sources lie end to end
 // (kp.pairs_per_source each) and every source has its own energy buffer (energy_tab / fixed_tab); a workgroup
 // takes (source, chunk) items and flushes its LDS histogram whenever the source changes.
-template <int B, int LOBES, bool BATCH>
+template <int B, int LOBES, bool BATCH, bool COUNT>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head,
@@ -969,6 +989,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     const uint32_t n = kp.num_local;
     const uint32_t total = 2u * n;
     unsigned my_deposits = 0;
+    uint32_t cnt_nv = 0u, cnt_nt = 0u;
     // whole workgroups step through the pairs: every lane of a wave takes part in the shared visibility queries,
     // also the ones without a pair or without a segment to test
     const uint32_t ppw = (uint32_t)pairs_per_wave, per_block = ppw * (kBlock / 64);
@@ -994,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
 #ifdef FS_WAVE_TIMELINE
         if (!tl[1]) tl[1] = __builtin_amdgcn_s_memrealtime();   // first chunk: set-up and end-state loads done
 #endif
-        const bool hit = trav_any_shared(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share);
+        const bool hit = trav_any_shared<COUNT>(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share, &cnt_nv, &cnt_nt);
 #ifdef FS_WAVE_TIMELINE
         if (!tl[2]) tl[2] = __builtin_amdgcn_s_memrealtime();   // first chunk: visibility queries done
 #endif
@@ -1085,6 +1106,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
 #ifdef FS_WAVE_TIMELINE
     tl[3] = __builtin_amdgcn_s_memrealtime();   // all chunks evaluated and deposited into LDS
 #endif
+    if (COUNT) add_fetch_counts(queue_head, 5, cnt_nv, cnt_nt);
     {   // work counters: summed per wave, then per workgroup in LDS — one global atomic per workgroup (thousands of
         // atomics on one address cost the kernel ~10 %)
         unsigned d = my_deposits;
@@ -1733,14 +1755,17 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
                             : (kp.num_local + per_block - 1) / per_block;
     if (blocks > 1024) blocks = 1024;
     size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.hist_window + kShareAnyLdsBytes;
-#define FS_LAUNCH_CONNECT(L, BT)                                                                                     \
+#define FS_LAUNCH_CONNECT(L, BT, CN)                                                                                 \
     do {                                                                                                             \
-        allow_lds(connect_kernel<B, L, BT>, lds);                                                                    \
-        hipLaunchKernelGGL((connect_kernel<B, L, BT>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, \
-                           queue_head, pairs_per_wave, energy_tab, fixed_tab);                                       \
+        allow_lds(connect_kernel<B, L, BT, CN>, lds);                                                                \
+        hipLaunchKernelGGL((connect_kernel<B, L, BT, CN>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy,   \
+                           fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);                                \
     } while (0)
-    if (batch) { if (kp.lobes) FS_LAUNCH_CONNECT(1, true); else FS_LAUNCH_CONNECT(0, true); }
-    else { if (kp.lobes) FS_LAUNCH_CONNECT(1, false); else FS_LAUNCH_CONNECT(0, false); }
+    // record-fetch counting (fs_set_profiling level 3) exists for the default frame shape only
+    if (batch) { if (kp.lobes) FS_LAUNCH_CONNECT(1, true, false); else FS_LAUNCH_CONNECT(0, true, false); }
+    else if (kp.lobes) FS_LAUNCH_CONNECT(1, false, false);
+    else if (kp.count) FS_LAUNCH_CONNECT(0, false, true);
+    else FS_LAUNCH_CONNECT(0, false, false);
 #undef FS_LAUNCH_CONNECT
 }
 
@@ -1766,32 +1791,26 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
     const bool shared = FS_SHARED_WALK(wl);
+    // record-fetch counting (fs_set_profiling level 3) exists for the default walk only (no lobes)
+#define FS_LAUNCH_WALK(K, GRID, ...)                                                                        \
+    do {                                                                                                    \
+        if (kp.lobes) { allow_lds(K<1, false>, lds); hipLaunchKernelGGL((K<1, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }        \
+        else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
+        else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \
+    } while (0)
     if (shared && wl.rays_per_wave > 0 && wl.rays_per_wave < 64) {   // small frame: sparse waves, idle lanes help
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
-        if (kp.lobes) {
-            allow_lds(walk_kernel_sparse<1>, lds);
-            hipLaunchKernelGGL(walk_kernel_sparse<1>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm,
-                               wl.rays_per_wave);
-        } else {
-            allow_lds(walk_kernel_sparse<0>, lds);
-            hipLaunchKernelGGL(walk_kernel_sparse<0>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm,
-                               wl.rays_per_wave);
-        }
+        FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave);
         return;
     }
     if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
-        if (kp.lobes) {
-            allow_lds(walk_kernel_shared<1>, lds);
-            hipLaunchKernelGGL(walk_kernel_shared<1>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm);
-        } else {
-            allow_lds(walk_kernel_shared<0>, lds);
-            hipLaunchKernelGGL(walk_kernel_shared<0>, dim3(full), dim3(kBlock), lds, s, sc, kp, st, wl.queue_head, perm);
-        }
+        FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm);
         return;
     }
+#undef FS_LAUNCH_WALK
 #ifdef FS_EXPERIMENTS
     if (kp.lobes) {
         allow_lds(walk_kernel_simple<1>, stack_bytes(sc));

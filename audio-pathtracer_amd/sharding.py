@@ -17,3 +17,15 @@ def pair_range(num_pairs: int, rank: int, world_size: int) -> tuple[int, int]:
 
 def all_ranges(num_pairs: int, world_size: int) -> list[tuple[int, int]]:
     return [pair_range(num_pairs, r, world_size) for r in range(world_size)]
+
+
+def library_pair_range(num_rays: int, rank: int, world_size: int) -> tuple[int, int]:
+    """the same rule as libfrequensee.so applies it (fs_shard_range: host code, needs no device)"""
+    import ctypes as C
+
+    from . import _capi
+    b, n = C.c_uint32(), C.c_uint32()
+    rc = _capi.load().fs_shard_range(num_rays, rank, world_size, C.byref(b), C.byref(n))
+    if rc != _capi.OK:
+        raise ValueError("bad num_rays / rank / world_size")
+    return b.value, b.value + n.value

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 2
+#define FS_ABI_VERSION 3
 #define FS_MAX_BANDS 8
 #define FS_NO_MATERIAL 0xFFFFu /* actor without UAcousticGeometryComponent / Material (ARTS.cpp:383) */
 #define FS_MAX_DEPTH 64        /* hard cap on segments per subpath when depth == 0 ("unbounded") */
@@ -45,7 +45,8 @@ enum {
     FS_ERR_NOT_COMMITTED = 4, /* scene not committed */
     FS_ERR_BAD_HANDLE = 5,
     FS_ERR_SIZE_MISMATCH = 6, /* UpdateEnergyBuffer's check(Num()==NumBins), FSAC.h:83 */
-    FS_ERR_OUT_OF_MEMORY = 7
+    FS_ERR_OUT_OF_MEMORY = 7,
+    FS_ERR_COMM = 8           /* multi-GPU: librccl not loadable, an RCCL call failed, or a sharded frame was not reduced */
 };
 
 /* compat flags: reproduce a reference quirk literally (default 0 = evident intent) */
@@ -135,6 +136,11 @@ typedef struct fs_stats {
     uint64_t segments;           /* walk segments = closest-hit queries (counted by the length plan; 0 when it is off) */
     uint64_t connections_tested; /* any-hit queries: one per pair, or one per (i, j) in all-connections mode */
     uint64_t deposits;           /* unobstructed connections = paths evaluated and deposited */
+    /* profiling level 3 only (counting instantiations of the kernels, not for timed frames): records the traversal
+     * fetched — 64-B nodes of the 4-wide tree and 48-B triangle records — by the closest-hit queries of the walk and
+     * by the any-hit queries of the connections: the kernel's OWN algorithmic bytes (SURVEY.md 8d prices the oracle's
+     * BVH2 instead) */
+    uint64_t walk_node_fetches, walk_tri_fetches, any_node_fetches, any_tri_fetches;
 } fs_stats;
 
 /* ---- lifecycle: UAudioRayTracingSubsystem::Initialize/Deinitialize (ARTS.cpp:32-42) ------------- */
@@ -198,6 +204,28 @@ int fs_energy_device_ptr(fs_context* ctx, fs_source src, void** dptr, size_t* by
  * If the frame was computed with FS_FLAG_DETERMINISTIC, *dptr is the [B][num_bins] uint64 fixed-point histogram
  * and *bytes = 8 * B * num_bins: reduce it with an integer sum (ncclUint64 / ncclSum); the reconstruct converts it. */
 int fs_energy_handoff(fs_context* ctx, fs_source src, void** dptr, size_t* bytes, void** tail_stream);
+
+/* ---- multi-GPU: the collective behind the boundary --------------------------------------------------
+ * The reference's loop over the pairs (GenerateFullPaths, ARTS.cpp:215-230) carries no state from one pair to the next,
+ * so rank r of W traces pairs [P r / W, P (r+1) / W) of every frame (fs_config.rank / world_size, one process per GPU)
+ * and the ranks sum their [B][bins] histograms: ONE all-reduce per source and frame (fp32, or uint64 in deterministic
+ * mode), issued by the library on the context's tail stream at the end of fs_compute_energy_response*, so that it and
+ * the reconstruct behind it overlap the next frame's tracing.  With a communicator attached fs_scene_commit also lets
+ * rank 0 alone build the acceleration structure and broadcasts it (nodes, triangle records, refit tables).
+ * RCCL is opened at run time (an already loaded librccl first, then $FS_RCCL_LIB, then the system's).
+ *   rank 0:     fs_comm_unique_id(id, FS_COMM_ID_BYTES)  -> ship the 128 bytes to the other ranks by any means
+ *   every rank: fs_comm_init(ctx, id, FS_COMM_ID_BYTES)  (collective: ncclCommInitRank(world_size, id, rank))
+ * or hand over a communicator the host already owns (fs_comm_attach; not destroyed with the context).
+ * A world_size > 1 context without a communicator refuses to reconstruct (FS_ERR_COMM) unless the caller reduced the
+ * frame itself behind fs_energy_handoff. */
+#define FS_COMM_ID_BYTES 128
+int fs_comm_unique_id(void* id_out, size_t bytes);
+int fs_comm_init(fs_context* ctx, const void* unique_id, size_t bytes);
+int fs_comm_attach(fs_context* ctx, void* nccl_comm /* ncclComm_t */);
+int fs_comm_detach(fs_context* ctx);   /* destroys a communicator made by fs_comm_init; fs_context_destroy calls it */
+/* The partition rule itself, host-only (no device needed): pairs [*pair_begin, *pair_begin + *pair_count) of a frame of
+ * num_rays subpaths belong to `rank` of `world_size`. */
+int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t* pair_begin, uint32_t* pair_count);
 
 /* ReconstructImpulseResponse (FSAC.cpp:320-380, called at ARTS.cpp:192): energy -> per-band IR
  * [B][num_samples] and the num_channels-channel view (both channels identical, FSAC.cpp:331) built
@@ -298,7 +326,8 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
                          float* transmitted);
 
 /* ---- measurement --------------------------------------------------------------------------------- */
-/* HIP events on the context's stream: 0 = off, 1 = around the dominant (walk) kernel only, 2 = every kernel */
+/* HIP events on the context's stream: 0 = off, 1 = around the dominant (walk) kernel only, 2 = every kernel,
+ * 3 = level 2 + the kernels count the node / triangle records they fetch (slower: not for timed frames) */
 int fs_set_profiling(fs_context* ctx, int32_t level);
 int fs_get_stats(fs_context* ctx, fs_stats* out);
 int fs_reset_stats(fs_context* ctx);

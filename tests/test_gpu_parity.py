@@ -671,6 +671,72 @@ def test_tail_stream_overlap_and_handoff(pkg, oracle_mod, scene_factory):
     ref_ctx.close()
 
 
+def test_library_collective_one_rank(pkg, oracle_mod, scene_factory):
+    """The RCCL all-reduce lives behind the C ABI (fs_comm_init): with a one-rank communicator attached every frame
+    runs the library's collective on the tail stream — a sum over one rank — and the scene goes through the broadcast
+    path of fs_scene_commit.  Energy, IR and counters must equal those of a plain context, over several overlapping
+    frames, also in deterministic mode (uint64 all-reduce) and for a batched frame."""
+    sc = scene_factory("starter_room", 4)
+    plain, psrc = make_ctx(pkg, sc)
+    ctx = pkg.Context(num_bands=4)
+    ctx.comm_init(pkg.Context.comm_unique_id())           # before set_scene: rank 0 builds + broadcasts the tree
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx.set_listener(sc.listener)
+    src = ctx.create_source(sc.source)
+    assert ctx.stats()["bvh_nodes"] == plain.stats()["bvh_nodes"]
+    for f, flags in enumerate((0, 0, 8, 0, 8)):
+        p = pkg.default_params(num_rays=16384, depth=8, seed=900 + f, flags=flags)
+        ctx.compute_energy_response_async(src, p)
+        ctx.reconstruct_impulse_response_async(src, p)
+        if f + 1 < 5:   # the next frame's tracing overlaps this frame's reduce + reconstruct
+            ctx.compute_energy_response_async(src, pkg.default_params(num_rays=4096, depth=8, seed=1))
+        want_e = plain.compute_energy_response(psrc, p)
+        plain.reconstruct_impulse_response(psrc, p)
+        ctx.synchronize()
+        got_ir, want_ir = ctx.impulse_response(src, 0), plain.impulse_response(psrc, 0)
+        assert np.abs(want_ir).max() > 0
+        if flags & 8:
+            assert np.array_equal(got_ir, want_ir)        # integer sums: bit-identical
+        else:
+            assert np.abs(got_ir - want_ir).max() <= IR_TOL * np.abs(want_ir).max()
+    # the reduced energy is what the helpers read back
+    p = pkg.default_params(num_rays=16384, depth=8, seed=77)
+    e = ctx.compute_energy_response(src, p)
+    want = plain.compute_energy_response(psrc, p)
+    assert np.array_equal(e != 0, want != 0) and max(rel_rms(e[b], want[b]) for b in range(4)) <= TIGHT_TOL
+    assert np.array_equal(ctx.energy_buffer(src) != 0, want != 0)
+    # closest hits through the broadcast tree
+    rng = np.random.default_rng(5)
+    o = np.tile(np.asarray(sc.source, np.float32), (512, 1))
+    d = rng.normal(size=(512, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a, b = ctx.trace_rays(o, d, 1e6), plain.trace_rays(o, d, 1e6)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    ctx.comm_detach()
+    ctx.close()
+    plain.close()
+
+
+def test_sharded_context_refuses_a_partial_reconstruct(pkg, scene_factory):
+    """ReconstructImpulseResponse is not linear in the energy: a rank of a sharded run must not publish the IR of
+    its partial histogram.  Without a communicator the library says so (FS_ERR_COMM) unless the caller reduced the
+    frame behind fs_energy_handoff; the partition each rank traces is the library's own fs_shard_range."""
+    sc = scene_factory("starter_room", 4)
+    p = pkg.default_params(num_rays=16384, depth=8)
+    ctx, src = make_ctx(pkg, sc, rank=1, world_size=2)
+    ctx.compute_energy_response(src, p)
+    a, b = pkg.sharding.library_pair_range(16384, 1, 2)
+    assert ctx.stats()["pairs"] == b - a
+    with pytest.raises(pkg.FrequenSeeError) as ei:
+        ctx.reconstruct_impulse_response(src, p)
+    assert ei.value.code == pkg._capi.ERR_COMM and "partial" in str(ei.value)
+    ctx.compute_energy_response_async(src, p)
+    ctx.energy_handoff(src)                                # the caller's collective would run here, on the tail stream
+    ctx.reconstruct_impulse_response(src, p)               # accepted now
+    assert np.abs(ctx.impulse_response(src, 0)).max() > 0
+    ctx.close()
+
+
 # ---- row f3: all-prefix connections ----------------------------------------------------------------------------
 def test_all_connections_properties_full_size(pkg, oracle_mod, scene_factory):
     """cfg3 size (262 144 rays, depth 8, 100 000 triangles) in all-connections mode: oracle parity on a pair

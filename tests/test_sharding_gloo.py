@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo.  Each rank traces its share of the pairs (the same split
-libfrequensee.so applies for fs_config.rank/world_size) with the oracle standing in for the kernels,
-the [bands][bins] histograms are all-reduced, and the sum must equal the single-rank frame."""
+"""N>1 path on CPU: world_size-2 gloo.  Each rank asks libfrequensee.so itself for its share of the pairs
+(fs_shard_range: the host code fs_compute_energy_response* partitions a frame with), traces it with the oracle
+standing in for the kernels (no device here), the [bands][bins] histograms are all-reduced, and the sum must equal
+the single-rank frame.  The library-side collective (fs_comm_*) is covered on the GPU: tests/test_gpu_parity.py."""
 import os
 import socket
 import sys
@@ -22,6 +23,19 @@ def test_pair_ranges_partition(pkg):
         pkg.sharding.pair_range(10, 2, 2)
 
 
+def test_library_partition_is_the_documented_one(pkg):
+    """fs_shard_range (C ABI, host only) == sharding.pair_range for every rank, and the ranks tile [0, P) exactly"""
+    for rays in (0, 2, 14, 2000, 16384, 262144, 1048576, 2 * 777):
+        for W in (1, 2, 3, 4, 5, 8):
+            got = [pkg.sharding.library_pair_range(rays, r, W) for r in range(W)]
+            assert got == pkg.sharding.all_ranges(rays // 2, W)
+            assert got[0][0] == 0 and got[-1][1] == rays // 2
+    with pytest.raises(ValueError):
+        pkg.sharding.library_pair_range(7, 0, 2)      # odd ray count
+    with pytest.raises(ValueError):
+        pkg.sharding.library_pair_range(8, 2, 2)      # rank out of range
+
+
 def _worker(rank, world, port, pairs, out_path):
     sys.path.insert(0, ROOT)
     import torch
@@ -35,7 +49,8 @@ def _worker(rank, world, port, pairs, out_path):
     sc = pkg.scenes.by_name("starter_room", 4)
     osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption)
     p = oracle.default_params(num_pairs=pairs, depth=8, seed=0x5EED)
-    a, b = pkg.sharding.pair_range(pairs, rank, world)
+    a, b = pkg.sharding.library_pair_range(2 * pairs, rank, world)   # the library's own partition of the frame
+    assert (a, b) == pkg.sharding.pair_range(pairs, rank, world)
     _, e64, _ = osc.compute_energy(p, sc.source, sc.listener, a, b)
     t = torch.from_numpy(e64.copy())
     dist.all_reduce(t)                      # the energy-buffer sum (RCCL on the GPU box, gloo here)
