@@ -31,6 +31,7 @@ FLAG_DETERMINISTIC = 8
 FLAG_ALL_CONNECTIONS = 16
 FLAG_MIS_BALANCE = 32
 FLAG_MATERIAL_LOBES = 64
+FLAG_ACCUMULATE_ENERGY = 128
 
 # every symbol include/frequensee.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -50,6 +51,7 @@ EXPORTS = [
 ]
 COMM_ID_BYTES = 128
 ERR_COMM = 8
+ERR_OVERFLOW = 9
 REVERB_LITERAL_TAIL = 1
 
 

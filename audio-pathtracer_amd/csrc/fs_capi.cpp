@@ -35,8 +35,12 @@ struct Source {
     hipEvent_t ev_rec[2] = {nullptr, nullptr};   // tail stream: the reconstruct that read buffer i is done
     bool rec_recorded[2] = {false, false};
     int last_rec = -1;                 // buffer the newest reconstruct read (its event also guards d_ir_*)
-    hipEvent_t ev_rev = nullptr;       // compute stream: the newest reverb callback has read d_ir_mono
+    hipEvent_t ev_rev = nullptr;       // reverb stream: the newest reverb callback has read d_ir_mono
     bool rev_recorded = false;
+    // fs_reverb_process runs on the AUDIO thread while the game thread reconstructs: ir_mu guards what both touch —
+    // last_rec / rec_recorded / ev_rec (written by the reconstruct, read by the callback) and rev_recorded / ev_rev
+    // (the other way round).  Held only while work is ENQUEUED (microseconds), never across a stream wait.
+    std::mutex ir_mu;
     float* energy() const { return d_energy[cur]; }
     // multi-GPU: the frame in the current buffer has been summed over the ranks (library collective), or handed to the
     // caller's collective (fs_energy_handoff); a world_size > 1 context refuses to reconstruct a frame that is neither
@@ -74,9 +78,11 @@ struct fs_context {
     // "tail" stream: [caller's all-reduce] -> reconstruct -> publish of frame f, concurrent with the tracing of
     // frame f+1 on `stream`
     hipStream_t copy_stream = nullptr;
+    hipStream_t rev_stream = nullptr;  // the reverb callbacks' own stream (audio thread): never queued behind a traced frame
     bool own_stream = false;
     bool device_ok = false;
     std::string err;
+    std::mutex err_mu;                 // the audio thread may fail too
 
     // scene (host staging + device)
     std::vector<float> h_xyz;
@@ -122,6 +128,12 @@ struct fs_context {
     size_t cap_lanes = 0, cap_seg = 0;
     float4* d_seg_pos = nullptr;   // node positions per walk step, all-connections mode only (row f3)
     size_t cap_pos = 0;
+    // second record tier of depth = 0 frames (walk steps beyond FS_MAX_DEPTH): [kOverLevels][over_cap] each, grown when
+    // a frame raises the overflow word; d_overflow = that word
+    float2* d_over_np = nullptr; uint32_t* d_over_mat = nullptr; float4* d_over_pos = nullptr;
+    uint32_t over_cap = 0, over_cap_pos = 0;
+    unsigned* d_overflow = nullptr;
+    bool overflow_armed = false;   // an unbounded frame has been enqueued since the word was last read
     // batched frames (fs_compute_energy_response_batch_async): per-frame tables of pointers and source positions
     static constexpr int kBatchSlots = 4;   // frames the host may run ahead of the table copies
     char* d_batch = nullptr; char* h_batch = nullptr; size_t batch_cap = 0;   // kBatchSlots blocks of batch_cap bytes
@@ -145,10 +157,12 @@ struct fs_context {
     fs_stats stats{};
 
     int fail(int code, const std::string& m) {
+        std::lock_guard<std::mutex> g(err_mu);
         err = m;
         return code;
     }
     int hip_fail(hipError_t e, const char* what) {
+        std::lock_guard<std::mutex> g(err_mu);
         err = std::string(what) + ": " + hipGetErrorString(e);
         return FS_ERR_HIP;
     }
@@ -234,6 +248,11 @@ void free_state(fs_context* ctx) {
     if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
     if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
     ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
+    if (ctx->st.slot_of) (void)hipFree(ctx->st.slot_of);
+    for (void* q : {(void*)ctx->d_over_np, (void*)ctx->d_over_mat, (void*)ctx->d_over_pos, (void*)ctx->d_overflow})
+        if (q) (void)hipFree(q);
+    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->d_overflow = nullptr;
+    ctx->over_cap = ctx->over_cap_pos = 0;
     if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
     ctx->walk.perm = nullptr;
     ctx->st = SubpathState{};
@@ -305,9 +324,10 @@ void poll_published(Source* s) {
     s->front.store(f, std::memory_order_release);
 }
 
-int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positions, bool want_normals) {
+// levels = walk steps with a record in the main tier (min(depth, FS_MAX_DEPTH)); unbounded: also the second tier
+int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, bool want_positions, bool want_normals) {
     size_t lanes = 2 * (size_t)n_local;
-    size_t seg = (size_t)depth * lanes;
+    size_t seg = (size_t)levels * lanes;
     const size_t want = want_positions ? seg * (want_normals ? 2 : 1) : 0;   // positions, then normals
     if (want > ctx->cap_pos) {
         if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
@@ -318,12 +338,14 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positio
     if (lanes > ctx->cap_lanes) {
         if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
         if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
+        if (ctx->st.slot_of) (void)hipFree(ctx->st.slot_of);
         if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
-        ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr;
+        ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr; ctx->st.slot_of = nullptr;
         ctx->walk.perm = nullptr;
         ctx->cap_lanes = 0;
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * lanes));
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.slot_of, sizeof(uint32_t) * lanes));
         ctx->cap_seg = 0;   // the bucket array is sized with the segment records below
         ctx->cap_lanes = lanes;
     }
@@ -336,10 +358,37 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int depth, bool want_positio
         FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_mat, sizeof(uint32_t) * seg));
         if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
         ctx->walk.perm = nullptr;
-        // [depth + 1][lanes] for every later frame shape that fits the two capacities without a reallocation:
-        // depth' * lanes' <= cap_seg and lanes' <= cap_lanes  =>  (depth' + 1) * lanes' <= seg + cap_lanes
+        // [levels + 1][lanes] for every later frame shape that fits the two capacities without a reallocation:
+        // levels' * lanes' <= cap_seg and lanes' <= cap_lanes  =>  (levels' + 1) * lanes' <= seg + cap_lanes
         FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * (seg + ctx->cap_lanes)));
         ctx->cap_seg = seg;
+    }
+    if (!ctx->d_overflow) {
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_overflow, sizeof(unsigned)));
+        FS_HIP(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(unsigned), ctx->stream));
+    }
+    if (unbounded) {
+        // the schedule puts the longest walks first: slots below 0.9^64 * lanes (x4 for the spread, + 64) own a second tier
+        uint32_t want_cap = std::max(ctx->over_cap, (uint32_t)std::min<size_t>(lanes, (size_t)(4.0 * 1.18e-3 * (double)lanes) + 64));
+        if (const char* v = std::getenv("FS_OVER_CAP")) want_cap = std::max(ctx->over_cap, (uint32_t)std::max(1, std::atoi(v)));   // tests: force the regrow path
+        const bool grow_main = want_cap > ctx->over_cap || !ctx->d_over_np;
+        const bool grow_pos = want_positions && (want_cap > ctx->over_cap_pos || !ctx->d_over_pos);
+        if (grow_main) {
+            FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);
+            if (ctx->d_over_mat) (void)hipFree(ctx->d_over_mat);
+            ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr;
+            FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_np, sizeof(float2) * (size_t)kOverLevels * want_cap));
+            FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_mat, sizeof(uint32_t) * (size_t)kOverLevels * want_cap));
+            ctx->over_cap = want_cap;
+        }
+        if (grow_pos) {
+            FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_over_pos) (void)hipFree(ctx->d_over_pos);
+            ctx->d_over_pos = nullptr;
+            FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_pos, sizeof(float4) * 2 * (size_t)kOverLevels * ctx->over_cap));   // positions | normals
+            ctx->over_cap_pos = ctx->over_cap;
+        }
     }
     return FS_OK;
 }
@@ -376,6 +425,9 @@ int check_params(fs_context* ctx, const fs_params* p) {
     if (p->num_rays > (1u << 30)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "num_rays above 2^30 per frame (32-bit subpath indices)");
     if ((p->flags & FS_FLAG_MATERIAL_LOBES) && (p->flags & FS_FLAG_MIS_BALANCE))
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "FS_FLAG_MATERIAL_LOBES and FS_FLAG_MIS_BALANCE cannot be combined");
+    if ((p->flags & FS_FLAG_ACCUMULATE_ENERGY) && ctx->cfg.world_size > 1)
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "FS_FLAG_ACCUMULATE_ENERGY (the reference's accumulation quirk) is single-GPU only: "
+                                                  "a sharded frame is summed over the ranks, an accumulated one would be summed again");
     if (!(p->dist_divisor > 0.f) || !(p->sound_speed > 0.f))
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "dist_divisor and sound_speed must be positive");
     return FS_OK;
@@ -471,6 +523,8 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     }
     e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate(copy): ") + hipGetErrorString(e));
+    e = hipStreamCreateWithFlags(&ctx->rev_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate(reverb): ") + hipGetErrorString(e));
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0)
         ctx->walk.num_cus = cus;
@@ -498,6 +552,7 @@ int fs_context_destroy(fs_context* ctx) {
         (void)hipSetDevice(ctx->cfg.device);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+        if (ctx->rev_stream) (void)hipStreamSynchronize(ctx->rev_stream);
         resolve_timings(ctx);
         (void)fs_comm_detach(ctx);
         for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
@@ -517,13 +572,22 @@ int fs_context_destroy(fs_context* ctx) {
     for (Source* s : ctx->sources) free_source(ctx, s);
     // streams exist even when a later step of fs_context_create failed (device_ok == false)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->rev_stream) (void)hipStreamDestroy(ctx->rev_stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (!ctx->device_ok && ctx->walk.queue_head) (void)hipFree(ctx->walk.queue_head);
     delete ctx;
     return FS_OK;
 }
 
-const char* fs_last_error(const fs_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* fs_last_error(const fs_context* ctx) {
+    if (!ctx) return "null context";
+    static thread_local std::string copy;   // the string may be rewritten by another thread while the caller reads it
+    {
+        std::lock_guard<std::mutex> g(const_cast<fs_context*>(ctx)->err_mu);
+        copy = ctx->err;
+    }
+    return copy.c_str();
+}
 int fs_num_bins(const fs_context* ctx) { return ctx ? ctx->num_bins : 0; }
 int fs_num_samples(const fs_context* ctx) { return ctx ? ctx->num_samples : 0; }
 
@@ -945,7 +1009,10 @@ int fs_source_destroy(fs_context* ctx, fs_source h) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
-    if (ctx->device_ok) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_stream); }
+    if (ctx->device_ok) {
+        (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->rev_stream);
+    }
     ctx->sources[(size_t)h] = nullptr;  // UnRegisterSource ARTS.cpp:50-53
     free_source(ctx, s);
     return FS_OK;
@@ -969,6 +1036,25 @@ int fs_listener_set_position(fs_context* ctx, const float xyz[3]) {
 // One traced frame for `count` sources (count == 1: the plain call).  A batch lays the sources' pairs end to end in one
 // plan / walk / connect sequence: every source gets exactly the pairs, random streams and therefore results of its own
 // fs_compute_energy_response_async call, but the chip sees one large frame instead of `count` small ones.
+// depth = 0 frames: did a walk's record miss both tiers?  (Called where the compute stream has just been synchronised.)
+// Then the frame's energy is incomplete: the tier is grown for the next attempt and the caller is told.
+static int check_overflow(fs_context* ctx) {
+    if (!ctx->overflow_armed || !ctx->d_overflow) return FS_OK;
+    ctx->overflow_armed = false;
+    unsigned flag = 0;
+    FS_HIP(ctx, hipMemcpy(&flag, ctx->d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
+    if (!flag) return FS_OK;
+    FS_HIP(ctx, hipMemset(ctx->d_overflow, 0, sizeof(flag)));
+    const uint32_t grown = std::max<uint32_t>(ctx->over_cap, 16) * 4;
+    if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);
+    if (ctx->d_over_mat) (void)hipFree(ctx->d_over_mat);
+    if (ctx->d_over_pos) (void)hipFree(ctx->d_over_pos);
+    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->over_cap_pos = 0;
+    ctx->over_cap = grown;   // ensure_state allocates at this size next time
+    return ctx->fail(FS_ERR_OVERFLOW, "depth = 0: more walks than expected outlived " + std::to_string(FS_MAX_DEPTH) +
+                     " steps; the record tier has been grown — trace the frame again");
+}
+
 static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
     Source* s = srcs[0];
     const bool batch = count > 1;
@@ -988,7 +1074,12 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     kp.pairs_per_source = pn;
     kp.num_local = kp.pairs_per_source * (uint32_t)count;
     kp.src_table = nullptr;
-    kp.depth = p->depth > 0 ? p->depth : FS_MAX_DEPTH;
+    // depth = 0: no cap, like the reference's while (true) (ARTS.cpp:294) — the roulette ends every walk; the records of
+    // steps beyond FS_MAX_DEPTH go to the second tier.  Without roulette an uncapped walk would never end: FS_MAX_DEPTH.
+    const bool unbounded = p->depth == 0 && p->russian_roulette && p->rr_prob < 1.0f;
+    const int levels = p->depth > 0 ? p->depth : FS_MAX_DEPTH;
+    kp.depth = unbounded ? FS_MAX_DEPTH + kOverLevels : levels;
+    kp.mis_depth = unbounded ? kUnboundedDepth : levels;
     kp.russian_roulette = p->russian_roulette;
     kp.cosine = (p->flags & FS_FLAG_COSINE_SAMPLING) ? 1 : 0;
     kp.rr_prob = p->rr_prob;
@@ -1013,11 +1104,19 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     const bool mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
     const bool all_conn = mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
     kp.mis = mis ? 1 : 0;
-    rc = ensure_state(ctx, kp.num_local, kp.depth, all_conn, mis);
+    rc = ensure_state(ctx, kp.num_local, levels, unbounded, all_conn, mis);
     if (rc) return rc;
     SubpathState st = ctx->st;
     st.seg_pos = all_conn ? ctx->d_seg_pos : nullptr;
-    st.seg_nrm = mis ? ctx->d_seg_pos + (size_t)kp.depth * 2 * (size_t)kp.num_local : nullptr;
+    st.seg_nrm = mis ? ctx->d_seg_pos + (size_t)levels * 2 * (size_t)kp.num_local : nullptr;
+    st.main_levels = levels;
+    st.over_levels = unbounded ? kOverLevels : 0;
+    st.over_cap = unbounded ? ctx->over_cap : 0;
+    st.over_np = ctx->d_over_np; st.over_mat = ctx->d_over_mat;
+    st.over_pos = all_conn ? ctx->d_over_pos : nullptr;
+    st.over_nrm = mis && ctx->d_over_pos ? ctx->d_over_pos + (size_t)kOverLevels * ctx->over_cap : nullptr;
+    st.overflow = ctx->d_overflow;
+    if (unbounded) ctx->overflow_armed = true;
 
     TimedFrame tf{};
     if (ctx->profiling) {
@@ -1028,20 +1127,25 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         if (ctx->profiling >= 2) tf.e[2] = take_event(ctx);
     }
     const bool fixed = (p->flags & FS_FLAG_DETERMINISTIC) != 0;
+    const bool accumulate = (p->flags & FS_FLAG_ACCUMULATE_ENERGY) != 0;
     for (int i = 0; i < count; ++i) {
         Source* si = srcs[i];
         if (fixed && !si->d_fixed[0]) {
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 2; ++k) {
                 FS_HIP(ctx, hipMalloc((void**)&si->d_fixed[k], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
+                FS_HIP(ctx, hipMemsetAsync(si->d_fixed[k], 0, sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+            }
         }
-        si->cur ^= 1;   // this frame deposits into the other buffer; the tail may still be busy with the last one
+        // this frame deposits into the other buffer; the tail may still be busy with the last one.  (FS_FLAG_ACCUMULATE_ENERGY
+        // stays in the buffer of the previous frame — behind its reduce / reconstruct — and adds to what it holds.)
+        if (!accumulate) si->cur ^= 1;
         si->cur_fixed = fixed;
         si->reduced = false; si->handed_off = false;
         FS_HIP(ctx, wait_energy_readers(ctx, si));
     }
     // FlushEnergyBuffer ARTS.cpp:157-161 is folded into the plan pass (one launch); plain memset otherwise.
     // Deterministic mode zeroes the fixed-point histogram instead (the fp32 buffer is rewritten from it).
-    float* zero_ptr = fixed ? reinterpret_cast<float*>(s->d_fixed[s->cur]) : s->energy();
+    float* zero_ptr = accumulate ? nullptr : (fixed ? reinterpret_cast<float*>(s->d_fixed[s->cur]) : s->energy());
     const int zero_words = (fixed ? 2 : 1) * B * ctx->num_bins;
     float* const* energy_tab = nullptr;
     unsigned long long* const* fixed_tab = nullptr;
@@ -1081,13 +1185,16 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         energy_tab = reinterpret_cast<float* const*>(db);
         fixed_tab = fixed ? reinterpret_cast<unsigned long long* const*>(db + (size_t)count * sizeof(void*)) : nullptr;
         kp.src_table = reinterpret_cast<const float*>(db + 2 * (size_t)count * sizeof(void*));
-        for (int i = 0; i < count; ++i) {
+        for (int i = 0; i < count && !accumulate; ++i) {
             float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[srcs[i]->cur]) : srcs[i]->energy();
             FS_HIP(ctx, hipMemsetAsync(zp, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
         }
         zero_ptr = nullptr;
     }
-    const uint32_t* perm = launch_plan(kp, ctx->walk, zero_ptr, zero_ptr ? zero_words : 0, ctx->stream);
+    WalkLaunch wplan = ctx->walk;
+    if (unbounded) wplan.plan = 1;   // the second record tier relies on the schedule: the longest walks own the lowest slots
+    const uint32_t* perm = launch_plan(kp, wplan, zero_ptr, zero_ptr ? zero_words : 0, ctx->stream);
+    if (!perm) st.slot_of = nullptr;   // no schedule: slot == subpath index
     if (!perm && zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
     if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
     if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
@@ -1157,7 +1264,15 @@ int fs_compute_energy_response_batch_async(fs_context* ctx, const fs_source* sou
 }
 
 int fs_compute_energy_response(fs_context* ctx, fs_source h, const fs_params* p, float* energy_out) {
-    int rc = fs_compute_energy_response_async(ctx, h, p);
+    int rc = FS_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {   // depth = 0: a frame whose records overflowed is traced again
+        rc = fs_compute_energy_response_async(ctx, h, p);
+        if (rc) return rc;
+        if (!ctx->overflow_armed) break;
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = check_overflow(ctx);
+        if (rc != FS_ERR_OVERFLOW) break;
+    }
     if (rc) return rc;
     Source* s = get_source(ctx, h);
     if (energy_out) {
@@ -1241,16 +1356,19 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     // next frame.  Reconstructs and publishes of one source are ordered among themselves by the tail stream.
     FS_HIP(ctx, handoff_energy(ctx, s));
     hipStream_t tail = ctx->copy_stream;
-    if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
-    if (timed) FS_HIP(ctx, hipEventRecord(tf.e[3], tail));
-    // deterministic mode: the caller's collective summed the fixed-point histogram; round it to fp32 once, now
-    if (s->cur_fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
-    launch_reconstruct(s->energy(), B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
-                       s->d_ir_mono, tail);
-    FS_HIP(ctx, hipGetLastError());
-    FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], tail));
-    s->rec_recorded[s->cur] = true;
-    s->last_rec = s->cur;
+    {
+        std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
+        if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
+        if (timed) FS_HIP(ctx, hipEventRecord(tf.e[3], tail));
+        // deterministic mode: the collective summed the fixed-point histogram; round it to fp32 once, now
+        if (s->cur_fixed && !s->reduced) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
+        launch_reconstruct(s->energy(), B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
+                           s->d_ir_mono, tail);
+        FS_HIP(ctx, hipGetLastError());
+        FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], tail));
+        s->rec_recorded[s->cur] = true;
+        s->last_rec = s->cur;
+    }
     uint64_t seq = s->enqueued + 1;
     int slot = (int)(seq % kIrRing);
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
@@ -1282,15 +1400,18 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
         }
     }
     hipStream_t tail = ctx->copy_stream;   // ordered with reconstructs and publishes of this source
-    if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));
     const size_t bytes = sizeof(float) * (size_t)n;
-    FS_HIP(ctx, hipMemcpyAsync(s->d_ir_mono, ir, bytes, hipMemcpyHostToDevice, tail));
-    for (int b = 0; b < ctx->cfg.num_bands; ++b)
-        FS_HIP(ctx, hipMemcpyAsync(s->d_ir_bands + (size_t)b * (size_t)n, s->d_ir_mono, bytes, hipMemcpyDeviceToDevice, tail));
-    const int cur = s->last_rec >= 0 ? s->last_rec : s->cur;
-    FS_HIP(ctx, hipEventRecord(s->ev_rec[cur], tail));   // the reverb waits on this before reading d_ir_mono
-    s->rec_recorded[cur] = true;
-    s->last_rec = cur;
+    {
+        std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
+        if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));
+        FS_HIP(ctx, hipMemcpyAsync(s->d_ir_mono, ir, bytes, hipMemcpyHostToDevice, tail));
+        for (int b = 0; b < ctx->cfg.num_bands; ++b)
+            FS_HIP(ctx, hipMemcpyAsync(s->d_ir_bands + (size_t)b * (size_t)n, s->d_ir_mono, bytes, hipMemcpyDeviceToDevice, tail));
+        const int cur = s->last_rec >= 0 ? s->last_rec : s->cur;
+        FS_HIP(ctx, hipEventRecord(s->ev_rec[cur], tail));   // the reverb waits on this before reading d_ir_mono
+        s->rec_recorded[cur] = true;
+        s->last_rec = cur;
+    }
     uint64_t seq = s->enqueued + 1;
     int slot = (int)(seq % kIrRing);
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, bytes, hipMemcpyDeviceToHost, tail));
@@ -1311,7 +1432,7 @@ int fs_synchronize(fs_context* ctx) {
     for (Source* s : ctx->sources)
         if (s && s->alive) poll_published(s);
     resolve_timings(ctx);
-    return FS_OK;
+    return check_overflow(ctx);   // FS_ERR_OVERFLOW: the last depth = 0 frame must be traced again (see the header)
 }
 
 int fs_reconstruct_impulse_response(fs_context* ctx, fs_source h, const fs_params* p) {
@@ -1617,14 +1738,14 @@ int fs_reverb_init(fs_context* ctx, fs_source h, int32_t frame_size) {
     if (frame_size < 1 || frame_size > 16384 || ctx->num_samples - 1 > kReverbRing)
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad reverb frame size / IR longer than the history ring");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->rev_stream));
     if (s->d_ring) { (void)hipFree(s->d_ring); (void)hipFree(s->d_rev_in); (void)hipFree(s->d_rev_cur); (void)hipFree(s->d_rev_out); }
     s->d_ring = s->d_rev_in = s->d_rev_cur = s->d_rev_out = nullptr;
     FS_HIP(ctx, hipMalloc((void**)&s->d_ring, sizeof(float) * 2 * kReverbRing));
     FS_HIP(ctx, hipMalloc((void**)&s->d_rev_in, sizeof(float) * 2 * (size_t)frame_size));
     FS_HIP(ctx, hipMalloc((void**)&s->d_rev_cur, sizeof(float) * 2 * (size_t)frame_size));
     FS_HIP(ctx, hipMalloc((void**)&s->d_rev_out, sizeof(float) * 2 * (size_t)frame_size));
-    FS_HIP(ctx, hipMemsetAsync(s->d_ring, 0, sizeof(float) * 2 * kReverbRing, ctx->stream));   // SetNumZeroed
+    FS_HIP(ctx, hipMemsetAsync(s->d_ring, 0, sizeof(float) * 2 * kReverbRing, ctx->rev_stream));   // SetNumZeroed
     s->rev_head = 0;
     s->rev_frame = frame_size;
     return FS_OK;
@@ -1642,18 +1763,23 @@ int fs_reverb_process(fs_context* ctx, fs_source h, const float* in, float* out,
         return FS_OK;
     }
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    // the device-resident IR is written by reconstructs on the tail stream: read it behind the newest one, and
-    // make the next one wait for this read (ev_rev)
-    if (s->last_rec >= 0) FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_rec[s->last_rec], 0));
-    FS_HIP(ctx, hipMemcpyAsync(s->d_rev_in, in, sizeof(float) * 2 * (size_t)frame, hipMemcpyHostToDevice, ctx->stream));
-    launch_reverb(s->d_ir_mono, ctx->num_samples, s->d_ring, s->rev_head, s->d_rev_in, s->d_rev_cur, s->d_rev_out, frame,
-                  (flags & FS_REVERB_LITERAL_TAIL) ? 1 : 0, ctx->stream);
-    FS_HIP(ctx, hipGetLastError());
-    FS_HIP(ctx, hipEventRecord(s->ev_rev, ctx->stream));
-    s->rev_recorded = true;
+    // Audio thread.  The callback has its own stream: it is never queued behind a traced frame on the compute stream.
+    // The device-resident IR is written by reconstructs on the tail stream: read it behind the newest one and make the
+    // next one wait for this read — both through events, exchanged with the game thread under the source's ir_mu.
+    hipStream_t rs = ctx->rev_stream;
+    {
+        std::lock_guard<std::mutex> g(s->ir_mu);
+        if (s->last_rec >= 0) FS_HIP(ctx, hipStreamWaitEvent(rs, s->ev_rec[s->last_rec], 0));
+        FS_HIP(ctx, hipMemcpyAsync(s->d_rev_in, in, sizeof(float) * 2 * (size_t)frame, hipMemcpyHostToDevice, rs));
+        launch_reverb(s->d_ir_mono, ctx->num_samples, s->d_ring, s->rev_head, s->d_rev_in, s->d_rev_cur, s->d_rev_out, frame,
+                      (flags & FS_REVERB_LITERAL_TAIL) ? 1 : 0, rs);
+        FS_HIP(ctx, hipGetLastError());
+        FS_HIP(ctx, hipEventRecord(s->ev_rev, rs));
+        s->rev_recorded = true;
+    }
     s->rev_head += (unsigned)frame;
-    FS_HIP(ctx, hipMemcpyAsync(out, s->d_rev_out, sizeof(float) * 2 * (size_t)frame, hipMemcpyDeviceToHost, ctx->stream));
-    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FS_HIP(ctx, hipMemcpyAsync(out, s->d_rev_out, sizeof(float) * 2 * (size_t)frame, hipMemcpyDeviceToHost, rs));
+    FS_HIP(ctx, hipStreamSynchronize(rs));
     return FS_OK;
 }
 
@@ -1663,7 +1789,7 @@ int fs_reverb_release(fs_context* ctx, fs_source h) {
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (s->d_ring && ctx->device_ok) {
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-        FS_HIP(ctx, hipMemsetAsync(s->d_ring, 0, sizeof(float) * 2 * kReverbRing, ctx->stream));
+        FS_HIP(ctx, hipMemsetAsync(s->d_ring, 0, sizeof(float) * 2 * kReverbRing, ctx->rev_stream));
         s->rev_head = 0;
     }
     return FS_OK;

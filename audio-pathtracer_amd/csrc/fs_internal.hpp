@@ -56,6 +56,8 @@ constexpr int kBlock = 256;       // 4 waves of 64 lanes
 // at cfg3 touches bins 0..60.  All 1000 bins cost 32 KB per workgroup at 8 bands — the 8 KB window keeps three
 // connect workgroups on a CU instead of two.  FS_HIST_WINDOW overrides it (tests exercise the far path with 16).
 constexpr int kHistWindow = 256;
+constexpr int kUnboundedDepth = 1 << 24;   // the weights' depth cap when the walk has none: every strategy exists
+constexpr int kOverLevels = 448;            // second-tier walk steps of depth = 0 frames (64 + 448 = 512 steps)
 
 struct DeviceScene {
     const NodeQ4* nodes;
@@ -77,7 +79,9 @@ struct KParams {
     uint32_t pairs_per_source;   // == num_local for one source; a batched frame lays its sources' pairs end to end:
                                  // pair li belongs to source li / pairs_per_source, RNG pair index li % pairs_per_source
     const float* src_table;      // [sources][3] source positions of a batched frame (device), else null (kp.src)
-    int32_t depth;         // max segments per subpath (1..FS_MAX_DEPTH)
+    int32_t depth;         // max segments per subpath: 1..FS_MAX_DEPTH, or main_levels + over_levels for depth = 0 (a bound the
+                           //   roulette practically never reaches: 0.9^512 ~ 4e-24)
+    int32_t mis_depth;     // depth cap D of the all-connections weights (kUnboundedDepth for depth = 0)
     int32_t russian_roulette;
     int32_t cosine;
     int32_t lobes;         // 1 = FS_FLAG_MATERIAL_LOBES: the walk picks a specular / diffuse / transmitted lobe per vertex
@@ -106,18 +110,29 @@ struct SoundAccum {
     float direct_energy_sum, occlusion;
 };
 
-// What the walk kernels leave for connect_kernel, SoA over total = 2*num_local subpaths
-// (side-major: [0,n) source side, [n,2n) listener side).
+// What the walk kernels leave for connect_kernel.  A subpath is known by its index g (side-major: [0,n) source side,
+// [n,2n) listener side) and by its LAUNCH SLOT: the lane that walks it under the length-sorted schedule.  Everything
+// the walk writes is indexed by slot — a wave's lanes write consecutive words — and slot_of[g] leads back to it
+// (null = no schedule, slot == g).  total = 2 * num_local.
 struct SubpathState {
-    float4* end_pos;    // [total] xyz = last node position, w = last node probability
-    uint2* end_misc;    // [total] x = last node material, y = segments taken
-    float2* seg_np;     // [depth][total] per walk step: x = scaled segment length, y = probability of the
-                        //   node EvaluatePath pairs with the segment (departure node on the source side,
-                        //   arrival node on the listener side)
-    uint32_t* seg_mat;  // [depth][total] material of that node
-    float4* seg_pos;    // [depth][total] xyz = position of the node a walk step arrives at; only written (and only
+    float4* end_pos;    // [total] by slot: xyz = last node position, w = last node probability
+    uint2* end_misc;    // [total] by slot: x = last node material, y = segments taken
+    float2* seg_np;     // [main_levels][total] per walk step, by slot: x = scaled segment length, y = probability of the
+                        //   node EvaluatePath pairs with the segment (departure node on the source side, arrival node
+                        //   on the listener side)
+    uint32_t* seg_mat;  // [main_levels][total] material of that node
+    float4* seg_pos;    // [main_levels][total] xyz = position of the node a walk step arrives at; only written (and only
                         //   non-null) in all-connections mode, which connects interior nodes too (row f3)
-    float4* seg_nrm;    // [depth][total] xyz = normal of that node; only with balance-heuristic weights
+    float4* seg_nrm;    // [main_levels][total] xyz = normal of that node; only with balance-heuristic weights
+    uint32_t* slot_of;  // [total] launch slot of subpath g, written by the walk; null: slot == g
+    // Walk steps beyond main_levels exist only for depth = 0 (no cap, ARTS.cpp:294): 0.9^64 of the walks take more than
+    // 64 steps, and the schedule puts the longest walks into the lowest slots, so their later records live in a small
+    // second tier [over_levels][over_cap] indexed by (step - main_levels, slot).  A record that fits neither tier
+    // raises *overflow; the host then grows the tier and traces the frame again (fs_capi.cpp).
+    float2* over_np; uint32_t* over_mat; float4* over_pos; float4* over_nrm;
+    unsigned* overflow;
+    uint32_t over_cap;
+    int32_t main_levels, over_levels;
 };
 
 // ---- host BVH builder ------------------------------------------------------------------------------

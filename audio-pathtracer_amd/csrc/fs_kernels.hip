@@ -450,7 +450,7 @@ __device__ __forceinline__ void apply_segment(float (&E)[B], float nd, uint32_t 
 // the walk, shared by both kernel variants
 // ---------------------------------------------------------------------------------------------------
 struct Walker {          // ARTS.cpp:287-291 state + bookkeeping
-    uint32_t g, side, li, pair;
+    uint32_t g, slot, side, li, pair;   // subpath index, launch slot (where its records go), side, pair of the frame, RNG pair
     int k;
     float px, py, pz, nx, ny, nz;
     bool has_normal;
@@ -460,9 +460,41 @@ struct Walker {          // ARTS.cpp:287-291 state + bookkeeping
     float prob, prob_new;
 };
 
-__device__ __forceinline__ void walker_start(Walker& w, uint32_t g, const KParams& kp) {
+// ---- segment records: [step][slot] in the main tier, (step - main_levels, slot) in the overflow tier ------------
+__device__ __forceinline__ bool rec_in_main(const SubpathState& st, int k) { return k < st.main_levels; }
+__device__ __forceinline__ size_t rec_main(uint32_t total, int k, uint32_t slot) { return (size_t)k * total + slot; }
+__device__ __forceinline__ size_t rec_over(const SubpathState& st, int k, uint32_t slot) {
+    return (size_t)(k - st.main_levels) * st.over_cap + slot;
+}
+// does step k of the walk in `slot` have a place?  (always, for a capped depth)
+__device__ __forceinline__ bool rec_fits(const SubpathState& st, int k, uint32_t slot) {
+    return k < st.main_levels || (slot < st.over_cap && k - st.main_levels < st.over_levels);
+}
+__device__ __forceinline__ float2 load_np(const SubpathState& st, uint32_t total, int k, uint32_t slot) {
+    return rec_in_main(st, k) ? st.seg_np[rec_main(total, k, slot)] : st.over_np[rec_over(st, k, slot)];
+}
+__device__ __forceinline__ uint32_t load_mat(const SubpathState& st, uint32_t total, int k, uint32_t slot) {
+    return rec_in_main(st, k) ? st.seg_mat[rec_main(total, k, slot)] : st.over_mat[rec_over(st, k, slot)];
+}
+__device__ __forceinline__ float4 load_pos(const SubpathState& st, uint32_t total, int k, uint32_t slot) {
+    return rec_in_main(st, k) ? st.seg_pos[rec_main(total, k, slot)] : st.over_pos[rec_over(st, k, slot)];
+}
+__device__ __forceinline__ float4 load_nrm(const SubpathState& st, uint32_t total, int k, uint32_t slot) {
+    return rec_in_main(st, k) ? st.seg_nrm[rec_main(total, k, slot)] : st.over_nrm[rec_over(st, k, slot)];
+}
+__device__ __forceinline__ void store_mat(const SubpathState& st, uint32_t total, int k, uint32_t slot, uint32_t v) {
+    if (rec_in_main(st, k)) st.seg_mat[rec_main(total, k, slot)] = v;
+    else if (rec_fits(st, k, slot)) st.over_mat[rec_over(st, k, slot)] = v;
+}
+// slot of subpath g
+__device__ __forceinline__ uint32_t slot_of(const SubpathState& st, uint32_t g) { return st.slot_of ? st.slot_of[g] : g; }
+
+__device__ __forceinline__ void walker_start(Walker& w, uint32_t g, uint32_t slot, const KParams& kp, const SubpathState& st,
+                                             bool own = true) {   // own = false: a helper lane without a subpath
     const uint32_t n = kp.num_local;
     w.g = g;
+    w.slot = slot;
+    if (own && st.slot_of) st.slot_of[g] = slot;   // the connect kernels find the walk's records through this
     w.side = g >= n ? 1u : 0u;
     w.li = g - w.side * n;
     w.pair = kp.pair_begin + w.li;
@@ -490,10 +522,11 @@ template <int LOBES = -1>
 __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, const DeviceScene& sc,
                                                 const SubpathState& st, Ray& ray) {
     const bool lobes_on = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
-    if (w.k >= kp.depth) return false;
+    if (w.k >= kp.depth && st.over_levels == 0) return false;             // the depth cap
     const uint32_t bs = ((uint32_t)w.k << 1) | w.side;
     const uint4 r = philox(w.pair, bs, 0, kp.seed_lo, kp.seed_hi);
     if (kp.russian_roulette && !(u01(r.x) < kp.rr_prob)) return false;    // ARTS.cpp:300-301, 349-353
+    if (w.k >= kp.depth) { *st.overflow = 1u; return false; }             // depth = 0 and the walk outlives both tiers
     float dx, dy, dz;
     if (!w.has_normal) {                                                  // ARTS.cpp:306-310
         sample_sphere(w.pair, bs, r, kp.seed_lo, kp.seed_hi, dx, dy, dz);
@@ -515,7 +548,7 @@ __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, co
             plobe = lobe == kLobeDiffuse ? p0 : (lobe == kLobeSpecular ? p1 : p2);
             // the listener side pairs a segment with its ARRIVAL vertex: the record of the previous step describes
             // this vertex and learns its lobe now
-            if (w.side) st.seg_mat[(size_t)(w.k - 1) * (2u * (size_t)kp.num_local) + w.g] = w.mat | (lobe << kLobeShift);
+            if (w.side) store_mat(st, 2u * kp.num_local, w.k - 1, w.slot, w.mat | (lobe << kLobeShift));
         }
         w.lobe = pick ? lobe << kLobeShift : 0u;
         float ox = w.px, oy = w.py, oz = w.pz;
@@ -563,11 +596,23 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
     // Record for EvaluatePath (done by connect_kernel in path order): node i of the reference's loop is
     // the DEPARTURE node on the source side and — the listener subpath being reversed in the connected
     // path — the ARRIVAL node on the listener side.
-    const size_t slot = (size_t)w.k * (2u * (size_t)kp.num_local) + w.g;
-    st.seg_np[slot] = w.side == 0 ? make_float2(nd, w.prob) : make_float2(nd, w.prob_new);
-    st.seg_mat[slot] = w.side == 0 ? (w.mat | w.lobe) : mat_new;   // w.lobe: 0 unless FS_FLAG_MATERIAL_LOBES picked one here
-    if (st.seg_pos) st.seg_pos[slot] = make_float4(qx, qy, qz, 0.0f);   // all-connections mode (wave-uniform)
-    if (st.seg_nrm) st.seg_nrm[slot] = make_float4(w.nx, w.ny, w.nz, 0.0f);   // balance-heuristic weights only
+    const float2 rec_np = w.side == 0 ? make_float2(nd, w.prob) : make_float2(nd, w.prob_new);
+    const uint32_t rec_mat = w.side == 0 ? (w.mat | w.lobe) : mat_new;   // w.lobe: 0 unless FS_FLAG_MATERIAL_LOBES picked one here
+    if (rec_in_main(st, w.k)) {
+        const size_t r = rec_main(2u * kp.num_local, w.k, w.slot);       // consecutive lanes, consecutive words
+        st.seg_np[r] = rec_np;
+        st.seg_mat[r] = rec_mat;
+        if (st.seg_pos) st.seg_pos[r] = make_float4(qx, qy, qz, 0.0f);   // all-connections mode (wave-uniform)
+        if (st.seg_nrm) st.seg_nrm[r] = make_float4(w.nx, w.ny, w.nz, 0.0f);   // balance-heuristic weights only
+    } else if (rec_fits(st, w.k, w.slot)) {                              // depth = 0: step 65.. of one of the longest walks
+        const size_t r = rec_over(st, w.k, w.slot);
+        st.over_np[r] = rec_np;
+        st.over_mat[r] = rec_mat;
+        if (st.seg_pos) st.over_pos[r] = make_float4(qx, qy, qz, 0.0f);
+        if (st.seg_nrm) st.over_nrm[r] = make_float4(w.nx, w.ny, w.nz, 0.0f);
+    } else {
+        *st.overflow = 1u;                                               // the host grows the tier and traces again
+    }
     w.px = qx; w.py = qy; w.pz = qz;
     w.mat = mat_new;
     w.prob = w.prob_new;
@@ -575,8 +620,8 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
 }
 
 __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathState& st) {
-    st.end_pos[w.g] = make_float4(w.px, w.py, w.pz, w.prob);
-    st.end_misc[w.g] = make_uint2(w.mat, (uint32_t)w.k);
+    st.end_pos[w.slot] = make_float4(w.px, w.py, w.pz, w.prob);
+    st.end_misc[w.slot] = make_uint2(w.mat, (uint32_t)w.k);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -609,23 +654,29 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
                                                       int energy_words) {
     __shared__ unsigned s_hist[kPlanBuckets];
     __shared__ unsigned s_base[kPlanBuckets];
+    __shared__ unsigned s_seg;
+    if (threadIdx.x == 0) s_seg = 0u;
     for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) s_hist[i] = 0u;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) energy[i] = 0.0f;
     __syncthreads();
     const uint32_t total = 2u * kp.num_local;
     // kPlanItems subpaths per thread: the bucket counters are a handful of hot addresses, and every workgroup
     // pays one global atomic per occupied length — fewer, larger workgroup batches mean fewer of them
-    int L[kPlanItems];
+    int L[kPlanItems];   // bucket = planned length, walks of more than FS_MAX_DEPTH steps (depth = 0 only) share the last one
     unsigned rank[kPlanItems];
+    unsigned my_segments = 0;
 #pragma unroll
     for (int it = 0; it < kPlanItems; ++it) {
         const uint32_t g = (blockIdx.x * kPlanItems + it) * kBlock + threadIdx.x;
         L[it] = 0; rank[it] = 0;
         if (g < total) {
-            L[it] = planned_length(g, kp);
+            const int len = planned_length(g, kp);
+            my_segments += (unsigned)len;
+            L[it] = min(len, FS_MAX_DEPTH);
             rank[it] = atomicAdd(&s_hist[L[it]], 1u);
         }
     }
+    if (my_segments) atomicAdd(&s_seg, my_segments);
     __syncthreads();
     for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
         if (s_hist[i]) s_base[i] = atomicAdd(&scratch[1 + i], s_hist[i]);
@@ -636,11 +687,7 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
         if (perm && g < total) perm[(size_t)L[it] * total + s_base[L[it]] + rank[it]] = g;
     }
     // work counter: walk segments of this frame (a walk of length L traces L rays), one atomic per workgroup
-    if (threadIdx.x == 0) {
-        unsigned long long seg = 0;
-        for (int i = 1; i < kPlanBuckets; ++i) seg += (unsigned long long)i * s_hist[i];
-        if (seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), seg);
-    }
+    if (threadIdx.x == 0 && s_seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), (unsigned long long)s_seg);
 }
 
 // launch slot -> subpath index through the buckets, longest walks first.  s_cnt = bucket counts in LDS.
@@ -667,16 +714,16 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {   // wave-uniform: bucket counts of the plan pass
-        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
+        for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
         __syncthreads();
     }
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= 2u * kp.num_local) return;
     // length-sorted schedule (plan pass) or identity
-    const uint32_t g = perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot;
+    const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
     int* stack = &s_stack[threadIdx.x];
     Walker w;
-    walker_start(w, g, kp);
+    walker_start(w, g, slot, kp, st);
     Ray ray;
     while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
         Trav T;
@@ -869,15 +916,15 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {
-        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
+        for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
     }
     if (perm) __syncthreads();
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= 2u * kp.num_local) return;
-    const uint32_t g = perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot;
+    const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
     int* stack = &s_stack[threadIdx.x];
     Walker w;
-    walker_start(w, g, kp);
+    walker_start(w, g, slot, kp, st);
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
 #ifdef FS_WAVE_TIMELINE
@@ -930,7 +977,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {
-        for (int i = threadIdx.x; i <= kp.depth; i += kBlock) s_cnt[i] = scratch[1 + i];
+        for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -939,7 +986,8 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
     bool alive = lane < (uint32_t)rays_per_wave && slot < 2u * kp.num_local;
     int* stack = &s_stack[threadIdx.x];
     Walker w;
-    walker_start(w, alive ? (perm ? planned_subpath(slot, kp.depth, 2u * kp.num_local, s_cnt, perm) : slot) : 0u, kp);
+    walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
+                 slot, kp, st, alive);
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
     while (true) {
@@ -1000,10 +1048,11 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         const uint32_t li = first + wave * ppw + lane;
         const bool active = lane < ppw && li < end;
         const uint32_t lc = active ? li : 0u;
-        const float4 F = st.end_pos[lc];
-        const uint2 Fm = st.end_misc[lc];
-        const float4 L = st.end_pos[n + lc];
-        const uint2 Lm = st.end_misc[n + lc];
+        const uint32_t sf = slot_of(st, lc), sl = slot_of(st, n + lc);   // where the walk left the two subpaths of the pair
+        const float4 F = st.end_pos[sf];
+        const uint2 Fm = st.end_misc[sf];
+        const float4 L = st.end_pos[sl];
+        const uint2 Lm = st.end_misc[sl];
         // visibility F_k -> B_m - 0.1 * unit(B_m - F_k) (ARTS.cpp:252-254); visible iff NO hit
         float dx = L.x - F.x, dy = L.y - F.y, dz = L.z - F.z;
         float l2 = dx * dx + dy * dy + dz * dz;
@@ -1028,9 +1077,9 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         float sd = 0.0f;
         const int kf = (int)Fm.y, kl = (int)Lm.y;
         for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
-            const float2 np = st.seg_np[(size_t)j * total + li];
+            const float2 np = load_np(st, total, j, sf);
             sd += np.x;                                               // ARTS.cpp:374
-            apply_segment<B, LOBES>(E, np.x, st.seg_mat[(size_t)j * total + li], np.y, kp, sc);
+            apply_segment<B, LOBES>(E, np.x, load_mat(st, total, j, sf), np.y, kp, sc);
         }
         {                                                             // connection segment: F_k's material/prob
             float dist = sqrtf(l2);
@@ -1039,9 +1088,9 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
             apply_segment<B, LOBES>(E, nd, Fm.x, F.w, kp, sc);
         }
         for (int j = kl - 1; j >= 0; --j) {                           // listener-side segments B_j+1 -> B_j
-            const float2 np = st.seg_np[(size_t)j * total + n + li];
+            const float2 np = load_np(st, total, j, sl);
             sd += np.x;
-            apply_segment<B, LOBES>(E, np.x, st.seg_mat[(size_t)j * total + n + li], np.y, kp, sc);
+            apply_segment<B, LOBES>(E, np.x, load_mat(st, total, j, sl), np.y, kp, sc);
         }
         float delay = sd / kp.sound_speed;                            // ARTS.cpp:419
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
@@ -1158,27 +1207,27 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
 // is degenerate or the ratio is not finite and positive.
 // Vertex k of the connected path: 0 = source, 1..i = forward nodes, i+1..t = backward nodes j..1, t+1 = listener.
 struct MisVertex { double x, y, z, nx, ny, nz; };
-__device__ __forceinline__ MisVertex mis_vertex(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t n,
-                                                uint32_t li, int i, int t, int k) {
+__device__ __forceinline__ MisVertex mis_vertex(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t sf,
+                                                uint32_t sl, int i, int t, int k) {
     MisVertex v;
     if (k == 0) { v.x = kp.src[0]; v.y = kp.src[1]; v.z = kp.src[2]; v.nx = v.ny = v.nz = 0.0; return v; }
     if (k == t + 1) { v.x = kp.lis[0]; v.y = kp.lis[1]; v.z = kp.lis[2]; v.nx = v.ny = v.nz = 0.0; return v; }
-    const size_t slot = k <= i ? (size_t)(k - 1) * total + li : (size_t)(t - k) * total + n + li;
-    const float4 q = st.seg_pos[slot], m = st.seg_nrm[slot];
+    const float4 q = k <= i ? load_pos(st, total, k - 1, sf) : load_pos(st, total, t - k, sl);
+    const float4 m = k <= i ? load_nrm(st, total, k - 1, sf) : load_nrm(st, total, t - k, sl);
     v.x = q.x; v.y = q.y; v.z = q.z; v.nx = m.x; v.ny = m.y; v.nz = m.z;
     return v;
 }
-__device__ float mis_weight(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t n, uint32_t li, int i,
+__device__ float mis_weight(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t sf, uint32_t sl, int i,
                             int j) {
-    const int t = i + j, D = kp.depth;
+    const int t = i + j, D = kp.mis_depth;
     const int lo = t - D > 0 ? t - D : 0, hi = t < D ? t : D;
     const double uniform = 1.0 / (double)(hi - lo + 1);
     if (t <= 0) return (float)uniform;
     const double inv4pi = 1.0 / (4.0 * 3.14159265358979323846), invpi = 1.0 / 3.14159265358979323846;
     double PF = 1.0, T = 0.0, Q = 0.0;
-    MisVertex a = mis_vertex(kp, st, total, n, li, i, t, 0);
+    MisVertex a = mis_vertex(kp, st, total, sf, sl, i, t, 0);
     for (int k = 0; k <= t; ++k) {
-        const MisVertex b = mis_vertex(kp, st, total, n, li, i, t, k + 1);
+        const MisVertex b = mis_vertex(kp, st, total, sf, sl, i, t, k + 1);
         double dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
         const double l2 = dx * dx + dy * dy + dz * dz;
         if (!(l2 > 1e-8)) return (float)uniform;
@@ -1228,8 +1277,9 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
     const uint32_t wave = threadIdx.x >> 6, waves = kBlock / 64;
     unsigned my_deposits = 0, my_tests = 0;
     for (uint32_t li = blockIdx.x * waves + wave; li < n; li += gridDim.x * waves) {
-        const uint2 Fm = st.end_misc[li];
-        const uint2 Lm = st.end_misc[n + li];
+        const uint32_t sf = slot_of(st, li), sl = slot_of(st, n + li);
+        const uint2 Fm = st.end_misc[sf];
+        const uint2 Lm = st.end_misc[sl];
         const int kf = (int)Fm.y, kl = (int)Lm.y;
         const int combos = (kf + 1) * (kl + 1);
         for (int c0 = 0; c0 < combos; c0 += 64) {   // wave-uniform trip count: all lanes share the visibility queries
@@ -1239,12 +1289,12 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             const int i = c / (kl + 1), j = c - i * (kl + 1);
             // node Fi (position, material, probability) and node Bj (position)
             float fx = kp.src[0], fy = kp.src[1], fz = kp.src[2];
-            if (i > 0) { const float4 q = st.seg_pos[(size_t)(i - 1) * total + li]; fx = q.x; fy = q.y; fz = q.z; }
+            if (i > 0) { const float4 q = load_pos(st, total, i - 1, sf); fx = q.x; fy = q.y; fz = q.z; }
             float bx = kp.lis[0], by = kp.lis[1], bz = kp.lis[2];
-            if (j > 0) { const float4 q = st.seg_pos[(size_t)(j - 1) * total + n + li]; bx = q.x; by = q.y; bz = q.z; }
+            if (j > 0) { const float4 q = load_pos(st, total, j - 1, sl); bx = q.x; by = q.y; bz = q.z; }
             uint32_t fmat; float fprob;
-            if (i < kf) { fmat = st.seg_mat[(size_t)i * total + li]; fprob = st.seg_np[(size_t)i * total + li].y; }
-            else { fmat = Fm.x; fprob = st.end_pos[li].w; }
+            if (i < kf) { fmat = load_mat(st, total, i, sf); fprob = load_np(st, total, i, sf).y; }
+            else { fmat = Fm.x; fprob = st.end_pos[sf].w; }
             fmat &= 0xFFFFu;   // a connection vertex scatters diffusely whatever lobe the walk took there later (row f4)
             float dx = bx - fx, dy = by - fy, dz = bz - fz;
             float l2 = dx * dx + dy * dy + dz * dz;
@@ -1261,9 +1311,9 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             for (int b = 0; b < B; ++b) E[b] = 1.0f;
             float sd = 0.0f;
             for (int a = 0; a < i; ++a) {                                 // F_a -> F_a+1
-                const float2 np = st.seg_np[(size_t)a * total + li];
+                const float2 np = load_np(st, total, a, sf);
                 sd += np.x;
-                apply_segment<B>(E, np.x, st.seg_mat[(size_t)a * total + li], np.y, kp, sc);
+                apply_segment<B>(E, np.x, load_mat(st, total, a, sf), np.y, kp, sc);
             }
             {                                                             // Fi -> Bj
                 float nd = sqrtf(l2) / kp.dist_divisor;
@@ -1271,16 +1321,16 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
                 apply_segment<B>(E, nd, fmat, fprob, kp, sc);
             }
             for (int a = j - 1; a >= 0; --a) {                            // B_a+1 -> B_a
-                const float2 np = st.seg_np[(size_t)a * total + n + li];
+                const float2 np = load_np(st, total, a, sl);
                 sd += np.x;
-                uint32_t bmat = st.seg_mat[(size_t)a * total + n + li];
+                uint32_t bmat = load_mat(st, total, a, sl);
                 if (a == j - 1) bmat &= 0xFFFFu;                          // Bj is the other connection vertex
                 apply_segment<B>(E, np.x, bmat, np.y, kp, sc);
             }
-            const int t = i + j, D = kp.depth;
+            const int t = i + j, D = kp.mis_depth;
             const int lo_t = t - D > 0 ? t - D : 0, hi_t = t < D ? t : D;
             float w = 1.0f / (float)(hi_t - lo_t + 1);
-            if (kp.mis) w = mis_weight(kp, st, total, n, li, i, j);
+            if (kp.mis) w = mis_weight(kp, st, total, sf, sl, i, j);
             float delay = sd / kp.sound_speed;
             float x = (delay * 1000.f) / 1.0f;
             float fl = floorf(x);

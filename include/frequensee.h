@@ -15,8 +15,9 @@
  * "compute" stream: its own, or the caller's via fs_config.stream); the tail of a frame — a caller's
  * multi-GPU reduce, the reconstruct and the publish of the impulse response — runs on a second stream of
  * the context, concurrently with the next frame's tracing (fs_energy_handoff).  A context is not re-entrant:
- * one producer thread calls compute/reconstruct; any number of threads may read published
- * impulse responses (fs_get_impulse_response) concurrently with the producer.
+ * one producer thread (the game thread) calls compute/reconstruct; concurrently with it any number of threads may
+ * read published impulse responses (fs_get_impulse_response), and ONE audio render thread may run the reverb callback
+ * (fs_reverb_process) — it has a HIP stream of its own and is never queued behind a traced frame.
  *
  * There is no CPU fallback: if no HIP device is usable every compute entry point fails with
  * FS_ERR_NO_DEVICE.
@@ -34,7 +35,9 @@ extern "C" {
 #define FS_ABI_VERSION 3
 #define FS_MAX_BANDS 8
 #define FS_NO_MATERIAL 0xFFFFu /* actor without UAcousticGeometryComponent / Material (ARTS.cpp:383) */
-#define FS_MAX_DEPTH 64        /* hard cap on segments per subpath when depth == 0 ("unbounded") */
+#define FS_MAX_DEPTH 64        /* largest explicit depth cap.  depth == 0 means NO cap, like the reference's while (true)
+                                * (ARTS.cpp:294): a walk ends when the roulette ends it (without roulette, or with
+                                * rr_prob >= 1, depth == 0 means FS_MAX_DEPTH) */
 
 /* status codes (replace the reference's check()/UE_LOG error behaviour) */
 enum {
@@ -46,12 +49,24 @@ enum {
     FS_ERR_BAD_HANDLE = 5,
     FS_ERR_SIZE_MISMATCH = 6, /* UpdateEnergyBuffer's check(Num()==NumBins), FSAC.h:83 */
     FS_ERR_OUT_OF_MEMORY = 7,
-    FS_ERR_COMM = 8           /* multi-GPU: librccl not loadable, an RCCL call failed, or a sharded frame was not reduced */
+    FS_ERR_COMM = 8,          /* multi-GPU: librccl not loadable, an RCCL call failed, or a sharded frame was not reduced */
+    FS_ERR_OVERFLOW = 9       /* depth = 0 only: more walks than provisioned outlived FS_MAX_DEPTH steps; the library has grown
+                               * its record store — trace the frame again (fs_compute_energy_response does so by itself,
+                               * the _async entry points report it at the next fs_synchronize) */
 };
 
 /* compat flags: reproduce a reference quirk literally (default 0 = evident intent) */
 #define FS_FLAG_FIXED_NORM_1000 1u          /* ARTS.cpp:164 normaliser 1/USED_RAY_COUNT whatever NumRays is */
-#define FS_FLAG_FLUSH_BEFORE_RECONSTRUCT 2u /* ARTS.cpp:191 second FlushEnergyBuffer (IR becomes all zero) */
+#define FS_FLAG_FLUSH_BEFORE_RECONSTRUCT 2u /* build-owned: what ARTS.cpp:191 would do if FlushEnergyBuffer zeroed the buffer as its name
+                                             * and comment say (FSAC.h:76-79) — the IR becomes all zero.  At HEAD it does NOT:
+                                             * TArray::SetNumZeroed only zero-fills elements it ADDS, so after the first call
+                                             * both flushes are no-ops; the literal behaviour is FS_FLAG_ACCUMULATE_ENERGY */
+#define FS_FLAG_ACCUMULATE_ENERGY 128u      /* HEAD literally: EnergyBuffer.SetNumZeroed(NumBins) (FSAC.h:78) keeps the old values,
+                                             * so the deposits of every UpdateSource add to those of all earlier ones (the
+                                             * "energy accumulation" the reference's README lists as a known bug).  The frame
+                                             * deposits into the buffer the previous frame of this source used, without clearing it
+                                             * (single-GPU contexts only; with FS_FLAG_DETERMINISTIC the fixed-point histogram
+                                             * accumulates — keep one mode for the whole accumulation) */
 #define FS_FLAG_COSINE_SAMPLING 4u          /* cosine-weighted bounce instead of VRandCone(n, 90 deg) */
 #define FS_FLAG_ALL_CONNECTIONS 16u         /* row f3, the reference's unfinished draft (Is_NaiveConnections, ARTS.cpp:518-546): connect every
                                              * forward prefix F0..Fi with every backward prefix B0..Bj of a pair (visibility test and
@@ -100,7 +115,7 @@ typedef struct fs_params {
     uint64_t seed;             /* counter-based RNG key (replaces the global rand() behind FMath::FRand) */
     uint32_t num_rays;         /* R = source + listener subpaths per frame over all ranks; pairs P = R/2.
                                   reference: NumRays = USED_RAY_COUNT = 1000 pairs = 2000 (ARTS.h:176) */
-    int32_t depth;             /* max segments per subpath; 0 = unbounded like ARTS.cpp:294 (capped at FS_MAX_DEPTH) */
+    int32_t depth;             /* max segments per subpath, 1..FS_MAX_DEPTH; 0 = unbounded like ARTS.cpp:294 */
     int32_t russian_roulette;  /* 1 = ARTS.cpp:300-301 */
     float rr_prob;             /* 0.9       ARTS.cpp:282 */
     float max_trace_dist;      /* 1e6 cm    ARTS.cpp:284 */
@@ -309,7 +324,10 @@ int fs_save_impulse_response(fs_context* ctx, fs_source src, int32_t channel, co
  *      Private/FrequenSeeAudioReverbPlugin.cpp.  The source's most recent impulse response is used on the device. */
 #define FS_REVERB_LITERAL_TAIL 1u /* RVB.cpp:147-148 literally: the interleaved buffer's first `frame` floats feed both channels */
 int fs_reverb_init(fs_context* ctx, fs_source src, int32_t frame_size /* BufferLength, 1024 */);
-/* in/out: interleaved stereo [frame_size * 2]; apply_reverb == 0 is the bApplyReverb bypass (memcpy, RVB.cpp:128-132) */
+/* in/out: interleaved stereo [frame_size * 2]; apply_reverb == 0 is the bApplyReverb bypass (memcpy, RVB.cpp:128-132).
+ * Audio-thread safe: runs on the context's reverb stream, reads the source's newest device-resident IR behind the
+ * reconstruct that wrote it (events, exchanged under a per-source mutex held only while work is enqueued) and waits for
+ * its own stream only.  fs_reverb_init / fs_reverb_release of a source must not run concurrently with its callback. */
 int fs_reverb_process(fs_context* ctx, fs_source src, const float* in, float* out, int32_t apply_reverb, uint32_t flags);
 int fs_reverb_release(fs_context* ctx, fs_source src); /* OnReleaseSource: ClearBuffers */
 

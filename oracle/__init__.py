@@ -25,6 +25,7 @@ FLAG_BRUTE_FORCE = 8
 FLAG_ALL_CONNECTIONS = 16
 FLAG_MIS_BALANCE = 32
 FLAG_MATERIAL_LOBES = 64
+FLAG_ACCUMULATE_ENERGY = 128
 LOBE_DIFFUSE, LOBE_SPECULAR, LOBE_TRANSMIT = 0, 1, 2
 LOBE_SHIFT = 16
 
@@ -192,6 +193,16 @@ def load(path: str | None = None):
     return _lib
 
 
+def load_dpos():
+    """The double-position build (-DFSO_DOUBLE_POSITIONS, oracle/Makefile target dpos): node positions, hit points and
+    segment lengths in double like the reference's FVector.  Only Scene.compute_energy* may be used with it (the Node
+    layout differs); it exists to MEASURE the deviation of the float positions (tests/test_double_positions.py)."""
+    so = os.path.join(_HERE, "libfs_oracle_dpos.so")
+    if not os.path.exists(so):
+        build()
+    return _bind(C.CDLL(so))
+
+
 def _vec3(v):
     return (C.c_float * 3)(*[float(x) for x in v])
 
@@ -284,12 +295,17 @@ class Scene:
         return np.array(list(gains)[: self.B], dtype=np.float32), float(delay.value)
 
     # --- frame --------------------------------------------------------------------------------
-    def compute_energy(self, params, src, lis, pair_begin=0, pair_end=None, num_bins=1000, want_f64=True):
-        """UpdateSource up to the deposit (ARTS.cpp:128-173) for pairs [pair_begin, pair_end)."""
+    def compute_energy(self, params, src, lis, pair_begin=0, pair_end=None, num_bins=1000, want_f64=True, into=None):
+        """UpdateSource up to the deposit (ARTS.cpp:128-173) for pairs [pair_begin, pair_end).
+        into = (e32, e64) of an earlier frame: with FLAG_ACCUMULATE_ENERGY the deposits add to them (HEAD's behaviour)."""
         if pair_end is None:
             pair_end = params.num_pairs
-        e32 = np.zeros((self.B, num_bins), dtype=np.float32)
-        e64 = np.zeros((self.B, num_bins), dtype=np.float64) if want_f64 else None
+        if into is not None:
+            e32, e64 = into
+            assert e32.dtype == np.float32 and e32.flags.c_contiguous and e64.dtype == np.float64 and e64.flags.c_contiguous
+        else:
+            e32 = np.zeros((self.B, num_bins), dtype=np.float32)
+            e64 = np.zeros((self.B, num_bins), dtype=np.float64) if want_f64 else None
         c = Counters()
         self.lib.fso_compute_energy(self.h, C.byref(params), _vec3(src), _vec3(lis), pair_begin, pair_end, num_bins,
                                     e32.ctypes.data, e64.ctypes.data if want_f64 else None, C.byref(c))

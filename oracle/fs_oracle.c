@@ -526,10 +526,23 @@ int32_t fso_trace_any(const fso_scene* s, const float o[3], const float d[3], fl
 /* ------------------------------------------------------------------------------------------- */
 /* GeneratePath  ARTS.cpp:279-355                                                              */
 /* ------------------------------------------------------------------------------------------- */
-int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair, uint32_t side,
-                          const float start[3], fso_node* nodes, int32_t max_nodes, fso_counters* c) {
+/* depth cap of one subpath: the explicit one, or none at all (the reference's while (true), ARTS.cpp:294) — the
+ * roulette ends such a walk with probability 1.  Without roulette an uncapped walk would never end: 64 then. */
+static int32_t depth_cap(const fso_params* p) {
+    if (p->depth > 0) return p->depth;
+    if (p->russian_roulette && p->rr_prob < 1.0f) return INT32_MAX;
+    return FSO_MAX_DEPTH;
+}
+
+/* The walk.  Nodes go to *nodes (capacity *cap); grow != 0: the buffer is realloc'ed as needed, else the walk is cut
+ * at the capacity. */
+static int32_t generate_path(const fso_scene* s, const fso_params* p, uint32_t pair, uint32_t side,
+                             const float start[3], fso_node** nodes_io, int32_t* cap_io, int grow, fso_counters* c) {
+    fso_node* nodes = *nodes_io;
+    int32_t max_nodes = *cap_io;
+    const int32_t cap = depth_cap(p);
     /* state variables ARTS.cpp:287-291 */
-    float pos[3] = {start[0], start[1], start[2]};
+    fso_pos_t pos[3] = {start[0], start[1], start[2]};
     float nrm[3] = {0.f, 0.f, 0.f};
     uint32_t mat = FSO_NO_MATERIAL;
     float prob = 1.0f;
@@ -547,13 +560,18 @@ int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair
     int32_t n = 0;
     for (uint32_t k = 0;; ++k) {
         /* 0. push node ARTS.cpp:296-297 */
-        if (n >= max_nodes) break;
+        if (n >= max_nodes) {
+            if (!grow) break;
+            max_nodes *= 2;
+            nodes = (fso_node*)realloc(nodes, sizeof(fso_node) * (size_t)max_nodes);
+            *nodes_io = nodes; *cap_io = max_nodes;
+        }
         fso_node* nd = &nodes[n++];
         memcpy(nd->pos, pos, sizeof(pos)); memcpy(nd->normal, nrm, sizeof(nrm));
         nd->material = mat; nd->prob = prob;
         if (c) c->path_nodes++;
         /* depth cap (build parameter; the reference loop is unbounded, quirk A.6-i) */
-        if ((int32_t)k >= (p->depth > 0 ? p->depth : FSO_MAX_DEPTH)) break;
+        if ((int32_t)k >= cap) break;
         /* 1. Russian roulette ARTS.cpp:300-301 */
         uint32_t r[4];
         fso_draw(p->seed, pair, side, k, 0, r);
@@ -595,18 +613,23 @@ int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair
             if (pick) prob = prob * plobe;
             if (lobe == FSO_LOBE_TRANSMIT) {
                 float back = -2.0f * p->surface_offset;
-                for (int q = 0; q < 3; ++q) org[q] = fmaf(back, nrm[q], pos[q]);
+                for (int q = 0; q < 3; ++q) org[q] = fmaf(back, nrm[q], (float)pos[q]);
                 shifted = 1;
             }
         }
         /* 3. closest hit on [pos, pos + dir * MAX_RAYCAST_DIST] ARTS.cpp:339-342 */
         float t, hn[3]; int32_t tri;
-        if (!shifted) memcpy(org, pos, sizeof(org));
+        if (!shifted) for (int q = 0; q < 3; ++q) org[q] = (float)pos[q];
         if (fso_trace_closest(s, org, dir, p->max_trace_dist, brute, &t, &tri, hn, c)) {
             /* 4. ARTS.cpp:345-347 */
             for (int q = 0; q < 3; ++q) {
+#ifdef FSO_DOUBLE_POSITIONS   /* Hit.ImpactPoint + Hit.ImpactNormal * 0.1f in FVector (double) arithmetic */
+                double ip = (shifted ? (double)org[q] : pos[q]) + (double)t * (double)dir[q];
+                pos[q] = ip + (double)p->surface_offset * (double)hn[q];
+#else
                 float ip = fmaf(t, dir[q], org[q]);
                 pos[q] = fmaf(p->surface_offset, hn[q], ip);
+#endif
                 nrm[q] = hn[q];
                 din[q] = dir[q];
             }
@@ -621,23 +644,33 @@ int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair
     return n;
 }
 
+int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair, uint32_t side,
+                          const float start[3], fso_node* nodes, int32_t max_nodes, fso_counters* c) {
+    return generate_path(s, p, pair, side, start, &nodes, &max_nodes, 0, c);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* ConnectSubpaths  ARTS.cpp:235-277  — visible iff the line trace does NOT hit                */
 /* ------------------------------------------------------------------------------------------- */
 int32_t fso_connect(const fso_scene* s, const fso_params* p, const fso_node* f, const fso_node* b,
                     fso_counters* c) {
-    float dx = b->pos[0] - f->pos[0], dy = b->pos[1] - f->pos[1], dz = b->pos[2] - f->pos[2];
-    float l2 = dx * dx + dy * dy + dz * dz;
+    fso_pos_t dx = b->pos[0] - f->pos[0], dy = b->pos[1] - f->pos[1], dz = b->pos[2] - f->pos[2];
+    fso_pos_t l2 = dx * dx + dy * dy + dz * dz;
     if (!(l2 > 1e-8f)) { /* GetSafeNormal() == 0: zero-length trace, nothing to hit */
         if (c) c->any_rays++;
         return 1;
     }
+#ifdef FSO_DOUBLE_POSITIONS
+    double len = sqrt(l2), inv = 1.0 / len;
+#else
     float len = sqrtf(l2);
     float inv = 1.0f / len;
-    float d[3] = {dx * inv, dy * inv, dz * inv};
-    float tmax = len - p->connect_pullback; /* End = B - 0.1 * unit(B - F), ARTS.cpp:253 */
+#endif
+    float d[3] = {(float)(dx * inv), (float)(dy * inv), (float)(dz * inv)};
+    float tmax = (float)(len - p->connect_pullback); /* End = B - 0.1 * unit(B - F), ARTS.cpp:253 */
     if (!(tmax > 0.0f)) { if (c) c->any_rays++; return 1; }
-    return !fso_trace_any(s, f->pos, d, tmax, (p->flags & FSO_FLAG_BRUTE_FORCE) != 0, c);
+    const float o[3] = {(float)f->pos[0], (float)f->pos[1], (float)f->pos[2]};
+    return !fso_trace_any(s, o, d, tmax, (p->flags & FSO_FLAG_BRUTE_FORCE) != 0, c);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -651,9 +684,14 @@ void fso_evaluate_path(const fso_scene* s, const fso_params* p, const fso_node* 
     for (int b = 0; b < B; ++b) E[b] = 1.0f;    /* Energy ARTS.cpp:365 */
     for (int i = 0; i < n - 1; ++i) {
         const fso_node* a = &nodes[i]; const fso_node* q = &nodes[i + 1];
+#ifdef FSO_DOUBLE_POSITIONS   /* FVector::Dist(...) / 1000.f: a double, narrowed by the assignment to float NodeDistance */
+        double dx = q->pos[0] - a->pos[0], dy = q->pos[1] - a->pos[1], dz = q->pos[2] - a->pos[2];
+        float nd = (float)(sqrt(dx * dx + dy * dy + dz * dz) / (double)p->dist_divisor);
+#else
         float dx = q->pos[0] - a->pos[0], dy = q->pos[1] - a->pos[1], dz = q->pos[2] - a->pos[2];
         float dist = sqrtf(dx * dx + dy * dy + dz * dz);     /* FVector::Dist ARTS.cpp:372 */
         float nd = dist / p->dist_divisor;                    /* ARTS.cpp:373 */
+#endif
         scaled += nd;                                         /* ARTS.cpp:374 */
         if (nd < p->min_seg) continue;                        /* ARTS.cpp:375-378 */
         float nd2 = nd * nd;
@@ -774,18 +812,21 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
                         uint32_t pair_begin, uint32_t pair_end, int32_t num_bins, float* energy_f32,
                         double* energy_f64, fso_counters* c) {
     int B = s->B;
-    int32_t max_nodes = (p->depth > 0 ? p->depth : FSO_MAX_DEPTH) + 1;
-    fso_node* fwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes);
-    fso_node* bwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes);
-    fso_node* all = (fso_node*)malloc(sizeof(fso_node) * (size_t)max_nodes * 2);
-    /* FlushEnergyBuffer ARTS.cpp:157-161 */
-    memset(energy_f32, 0, sizeof(float) * (size_t)B * (size_t)num_bins);
-    if (energy_f64) memset(energy_f64, 0, sizeof(double) * (size_t)B * (size_t)num_bins);
+    int32_t cap_f = (p->depth > 0 ? p->depth : FSO_MAX_DEPTH) + 1, cap_b = cap_f, cap_all = 2 * cap_f;
+    fso_node* fwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)cap_f);      /* grown as needed: depth 0 has no cap */
+    fso_node* bwd = (fso_node*)malloc(sizeof(fso_node) * (size_t)cap_b);
+    fso_node* all = (fso_node*)malloc(sizeof(fso_node) * (size_t)cap_all);
+    /* FlushEnergyBuffer ARTS.cpp:157-161 (a no-op at HEAD after the first call: FSO_FLAG_ACCUMULATE_ENERGY) */
+    if (!(p->flags & FSO_FLAG_ACCUMULATE_ENERGY)) {
+        memset(energy_f32, 0, sizeof(float) * (size_t)B * (size_t)num_bins);
+        if (energy_f64) memset(energy_f64, 0, sizeof(double) * (size_t)B * (size_t)num_bins);
+    }
     /* NormalizationFactor ARTS.cpp:164 (quirk A.6-c: literally 1/1000) */
     float norm = (p->flags & FSO_FLAG_FIXED_NORM_1000) ? 1.0f / 1000.0f : 1.0f / (float)p->num_pairs;
     for (uint32_t i = pair_begin; i < pair_end; ++i) {     /* GenerateFullPaths ARTS.cpp:215-230 */
-        int32_t nf = fso_generate_path(s, p, i, 0, src, fwd, max_nodes, c);
-        int32_t nb = fso_generate_path(s, p, i, 1, lis, bwd, max_nodes, c);
+        int32_t nf = generate_path(s, p, i, 0, src, &fwd, &cap_f, 1, c);
+        int32_t nb = generate_path(s, p, i, 1, lis, &bwd, &cap_b, 1, c);
+        if (nf + nb > cap_all) { cap_all = 2 * (nf + nb); all = (fso_node*)realloc(all, sizeof(fso_node) * (size_t)cap_all); }
         if (nf == 0 || nb == 0) continue;                  /* ARTS.cpp:237 */
         if (p->flags & (FSO_FLAG_ALL_CONNECTIONS | FSO_FLAG_MIS_BALANCE)) {
             /* Row f3 — the reference's unfinished "naive connections" draft (Is_NaiveConnections, ARTS.cpp:518-546:
@@ -795,7 +836,7 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
              * F0..Fi, Bj..B0.  Several (i, j) produce paths with the same number of segments i + j + 1; they are
              * combined with uniform multiple-importance weights 1 / N(i + j), N(t) = number of (i', j') in
              * [0, D]^2 with i' + j' = t (D = depth cap) — the weights of one path length sum to 1. */
-            int32_t D = p->depth > 0 ? p->depth : FSO_MAX_DEPTH;
+            int32_t D = p->depth > 0 ? p->depth : (depth_cap(p) == INT32_MAX ? FSO_UNBOUNDED_DEPTH : FSO_MAX_DEPTH);
             for (int32_t fi = 0; fi < nf; ++fi)
                 for (int32_t bj = 0; bj < nb; ++bj) {
                     if (!fso_connect(s, p, &fwd[fi], &bwd[bj], c)) continue;

@@ -1,0 +1,37 @@
+"""How much do float positions cost?  The reference's node positions are UE5 FVector = double
+(Public/AudioRayTracingSubsystem.h:61); EvaluatePath narrows when it divides FVector::Dist by 1000.f
+(Private/AudioRayTracingSubsystem.cpp:372-373).  Oracle and kernels keep positions in fp32 from the start (SURVEY.md 8a,
+row a10).  The -DFSO_DOUBLE_POSITIONS build of the oracle keeps node positions, hit points and segment lengths in
+double; this test MEASURES the deviation of the fp32 build against it and fails if it ever approaches the parity bar
+(1e-3 relative RMS per band).  The numbers are quoted in DESIGN.md section 4."""
+import numpy as np
+
+
+def rel_rms(a, ref):
+    den = np.sqrt(np.mean(ref ** 2))
+    return float(np.sqrt(np.mean((a - ref) ** 2)) / max(den, 1e-300))
+
+
+def compare(pkg, oracle_mod, scene, bands, pairs, depth, scale=1.0, offset=0.0):
+    sc = pkg.scenes.by_name(scene, bands)
+    tri = (sc.triangles.astype(np.float64) * scale + offset).astype(np.float32)
+    src = (np.asarray(sc.source, np.float64) * scale + offset).astype(np.float32)
+    lis = (np.asarray(sc.listener, np.float64) * scale + offset).astype(np.float32)
+    dlib = oracle_mod.load_dpos()
+    p = oracle_mod.default_params(num_pairs=pairs, depth=depth, seed=0x5EED)
+    e32f, e64f, cf = oracle_mod.Scene(tri, sc.material_ids, sc.absorption).compute_energy_mt(p, src, lis, threads=8)
+    e32d, e64d, cd = oracle_mod.Scene(tri, sc.material_ids, sc.absorption, lib=dlib).compute_energy_mt(p, src, lis, threads=8)
+    rms = max(rel_rms(e64f[b], e64d[b]) for b in range(bands))
+    moved = int(((e64f != 0) != (e64d != 0)).sum())
+    return {"rel_rms": rms, "bins_differ": moved, "connected_f32": int(cf.connected), "connected_f64": int(cd.connected),
+            "segments_f32": int(cf.closest_rays), "segments_f64": int(cd.closest_rays)}
+
+
+def test_float_positions_stay_far_below_the_parity_bar(pkg, oracle_mod):
+    r = compare(pkg, oracle_mod, "starter_room", 4, 8192, 8)
+    print("starter_room:", r)
+    assert r["rel_rms"] < 2e-4 and r["segments_f32"] == r["segments_f64"]
+    # the same room 40 km from the origin: fp32 positions carry ~0.25 cm of rounding there
+    far = compare(pkg, oracle_mod, "starter_room", 4, 8192, 8, offset=4.0e6)
+    print("starter_room + 40 km:", far)
+    assert far["segments_f32"] == far["segments_f64"]

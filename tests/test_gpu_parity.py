@@ -671,6 +671,65 @@ def test_tail_stream_overlap_and_handoff(pkg, oracle_mod, scene_factory):
     ref_ctx.close()
 
 
+def test_unbounded_depth_walks_until_the_roulette_ends(pkg, oracle_mod, scene_factory, monkeypatch):
+    """depth = 0 is the reference's while (true) (ARTS.cpp:294): a walk ends only when the roulette ends it.  At 65 536
+    rays ~77 subpaths take more than FS_MAX_DEPTH = 64 steps (0.9^64); their later records live in the second tier.
+    Oracle parity incl. the work counters, also for the all-connections weights (depth cap D = infinity); and a tier
+    provisioned too small is grown and the frame traced again (FS_ERR_OVERFLOW on the async path)."""
+    sc = scene_factory("starter_room", 4)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx, src = make_ctx(pkg, sc)
+    for rays, flags in ((65536, 0), (2000, 0), (512, 16), (512, 32)):
+        ctx.reset_stats()
+        e = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=0, seed=rays, flags=flags))
+        st = ctx.stats()
+        e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=0, seed=rays, flags=flags),
+                                           sc.source, sc.listener)
+        check_energy(e, e32, e64, 4)
+        assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+        if rays == 65536:
+            assert cnt.closest_rays > 9.0 * rays * 0.98          # mean walk length 9 (not 8.99 capped at 64)
+    ctx.close()
+    # a second tier of ONE slot cannot hold the ~77 long walks of this frame
+    monkeypatch.setenv("FS_OVER_CAP", "1")
+    ctx, src = make_ctx(pkg, sc)
+    p = pkg.default_params(num_rays=65536, depth=0, seed=65536)
+    ctx.compute_energy_response_async(src, p)
+    with pytest.raises(pkg.FrequenSeeError) as ei:
+        ctx.synchronize()
+    assert ei.value.code == pkg._capi.ERR_OVERFLOW
+    e = ctx.compute_energy_response(src, p)                  # the synchronous entry point retraces by itself
+    e32, e64, _ = osc.compute_energy(oracle_mod.default_params(num_pairs=32768, depth=0, seed=65536), sc.source, sc.listener)
+    check_energy(e, e32, e64, 4)
+    ctx.close()
+
+
+def test_accumulate_energy_like_head(pkg, oracle_mod, scene_factory):
+    """FS_FLAG_ACCUMULATE_ENERGY: at HEAD FlushEnergyBuffer is EnergyBuffer.SetNumZeroed(NumBins) (FSAC.h:76-79), which
+    keeps existing values — every UpdateSource adds to the energy of all earlier ones.  Three frames with the flag equal
+    the oracle's accumulated buffer; a frame without it starts from zero again."""
+    sc = scene_factory("starter_room", 4)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx, src = make_ctx(pkg, sc)
+    acc = None
+    for f in range(3):
+        e = ctx.compute_energy_response(src, pkg.default_params(num_rays=8192, depth=8, seed=40 + f, flags=128))
+        op = oracle_mod.default_params(num_pairs=4096, depth=8, seed=40 + f, flags=128 if f else 0)
+        acc = osc.compute_energy(op, sc.source, sc.listener, into=acc[:2] if acc else None)
+        assert np.array_equal(e != 0, acc[0] != 0)
+        assert max(rel_rms(e[b], acc[1][b]) for b in range(4)) <= TIGHT_TOL
+        ctx.reconstruct_impulse_response(src)
+    single = ctx.compute_energy_response(src, pkg.default_params(num_rays=8192, depth=8, seed=40))
+    e32, e64, _ = osc.compute_energy(oracle_mod.default_params(num_pairs=4096, depth=8, seed=40), sc.source, sc.listener)
+    check_energy(single, e32, e64, 4)
+    ctx.close()
+    ctx, src = make_ctx(pkg, sc, rank=0, world_size=2)
+    with pytest.raises(pkg.FrequenSeeError) as ei:
+        ctx.compute_energy_response(src, pkg.default_params(num_rays=8192, depth=8, flags=128))
+    assert ei.value.code == pkg._capi.ERR_INVALID_ARGUMENT
+    ctx.close()
+
+
 def test_library_collective_one_rank(pkg, oracle_mod, scene_factory):
     """The RCCL all-reduce lives behind the C ABI (fs_comm_init): with a one-rank communicator attached every frame
     runs the library's collective on the tail stream — a sum over one rank — and the scene goes through the broadcast
