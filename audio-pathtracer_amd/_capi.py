@@ -47,7 +47,7 @@ EXPORTS = [
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
     "fs_apply_material_fd", "fs_energy_handoff", "fs_scene_update_triangles", "fs_scene_refit", "fs_set_impulse_response",
-    "fs_comm_unique_id", "fs_comm_init", "fs_comm_attach", "fs_comm_detach", "fs_shard_range",
+    "fs_scene_commit_fast", "fs_comm_unique_id", "fs_comm_init", "fs_comm_attach", "fs_comm_detach", "fs_shard_range",
 ]
 COMM_ID_BYTES = 128
 ERR_COMM = 8
@@ -179,6 +179,7 @@ def load():
         "fs_scene_set_triangles": (C.c_int, [vp, f32p, u16p, i32]),
         "fs_scene_set_materials": (C.c_int, [vp, f32p, f32p, f32p, i32, i32]),
         "fs_scene_commit": (C.c_int, [vp]),
+        "fs_scene_commit_fast": (C.c_int, [vp]),
         "fs_source_create": (C.c_int, [vp, C.POINTER(i32)]),
         "fs_source_destroy": (C.c_int, [vp, i32]),
         "fs_source_set_position": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),

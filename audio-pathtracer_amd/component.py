@@ -82,7 +82,8 @@ class Context:
         self.check(self.lib.fs_comm_detach(self.h))
 
     # ---- scene ----
-    def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None, object_ids=None):
+    def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None, object_ids=None, fast=False):
+        """fast = True: the acceleration structure is built on the device (fs_scene_commit_fast)"""
         tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
         mat = np.ascontiguousarray(material_ids, dtype=np.uint16).reshape(-1)
         if mat.shape[0] != tri.shape[0]:
@@ -103,7 +104,7 @@ class Context:
             self.check(self.lib.fs_scene_set_objects(self.h, obj.ctypes.data, obj.shape[0]))
         else:
             self.check(self.lib.fs_scene_set_objects(self.h, None, tri.shape[0]))
-        self.check(self.lib.fs_scene_commit(self.h))
+        self.check((self.lib.fs_scene_commit_fast if fast else self.lib.fs_scene_commit)(self.h))
 
     def update_triangles(self, first, triangles):
         """move committed triangles [first, first + n) (row f4: dynamic props); the refit runs before the next trace"""

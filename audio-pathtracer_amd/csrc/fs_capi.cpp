@@ -101,6 +101,9 @@ struct fs_context {
     float* d_move = nullptr;          // staging for moved triangles
     size_t move_cap = 0;              // in triangles
     float amax = 0.f;                 // largest |coordinate| seen (sets the box padding)
+    char* d_build = nullptr;          // fs_scene_commit_fast: device copies of the inputs + build scratch (grow-only)
+    size_t build_cap = 0;
+    size_t fast_cap_tris = 0;         // triangles the scene arrays of the last fast commit have room for (0: not reusable)
     bool refit_pending = false;
     DeviceScene scene{};
     // ApplyMaterialFD work buffers (row f4), sized for the largest block seen
@@ -566,6 +569,7 @@ int fs_context_destroy(fs_context* ctx) {
         if (ctx->fft_graph) (void)hipGraphExecDestroy(ctx->fft_graph);
         if (ctx->h_fft_stage) (void)hipHostFree(ctx->h_fft_stage);
         if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+        if (ctx->d_build) (void)hipFree(ctx->d_build);
         if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
         for (hipEvent_t e : ctx->ev_batch) if (e) (void)hipEventDestroy(e);
     }
@@ -778,12 +782,76 @@ int fs_scene_set_materials(fs_context* ctx, const float* absorption, const float
     return FS_OK;
 }
 
+// the material table of a committed scene: absorption [M][B] | lobe gains [M][3][B] | lobe probabilities [M][3]
+static int upload_materials(fs_context* ctx) {
+    const size_t mb = ctx->h_absorption.size() * sizeof(float);
+    if (mb) {
+        // absorption [M][B] | lobe gains [M][3][B] | lobe probabilities [M][3] (FS_FLAG_MATERIAL_LOBES).  The split is
+        // the per-bin rule of ApplyMaterialFD (MaterialAcousticProcessor.cpp:51-72) per band: Refl = 1 - alpha, tau
+        // clamped to Refl + tau <= 1, diffuse Refl sigma, specular Refl (1 - sigma), transmitted tau; a lobe is
+        // picked with the band mean of its gain over the sum of the three.  No arrays: tau = 0, sigma = 1.
+        const int B = ctx->cfg.num_bands, M = ctx->M;
+        std::vector<float> table(ctx->h_absorption);
+        table.resize((size_t)M * B + (size_t)M * 3 * B + (size_t)M * 3, 0.f);
+        float* gain = table.data() + (size_t)M * B;
+        float* prob = gain + (size_t)M * 3 * B;
+        const bool has_t = ctx->h_transmission.size() == (size_t)M * B, has_s = ctx->h_scattering.size() == (size_t)M * B;
+        for (int m = 0; m < M; ++m) {
+            float sum[3] = {0.f, 0.f, 0.f};
+            for (int b = 0; b < B; ++b) {
+                const float alpha = ctx->h_absorption[(size_t)m * B + b];
+                float tau = has_t ? ctx->h_transmission[(size_t)m * B + b] : 0.0f;
+                const float sigma = has_s ? ctx->h_scattering[(size_t)m * B + b] : 1.0f;
+                const float refl = 1.0f - alpha;
+                if (refl + tau > 1.0f) tau = 1.0f - refl;
+                float g[3] = {refl * sigma, refl * (1.0f - sigma), tau};
+                for (int l = 0; l < 3; ++l) {
+                    if (!(g[l] > 0.0f)) g[l] = 0.0f;
+                    gain[((size_t)m * 3 + l) * B + b] = g[l];
+                    sum[l] += g[l];
+                }
+            }
+            float mean[3], tot = 0.0f;
+            for (int l = 0; l < 3; ++l) { mean[l] = sum[l] / (float)B; tot += mean[l]; }
+            for (int l = 0; l < 3; ++l) prob[(size_t)m * 3 + l] = tot > 0.0f ? mean[l] / tot : (l == 0 ? 1.0f : 0.0f);
+        }
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_absorption, table.size() * sizeof(float)));
+        FS_HIP(ctx, hipMemcpy(ctx->d_absorption, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return FS_OK;
+}
+
+// what every kind of commit ends with: the kernels' view of the scene and the stats
+static void finish_commit(fs_context* ctx, size_t scene_bytes) {
+    ctx->amax = 0.f;
+    for (float v : ctx->h_xyz) ctx->amax = std::max(ctx->amax, std::fabs(v));
+    ctx->scene.nodes = ctx->d_nodes;
+    ctx->scene.tris = ctx->d_tris;
+    ctx->scene.absorption = ctx->d_absorption;
+    ctx->scene.lobe_gain = ctx->d_absorption ? ctx->d_absorption + (size_t)ctx->M * ctx->cfg.num_bands : nullptr;
+    ctx->scene.lobe_prob = ctx->d_absorption ? ctx->scene.lobe_gain + (size_t)ctx->M * 3 * ctx->cfg.num_bands : nullptr;
+    ctx->scene.num_nodes = (int32_t)ctx->bvh.nodes.size();
+    ctx->scene.num_tris = ctx->T;
+    ctx->scene.num_materials = ctx->M;
+    ctx->scene.stack_rows = std::max(ctx->bvh.stack_need, 2) + kStackSlack;
+#ifdef FS_EXPERIMENTS   // occupancy experiments only: fewer rows than the tree's worst case (an overflowing lane corrupts the share area)
+    if (const char* v = std::getenv("FS_UNSAFE_STACK_ROWS")) ctx->scene.stack_rows = std::max(4, std::atoi(v));
+#endif
+    ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
+    ctx->stats.triangles = (uint32_t)ctx->T;
+    ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;
+    ctx->stats.bvh_depth = (uint32_t)ctx->bvh.max_depth;
+    ctx->stats.scene_bytes = scene_bytes;
+    ctx->committed = true;
+}
+
 int fs_scene_commit(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
+    ctx->fast_cap_tris = 0;
     // With a communicator attached rank 0 alone builds the acceleration structure and broadcasts it; the
     // other ranks only hold the triangles for later fs_scene_update_triangles bookkeeping.
     RcclApi* ra = ctx->comm ? rccl() : nullptr;
@@ -841,39 +909,7 @@ int fs_scene_commit(fs_context* ctx) {
         if (bcast) FS_NCCL(ctx, ra->Broadcast(ctx->d_tris, ctx->d_tris, tb, ncclUint8, 0, ctx->comm, ctx->stream));
     }
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (mb) {
-        // absorption [M][B] | lobe gains [M][3][B] | lobe probabilities [M][3] (FS_FLAG_MATERIAL_LOBES).  The split is
-        // the per-bin rule of ApplyMaterialFD (MaterialAcousticProcessor.cpp:51-72) per band: Refl = 1 - alpha, tau
-        // clamped to Refl + tau <= 1, diffuse Refl sigma, specular Refl (1 - sigma), transmitted tau; a lobe is
-        // picked with the band mean of its gain over the sum of the three.  No arrays: tau = 0, sigma = 1.
-        const int B = ctx->cfg.num_bands, M = ctx->M;
-        std::vector<float> table(ctx->h_absorption);
-        table.resize((size_t)M * B + (size_t)M * 3 * B + (size_t)M * 3, 0.f);
-        float* gain = table.data() + (size_t)M * B;
-        float* prob = gain + (size_t)M * 3 * B;
-        const bool has_t = ctx->h_transmission.size() == (size_t)M * B, has_s = ctx->h_scattering.size() == (size_t)M * B;
-        for (int m = 0; m < M; ++m) {
-            float sum[3] = {0.f, 0.f, 0.f};
-            for (int b = 0; b < B; ++b) {
-                const float alpha = ctx->h_absorption[(size_t)m * B + b];
-                float tau = has_t ? ctx->h_transmission[(size_t)m * B + b] : 0.0f;
-                const float sigma = has_s ? ctx->h_scattering[(size_t)m * B + b] : 1.0f;
-                const float refl = 1.0f - alpha;
-                if (refl + tau > 1.0f) tau = 1.0f - refl;
-                float g[3] = {refl * sigma, refl * (1.0f - sigma), tau};
-                for (int l = 0; l < 3; ++l) {
-                    if (!(g[l] > 0.0f)) g[l] = 0.0f;
-                    gain[((size_t)m * 3 + l) * B + b] = g[l];
-                    sum[l] += g[l];
-                }
-            }
-            float mean[3], tot = 0.0f;
-            for (int l = 0; l < 3; ++l) { mean[l] = sum[l] / (float)B; tot += mean[l]; }
-            for (int l = 0; l < 3; ++l) prob[(size_t)m * 3 + l] = tot > 0.0f ? mean[l] / tot : (l == 0 ? 1.0f : 0.0f);
-        }
-        FS_HIP(ctx, hipMalloc((void**)&ctx->d_absorption, table.size() * sizeof(float)));
-        FS_HIP(ctx, hipMemcpy(ctx->d_absorption, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
+    { int mr = upload_materials(ctx); if (mr) return mr; }
     if (tb) {   // refit support: leaf positions, level table and the bounds scratch
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_pos, sizeof(uint32_t) * std::max<size_t>(n_leaf, 1)));
         if (root) FS_HIP(ctx, hipMemcpyAsync(ctx->d_leaf_pos, ctx->bvh.leaf_pos.data(), sizeof(uint32_t) * n_leaf,
@@ -894,26 +930,83 @@ int fs_scene_commit(fs_context* ctx) {
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_node_box, sizeof(float4) * 2 * std::max<size_t>(n_nodes, 1)));
     }
-    ctx->amax = 0.f;
-    for (float v : ctx->h_xyz) ctx->amax = std::max(ctx->amax, std::fabs(v));
-    ctx->scene.nodes = ctx->d_nodes;
-    ctx->scene.tris = ctx->d_tris;
-    ctx->scene.absorption = ctx->d_absorption;
-    ctx->scene.lobe_gain = ctx->d_absorption ? ctx->d_absorption + (size_t)ctx->M * ctx->cfg.num_bands : nullptr;
-    ctx->scene.lobe_prob = ctx->d_absorption ? ctx->scene.lobe_gain + (size_t)ctx->M * 3 * ctx->cfg.num_bands : nullptr;
-    ctx->scene.num_nodes = (int32_t)ctx->bvh.nodes.size();
-    ctx->scene.num_tris = ctx->T;
-    ctx->scene.num_materials = ctx->M;
-    ctx->scene.stack_rows = std::max(ctx->bvh.stack_need, 2) + kStackSlack;
-#ifdef FS_EXPERIMENTS   // occupancy experiments only: fewer rows than the tree's worst case (an overflowing lane corrupts the share area)
-    if (const char* v = std::getenv("FS_UNSAFE_STACK_ROWS")) ctx->scene.stack_rows = std::max(4, std::atoi(v));
-#endif
-    ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
-    ctx->stats.triangles = (uint32_t)ctx->T;
-    ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;
-    ctx->stats.bvh_depth = (uint32_t)ctx->bvh.max_depth;
-    ctx->stats.scene_bytes = nb + tb + mb;
-    ctx->committed = true;
+    finish_commit(ctx, nb + tb + mb);
+    return FS_OK;
+}
+
+// RegisterGeometry / UnregisterGeometry at run time (ARTS.h:99-100): a changed triangle set needs a new tree NOW.
+// The whole build runs on the device (fs_build.hip) behind one upload of the triangles; the host only reads back the
+// level table and the stack bound.  Falls back to the host build when the Morton tree comes out too deep.
+int fs_scene_commit_fast(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (ctx->T < 1 || ctx->comm) return fs_scene_commit(ctx);   // empty scene / sharded run: the one build rank 0 broadcasts
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int T = ctx->T;
+    const size_t n = (size_t)T;
+    const bool reuse = ctx->fast_cap_tris >= n && ctx->d_nodes && ctx->d_tris && ctx->d_leaf_pos && ctx->d_node_box;
+    if (!reuse) { free_scene(ctx); ctx->fast_cap_tris = 0; }
+    else {   // keep the four arrays of the previous fast commit, drop the rest of the old scene
+        if (ctx->d_absorption) (void)hipFree(ctx->d_absorption);
+        ctx->d_absorption = nullptr;
+        ctx->refit_pending = false;
+        ctx->committed = false;
+    }
+    // inputs + scratch in one grow-only device block (hipMalloc costs more than the build)
+    const size_t in_bytes = ((sizeof(float) * 9 * n + 255) & ~(size_t)255) + ((sizeof(uint16_t) * n + 255) & ~(size_t)255) +
+                            ((sizeof(uint32_t) * n + 255) & ~(size_t)255) + 256;
+    const size_t scratch_bytes = device_build_scratch_bytes(T);
+    if (in_bytes + scratch_bytes > ctx->build_cap) {
+        if (ctx->d_build) (void)hipFree(ctx->d_build);
+        ctx->d_build = nullptr; ctx->build_cap = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_build, in_bytes + scratch_bytes));
+        ctx->build_cap = in_bytes + scratch_bytes;
+    }
+    char* q = ctx->d_build;
+    float* d_xyz = reinterpret_cast<float*>(q); q += (sizeof(float) * 9 * n + 255) & ~(size_t)255;
+    uint16_t* d_mat = reinterpret_cast<uint16_t*>(q); q += (sizeof(uint16_t) * n + 255) & ~(size_t)255;
+    uint32_t* d_obj = reinterpret_cast<uint32_t*>(q); q += (sizeof(uint32_t) * n + 255) & ~(size_t)255;
+    DeviceBuildInfo* d_info = reinterpret_cast<DeviceBuildInfo*>(q); q += 256 + ((sizeof(DeviceBuildInfo) + 255) & ~(size_t)255);
+    const bool has_obj = ctx->h_obj.size() == n;
+    FS_HIP(ctx, hipMemcpyAsync(d_xyz, ctx->h_xyz.data(), sizeof(float) * 9 * n, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx, hipMemcpyAsync(d_mat, ctx->h_mat.data(), sizeof(uint16_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    if (has_obj) FS_HIP(ctx, hipMemcpyAsync(d_obj, ctx->h_obj.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, amax = 0.f;
+    for (size_t i = 0; i < 9 * n; ++i) {
+        const float v = ctx->h_xyz[i];
+        lo[i % 3] = std::min(lo[i % 3], v); hi[i % 3] = std::max(hi[i % 3], v);
+        amax = std::max(amax, std::fabs(v));
+    }
+    const size_t tb = n * sizeof(Tri64);
+    if (!reuse) {
+        const size_t cap = n + n / 4 + 64;   // room for the next registration
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, cap * sizeof(NodeQ4)));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_tris, cap * sizeof(Tri64)));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_leaf_pos, sizeof(uint32_t) * cap));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_node_box, sizeof(float4) * 2 * cap));
+        ctx->fast_cap_tris = cap;
+    }
+    if (!launch_device_build(d_xyz, d_mat, has_obj ? d_obj : nullptr, T, lo, hi, ctx->d_nodes, ctx->d_tris, ctx->d_leaf_pos, q,
+                             (size_t)(ctx->d_build + ctx->build_cap - q), d_info, ctx->stream))
+        return fs_scene_commit(ctx);
+    FS_HIP(ctx, hipGetLastError());
+    DeviceBuildInfo info{};
+    FS_HIP(ctx, hipMemcpyAsync(&info, d_info, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (info.levels < 1 || info.stack_need > kStackDepth ||
+        traversal_lds_bytes(std::max(info.stack_need, 2) + kStackSlack, ctx->cfg.num_bands, ctx->num_bins) > ctx->lds_limit)
+        return fs_scene_commit(ctx);   // a degenerate Morton tree (deeper than the LDS stack allows): take the host's SAH build
+    ctx->bvh = HostBVH{};
+    ctx->bvh.nodes.resize((size_t)info.num_nodes); ctx->bvh.tris.resize(n);   // sizes only: the records live on the device
+    ctx->bvh.stack_need = info.stack_need;
+    ctx->bvh.max_depth = info.levels;
+    ctx->bvh.pad = std::max(0.01f, amax * 3.8146973e-06f);                     // as fs_bvh.cpp
+    ctx->bvh.level_begin.assign(info.level_begin, info.level_begin + info.levels + 1);
+    launch_refit(ctx->d_nodes, ctx->d_tris, ctx->d_node_box, ctx->bvh.level_begin.data(), info.levels, ctx->bvh.pad, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    { int mr = upload_materials(ctx); if (mr) return mr; }
+    finish_commit(ctx, (size_t)info.num_nodes * sizeof(NodeQ4) + tb + ctx->h_absorption.size() * sizeof(float));
     return FS_OK;
 }
 

@@ -199,6 +199,18 @@ size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins);
 void launch_update_triangles(Tri64* tris, const uint32_t* leaf_pos, int first, int count, const float* xyz, hipStream_t s);
 void launch_refit(NodeQ4* nodes, const Tri64* tris, float4* node_box, const int32_t* level_begin, int levels, float pad,
                   hipStream_t s);
+// fs_build.hip: the acceleration structure built on the device (Morton codes, radix sort, Karras' binary radix tree,
+// breadth-first collapse to 4-wide nodes); launch_refit then derives the quantised boxes.  DeviceBuildInfo is what the
+// host reads back: levels < 0 = the tree is deeper than kMaxBuildLevels or ran out of node space (use the host build).
+constexpr int kMaxBuildLevels = 96;
+struct DeviceBuildInfo {
+    int32_t num_nodes, levels, stack_need, reserved;
+    int32_t level_begin[kMaxBuildLevels + 1];
+};
+size_t device_build_scratch_bytes(int T);
+bool launch_device_build(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int T, const float lo[3],
+                         const float hi[3], NodeQ4* nodes, Tri64* tris, uint32_t* leaf_pos, void* scratch, size_t scratch_bytes,
+                         DeviceBuildInfo* info_dev, hipStream_t s);
 // row f4 (fs_fft.hip): ApplyMaterialFD.  x [N] and y [3][N] complex work buffers, W [N/2] twiddles,
 // resp [3][N/2+1] = absorption | transmission | scattering, out [3][L] = specular | diffuse | transmitted
 constexpr int kFftChunkLog = 11;     // FFT stages with spans below 2^11 points run inside LDS

@@ -25,9 +25,9 @@ def rel_rms(a, ref):
     return float(np.sqrt(np.mean((a - ref) ** 2)) / max(den, 1e-300))
 
 
-def make_ctx(pkg, sc, **kw):
+def make_ctx(pkg, sc, fast=False, **kw):
     ctx = pkg.Context(num_bands=sc.num_bands, **kw)
-    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast=fast)   # fast: the tree is built on the device
     ctx.set_listener(sc.listener)
     src = ctx.create_source(sc.source)
     return ctx, src
@@ -41,10 +41,13 @@ def check_energy(e_gpu, e32, e64, bands):
 
 
 # ---- a10: the engine line trace ---------------------------------------------------------------------------
+@pytest.mark.parametrize("build", ["host_sah", "device_morton"])
 @pytest.mark.parametrize("name", ["shoebox", "starter_room", "old_mine"])
-def test_line_trace_matches_brute_force(pkg, oracle_mod, scene_factory, name):
+def test_line_trace_matches_brute_force(pkg, oracle_mod, scene_factory, name, build):
+    """closest and any hit against the oracle's BRUTE-FORCE scan, for the host-built (binned SAH) and the device-built
+    (Morton / Karras, fs_scene_commit_fast) tree: the answer is a function of ray and triangles only"""
     sc = scene_factory(name)
-    ctx, _ = make_ctx(pkg, sc)
+    ctx, _ = make_ctx(pkg, sc, fast=build == "device_morton")
     osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
     rng = np.random.default_rng(3)
     n = 2000 if name != "old_mine" else 600
@@ -71,8 +74,9 @@ def test_line_trace_matches_brute_force(pkg, oracle_mod, scene_factory, name):
 SOUPS = ["uniform", "slivers", "duplicates", "huge_coordinates", "coplanar_grid", "one_triangle", "tiny_and_big"]
 
 
+@pytest.mark.parametrize("build", ["host_sah", "device_morton"])
 @pytest.mark.parametrize("kind", SOUPS)
-def test_line_trace_fuzz_soups(pkg, oracle_mod, kind):
+def test_line_trace_fuzz_soups(pkg, oracle_mod, kind, build):
     """Random triangle soups that stress the builder and the tests at their edges: needle triangles, exact
     duplicates (ties broken by input index), coordinates around 1e6 cm, a coplanar grid (rays in the plane, rays
     through shared edges and vertices), a single triangle, four orders of magnitude of triangle sizes.  Closest
@@ -113,7 +117,7 @@ def test_line_trace_fuzz_soups(pkg, oracle_mod, kind):
     mat = np.zeros(T, np.uint16)
     absorption = np.full((1, 1), 0.5, np.float32)
     ctx = pkg.Context(num_bands=1)
-    ctx.set_scene(tri, mat, absorption)
+    ctx.set_scene(tri, mat, absorption, fast=build == "device_morton")
     osc = oracle_mod.Scene(tri, mat, absorption)
     lo, hi = tri.min(axis=(0, 1)).astype(np.float64), tri.max(axis=(0, 1)).astype(np.float64)
     ext = np.maximum(hi - lo, 1.0)
@@ -727,6 +731,47 @@ def test_accumulate_energy_like_head(pkg, oracle_mod, scene_factory):
     with pytest.raises(pkg.FrequenSeeError) as ei:
         ctx.compute_energy_response(src, pkg.default_params(num_rays=8192, depth=8, flags=128))
     assert ei.value.code == pkg._capi.ERR_INVALID_ARGUMENT
+    ctx.close()
+
+
+def test_device_built_tree_gives_the_same_frames(pkg, oracle_mod, scene_factory):
+    """fs_scene_commit_fast (RegisterGeometry / UnregisterGeometry at run time, ARTS.h:99-100): the tree is built on
+    the device.  The set of paths does not depend on the tree: energy bins, counters and the IR equal the oracle's and
+    the host-built tree's; a registration change (triangles added, then removed) is a fresh fast commit; moving
+    geometry refits the device-built tree like the host-built one."""
+    sc = scene_factory("starter_room", 4)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    p = pkg.default_params(num_rays=16384, depth=8, seed=31)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=8192, depth=8, seed=31), sc.source, sc.listener)
+    ctx, src = make_ctx(pkg, sc, fast=True)
+    st = ctx.stats()
+    assert st["triangles"] == sc.num_triangles and 0 < st["bvh_stack_need"] <= 64 and st["bvh_nodes"] > sc.num_triangles // 8
+    ctx.reset_stats()
+    e = ctx.compute_energy_response(src, p)
+    check_energy(e, e32, e64, 4)
+    st = ctx.stats()
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+    # an actor registers (a slab in the middle of the room), then unregisters again
+    slab = np.array([[[900, 300, 0], [1100, 300, 0], [1100, 300, 380]], [[900, 300, 0], [1100, 300, 380], [900, 300, 380]]], np.float32)
+    tri2 = np.concatenate([sc.triangles, slab]).astype(np.float32)
+    mat2 = np.concatenate([sc.material_ids, np.zeros(2, np.uint16)])
+    ctx.set_scene(tri2, mat2, sc.absorption, fast=True)
+    e2 = ctx.compute_energy_response(src, p)
+    o2 = oracle_mod.Scene(tri2, mat2, sc.absorption).compute_energy(oracle_mod.default_params(num_pairs=8192, depth=8, seed=31),
+                                                                    sc.source, sc.listener)
+    check_energy(e2, o2[0], o2[1], 4)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast=True)
+    check_energy(ctx.compute_energy_response(src, p), e32, e64, 4)
+    # moving geometry on the device-built tree: shift the first 200 triangles, refit, compare with a fresh host build
+    moved = sc.triangles.copy()
+    moved[:200] += np.array([35.0, -20.0, 10.0], np.float32)
+    ctx.update_triangles(0, moved[:200])
+    em = ctx.compute_energy_response(src, p)
+    ref, rsrc = make_ctx(pkg, sc)
+    ref.set_scene(moved, sc.material_ids, sc.absorption)       # a fresh host (SAH) build of the moved geometry
+    er = ref.compute_energy_response(rsrc, p)
+    assert np.array_equal(em != 0, er != 0) and max(rel_rms(em[b], er[b]) for b in range(4)) <= TIGHT_TOL
+    ref.close()
     ctx.close()
 
 

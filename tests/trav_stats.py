@@ -17,7 +17,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contr
                 "-munsafe-fp-atomics", "--offload-arch=gfx950", "-DFS_TRAV_STATS", "-shared", "-o",
                 os.path.join(out, "libfrequensee.so"), "-x", "hip", os.path.join(src, "fs_capi.cpp"),
                 os.path.join(src, "fs_bvh.cpp"), os.path.join(src, "fs_kernels.hip"), os.path.join(src, "fs_fft.hip"),
-                os.path.join(src, "fs_refit.hip")], check=True)
+                os.path.join(src, "fs_refit.hip"), os.path.join(src, "fs_build.hip")], check=True)
 import __graft_entry__ as graft  # noqa: E402
 pkg = graft.load_package()
 pkg._capi.LIB_PATH = os.path.join(out, "libfrequensee.so")

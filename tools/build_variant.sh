@@ -8,5 +8,5 @@ mkdir -p tools/tmp/$name
 cd audio-pathtracer_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -munsafe-fp-atomics --offload-arch=gfx950 \
   -Wall -Wextra -Wno-unused-parameter "$@" -shared -o ../../tools/tmp/$name/libfrequensee.so -x hip \
-  fs_capi.cpp fs_bvh.cpp fs_kernels.hip fs_fft.hip fs_refit.hip
+  fs_capi.cpp fs_bvh.cpp fs_kernels.hip fs_fft.hip fs_refit.hip fs_build.hip
 echo built tools/tmp/$name

@@ -1,38 +1,55 @@
 #!/usr/bin/env python3
-"""fs_scene_commit time (host SAH build + upload) for cfg3's 100 000 triangles and for a million-triangle slab,
-with the builder's worker threads off and on.  usage: python tools/measure_commit.py"""
+"""fs_scene_commit (host binned-SAH build) against fs_scene_commit_fast (device Morton / Karras build) at the cfg3
+scene, and what each tree costs per traced frame.  usage (GPU box): python tools/measure_commit.py"""
 import json
 import os
-import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CHILD = r'''
-import sys, time, json
-import numpy as np
-sys.path.insert(0, %r)
-import __graft_entry__ as graft
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
 pkg = graft.load_package()
-out = {}
-sc = pkg.scenes.old_mine(8)
-ctx = pkg.Context(num_bands=8)
-ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)        # warm: first HIP allocations
-for name, tri, mat, ab in (("old_mine_100k", sc.triangles, sc.material_ids, sc.absorption),):
-    ts = []
-    for _ in range(3):
-        t = time.perf_counter(); ctx.set_scene(tri, mat, ab); ctx.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
-    out[name] = min(ts)
-rng = np.random.default_rng(1)
-T = 1000000
-c = rng.uniform(0, 10000, (T, 1, 3)); c[:, :, 2] *= 0.05
-tri = (c + rng.uniform(-30, 30, (T, 3, 3))).astype(np.float32)
-t = time.perf_counter(); ctx.set_scene(tri, np.zeros(T, np.uint16), sc.absorption); ctx.synchronize()
-out["slab_1m"] = 1e3 * (time.perf_counter() - t)
-print(json.dumps(out))
-''' % ROOT
 res = {}
-for threads in (1, 8, 16):
-    env = dict(os.environ, FS_BVH_THREADS=str(threads))
-    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
-    res[f"threads_{threads}"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else r.stderr[-300:]
-print(json.dumps({"fs_scene_commit_ms": res}))
+for name, bands, rays in (("old_mine", 8, 262144), ("starter_room", 4, 16384)):
+    sc = pkg.scenes.by_name(name, bands)
+    ctx = pkg.Context(num_bands=bands)
+    ctx.set_listener(sc.listener)
+    src = ctx.create_source(sc.source)
+    p = pkg.default_params(num_rays=rays, depth=8)
+    row = {"triangles": sc.num_triangles}
+    for kind, fast in (("host_sah", False), ("device_morton", True)):
+        ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast=fast)     # warm (allocations, code objects)
+        best = best_all = 1e9
+        commit = ctx.lib.fs_scene_commit_fast if fast else ctx.lib.fs_scene_commit
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast=fast)   # copies the inputs, then commits
+            ctx.synchronize()
+            best_all = min(best_all, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            ctx.check(commit(ctx.h))                                                 # the commit alone
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        st = ctx.stats()
+        for i in range(20):
+            p.seed = 100 + i
+            ctx.compute_energy_response_async(src, p)
+        ctx.synchronize()
+        ctx.reset_stats()
+        ctx.set_profiling(2)
+        t0 = time.perf_counter()
+        for i in range(100):
+            p.seed = 1000 + i
+            ctx.compute_energy_response_async(src, p)
+        ctx.synchronize()
+        el = time.perf_counter() - t0
+        s2 = ctx.stats()
+        ctx.set_profiling(0)
+        row[kind] = {"commit_ms": 1e3 * best, "set_triangles_and_commit_ms": 1e3 * best_all, "bvh_nodes": st["bvh_nodes"], "stack_need": st["bvh_stack_need"],
+                     "frame_ms": 1e3 * el / 100, "walk_ms": s2["walk_kernel_ms_sum"] / max(s2["timed_frames"], 1),
+                     "connect_ms": s2["connect_kernel_ms_sum"] / max(s2["timed_connects"], 1)}
+    res[name] = row
+    ctx.close()
+print(json.dumps(res))
