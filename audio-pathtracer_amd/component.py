@@ -373,6 +373,7 @@ class AudioRayTracingSubsystem:
         self._next_actor = 0
         self._materials = None
         self._dirty = True
+        self._committed = False   # the first commit builds the tree on the host (SAH), later registration changes on the device
         self.params = _capi.default_params()
 
     def Deinitialize(self):
@@ -412,8 +413,14 @@ class AudioRayTracingSubsystem:
             tri, mat, obj = np.zeros((0, 3, 3), np.float32), np.zeros((0,), np.uint16), None
         ab, tr, sc = self._materials if self._materials is not None else (
             np.zeros((0, self.ctx.num_bands), np.float32), None, None)
-        self.ctx.set_scene(tri, mat, ab, tr, sc, object_ids=obj)
+        self.ctx.set_scene(tri, mat, ab, tr, sc, object_ids=obj, fast=self._committed)
         self._dirty = False
+        self._committed = True
+
+    def RebuildQuality(self):
+        """after run-time registration changes (device-built Morton tree): the host's SAH build again, when a frame can afford it"""
+        self._dirty, self._committed = True, False
+        self._commit()
 
     def GeometryMoved(self, comp_index, triangles):
         """A registered geometry component (index in registration order) moved: same triangle count, new

@@ -96,11 +96,19 @@ public:
     AudioRayTracingSubsystem(const AudioRayTracingSubsystem&) = delete;
     AudioRayTracingSubsystem& operator=(const AudioRayTracingSubsystem&) = delete;
 
-    void RegisterGeometry(const AcousticGeometryComponent* Comp) { Geometry_.push_back(Comp); Dirty_ = true; }   // .h:99
-    void UnregisterGeometry(const AcousticGeometryComponent* Comp) {                                            // .h:100
+    // RegisterGeometry / UnregisterGeometry (.h:99-100).  The first commit builds the tree on the host (binned SAH);
+    // a registration change DURING play (Committed_ already) rebuilds it on the device instead (fs_scene_commit_fast,
+    // a tenth of the time; call RebuildQuality() when a frame can afford the SAH build again).
+    void RegisterGeometry(const AcousticGeometryComponent* Comp) { Geometry_.push_back(Comp); Dirty_ = true; }
+    void UnregisterGeometry(const AcousticGeometryComponent* Comp) {
         for (size_t i = 0; i < Geometry_.size(); ++i)
             if (Geometry_[i] == Comp) { Geometry_.erase(Geometry_.begin() + (long)i); Dirty_ = true; break; }
     }
+    void RebuildQuality() { Dirty_ = true; Committed_ = false; Commit(); }
+    // Multi-GPU (one process per GPU, Rank / WorldSize given to the constructor): Id = the FS_COMM_ID_BYTES bytes rank 0
+    // got from fs_comm_unique_id, shipped to every rank.  From then on every frame's energy buffer is summed over the
+    // ranks inside the library and Commit() lets rank 0 build the tree for all.
+    void CommInit(const void* Id) { Check(fs_comm_init(Ctx_, Id, FS_COMM_ID_BYTES)); }
     // UAcousticMaterial table: Absorption [M][bands] (AcousticMaterial.h:22-30)
     void SetMaterials(const std::vector<float>& Absorption, int NumMaterials) {
         Absorption_ = Absorption; NumMaterials_ = NumMaterials; Dirty_ = true;
@@ -141,7 +149,9 @@ public:
         for (auto* s : ActiveSources) Check(fs_reconstruct_impulse_response_async(Ctx_, s->Handle_, &Params));
         Check(fs_synchronize(Ctx_));
     }
-    void Tick(float /*DeltaTime*/) { if (!ActiveSources.empty()) ForceUpdateSources(); }   // .cpp:55-85 (caller drives every frame)
+    // .cpp:55-85 (the caller drives every frame).  The reference draws from the engine's global rand() stream, so every
+    // frame sees fresh samples: the seed advances.
+    void Tick(float /*DeltaTime*/) { if (!ActiveSources.empty()) { ForceUpdateSources(); ++Params.seed; } }
 
     int NumBands() const { return NumBands_; }
     fs_context* Context() const { return Ctx_; }
@@ -157,8 +167,9 @@ public:
         Check(fs_scene_set_materials(Ctx_, Absorption_.data(), nullptr, nullptr, NumMaterials_,
                                      NumMaterials_ ? (int32_t)(Absorption_.size() / (size_t)NumMaterials_) : NumBands()));
         Check(fs_scene_set_objects(Ctx_, obj.data(), (int32_t)obj.size()));
-        Check(fs_scene_commit(Ctx_));
+        Check(Committed_ ? fs_scene_commit_fast(Ctx_) : fs_scene_commit(Ctx_));
         Dirty_ = false;
+        Committed_ = true;
     }
     // A registered geometry component moved (ECC_WorldDynamic prop): its triangles are rewritten in place and the
     // acceleration structure is refitted on the device before the next trace — no rebuild.  `Comp->Triangles`
@@ -186,6 +197,7 @@ private:
     std::vector<float> Absorption_;
     int NumMaterials_ = 0;
     bool Dirty_ = true;
+    bool Committed_ = false;
     int NumBands_ = 1;
     friend class FrequenSeeAudioComponent;
     friend class MaterialAcousticProcessor;
