@@ -1,9 +1,9 @@
 #!/bin/bash
 # The BASELINE.json configurations other than the headline one, plus the mode variants, on one GPU:
 #   bash tools/bench_other.sh > gpurun_out/bench_other.jsonl
-# One JSON line per run (bench.py's own line); copy into profiles/r01_bench_other.jsonl.
+# One JSON line per run (bench.py's own line); copy into profiles/rNN_bench_other.jsonl.
 set -o pipefail
-run() { timeout -k 10 400 python3 bench.py "$@" --no-pipelined 2>/dev/null | tail -1; }
+run() { timeout -k 10 400 python3 bench.py "$@" --no-extra 2>/dev/null | tail -1; }
 run --workload cfg2_starter_room --steps 200 --warmup 20
 run --workload cfg4_old_mine_d12 --steps 100 --warmup 10
 run --workload cfg4_old_mine_1m_d12 --steps 50 --warmup 5
