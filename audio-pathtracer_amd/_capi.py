@@ -42,7 +42,7 @@ EXPORTS = [
     "fs_reconstruct_impulse_response_async", "fs_synchronize", "fs_get_impulse_response",
     "fs_copy_impulse_response", "fs_copy_band_impulse_response", "fs_get_energy_buffer", "fs_flush_energy_buffer",
     "fs_add_energy_at_delay", "fs_update_energy_buffer", "fs_num_bins", "fs_num_samples", "fs_trace_rays",
-    "fs_set_profiling", "fs_get_stats", "fs_reset_stats",
+    "fs_set_profiling", "fs_set_profiling_interval", "fs_get_stats", "fs_reset_stats",
     "fs_sound_params_default", "fs_scene_set_objects", "fs_update_sound", "fs_get_occlusion_attenuation",
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
@@ -206,6 +206,7 @@ def load():
         "fs_num_samples": (C.c_int, [vp]),
         "fs_trace_rays": (C.c_int, [vp, f32p, f32p, f32p, i32, i32, vp, f32p, vp, f32p]),
         "fs_set_profiling": (C.c_int, [vp, i32]),
+        "fs_set_profiling_interval": (C.c_int, [vp, i32]),
         "fs_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
         "fs_reset_stats": (C.c_int, [vp]),
         "fs_sound_params_default": (None, [C.POINTER(SoundParams)]),

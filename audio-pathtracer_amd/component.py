@@ -250,9 +250,11 @@ class Context:
                                                  sc.ctypes.data, a.size, *[o.ctypes.data for o in outs]))
         return tuple(outs)
 
-    def set_profiling(self, level=2):
-        """0 off, 1 = HIP events around the dominant (walk) kernel only, 2 = every kernel"""
+    def set_profiling(self, level=2, interval=1):
+        """0 off, 1 = HIP events around the dominant (walk) kernel only (every `interval`-th frame), 2 = every kernel,
+        3 = 2 + the kernels count the records they fetch"""
         self.check(self.lib.fs_set_profiling(self.h, int(level)))
+        self.check(self.lib.fs_set_profiling_interval(self.h, int(interval)))
 
     def stats(self):
         s = _capi.Stats()

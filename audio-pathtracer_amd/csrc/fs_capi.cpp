@@ -155,6 +155,8 @@ struct fs_context {
 
     // measurement
     int profiling = 0;   // 0 off, 1 = HIP events around the dominant (walk) kernel only, 2 = every kernel
+    int profile_interval = 1;   // level 1: every n-th frame carries the events (fs_set_profiling_interval)
+    unsigned profile_tick = 0;
     std::vector<TimedFrame> pending;
     std::vector<hipEvent_t> free_events;
     fs_stats stats{};
@@ -534,6 +536,11 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, c.device) == hipSuccess && lds > 0)
         ctx->lds_limit = (size_t)lds;
+    // the reconstruct kernel stages one amplitude per bin in LDS; the traversal kernels' need depends on the tree and is
+    // checked at fs_scene_commit
+    if (sizeof(float) * (size_t)ctx->num_bins > ctx->lds_limit || ctx->num_bins < 1 || ctx->num_samples < 1)
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "simulated_duration / bin_duration give " + std::to_string(ctx->num_bins) +
+                         " bins: more than the reconstruct kernel can stage in the device's LDS");
 #ifdef FS_EXPERIMENTS
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
 #endif
@@ -1212,7 +1219,11 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     if (unbounded) ctx->overflow_armed = true;
 
     TimedFrame tf{};
-    if (ctx->profiling) {
+    // level 1 may sample: events around every profile_interval-th frame only (an event pair costs the frame a few
+    // microseconds of queue bubbles — bench.py times every 8th frame of its timed region)
+    const bool timed_frame = ctx->profiling && (ctx->profiling >= 2 || ctx->profile_interval <= 1 ||
+                                                (ctx->profile_tick++ % (unsigned)ctx->profile_interval) == 0);
+    if (timed_frame) {
         resolve_completed_timings(ctx);
         for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
         tf.e[0] = take_event(ctx);
@@ -1290,11 +1301,11 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     if (!perm) st.slot_of = nullptr;   // no schedule: slot == subpath index
     if (!perm && zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
     if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
-    if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
+    if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     WalkLaunch wl = ctx->walk;
     wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
     launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
-    if (ctx->profiling) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+    if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
     if (all_conn)
         launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
                            ctx->stream);
@@ -1306,7 +1317,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         for (int i = 0; i < count; ++i)
             launch_fixed_to_energy(srcs[i]->d_fixed[srcs[i]->cur], srcs[i]->energy(), B * ctx->num_bins, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
-    if (ctx->profiling) {
+    if (timed_frame) {
         if (tf.e[2]) FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
         tf.has_trace = true;
         ctx->pending.push_back(tf);
@@ -2007,6 +2018,13 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
 int fs_set_profiling(fs_context* ctx, int32_t enabled) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     ctx->profiling = enabled < 0 ? 0 : (enabled > 3 ? 3 : enabled);
+    return FS_OK;
+}
+
+int fs_set_profiling_interval(fs_context* ctx, int32_t frames) {
+    if (!ctx || frames < 1) return FS_ERR_INVALID_ARGUMENT;
+    ctx->profile_interval = frames;
+    ctx->profile_tick = 0;
     return FS_OK;
 }
 

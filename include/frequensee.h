@@ -354,6 +354,9 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
 /* HIP events on the context's stream: 0 = off, 1 = around the dominant (walk) kernel only, 2 = every kernel,
  * 3 = level 2 + the kernels count the node / triangle records they fetch (slower: not for timed frames) */
 int fs_set_profiling(fs_context* ctx, int32_t level);
+/* level 1 only: put the event pair around every n-th frame (default 1 = every frame).  An event pair costs a frame a few
+ * microseconds of queue bubbles; sampling keeps a live measurement inside a timed region without paying that per frame. */
+int fs_set_profiling_interval(fs_context* ctx, int32_t frames);
 int fs_get_stats(fs_context* ctx, fs_stats* out);
 int fs_reset_stats(fs_context* ctx);
 
