@@ -46,7 +46,9 @@ __device__ unsigned long long* g_wave_buf;       // [waves][8]: start, end (100 
 __device__ unsigned long long* g_conn_buf;       // [waves][8]: connect kernel: start, set-up done, visibility done, evaluated, end (100 MHz), lane-0 deposits
 #endif
 #ifdef FS_TRAV_STATS
-__device__ unsigned long long g_trav_stats[8];   // [0] step calls, [1] node iterations, [2] node lanes, [3] tri iterations, [4] tri lanes
+__device__ unsigned long long g_trav_stats[32];  // closest-hit queries at [0..15], any-hit at [16..31]: [0] step calls, [1] node iterations,
+                                                 // [2] node lanes, [3] tri iterations, [4] tri lanes, [5..7] node visits by children hit,
+                                                 // [8] busy lanes, [9] lanes on taken work, [10] sharing-loop iterations, [11] lanes with both kinds
 __device__ unsigned short* g_step_buf;           // optional [depth][2P]: traversal iterations of every walk segment
 #endif
 
@@ -278,10 +280,12 @@ __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r
 #ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.py): SIMD occupancy of the two step kinds
     {
         const unsigned long long mt = __ballot(has_tri), mn = __ballot(has_node);
+        unsigned long long* gs = g_trav_stats + (ANY ? 16 : 0);
         if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(true)) - 1)) {
-            atomicAdd(&g_trav_stats[0], 1ull);
-            if (mn) { atomicAdd(&g_trav_stats[1], 1ull); atomicAdd(&g_trav_stats[2], (unsigned long long)__popcll(mn)); }
-            if (mt) { atomicAdd(&g_trav_stats[3], 1ull); atomicAdd(&g_trav_stats[4], (unsigned long long)__popcll(mt)); }
+            atomicAdd(&gs[0], 1ull);
+            if (mn) { atomicAdd(&gs[1], 1ull); atomicAdd(&gs[2], (unsigned long long)__popcll(mn)); }
+            if (mt) { atomicAdd(&gs[3], 1ull); atomicAdd(&gs[4], (unsigned long long)__popcll(mt)); }
+            atomicAdd(&gs[11], (unsigned long long)__popcll(mn & mt));
         }
     }
 #endif
@@ -352,7 +356,7 @@ __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r
         int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), ref2 = __float_as_int(q3.z),
             ref3 = __float_as_int(q3.w);
 #ifdef FS_TRAV_STATS
-        atomicAdd(&g_trav_stats[5 + (hits > 2 ? 2 : hits)], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
+        atomicAdd(&g_trav_stats[(ANY ? 16 : 0) + 5 + (hits > 2 ? 2 : hits)], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
 #endif
         // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free.  (Measured in
         // round 2: choosing only the nearest child and pushing the rest in slot order — also no ordering at all for
@@ -814,6 +818,16 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     trav_issue(sc, T, R);
     while (true) {
         trav_wait(R);
+#ifdef FS_TRAV_STATS
+        {
+            const unsigned long long mb = __ballot(trav_busy(T)), mth = __ballot(trav_busy(T) && owner != tid);
+            if (lane == 0u) {
+                unsigned long long* gs = g_trav_stats + (ANY ? 16 : 0);
+                atomicAdd(&gs[8], (unsigned long long)__popcll(mb)); atomicAdd(&gs[9], (unsigned long long)__popcll(mth));
+                atomicAdd(&gs[10], 1ull);
+            }
+        }
+#endif
         if (trav_busy(T)) {
             trav_consume<ANY, IGN, COUNT>(sc, wr, T, stack, R, wign);
             if (ANY) {
@@ -1964,8 +1978,8 @@ extern "C" void fs_debug_connect_buffer(unsigned long long* device_ptr) {
 #endif
 #ifdef FS_TRAV_STATS
 extern "C" void fs_debug_trav_stats(unsigned long long* out, int reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof(z)); }
 }
 extern "C" void fs_debug_step_buffer(unsigned short* device_ptr) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_buf), &device_ptr, sizeof(device_ptr));

@@ -192,6 +192,12 @@ def test_million_triangle_scene(pkg, oracle_mod):
         check_energy(e_gpu, e32, e64, 2)
     else:
         assert not e_gpu.any()
+    # the same million triangles through the device-side (Morton) builder: another tree, the same closest hits
+    ctx.set_scene(tri, mat, absorption, fast=True)
+    assert ctx.stats()["triangles"] == T
+    hit2, t2, idx2, nrm2 = ctx.trace_rays(o, d, 1e7)
+    assert np.array_equal(hit2, hit) and np.array_equal(t2[hit], t[hit])
+    assert np.array_equal(idx2[hit], idx[hit]) and np.array_equal(nrm2[hit], nrm[hit])
     ctx.close()
 
 

@@ -29,7 +29,7 @@ ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
 ctx.set_listener(sc.listener)
 s = ctx.create_source(sc.source)
 p = pkg.default_params(num_rays=262144, depth=8)
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 32)()
 res = {}
 for plan in (1,):
     lib.fs_debug_trav_stats(buf, 1)
@@ -38,7 +38,12 @@ for plan in (1,):
     v = list(buf)
     res = {"wave_step_calls": v[0], "node_iterations": v[1], "node_lane_steps": v[2], "tri_iterations": v[3],
            "tri_lane_steps": v[4], "node_lanes_per_iteration": v[2] / max(v[1], 1), "tri_lanes_per_iteration": v[4] / max(v[3], 1),
-           "node_visits_by_children_hit_0_1_2plus": [v[5], v[6], v[7]]}
+           "node_visits_by_children_hit_0_1_2plus": [v[5], v[6], v[7]],
+           "lanes_with_both_kinds": v[11], "sharing_loop_iterations": v[10], "busy_lanes_per_iteration": v[8] / max(v[10], 1),
+           "lanes_on_taken_work_per_iteration": v[9] / max(v[10], 1),
+           "visibility": {"wave_step_calls": v[16], "node_iterations": v[17], "node_lane_steps": v[18], "tri_iterations": v[19],
+                          "tri_lane_steps": v[20], "sharing_loop_iterations": v[26], "busy_lanes_per_iteration": v[24] / max(v[26], 1),
+                          "lanes_on_taken_work_per_iteration": v[25] / max(v[26], 1)}}
 if os.environ.get("FS_WALK_VARIANT", "2") != "0":   # the per-segment counts below are recorded by the one-subpath-per-lane
     print(json.dumps(res))                           # kernel only: FS_WALK_VARIANT=0 python tests/trav_stats.py
     sys.exit(0)
