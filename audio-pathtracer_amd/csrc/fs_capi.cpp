@@ -1252,6 +1252,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     float* zero_ptr = accumulate ? nullptr : (fixed ? reinterpret_cast<float*>(s->d_fixed[s->cur]) : s->energy());
     const int zero_words = (fixed ? 2 : 1) * B * ctx->num_bins;
     float* const* energy_tab = nullptr;
+    float* const* zero_tab = nullptr;   // batched frame: the table of buffers the plan pass zeroes
     unsigned long long* const* fixed_tab = nullptr;
     if (batch) {
         // per-frame tables in one pinned staging block: energy pointers [count] | fixed-point buffer pointers [count] |
@@ -1289,17 +1290,21 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         energy_tab = reinterpret_cast<float* const*>(db);
         fixed_tab = fixed ? reinterpret_cast<unsigned long long* const*>(db + (size_t)count * sizeof(void*)) : nullptr;
         kp.src_table = reinterpret_cast<const float*>(db + 2 * (size_t)count * sizeof(void*));
-        for (int i = 0; i < count && !accumulate; ++i) {
-            float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[srcs[i]->cur]) : srcs[i]->energy();
-            FS_HIP(ctx, hipMemsetAsync(zp, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
-        }
         zero_ptr = nullptr;
+        if (!accumulate) zero_tab = fixed ? reinterpret_cast<float* const*>(fixed_tab) : energy_tab;
     }
     WalkLaunch wplan = ctx->walk;
     if (unbounded) wplan.plan = 1;   // the second record tier relies on the schedule: the longest walks own the lowest slots
-    const uint32_t* perm = launch_plan(kp, wplan, zero_ptr, zero_ptr ? zero_words : 0, ctx->stream);
+    const bool plan_zeroes = kp.russian_roulette && 2u * kp.num_local > 0;   // launch_plan runs its pass (and the flush with it)
+    const uint32_t* perm = launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
     if (!perm) st.slot_of = nullptr;   // no schedule: slot == subpath index
-    if (!perm && zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+    if (!plan_zeroes) {
+        if (zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+        for (int i = 0; i < count && zero_tab; ++i) {
+            float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[srcs[i]->cur]) : srcs[i]->energy();
+            FS_HIP(ctx, hipMemsetAsync(zp, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+        }
+    }
     if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
     if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     WalkLaunch wl = ctx->walk;

@@ -167,7 +167,10 @@ constexpr int kNumCounters = 8;   // walk segments, connections tested, deposits
 constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
 // nullptr when no plan applies (the caller then clears the energy buffer itself)
-const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words, hipStream_t s);
+// energy / energy_words: buffer the pass zeroes (FlushEnergyBuffer); energy_tab / energy_count: a device table of such
+// buffers instead (batched frame).  Returns nullptr — and zeroes nothing — when there is no roulette to plan for.
+const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
+                            float* const* energy_tab, int energy_count, hipStream_t s);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead

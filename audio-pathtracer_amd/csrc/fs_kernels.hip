@@ -655,13 +655,21 @@ __device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
 
 __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __restrict__ scratch,
                                                       uint32_t* __restrict__ perm, float* __restrict__ energy,
-                                                      int energy_words) {
+                                                      int energy_words, float* const* __restrict__ energy_tab,
+                                                      int energy_count) {
     __shared__ unsigned s_hist[kPlanBuckets];
     __shared__ unsigned s_base[kPlanBuckets];
     __shared__ unsigned s_seg;
     if (threadIdx.x == 0) s_seg = 0u;
     for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) s_hist[i] = 0u;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) energy[i] = 0.0f;
+    if (energy_tab) {   // batched frame: every source's buffer (the table was copied on this stream before the launch)
+        for (int k = 0; k < energy_count; ++k) {
+            float* e = energy_tab[k];
+            for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) e[i] = 0.0f;
+        }
+    } else {
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) energy[i] = 0.0f;
+    }
     __syncthreads();
     const uint32_t total = 2u * kp.num_local;
     // kPlanItems subpaths per thread: the bucket counters are a handful of hot addresses, and every workgroup
@@ -1836,7 +1844,7 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
 }  // namespace
 
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
-                            hipStream_t s) {
+                            float* const* energy_tab, int energy_count, hipStream_t s) {
     uint32_t lanes = 2u * kp.num_local;
     // Without roulette every walk takes kp.depth segments: nothing to sort, and the caller counts the segments on
     // the host.  With roulette the pass always runs — it is also what counts the frame's walk segments — but it
@@ -1845,7 +1853,7 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
     const bool sort = wl.plan && kp.depth > 1 && wl.perm;
     uint32_t full = (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
     hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, sort ? wl.perm : nullptr, energy,
-                       energy_words);
+                       energy_words, energy_tab, energy_count);
     return sort ? wl.perm : nullptr;
 }
 
