@@ -634,9 +634,9 @@ RcclApi* rccl() {
     std::call_once(once, [] {
         const char* env = std::getenv("FS_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "librccl.so"};
+        if (env && *env) api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);       // an explicit choice wins
         for (const char* n : names)
             if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy the process already has
-        if (!api.handle && env && *env) api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
         for (const char* n : names)
             if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (!api.handle) { const char* e = dlerror(); api.why = std::string("librccl not found: ") + (e ? e : "?"); return; }

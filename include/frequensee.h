@@ -234,7 +234,7 @@ int fs_energy_handoff(fs_context* ctx, fs_source src, void** dptr, size_t* bytes
  * mode), issued by the library on the context's tail stream at the end of fs_compute_energy_response*, so that it and
  * the reconstruct behind it overlap the next frame's tracing.  With a communicator attached fs_scene_commit also lets
  * rank 0 alone build the acceleration structure and broadcasts it (nodes, triangle records, refit tables).
- * RCCL is opened at run time (an already loaded librccl first, then $FS_RCCL_LIB, then the system's).
+ * RCCL is opened at run time ($FS_RCCL_LIB if set, else a librccl the process has already loaded, else the system's).
  *   rank 0:     fs_comm_unique_id(id, FS_COMM_ID_BYTES)  -> ship the 128 bytes to the other ranks by any means
  *   every rank: fs_comm_init(ctx, id, FS_COMM_ID_BYTES)  (collective: ncclCommInitRank(world_size, id, rank))
  * or hand over a communicator the host already owns (fs_comm_attach; not destroyed with the context).

@@ -1,0 +1,59 @@
+"""One rank of tests/test_two_ranks_one_gpu.py (not collected by pytest): a world_size-N context on cuda:0 whose
+collectives go through the test double tests/fake_rccl.cpp ($FS_RCCL_LIB), driven exactly like a rank of a real run.
+usage: python tests/_two_rank_worker.py <rank> <world_size> <id_file> <out.npz>"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+rank, world, id_file, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+pkg = graft.load_package()
+assert os.environ.get("FS_RCCL_LIB"), "the worker must run on the test double"
+sc = pkg.scenes.starter_room(4)
+ctx = pkg.Context(num_bands=4, rank=rank, world_size=world)
+if rank == 0:                                   # the id travels by any host-side transport: here a file
+    uid = pkg.Context.comm_unique_id()
+    with open(id_file + ".tmp", "wb") as f:
+        f.write(uid)
+    os.replace(id_file + ".tmp", id_file)
+else:
+    t0 = time.time()
+    while not os.path.exists(id_file):
+        assert time.time() - t0 < 60, "rank 0 never wrote the id"
+        time.sleep(0.01)
+    with open(id_file, "rb") as f:
+        uid = f.read()
+ctx.comm_init(uid)
+# every rank registers the same triangles; rank 0 builds the tree, the others receive it (fs_scene_commit)
+ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+ctx.set_listener(sc.listener)
+src = ctx.create_source(sc.source)
+res = {"bvh_nodes": np.int64(ctx.stats()["bvh_nodes"])}
+frames = [(0, 901), (8, 902), (0, 903)]         # (flags, seed): fp32 frame, deterministic frame, fp32 again
+for k, (flags, seed) in enumerate(frames):
+    p = pkg.default_params(num_rays=16384, depth=8, seed=seed, flags=flags)
+    ctx.compute_energy_response_async(src, p)
+    ctx.reconstruct_impulse_response_async(src, p)
+    if k + 1 < len(frames):                     # the next frame's tracing is queued behind this frame's reduce
+        ctx.compute_energy_response_async(src, pkg.default_params(num_rays=4096, depth=8, seed=5))
+    ctx.synchronize()
+    res[f"ir{k}"] = ctx.impulse_response(src, 0).copy()
+p = pkg.default_params(num_rays=16384, depth=8, seed=77)
+res["energy"] = ctx.compute_energy_response(src, p).copy()        # the helpers read the summed buffer
+rng = np.random.default_rng(5)
+o = np.tile(np.asarray(sc.source, np.float32), (256, 1))
+d = rng.normal(size=(256, 3)).astype(np.float32)
+d /= np.linalg.norm(d, axis=1, keepdims=True)
+hit, t, idx, nrm = ctx.trace_rays(o, d, 1e6)                      # through the broadcast tree
+res.update(hit=hit, t=t, idx=idx)
+# moving geometry on a sharded context: every rank refits its own copy
+ctx.update_triangles(0, np.asarray(sc.triangles[:64], np.float32) + np.float32(3.0))
+res["energy_moved"] = ctx.compute_energy_response(src, p).copy()
+ctx.comm_detach()
+ctx.close()
+np.savez(out, **res)
