@@ -789,6 +789,11 @@ struct ShareArea {
     }
 };
 constexpr size_t kShareLdsBytes = ShareArea<false, false>::kBytes;      // 60 B per lane
+// The sharing round (ballots, donation boxes, the thieves' ray reload: ~50 VALU + ~35 SALU for the whole wave) runs only
+// once this many lanes have nothing to do: feeding the first few idle lanes costs every lane more than it returns.
+// Measured at cfg3 (profiles/r02_share_min_idle.log): 1 / 4 / 8 / 16 / 24 / 32 / 48 -> walk 0.304 / 0.303 / 0.298 /
+// 0.294 / 0.300 / 0.309 / 0.334 ms, connect 0.075 -> 0.072 ms at 16.  Sparse waves start above it.
+constexpr int kShareMinIdle = 16;
 constexpr size_t kShareAnyLdsBytes = ShareArea<true, false>::kBytes;    // 40 B per lane
 constexpr size_t kShareIgnLdsBytes = ShareArea<false, true>::kBytes;    // 64 B per lane
 
@@ -853,6 +858,7 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
         const unsigned long long busy_m = __ballot(!idle);
         if (busy_m == 0ull) break;                      // nothing left anywhere in the wave
         const unsigned long long idle_m = __ballot(idle);
+        if (__popcll(idle_m) < kShareMinIdle) continue;
         const bool can_give = !idle && T.sp > T.sb;
         const unsigned long long give_m = __ballot(can_give);
         if (idle_m != 0ull && give_m != 0ull) {
