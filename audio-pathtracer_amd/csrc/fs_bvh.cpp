@@ -376,19 +376,17 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
         for (int c = 0; c < w.n; ++c) nb.grow(b.nodes[w.child[c]].box);
         NodeQ4 q{};
         double origin[3], scale[3];
-        uint32_t exps = 0;
         for (int k = 0; k < 3; ++k) {
             origin[k] = (double)(nb.lo[k] - pad);
             double ext = (double)(nb.hi[k] + pad) - origin[k];
             int e = (int)std::ceil(std::log2(std::max(ext, 1e-30) / 255.0));
             e = std::max(-100, std::min(100, e));
             while (std::ldexp(255.0, e) < ext) ++e;     // guard the log2 rounding
-            scale[k] = std::ldexp(1.0, e);
-            exps |= (uint32_t)(e + 127) << (8 * k);
+            scale[k] = std::ldexp(1.0, e);   // exact as a float: |e| <= 100
         }
         q.ox = (float)origin[0]; q.oy = (float)origin[1]; q.oz = (float)origin[2];
         // the float origin may round up by half an ulp; the >= 0.01 cm padding dwarfs it
-        q.exps = exps;
+        q.sx = (float)scale[0]; q.sy = (float)scale[1]; q.sz = (float)scale[2];
         uint32_t lo4[3] = {0, 0, 0}, hi4[3] = {0, 0, 0};
         for (int c = 0; c < 4; ++c) {
             for (int k = 0; k < 3; ++k) {

@@ -18,17 +18,18 @@ namespace fs {
 
 // ---- device data layout (HBM) --------------------------------------------------------------------
 // 4-wide BVH node, 64 B = half a 128-B cache line = four 16-byte loads:
-//   q0 = (origin.x origin.y origin.z, exps)   exps: byte k = biased exponent of the power-of-two grid step
-//                                             of axis k (step = 2^(byte-127))
-//   q1 = (lox4 loy4 loz4 hix4)  q2 = (hiy4 hiz4 - -)   byte c of each word = child c's plane on that
+//   q0 = (origin.x origin.y origin.z, step.x)  step: the power-of-two grid step of each axis, as a float (the
+//                                             traversal multiplies it by the ray's reciprocal direction right away)
+//   q1 = (lox4 loy4 loz4 hix4)  q2 = (hiy4 hiz4 step.y step.z)   byte c of each word = child c's plane on that
 //                                             grid: box = origin + q * step, rounded outwards
 //   q3 = child[4] as int bits; child >= 0: inner node index; child < 0: leaf,
 //        ~child = first_tri * 4 + (count - 1), count in 1..4 (the builder makes 1..2); empty slot: lo = 255 > hi = 0 (never hit).
 struct alignas(16) NodeQ4 {
     float ox, oy, oz;
-    uint32_t exps;
+    float sx;
     uint32_t lox, loy, loz, hix;
-    uint32_t hiy, hiz, pad0, pad1;
+    uint32_t hiy, hiz;
+    float sy, sz;
     int32_t child[4];
 };
 static_assert(sizeof(NodeQ4) == 64, "NodeQ4 must be 64 B");

@@ -320,10 +320,7 @@ __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r
     }
     if (has_node) {
         // ---- 4-wide node, child boxes on the node's 8-bit grid: plane distance = fma(q, step*inv, (origin-o)*inv)
-        const uint32_t exps = __float_as_uint(q0.w);
-        const float sx = __uint_as_float((exps & 0xFFu) << 23) * r.ix;
-        const float sy = __uint_as_float(((exps >> 8) & 0xFFu) << 23) * r.iy;
-        const float sz = __uint_as_float(((exps >> 16) & 0xFFu) << 23) * r.iz;
+        const float sx = q0.w * r.ix, sy = q2.z * r.iy, sz = q2.w * r.iz;   // grid step (a power of two) / direction
         const float bx = fmaf(q0.x, r.ix, r.nox);
         const float by = fmaf(q0.y, r.iy, r.noy);
         const float bz = fmaf(q0.z, r.iz, r.noz);

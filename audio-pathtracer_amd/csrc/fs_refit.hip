@@ -91,15 +91,13 @@ __global__ __launch_bounds__(kRefitBlock) void refit_level_kernel(NodeQ4* __rest
 
     double origin[3], scale[3];
     float originf[3];
-    uint32_t exps = 0;
     for (int k = 0; k < 3; ++k) {
         origin[k] = (double)(nb.lo[k] - pad);
         const double ext = (double)(nb.hi[k] + pad) - origin[k];
         int e = (int)ceil(log2(fmax(ext, 1e-30) / 255.0));
         e = max(-100, min(100, e));
         while (ldexp(255.0, e) < ext) ++e;     // guard the log2 rounding
-        scale[k] = ldexp(1.0, e);
-        exps |= (uint32_t)(e + 127) << (8 * k);
+        scale[k] = ldexp(1.0, e);   // exact as a float: |e| <= 100
         originf[k] = (float)origin[k];
     }
     uint32_t lo4[3] = {0, 0, 0}, hi4[3] = {0, 0, 0};
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(kRefitBlock) void refit_level_kernel(NodeQ4* __rest
             hi4[k] |= qh << (8 * c);
         }
     q.ox = originf[0]; q.oy = originf[1]; q.oz = originf[2];
-    q.exps = exps;
+    q.sx = (float)scale[0]; q.sy = (float)scale[1]; q.sz = (float)scale[2];
     q.lox = lo4[0]; q.loy = lo4[1]; q.loz = lo4[2];
     q.hix = hi4[0]; q.hiy = hi4[1]; q.hiz = hi4[2];
     nodes[i] = q;
