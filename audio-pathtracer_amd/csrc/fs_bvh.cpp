@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -370,6 +371,8 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
 
     // quantise + flatten
     out.nodes.resize(wide.size());
+    double dbg_exact[2] = {0, 0}, dbg_quant[2] = {0, 0};   // FS_BVH_DEBUG: half-areas of the child boxes, [inner, leaf]
+    const bool dbg = std::getenv("FS_BVH_DEBUG") != nullptr;
     for (size_t i = 0; i < wide.size(); ++i) {
         const Wide& w = wide[i];
         Box nb; nb.reset();
@@ -401,6 +404,17 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
                 lo4[k] |= ql << (8 * c);
                 hi4[k] |= qh << (8 * c);
             }
+            if (dbg && c < w.n) {
+                const Box& cbx = b.nodes[w.child[c]].box;
+                double e[3], g[3];
+                for (int k = 0; k < 3; ++k) {
+                    e[k] = (double)cbx.hi[k] - (double)cbx.lo[k] + 2.0 * pad;
+                    g[k] = (double)(((hi4[k] >> (8 * c)) & 255u) - ((lo4[k] >> (8 * c)) & 255u)) * scale[k];
+                }
+                const int leaf = b.nodes[w.child[c]].left >= 0 ? 0 : 1;
+                dbg_exact[leaf] += e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+                dbg_quant[leaf] += g[0] * g[1] + g[1] * g[2] + g[2] * g[0];
+            }
             if (c < w.n) {
                 const BuildNode& cn = b.nodes[w.child[c]];
                 q.child[c] = cn.left >= 0 ? wide_of[w.child[c]] : leaf_code(cn.first, cn.count);
@@ -412,6 +426,9 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
         q.hix = hi4[0]; q.hiy = hi4[1]; q.hiz = hi4[2];
         out.nodes[i] = q;
     }
+    if (dbg)
+        std::fprintf(stderr, "[fs_bvh] child boxes on the 8-bit grids: inner area x%.3f, leaf area x%.3f (%zu wide nodes)\n",
+                     dbg_quant[0] / std::max(dbg_exact[0], 1e-30), dbg_quant[1] / std::max(dbg_exact[1], 1e-30), wide.size());
 }
 
 }  // namespace fs
