@@ -2,6 +2,7 @@
 // file and replays the kernels' closest-hit traversal order on the CPU for rays leaving random surface points, counting node
 // visits and triangle tests per ray.  old_mine, 100 000 triangles: 14.4 node visits + 5.0 triangle tests per ray with the
 // default builder (<= 2 triangles per leaf, 32 SAH bins); <= 1 per leaf 15.8 + 4.1; 16 / 64 / 128 bins 14.7 / 14.3 / 14.3;
+// Kensler tree rotations on the binary tree before the collapse (up to 8 bottom-up passes): 14.40 + 4.98, i.e. nothing.
 // FS_BVH_DEBUG=1 prints how much the 8-bit child grids inflate the boxes (x1.02 inner, x1.016 leaf area).
 //   python -c "import __graft_entry__ as g, numpy as np; np.ascontiguousarray(g.load_package().scenes.old_mine(8).triangles, np.float32).tofile('/tmp/tri.f32')"
 //   g++ -O2 -std=c++17 -Iaudio-pathtracer_amd/csrc -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ tools/bvh_sim.cpp audio-pathtracer_amd/csrc/fs_bvh.cpp -o /tmp/bvh_sim -lpthread && /tmp/bvh_sim /tmp/tri.f32
