@@ -21,10 +21,11 @@ struct Box { float lo[3], hi[3]; };
 
 static void decode(const NodeQ4& n, int c, Box& b) {
     const uint32_t lo4[3] = {n.lox, n.loy, n.loz}, hi4[3] = {n.hix, n.hiy, n.hiz};
-    const float org[3] = {n.ox, n.oy, n.oz};
+    const float org[3] = {n.ox, n.oy, n.oz}, steps[3] = {n.sx, n.sy, n.sz};
     for (int k = 0; k < 3; ++k) {
-        int e = (int)((n.exps >> (8 * k)) & 0xFF) - 127;
-        float step = std::ldexp(1.0f, e);
+        const float step = steps[k];
+        int e = 0;
+        CHECK(step > 0.0f && std::frexp(step, &e) == 0.5f, "grid step %g of axis %d is not a power of two", (double)step, k);
         b.lo[k] = org[k] + (float)((lo4[k] >> (8 * c)) & 0xFF) * step;
         b.hi[k] = org[k] + (float)((hi4[k] >> (8 * c)) & 0xFF) * step;
     }
