@@ -81,6 +81,32 @@ class Context:
     def comm_detach(self):
         self.check(self.lib.fs_comm_detach(self.h))
 
+    # cfg5: independent sources, one per GPU — a peer communicator for the optional all-gather
+    def peers_init(self, unique_id: bytes, rank: int, world_size: int):
+        """collective over the processes that each own a source; frames are not sharded or reduced by it"""
+        if len(unique_id) != _capi.COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = (C.c_char * _capi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self.check(self.lib.fs_peers_init(self.h, buf, _capi.COMM_ID_BYTES, int(rank), int(world_size)))
+        self._peers = int(world_size)
+
+    def peers_detach(self):
+        self.check(self.lib.fs_peers_detach(self.h))
+        self._peers = 0
+
+    def gather_energy(self, src: int) -> np.ndarray:
+        """collective: [world_size][B][bins] — entry r is the current frame's histogram of the source rank r passed"""
+        n = int(getattr(self, "_peers", 0))
+        out = np.empty((max(n, 1), self.num_bands, self.num_bins), np.float32)
+        self.check(self.lib.fs_gather_energy(self.h, int(src), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def gather_energy_async(self, src: int):
+        """enqueue only: (device pointer, bytes) of the gathered [world_size][B][bins] histograms, in tail-stream order"""
+        d, b = C.c_void_p(), C.c_size_t()
+        self.check(self.lib.fs_gather_energy_async(self.h, int(src), C.byref(d), C.byref(b)))
+        return d.value, b.value
+
     # ---- scene ----
     def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None, object_ids=None, fast=False):
         """fast = True: the acceleration structure is built on the device (fs_scene_commit_fast)"""
@@ -187,6 +213,11 @@ class Context:
         out = np.empty(self.num_samples, dtype=np.float32)
         self.check(self.lib.fs_copy_band_impulse_response(self.h, src, band, out.ctypes.data, out.shape[0]))
         return out
+
+    def update_energy_buffer(self, src, values):
+        """UpdateEnergyBuffer (FSAC.h:81-85): install a whole [bands][bins] histogram as the source's current frame"""
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        self.check(self.lib.fs_update_energy_buffer(self.h, int(src), v.ctypes.data, v.size))
 
     def energy_buffer(self, src):
         out = np.empty((self.num_bands, self.num_bins), dtype=np.float32)

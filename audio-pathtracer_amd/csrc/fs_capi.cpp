@@ -124,6 +124,10 @@ struct fs_context {
 
     // multi-GPU: RCCL communicator over the ranks that share the pairs of every frame
     ncclComm_t comm = nullptr;
+    // cfg5 (independent sources, one per GPU): a communicator that never touches a frame — only fs_gather_energy uses it
+    ncclComm_t peers = nullptr;
+    int peers_size = 0;
+    float* d_gather = nullptr; size_t gather_cap = 0;   // [peers][B][bins] fp32
     bool comm_owned = false;           // created by fs_comm_init (destroyed with the context) vs attached by the caller
 
     // subpath state (sized on demand)
@@ -565,6 +569,8 @@ int fs_context_destroy(fs_context* ctx) {
         if (ctx->rev_stream) (void)hipStreamSynchronize(ctx->rev_stream);
         resolve_timings(ctx);
         (void)fs_comm_detach(ctx);
+        (void)fs_peers_detach(ctx);
+        if (ctx->d_gather) (void)hipFree(ctx->d_gather);
         for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
         free_scene(ctx);
         free_state(ctx);
@@ -752,6 +758,77 @@ int fs_comm_detach(fs_context* ctx) {
     if (ctx->comm_owned && a) (void)a->CommDestroy(ctx->comm);
     ctx->comm = nullptr;
     ctx->comm_owned = false;
+    return FS_OK;
+}
+
+int fs_peers_init(fs_context* ctx, const void* unique_id, size_t bytes, int32_t rank, int32_t world_size) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!unique_id || bytes != FS_COMM_ID_BYTES) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "unique id must be FS_COMM_ID_BYTES bytes");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad rank / world_size");
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (ctx->peers) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a peer communicator is already attached");
+    RcclApi* a = rccl();
+    if (!a) return ctx->fail(FS_ERR_COMM, "librccl is not loadable (set FS_RCCL_LIB)");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    FS_NCCL(ctx, a->CommInitRank(&ctx->peers, world_size, id, rank));
+    ctx->peers_size = world_size;
+    return FS_OK;
+}
+
+int fs_peers_detach(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->peers) return FS_OK;
+    if (ctx->device_ok) {
+        (void)hipSetDevice(ctx->cfg.device);
+        (void)hipStreamSynchronize(ctx->copy_stream);
+    }
+    if (RcclApi* a = rccl()) (void)a->CommDestroy(ctx->peers);
+    ctx->peers = nullptr;
+    ctx->peers_size = 0;
+    return FS_OK;
+}
+
+int fs_gather_energy_async(fs_context* ctx, fs_source h, void** dptr, size_t* bytes) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (!ctx->peers) return ctx->fail(FS_ERR_COMM, "fs_gather_energy needs fs_peers_init first");
+    RcclApi* a = rccl();
+    if (!a) return ctx->fail(FS_ERR_COMM, "peer communicator attached but librccl is not loadable");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    const size_t need = words * (size_t)ctx->peers_size;
+    if (need > ctx->gather_cap) {
+        FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        if (ctx->d_gather) (void)hipFree(ctx->d_gather);
+        ctx->d_gather = nullptr; ctx->gather_cap = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_gather, sizeof(float) * need));
+        ctx->gather_cap = need;
+    }
+    // behind this frame's deposit (and its all-reduce, on a sharded context), in tail-stream order
+    if (ctx->comm) { int rr = reduce_energy(ctx, s); if (rr) return rr; }
+    else FS_HIP(ctx, handoff_energy(ctx, s));
+    FS_NCCL(ctx, a->AllGather(s->energy(), ctx->d_gather, words, ncclFloat32, ctx->peers, ctx->copy_stream));
+    // the buffer is being read on the tail stream: the frame after next must not deposit into it before that
+    FS_HIP(ctx, hipEventRecord(s->ev_red[s->cur], ctx->copy_stream));
+    s->red_recorded[s->cur] = true;
+    if (dptr) *dptr = ctx->d_gather;
+    if (bytes) *bytes = sizeof(float) * need;
+    return FS_OK;
+}
+
+int fs_gather_energy(fs_context* ctx, fs_source h, float* out, int32_t n) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (ctx->peers && n != ctx->peers_size * ctx->cfg.num_bands * ctx->num_bins)
+        return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != peers * bands * bins");
+    void* d = nullptr; size_t b = 0;
+    const int rc = fs_gather_energy_async(ctx, h, &d, &b);
+    if (rc) return rc;
+    FS_HIP(ctx, hipMemcpyAsync(out, d, b, hipMemcpyDeviceToHost, ctx->copy_stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return FS_OK;
 }
 

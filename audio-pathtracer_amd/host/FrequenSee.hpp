@@ -109,6 +109,14 @@ public:
     // got from fs_comm_unique_id, shipped to every rank.  From then on every frame's energy buffer is summed over the
     // ranks inside the library and Commit() lets rank 0 build the tree for all.
     void CommInit(const void* Id) { Check(fs_comm_init(Ctx_, Id, FS_COMM_ID_BYTES)); }
+    // One source per GPU (cfg5): no sharding, no reduce — a peer communicator only for GatherEnergy, after which any
+    // rank can install a peer's histogram (UpdateEnergyBuffer on a mirror component) and serve its IR.
+    void PeersInit(const void* Id, int Rank, int WorldSize) { Check(fs_peers_init(Ctx_, Id, FS_COMM_ID_BYTES, Rank, WorldSize)); Peers_ = WorldSize; }
+    std::vector<float> GatherEnergy(fs_source Src) {             // [WorldSize][bands][bins], collective
+        std::vector<float> Out((size_t)Peers_ * (size_t)NumBands_ * (size_t)fs_num_bins(Ctx_));
+        Check(fs_gather_energy(Ctx_, Src, Out.data(), (int32_t)Out.size()));
+        return Out;
+    }
     // UAcousticMaterial table: Absorption [M][bands] (AcousticMaterial.h:22-30)
     void SetMaterials(const std::vector<float>& Absorption, int NumMaterials) {
         Absorption_ = Absorption; NumMaterials_ = NumMaterials; Dirty_ = true;
@@ -199,6 +207,7 @@ private:
     bool Dirty_ = true;
     bool Committed_ = false;
     int NumBands_ = 1;
+    int Peers_ = 0;
     friend class FrequenSeeAudioComponent;
     friend class MaterialAcousticProcessor;
 };

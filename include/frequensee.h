@@ -245,6 +245,19 @@ int fs_comm_unique_id(void* id_out, size_t bytes);
 int fs_comm_init(fs_context* ctx, const void* unique_id, size_t bytes);
 int fs_comm_attach(fs_context* ctx, void* nccl_comm /* ncclComm_t */);
 int fs_comm_detach(fs_context* ctx);   /* destroys a communicator made by fs_comm_init; fs_context_destroy calls it */
+/* cfg5 — independent sources, one per GPU ("optional ncclAllGather of 8 x 32 KB so any rank can serve any
+ * source's IR").  Nothing of a frame is sharded or reduced there (fs_config.world_size stays 1); a PEER communicator
+ * of the processes that each own a source serves one collective only:
+ *   every rank: fs_peers_init(ctx, id, FS_COMM_ID_BYTES, rank, world_size)        (id from fs_comm_unique_id on rank 0)
+ *   every rank: fs_gather_energy(ctx, my_source, out, world_size * B * bins)      (collective, in rank order)
+ * out[r] is the [B][bins] histogram of the source rank r passed (its current frame, behind the deposit — and behind the
+ * all-reduce on a sharded context).  To serve a peer's IR: fs_update_energy_buffer(mirror_source, out + r * B * bins, …)
+ * and fs_reconstruct_impulse_response(mirror_source) — the same energy gives the same samples on every rank.
+ * fs_gather_energy_async leaves the gathered histograms on the device, in tail-stream order (valid until the next gather). */
+int fs_peers_init(fs_context* ctx, const void* unique_id, size_t bytes, int32_t rank, int32_t world_size);
+int fs_peers_detach(fs_context* ctx);   /* fs_context_destroy calls it */
+int fs_gather_energy(fs_context* ctx, fs_source src, float* out /* host [world_size][B][bins] */, int32_t n);
+int fs_gather_energy_async(fs_context* ctx, fs_source src, void** dptr, size_t* bytes);
 /* The partition rule itself, host-only (no device needed): pairs [*pair_begin, *pair_begin + *pair_count) of a frame of
  * num_rays subpaths belong to `rank` of `world_size`. */
 int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t* pair_begin, uint32_t* pair_count);

@@ -12,10 +12,11 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 rank, world, id_file, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+mode = sys.argv[5] if len(sys.argv) > 5 else "shard"
 pkg = graft.load_package()
 assert os.environ.get("FS_RCCL_LIB"), "the worker must run on the test double"
 sc = pkg.scenes.starter_room(4)
-ctx = pkg.Context(num_bands=4, rank=rank, world_size=world)
+ctx = pkg.Context(num_bands=4, rank=rank, world_size=world) if mode == "shard" else pkg.Context(num_bands=4)
 if rank == 0:                                   # the id travels by any host-side transport: here a file
     uid = pkg.Context.comm_unique_id()
     with open(id_file + ".tmp", "wb") as f:
@@ -28,6 +29,39 @@ else:
         time.sleep(0.01)
     with open(id_file, "rb") as f:
         uid = f.read()
+if mode == "gather":
+    # cfg5's arrangement: every rank owns ONE source and traces all of its pairs; the peers only exchange histograms
+    ctx.peers_init(uid, rank, world)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx.set_listener(sc.listener)
+    my_pos = np.asarray(sc.source, np.float32) + np.float32(60.0 * rank) * np.array([1, -1, 0], np.float32)
+    src = ctx.create_source(my_pos)
+    res = {}
+    for k, flags in enumerate((0, 8)):
+        p = pkg.default_params(num_rays=8192, depth=8, seed=40 + k, flags=flags)
+        ctx.compute_energy_response_async(src, p)
+        ctx.reconstruct_impulse_response_async(src, p)
+        if k == 0:                                     # the next frame is already tracing while the gather runs
+            ctx.compute_energy_response_async(src, pkg.default_params(num_rays=2048, depth=4, seed=9))
+            ctx.reconstruct_impulse_response_async(src, pkg.default_params(num_rays=2048, depth=4, seed=9))
+        # note: gather_energy returns the CURRENT frame's histograms: gather right behind the frame that matters
+    p = pkg.default_params(num_rays=8192, depth=8, seed=41, flags=8)
+    ctx.compute_energy_response_async(src, p)
+    ctx.reconstruct_impulse_response_async(src, p)
+    allE = ctx.gather_energy(src)                      # collective: [world][B][bins]
+    ctx.synchronize()
+    res["gathered"] = allE
+    res["own_ir"] = ctx.impulse_response(src, 0).copy()
+    # serve the NEXT rank's source from here: install its histogram on a mirror source and reconstruct
+    peer = (rank + 1) % world
+    mirror = ctx.create_source(my_pos)
+    ctx.update_energy_buffer(mirror, allE[peer])
+    ctx.reconstruct_impulse_response(mirror, p)
+    res["peer_ir"] = ctx.impulse_response(mirror, 0).copy()
+    ctx.peers_detach()
+    ctx.close()
+    np.savez(out, **res)
+    sys.exit(0)
 ctx.comm_init(uid)
 # every rank registers the same triangles; rank 0 builds the tree, the others receive it (fs_scene_commit)
 ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)

@@ -89,3 +89,46 @@ def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world
             assert (num <= 2e-5 * np.sqrt((want.astype(np.float64) ** 2).sum(axis=1))).all(), r
         assert np.array_equal(rk["hit"], hit) and np.array_equal(rk["t"], t) and np.array_equal(rk["idx"], idx), r
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_one_source_per_rank_and_any_rank_serves_any_source(pkg, fake_rccl, tmp_path):
+    """cfg5's arrangement: every rank owns one source, nothing of a frame is sharded or reduced; the peer
+    communicator's all-gather hands every rank all histograms, and a histogram installed on a mirror source
+    reconstructs to exactly the IR its owner publishes."""
+    world = 3
+    env = dict(os.environ, FS_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="60")
+    id_file = str(tmp_path / "comm_id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), str(r), str(world),
+                               id_file, str(tmp_path / f"g{r}.npz"), "gather"], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for pr in procs:
+        try:
+            logs.append(pr.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, f"rank {r}:\n{logs[r][-3000:]}"
+    ranks = [np.load(tmp_path / f"g{r}.npz") for r in range(world)]
+    sc = pkg.scenes.starter_room(4)
+    ctx = pkg.Context(num_bands=4)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    ctx.set_listener(sc.listener)
+    p = pkg.default_params(num_rays=8192, depth=8, seed=41, flags=8)       # the gathered frame (deterministic: exact)
+    want = []
+    for r in range(world):
+        pos = np.asarray(sc.source, np.float32) + np.float32(60.0 * r) * np.array([1, -1, 0], np.float32)
+        src = ctx.create_source(pos)
+        want.append(ctx.compute_energy_response(src, p).copy())
+    assert not np.array_equal(want[0], want[1])                            # the sources really differ
+    for r, rk in enumerate(ranks):
+        g = rk["gathered"]
+        assert g.shape == (world, 4, ctx.num_bins)
+        for q in range(world):
+            assert np.array_equal(g[q], want[q]), (r, q)                  # every rank holds every source's histogram
+        assert np.abs(rk["own_ir"]).max() > 0
+        assert np.array_equal(rk["peer_ir"], ranks[(r + 1) % world]["own_ir"]), r   # ... and serves the peer's IR
+    ctx.close()
