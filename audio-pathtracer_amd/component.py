@@ -101,6 +101,13 @@ class Context:
         self.check(self.lib.fs_gather_energy(self.h, int(src), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out
 
+    def set_pipelining(self, on: bool):
+        """hold every frame's connect pass back and launch it with the next frame's walk (include/frequensee.h)"""
+        self.check(self.lib.fs_set_pipelining(self.h, 1 if on else 0))
+
+    def submit(self):
+        self.check(self.lib.fs_submit(self.h))
+
     def gather_energy_async(self, src: int):
         """enqueue only: (device pointer, bytes) of the gathered [world_size][B][bins] histograms, in tail-stream order"""
         d, b = C.c_void_p(), C.c_size_t()

@@ -24,16 +24,21 @@ namespace {
 
 constexpr int kIrRing = 3;  // published IR ring: a returned pointer stays valid until the second-next publish
 
+// Energy buffers per source, used in rotation: frame f deposits into one while the tail stream still reduces /
+// reconstructs frame f - 1 from another; pipelined frames finish frame f - 1 only after the walk of frame f, so that
+// frame f + 1 needs a third one to start without waiting for that tail.
+constexpr int kEnergyBufs = 3;
+
 struct Source {
     bool alive = false;
     float pos[3] = {0, 0, 0};
     // Two energy buffers [B][bins], alternating per frame: while the tail stream still reduces /
     // reconstructs frame f from one of them, the compute stream already traces frame f+1 into the other.
-    float* d_energy[2] = {nullptr, nullptr};
+    float* d_energy[kEnergyBufs] = {nullptr, nullptr, nullptr};
     int cur = 0;                       // buffer of the current frame (rotates in fs_compute_energy_response*)
     hipEvent_t ev_dep = nullptr;       // compute stream: everything that writes the current buffer is enqueued
-    hipEvent_t ev_rec[2] = {nullptr, nullptr};   // tail stream: the reconstruct that read buffer i is done
-    bool rec_recorded[2] = {false, false};
+    hipEvent_t ev_rec[kEnergyBufs] = {nullptr, nullptr, nullptr};   // tail stream: the reconstruct that read buffer i is done
+    bool rec_recorded[kEnergyBufs] = {false, false, false};
     int last_rec = -1;                 // buffer the newest reconstruct read (its event also guards d_ir_*)
     hipEvent_t ev_rev = nullptr;       // reverb stream: the newest reverb callback has read d_ir_mono
     bool rev_recorded = false;
@@ -45,11 +50,11 @@ struct Source {
     // multi-GPU: the frame in the current buffer has been summed over the ranks (library collective), or handed to the
     // caller's collective (fs_energy_handoff); a world_size > 1 context refuses to reconstruct a frame that is neither
     bool reduced = false, handed_off = false;
-    hipEvent_t ev_red[2] = {nullptr, nullptr};   // tail stream: the library's all-reduce of buffer i is done
-    bool red_recorded[2] = {false, false};
+    hipEvent_t ev_red[kEnergyBufs] = {nullptr, nullptr, nullptr};   // tail stream: the library's all-reduce of buffer i is done
+    bool red_recorded[kEnergyBufs] = {false, false, false};
     // deterministic mode (FS_FLAG_DETERMINISTIC): u64 fixed-point histograms [B][bins], allocated on first use,
     // alternating like the energy buffers; cur_fixed = the current frame deposited into d_fixed[cur]
-    unsigned long long* d_fixed[2] = {nullptr, nullptr};
+    unsigned long long* d_fixed[kEnergyBufs] = {nullptr, nullptr, nullptr};
     bool cur_fixed = false;
     float* d_ir_bands = nullptr;  // [B][samples]
     float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
@@ -128,6 +133,21 @@ struct fs_context {
     ncclComm_t peers = nullptr;
     int peers_size = 0;
     float* d_gather = nullptr; size_t gather_cap = 0;   // [peers][B][bins] fp32
+    // Pipelined frames (fs_set_pipelining): the connect pass of frame f is held back and launched together with the walk
+    // of frame f + 1 as ONE kernel (launch_frame) — or alone, as soon as anything needs frame f's result (flush_pending).
+    struct PipeFrame {
+        bool has = false;
+        KParams kp; SubpathState st;
+        Source* s = nullptr;
+        bool fixed = false;
+        int cur = 0;                 // which of the source's two energy buffers the frame deposits into
+        unsigned* scratch = nullptr; // the frame's scratch set (its connect pass re-arms it)
+        int ppw = 64;
+        bool want_recon = false;     // fs_reconstruct_impulse_response_async arrived while the frame was pending
+        fs_params recon;
+    } pipe;
+    bool pipelining = false;
+    unsigned frame_parity = 0;       // consecutive traced frames alternate between the two state / scratch sets
     bool comm_owned = false;           // created by fs_comm_init (destroyed with the context) vs attached by the caller
 
     // subpath state (sized on demand)
@@ -177,6 +197,14 @@ struct fs_context {
     }
 };
 
+// pipelined frames: launch a held-back connect pass on its own (defined next to trace_sources)
+static int flush_pending(fs_context* ctx);
+#define FS_FLUSH(ctx)                       \
+    do {                                    \
+        int fr_ = flush_pending(ctx);       \
+        if (fr_) return fr_;                \
+    } while (0)
+
 #define FS_HIP(ctx, call)                                        \
     do {                                                         \
         hipError_t e_ = (call);                                  \
@@ -213,13 +241,13 @@ void free_source(fs_context* ctx, Source* s) {
     if (!s) return;
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->cfg.device);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kEnergyBufs; ++i) {
             if (s->d_energy[i]) (void)hipFree(s->d_energy[i]);
             if (s->d_fixed[i]) (void)hipFree(s->d_fixed[i]);
             if (s->ev_rec[i]) (void)hipEventDestroy(s->ev_rec[i]);
         }
         if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
-        for (int i = 0; i < 2; ++i) if (s->ev_red[i]) (void)hipEventDestroy(s->ev_red[i]);
+        for (int i = 0; i < kEnergyBufs; ++i) if (s->ev_red[i]) (void)hipEventDestroy(s->ev_red[i]);
         if (s->ev_rev) (void)hipEventDestroy(s->ev_rev);
         if (s->d_ir_bands) (void)hipFree(s->d_ir_bands);
         if (s->d_ir_mono) (void)hipFree(s->d_ir_mono);
@@ -352,9 +380,10 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
         ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr; ctx->st.slot_of = nullptr;
         ctx->walk.perm = nullptr;
         ctx->cap_lanes = 0;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * lanes));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * lanes));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.slot_of, sizeof(uint32_t) * lanes));
+        // two sets of everything a frame's walk hands to its connect pass: pipelined frames overlap walk f + 1 with connect f
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * 2 * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * 2 * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.slot_of, sizeof(uint32_t) * 2 * lanes));
         ctx->cap_seg = 0;   // the bucket array is sized with the segment records below
         ctx->cap_lanes = lanes;
     }
@@ -363,8 +392,8 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
         if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
         ctx->st.seg_np = nullptr; ctx->st.seg_mat = nullptr;
         ctx->cap_seg = 0;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_np, sizeof(float2) * seg));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_mat, sizeof(uint32_t) * seg));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_np, sizeof(float2) * 2 * seg));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_mat, sizeof(uint32_t) * 2 * seg));
         if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
         ctx->walk.perm = nullptr;
         // [levels + 1][lanes] for every later frame shape that fits the two capacities without a reallocation:
@@ -553,8 +582,8 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_CONNECT_PAIRS_PER_WAVE")) ctx->connect_pairs_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
-    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchAllocWords);
-    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchAllocWords);
+    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * 2 * kScratchAllocWords);   // two sets, each with its counters
+    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * 2 * kScratchAllocWords);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
     ctx->device_ok = true;
     return FS_OK;
@@ -564,6 +593,7 @@ int fs_context_destroy(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->cfg.device);
+        (void)flush_pending(ctx);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
         if (ctx->rev_stream) (void)hipStreamSynchronize(ctx->rev_stream);
@@ -718,6 +748,7 @@ int fs_comm_init(fs_context* ctx, const void* unique_id, size_t bytes) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!unique_id || bytes != FS_COMM_ID_BYTES) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "unique id must be FS_COMM_ID_BYTES bytes");
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     if (ctx->comm) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a communicator is already attached");
     RcclApi* a = rccl();
     if (!a) return ctx->fail(FS_ERR_COMM, rccl() ? "" : "librccl is not loadable (set FS_RCCL_LIB)");
@@ -733,6 +764,7 @@ int fs_comm_attach(fs_context* ctx, void* nccl_comm) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!nccl_comm) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "null communicator");
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     if (ctx->comm) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a communicator is already attached");
     RcclApi* a = rccl();
     if (!a) return ctx->fail(FS_ERR_COMM, "librccl is not loadable (set FS_RCCL_LIB)");
@@ -748,6 +780,7 @@ int fs_comm_attach(fs_context* ctx, void* nccl_comm) {
 
 int fs_comm_detach(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     if (!ctx->comm) return FS_OK;
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->cfg.device);
@@ -793,6 +826,7 @@ int fs_peers_detach(fs_context* ctx) {
 int fs_gather_energy_async(fs_context* ctx, fs_source h, void** dptr, size_t* bytes) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (!ctx->peers) return ctx->fail(FS_ERR_COMM, "fs_gather_energy needs fs_peers_init first");
@@ -932,6 +966,7 @@ static void finish_commit(fs_context* ctx, size_t scene_bytes) {
 int fs_scene_commit(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
@@ -1024,6 +1059,7 @@ int fs_scene_commit(fs_context* ctx) {
 int fs_scene_commit_fast(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     if (ctx->T < 1 || ctx->comm) return fs_scene_commit(ctx);   // empty scene / sharded run: the one build rank 0 broadcasts
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1098,6 +1134,7 @@ int fs_scene_commit_fast(fs_context* ctx) {
 int fs_scene_update_triangles(fs_context* ctx, int32_t first, int32_t count, const float* xyz) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
     if (first < 0 || count < 0 || (int64_t)first + count > ctx->T || (count > 0 && !xyz))
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "triangle range outside the committed scene");
@@ -1126,6 +1163,7 @@ int fs_scene_update_triangles(fs_context* ctx, int32_t first, int32_t count, con
 int fs_scene_refit(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
     ctx->refit_pending = false;
     if (ctx->bvh.nodes.empty()) return FS_OK;
@@ -1153,7 +1191,7 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         return rc;
     };
     hipError_t e;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kEnergyBufs; ++i) {
         if ((e = hipMalloc((void**)&s->d_energy[i], eb)) != hipSuccess) return bail(e, "hipMalloc(energy)");
         if ((e = hipMemsetAsync(s->d_energy[i], 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
         if ((e = hipEventCreateWithFlags(&s->ev_rec[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -1168,7 +1206,7 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
     if ((e = hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kEnergyBufs; ++i)
         if ((e = hipEventCreateWithFlags(&s->ev_red[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&s->ev_rev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     // the initial fills above ran on the compute stream; the first reconstruct runs on the tail stream
@@ -1184,6 +1222,7 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
 
 int fs_source_destroy(fs_context* ctx, fs_source h) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (ctx->device_ok) {
@@ -1232,6 +1271,38 @@ static int check_overflow(fs_context* ctx) {
                      " steps; the record tier has been grown — trace the frame again");
 }
 
+static int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
+
+// ---- pipelined frames ---------------------------------------------------------------------------------------------
+// What a held-back frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum
+// over the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to its
+// next frame (cur toggled): the per-frame fields are switched back for the duration.
+static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
+    Source* s = q.s;
+    const bool moved_on = s->cur != q.cur;
+    const int cur = s->cur;
+    const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off;
+    s->cur = q.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
+    int rc = FS_OK;
+    if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
+    if (ctx->comm) rc = reduce_energy(ctx, s);
+    if (!rc && q.want_recon) rc = reconstruct_now(ctx, s, &q.recon);
+    if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; }
+    return rc;
+}
+
+// Launch the held-back connect pass on its own: something needs the frame's result now.
+static int flush_pending(fs_context* ctx) {
+    if (!ctx->pipe.has) return FS_OK;
+    const fs_context::PipeFrame q = ctx->pipe;
+    ctx->pipe.has = false;
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.s->d_energy[q.cur], q.fixed ? q.s->d_fixed[q.cur] : nullptr,
+                   q.scratch, q.ppw, nullptr, nullptr, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    return finish_held_frame(ctx, q);
+}
+
 static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
     Source* s = srcs[0];
     const bool batch = count > 1;
@@ -1239,6 +1310,11 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     int rc = check_params(ctx, p);
     if (rc) return rc;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    // Pipelined frames: this frame's connect pass is held back (to be launched with the next frame's walk) when the
+    // frame has the default shape; any other frame first lets the held-back one finish on its own.
+    const bool pipe_ok = ctx->pipelining && count == 1 && ctx->profiling < 2 && p->depth > 0 &&
+                         !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY));
+    if (!pipe_ok) FS_FLUSH(ctx);
 
     const int B = ctx->cfg.num_bands;
     const uint64_t P = p->num_rays / 2;
@@ -1281,9 +1357,17 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     const bool mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
     const bool all_conn = mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
     kp.mis = mis ? 1 : 0;
+    if (ctx->pipe.has && (2 * (size_t)kp.num_local > ctx->cap_lanes || (size_t)levels * 2 * (size_t)kp.num_local > ctx->cap_seg))
+        FS_FLUSH(ctx);   // the state arrays are about to be reallocated: the held-back frame still reads them
     rc = ensure_state(ctx, kp.num_local, levels, unbounded, all_conn, mis);
     if (rc) return rc;
     SubpathState st = ctx->st;
+    const int set = (int)(ctx->frame_parity++ & 1u);   // consecutive frames alternate between the two state / scratch sets
+    if (set) {
+        st.end_pos += ctx->cap_lanes; st.end_misc += ctx->cap_lanes; st.slot_of += ctx->cap_lanes;
+        st.seg_np += ctx->cap_seg; st.seg_mat += ctx->cap_seg;
+    }
+    unsigned* const scratch = ctx->walk.queue_head + (size_t)set * kScratchAllocWords;
     st.seg_pos = all_conn ? ctx->d_seg_pos : nullptr;
     st.seg_nrm = mis ? ctx->d_seg_pos + (size_t)levels * 2 * (size_t)kp.num_local : nullptr;
     st.main_levels = levels;
@@ -1312,14 +1396,14 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     for (int i = 0; i < count; ++i) {
         Source* si = srcs[i];
         if (fixed && !si->d_fixed[0]) {
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < kEnergyBufs; ++k) {
                 FS_HIP(ctx, hipMalloc((void**)&si->d_fixed[k], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
                 FS_HIP(ctx, hipMemsetAsync(si->d_fixed[k], 0, sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
             }
         }
         // this frame deposits into the other buffer; the tail may still be busy with the last one.  (FS_FLAG_ACCUMULATE_ENERGY
         // stays in the buffer of the previous frame — behind its reduce / reconstruct — and adds to what it holds.)
-        if (!accumulate) si->cur ^= 1;
+        if (!accumulate) si->cur = (si->cur + 1) % kEnergyBufs;
         si->cur_fixed = fixed;
         si->reduced = false; si->handed_off = false;
         FS_HIP(ctx, wait_energy_readers(ctx, si));
@@ -1371,6 +1455,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         if (!accumulate) zero_tab = fixed ? reinterpret_cast<float* const*>(fixed_tab) : energy_tab;
     }
     WalkLaunch wplan = ctx->walk;
+    wplan.queue_head = scratch;
     if (unbounded) wplan.plan = 1;   // the second record tier relies on the schedule: the longest walks own the lowest slots
     const bool plan_zeroes = kp.russian_roulette && 2u * kp.num_local > 0;   // launch_plan runs its pass (and the flush with it)
     const uint32_t* perm = launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
@@ -1385,15 +1470,41 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
     if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     WalkLaunch wl = ctx->walk;
+    wl.queue_head = scratch;
     wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
-    launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
-    if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+    const int ppw = ctx->connect_pairs_per_wave > 0 ? ctx->connect_pairs_per_wave : auto_pairs_per_wave(kp.num_local);
+    if (ctx->pipe.has) {   // (pipe_ok: anything else has flushed it above) this walk and the held-back connect pass as ONE launch
+        const fs_context::PipeFrame q = ctx->pipe;
+        ctx->pipe.has = false;
+        float* q_energy = q.s->d_energy[q.cur];
+        unsigned long long* q_fixed = q.fixed ? q.s->d_fixed[q.cur] : nullptr;
+        if (!launch_frame(B, ctx->scene, kp, st, wl, perm, q.kp, q.st, q_energy, q_fixed, q.scratch, q.ppw, ctx->stream)) {
+            launch_connect(B, ctx->scene, q.kp, q.st, q_energy, q_fixed, q.scratch, q.ppw, nullptr, nullptr, ctx->stream);
+            launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+        }
+        if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+        FS_HIP(ctx, hipGetLastError());
+        rc = finish_held_frame(ctx, q);
+        if (rc) return rc;
+    } else {
+        launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+        if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+    }
+    if (pipe_ok) {   // hold this frame's connect pass back
+        fs_context::PipeFrame& q = ctx->pipe;
+        q.has = true; q.kp = kp; q.st = st; q.s = s; q.fixed = fixed; q.cur = s->cur; q.scratch = scratch; q.ppw = ppw;
+        q.want_recon = false;
+        FS_HIP(ctx, hipGetLastError());
+        if (timed_frame) { tf.has_trace = true; ctx->pending.push_back(tf); }
+        ctx->stats.frames++;
+        ctx->stats.pairs += kp.num_local;
+        ctx->stats.rays += 2ull * kp.num_local;
+        return FS_OK;
+    }
     if (all_conn)
-        launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
-                           ctx->stream);
+        launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, scratch, ctx->stream);
     else
-        launch_connect(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, ctx->walk.queue_head,
-                       ctx->connect_pairs_per_wave > 0 ? ctx->connect_pairs_per_wave : auto_pairs_per_wave(kp.num_local),
+        launch_connect(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, scratch, ppw,
                        energy_tab, fixed_tab, ctx->stream);
     if (fixed)
         for (int i = 0; i < count; ++i)
@@ -1454,6 +1565,7 @@ int fs_compute_energy_response(fs_context* ctx, fs_source h, const fs_params* p,
     for (int attempt = 0; attempt < 4; ++attempt) {   // depth = 0: a frame whose records overflowed is traced again
         rc = fs_compute_energy_response_async(ctx, h, p);
         if (rc) return rc;
+        FS_FLUSH(ctx);   // the caller waits for this frame: no point in holding its connect pass back
         if (!ctx->overflow_armed) break;
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         rc = check_overflow(ctx);
@@ -1476,6 +1588,7 @@ int fs_compute_energy_response(fs_context* ctx, fs_source h, const fs_params* p,
 
 int fs_energy_device_ptr(fs_context* ctx, fs_source h, void** dptr, size_t* bytes) {
     if (!ctx || !dptr) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     *dptr = s->energy();
@@ -1486,6 +1599,7 @@ int fs_energy_device_ptr(fs_context* ctx, fs_source h, void** dptr, size_t* byte
 int fs_energy_handoff(fs_context* ctx, fs_source h, void** dptr, size_t* bytes, void** tail_stream) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
@@ -1506,6 +1620,20 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     fs_params def;
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    // pipelined frames: the source's current frame still waits for its connect pass — the reconstruct goes with it
+    if (ctx->pipe.has && ctx->pipe.s == s && !ctx->pipe.want_recon && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) &&
+        (ctx->cfg.world_size == 1 || ctx->comm)) {
+        ctx->pipe.want_recon = true;
+        ctx->pipe.recon = *p;
+        return FS_OK;
+    }
+    FS_FLUSH(ctx);
+    return reconstruct_now(ctx, s, p);
+}
+
+}  // extern "C"
+
+static int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     // ReconstructImpulseResponse is not linear in the energy (a = e / sqrt(e * Pi4)): the IR of a rank's PARTIAL
     // histogram is not a partial IR.  A sharded context only reconstructs a frame that was summed over the ranks — by
     // the library (fs_comm_init / fs_comm_attach) or by the caller's collective on the tail stream (fs_energy_handoff).
@@ -1570,9 +1698,12 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     return FS_OK;
 }
 
+extern "C" {
+
 int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32_t n) {
     if (!ctx || !ir) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
@@ -1612,6 +1743,7 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
 int fs_synchronize(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
@@ -1651,6 +1783,7 @@ int fs_copy_impulse_response(fs_context* ctx, fs_source h, int32_t channel, floa
 int fs_copy_band_impulse_response(fs_context* ctx, fs_source h, int32_t band, float* out, int32_t n) {
     if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
@@ -1667,6 +1800,7 @@ int fs_copy_band_impulse_response(fs_context* ctx, fs_source h, int32_t band, fl
 int fs_get_energy_buffer(fs_context* ctx, fs_source h, float* out, int32_t n) {
     if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
@@ -1680,6 +1814,7 @@ int fs_get_energy_buffer(fs_context* ctx, fs_source h, float* out, int32_t n) {
 int fs_flush_energy_buffer(fs_context* ctx, fs_source h) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
@@ -1694,6 +1829,7 @@ int fs_flush_energy_buffer(fs_context* ctx, fs_source h) {
 int fs_add_energy_at_delay(fs_context* ctx, fs_source h, int32_t band, float delay_seconds, float energy) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
@@ -1710,6 +1846,7 @@ int fs_add_energy_at_delay(fs_context* ctx, fs_source h, int32_t band, float del
 int fs_update_energy_buffer(fs_context* ctx, fs_source h, const float* values, int32_t n) {
     if (!ctx || !values) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     // check(NewEnergyValues.Num() == NumBins) FSAC.h:83 -> status instead of abort
@@ -1908,6 +2045,7 @@ int fs_load_float_array(const char* path, float* out, int32_t cap, int32_t* n_ou
 
 int fs_save_impulse_response(fs_context* ctx, fs_source h, int32_t channel, const char* path) {
     if (!ctx || !path) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     const float* p = nullptr;
     int32_t n = 0;
     int rc = fs_get_impulse_response(ctx, h, channel, &p, &n);
@@ -2097,8 +2235,22 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
 }
 
 // ---- measurement ----------------------------------------------------------------------------------------------
+int fs_set_pipelining(fs_context* ctx, int32_t on) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!on) FS_FLUSH(ctx);
+    ctx->pipelining = on != 0;
+    return FS_OK;
+}
+
+int fs_submit(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    return flush_pending(ctx);
+}
+
 int fs_set_profiling(fs_context* ctx, int32_t enabled) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     ctx->profiling = enabled < 0 ? 0 : (enabled > 3 ? 3 : enabled);
     return FS_OK;
 }
@@ -2112,6 +2264,7 @@ int fs_set_profiling_interval(fs_context* ctx, int32_t frames) {
 
 int fs_get_stats(fs_context* ctx, fs_stats* out) {
     if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     if (ctx->device_ok && !ctx->pending.empty()) {
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2119,10 +2272,12 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         resolve_timings(ctx);
     }
     if (ctx->device_ok && ctx->walk.queue_head) {   // work counters kept on the device since the last reset
-        unsigned long long c[kNumCounters] = {0};
+        unsigned long long c[kNumCounters] = {0}, c1[kNumCounters] = {0};   // each scratch set carries its own counters
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
         FS_HIP(ctx, hipMemcpyAsync(c, ctx->walk.queue_head + kCounterWord, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        FS_HIP(ctx, hipMemcpyAsync(c1, ctx->walk.queue_head + kScratchAllocWords + kCounterWord, sizeof(c1), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < kNumCounters; ++k) c[k] += c1[k];
         ctx->stats.segments = c[0] + ctx->host_segments;
         ctx->stats.connections_tested = c[1];
         ctx->stats.deposits = c[2];
@@ -2137,6 +2292,7 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
 
 int fs_reset_stats(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
     fs_stats keep = ctx->stats;
     ctx->stats = fs_stats{};
     ctx->host_segments = 0;
@@ -2147,7 +2303,9 @@ int fs_reset_stats(fs_context* ctx) {
     ctx->stats.scene_bytes = keep.scene_bytes;
     if (ctx->device_ok && ctx->walk.queue_head) {
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-        FS_HIP(ctx, hipMemsetAsync(ctx->walk.queue_head + kCounterWord, 0, sizeof(unsigned long long) * kNumCounters, ctx->stream));
+        for (int k = 0; k < 2; ++k)
+            FS_HIP(ctx, hipMemsetAsync(ctx->walk.queue_head + (size_t)k * kScratchAllocWords + kCounterWord, 0,
+                                       sizeof(unsigned long long) * kNumCounters, ctx->stream));
     }
     return FS_OK;
 }

@@ -172,6 +172,12 @@ constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // buffers instead (batched frame).  Returns nullptr — and zeroes nothing — when there is no roulette to plan for.
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
                             float* const* energy_tab, int energy_count, hipStream_t s);
+// Pipelined frames: ONE launch whose first workgroups walk frame f + 1 (kpw, stw, wl, perm) while the others connect
+// frame f (kpc, stc, energy / fixed, scratch_c).  false = no fused form for this shape (lobes, counting instantiations,
+// experiment walk variants): the caller launches the two kernels one after the other.
+bool launch_frame(int B, const DeviceScene& sc, const KParams& kpw, const SubpathState& stw, const WalkLaunch& wl,
+                  const uint32_t* perm, const KParams& kpc, const SubpathState& stc, float* energy,
+                  unsigned long long* fixed, unsigned* scratch_c, int pairs_per_wave, hipStream_t s);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead

@@ -934,9 +934,9 @@ __device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_co
 }
 
 template <int LOBES, bool COUNT>
-__global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
-                                                             const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm) {
+__device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
+                                                 const SubpathState& st, const unsigned* __restrict__ scratch,
+                                                 const uint32_t* __restrict__ perm) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
         for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
     }
     if (perm) __syncthreads();
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t slot = bid * kBlock + threadIdx.x;
     if (slot >= 2u * kp.num_local) return;
     const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
     int* stack = &s_stack[threadIdx.x];
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
             trav_max = max(trav_max, (unsigned long long)__shfl_xor((long long)trav_max, o));
         }
         if ((threadIdx.x & 63u) == 0u && g_wave_buf) {
-            unsigned long long* o = g_wave_buf + 8ull * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+            unsigned long long* o = g_wave_buf + 8ull * (bid * (kBlock / 64) + (threadIdx.x >> 6));
             o[0] = tl_r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = trav_max;
             o[3] = __builtin_amdgcn_s_memtime() - tl_c0; o[4] = 0; o[5] = seg_max;
             o[6] = __builtin_amdgcn_s_getreg(((8 - 1) << 11) | (0 << 6) | 4)            // HW_REG_HW_ID bits [7:0]
@@ -990,14 +990,21 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KPa
 #endif
 }
 
+template <int LOBES, bool COUNT>
+__global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
+                                                             const uint32_t* __restrict__ perm) {
+    walk_shared_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm);
+}
+
 // Small frames on sparse waves: a frame of a few thousand subpaths is a handful of waves and takes the latency of
 // its longest chain of closest-hit queries.  Here a wave owns only `rays_per_wave` subpaths (its first lanes) and
 // the other lanes help with every query — the legacy tracer's scheme (update_sound_shared_kernel).  The loop is
 // wave-uniform: lanes whose walk has ended (or that never had one) keep calling the shared traversal as helpers.
 template <int LOBES, bool COUNT>
-__global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
-                                                             const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm, int rays_per_wave) {
+__device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
+                                                 const SubpathState& st, const unsigned* __restrict__ scratch,
+                                                 const uint32_t* __restrict__ perm, const int rays_per_wave) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t wave = bid * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
     bool alive = lane < (uint32_t)rays_per_wave && slot < 2u * kp.num_local;
     int* stack = &s_stack[threadIdx.x];
@@ -1027,6 +1034,13 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 }
 
+template <int LOBES, bool COUNT>
+__global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
+                                                             const uint32_t* __restrict__ perm, int rays_per_wave) {
+    walk_sparse_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // connect_kernel: ConnectSubpaths + EvaluatePath + clamp/gain + deposit
 // ---------------------------------------------------------------------------------------------------
@@ -1037,11 +1051,11 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
 // (kp.pairs_per_source each) and every source has its own energy buffer (energy_tab / fixed_tab); a workgroup
 // takes (source, chunk) items and flushes its LDS histogram whenever the source changes.
 template <int B, int LOBES, bool BATCH, bool COUNT>
-__global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
-                                                         float* __restrict__ energy,
-                                                         unsigned long long* __restrict__ fixed, unsigned* queue_head,
-                                                         int pairs_per_wave, float* const* __restrict__ energy_tab,
-                                                         unsigned long long* const* __restrict__ fixed_tab) {
+__device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t nblocks, const DeviceScene& sc,
+                                             const KParams& kp, const SubpathState& st, float* __restrict__ energy,
+                                             unsigned long long* __restrict__ fixed, unsigned* queue_head,
+                                             const int pairs_per_wave, float* const* __restrict__ energy_tab,
+                                             unsigned long long* const* __restrict__ fixed_tab) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][hist_window] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
@@ -1055,7 +1069,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     for (int i = threadIdx.x; i < B * W; i += kBlock) s_hist[i] = 0.0f;
     if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; }
     // this frame's walk is over: rearm the frame scratch (queue head, plan counts and cursors) for the next one
-    if (blockIdx.x == 0)
+    if (bid == 0u)
         for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
     __syncthreads();
 
@@ -1164,7 +1178,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         const uint32_t nps = kp.pairs_per_source, sources = n / nps;
         const uint32_t chunks = (nps + per_block - 1) / per_block;   // per source
         int cur = -1;
-        for (uint32_t it = blockIdx.x; it < chunks * sources; it += gridDim.x) {
+        for (uint32_t it = bid; it < chunks * sources; it += nblocks) {
             const uint32_t sid = it / chunks;
             if ((int)sid != cur) {
                 if (cur >= 0 && !fixed_tab) flush(energy_tab[cur], true);
@@ -1175,7 +1189,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
         }
         if (cur >= 0 && !fixed_tab) flush(energy_tab[cur], false);
     } else {
-        for (uint32_t base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) chunk(base, n, fixed, energy);
+        for (uint32_t base = bid * per_block; base < n; base += nblocks * per_block) chunk(base, n, fixed, energy);
     }
 #ifdef FS_WAVE_TIMELINE
     tl[3] = __builtin_amdgcn_s_memrealtime();   // all chunks evaluated and deposited into LDS
@@ -1191,7 +1205,7 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     if (threadIdx.x == 0) {
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
         if (s_dep) atomicAdd(&counters[2], (unsigned long long)s_dep);
-        if (blockIdx.x == 0) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
+        if (bid == 0u) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
     }
     if (!BATCH) {
         const int lo = s_lo, hi = s_hi;
@@ -1206,11 +1220,40 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     }
 #ifdef FS_WAVE_TIMELINE
     if ((threadIdx.x & 63u) == 0u && g_conn_buf) {
-        unsigned long long* o = g_conn_buf + 8ull * (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+        unsigned long long* o = g_conn_buf + 8ull * (bid * (kBlock / 64) + (threadIdx.x >> 6));
         o[0] = tl[0]; o[1] = tl[1]; o[2] = tl[2]; o[3] = tl[3]; o[4] = __builtin_amdgcn_s_memrealtime();
         o[5] = my_deposits; o[6] = 0; o[7] = 0;
     }
 #endif
+}
+
+template <int B, int LOBES, bool BATCH, bool COUNT>
+__global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
+                                                         float* __restrict__ energy,
+                                                         unsigned long long* __restrict__ fixed, unsigned* queue_head,
+                                                         int pairs_per_wave, float* const* __restrict__ energy_tab,
+                                                         unsigned long long* const* __restrict__ fixed_tab) {
+    connect_body<B, LOBES, BATCH, COUNT>(blockIdx.x, gridDim.x, sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);
+}
+
+// One launch for two frames: workgroups [0, walk_blocks) walk the subpaths of frame f + 1, the others connect the
+// pairs of frame f (its walk ended with the previous launch) — the thin single round of the connect kernel and the
+// thin tail of the walk's longest waves fill each other's idle wave slots.  The two frames share nothing but the
+// scene: each has its own subpath state, frame scratch and energy buffer (fs_capi.cpp: pipelined frames).
+template <int B>
+__global__ __launch_bounds__(kBlock) void frame_kernel(DeviceScene sc, uint32_t walk_blocks, KParams kpw, SubpathState stw,
+                                                       const unsigned* __restrict__ scratch_w,
+                                                       const uint32_t* __restrict__ perm, int rays_per_wave,
+                                                       KParams kpc, SubpathState stc, float* __restrict__ energy,
+                                                       unsigned long long* __restrict__ fixed, unsigned* scratch_c,
+                                                       int pairs_per_wave) {
+    if (blockIdx.x < walk_blocks) {   // (walks first: starting the connect pass before the short walks measured slower)
+        if (rays_per_wave < 64) walk_sparse_body<0, false>(blockIdx.x, sc, kpw, stw, scratch_w, perm, rays_per_wave);
+        else walk_shared_body<0, false>(blockIdx.x, sc, kpw, stw, scratch_w, perm);
+    } else {
+        connect_body<B, 0, false, false>(blockIdx.x - walk_blocks, gridDim.x - walk_blocks, sc, kpc, stc, energy, fixed,
+                                         scratch_c, pairs_per_wave, nullptr, nullptr);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1858,6 +1901,41 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
     hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, sort ? wl.perm : nullptr, energy,
                        energy_words, energy_tab, energy_count);
     return sort ? wl.perm : nullptr;
+}
+
+namespace {
+template <int B>
+void launch_frame_t(const DeviceScene& sc, uint32_t walk_blocks, uint32_t connect_blocks, size_t lds, const KParams& kpw,
+                    const SubpathState& stw, const unsigned* scratch_w, const uint32_t* perm, int rays_per_wave,
+                    const KParams& kpc, const SubpathState& stc, float* energy, unsigned long long* fixed,
+                    unsigned* scratch_c, int pairs_per_wave, hipStream_t s) {
+    allow_lds(frame_kernel<B>, lds);
+    hipLaunchKernelGGL(frame_kernel<B>, dim3(walk_blocks + connect_blocks), dim3(kBlock), lds, s, sc, walk_blocks, kpw, stw,
+                       scratch_w, perm, rays_per_wave, kpc, stc, energy, fixed, scratch_c, pairs_per_wave);
+}
+}  // namespace
+
+bool launch_frame(int B, const DeviceScene& sc, const KParams& kpw, const SubpathState& stw, const WalkLaunch& wl,
+                  const uint32_t* perm, const KParams& kpc, const SubpathState& stc, float* energy,
+                  unsigned long long* fixed, unsigned* scratch_c, int pairs_per_wave, hipStream_t s) {
+    const uint32_t lanes = 2u * kpw.num_local;
+    if (lanes == 0 || kpc.num_local == 0 || !FS_SHARED_WALK(wl)) return false;
+    if (kpw.lobes || kpw.count || kpc.lobes || kpc.count) return false;   // the default instantiations only
+    int rpw = wl.rays_per_wave > 0 && wl.rays_per_wave < 64 ? wl.rays_per_wave : 64;
+    const uint32_t waves = (lanes + (uint32_t)rpw - 1) / (uint32_t)rpw;
+    const uint32_t walk_blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
+    if (pairs_per_wave < 1 || pairs_per_wave > 64) pairs_per_wave = 64;
+    const uint32_t per_block = (uint32_t)pairs_per_wave * (kBlock / 64);
+    uint32_t connect_blocks = (kpc.num_local + per_block - 1) / per_block;
+    if (connect_blocks > 1024) connect_blocks = 1024;
+    const size_t lds = stack_bytes(sc) + std::max(kShareLdsBytes, sizeof(float) * (size_t)B * (size_t)kpc.hist_window + kShareAnyLdsBytes);
+    switch (B) {
+#define FS_CASE(N) case N: launch_frame_t<N>(sc, walk_blocks, connect_blocks, lds, kpw, stw, wl.queue_head, perm, rpw, kpc, stc, energy, fixed, scratch_c, pairs_per_wave, s); break;
+        FS_CASE(1) FS_CASE(2) FS_CASE(3) FS_CASE(4) FS_CASE(5) FS_CASE(6) FS_CASE(7)
+        default: launch_frame_t<8>(sc, walk_blocks, connect_blocks, lds, kpw, stw, wl.queue_head, perm, rpw, kpc, stc, energy, fixed, scratch_c, pairs_per_wave, s); break;
+#undef FS_CASE
+    }
+    return true;
 }
 
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,

@@ -214,7 +214,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source src, const fs_pa
  * only once in the list. */
 int fs_compute_energy_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 /* Device pointer of the energy buffer [B][num_bins] fp32 the source's CURRENT frame deposits into.  A source
- * owns two such buffers and every fs_compute_energy_response* switches to the other one, so that the tail of
+ * owns three such buffers and every fs_compute_energy_response* moves on to the next one, so that the tail of
  * frame f (reduce, reconstruct, publish) overlaps the tracing of frame f+1: query the pointer per frame. */
 int fs_energy_device_ptr(fs_context* ctx, fs_source src, void** dptr, size_t* bytes);
 /* Multi-GPU hook (one sum all-reduce of [B][1000] fp32 between ARTS.cpp:173 and :192).  Hands
@@ -261,6 +261,20 @@ int fs_gather_energy_async(fs_context* ctx, fs_source src, void** dptr, size_t* 
 /* The partition rule itself, host-only (no device needed): pairs [*pair_begin, *pair_begin + *pair_count) of a frame of
  * num_rays subpaths belong to `rank` of `world_size`. */
 int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t* pair_begin, uint32_t* pair_count);
+
+/* Pipelined frames (off by default).  A frame is three passes in a row — plan, walk, connect — and the last two leave
+ * wave slots idle that the other could use: the walk's longest waves end in a thin tail, the connect pass is one thin
+ * round.  With pipelining on, fs_compute_energy_response_async HOLDS BACK the connect pass of its frame and the next
+ * call launches it together with its own walk as one kernel (the two frames share nothing but the scene: two sets of
+ * subpath state and frame scratch).  A held-back frame's fs_reconstruct_impulse_response_async is recorded and runs
+ * right behind its connect pass.  Everything that observes, synchronises or changes what a held-back frame needs
+ * (fs_synchronize, the blocking variants, energy / stats / scene / communicator calls, fs_submit) lets it finish on
+ * its own first, so results never depend on the setting; only WHEN work reaches the GPU does: a producer that streams
+ * frames (many sources, offline rendering, bench.py) gains ~15 %, a producer that issues one frame per game tick should
+ * end the tick with fs_submit (or leave pipelining off) or the frame's IR is published one tick later.  Frames with
+ * lobes, all-connections modes, depth = 0, FS_FLAG_ACCUMULATE_ENERGY, batches and profiling level >= 2 are never held. */
+int fs_set_pipelining(fs_context* ctx, int32_t on);
+int fs_submit(fs_context* ctx);   /* hand everything requested so far to the GPU; does not wait */
 
 /* ReconstructImpulseResponse (FSAC.cpp:320-380, called at ARTS.cpp:192): energy -> per-band IR
  * [B][num_samples] and the num_channels-channel view (both channels identical, FSAC.cpp:331) built
