@@ -33,9 +33,9 @@ def test_fake_rccl_builds_and_exports_what_the_library_opens(fake_rccl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world):
-    env = dict(os.environ, FS_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="60")
+@pytest.mark.parametrize("world,pipelined", [(2, False), (3, False), (2, True)])
+def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world, pipelined):
+    env = dict(os.environ, FS_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="60", FS_TEST_PIPELINE="1" if pipelined else "0")
     id_file = str(tmp_path / "comm_id")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), str(r), str(world),
                                id_file, str(tmp_path / f"rank{r}.npz")], env=env, stdout=subprocess.PIPE,
