@@ -101,9 +101,10 @@ class Context:
         self.check(self.lib.fs_gather_energy(self.h, int(src), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out
 
-    def set_pipelining(self, on: bool):
-        """hold every frame's connect pass back and launch it with the next frame's walk (include/frequensee.h)"""
-        self.check(self.lib.fs_set_pipelining(self.h, 1 if on else 0))
+    def set_pipelining(self, depth):
+        """0 / False: off; 1 / True: a frame's connect pass is held back and launched with the next frame's walk; 2: its walk
+        is held back as well — one launch plans frame f, walks f - 1 and connects f - 2 (include/frequensee.h)"""
+        self.check(self.lib.fs_set_pipelining(self.h, int(depth)))
 
     def submit(self):
         self.check(self.lib.fs_submit(self.h))

@@ -25,20 +25,22 @@ namespace {
 constexpr int kIrRing = 3;  // published IR ring: a returned pointer stays valid until the second-next publish
 
 // Energy buffers per source, used in rotation: frame f deposits into one while the tail stream still reduces /
-// reconstructs frame f - 1 from another; pipelined frames finish frame f - 1 only after the walk of frame f, so that
-// frame f + 1 needs a third one to start without waiting for that tail.
-constexpr int kEnergyBufs = 3;
+// reconstructs frame f - 1 from another; pipelined frames finish frame f - 2 only in the launch that plans frame f
+// (and flushes ITS buffer), so that a fourth one lets frame f + 1 start without waiting for that tail.
+constexpr int kEnergyBufs = 4;
+constexpr int kScratchSets = 3;   // frame scratch (plan counts, cursors, work counters): plan f, walk f-1, connect f-2 in one launch
+constexpr int kPermSets = 2;      // schedules: plan f writes one while walk f-1 reads the other
 
 struct Source {
     bool alive = false;
     float pos[3] = {0, 0, 0};
     // Two energy buffers [B][bins], alternating per frame: while the tail stream still reduces /
     // reconstructs frame f from one of them, the compute stream already traces frame f+1 into the other.
-    float* d_energy[kEnergyBufs] = {nullptr, nullptr, nullptr};
+    float* d_energy[kEnergyBufs] = {};
     int cur = 0;                       // buffer of the current frame (rotates in fs_compute_energy_response*)
     hipEvent_t ev_dep = nullptr;       // compute stream: everything that writes the current buffer is enqueued
-    hipEvent_t ev_rec[kEnergyBufs] = {nullptr, nullptr, nullptr};   // tail stream: the reconstruct that read buffer i is done
-    bool rec_recorded[kEnergyBufs] = {false, false, false};
+    hipEvent_t ev_rec[kEnergyBufs] = {};   // tail stream: the reconstruct that read buffer i is done
+    bool rec_recorded[kEnergyBufs] = {};
     int last_rec = -1;                 // buffer the newest reconstruct read (its event also guards d_ir_*)
     hipEvent_t ev_rev = nullptr;       // reverb stream: the newest reverb callback has read d_ir_mono
     bool rev_recorded = false;
@@ -50,11 +52,11 @@ struct Source {
     // multi-GPU: the frame in the current buffer has been summed over the ranks (library collective), or handed to the
     // caller's collective (fs_energy_handoff); a world_size > 1 context refuses to reconstruct a frame that is neither
     bool reduced = false, handed_off = false;
-    hipEvent_t ev_red[kEnergyBufs] = {nullptr, nullptr, nullptr};   // tail stream: the library's all-reduce of buffer i is done
-    bool red_recorded[kEnergyBufs] = {false, false, false};
+    hipEvent_t ev_red[kEnergyBufs] = {};   // tail stream: the library's all-reduce of buffer i is done
+    bool red_recorded[kEnergyBufs] = {};
     // deterministic mode (FS_FLAG_DETERMINISTIC): u64 fixed-point histograms [B][bins], allocated on first use,
     // alternating like the energy buffers; cur_fixed = the current frame deposited into d_fixed[cur]
-    unsigned long long* d_fixed[kEnergyBufs] = {nullptr, nullptr, nullptr};
+    unsigned long long* d_fixed[kEnergyBufs] = {};
     bool cur_fixed = false;
     float* d_ir_bands = nullptr;  // [B][samples]
     float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
@@ -133,21 +135,25 @@ struct fs_context {
     ncclComm_t peers = nullptr;
     int peers_size = 0;
     float* d_gather = nullptr; size_t gather_cap = 0;   // [peers][B][bins] fp32
-    // Pipelined frames (fs_set_pipelining): the connect pass of frame f is held back and launched together with the walk
-    // of frame f + 1 as ONE kernel (launch_frame) — or alone, as soon as anything needs frame f's result (flush_pending).
+    // Pipelined frames (fs_set_pipelining).  depth 1: the connect pass of frame f is held back and launched together with
+    // the walk of frame f + 1 as ONE kernel; depth 2: the walk is held back as well — call f launches {plan of f, walk of
+    // f - 1, connect of f - 2} as one kernel.  Anything that needs a held frame's result lets it finish alone (flush_pending).
     struct PipeFrame {
         bool has = false;
         KParams kp; SubpathState st;
+        WalkLaunch wl;               // queue_head = the frame's scratch set, rays_per_wave
+        const uint32_t* perm = nullptr;   // its schedule (nullptr: none)
+        bool walked = false;         // only the connect pass is owed
         Source* s = nullptr;
         bool fixed = false;
-        int cur = 0;                 // which of the source's two energy buffers the frame deposits into
-        unsigned* scratch = nullptr; // the frame's scratch set (its connect pass re-arms it)
+        int cur = 0;                 // which of the source's energy buffers the frame deposits into
         int ppw = 64;
-        bool want_recon = false;     // fs_reconstruct_impulse_response_async arrived while the frame was pending
+        bool want_recon = false;     // fs_reconstruct_impulse_response_async arrived while the frame was held
         fs_params recon;
-    } pipe;
-    bool pipelining = false;
-    unsigned frame_parity = 0;       // consecutive traced frames alternate between the two state / scratch sets
+    } held[2];                       // [0] the older frame, [1] the newer one (depth 2 only)
+    int pipelining = 0;              // 0 off, 1 / 2 = frames held back
+    unsigned frame_index = 0;        // consecutive traced frames rotate through the state / schedule / scratch sets
+    size_t perm_words = 0;           // words of ONE schedule set (walk.perm holds kPermSets)
     bool comm_owned = false;           // created by fs_comm_init (destroyed with the context) vs attached by the caller
 
     // subpath state (sized on demand)
@@ -398,7 +404,8 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
         ctx->walk.perm = nullptr;
         // [levels + 1][lanes] for every later frame shape that fits the two capacities without a reallocation:
         // levels' * lanes' <= cap_seg and lanes' <= cap_lanes  =>  (levels' + 1) * lanes' <= seg + cap_lanes
-        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * (seg + ctx->cap_lanes)));
+        ctx->perm_words = seg + ctx->cap_lanes;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * kPermSets * ctx->perm_words));
         ctx->cap_seg = seg;
     }
     if (!ctx->d_overflow) {
@@ -582,8 +589,8 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_CONNECT_PAIRS_PER_WAVE")) ctx->connect_pairs_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
-    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * 2 * kScratchAllocWords);   // two sets, each with its counters
-    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * 2 * kScratchAllocWords);
+    e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchSets * kScratchAllocWords);   // each set with its counters
+    if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchSets * kScratchAllocWords);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
     ctx->device_ok = true;
     return FS_OK;
@@ -1274,9 +1281,9 @@ static int check_overflow(fs_context* ctx) {
 static int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
 
 // ---- pipelined frames ---------------------------------------------------------------------------------------------
-// What a held-back frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum
-// over the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to its
-// next frame (cur toggled): the per-frame fields are switched back for the duration.
+// What a held frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum over
+// the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
+// frames (cur rotated): the per-frame fields are switched back for the duration.
 static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
     Source* s = q.s;
     const bool moved_on = s->cur != q.cur;
@@ -1291,16 +1298,30 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
     return rc;
 }
 
-// Launch the held-back connect pass on its own: something needs the frame's result now.
+static void held_connect_part(const fs_context::PipeFrame& q, FrameParts& f) {
+    f.has_connect = true; f.kpc = q.kp; f.stc = q.st; f.energy = q.s->d_energy[q.cur];
+    f.fixed = q.fixed ? q.s->d_fixed[q.cur] : nullptr; f.scratch_c = q.wl.queue_head; f.ppw = q.ppw;
+}
+static void held_walk_part(const fs_context::PipeFrame& q, FrameParts& f) {
+    f.has_walk = true; f.kpw = q.kp; f.stw = q.st; f.wl = q.wl; f.perm = q.perm;
+}
+
+// Let every held frame finish on its own kernels, oldest first: something needs their results (or their buffers) now.
 static int flush_pending(fs_context* ctx) {
-    if (!ctx->pipe.has) return FS_OK;
-    const fs_context::PipeFrame q = ctx->pipe;
-    ctx->pipe.has = false;
+    if (!ctx->held[0].has && !ctx->held[1].has) return FS_OK;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.s->d_energy[q.cur], q.fixed ? q.s->d_fixed[q.cur] : nullptr,
-                   q.scratch, q.ppw, nullptr, nullptr, ctx->stream);
-    FS_HIP(ctx, hipGetLastError());
-    return finish_held_frame(ctx, q);
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->held[k].has) continue;
+        const fs_context::PipeFrame q = ctx->held[k];
+        ctx->held[k].has = false;
+        if (!q.walked) launch_walk(ctx->scene, q.kp, q.st, q.wl, q.perm, ctx->stream);
+        launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.s->d_energy[q.cur], q.fixed ? q.s->d_fixed[q.cur] : nullptr,
+                       q.wl.queue_head, q.ppw, nullptr, nullptr, ctx->stream);
+        FS_HIP(ctx, hipGetLastError());
+        const int rc = finish_held_frame(ctx, q);
+        if (rc) return rc;
+    }
+    return FS_OK;
 }
 
 static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
@@ -1312,7 +1333,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     // Pipelined frames: this frame's connect pass is held back (to be launched with the next frame's walk) when the
     // frame has the default shape; any other frame first lets the held-back one finish on its own.
-    const bool pipe_ok = ctx->pipelining && count == 1 && ctx->profiling < 2 && p->depth > 0 &&
+    const bool pipe_ok = ctx->pipelining > 0 && count == 1 && ctx->profiling < 2 && p->depth > 0 &&
                          !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY));
     if (!pipe_ok) FS_FLUSH(ctx);
 
@@ -1357,17 +1378,18 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     const bool mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
     const bool all_conn = mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
     kp.mis = mis ? 1 : 0;
-    if (ctx->pipe.has && (2 * (size_t)kp.num_local > ctx->cap_lanes || (size_t)levels * 2 * (size_t)kp.num_local > ctx->cap_seg))
-        FS_FLUSH(ctx);   // the state arrays are about to be reallocated: the held-back frame still reads them
+    if (2 * (size_t)kp.num_local > ctx->cap_lanes || (size_t)levels * 2 * (size_t)kp.num_local > ctx->cap_seg)
+        FS_FLUSH(ctx);   // the state arrays are about to be reallocated: held frames still read them
     rc = ensure_state(ctx, kp.num_local, levels, unbounded, all_conn, mis);
     if (rc) return rc;
     SubpathState st = ctx->st;
-    const int set = (int)(ctx->frame_parity++ & 1u);   // consecutive frames alternate between the two state / scratch sets
-    if (set) {
+    const unsigned fidx = ctx->frame_index++;   // consecutive frames rotate through the state / schedule / scratch sets
+    if (fidx & 1u) {
         st.end_pos += ctx->cap_lanes; st.end_misc += ctx->cap_lanes; st.slot_of += ctx->cap_lanes;
         st.seg_np += ctx->cap_seg; st.seg_mat += ctx->cap_seg;
     }
-    unsigned* const scratch = ctx->walk.queue_head + (size_t)set * kScratchAllocWords;
+    unsigned* const scratch = ctx->walk.queue_head + (size_t)(fidx % kScratchSets) * kScratchAllocWords;
+    uint32_t* const perm_buf = ctx->walk.perm ? ctx->walk.perm + (size_t)(fidx % kPermSets) * ctx->perm_words : nullptr;
     st.seg_pos = all_conn ? ctx->d_seg_pos : nullptr;
     st.seg_nrm = mis ? ctx->d_seg_pos + (size_t)levels * 2 * (size_t)kp.num_local : nullptr;
     st.main_levels = levels;
@@ -1456,11 +1478,16 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     }
     WalkLaunch wplan = ctx->walk;
     wplan.queue_head = scratch;
+    wplan.perm = perm_buf;
     if (unbounded) wplan.plan = 1;   // the second record tier relies on the schedule: the longest walks own the lowest slots
-    const bool plan_zeroes = kp.russian_roulette && 2u * kp.num_local > 0;   // launch_plan runs its pass (and the flush with it)
-    const uint32_t* perm = launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
+    bool sort = false;
+    const bool plan_runs = plan_shape(kp, wplan, nullptr, &sort);   // the plan pass (and the flush with it) runs for this frame
+    const uint32_t* perm = plan_runs && sort ? perm_buf : nullptr;
     if (!perm) st.slot_of = nullptr;   // no schedule: slot == subpath index
-    if (!plan_zeroes) {
+    const bool plan_held = pipe_ok && ctx->pipelining >= 2 && plan_runs && zero_tab == nullptr;   // depth 2: the pass joins the fused launch below
+    if (plan_runs && !plan_held)
+        (void)launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
+    if (!plan_runs) {
         if (zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
         for (int i = 0; i < count && zero_tab; ++i) {
             float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[srcs[i]->cur]) : srcs[i]->energy();
@@ -1473,34 +1500,51 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     wl.queue_head = scratch;
     wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
     const int ppw = ctx->connect_pairs_per_wave > 0 ? ctx->connect_pairs_per_wave : auto_pairs_per_wave(kp.num_local);
-    if (ctx->pipe.has) {   // (pipe_ok: anything else has flushed it above) this walk and the held-back connect pass as ONE launch
-        const fs_context::PipeFrame q = ctx->pipe;
-        ctx->pipe.has = false;
-        float* q_energy = q.s->d_energy[q.cur];
-        unsigned long long* q_fixed = q.fixed ? q.s->d_fixed[q.cur] : nullptr;
-        if (!launch_frame(B, ctx->scene, kp, st, wl, perm, q.kp, q.st, q_energy, q_fixed, q.scratch, q.ppw, ctx->stream)) {
-            launch_connect(B, ctx->scene, q.kp, q.st, q_energy, q_fixed, q.scratch, q.ppw, nullptr, nullptr, ctx->stream);
-            launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+    if (pipe_ok) {   // (anything else has flushed the held frames above)
+        fs_context::PipeFrame me;
+        me.has = true; me.kp = kp; me.st = st; me.wl = wl; me.perm = perm; me.walked = false; me.s = s; me.fixed = fixed;
+        me.cur = s->cur; me.ppw = ppw; me.want_recon = false;
+        FrameParts f;
+        f.wl = wl;
+        const bool deep = ctx->pipelining >= 2;
+        // the held frames (copies: the slots are rewritten below): one that only owes its connect pass, one that was only planned
+        fs_context::PipeFrame to_connect, to_walk;
+        if (ctx->held[0].has && ctx->held[0].walked) to_connect = ctx->held[0];
+        if (ctx->held[1].has) to_walk = ctx->held[1];
+        else if (ctx->held[0].has && !ctx->held[0].walked) to_walk = ctx->held[0];
+        if (deep) {   // {plan of this frame, walk of the planned frame, connect of the walked one}
+            if (plan_held) { f.has_plan = true; f.kpp = kp; f.scratch_p = scratch; f.perm_p = sort ? perm_buf : nullptr; f.zero_p = zero_ptr; f.zero_words_p = zero_ptr ? zero_words : 0; }
+            if (to_walk.has) held_walk_part(to_walk, f);
+        } else {      // {walk of this frame, connect of the walked one}
+            held_walk_part(me, f);
+        }
+        if (to_connect.has) held_connect_part(to_connect, f);
+        if (f.has_walk || f.has_connect || f.has_plan) {
+            if (!launch_frame(B, ctx->scene, f, ctx->stream)) {   // no fused form: the same passes one after the other
+                if (f.has_connect) launch_connect(B, ctx->scene, f.kpc, f.stc, f.energy, f.fixed, f.scratch_c, f.ppw, nullptr, nullptr, ctx->stream);
+                if (f.has_walk) launch_walk(ctx->scene, f.kpw, f.stw, f.wl, f.perm, ctx->stream);
+                if (f.has_plan) (void)launch_plan(kp, wplan, zero_ptr, zero_ptr ? zero_words : 0, nullptr, 1, ctx->stream);
+            }
         }
         if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
         FS_HIP(ctx, hipGetLastError());
-        rc = finish_held_frame(ctx, q);
-        if (rc) return rc;
-    } else {
-        launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
-        if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
-    }
-    if (pipe_ok) {   // hold this frame's connect pass back
-        fs_context::PipeFrame& q = ctx->pipe;
-        q.has = true; q.kp = kp; q.st = st; q.s = s; q.fixed = fixed; q.cur = s->cur; q.scratch = scratch; q.ppw = ppw;
-        q.want_recon = false;
-        FS_HIP(ctx, hipGetLastError());
+        ctx->held[0].has = false; ctx->held[1].has = false;
+        if (to_connect.has) { rc = finish_held_frame(ctx, to_connect); if (rc) return rc; }
+        if (deep) {   // the planned frame has been walked now; this one has only been planned
+            if (to_walk.has) { ctx->held[0] = to_walk; ctx->held[0].walked = true; ctx->held[1] = me; }
+            else ctx->held[0] = me;
+        } else {
+            me.walked = true;
+            ctx->held[0] = me;
+        }
         if (timed_frame) { tf.has_trace = true; ctx->pending.push_back(tf); }
         ctx->stats.frames++;
         ctx->stats.pairs += kp.num_local;
         ctx->stats.rays += 2ull * kp.num_local;
         return FS_OK;
     }
+    launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+    if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
     if (all_conn)
         launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, scratch, ctx->stream);
     else
@@ -1621,11 +1665,15 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
     // pipelined frames: the source's current frame still waits for its connect pass — the reconstruct goes with it
-    if (ctx->pipe.has && ctx->pipe.s == s && !ctx->pipe.want_recon && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) &&
-        (ctx->cfg.world_size == 1 || ctx->comm)) {
-        ctx->pipe.want_recon = true;
-        ctx->pipe.recon = *p;
-        return FS_OK;
+    for (int k = 1; k >= 0; --k) {   // the source's CURRENT frame is the newest held one
+        fs_context::PipeFrame& q = ctx->held[k];
+        if (!q.has || q.s != s) continue;
+        if (!q.want_recon && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && (ctx->cfg.world_size == 1 || ctx->comm)) {
+            q.want_recon = true;
+            q.recon = *p;
+            return FS_OK;
+        }
+        break;
     }
     FS_FLUSH(ctx);
     return reconstruct_now(ctx, s, p);
@@ -2237,8 +2285,9 @@ int fs_apply_material_fd(fs_context* ctx, const float* in, int32_t L, const floa
 // ---- measurement ----------------------------------------------------------------------------------------------
 int fs_set_pipelining(fs_context* ctx, int32_t on) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
-    if (!on) FS_FLUSH(ctx);
-    ctx->pipelining = on != 0;
+    if (on < 0 || on > 2) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_set_pipelining: 0 (off), 1 or 2 frames held back");
+    if (on != ctx->pipelining) FS_FLUSH(ctx);
+    ctx->pipelining = on;
     return FS_OK;
 }
 
@@ -2272,12 +2321,14 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         resolve_timings(ctx);
     }
     if (ctx->device_ok && ctx->walk.queue_head) {   // work counters kept on the device since the last reset
-        unsigned long long c[kNumCounters] = {0}, c1[kNumCounters] = {0};   // each scratch set carries its own counters
+        unsigned long long c[kNumCounters] = {0}, cs[kScratchSets][kNumCounters] = {};   // each scratch set carries its own counters
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-        FS_HIP(ctx, hipMemcpyAsync(c, ctx->walk.queue_head + kCounterWord, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-        FS_HIP(ctx, hipMemcpyAsync(c1, ctx->walk.queue_head + kScratchAllocWords + kCounterWord, sizeof(c1), hipMemcpyDeviceToHost, ctx->stream));
+        for (int k = 0; k < kScratchSets; ++k)
+            FS_HIP(ctx, hipMemcpyAsync(cs[k], ctx->walk.queue_head + (size_t)k * kScratchAllocWords + kCounterWord, sizeof(cs[k]),
+                                       hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int k = 0; k < kNumCounters; ++k) c[k] += c1[k];
+        for (int k = 0; k < kScratchSets; ++k)
+            for (int i = 0; i < kNumCounters; ++i) c[i] += cs[k][i];
         ctx->stats.segments = c[0] + ctx->host_segments;
         ctx->stats.connections_tested = c[1];
         ctx->stats.deposits = c[2];
@@ -2303,7 +2354,7 @@ int fs_reset_stats(fs_context* ctx) {
     ctx->stats.scene_bytes = keep.scene_bytes;
     if (ctx->device_ok && ctx->walk.queue_head) {
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < kScratchSets; ++k)
             FS_HIP(ctx, hipMemsetAsync(ctx->walk.queue_head + (size_t)k * kScratchAllocWords + kCounterWord, 0,
                                        sizeof(unsigned long long) * kNumCounters, ctx->stream));
     }

@@ -172,12 +172,20 @@ constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // buffers instead (batched frame).  Returns nullptr — and zeroes nothing — when there is no roulette to plan for.
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
                             float* const* energy_tab, int energy_count, hipStream_t s);
-// Pipelined frames: ONE launch whose first workgroups walk frame f + 1 (kpw, stw, wl, perm) while the others connect
-// frame f (kpc, stc, energy / fixed, scratch_c).  false = no fused form for this shape (lobes, counting instantiations,
-// experiment walk variants): the caller launches the two kernels one after the other.
-bool launch_frame(int B, const DeviceScene& sc, const KParams& kpw, const SubpathState& stw, const WalkLaunch& wl,
-                  const uint32_t* perm, const KParams& kpc, const SubpathState& stc, float* energy,
-                  unsigned long long* fixed, unsigned* scratch_c, int pairs_per_wave, hipStream_t s);
+// Pipelined frames: ONE launch with up to three parts — the walk of one frame (planned before), the connect pass of an
+// older one (walked before), the plan pass of the newest.  false = no fused form for this shape (lobes, counting
+// instantiations, experiment walk variants, nothing to do): the caller launches the kernels one after the other.
+struct FrameParts {
+    bool has_walk = false;      // kpw, stw, wl (queue_head = the frame's scratch set, rays_per_wave), perm (nullptr: no schedule)
+    KParams kpw; SubpathState stw; WalkLaunch wl; const uint32_t* perm = nullptr;
+    bool has_connect = false;   // kpc, stc, energy / fixed, scratch_c (re-armed by the pass), ppw
+    KParams kpc; SubpathState stc; float* energy = nullptr; unsigned long long* fixed = nullptr; unsigned* scratch_c = nullptr; int ppw = 64;
+    bool has_plan = false;      // kpp, scratch_p, perm_p (the schedule to write, nullptr: counts only), zero_p / zero_words_p (the flush)
+    KParams kpp; unsigned* scratch_p = nullptr; uint32_t* perm_p = nullptr; float* zero_p = nullptr; int zero_words_p = 0;
+};
+bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s);
+// does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule
+bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead

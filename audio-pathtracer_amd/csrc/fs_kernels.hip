@@ -650,10 +650,10 @@ __device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
     return k;
 }
 
-__global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __restrict__ scratch,
-                                                      uint32_t* __restrict__ perm, float* __restrict__ energy,
-                                                      int energy_words, float* const* __restrict__ energy_tab,
-                                                      int energy_count) {
+__device__ __forceinline__ void plan_body(const uint32_t bid, const uint32_t nblocks, const KParams& kp,
+                                          unsigned* __restrict__ scratch, uint32_t* __restrict__ perm,
+                                          float* __restrict__ energy, const int energy_words,
+                                          float* const* __restrict__ energy_tab, const int energy_count) {
     __shared__ unsigned s_hist[kPlanBuckets];
     __shared__ unsigned s_base[kPlanBuckets];
     __shared__ unsigned s_seg;
@@ -662,10 +662,10 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
     if (energy_tab) {   // batched frame: every source's buffer (the table was copied on this stream before the launch)
         for (int k = 0; k < energy_count; ++k) {
             float* e = energy_tab[k];
-            for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) e[i] = 0.0f;
+            for (int i = bid * kBlock + threadIdx.x; i < energy_words; i += nblocks * kBlock) e[i] = 0.0f;
         }
     } else {
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < energy_words; i += gridDim.x * kBlock) energy[i] = 0.0f;
+        for (int i = bid * kBlock + threadIdx.x; i < energy_words; i += nblocks * kBlock) energy[i] = 0.0f;
     }
     __syncthreads();
     const uint32_t total = 2u * kp.num_local;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
     unsigned my_segments = 0;
 #pragma unroll
     for (int it = 0; it < kPlanItems; ++it) {
-        const uint32_t g = (blockIdx.x * kPlanItems + it) * kBlock + threadIdx.x;
+        const uint32_t g = (bid * kPlanItems + it) * kBlock + threadIdx.x;
         L[it] = 0; rank[it] = 0;
         if (g < total) {
             const int len = planned_length(g, kp);
@@ -692,11 +692,18 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kPlanItems; ++it) {
-        const uint32_t g = (blockIdx.x * kPlanItems + it) * kBlock + threadIdx.x;
+        const uint32_t g = (bid * kPlanItems + it) * kBlock + threadIdx.x;
         if (perm && g < total) perm[(size_t)L[it] * total + s_base[L[it]] + rank[it]] = g;
     }
     // work counter: walk segments of this frame (a walk of length L traces L rays), one atomic per workgroup
     if (threadIdx.x == 0 && s_seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), (unsigned long long)s_seg);
+}
+
+__global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __restrict__ scratch,
+                                                      uint32_t* __restrict__ perm, float* __restrict__ energy,
+                                                      int energy_words, float* const* __restrict__ energy_tab,
+                                                      int energy_count) {
+    plan_body(blockIdx.x, gridDim.x, kp, scratch, perm, energy, energy_words, energy_tab, energy_count);
 }
 
 // launch slot -> subpath index through the buckets, longest walks first.  s_cnt = bucket counts in LDS.
@@ -1236,23 +1243,31 @@ __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams
     connect_body<B, LOBES, BATCH, COUNT>(blockIdx.x, gridDim.x, sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);
 }
 
-// One launch for two frames: workgroups [0, walk_blocks) walk the subpaths of frame f + 1, the others connect the
-// pairs of frame f (its walk ended with the previous launch) — the thin single round of the connect kernel and the
-// thin tail of the walk's longest waves fill each other's idle wave slots.  The two frames share nothing but the
-// scene: each has its own subpath state, frame scratch and energy buffer (fs_capi.cpp: pipelined frames).
+// One launch for up to three frames (pipelined frames, fs_capi.cpp): workgroups [0, walk_blocks) walk the subpaths of
+// frame f - 1 (planned by the previous launch), the next connect_blocks connect the pairs of frame f - 2 (walked by the
+// previous launch), the rest run the plan pass of frame f.  The thin single round of the connect pass, the thin tail of
+// the walk's longest waves and the short plan pass fill each other's idle wave slots — and two kernel boundaries per
+// frame disappear.  The frames share nothing but the scene: each has its own subpath state, schedule, frame scratch
+// and energy buffer.
 template <int B>
-__global__ __launch_bounds__(kBlock) void frame_kernel(DeviceScene sc, uint32_t walk_blocks, KParams kpw, SubpathState stw,
-                                                       const unsigned* __restrict__ scratch_w,
+__global__ __launch_bounds__(kBlock) void frame_kernel(DeviceScene sc, uint32_t walk_blocks, uint32_t connect_blocks,
+                                                       KParams kpw, SubpathState stw, const unsigned* __restrict__ scratch_w,
                                                        const uint32_t* __restrict__ perm, int rays_per_wave,
                                                        KParams kpc, SubpathState stc, float* __restrict__ energy,
                                                        unsigned long long* __restrict__ fixed, unsigned* scratch_c,
-                                                       int pairs_per_wave) {
-    if (blockIdx.x < walk_blocks) {   // (walks first: starting the connect pass before the short walks measured slower)
-        if (rays_per_wave < 64) walk_sparse_body<0, false>(blockIdx.x, sc, kpw, stw, scratch_w, perm, rays_per_wave);
-        else walk_shared_body<0, false>(blockIdx.x, sc, kpw, stw, scratch_w, perm);
+                                                       int pairs_per_wave,
+                                                       KParams kpp, unsigned* __restrict__ scratch_p, uint32_t* __restrict__ perm_p,
+                                                       float* __restrict__ zero_p, int zero_words_p) {
+    const uint32_t b = blockIdx.x;
+    if (b < walk_blocks) {   // (walks first: starting the connect pass before the short walks measured slower)
+        if (rays_per_wave < 64) walk_sparse_body<0, false>(b, sc, kpw, stw, scratch_w, perm, rays_per_wave);
+        else walk_shared_body<0, false>(b, sc, kpw, stw, scratch_w, perm);
+    } else if (b < walk_blocks + connect_blocks) {
+        connect_body<B, 0, false, false>(b - walk_blocks, connect_blocks, sc, kpc, stc, energy, fixed, scratch_c,
+                                         pairs_per_wave, nullptr, nullptr);
     } else {
-        connect_body<B, 0, false, false>(blockIdx.x - walk_blocks, gridDim.x - walk_blocks, sc, kpc, stc, energy, fixed,
-                                         scratch_c, pairs_per_wave, nullptr, nullptr);
+        plan_body(b - walk_blocks - connect_blocks, gridDim.x - walk_blocks - connect_blocks, kpp, scratch_p, perm_p, zero_p,
+                  zero_words_p, nullptr, 0);
     }
 }
 
@@ -1891,13 +1906,12 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
 
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
                             float* const* energy_tab, int energy_count, hipStream_t s) {
-    uint32_t lanes = 2u * kp.num_local;
     // Without roulette every walk takes kp.depth segments: nothing to sort, and the caller counts the segments on
     // the host.  With roulette the pass always runs — it is also what counts the frame's walk segments — but it
     // only produces the length-sorted schedule when that is enabled and can matter.
-    if (lanes == 0 || !kp.russian_roulette) return nullptr;
-    const bool sort = wl.plan && kp.depth > 1 && wl.perm;
-    uint32_t full = (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
+    uint32_t full = 0;
+    bool sort = false;
+    if (!plan_shape(kp, wl, &full, &sort)) return nullptr;
     hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, sort ? wl.perm : nullptr, energy,
                        energy_words, energy_tab, energy_count);
     return sort ? wl.perm : nullptr;
@@ -1905,34 +1919,51 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
 
 namespace {
 template <int B>
-void launch_frame_t(const DeviceScene& sc, uint32_t walk_blocks, uint32_t connect_blocks, size_t lds, const KParams& kpw,
-                    const SubpathState& stw, const unsigned* scratch_w, const uint32_t* perm, int rays_per_wave,
-                    const KParams& kpc, const SubpathState& stc, float* energy, unsigned long long* fixed,
-                    unsigned* scratch_c, int pairs_per_wave, hipStream_t s) {
+void launch_frame_t(const DeviceScene& sc, uint32_t wb, uint32_t cb, uint32_t pb, size_t lds, const FrameParts& f, int rpw,
+                    bool sort, hipStream_t s) {
     allow_lds(frame_kernel<B>, lds);
-    hipLaunchKernelGGL(frame_kernel<B>, dim3(walk_blocks + connect_blocks), dim3(kBlock), lds, s, sc, walk_blocks, kpw, stw,
-                       scratch_w, perm, rays_per_wave, kpc, stc, energy, fixed, scratch_c, pairs_per_wave);
+    hipLaunchKernelGGL(frame_kernel<B>, dim3(wb + cb + pb), dim3(kBlock), lds, s, sc, wb, cb, f.kpw, f.stw, f.wl.queue_head,
+                       f.perm, rpw, f.kpc, f.stc, f.energy, f.fixed, f.scratch_c, f.ppw, f.kpp, f.scratch_p,
+                       sort ? f.perm_p : nullptr, f.zero_p, f.zero_words_p);
 }
 }  // namespace
 
-bool launch_frame(int B, const DeviceScene& sc, const KParams& kpw, const SubpathState& stw, const WalkLaunch& wl,
-                  const uint32_t* perm, const KParams& kpc, const SubpathState& stc, float* energy,
-                  unsigned long long* fixed, unsigned* scratch_c, int pairs_per_wave, hipStream_t s) {
-    const uint32_t lanes = 2u * kpw.num_local;
-    if (lanes == 0 || kpc.num_local == 0 || !FS_SHARED_WALK(wl)) return false;
-    if (kpw.lobes || kpw.count || kpc.lobes || kpc.count) return false;   // the default instantiations only
-    int rpw = wl.rays_per_wave > 0 && wl.rays_per_wave < 64 ? wl.rays_per_wave : 64;
-    const uint32_t waves = (lanes + (uint32_t)rpw - 1) / (uint32_t)rpw;
-    const uint32_t walk_blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
-    if (pairs_per_wave < 1 || pairs_per_wave > 64) pairs_per_wave = 64;
-    const uint32_t per_block = (uint32_t)pairs_per_wave * (kBlock / 64);
-    uint32_t connect_blocks = (kpc.num_local + per_block - 1) / per_block;
-    if (connect_blocks > 1024) connect_blocks = 1024;
-    const size_t lds = stack_bytes(sc) + std::max(kShareLdsBytes, sizeof(float) * (size_t)B * (size_t)kpc.hist_window + kShareAnyLdsBytes);
+bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort) {
+    const uint32_t lanes = 2u * kp.num_local;
+    if (lanes == 0 || !kp.russian_roulette) return false;
+    if (blocks) *blocks = (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
+    if (sort) *sort = wl.plan && kp.depth > 1 && wl.perm;
+    return true;
+}
+
+bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s) {
+    if (!FS_SHARED_WALK(f.wl)) return false;
+    uint32_t wb = 0, cb = 0, pb = 0;
+    int rpw = 64;
+    bool sort = false;
+    size_t lds = 0;
+    if (f.has_walk) {
+        if (f.kpw.lobes || f.kpw.count || f.kpw.num_local == 0) return false;   // the default instantiations only
+        rpw = f.wl.rays_per_wave > 0 && f.wl.rays_per_wave < 64 ? f.wl.rays_per_wave : 64;
+        const uint32_t waves = (2u * f.kpw.num_local + (uint32_t)rpw - 1) / (uint32_t)rpw;
+        wb = (waves + kBlock / 64 - 1) / (kBlock / 64);
+        lds = std::max(lds, stack_bytes(sc) + kShareLdsBytes);
+    }
+    if (f.has_connect) {
+        if (f.kpc.lobes || f.kpc.count || f.kpc.num_local == 0 || f.ppw < 1 || f.ppw > 64) return false;
+        const uint32_t per_block = (uint32_t)f.ppw * (kBlock / 64);
+        cb = std::min<uint32_t>((f.kpc.num_local + per_block - 1) / per_block, 1024u);
+        lds = std::max(lds, stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)f.kpc.hist_window + kShareAnyLdsBytes);
+    }
+    if (f.has_plan) {
+        if (!plan_shape(f.kpp, f.wl, &pb, nullptr)) return false;
+        sort = f.perm_p != nullptr;
+    }
+    if (wb + cb + pb == 0) return false;
     switch (B) {
-#define FS_CASE(N) case N: launch_frame_t<N>(sc, walk_blocks, connect_blocks, lds, kpw, stw, wl.queue_head, perm, rpw, kpc, stc, energy, fixed, scratch_c, pairs_per_wave, s); break;
+#define FS_CASE(N) case N: launch_frame_t<N>(sc, wb, cb, pb, lds, f, rpw, sort, s); break;
         FS_CASE(1) FS_CASE(2) FS_CASE(3) FS_CASE(4) FS_CASE(5) FS_CASE(6) FS_CASE(7)
-        default: launch_frame_t<8>(sc, walk_blocks, connect_blocks, lds, kpw, stw, wl.queue_head, perm, rpw, kpc, stc, energy, fixed, scratch_c, pairs_per_wave, s); break;
+        default: launch_frame_t<8>(sc, wb, cb, pb, lds, f, rpw, sort, s); break;
 #undef FS_CASE
     }
     return true;

@@ -262,18 +262,23 @@ int fs_gather_energy_async(fs_context* ctx, fs_source src, void** dptr, size_t* 
  * num_rays subpaths belong to `rank` of `world_size`. */
 int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t* pair_begin, uint32_t* pair_count);
 
-/* Pipelined frames (off by default).  A frame is three passes in a row — plan, walk, connect — and the last two leave
- * wave slots idle that the other could use: the walk's longest waves end in a thin tail, the connect pass is one thin
- * round.  With pipelining on, fs_compute_energy_response_async HOLDS BACK the connect pass of its frame and the next
- * call launches it together with its own walk as one kernel (the two frames share nothing but the scene: two sets of
- * subpath state and frame scratch).  A held-back frame's fs_reconstruct_impulse_response_async is recorded and runs
- * right behind its connect pass.  Everything that observes, synchronises or changes what a held-back frame needs
- * (fs_synchronize, the blocking variants, energy / stats / scene / communicator calls, fs_submit) lets it finish on
- * its own first, so results never depend on the setting; only WHEN work reaches the GPU does: a producer that streams
- * frames (many sources, offline rendering, bench.py) gains ~15 %, a producer that issues one frame per game tick should
- * end the tick with fs_submit (or leave pipelining off) or the frame's IR is published one tick later.  Frames with
- * lobes, all-connections modes, depth = 0, FS_FLAG_ACCUMULATE_ENERGY, batches and profiling level >= 2 are never held. */
-int fs_set_pipelining(fs_context* ctx, int32_t on);
+/* Pipelined frames (off by default).  A frame is three passes in a row — plan, walk, connect — and each leaves wave
+ * slots idle that the others could use: the walk's longest waves end in a thin tail, the connect pass is one thin
+ * round, the plan pass is short.  fs_set_pipelining(ctx, depth):
+ *   depth 1  fs_compute_energy_response_async HOLDS BACK the connect pass of its frame; the next call launches it
+ *            together with its own walk as ONE kernel;
+ *   depth 2  the walk is held back as well: call f launches {plan of frame f, walk of frame f-1, connect of frame f-2}
+ *            as one kernel (two kernel boundaries per frame disappear too).
+ * The frames in one launch share nothing but the scene (rotating sets of subpath state, schedule, frame scratch and
+ * energy buffers).  A held frame's fs_reconstruct_impulse_response_async is recorded and runs right behind its connect
+ * pass.  Everything that observes, synchronises or changes what a held frame needs (fs_synchronize, the blocking
+ * variants, energy / stats / scene / communicator calls, fs_submit) lets the held frames finish on their own kernels
+ * first, so results never depend on the setting; only WHEN work reaches the GPU does: a producer that streams frames
+ * (many sources, offline rendering, bench.py) gains 12-14 % (36 % on 16 384-ray frames), a producer that issues one
+ * frame per game tick should end the tick with fs_submit (or leave pipelining off) or the frame's IR is published one
+ * or two ticks later.  Frames with lobes, all-connections modes, depth = 0, FS_FLAG_ACCUMULATE_ENERGY, batches and
+ * profiling level >= 2 are never held. */
+int fs_set_pipelining(fs_context* ctx, int32_t depth);   /* 0 = off, 1, 2 */
 int fs_submit(fs_context* ctx);   /* hand everything requested so far to the GPU; does not wait */
 
 /* ReconstructImpulseResponse (FSAC.cpp:320-380, called at ARTS.cpp:192): energy -> per-band IR

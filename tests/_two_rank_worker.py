@@ -64,7 +64,7 @@ if mode == "gather":
     sys.exit(0)
 ctx.comm_init(uid)
 if os.environ.get("FS_TEST_PIPELINE") == "1":
-    ctx.set_pipelining(True)      # held-back connect passes: the all-reduce and the reconstruct follow them
+    ctx.set_pipelining(2)         # held-back connect passes: the all-reduce and the reconstruct follow them
 # every rank registers the same triangles; rank 0 builds the tree, the others receive it (fs_scene_commit)
 ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
 ctx.set_listener(sc.listener)

@@ -13,13 +13,14 @@ def frames(pkg, n, rays=16384, flags=DET):
     return [pkg.default_params(num_rays=rays, depth=8, seed=300 + i, flags=flags) for i in range(n)]
 
 
-def test_streamed_frames_equal_the_unpipelined_ones(pkg, scene_factory):
+@pytest.mark.parametrize("depth", [1, 2])
+def test_streamed_frames_equal_the_unpipelined_ones(pkg, scene_factory, depth):
     """A stream of frames on one source: every frame's energy and IR, read after the stream, equal those of a context
     without pipelining — bit-identical in deterministic mode, to tolerance with fp32 atomics; work counters equal."""
     sc = scene_factory("starter_room", 4)
     plain, ps = make_ctx(pkg, sc)
     pipe, qs = make_ctx(pkg, sc)
-    pipe.set_pipelining(True)
+    pipe.set_pipelining(depth)
     for flags in (DET, 0):
         want_ir, got_ir = [], []
         plain.reset_stats(); pipe.reset_stats()
@@ -42,18 +43,19 @@ def test_streamed_frames_equal_the_unpipelined_ones(pkg, scene_factory):
     plain.close(); pipe.close()
 
 
-def test_every_observation_point_sees_the_finished_frame(pkg, scene_factory, oracle_mod):
+@pytest.mark.parametrize("depth", [1, 2])
+def test_every_observation_point_sees_the_finished_frame(pkg, scene_factory, oracle_mod, depth):
     """Whatever the caller does after an asynchronous compute — read the energy, the stats, the IR, move geometry, change
     the frame size, switch modes, trace another source — it sees exactly what a context without pipelining shows."""
     sc = scene_factory("starter_room", 4)
     plain, ps = make_ctx(pkg, sc)
     pipe, qs = make_ctx(pkg, sc)
-    pipe.set_pipelining(True)
+    pipe.set_pipelining(depth)
     ps2, qs2 = plain.create_source(sc.source + np.float32(90.0)), pipe.create_source(sc.source + np.float32(90.0))
     tri = np.asarray(sc.triangles, np.float32)
     rng = np.random.default_rng(3)
-    for step in range(40):
-        op = int(rng.integers(0, 9))
+    for step in range(60):
+        op = int(rng.integers(0, 10))
         p = pkg.default_params(num_rays=int(rng.choice([2048, 8192, 16384, 65536])), depth=int(rng.choice([2, 8])),
                                seed=1000 + step, flags=DET | (1 if rng.random() < 0.3 else 0))
         for c, s1, s2 in ((plain, ps, ps2), (pipe, qs, qs2)):
@@ -74,6 +76,8 @@ def test_every_observation_point_sees_the_finished_frame(pkg, scene_factory, ora
                 c.reconstruct_impulse_response_async(src, p)
             elif op == 8:
                 c.submit()
+            elif op == 9 and c is pipe:   # change the depth in mid-stream
+                c.set_pipelining(1 + (step % 2))
         if op in (2, 3):
             assert np.array_equal(np.asarray(plain._last), np.asarray(pipe._last)), (step, op)
     plain.synchronize(); pipe.synchronize()
@@ -90,7 +94,7 @@ def test_blocking_calls_and_the_oracle(pkg, scene_factory, oracle_mod):
     """The blocking variants never leave a frame held back: cfg2 against the oracle with pipelining on."""
     sc = scene_factory("starter_room", 4)
     ctx, src = make_ctx(pkg, sc)
-    ctx.set_pipelining(True)
+    ctx.set_pipelining(2)
     osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
     for seed in (5, 6):
         e = ctx.compute_energy_response(src, pkg.default_params(num_rays=16384, depth=8, seed=seed))

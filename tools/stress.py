@@ -37,8 +37,8 @@ def main(iters=400, seed=1):
     extra_a = [a.create_source(q) for q in extra_pos]
     extra_b = [b.create_source(q) for q in extra_pos]
     a.reverb_init(sa, 1024)
-    if os.environ.get("FS_STRESS_PIPELINE") == "1":   # context a holds connect passes back; b (the reference) never does
-        a.set_pipelining(True)
+    if os.environ.get("FS_STRESS_PIPELINE") in ("1", "2"):   # context a holds connect passes back; b (the reference) never does
+        a.set_pipelining(int(os.environ["FS_STRESS_PIPELINE"]))
     F = pkg._capi
     flags_pool = [0, 0, 0, F.FLAG_DETERMINISTIC, F.FLAG_ALL_CONNECTIONS, F.FLAG_ALL_CONNECTIONS | F.FLAG_DETERMINISTIC,
                   F.FLAG_COSINE_SAMPLING, F.FLAG_MIS_BALANCE, F.FLAG_MATERIAL_LOBES, F.FLAG_MATERIAL_LOBES | F.FLAG_ALL_CONNECTIONS,
