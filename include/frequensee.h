@@ -214,7 +214,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source src, const fs_pa
  * only once in the list. */
 int fs_compute_energy_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 /* Device pointer of the energy buffer [B][num_bins] fp32 the source's CURRENT frame deposits into.  A source
- * owns three such buffers and every fs_compute_energy_response* moves on to the next one, so that the tail of
+ * owns four such buffers and every fs_compute_energy_response* moves on to the next one, so that the tail of
  * frame f (reduce, reconstruct, publish) overlaps the tracing of frame f+1: query the pointer per frame. */
 int fs_energy_device_ptr(fs_context* ctx, fs_source src, void** dptr, size_t* bytes);
 /* Multi-GPU hook (one sum all-reduce of [B][1000] fp32 between ARTS.cpp:173 and :192).  Hands
