@@ -1404,7 +1404,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     TimedFrame tf{};
     // level 1 may sample: events around every profile_interval-th frame only (an event pair costs the frame a few
     // microseconds of queue bubbles — bench.py times every 8th frame of its timed region)
-    const bool timed_frame = ctx->profiling && (ctx->profiling >= 2 || ctx->profile_interval <= 1 ||
+    bool timed_frame = ctx->profiling && (ctx->profiling >= 2 || ctx->profile_interval <= 1 ||
                                                 (ctx->profile_tick++ % (unsigned)ctx->profile_interval) == 0);
     if (timed_frame) {
         resolve_completed_timings(ctx);
@@ -1519,6 +1519,12 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
             held_walk_part(me, f);
         }
         if (to_connect.has) held_connect_part(to_connect, f);
+        if (timed_frame && !(f.has_walk && (f.has_connect || !deep))) {
+            // a pipeline-fill launch (no walk, or depth 2 without its connect part yet) is not a sample of the frame kernel:
+            // take the first event back out of the stream's timing (it was recorded above; both go back to the pool unused)
+            for (int i = 0; i < 3; ++i) if (tf.e[i]) { ctx->free_events.push_back(tf.e[i]); tf.e[i] = nullptr; }
+            timed_frame = false;
+        }
         if (f.has_walk || f.has_connect || f.has_plan) {
             if (!launch_frame(B, ctx->scene, f, ctx->stream)) {   // no fused form: the same passes one after the other
                 if (f.has_connect) launch_connect(B, ctx->scene, f.kpc, f.stc, f.energy, f.fixed, f.scratch_c, f.ppw, nullptr, nullptr, ctx->stream);
