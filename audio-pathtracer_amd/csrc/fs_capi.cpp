@@ -144,12 +144,17 @@ struct fs_context {
         WalkLaunch wl;               // queue_head = the frame's scratch set, rays_per_wave
         const uint32_t* perm = nullptr;   // its schedule (nullptr: none)
         bool walked = false;         // only the connect pass is owed
-        Source* s = nullptr;
         bool fixed = false;
-        int cur = 0;                 // which of the source's energy buffers the frame deposits into
         int ppw = 64;
-        bool want_recon = false;     // fs_reconstruct_impulse_response_async arrived while the frame was held
-        fs_params recon;
+        struct Item {                // one per source of the frame (a batched frame has several)
+            Source* s = nullptr;
+            int cur = 0;             // which of the source's energy buffers the frame deposits into
+            bool want_recon = false; // fs_reconstruct_impulse_response_async arrived while the frame was held
+            fs_params recon;
+        };
+        std::vector<Item> items;
+        float* const* energy_tab = nullptr;               // batched frame: the per-frame device tables (kBatchSlots of them
+        unsigned long long* const* fixed_tab = nullptr;   // rotate; a held frame is connected two calls later at most)
     } held[2];                       // [0] the older frame, [1] the newer one (depth 2 only)
     int pipelining = 0;              // 0 off, 1 / 2 = frames held back
     unsigned frame_index = 0;        // consecutive traced frames rotate through the state / schedule / scratch sets
@@ -1285,22 +1290,27 @@ static int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
 // the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
 // frames (cur rotated): the per-frame fields are switched back for the duration.
 static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
-    Source* s = q.s;
-    const bool moved_on = s->cur != q.cur;
-    const int cur = s->cur;
-    const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off;
-    s->cur = q.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
-    int rc = FS_OK;
-    if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
-    if (ctx->comm) rc = reduce_energy(ctx, s);
-    if (!rc && q.want_recon) rc = reconstruct_now(ctx, s, &q.recon);
-    if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; }
-    return rc;
+    for (const fs_context::PipeFrame::Item& it : q.items) {
+        Source* s = it.s;
+        const bool moved_on = s->cur != it.cur;
+        const int cur = s->cur;
+        const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off;
+        s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
+        int rc = FS_OK;
+        if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
+        if (ctx->comm) rc = reduce_energy(ctx, s);
+        if (!rc && it.want_recon) rc = reconstruct_now(ctx, s, &it.recon);
+        if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; }
+        if (rc) return rc;
+    }
+    return FS_OK;
 }
 
 static void held_connect_part(const fs_context::PipeFrame& q, FrameParts& f) {
-    f.has_connect = true; f.kpc = q.kp; f.stc = q.st; f.energy = q.s->d_energy[q.cur];
-    f.fixed = q.fixed ? q.s->d_fixed[q.cur] : nullptr; f.scratch_c = q.wl.queue_head; f.ppw = q.ppw;
+    const fs_context::PipeFrame::Item& it = q.items[0];
+    f.has_connect = true; f.kpc = q.kp; f.stc = q.st; f.energy = it.s->d_energy[it.cur];
+    f.fixed = q.fixed ? it.s->d_fixed[it.cur] : nullptr; f.scratch_c = q.wl.queue_head; f.ppw = q.ppw;
+    f.energy_tab = q.energy_tab; f.fixed_tab = q.fixed_tab;
 }
 static void held_walk_part(const fs_context::PipeFrame& q, FrameParts& f) {
     f.has_walk = true; f.kpw = q.kp; f.stw = q.st; f.wl = q.wl; f.perm = q.perm;
@@ -1315,8 +1325,9 @@ static int flush_pending(fs_context* ctx) {
         const fs_context::PipeFrame q = ctx->held[k];
         ctx->held[k].has = false;
         if (!q.walked) launch_walk(ctx->scene, q.kp, q.st, q.wl, q.perm, ctx->stream);
-        launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.s->d_energy[q.cur], q.fixed ? q.s->d_fixed[q.cur] : nullptr,
-                       q.wl.queue_head, q.ppw, nullptr, nullptr, ctx->stream);
+        launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.items[0].s->d_energy[q.items[0].cur],
+                       q.fixed ? q.items[0].s->d_fixed[q.items[0].cur] : nullptr, q.wl.queue_head, q.ppw, q.energy_tab, q.fixed_tab,
+                       ctx->stream);
         FS_HIP(ctx, hipGetLastError());
         const int rc = finish_held_frame(ctx, q);
         if (rc) return rc;
@@ -1333,7 +1344,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     // Pipelined frames: this frame's connect pass is held back (to be launched with the next frame's walk) when the
     // frame has the default shape; any other frame first lets the held-back one finish on its own.
-    const bool pipe_ok = ctx->pipelining > 0 && count == 1 && ctx->profiling < 2 && p->depth > 0 &&
+    const bool pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && p->depth > 0 &&
                          !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY));
     if (!pipe_ok) FS_FLUSH(ctx);
 
@@ -1484,7 +1495,7 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     const bool plan_runs = plan_shape(kp, wplan, nullptr, &sort);   // the plan pass (and the flush with it) runs for this frame
     const uint32_t* perm = plan_runs && sort ? perm_buf : nullptr;
     if (!perm) st.slot_of = nullptr;   // no schedule: slot == subpath index
-    const bool plan_held = pipe_ok && ctx->pipelining >= 2 && plan_runs && zero_tab == nullptr;   // depth 2: the pass joins the fused launch below
+    const bool plan_held = pipe_ok && ctx->pipelining >= 2 && plan_runs;   // depth 2: the pass joins the fused launch below
     if (plan_runs && !plan_held)
         (void)launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
     if (!plan_runs) {
@@ -1502,8 +1513,10 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
     const int ppw = ctx->connect_pairs_per_wave > 0 ? ctx->connect_pairs_per_wave : auto_pairs_per_wave(kp.num_local);
     if (pipe_ok) {   // (anything else has flushed the held frames above)
         fs_context::PipeFrame me;
-        me.has = true; me.kp = kp; me.st = st; me.wl = wl; me.perm = perm; me.walked = false; me.s = s; me.fixed = fixed;
-        me.cur = s->cur; me.ppw = ppw; me.want_recon = false;
+        me.has = true; me.kp = kp; me.st = st; me.wl = wl; me.perm = perm; me.walked = false; me.fixed = fixed; me.ppw = ppw;
+        me.items.resize((size_t)count);
+        for (int i = 0; i < count; ++i) { me.items[(size_t)i].s = srcs[i]; me.items[(size_t)i].cur = srcs[i]->cur; }
+        me.energy_tab = energy_tab; me.fixed_tab = fixed_tab;
         FrameParts f;
         f.wl = wl;
         const bool deep = ctx->pipelining >= 2;
@@ -1513,7 +1526,10 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         if (ctx->held[1].has) to_walk = ctx->held[1];
         else if (ctx->held[0].has && !ctx->held[0].walked) to_walk = ctx->held[0];
         if (deep) {   // {plan of this frame, walk of the planned frame, connect of the walked one}
-            if (plan_held) { f.has_plan = true; f.kpp = kp; f.scratch_p = scratch; f.perm_p = sort ? perm_buf : nullptr; f.zero_p = zero_ptr; f.zero_words_p = zero_ptr ? zero_words : 0; }
+            if (plan_held) {
+                f.has_plan = true; f.kpp = kp; f.scratch_p = scratch; f.perm_p = sort ? perm_buf : nullptr;
+                f.zero_p = zero_ptr; f.zero_words_p = (zero_ptr || zero_tab) ? zero_words : 0; f.zero_tab_p = zero_tab; f.zero_count_p = count;
+            }
             if (to_walk.has) held_walk_part(to_walk, f);
         } else {      // {walk of this frame, connect of the walked one}
             held_walk_part(me, f);
@@ -1527,9 +1543,9 @@ static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const 
         }
         if (f.has_walk || f.has_connect || f.has_plan) {
             if (!launch_frame(B, ctx->scene, f, ctx->stream)) {   // no fused form: the same passes one after the other
-                if (f.has_connect) launch_connect(B, ctx->scene, f.kpc, f.stc, f.energy, f.fixed, f.scratch_c, f.ppw, nullptr, nullptr, ctx->stream);
+                if (f.has_connect) launch_connect(B, ctx->scene, f.kpc, f.stc, f.energy, f.fixed, f.scratch_c, f.ppw, f.energy_tab, f.fixed_tab, ctx->stream);
                 if (f.has_walk) launch_walk(ctx->scene, f.kpw, f.stw, f.wl, f.perm, ctx->stream);
-                if (f.has_plan) (void)launch_plan(kp, wplan, zero_ptr, zero_ptr ? zero_words : 0, nullptr, 1, ctx->stream);
+                if (f.has_plan) (void)launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
             }
         }
         if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
@@ -1673,10 +1689,13 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     // pipelined frames: the source's current frame still waits for its connect pass — the reconstruct goes with it
     for (int k = 1; k >= 0; --k) {   // the source's CURRENT frame is the newest held one
         fs_context::PipeFrame& q = ctx->held[k];
-        if (!q.has || q.s != s) continue;
-        if (!q.want_recon && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && (ctx->cfg.world_size == 1 || ctx->comm)) {
-            q.want_recon = true;
-            q.recon = *p;
+        if (!q.has) continue;
+        fs_context::PipeFrame::Item* it = nullptr;
+        for (fs_context::PipeFrame::Item& c : q.items) if (c.s == s) it = &c;
+        if (!it) continue;
+        if (!it->want_recon && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && (ctx->cfg.world_size == 1 || ctx->comm)) {
+            it->want_recon = true;
+            it->recon = *p;
             return FS_OK;
         }
         break;

@@ -180,8 +180,10 @@ struct FrameParts {
     KParams kpw; SubpathState stw; WalkLaunch wl; const uint32_t* perm = nullptr;
     bool has_connect = false;   // kpc, stc, energy / fixed, scratch_c (re-armed by the pass), ppw
     KParams kpc; SubpathState stc; float* energy = nullptr; unsigned long long* fixed = nullptr; unsigned* scratch_c = nullptr; int ppw = 64;
+    float* const* energy_tab = nullptr; unsigned long long* const* fixed_tab = nullptr;   // batched frame: per-source buffers
     bool has_plan = false;      // kpp, scratch_p, perm_p (the schedule to write, nullptr: counts only), zero_p / zero_words_p (the flush)
     KParams kpp; unsigned* scratch_p = nullptr; uint32_t* perm_p = nullptr; float* zero_p = nullptr; int zero_words_p = 0;
+    float* const* zero_tab_p = nullptr; int zero_count_p = 0;                              // batched frame: the buffers to flush
 };
 bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s);
 // does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule

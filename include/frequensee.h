@@ -276,8 +276,9 @@ int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t
  * first, so results never depend on the setting; only WHEN work reaches the GPU does: a producer that streams frames
  * (many sources, offline rendering, bench.py) gains 12-14 % (36 % on 16 384-ray frames), a producer that issues one
  * frame per game tick should end the tick with fs_submit (or leave pipelining off) or the frame's IR is published one
- * or two ticks later.  Frames with lobes, all-connections modes, depth = 0, FS_FLAG_ACCUMULATE_ENERGY, batches and
- * profiling level >= 2 are never held. */
+ * or two ticks later.  Batched frames are held like any other (they gain little: a frame of several chip-fulls has no
+ * thin tail to fill).  Frames with lobes, all-connections modes, depth = 0, FS_FLAG_ACCUMULATE_ENERGY and profiling
+ * level >= 2 are never held. */
 int fs_set_pipelining(fs_context* ctx, int32_t depth);   /* 0 = off, 1, 2 */
 int fs_submit(fs_context* ctx);   /* hand everything requested so far to the GPU; does not wait */
 

@@ -103,3 +103,36 @@ def test_blocking_calls_and_the_oracle(pkg, scene_factory, oracle_mod):
         assert max(rel_rms(e[b], e64[b]) for b in range(4)) <= 1e-3
     ctx.set_pipelining(False)
     ctx.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_batched_frames_are_pipelined_too(pkg, scene_factory, depth):
+    """Several sources traced as one batched frame (ForceUpdateSources): the held-back passes carry the per-source tables;
+    every source's energy and IR equal those of an unpipelined context, stream after stream, also with single-source
+    frames in between."""
+    sc = scene_factory("starter_room", 4)
+    plain, ps = make_ctx(pkg, sc)
+    pipe, qs = make_ctx(pkg, sc)
+    pipe.set_pipelining(depth)
+    pos = [np.asarray(sc.source, np.float32) + np.float32(40.0 * k) * np.array([1, -1, 0], np.float32) for k in range(1, 4)]
+    pa = [ps] + [plain.create_source(q) for q in pos]
+    qa = [qs] + [pipe.create_source(q) for q in pos]
+    for rnd in range(3):
+        for i in range(5):
+            p = pkg.default_params(num_rays=8192, depth=8, seed=700 + 10 * rnd + i, flags=DET)
+            for c, srcs in ((plain, pa), (pipe, qa)):
+                if i == 3:      # a single-source frame between the batches
+                    c.compute_energy_response_async(srcs[1], p)
+                    c.reconstruct_impulse_response_async(srcs[1], p)
+                else:
+                    c.compute_energy_response_batch_async(srcs, p)
+                    for s_ in (srcs if i != 2 else srcs[:2]):      # (one batch reconstructs only two of its sources)
+                        c.reconstruct_impulse_response_async(s_, p)
+        plain.synchronize(); pipe.synchronize()
+        for a, b in zip(pa, qa):
+            assert np.array_equal(plain.energy_buffer(a), pipe.energy_buffer(b)), rnd
+            assert np.array_equal(plain.impulse_response(a, 0), pipe.impulse_response(b, 0)), rnd
+        sa, sb = plain.stats(), pipe.stats()
+        for k in ("frames", "rays", "segments", "connections_tested", "deposits"):
+            assert sa[k] == sb[k], (rnd, k)
+    plain.close(); pipe.close()
