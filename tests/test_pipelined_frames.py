@@ -136,3 +136,22 @@ def test_batched_frames_are_pipelined_too(pkg, scene_factory, depth):
         for k in ("frames", "rays", "segments", "connections_tested", "deposits"):
             assert sa[k] == sb[k], (rnd, k)
     plain.close(); pipe.close()
+
+
+def test_argument_errors_of_the_new_calls(pkg, scene_factory):
+    """fs_set_pipelining takes 0, 1 or 2; the gather needs a peer communicator; both say so instead of guessing."""
+    sc = scene_factory("shoebox", 1)
+    ctx, src = make_ctx(pkg, sc)
+    for bad in (3, -1):
+        with pytest.raises(pkg.FrequenSeeError) as e:
+            ctx.set_pipelining(bad)
+        assert e.value.code == pkg._capi.ERR_INVALID_ARGUMENT
+    ctx.set_pipelining(2)
+    ctx.compute_energy_response_async(src, pkg.default_params(num_rays=1024, depth=4))
+    with pytest.raises(pkg.FrequenSeeError) as e:      # (the held frame is flushed first; then the missing communicator is reported)
+        ctx.gather_energy(src)
+    assert e.value.code == pkg._capi.ERR_COMM
+    ctx.submit()
+    ctx.synchronize()
+    assert ctx.energy_buffer(src).sum() > 0
+    ctx.close()
