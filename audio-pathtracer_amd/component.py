@@ -507,10 +507,24 @@ class AudioRayTracingSubsystem:
             self.ctx.reconstruct_impulse_response_async(s._src, self.params)
         self.ctx.synchronize()
 
+    def SetPipelining(self, depth):
+        """fs_set_pipelining: Tick then updates the sources one after the other like the reference's loop (ARTS.cpp:60-68),
+        streamed — every call launches one kernel that plans this source's frame, walks the previous source's and
+        connects the one before — and ends with fs_submit; the IRs appear as they are published"""
+        self.ctx.set_pipelining(depth)
+        self._streamed = bool(depth)
+
     def Tick(self, DeltaTime):  # ARTS.cpp:55-85 without the 1 s warm-up: the caller drives every frame
         if not self.ActiveSources:
             return
-        self.ForceUpdateSources()
+        if getattr(self, "_streamed", False):
+            self._commit()
+            for s in self.ActiveSources:
+                self.ctx.compute_energy_response_async(s._src, self.params)
+                self.ctx.reconstruct_impulse_response_async(s._src, self.params)
+            self.ctx.submit()
+        else:
+            self.ForceUpdateSources()
         # the reference draws from the engine's global rand() stream: every frame sees fresh samples
         self.params.seed = (self.params.seed + 1) & 0xFFFFFFFFFFFFFFFF
 

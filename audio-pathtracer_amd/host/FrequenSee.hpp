@@ -159,7 +159,23 @@ public:
     }
     // .cpp:55-85 (the caller drives every frame).  The reference draws from the engine's global rand() stream, so every
     // frame sees fresh samples: the seed advances.
-    void Tick(float /*DeltaTime*/) { if (!ActiveSources.empty()) { ForceUpdateSources(); ++Params.seed; } }
+    void Tick(float /*DeltaTime*/) {
+        if (ActiveSources.empty()) return;
+        if (Streamed_) {   // the reference's loop over the sources (.cpp:60-68), one pipelined launch per source
+            Commit();
+            for (auto* s : ActiveSources) {
+                Check(fs_compute_energy_response_async(Ctx_, s->Handle_, &Params));
+                Check(fs_reconstruct_impulse_response_async(Ctx_, s->Handle_, &Params));
+            }
+            Check(fs_submit(Ctx_));   // nothing waits: the IRs appear as they are published
+        } else {
+            ForceUpdateSources();
+        }
+        ++Params.seed;
+    }
+    // fs_set_pipelining (0 off, 1, 2): Tick streams the sources instead of batching them
+    void SetPipelining(int Depth) { Check(fs_set_pipelining(Ctx_, Depth)); Streamed_ = Depth != 0; }
+    void Synchronize() { Check(fs_synchronize(Ctx_)); }
 
     int NumBands() const { return NumBands_; }
     fs_context* Context() const { return Ctx_; }
@@ -208,6 +224,7 @@ private:
     bool Committed_ = false;
     int NumBands_ = 1;
     int Peers_ = 0;
+    bool Streamed_ = false;
     friend class FrequenSeeAudioComponent;
     friend class MaterialAcousticProcessor;
 };

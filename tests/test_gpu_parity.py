@@ -375,6 +375,21 @@ def test_force_update_sources_batches_all_active_sources(pkg, oracle_mod, scene_
         assert np.array_equal(got != 0, e != 0) and max(rel_rms(got[b], e[b].astype(np.float64)) for b in range(4)) <= TIGHT_TOL
         assert np.abs(c.GetImpulseResponse()[0] - ir).max() <= IR_TOL * max(np.abs(ir).max(), 1e-30)
     assert not np.array_equal(one_by_one[0], one_by_one[1])
+    # the reference's own shape of Tick — one UpdateSource after the other — streamed through pipelined frames
+    sub.SetPipelining(2)
+    seed = sub.params.seed                      # Tick advanced it: the streamed frames use the next seed
+    want = [sub.UpdateSource(c, sub.params).copy() for c in comps]
+    want_ir = [c.GetImpulseResponse()[0].copy() for c in comps]
+    for c in comps:
+        c.FlushEnergyBuffer()
+    assert sub.params.seed == seed
+    sub.Tick(0.016)
+    sub.ctx.synchronize()
+    for c, e, ir in zip(comps, want, want_ir):
+        got = c.EnergyBuffer.reshape(e.shape)
+        assert np.array_equal(got != 0, e != 0) and max(rel_rms(got[b], e[b].astype(np.float64)) for b in range(4)) <= TIGHT_TOL
+        assert np.abs(c.GetImpulseResponse()[0] - ir).max() <= IR_TOL * max(np.abs(ir).max(), 1e-30)
+    sub.Deinitialize()
 
 
 BATCH_CASES = [
