@@ -117,7 +117,8 @@ class Context:
 
     # ---- scene ----
     def set_scene(self, triangles, material_ids, absorption, transmission=None, scattering=None, object_ids=None, fast=False):
-        """fast = True: the acceleration structure is built on the device (fs_scene_commit_fast)"""
+        """fast = True: the acceleration structure is built on the device (fs_scene_commit_fast); fast = "progressive": that
+        tree now and the host's SAH tree as soon as a background thread has built it (fs_scene_commit_progressive)"""
         tri = np.ascontiguousarray(triangles, dtype=np.float32).reshape(-1, 3, 3)
         mat = np.ascontiguousarray(material_ids, dtype=np.uint16).reshape(-1)
         if mat.shape[0] != tri.shape[0]:
@@ -138,7 +139,18 @@ class Context:
             self.check(self.lib.fs_scene_set_objects(self.h, obj.ctypes.data, obj.shape[0]))
         else:
             self.check(self.lib.fs_scene_set_objects(self.h, None, tri.shape[0]))
-        self.check((self.lib.fs_scene_commit_fast if fast else self.lib.fs_scene_commit)(self.h))
+        commit = {False: self.lib.fs_scene_commit, True: self.lib.fs_scene_commit_fast,
+                  "progressive": self.lib.fs_scene_commit_progressive}[fast]
+        self.check(commit(self.h))
+
+    def refine_pending(self) -> bool:
+        """fast="progressive": is the background SAH build still outstanding (the swap happens at the next trace after it)"""
+        v = C.c_int32(0)
+        self.check(self.lib.fs_scene_refine_pending(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def refine_wait(self):
+        self.check(self.lib.fs_scene_refine_wait(self.h))
 
     def update_triangles(self, first, triangles):
         """move committed triangles [first, first + n) (row f4: dynamic props); the refit runs before the next trace"""
@@ -454,7 +466,9 @@ class AudioRayTracingSubsystem:
             tri, mat, obj = np.zeros((0, 3, 3), np.float32), np.zeros((0,), np.uint16), None
         ab, tr, sc = self._materials if self._materials is not None else (
             np.zeros((0, self.ctx.num_bands), np.float32), None, None)
-        self.ctx.set_scene(tri, mat, ab, tr, sc, object_ids=obj, fast=self._committed)
+        # the first commit builds the SAH tree on the host; a registration change during play takes the device-built tree at
+        # once and gets the SAH tree swapped in when the library's background thread has built it
+        self.ctx.set_scene(tri, mat, ab, tr, sc, object_ids=obj, fast="progressive" if self._committed else False)
         self._dirty = False
         self._committed = True
 

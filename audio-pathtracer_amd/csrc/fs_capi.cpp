@@ -6,12 +6,15 @@
 // is HIP on the context's stream; there is no CPU fallback.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: librccl is opened at run time (fs_comm_*), never linked
@@ -77,6 +80,16 @@ struct TimedFrame {
 };
 
 }  // namespace
+
+// fs_scene_commit_progressive: the host's SAH build of a snapshot of the registered triangles, on its own thread, while
+// the frames already trace through the device-built tree.  The thread touches nothing but this object.
+struct RefineJob {
+    std::vector<float> xyz; std::vector<uint16_t> mat; std::vector<uint32_t> obj;
+    int T = 0;
+    fs::HostBVH bvh;
+    std::mutex mu; std::condition_variable cv;
+    bool done = false;
+};
 
 struct fs_context {
     fs_config cfg{};
@@ -156,6 +169,9 @@ struct fs_context {
         float* const* energy_tab = nullptr;               // batched frame: the per-frame device tables (kBatchSlots of them
         unsigned long long* const* fixed_tab = nullptr;   // rotate; a held frame is connected two calls later at most)
     } held[2];                       // [0] the older frame, [1] the newer one (depth 2 only)
+    std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
+    bool moved_since_refine = false;     // fs_scene_update_triangles since the snapshot: re-apply the positions after the swap
+    fs::HostBVH* prebuilt = nullptr;     // fs_scene_commit takes this tree instead of building one (install of a refined tree)
     int pipelining = 0;              // 0 off, 1 / 2 = frames held back
     unsigned frame_index = 0;        // consecutive traced frames rotate through the state / schedule / scratch sets
     size_t perm_words = 0;           // words of ONE schedule set (walk.perm holds kPermSets)
@@ -210,6 +226,13 @@ struct fs_context {
 
 // pipelined frames: launch a held-back connect pass on its own (defined next to trace_sources)
 static int flush_pending(fs_context* ctx);
+// fs_scene_commit_progressive: swap the finished background tree in (defined next to the commit functions)
+static int maybe_install_refined(fs_context* ctx);
+static void cancel_refine(fs_context* ctx) { ctx->refine.reset(); ctx->moved_since_refine = false; }
+static void wait_refine(const std::shared_ptr<RefineJob>& j) {
+    std::unique_lock<std::mutex> l(j->mu);
+    j->cv.wait(l, [&] { return j->done; });
+}
 #define FS_FLUSH(ctx)                       \
     do {                                    \
         int fr_ = flush_pending(ctx);       \
@@ -606,6 +629,7 @@ int fs_context_destroy(fs_context* ctx) {
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->cfg.device);
         (void)flush_pending(ctx);
+        if (ctx->refine) { wait_refine(ctx->refine); cancel_refine(ctx); }   // let the background build end before the process may
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
         if (ctx->rev_stream) (void)hipStreamSynchronize(ctx->rev_stream);
@@ -889,6 +913,7 @@ int fs_scene_set_triangles(fs_context* ctx, const float* xyz, const uint16_t* ma
     if (T > (1 << 28)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "too many triangles");
     for (size_t i = 0; i < 9 * (size_t)T; ++i)
         if (!std::isfinite(xyz[i])) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "non-finite vertex coordinate");
+    cancel_refine(ctx);   // a background build of the previous triangle set is of no use any more
     ctx->h_xyz.assign(xyz, xyz + 9 * (size_t)T);
     if (mat_id) ctx->h_mat.assign(mat_id, mat_id + T);
     else ctx->h_mat.assign((size_t)T, (uint16_t)FS_NO_MATERIAL);
@@ -979,6 +1004,7 @@ int fs_scene_commit(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
     FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    if (!ctx->prebuilt) cancel_refine(ctx);
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
@@ -991,8 +1017,10 @@ int fs_scene_commit(fs_context* ctx) {
     const bool root = !bcast || ctx->cfg.rank == 0;
     size_t n_nodes = 0, n_tris = 0, n_leaf = 0, n_lvl = 0;
     if (root) {
-        build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(),
-                  ctx->h_obj.size() == (size_t)ctx->T && ctx->T > 0 ? ctx->h_obj.data() : nullptr, ctx->T, ctx->bvh);
+        if (ctx->prebuilt) ctx->bvh = std::move(*ctx->prebuilt);   // the background build of fs_scene_commit_progressive
+        else
+            build_bvh(ctx->h_xyz.data(), ctx->h_mat.data(),
+                      ctx->h_obj.size() == (size_t)ctx->T && ctx->T > 0 ? ctx->h_obj.data() : nullptr, ctx->T, ctx->bvh);
         n_nodes = ctx->bvh.nodes.size(); n_tris = ctx->bvh.tris.size();
         n_leaf = ctx->bvh.leaf_pos.size(); n_lvl = ctx->bvh.level_begin.size();
     }
@@ -1072,6 +1100,7 @@ int fs_scene_commit_fast(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
     FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    cancel_refine(ctx);
     if (ctx->T < 1 || ctx->comm) return fs_scene_commit(ctx);   // empty scene / sharded run: the one build rank 0 broadcasts
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1142,6 +1171,39 @@ int fs_scene_commit_fast(fs_context* ctx) {
     return FS_OK;
 }
 
+// The tree of fs_scene_commit_fast now, the host's SAH tree as soon as it is built (header).
+int fs_scene_commit_progressive(fs_context* ctx) {
+    const int rc = fs_scene_commit_fast(ctx);
+    if (rc) return rc;
+    if (ctx->fast_cap_tris == 0) return FS_OK;   // the fast commit took the host's build itself (sharded run, degenerate tree): nothing to refine
+    std::shared_ptr<RefineJob> job = std::make_shared<RefineJob>();
+    job->xyz = ctx->h_xyz; job->mat = ctx->h_mat;
+    if (ctx->h_obj.size() == (size_t)ctx->T) job->obj = ctx->h_obj;
+    job->T = ctx->T;
+    ctx->refine = job;
+    ctx->moved_since_refine = false;
+    std::thread([job] {
+        build_bvh(job->xyz.data(), job->mat.data(), job->obj.empty() ? nullptr : job->obj.data(), job->T, job->bvh);
+        { std::lock_guard<std::mutex> l(job->mu); job->done = true; }
+        job->cv.notify_all();
+    }).detach();
+    return FS_OK;
+}
+
+int fs_scene_refine_pending(fs_context* ctx, int32_t* pending) {
+    if (!ctx || !pending) return FS_ERR_INVALID_ARGUMENT;
+    *pending = ctx->refine ? 1 : 0;
+    return FS_OK;
+}
+
+int fs_scene_refine_wait(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->refine) return FS_OK;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    wait_refine(ctx->refine);
+    return maybe_install_refined(ctx);
+}
+
 // ---- moving geometry (row f4): ECC_WorldDynamic movers are seen by the next trace (ARTS.cpp:333-336) -------------
 int fs_scene_update_triangles(fs_context* ctx, int32_t first, int32_t count, const float* xyz) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
@@ -1162,6 +1224,7 @@ int fs_scene_update_triangles(fs_context* ctx, int32_t first, int32_t count, con
         ctx->move_cap = (size_t)count;
     }
     std::memcpy(ctx->h_xyz.data() + 9 * (size_t)first, xyz, sizeof(float) * 9 * (size_t)count);   // a later commit stays consistent
+    if (ctx->refine) ctx->moved_since_refine = true;   // the background tree was built from the old positions
     for (size_t i = 0; i < 9 * (size_t)count; ++i) ctx->amax = std::max(ctx->amax, std::fabs(xyz[i]));
     // the staging buffer may still be read by the previous update's kernel: same stream, so ordered
     FS_HIP(ctx, hipMemcpyAsync(ctx->d_move, xyz, sizeof(float) * 9 * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
@@ -1285,6 +1348,28 @@ static int check_overflow(fs_context* ctx) {
 
 static int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
 
+// fs_scene_commit_progressive: once the background build has finished, the next call that traces anything swaps its tree
+// in — held frames finish first (they were traced through the old tree's arrays), the stream drains, the records are
+// uploaded; triangles moved since the snapshot get their current positions and a refit.
+static int maybe_install_refined(fs_context* ctx) {
+    if (!ctx->refine) return FS_OK;
+    std::shared_ptr<RefineJob> j = ctx->refine;
+    { std::lock_guard<std::mutex> l(j->mu); if (!j->done) return FS_OK; }
+    const bool moved = ctx->moved_since_refine;
+    ctx->refine.reset();
+    ctx->moved_since_refine = false;
+    if (j->T != ctx->T || !ctx->committed) return FS_OK;
+    ctx->prebuilt = &j->bvh;
+    const int rc = fs_scene_commit(ctx);
+    ctx->prebuilt = nullptr;
+    if (rc) return rc;
+    if (moved) {
+        const std::vector<float> now = ctx->h_xyz;
+        return fs_scene_update_triangles(ctx, 0, ctx->T, now.data());
+    }
+    return FS_OK;
+}
+
 // ---- pipelined frames ---------------------------------------------------------------------------------------------
 // What a held frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum over
 // the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
@@ -1338,6 +1423,7 @@ static int flush_pending(fs_context* ctx) {
 static int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
     Source* s = srcs[0];
     const bool batch = count > 1;
+    { int ir = maybe_install_refined(ctx); if (ir) return ir; }                     // fs_scene_commit_progressive: the better tree is ready
     if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     int rc = check_params(ctx, p);
     if (rc) return rc;
@@ -1961,6 +2047,7 @@ int fs_update_sound(fs_context* ctx, fs_source h, const fs_sound_params* p, fs_s
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    { int ir = maybe_install_refined(ctx); if (ir) return ir; }                     // fs_scene_commit_progressive: the better tree is ready
     if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     fs_sound_params def;
     if (!p) { fs_sound_params_default(&def); p = &def; }
@@ -2010,6 +2097,7 @@ int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, cons
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    { int ir = maybe_install_refined(ctx); if (ir) return ir; }                     // fs_scene_commit_progressive: the better tree is ready
     if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     if (N < 0 || (N > 0 && (!origins || !dirs || !tmax || !hit))) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad ray arrays");
     if (!any_hit && N > 0 && (!t || !tri || !normal)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "closest-hit outputs required");

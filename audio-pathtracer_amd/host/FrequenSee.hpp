@@ -97,8 +97,8 @@ public:
     AudioRayTracingSubsystem& operator=(const AudioRayTracingSubsystem&) = delete;
 
     // RegisterGeometry / UnregisterGeometry (.h:99-100).  The first commit builds the tree on the host (binned SAH);
-    // a registration change DURING play (Committed_ already) rebuilds it on the device instead (fs_scene_commit_fast,
-    // a tenth of the time; call RebuildQuality() when a frame can afford the SAH build again).
+    // a registration change DURING play (Committed_ already) rebuilds it on the device instead, a tenth of the time
+    // (fs_scene_commit_progressive: the SAH tree follows by itself from a background thread; RebuildQuality() forces it now).
     void RegisterGeometry(const AcousticGeometryComponent* Comp) { Geometry_.push_back(Comp); Dirty_ = true; }
     void UnregisterGeometry(const AcousticGeometryComponent* Comp) {
         for (size_t i = 0; i < Geometry_.size(); ++i)
@@ -191,7 +191,7 @@ public:
         Check(fs_scene_set_materials(Ctx_, Absorption_.data(), nullptr, nullptr, NumMaterials_,
                                      NumMaterials_ ? (int32_t)(Absorption_.size() / (size_t)NumMaterials_) : NumBands()));
         Check(fs_scene_set_objects(Ctx_, obj.data(), (int32_t)obj.size()));
-        Check(Committed_ ? fs_scene_commit_fast(Ctx_) : fs_scene_commit(Ctx_));
+        Check(Committed_ ? fs_scene_commit_progressive(Ctx_) : fs_scene_commit(Ctx_));
         Dirty_ = false;
         Committed_ = true;
     }

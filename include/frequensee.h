@@ -181,6 +181,16 @@ int fs_scene_commit(fs_context* ctx); /* builds the flattened BVH (binned SAH, o
  * fs_scene_commit again when there is time.  Falls back to fs_scene_commit by itself for empty scenes, sharded contexts
  * with a communicator (rank 0's build is broadcast) and degenerate inputs. */
 int fs_scene_commit_fast(fs_context* ctx);
+/* Both: the device-built tree NOW (frames trace through it right away) and the host's SAH tree as soon as a background
+ * thread has built it from a snapshot of the registered triangles (18 ms per 100 000 triangles) — the next call that
+ * traces anything after that swaps it in (held frames finish first, the stream drains, 8 MB of records are uploaded:
+ * ~1 ms once).  Results never change, only the tracing speed (the SAH tree traces 1.6x faster).  Triangles moved by
+ * fs_scene_update_triangles in the meantime keep their current positions (re-applied + refit after the swap); a new
+ * fs_scene_set_triangles / commit abandons the background build.  fs_scene_refine_pending: is a build still outstanding;
+ * fs_scene_refine_wait: block until it has finished and swap now.  fs_context_destroy waits for an outstanding build. */
+int fs_scene_commit_progressive(fs_context* ctx);
+int fs_scene_refine_pending(fs_context* ctx, int32_t* pending);
+int fs_scene_refine_wait(fs_context* ctx);
 /* Moving geometry without a rebuild (row f4).  The reference's line traces run against the live physics scene and
  * include ECC_WorldDynamic objects (ARTS.cpp:333-336, FSAC.cpp:229-232): a prop that moved is seen by the next
  * frame.  fs_scene_update_triangles overwrites `count` committed triangles starting at input index `first` with new

@@ -796,6 +796,66 @@ def test_device_built_tree_gives_the_same_frames(pkg, oracle_mod, scene_factory)
     ctx.close()
 
 
+def test_progressive_commit_swaps_the_sah_tree_in(pkg, scene_factory):
+    """fs_scene_commit_progressive: frames trace through the device-built tree at once; the host's SAH build runs on a
+    background thread and is swapped in by the first trace after it has finished.  Nothing a caller can observe changes
+    but the tree's statistics (and the speed): deterministic frames are bit-identical before and after the swap, also with
+    triangles moved while the build was running, with pipelined frames held across the swap, and a new registration
+    abandons an outstanding build."""
+    sc = scene_factory("old_mine", 8)
+    DETF = 8
+    ref, rsrc = make_ctx(pkg, sc)                      # host-built SAH tree from the start
+    host_nodes = ref.stats()["bvh_nodes"]
+    ctx = pkg.Context(num_bands=8)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast="progressive")
+    ctx.set_listener(sc.listener)
+    src = ctx.create_source(sc.source)
+    assert ctx.stats()["bvh_nodes"] != host_nodes      # the Morton tree for now
+    frames = [pkg.default_params(num_rays=32768, depth=8, seed=60 + i, flags=DETF) for i in range(6)]
+    want = []
+    moved = np.asarray(sc.triangles[:300], np.float32) + np.array([25.0, -15.0, 8.0], np.float32)
+    for i, p in enumerate(frames):
+        if i == 2:
+            ref.update_triangles(0, moved)
+        want.append(ref.compute_energy_response(rsrc, p).copy())
+    ctx.set_pipelining(2)
+    got = []
+    for i, p in enumerate(frames):
+        if i == 2:                                     # moving geometry while the background build may still be running
+            ctx.update_triangles(0, moved)
+        if i == 4:                                     # from here on the SAH tree: wait for the build, swap
+            ctx.refine_wait()
+            assert not ctx.refine_pending()
+            assert ctx.stats()["bvh_nodes"] == host_nodes
+        ctx.compute_energy_response_async(src, p)      # (frames 2 and 3 are held across the swap)
+        if i != 3:
+            ctx.synchronize()
+            got.append(ctx.energy_buffer(src).copy())
+        else:
+            got.append(None)
+    ctx.synchronize()
+    for i, (g, w) in enumerate(zip(got, want)):
+        if g is not None:
+            assert np.array_equal(g, w), i
+    assert np.array_equal(ctx.energy_buffer(src), want[-1])
+    # without the explicit wait the swap happens by itself at a later trace
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast="progressive")
+    import time
+    t0 = time.time()
+    while ctx.refine_pending() and time.time() - t0 < 30:
+        ctx.compute_energy_response(src, frames[0])
+    assert not ctx.refine_pending() and ctx.stats()["bvh_nodes"] == host_nodes
+    ref.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+    assert np.array_equal(ctx.compute_energy_response(src, frames[1]), ref.compute_energy_response(rsrc, frames[1]))
+    # a new registration abandons an outstanding build
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast="progressive")
+    ctx.set_scene(sc.triangles[:5000], sc.material_ids[:5000], sc.absorption, fast=True)
+    assert not ctx.refine_pending() and ctx.stats()["triangles"] == 5000
+    ctx.compute_energy_response(src, frames[0])
+    ctx.close()
+    ref.close()
+
+
 def test_library_collective_one_rank(pkg, oracle_mod, scene_factory):
     """The RCCL all-reduce lives behind the C ABI (fs_comm_init): with a one-rank communicator attached every frame
     runs the library's collective on the tail stream — a sum over one rank — and the scene goes through the broadcast

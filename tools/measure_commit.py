@@ -50,6 +50,28 @@ for name, bands, rays in (("old_mine", 8, 262144), ("starter_room", 4, 16384)):
         row[kind] = {"commit_ms": 1e3 * best, "set_triangles_and_commit_ms": 1e3 * best_all, "bvh_nodes": st["bvh_nodes"], "stack_need": st["bvh_stack_need"],
                      "frame_ms": 1e3 * el / 100, "walk_ms": s2["walk_kernel_ms_sum"] / max(s2["timed_frames"], 1),
                      "connect_ms": s2["connect_kernel_ms_sum"] / max(s2["timed_connects"], 1)}
+    # fs_scene_commit_progressive: the device tree at once, the SAH tree swapped in when the background build is done
+    t0 = time.perf_counter()
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, fast="progressive")
+    ctx.synchronize()
+    t_call = time.perf_counter() - t0
+    frames_before = 0
+    while ctx.refine_pending():                       # frames keep going through the Morton tree meanwhile
+        p.seed = 5000 + frames_before
+        t1 = time.perf_counter()
+        ctx.compute_energy_response_async(src, p)
+        ctx.synchronize()
+        t_last = time.perf_counter() - t1             # the last one of these includes the swap
+        frames_before += 1
+    t_ready = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(50):
+        p.seed = 6000 + i
+        ctx.compute_energy_response_async(src, p)
+    ctx.synchronize()
+    row["progressive"] = {"set_triangles_and_commit_ms": 1e3 * t_call, "frames_traced_before_the_swap": frames_before,
+                          "swapped_after_ms": 1e3 * t_ready, "frame_with_the_swap_ms": 1e3 * t_last,
+                          "frame_ms_afterwards": 1e3 * (time.perf_counter() - t1) / 50, "bvh_nodes": ctx.stats()["bvh_nodes"]}
     res[name] = row
     ctx.close()
 print(json.dumps(res))
