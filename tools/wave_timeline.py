@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (not the product build): when every wave of the cfg3 walk kernel ran and what it spent its cycles on.
 Builds a -DFS_WAVE_TIMELINE copy of libfrequensee.so into gpurun_out/ and traces a few cfg3 frames through it.
-usage (GPU box): python tools/wave_timeline.py [extra -D flags]  > gpurun_out/r02_wave_timeline.json"""
+usage (GPU box): [FS_TIMELINE_PIPELINED=1] python tools/wave_timeline.py [extra -D flags]  > gpurun_out/r02_wave_timeline.json"""
 import ctypes as C
 import json
 import os
@@ -52,7 +52,23 @@ hip.hipMemset(cptr, 0, 8 * 8 * CW)
 lib.fs_debug_connect_buffer.argtypes = [C.c_void_p]
 lib.fs_debug_connect_buffer(cptr)
 p.seed = 0x5EED
-ctx.compute_energy_response(s, p)
+if os.environ.get("FS_TIMELINE_PIPELINED") == "1":
+    # the pipelined launch instead: {plan of frame f, walk of frame f-1, connect of frame f-2} — arm the buffers for
+    # exactly one such launch (the stream is drained through HIP, not through the library, which would flush)
+    lib.fs_debug_wave_buffer(None); lib.fs_debug_connect_buffer(None)
+    ctx.set_pipelining(2)
+    for i in range(6):
+        p.seed = 200 + i
+        ctx.compute_energy_response_async(s, p)
+    hip.hipDeviceSynchronize()
+    lib.fs_debug_wave_buffer(dptr); lib.fs_debug_connect_buffer(cptr)
+    p.seed = 0x5EED
+    ctx.compute_energy_response_async(s, p)
+    hip.hipDeviceSynchronize()
+    lib.fs_debug_wave_buffer(None); lib.fs_debug_connect_buffer(None)
+    ctx.synchronize()
+else:
+    ctx.compute_energy_response(s, p)
 buf = np.zeros((W, 8), np.uint64)
 assert hip.hipMemcpy(buf.ctypes.data, dptr, buf.nbytes, 2) == 0
 lib.fs_debug_wave_buffer(None)
@@ -91,7 +107,11 @@ if len(cl):
     c0 = cl[:, 0].min()
     ph = lambda a, b: {"p50": float(np.median((cl[:, b] - cl[:, a]) / 100.0)), "p90": float(np.percentile((cl[:, b] - cl[:, a]) / 100.0, 90)),
                        "max": float(((cl[:, b] - cl[:, a]) / 100.0).max())}
+    cs, ce = (cl[:, 0] - t0) / 100.0, (cl[:, 4] - t0) / 100.0
+    res["connect_waves_over_time"] = [[float(t), int(((cs <= t) & (ce > t)).sum())] for t in np.linspace(0, max(end.max(), ce.max()), 41)]
+    res["launch_span_us"] = float(max(end.max(), ce.max()))
     res["connect"] = {"waves": int(len(cl)), "span_us": float((cl[:, 4].max() - c0) / 100.0),
+                      "first_start_us": float(cs.min()), "start_us_p50": float(np.median(cs)), "end_us_max": float(ce.max()),
                       "start_us_max": float((cl[:, 0].max() - c0) / 100.0),
                       "gap_after_walk_us": float((c0 - t0) / 100.0 - end.max()),
                       "setup_us": ph(0, 1), "visibility_us": ph(1, 2), "evaluate_us": ph(2, 3), "flush_us": ph(3, 4), "wave_us": ph(0, 4)}
