@@ -82,3 +82,15 @@ def test_scene_generators_exact_counts(scene_factory):
     assert om.num_triangles == 100000 and om.absorption.shape == (8, 8)
     assert om.extra_sources.shape == (8, 3)
     assert 0.05 <= om.absorption.min() and om.absorption.max() <= 0.9
+
+
+def test_every_export_is_explained_to_the_integrator():
+    """INTEGRATION.md's last table names the reference interface every entry point of include/frequensee.h stands for."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "frequensee.h")).read()
+    names = set(re.findall(r"^(?:int|void|const char\*) (fs_[a-z_]+)\(", header, re.M))
+    assert len(names) >= 60
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc and n.replace("fs_", "fs_").rsplit("_async", 1)[0] not in doc)
+    assert not missing, missing
