@@ -470,12 +470,15 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
 // and takes the latency of its longest chain of closest-hit queries, which shrinks when the idle lanes of sparse
 // waves help with every query (walk_kernel_sparse).  Thresholds measured on MI355X
 // (tools/sparse_sweep.py, tools/sparse_check.py, profiles/r01_sparse_waves.json).  Frames of shallow walks do best at
-// about 2048 waves (16 384 subpaths at depth 8: 0.33 -> 0.19 ms with 8 per wave; from 131 072 subpaths on dense
+// about 2048 waves (16 384 subpaths at depth 8: 0.33 -> 0.19 ms with 8 per wave; from 262 144 subpaths on dense
 // waves win).  Walks deeper than 16 segments (the reference's unbounded default) leave long chains of a few
 // survivors and do best at about 16 384 waves at every size measured (262 144 subpaths, unbounded depth, 5 000
 // triangles: 1.29 -> 0.82 ms with 16 per wave; 1 048 576: dense again).
 int auto_rays_per_wave(unsigned long long lanes, int depth) {
-    const unsigned long long target_waves = depth > 16 ? 16384ull : 2048ull;
+    // round 2 (kShareMinIdle, pipelined frames; tools/pipelined_rpw_sweep.py, profiles/r02_pipelined_rpw_sweep.json): mid-size
+    // frames do better at ~4096 waves — 65 536 subpaths 16 per wave, 131 072 subpaths 32 per wave (0.244 -> 0.233 ms at
+    // depth 8, 0.355 -> 0.309 ms at depth 12; unpipelined 0.300 -> 0.267 ms); 262 144 and more stay dense
+    const unsigned long long target_waves = depth > 16 ? 16384ull : (lanes >= 65536ull ? 4096ull : 2048ull);
     int rpw = 4;
     while (rpw < 64 && (unsigned long long)rpw * 2 * target_waves <= lanes) rpw *= 2;   // largest power of two <= lanes / target
     return rpw;
