@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two frames in flight: N contexts on the same scene, frames issued round-robin without waiting (product path only).
-Does the walk of one frame fill the thin tail of the previous one?  usage: python tools/two_in_flight.py [contexts] [rays]"""
+Does the walk of one frame fill the thin tail of the previous one?  usage: python tools/two_in_flight.py [contexts] [rays] [frames] [depth]"""
 import json
 import os
 import sys
@@ -13,6 +13,7 @@ pkg = graft.load_package()
 nctx = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 rays = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+depth = int(sys.argv[4]) if len(sys.argv) > 4 else 8      # 0 = unbounded walks (the reference's while (true))
 sc = pkg.scenes.old_mine(8)
 ctxs, srcs = [], []
 for _ in range(nctx):
@@ -21,7 +22,7 @@ for _ in range(nctx):
     c.set_listener(sc.listener)
     ctxs.append(c)
     srcs.append(c.create_source(sc.source))
-p = pkg.default_params(num_rays=rays, depth=8)
+p = pkg.default_params(num_rays=rays, depth=depth)
 
 
 def run(n, seed0):
@@ -38,4 +39,4 @@ run(40, 10)
 t = time.perf_counter()
 run(frames, 100)
 dt = (time.perf_counter() - t) / frames
-print(json.dumps({"contexts": nctx, "rays_per_frame": rays, "ms_per_frame": 1e3 * dt, "rays_per_s": rays / dt}))
+print(json.dumps({"contexts": nctx, "depth": depth, "rays_per_frame": rays, "ms_per_frame": 1e3 * dt, "rays_per_s": rays / dt}))
