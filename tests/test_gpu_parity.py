@@ -401,6 +401,7 @@ BATCH_CASES = [
     ("lobes_no_rr", "starter_room", 4, 2048, 5, 4, {"flags": 64, "russian_roulette": 0}),
     ("all_connections_fallback", "shoebox", 1, 512, 4, 3, {"flags": 16}),
     ("one_source", "shoebox", 1, 1024, 6, 1, {}),
+    ("unbounded_walks", "starter_room", 4, 8192, 0, 3, {}),
 ]
 
 
