@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
     const int pairs = argc > 2 ? std::atoi(argv[2]) : AudioRayTracingSubsystem::USED_RAY_COUNT;
     const int depth = argc > 3 ? std::atoi(argv[3]) : 0;
     const std::string out = argc > 4 ? argv[4] : "saved_ir.txt";
+    const int pipelining = argc > 5 ? std::atoi(argv[5]) : 0;   // fs_set_pipelining depth: Tick then streams the sources
     try {
         AudioRayTracingSubsystem SubSys(/*NumBands=*/1);
         // shoebox 1000 x 800 x 300 cm, one material rho = 0.5 (BASELINE.json configs[0])
@@ -45,11 +46,13 @@ int main(int argc, char** argv) {
 
         std::vector<float> Energy;
         SubSys.UpdateSource(Comp, &Energy);                       // warm-up + first result
+        if (pipelining) SubSys.SetPipelining(pipelining);
         auto t0 = std::chrono::steady_clock::now();
         for (int f = 0; f < frames; ++f) {
             SubSys.Params.seed = 0x5EED + (uint64_t)f;            // a new sample set every frame
             SubSys.Tick(1.0f / 60.0f);
         }
+        SubSys.Synchronize();                                     // (streamed Ticks only submit)
         double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         int n = 0;
         const float* ir = Comp.GetImpulseResponse(0, &n);

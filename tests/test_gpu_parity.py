@@ -1462,6 +1462,13 @@ def test_cpp_harness_matches_oracle(pkg, oracle_mod, scene_factory, tmp_path):
     osc.set_objects(np.zeros(12, np.uint32))
     assert j["occlusion_attenuation"] == pytest.approx(osc.update_sound(sc.source, sc.listener)["occlusion_attenuation"], rel=1e-5)
     assert j["material_fd_max_err"] <= 1e-5 * max(j["ir_peak"], 1e-3)   # MaterialAcousticProcessor through the C++ mirror
+    # the same run with the mirror's streamed Tick (fs_set_pipelining 2 + fs_submit per tick): the same impulse response
+    out2 = tmp_path / "saved_ir_streamed.txt"
+    r2 = subprocess.run([exe, "3", "512", "4", str(out2), "2"], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0, r2.stderr
+    ir2 = pkg._capi.load_float_array(out2)
+    assert np.abs(ir2 - ir_ref).max() <= 6e-7 + 1e-5 * np.abs(ir_ref).max()
+    assert json.loads(r2.stdout)["ir_peak"] == pytest.approx(j["ir_peak"], rel=1e-5)
 
 
 def test_api_state_machine_stress():
