@@ -1061,8 +1061,14 @@ int fs_scene_commit(fs_context* ctx) {
     size_t nb = n_nodes * sizeof(NodeQ4), tb = n_tris * sizeof(Tri64);
     size_t mb = ctx->h_absorption.size() * sizeof(float);
     if (nb) {
+#if defined(FS_NODE_STRIDE) && FS_NODE_STRIDE != 64   // sensitivity build: one node per 128-B line (this commit path only)
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, n_nodes * FS_NODE_STRIDE));
+        FS_HIP(ctx, hipMemcpy2DAsync(ctx->d_nodes, FS_NODE_STRIDE, ctx->bvh.nodes.data(), sizeof(NodeQ4), sizeof(NodeQ4), n_nodes,
+                                     hipMemcpyHostToDevice, ctx->stream));
+#else
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_nodes, nb));
         if (root) FS_HIP(ctx, hipMemcpyAsync(ctx->d_nodes, ctx->bvh.nodes.data(), nb, hipMemcpyHostToDevice, ctx->stream));
+#endif
         if (bcast) FS_NCCL(ctx, ra->Broadcast(ctx->d_nodes, ctx->d_nodes, nb, ncclUint8, 0, ctx->comm, ctx->stream));
     }
     if (tb) {

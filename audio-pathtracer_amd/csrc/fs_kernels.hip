@@ -40,6 +40,7 @@ constexpr uint32_t kNoMat = FS_NO_MATERIAL;
 constexpr uint32_t kLobeDiffuse = 0u, kLobeSpecular = 1u, kLobeTransmit = 2u;
 constexpr int kLobeShift = 16;   // segment record: material id | lobe << 16
 constexpr int kDone = (int)0x80000000;  // traversal cursor: nothing left
+constexpr uint32_t kMissKey = 0xFFFFFFFCu;   // node test: sort key of a child the ray misses (| slot)
 constexpr double kFixedScale = 1099511627776.0;   // 2^40: quantum of the deterministic (fixed-point) energy sum
 #ifdef FS_WAVE_TIMELINE   // diagnostic build only (tools/wave_timeline.py): when every walk wave ran and what it spent its cycles on
 __device__ unsigned long long* g_wave_buf;       // [waves][8]: start, end (100 MHz), cycles in traversal, cycles in all, iterations, segments, hw id, slot
@@ -229,19 +230,34 @@ __device__ __forceinline__ void trav_init(Trav& T, float tmax, bool scene_nonemp
 }
 __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tri_n || T.cur != kDone; }
 
-// The step in four pieces, so that a caller can put other work between the request and the use of the records:
-//   trav_settle   a pending leaf becomes the triangle cursor and the next node is popped right away
-//   trav_issue    request the node and / or triangle record the lane needs next
-//   trav_wait     the records have arrived
-//   trav_consume  triangle test, node test, pushes, next node
+// The step in pieces, ordered so that as little as possible lies between the arrival of a lane's records and the
+// request for its next ones (round 3: one extra L1-hit load per step costs the walk as much as 20 more vector
+// instructions — every instruction of a wave between `wait` and the next `issue` is on its serial critical path):
+//   trav_wait       the records have arrived
+//   trav_node_part  4 child boxes of the lane's node against the bound known so far, sort, pushes, next node
+//   trav_settle     a pending leaf becomes the triangle cursor and the next node is popped right away
+//   trav_issue      request the node and / or triangle record the lane needs NEXT (the triangle into the other register set)
+//   trav_tri_part   test the triangle that arrived with this step — in the shadow of the fetch just issued
+// The node test uses the bound from before this step's triangle test: a looser bound only admits more candidates,
+// and the (t, id) key decides among them, so the closest hit is unchanged bit for bit.
 // The loads are inline asm under the lanes' own exec mask, waited for once behind both groups: a lane without a
-// pending triangle (or node) requests nothing, both records of a lane are in flight together, and the request may be
-// issued long before the use — trav_shared issues it before the work-sharing round.  (Round 1 let every lane fetch a
-// dummy record 0 with plain loads instead, because inside `if (has_node)` / `if (has_tri)` blocks the compiler sinks
-// the first arithmetic on the loaded words into the block of the loads, i.e. waits for one record before it requests
-// the other: 448 lane-loads per wave iteration for 207 useful ones, the CU's vector memory return path 79 % busy.)
+// pending triangle (or node) requests nothing, both records of a lane are in flight together.  (Round 1 let every lane
+// fetch a dummy record 0 with plain loads instead, because inside `if (has_node)` / `if (has_tri)` blocks the compiler
+// sinks the first arithmetic on the loaded words into the block of the loads, i.e. waits for one record before it
+// requests the other: 448 lane-loads per wave iteration for 207 useful ones.)
 typedef float v4f __attribute__((ext_vector_type(4)));
-struct TravRegs { v4f q0, q1, q2, q3, a, b, c; };
+struct NodeRegs {
+    v4f q0, q1, q2, q3;
+#if defined(FS_SENS_XLOADS)   // sensitivity builds only (tools/build_variant.sh): extra L1-hit loads per node visit
+    v4f x0, x1;
+#endif
+};
+struct TriRegs { v4f a, b, c; };
+// Node stride in bytes: 64 in the product.  FS_NODE_STRIDE=128 is a sensitivity build (host commit path only) in which
+// every node owns a whole 128-B cache line.
+#ifndef FS_NODE_STRIDE
+#define FS_NODE_STRIDE 64
+#endif
 
 __device__ __forceinline__ void trav_settle(Trav& T, int* stack) {
     if (T.tri_i >= T.tri_n && T.cur < 0 && T.cur != kDone) {
@@ -252,30 +268,168 @@ __device__ __forceinline__ void trav_settle(Trav& T, int* stack) {
     }
 }
 
-__device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T, TravRegs& R) {
-    if (T.cur >= 0) {
-        const NodeQ4* np = sc.nodes + T.cur;
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
-                     : "=&v"(R.q0), "=&v"(R.q1), "=&v"(R.q2), "=&v"(R.q3) : "v"(np) : "memory");
-    }
-    if (T.tri_i < T.tri_n) {
-        const Tri64* tp = sc.tris + T.tri_i;
-        asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\t"
-                     "global_load_dwordx4 %2, %3, off offset:32"
-                     : "=&v"(R.a), "=&v"(R.b), "=&v"(R.c) : "v"(tp) : "memory");
+// The request.  ONE asm statement, executed by every lane that reaches it, with every destination register tied in and
+// out ("+v"): the lanes that want a record are selected by writing their ballot to EXEC inside the statement.  Both
+// matter.  (1) The compiler does not know that the destinations are still being written until the next trav_wait; with
+// conditionally executed "=v" outputs the old and the new value meet in a phi, and register allocation is free to
+// resolve that phi with copies placed right behind the request — reading registers whose data has not arrived (round 3
+// lost a day's first build to exactly that; tools/check_isa_hazards.py now proves the absence of such accesses on the
+// final ISA).  A tied operand chain issue -> wait -> use has no phi to resolve.  (2) Every wave executes the same
+// number of vector memory instructions per step whatever its lanes need, so counted waits stay possible.
+__device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T, NodeRegs& N, TriRegs& X) {
+    const unsigned long long mn = __ballot(T.cur >= 0), mt = __ballot(T.tri_i < T.tri_n);   // subsets of EXEC
+    // (addresses of lanes that want nothing are never dereferenced)
+    const char* np = reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)T.cur * FS_NODE_STRIDE;
+    const Tri64* tp = sc.tris + (uint32_t)T.tri_i;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[mn]\n\t"
+                 "global_load_dwordx4 %[q0], %[np], off\n\t"
+                 "global_load_dwordx4 %[q1], %[np], off offset:16\n\t"
+                 "global_load_dwordx4 %[q2], %[np], off offset:32\n\t"
+                 "global_load_dwordx4 %[q3], %[np], off offset:48\n\t"
+#if defined(FS_SENS_XLOADS)
+                 "global_load_dwordx4 %[x0], %[np], off\n\t"
+#if FS_SENS_XLOADS >= 2
+                 "global_load_dwordx4 %[x1], %[np], off offset:32\n\t"
+#endif
+#endif
+                 "s_mov_b64 exec, %[mt]\n\t"
+#ifndef FS_NO_TRI_SKIP
+                 "s_cbranch_execz 1f\n\t"      // one wave step in four has no lane with a pending triangle
+#endif
+                 "global_load_dwordx4 %[ta], %[tp], off\n\t"
+                 "global_load_dwordx4 %[tb], %[tp], off offset:16\n\t"
+                 "global_load_dwordx4 %[tc], %[tp], off offset:32\n"
+                 "1:\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [q0] "+&v"(N.q0), [q1] "+&v"(N.q1), [q2] "+&v"(N.q2), [q3] "+&v"(N.q3),
+#if defined(FS_SENS_XLOADS)
+                   [x0] "+&v"(N.x0), [x1] "+&v"(N.x1),
+#endif
+                   [ta] "+&v"(X.a), [tb] "+&v"(X.b), [tc] "+&v"(X.c), [sv] "=&s"(sv)
+                 : [np] "v"(np), [tp] "v"(tp), [mn] "s"(mn), [mt] "s"(mt)
+                 : "memory");
+}
+
+__device__ __forceinline__ void trav_wait(NodeRegs& N, TriRegs& X) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(N.q0), "+v"(N.q1), "+v"(N.q2), "+v"(N.q3), "+v"(X.a), "+v"(X.b), "+v"(X.c));
+#if defined(FS_SENS_XLOADS)
+    asm volatile("" : "+v"(N.x0), "+v"(N.x1));
+#endif
+}
+
+// the triangle that arrived with this step (leaf-order index `tested`): Moeller-Trumbore, closest-hit update as selects
+template <bool ANY, bool IGN = false>
+__device__ __forceinline__ void trav_tri_part(const Ray& r, Trav& T, const TriRegs& X, const int tested,
+                                              uint32_t ignore_object = 0xFFFFFFFFu) {
+    const float4 a = make_float4(X.a.x, X.a.y, X.a.z, X.a.w), b = make_float4(X.b.x, X.b.y, X.b.z, X.b.w),
+                 c = make_float4(X.c.x, X.c.y, X.c.z, X.c.w);   // triangle: v0 | e1 | e2 (+ material, id, object)
+    float t = 0.0f;
+    // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
+    bool hit = tri_hit(a, b, c, r, T.t, t);
+    if (IGN) hit = hit & (__float_as_uint(c.w) != ignore_object);
+    const uint32_t id = __float_as_uint(c.z);
+    if (ANY) {
+        if (hit) {
+            T.t = t; T.leaf_index = tested; T.id = id;
+            T.tri_i = 0; T.tri_n = 0; T.cur = kDone; T.sp = T.sb;  // first hit ends the query (records already requested are ignored)
+        }
+    } else {
+        // closest hit, ties to the lower input index — as selects, not branches.  (t, id) compares as ONE 64-bit
+        // key: t > 0, so its bits order like an integer, and a traversal without a hit yet carries id = ~0
+        // (equivalent to t < T.t | no hit yet | (t == T.t & id < T.id); one v_cmp_lt_u64 instead of five compares)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | id;
+        const unsigned long long cur = ((unsigned long long)__float_as_uint(T.t) << 32) | T.id;
+        const bool better = hit & (key < cur);
+        T.t = better ? t : T.t;
+        T.leaf_index = better ? tested : T.leaf_index;
+        T.id = better ? id : T.id;
     }
 }
 
-__device__ __forceinline__ void trav_wait(TravRegs& R) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R.q0), "+v"(R.q1), "+v"(R.q2), "+v"(R.q3), "+v"(R.a), "+v"(R.b), "+v"(R.c));
+// the lane's inner node (T.cur >= 0): 4 child boxes, near-first order, far children to the stack, next node
+__device__ __forceinline__ void trav_node_part(const Ray& r, Trav& T, int* stack, const NodeRegs& N) {
+    const float4 q0 = make_float4(N.q0.x, N.q0.y, N.q0.z, N.q0.w), q1 = make_float4(N.q1.x, N.q1.y, N.q1.z, N.q1.w),
+                 q2 = make_float4(N.q2.x, N.q2.y, N.q2.z, N.q2.w), q3 = make_float4(N.q3.x, N.q3.y, N.q3.z, N.q3.w);
+    // ---- 4-wide node, child boxes on the node's 8-bit grid: plane distance = fma(q, step*inv, (origin-o)*inv)
+    const float sx = q0.w * r.ix, sy = q2.z * r.iy, sz = q2.w * r.iz;   // grid step (a power of two) / direction
+    const float bx = fmaf(q0.x, r.ix, r.nox);
+    const float by = fmaf(q0.y, r.iy, r.noy);
+    const float bz = fmaf(q0.z, r.iz, r.noz);
+    const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+    const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+    // the ray's direction signs pick the entry / exit plane words once per node
+    const uint32_t nxw = r.ix < 0.0f ? hix : lox, fxw = r.ix < 0.0f ? lox : hix;
+    const uint32_t nyw = r.iy < 0.0f ? hiy : loy, fyw = r.iy < 0.0f ? loy : hiy;
+    const uint32_t nzw = r.iz < 0.0f ? hiz : loz, fzw = r.iz < 0.0f ? loz : hiz;
+    const v2f sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
+    uint32_t key[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // (entry, exit) plane distances per axis as one packed fma each (v_pk_fma_f32)
+        const v2f qx = {(float)((nxw >> (8 * c)) & 0xFFu), (float)((fxw >> (8 * c)) & 0xFFu)};
+        const v2f qy = {(float)((nyw >> (8 * c)) & 0xFFu), (float)((fyw >> (8 * c)) & 0xFFu)};
+        const v2f qz = {(float)((nzw >> (8 * c)) & 0xFFu), (float)((fzw >> (8 * c)) & 0xFFu)};
+        const v2f tx = __builtin_elementwise_fma(qx, sx2, bx2);
+        const v2f ty = __builtin_elementwise_fma(qy, sy2, by2);
+        const v2f tz = __builtin_elementwise_fma(qz, sz2, bz2);
+        const float tnx = tx.x, tfx = tx.y, tny = ty.x, tfy = ty.y, tnz = tz.x, tfz = tz.y;
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, T.t));
+        const bool h = tn <= tf;
+        // entry distance (>= 0, so its bits order like an integer) with the slot in the low 2 bits; a missed child
+        // sorts behind every hit one (kMissKey | slot)
+        key[c] = h ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : (kMissKey | (uint32_t)c);
+    }
+    int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), ref2 = __float_as_int(q3.z),
+        ref3 = __float_as_int(q3.w);
+    // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free.  (Measured in
+    // round 2: choosing only the nearest child and pushing the rest in slot order — also no ordering at all for
+    // visibility rays — saves a dozen instructions per visit and costs as much in extra visits: walk 0.356 ->
+    // 0.361 ms, connect 0.075 -> 0.078 ms.)
+#define FS_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t lo_ = min(key[a], key[b]); \
+                         const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; \
+                         const int ra_ = sw_ ? ref##b : ref##a; const int rb_ = sw_ ? ref##a : ref##b; \
+                         ref##a = ra_; ref##b = rb_; }
+    FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
+#undef FS_CSWAP
+    // the number of children hit, read off the sorted keys: at least k + 1 <=> key[k] is a hit
+    const bool h1 = key[0] < kMissKey, h2 = key[1] < kMissKey, h3 = key[2] < kMissKey, h4 = key[3] < kMissKey;
+#ifdef FS_TRAV_STATS
+    atomicAdd(&g_trav_stats[5 + (h2 ? 2 : (h1 ? 1 : 0))], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
+#endif
+    // far children wait on the stack, farthest pushed first, at sp .. sp + hits - 2: with two hits all three stores
+    // land on sp and the last one (the second nearest) stays, with three hits the first two share sp — no store
+    // goes above the new top, so the stack needs exactly the tree's worst-case number of rows.  With fewer than two
+    // hits the three stores write (unused) words to the free row above the top: cheaper than branching around them,
+    // a wave nearly always has a lane that pushes.
+    const int p3 = T.sp;
+    const int p2 = p3 + (h4 ? 1 : 0);
+    const int p1 = p2 + (h3 ? 1 : 0);
+    stack[p3 * kBlock] = ref3;
+    stack[p2 * kBlock] = ref2;
+    stack[p1 * kBlock] = ref1;
+    T.sp = p1 + (h2 ? 1 : 0);
+    if (h1) {
+        T.cur = ref0;
+    } else if (T.sp > T.sb) {
+        --T.sp;
+        T.cur = stack[T.sp * kBlock];
+    } else {
+        T.cur = kDone;
+    }
 }
 
+// One whole step of a busy lane, in the pipelined order: node part, advance, request the next records (the
+// triangle into `nxt`), then the triangle part on `cur` while they are in flight.  Entry: the records of (T.cur,
+// T.tri_i) have arrived in (N, cur).
 template <bool ANY, bool IGN = false, bool COUNT = false>
-__device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r, Trav& T, int* stack, const TravRegs& R,
-                                             uint32_t ignore_object = 0xFFFFFFFFu) {
+__device__ __forceinline__ void trav_advance(const DeviceScene& sc, const Ray& r, Trav& T, int* stack, NodeRegs& N,
+                                             TriRegs& cur, TriRegs& nxt, uint32_t ignore_object = 0xFFFFFFFFu) {
     const bool has_tri = T.tri_i < T.tri_n;
     const bool has_node = T.cur >= 0;
+    const int tested = T.tri_i;
     if (COUNT) { T.nv += has_node ? 1u : 0u; T.nt += has_tri ? 1u : 0u; }
 #ifdef FS_TRAV_STATS   // diagnostic build only (tests/trav_stats.py): SIMD occupancy of the two step kinds
     {
@@ -289,119 +443,47 @@ __device__ __forceinline__ void trav_consume(const DeviceScene& sc, const Ray& r
         }
     }
 #endif
-    const float4 q0 = make_float4(R.q0.x, R.q0.y, R.q0.z, R.q0.w), q1 = make_float4(R.q1.x, R.q1.y, R.q1.z, R.q1.w),
-                 q2 = make_float4(R.q2.x, R.q2.y, R.q2.z, R.q2.w), q3 = make_float4(R.q3.x, R.q3.y, R.q3.z, R.q3.w);   // node
-    const float4 a = make_float4(R.a.x, R.a.y, R.a.z, R.a.w), b = make_float4(R.b.x, R.b.y, R.b.z, R.b.w),
-                 c = make_float4(R.c.x, R.c.y, R.c.z, R.c.w);   // triangle: v0 | e1 | e2 (+ material, id, object)
-    if (has_tri) {
-        float t = 0.0f;
-        // IGN: FCollisionQueryParams::AddIgnoredActor — triangles of one actor (object id in c.w) are skipped
-        bool hit = tri_hit(a, b, c, r, T.t, t);
-        if (IGN) hit = hit & (__float_as_uint(c.w) != ignore_object);
-        const uint32_t id = __float_as_uint(c.z);
-        if (ANY) {
-            if (hit) {
-                T.t = t; T.leaf_index = T.tri_i; T.id = id;
-                T.tri_n = T.tri_i; T.cur = kDone; T.sp = T.sb;  // first hit ends the query
-                return;
-            }
-        } else {
-            // closest hit, ties to the lower input index — as selects, not branches.  (t, id) compares as ONE 64-bit
-            // key: t > 0, so its bits order like an integer, and a traversal without a hit yet carries id = ~0
-            // (equivalent to t < T.t | no hit yet | (t == T.t & id < T.id); one v_cmp_lt_u64 instead of five compares)
-            const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | id;
-            const unsigned long long cur = ((unsigned long long)__float_as_uint(T.t) << 32) | T.id;
-            const bool better = hit & (key < cur);
-            T.t = better ? t : T.t;
-            T.leaf_index = better ? T.tri_i : T.leaf_index;
-            T.id = better ? id : T.id;
-        }
-        ++T.tri_i;
-    }
-    if (has_node) {
-        // ---- 4-wide node, child boxes on the node's 8-bit grid: plane distance = fma(q, step*inv, (origin-o)*inv)
-        const float sx = q0.w * r.ix, sy = q2.z * r.iy, sz = q2.w * r.iz;   // grid step (a power of two) / direction
-        const float bx = fmaf(q0.x, r.ix, r.nox);
-        const float by = fmaf(q0.y, r.iy, r.noy);
-        const float bz = fmaf(q0.z, r.iz, r.noz);
-        const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
-        const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
-        // the ray's direction signs pick the entry / exit plane words once per node
-        const uint32_t nxw = r.ix < 0.0f ? hix : lox, fxw = r.ix < 0.0f ? lox : hix;
-        const uint32_t nyw = r.iy < 0.0f ? hiy : loy, fyw = r.iy < 0.0f ? loy : hiy;
-        const uint32_t nzw = r.iz < 0.0f ? hiz : loz, fzw = r.iz < 0.0f ? loz : hiz;
-        const v2f sx2 = {sx, sx}, sy2 = {sy, sy}, sz2 = {sz, sz}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
-        uint32_t key[4];
-        int hits = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            // (entry, exit) plane distances per axis as one packed fma each (v_pk_fma_f32)
-            const v2f qx = {(float)((nxw >> (8 * c)) & 0xFFu), (float)((fxw >> (8 * c)) & 0xFFu)};
-            const v2f qy = {(float)((nyw >> (8 * c)) & 0xFFu), (float)((fyw >> (8 * c)) & 0xFFu)};
-            const v2f qz = {(float)((nzw >> (8 * c)) & 0xFFu), (float)((fzw >> (8 * c)) & 0xFFu)};
-            const v2f tx = __builtin_elementwise_fma(qx, sx2, bx2);
-            const v2f ty = __builtin_elementwise_fma(qy, sy2, by2);
-            const v2f tz = __builtin_elementwise_fma(qz, sz2, bz2);
-            const float tnx = tx.x, tfx = tx.y, tny = ty.x, tfy = ty.y, tnz = tz.x, tfz = tz.y;
-            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, T.t));
-            const bool h = tn <= tf;
-            hits += h ? 1 : 0;
-            // entry distance (>= 0, so its bits order like an integer) with the slot in the low 2 bits
-            key[c] = h ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : (0xFFFFFFFCu | (uint32_t)c);
-        }
-        int ref0 = __float_as_int(q3.x), ref1 = __float_as_int(q3.y), ref2 = __float_as_int(q3.z),
-            ref3 = __float_as_int(q3.w);
-#ifdef FS_TRAV_STATS
-        atomicAdd(&g_trav_stats[(ANY ? 16 : 0) + 5 + (hits > 2 ? 2 : hits)], 1ull);   // [5] visits with no child hit, [6] one, [7] two or more
-#endif
-        // sort the 4 (key, child reference) pairs, nearest first: 5-comparator network, branch-free.  (Measured in
-        // round 2: choosing only the nearest child and pushing the rest in slot order — also no ordering at all for
-        // visibility rays — saves a dozen instructions per visit and costs as much in extra visits: walk 0.356 ->
-        // 0.361 ms, connect 0.075 -> 0.078 ms.)
-#define FS_CSWAP(a, b) { const bool sw_ = key[b] < key[a]; const uint32_t lo_ = min(key[a], key[b]); \
-                         const uint32_t hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; \
-                         const int ra_ = sw_ ? ref##b : ref##a; const int rb_ = sw_ ? ref##a : ref##b; \
-                         ref##a = ra_; ref##b = rb_; }
-        FS_CSWAP(0, 1) FS_CSWAP(2, 3) FS_CSWAP(0, 2) FS_CSWAP(1, 3) FS_CSWAP(1, 2)
-#undef FS_CSWAP
-        // far children wait on the stack, farthest pushed first, at sp .. sp + hits - 2: with two hits all three stores
-        // land on sp and the last one (the second nearest) stays, with three hits the first two share sp — no store
-        // goes above the new top, so the stack needs exactly the tree's worst-case number of rows.
-        const int p3 = T.sp;
-        const int p2 = p3 + (hits >= 4 ? 1 : 0);
-        const int p1 = p2 + (hits >= 3 ? 1 : 0);
-        if (hits >= 2) {   // 3 of 4 visits hit at most one child and push nothing
-            stack[p3 * kBlock] = ref3;
-            stack[p2 * kBlock] = ref2;
-            stack[p1 * kBlock] = ref1;
-        }
-        T.sp = p1 + (hits >= 2 ? 1 : 0);
-        if (hits >= 1) {
-            T.cur = ref0;
-        } else if (T.sp > T.sb) {
-            --T.sp;
-            T.cur = stack[T.sp * kBlock];
-        } else {
-            T.cur = kDone;
-        }
-    }
-}
-
-template <bool ANY, bool IGN = false>
-__device__ __forceinline__ void trav_step(const DeviceScene& sc, const Ray& r, Trav& T, int* stack,
-                                          uint32_t ignore_object = 0xFFFFFFFFu) {
-    TravRegs R;
+    if (has_node) trav_node_part(r, T, stack, N);
+    if (has_tri) ++T.tri_i;
     trav_settle(T, stack);
-    trav_issue(sc, T, R);
-    trav_wait(R);
-    trav_consume<ANY, IGN>(sc, r, T, stack, R, ignore_object);
+    trav_issue(sc, T, N, nxt);
+    // the triangle test must stay BEHIND the requests: it is plain arithmetic on registers, which the compiler would
+    // otherwise move in front of the (to it unrelated) load instructions — and then fold the two register sets into one
+    asm volatile("" : "+v"(cur.a), "+v"(cur.b), "+v"(cur.c));
+    if (has_tri) trav_tri_part<ANY, IGN>(r, T, cur, tested, ignore_object);
 }
 
+// Before a traversal returns, every record it has requested must have landed: the compiler knows nothing of loads in
+// flight and would hand their destination registers to other values (an any-hit query ends with requests outstanding).
+__device__ __forceinline__ void trav_drain(NodeRegs& N, TriRegs& X, TriRegs& Y) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(N.q0), "+v"(N.q1), "+v"(N.q2), "+v"(N.q3), "+v"(X.a), "+v"(X.b), "+v"(X.c),
+                                        "+v"(Y.a), "+v"(Y.b), "+v"(Y.c));
+#if defined(FS_SENS_XLOADS)
+    asm volatile("" : "+v"(N.x0), "+v"(N.x1));
+#endif
+}
+
+// one ray per lane without work sharing (tests, tools, diagnostic builds); returns the number of steps taken
 template <bool ANY, bool IGN = false>
-__device__ __forceinline__ void trav_run(const DeviceScene& sc, const Ray& r, Trav& T, int* stack,
-                                         uint32_t ignore_object = 0xFFFFFFFFu) {
-    while (trav_busy(T)) trav_step<ANY, IGN>(sc, r, T, stack, ignore_object);
+__device__ __forceinline__ int trav_run(const DeviceScene& sc, const Ray& r, Trav& T, int* stack,
+                                        uint32_t ignore_object = 0xFFFFFFFFu) {
+    NodeRegs N;
+    TriRegs X, Y;
+    int steps = 0;
+    trav_settle(T, stack);
+    trav_issue(sc, T, N, X);
+    // The loop is wave-uniform (lanes whose ray is finished idle along): a per-lane exit would make the compiler carry
+    // every lane's register sets out of the loop through copies — of registers that may still be in flight.
+    while (true) {
+        if (__ballot(trav_busy(T)) == 0ull) break;
+        trav_wait(N, X);
+        if (trav_busy(T)) { trav_advance<ANY, IGN>(sc, r, T, stack, N, X, Y, ignore_object); ++steps; }
+        if (__ballot(trav_busy(T)) == 0ull) break;
+        trav_wait(N, Y);
+        if (trav_busy(T)) { trav_advance<ANY, IGN>(sc, r, T, stack, N, Y, X, ignore_object); ++steps; }
+    }
+    trav_drain(N, X, Y);
+    return steps;
 }
 
 // ImpactNormal: the record's unit geometric normal, flipped to face the ray origin side; material of the hit
@@ -601,8 +683,13 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
     const uint32_t rec_mat = w.side == 0 ? (w.mat | w.lobe) : mat_new;   // w.lobe: 0 unless FS_FLAG_MATERIAL_LOBES picked one here
     if (rec_in_main(st, w.k)) {
         const size_t r = rec_main(2u * kp.num_local, w.k, w.slot);       // consecutive lanes, consecutive words
+#ifdef FS_NT_STORES   // experiment: streaming stores, so that the records do not push the scene out of the L2s
+        __builtin_nontemporal_store(v2f{rec_np.x, rec_np.y}, reinterpret_cast<v2f*>(&st.seg_np[r]));
+        __builtin_nontemporal_store(rec_mat, &st.seg_mat[r]);
+#else
         st.seg_np[r] = rec_np;
         st.seg_mat[r] = rec_mat;
+#endif
         if (st.seg_pos) st.seg_pos[r] = make_float4(qx, qy, qz, 0.0f);   // all-connections mode (wave-uniform)
         if (st.seg_nrm) st.seg_nrm[r] = make_float4(w.nx, w.ny, w.nz, 0.0f);   // balance-heuristic weights only
     } else if (rec_fits(st, w.k, w.slot)) {                              // depth = 0: step 65.. of one of the longest walks
@@ -621,8 +708,14 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
 }
 
 __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathState& st) {
+#ifdef FS_NT_STORES
+    __builtin_nontemporal_store(v4f{w.px, w.py, w.pz, w.prob}, reinterpret_cast<v4f*>(&st.end_pos[w.slot]));
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(v2u{w.mat, (uint32_t)w.k}, reinterpret_cast<v2u*>(&st.end_misc[w.slot]));
+#else
     st.end_pos[w.slot] = make_float4(w.px, w.py, w.pz, w.prob);
     st.end_misc[w.slot] = make_uint2(w.mat, (uint32_t)w.k);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -745,8 +838,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
         Trav T;
         trav_init(T, kp.max_trace_dist, sc.num_nodes > 0);
 #ifdef FS_TRAV_STATS
-        unsigned steps = 0;
-        while (trav_busy(T)) { trav_step<false>(sc, ray, T, stack); ++steps; }
+        const unsigned steps = (unsigned)trav_run<false>(sc, ray, T, stack);
         if (g_step_buf) g_step_buf[(size_t)w.k * (2u * (size_t)kp.num_local) + w.g] = (unsigned short)steps;
 #else
         trav_run<false>(sc, ray, T, stack);
@@ -797,7 +889,10 @@ constexpr size_t kShareLdsBytes = ShareArea<false, false>::kBytes;      // 60 B 
 // once this many lanes have nothing to do: feeding the first few idle lanes costs every lane more than it returns.
 // Measured at cfg3 (profiles/r02_share_min_idle.log): 1 / 4 / 8 / 16 / 24 / 32 / 48 -> walk 0.304 / 0.303 / 0.298 /
 // 0.294 / 0.300 / 0.309 / 0.334 ms, connect 0.075 -> 0.072 ms at 16.  Sparse waves start above it.
-constexpr int kShareMinIdle = 16;
+#ifndef FS_SHARE_MIN_IDLE
+#define FS_SHARE_MIN_IDLE 16
+#endif
+constexpr int kShareMinIdle = FS_SHARE_MIN_IDLE;
 constexpr size_t kShareAnyLdsBytes = ShareArea<true, false>::kBytes;    // 40 B per lane
 constexpr size_t kShareIgnLdsBytes = ShareArea<false, true>::kBytes;    // 64 B per lane
 
@@ -825,16 +920,20 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     uint32_t wign = ignore;
     Ray wr = own;
     trav_init(T, tmax, has_ray && sc.num_nodes > 0);
-    // The records of the NEXT step are requested as soon as this step has decided what they are — before the
-    // work-sharing round below (ballots, donation boxes, mailboxes: half a dozen LDS round trips), which then runs
-    // in the shadow of the fetch.  A wave in the thin tail of the frame runs alone on its SIMD and nothing else
-    // hides that latency.  Lanes that take work in the round request theirs at its end; a busy lane's (cur, tri
-    // cursor) does not change between its request and trav_consume.
-    TravRegs R;
+    // The records of the NEXT step are requested as soon as this step has decided what they are: behind the node part
+    // of the step, before its triangle test (trav_advance) and before the work-sharing round below (ballots, donation
+    // boxes, mailboxes: half a dozen LDS round trips), which both run in the shadow of the fetch.  A wave in the thin
+    // tail of the frame runs alone on its SIMD and nothing else hides that latency.  Lanes that take work in the round
+    // request theirs at its end.  The triangle records alternate between two register sets (the loop body is
+    // instantiated twice): the one being tested is still needed while the next one is already arriving.
+    NodeRegs N;
+    TriRegs X, Y;
     trav_settle(T, stack);
-    trav_issue(sc, T, R);
-    while (true) {
-        trav_wait(R);
+    trav_issue(sc, T, N, X);
+    // one step of the wave; cur = the triangle registers that arrive with this step, nxt = the ones requested for the
+    // next.  true = nothing is left anywhere in the wave.
+    auto step = [&](TriRegs& cur, TriRegs& nxt) -> bool {
+        trav_wait(N, cur);
 #ifdef FS_TRAV_STATS
         {
             const unsigned long long mb = __ballot(trav_busy(T)), mth = __ballot(trav_busy(T) && owner != tid);
@@ -846,23 +945,21 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
         }
 #endif
         if (trav_busy(T)) {
-            trav_consume<ANY, IGN, COUNT>(sc, wr, T, stack, R, wign);
+            trav_advance<ANY, IGN, COUNT>(sc, wr, T, stack, N, cur, nxt, wign);
             if (ANY) {
                 if (T.leaf_index >= 0) { A.blocked[owner] = 1; T.leaf_index = -1; }   // first hit ends the query (T is idle now)
-                else if (A.blocked[owner]) { T.cur = kDone; T.sp = 0; T.sb = 0; T.tri_n = T.tri_i; }   // settled by another lane
+                else if (A.blocked[owner]) { T.cur = kDone; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0; }   // settled by another lane
             } else if (!trav_busy(T) && T.leaf_index >= 0) {   // this (sub)traversal is over: report to the owner of the ray
                 const unsigned long long key = ((unsigned long long)__float_as_uint(T.t) << 32) | (unsigned long long)T.id;
                 atomicMin(&A.rkey[owner], key);
                 if (A.rkey[owner] == key) A.rleaf[owner] = T.leaf_index;
             }
-            trav_settle(T, stack);
-            trav_issue(sc, T, R);
         }
         const bool idle = !trav_busy(T);
         const unsigned long long busy_m = __ballot(!idle);
-        if (busy_m == 0ull) break;                      // nothing left anywhere in the wave
+        if (busy_m == 0ull) return true;                // nothing left anywhere in the wave
         const unsigned long long idle_m = __ballot(idle);
-        if (__popcll(idle_m) < kShareMinIdle) continue;
+        if (__popcll(idle_m) < kShareMinIdle) return false;
         const bool can_give = !idle && T.sp > T.sb;
         const unsigned long long give_m = __ballot(can_give);
         if (idle_m != 0ull && give_m != 0ull) {
@@ -899,11 +996,17 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
                     T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
                     T.t = bound; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
                     trav_settle(T, stack);
-                    trav_issue(sc, T, R);
+                    trav_issue(sc, T, N, nxt);
                 }
             }
         }
+        return false;
+    };
+    while (true) {
+        if (step(X, Y)) break;
+        if (step(Y, X)) break;
     }
+    trav_drain(N, X, Y);
     if (ANY) return A.blocked[tid] != 0;
     // everything searched: the mailbox holds the closest hit of this lane's own ray
     const unsigned long long key = A.rkey[tid];
