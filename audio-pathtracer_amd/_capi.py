@@ -36,7 +36,7 @@ FLAG_ACCUMULATE_ENERGY = 128
 # every symbol include/frequensee.h declares (tests check the library exports all of them)
 EXPORTS = [
     "fs_config_default", "fs_params_default", "fs_abi_version", "fs_context_create", "fs_context_destroy",
-    "fs_last_error", "fs_scene_set_triangles", "fs_scene_set_materials", "fs_scene_commit", "fs_source_create",
+    "fs_last_error", "fs_context_advice", "fs_scene_set_triangles", "fs_scene_set_materials", "fs_scene_commit", "fs_source_create",
     "fs_source_destroy", "fs_source_set_position", "fs_listener_set_position", "fs_compute_energy_response",
     "fs_compute_energy_response_async", "fs_compute_energy_response_batch_async", "fs_energy_device_ptr", "fs_reconstruct_impulse_response",
     "fs_reconstruct_impulse_response_async", "fs_synchronize", "fs_get_impulse_response",
@@ -168,6 +168,9 @@ def load():
         raise FileNotFoundError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # Host requirement of the library (fs_context_advice): 16 hardware queues, decided before the
+    # HIP runtime initialises — this binding is the host here.  An explicit setting of the process wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     lib = C.CDLL(LIB_PATH)
     vp, i32, u16p, f32p = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p
     sig = {
@@ -177,6 +180,7 @@ def load():
         "fs_context_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
         "fs_context_destroy": (C.c_int, [vp]),
         "fs_last_error": (C.c_char_p, [vp]),
+        "fs_context_advice": (C.c_char_p, [vp]),
         "fs_scene_set_triangles": (C.c_int, [vp, f32p, u16p, i32]),
         "fs_scene_set_materials": (C.c_int, [vp, f32p, f32p, f32p, i32, i32]),
         "fs_scene_commit": (C.c_int, [vp]),

@@ -46,6 +46,10 @@ class Context:
         if rc != _capi.OK:
             raise FrequenSeeError(rc, self.lib.fs_last_error(self.h).decode())
 
+    def advice(self):
+        """fs_context_advice: what fs_context_create found worth telling the host about its environment ('' = nothing)"""
+        return self.lib.fs_context_advice(self.h).decode()
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.fs_context_destroy(self.h)

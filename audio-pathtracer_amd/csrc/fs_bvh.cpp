@@ -79,6 +79,7 @@ struct Builder {
     // `deferred`; worker threads build their subtrees with private builders, spliced in afterwards
     int defer_below = 0;
     std::vector<int> deferred;
+    const std::atomic<bool>* cancel = nullptr;   // set: the result is no longer wanted — stop splitting (the caller discards the tree)
 
     explicit Builder(BuildInput& i) : in(i), prims(i.prims) {}
 
@@ -106,6 +107,7 @@ struct Builder {
             nodes[id] = n;
             return id;
         }
+        if (count > 2048 && cancel && cancel->load(std::memory_order_relaxed)) { nodes[id] = n; return id; }
         if (count > kLeaf) {
             int mid = -1;
             // levels a balanced split still needs below this node
@@ -242,7 +244,8 @@ int stack_need(const std::vector<BuildNode>& bn, const std::vector<Wide>& wide, 
 
 }  // namespace
 
-void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out) {
+void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out,
+               const std::atomic<bool>* cancel) {
     out.nodes.clear();
     out.tris.clear();
     out.max_depth = 0;
@@ -254,6 +257,7 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
 
     BuildInput input;
     Builder b(input);
+    b.cancel = cancel;
     if (const char* v = std::getenv("FS_BVH_LEAF")) b.kLeaf = std::max(1, std::min(4, std::atoi(v)));
     int threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* v = std::getenv("FS_BVH_THREADS")) threads = std::max(1, std::min(64, std::atoi(v)));
@@ -299,8 +303,10 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
             std::atomic<size_t> next{0};
             auto work = [&]() {
                 for (size_t k = next.fetch_add(1); k < tasks.size(); k = next.fetch_add(1)) {
+                    if (cancel && cancel->load(std::memory_order_relaxed)) continue;
                     const BuildNode& ph = b.nodes[(size_t)tasks[k]];
                     Builder lb(input);
+                    lb.cancel = cancel;
                     lb.kLeaf = b.kLeaf;
                     lb.depth_cap = b.depth_cap;
                     lb.nodes.reserve(2 * (size_t)ph.count / 3 + 16);
@@ -313,6 +319,7 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
             for (int w = 1; w < threads; ++w) pool.emplace_back(work);
             work();
             for (std::thread& th : pool) th.join();
+            if (cancel && cancel->load(std::memory_order_relaxed)) { out = HostBVH{}; return; }
             for (size_t k = 0; k < tasks.size(); ++k) {   // splice: local node 0 replaces the placeholder
                 const int ph = tasks[k];
                 const int base = (int)b.nodes.size() - 1;   // local j >= 1 -> base + j
@@ -326,6 +333,7 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
                 b.max_depth = std::max(b.max_depth, sub_depth[k]);
             }
         }
+        if (cancel && cancel->load(std::memory_order_relaxed)) { out = HostBVH{}; return; }
         collapse(b.nodes, root, wide, wide_of, level);
         out.stack_need = stack_need(b.nodes, wide, wide_of);
         if (out.stack_need <= kStackDepth) break;

@@ -1,0 +1,855 @@
+// fs_capi_frame.cpp — sources, the traced frame (UpdateSource, ARTS.cpp:128-195) and its pipeline, reconstruct /
+// publish, impulse-response and energy-buffer access (C ABI: include/frequensee.h).
+#include "fs_context.hpp"
+
+namespace fsi {
+
+// depth = 0 frames: did a walk's record miss both tiers?  (Called where the compute stream has just been synchronised.)
+// Then the frame's energy is incomplete: the tier is grown for the next attempt and the caller is told.
+int check_overflow(fs_context* ctx) {
+    if (!ctx->overflow_armed || !ctx->d_overflow) return FS_OK;
+    ctx->overflow_armed = false;
+    unsigned flag = 0;
+    if (ctx->comm) {
+        // sharded frame: the ranks must agree — a rank that traced the frame again alone would issue one all-reduce more
+        // than the others.  Every rank armed the word for the same frames, so every rank gets here: MAX over the ranks.
+        RcclApi* a = rccl();
+        if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
+        FS_NCCL(ctx, a->AllReduce(ctx->d_overflow, ctx->d_overflow, 1, ncclUint32, ncclMax, ctx->comm, ctx->stream));
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    FS_HIP(ctx, hipMemcpy(&flag, ctx->d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
+    if (!flag) return FS_OK;
+    FS_HIP(ctx, hipMemset(ctx->d_overflow, 0, sizeof(flag)));
+    const uint32_t grown = std::max<uint32_t>(ctx->over_cap, 16) * 4;
+    if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);
+    if (ctx->d_over_mat) (void)hipFree(ctx->d_over_mat);
+    if (ctx->d_over_pos) (void)hipFree(ctx->d_over_pos);
+    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->over_cap_pos = 0;
+    ctx->over_cap = grown;   // ensure_state allocates at this size next time
+    return ctx->fail(FS_ERR_OVERFLOW, "depth = 0: more walks than expected outlived " + std::to_string(FS_MAX_DEPTH) +
+                     " steps; the record tier has been grown — trace the frame again");
+}
+
+// ---- pipelined frames ---------------------------------------------------------------------------------------------
+namespace {
+// What a held frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum over
+// the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
+// frames (cur rotated): the per-frame fields are switched back for the duration.
+static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
+    for (const fs_context::PipeFrame::Item& it : q.items) {
+        Source* s = it.s;
+        const bool moved_on = s->cur != it.cur;
+        const int cur = s->cur;
+        const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off;
+        s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
+        int rc = FS_OK;
+        if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
+        if (ctx->comm) rc = reduce_energy(ctx, s);
+        if (!rc && it.want_recon) rc = reconstruct_now(ctx, s, &it.recon);
+        if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; }
+        if (rc) return rc;
+    }
+    return FS_OK;
+}
+
+static void held_connect_part(const fs_context::PipeFrame& q, FrameParts& f) {
+    const fs_context::PipeFrame::Item& it = q.items[0];
+    f.has_connect = true; f.kpc = q.kp; f.stc = q.st; f.energy = it.s->d_energy[it.cur];
+    f.fixed = q.fixed ? it.s->d_fixed[it.cur] : nullptr; f.scratch_c = q.wl.queue_head; f.ppw = q.ppw;
+    f.energy_tab = q.energy_tab; f.fixed_tab = q.fixed_tab;
+}
+static void held_walk_part(const fs_context::PipeFrame& q, FrameParts& f) {
+    f.has_walk = true; f.kpw = q.kp; f.stw = q.st; f.wl = q.wl; f.perm = q.perm;
+}
+
+// Let every held frame finish on its own kernels, oldest first: something needs their results (or their buffers) now.
+}  // namespace
+
+int flush_pending(fs_context* ctx) {
+    if (!ctx->held[0].has && !ctx->held[1].has) return FS_OK;
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->held[k].has) continue;
+        const fs_context::PipeFrame q = ctx->held[k];
+        ctx->held[k].has = false;
+        if (!q.walked) launch_walk(ctx->scene, q.kp, q.st, q.wl, q.perm, ctx->stream);
+        launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.items[0].s->d_energy[q.items[0].cur],
+                       q.fixed ? q.items[0].s->d_fixed[q.items[0].cur] : nullptr, q.wl.queue_head, q.ppw, q.energy_tab, q.fixed_tab,
+                       ctx->stream);
+        FS_HIP(ctx, hipGetLastError());
+        const int rc = finish_held_frame(ctx, q);
+        if (rc) return rc;
+    }
+    return FS_OK;
+}
+
+int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
+    // ReconstructImpulseResponse is not linear in the energy (a = e / sqrt(e * Pi4)): the IR of a rank's PARTIAL
+    // histogram is not a partial IR.  A sharded context only reconstructs a frame that was summed over the ranks — by
+    // the library (fs_comm_init / fs_comm_attach) or by the caller's collective on the tail stream (fs_energy_handoff).
+    if (ctx->cfg.world_size > 1 && !s->reduced && !s->handed_off)
+        return ctx->fail(FS_ERR_COMM, "world_size > 1: the energy buffer holds this rank's partial sums only — attach a "
+                                      "communicator (fs_comm_init) or reduce it behind fs_energy_handoff before reconstructing");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int B = ctx->cfg.num_bands;
+    int spb = p->samples_per_bin > 0 ? p->samples_per_bin
+                                     : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
+
+    poll_published(s);
+    // never overwrite the front buffer: at most two publishes in flight
+    if (s->enqueued >= 2) {
+        int slot = (int)((s->enqueued - 1) % kIrRing);
+        if (s->seq_of[slot] == s->enqueued - 1 && s->front.load(std::memory_order_relaxed) < s->enqueued - 1) {
+            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
+            poll_published(s);
+        }
+    }
+    TimedFrame tf{};
+    bool timed = ctx->profiling >= 2;
+    if (timed) {
+        for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
+        tf.e[3] = take_event(ctx);
+        tf.e[4] = take_event(ctx);
+    }
+    if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) {  // ARTS.cpp:191 literally
+        FS_HIP(ctx, wait_energy_readers(ctx, s));
+        FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+    }
+    // The tail stream takes over: it waits for this frame's deposit (and runs behind any collective the caller
+    // put there after fs_energy_handoff), reconstructs and publishes while the compute stream goes on to the
+    // next frame.  Reconstructs and publishes of one source are ordered among themselves by the tail stream.
+    FS_HIP(ctx, handoff_energy(ctx, s));
+    hipStream_t tail = ctx->copy_stream;
+    {
+        std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
+        if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
+        if (timed) FS_HIP(ctx, hipEventRecord(tf.e[3], tail));
+        // deterministic mode: the collective summed the fixed-point histogram; round it to fp32 once, now
+        if (s->cur_fixed && !s->reduced) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
+        launch_reconstruct(s->energy(), B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
+                           s->d_ir_mono, tail);
+        FS_HIP(ctx, hipGetLastError());
+        FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], tail));
+        s->rec_recorded[s->cur] = true;
+        s->last_rec = s->cur;
+    }
+    uint64_t seq = s->enqueued + 1;
+    int slot = (int)(seq % kIrRing);
+    FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
+                               hipMemcpyDeviceToHost, tail));
+    FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
+    s->seq_of[slot] = seq;
+    s->enqueued = seq;
+    if (timed) {
+        FS_HIP(ctx, hipEventRecord(tf.e[4], tail));
+        tf.has_recon = true;
+        ctx->pending.push_back(tf);
+    }
+    return FS_OK;
+}
+
+}  // namespace fsi
+
+// ---- one traced frame ----------------------------------------------------------------------------------------------
+// UpdateSource up to the deposit (ARTS.cpp:128-173) for `count` sources (count == 1: the plain call).  A batch lays the
+// sources' pairs end to end in one plan / walk / connect sequence: every source gets exactly the pairs, random streams
+// and therefore results of its own fs_compute_energy_response_async call, but the chip sees one large frame instead
+// of `count` small ones.  The work is cut into four steps so that nothing of the context has rotated when a step that
+// can fail returns early:
+//   frame_describe   host only: the kernels' constants, the frame's mode
+//   frame_resources  everything that allocates, waits or copies: state arrays, fixed-point buffers, batch tables —
+//                    works on the buffers the frame WILL use, without making them current
+//   frame_commit     the rotation: frame index, the sources' current energy buffer, batch table slot (cannot fail)
+//   frame_launch     the passes (or the fused launch of pipelined frames) and the bookkeeping
+namespace {
+
+struct Frame {
+    Source* const* srcs = nullptr;
+    int count = 0;
+    const fs_params* p = nullptr;
+    // frame_describe
+    KParams kp{};
+    int B = 1, levels = 0;
+    bool batch = false, unbounded = false, all_conn = false, mis = false, fixed = false, accumulate = false, pipe_ok = false;
+    // frame_resources
+    unsigned fidx = 0;                  // the frame's index: which state / schedule / scratch set it uses
+    SubpathState st{};
+    unsigned* scratch = nullptr;
+    uint32_t* perm_buf = nullptr;
+    int next_cur[64];                   // energy buffer each source deposits into (batches above 64 sources: heap)
+    std::vector<int> next_cur_heap;
+    int* cur_of = nullptr;
+    float* const* energy_tab = nullptr; // batched frame: device tables
+    unsigned long long* const* fixed_tab = nullptr;
+    bool used_batch_slot = false;
+};
+
+void frame_describe(fs_context* ctx, Frame& f) {
+    const fs_params* p = f.p;
+    Source* s = f.srcs[0];
+    f.batch = f.count > 1;
+    f.B = ctx->cfg.num_bands;
+    const uint64_t P = p->num_rays / 2;
+    uint32_t p0 = 0, pn = 0;
+    (void)fs_shard_range(p->num_rays, ctx->cfg.rank, ctx->cfg.world_size, &p0, &pn);   // validated by check_params / create
+    KParams& kp = f.kp;
+    kp.seed_lo = (uint32_t)p->seed;
+    kp.seed_hi = (uint32_t)(p->seed >> 32);
+    kp.pair_begin = p0;
+    kp.pairs_per_source = pn;
+    kp.num_local = kp.pairs_per_source * (uint32_t)f.count;
+    kp.src_table = nullptr;
+    // depth = 0: no cap, like the reference's while (true) (ARTS.cpp:294) — the roulette ends every walk; the records of
+    // steps beyond FS_MAX_DEPTH go to the second tier.  Without roulette an uncapped walk would never end: FS_MAX_DEPTH.
+    f.unbounded = p->depth == 0 && p->russian_roulette && p->rr_prob < 1.0f;
+    f.levels = p->depth > 0 ? p->depth : FS_MAX_DEPTH;
+    kp.depth = f.unbounded ? FS_MAX_DEPTH + kOverLevels : f.levels;
+    kp.mis_depth = f.unbounded ? kUnboundedDepth : f.levels;
+    kp.russian_roulette = p->russian_roulette;
+    kp.cosine = (p->flags & FS_FLAG_COSINE_SAMPLING) ? 1 : 0;
+    kp.rr_prob = p->rr_prob;
+    kp.max_trace_dist = p->max_trace_dist;
+    kp.surface_offset = p->surface_offset;
+    kp.connect_pullback = p->connect_pullback;
+    kp.dist_divisor = p->dist_divisor;
+    kp.min_seg = p->min_seg;
+    kp.prob_exponent = p->prob_exponent;
+    kp.energy_clamp = p->energy_clamp;
+    kp.energy_gain = p->energy_gain;
+    kp.sound_speed = p->sound_speed;
+    kp.norm = (p->flags & FS_FLAG_FIXED_NORM_1000) ? 1.0f / 1000.0f : (P ? 1.0f / (float)P : 0.f);  // ARTS.cpp:164
+    for (int b = 0; b < FS_MAX_BANDS; ++b) kp.air[b] = p->air_absorption[b];
+    std::memcpy(kp.src, s->pos, sizeof(kp.src));
+    std::memcpy(kp.lis, ctx->listener, sizeof(kp.lis));
+    kp.count = ctx->profiling >= 3 ? 1 : 0;
+    kp.num_bins = ctx->num_bins;
+    kp.num_bands = f.B;
+    kp.hist_window = std::min(ctx->num_bins, ctx->hist_window);
+    kp.lobes = (p->flags & FS_FLAG_MATERIAL_LOBES) ? 1 : 0;
+    f.mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
+    f.all_conn = f.mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
+    kp.mis = f.mis ? 1 : 0;
+    f.fixed = (p->flags & FS_FLAG_DETERMINISTIC) != 0;
+    f.accumulate = (p->flags & FS_FLAG_ACCUMULATE_ENERGY) != 0;
+    // Pipelined frames: this frame's passes are held back (to be launched with the next frames') when the frame has the
+    // default shape; any other frame first lets the held-back ones finish on their own.
+    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && p->depth > 0 &&
+                !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY));
+}
+
+int frame_resources(fs_context* ctx, Frame& f) {
+    KParams& kp = f.kp;
+    const int B = f.B, count = f.count;
+    if (2 * (size_t)kp.num_local > ctx->cap_lanes || (size_t)f.levels * 2 * (size_t)kp.num_local > ctx->cap_seg)
+        FS_FLUSH(ctx);   // the state arrays are about to be reallocated: held frames still read them
+    int rc = ensure_state(ctx, kp.num_local, f.levels, f.unbounded, (double)f.p->rr_prob, f.all_conn, f.mis);
+    if (rc) return rc;
+    f.fidx = ctx->frame_index;   // consecutive frames rotate through the state / schedule / scratch sets
+    SubpathState& st = f.st;
+    st = ctx->st;
+    if (f.fidx & 1u) {
+        st.end_pos += ctx->cap_lanes; st.end_misc += ctx->cap_lanes; st.slot_of += ctx->cap_lanes;
+        st.seg_np += ctx->cap_seg; st.seg_mat += ctx->cap_seg;
+    }
+    f.scratch = ctx->walk.queue_head + (size_t)(f.fidx % kScratchSets) * kScratchAllocWords;
+    f.perm_buf = ctx->walk.perm ? ctx->walk.perm + (size_t)(f.fidx % kPermSets) * ctx->perm_words : nullptr;
+    st.seg_pos = f.all_conn ? ctx->d_seg_pos : nullptr;
+    st.seg_nrm = f.mis ? ctx->d_seg_pos + (size_t)f.levels * 2 * (size_t)kp.num_local : nullptr;
+    st.main_levels = f.levels;
+    st.over_levels = f.unbounded ? kOverLevels : 0;
+    st.over_cap = f.unbounded ? ctx->over_cap : 0;
+    st.over_np = ctx->d_over_np; st.over_mat = ctx->d_over_mat;
+    st.over_pos = f.all_conn ? ctx->d_over_pos : nullptr;
+    st.over_nrm = f.mis && ctx->d_over_pos ? ctx->d_over_pos + (size_t)kOverLevels * ctx->over_cap : nullptr;
+    st.overflow = ctx->d_overflow;
+
+    if (count > 64) { f.next_cur_heap.resize((size_t)count); f.cur_of = f.next_cur_heap.data(); } else f.cur_of = f.next_cur;
+    for (int i = 0; i < count; ++i) {
+        Source* si = f.srcs[i];
+        if (f.fixed && !si->d_fixed[0]) {
+            for (int k = 0; k < kEnergyBufs; ++k) {
+                FS_HIP(ctx, hipMalloc((void**)&si->d_fixed[k], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
+                FS_HIP(ctx, hipMemsetAsync(si->d_fixed[k], 0, sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+            }
+        }
+        // this frame deposits into the next buffer of the rotation; the tail may still be busy with it.  (FS_FLAG_ACCUMULATE_ENERGY
+        // stays in the buffer of the previous frame — behind its reduce / reconstruct — and adds to what it holds.)
+        f.cur_of[i] = f.accumulate ? si->cur : (si->cur + 1) % kEnergyBufs;
+        FS_HIP(ctx, wait_energy_readers(ctx, si, f.cur_of[i]));
+    }
+    if (f.batch) {
+        // per-frame tables in one pinned staging block: energy pointers [count] | fixed-point buffer pointers [count] |
+        // source positions [count][3].  The block is rewritten only after the previous frame's copy has left it.
+        const size_t bytes = 2 * (size_t)count * sizeof(void*) + (size_t)count * 3 * sizeof(float);
+        if (bytes > ctx->batch_cap) {
+            FS_FLUSH(ctx);   // a held batched frame still carries pointers into the block that is about to be freed
+            FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+            if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+            ctx->d_batch = nullptr; ctx->h_batch = nullptr; ctx->batch_cap = 0;
+            const size_t cap = (bytes + 255) & ~(size_t)255;
+            FS_HIP(ctx, hipMalloc((void**)&ctx->d_batch, cap * fs_context::kBatchSlots));
+            FS_HIP(ctx, hipHostMalloc((void**)&ctx->h_batch, cap * fs_context::kBatchSlots, hipHostMallocDefault));
+            ctx->batch_cap = cap;
+            for (int k = 0; k < fs_context::kBatchSlots; ++k) {
+                if (!ctx->ev_batch[k]) FS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_batch[k], hipEventDisableTiming));
+                ctx->batch_pending[k] = false;
+            }
+        }
+        const int slot = (int)(ctx->batch_frame % fs_context::kBatchSlots);
+        if (ctx->batch_pending[slot]) FS_HIP(ctx, hipEventSynchronize(ctx->ev_batch[slot]));   // its last copy has left the block
+        char* hb = ctx->h_batch + (size_t)slot * ctx->batch_cap;
+        char* db = ctx->d_batch + (size_t)slot * ctx->batch_cap;
+        void** h_en = reinterpret_cast<void**>(hb);
+        void** h_fx = h_en + count;
+        float* h_pos = reinterpret_cast<float*>(h_fx + count);
+        for (int i = 0; i < count; ++i) {
+            h_en[i] = f.srcs[i]->d_energy[f.cur_of[i]];
+            h_fx[i] = f.fixed ? (void*)f.srcs[i]->d_fixed[f.cur_of[i]] : nullptr;
+            std::memcpy(h_pos + 3 * i, f.srcs[i]->pos, sizeof(float) * 3);
+        }
+        FS_HIP(ctx, hipMemcpyAsync(db, hb, bytes, hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(ctx, hipEventRecord(ctx->ev_batch[slot], ctx->stream));
+        ctx->batch_pending[slot] = true;
+        f.used_batch_slot = true;
+        f.energy_tab = reinterpret_cast<float* const*>(db);
+        f.fixed_tab = f.fixed ? reinterpret_cast<unsigned long long* const*>(db + (size_t)count * sizeof(void*)) : nullptr;
+        kp.src_table = reinterpret_cast<const float*>(db + 2 * (size_t)count * sizeof(void*));
+    }
+    return FS_OK;
+}
+
+// the rotation — nothing here can fail
+void frame_commit(fs_context* ctx, Frame& f) {
+    ctx->frame_index = f.fidx + 1;
+    if (f.used_batch_slot) ctx->batch_frame++;
+    if (f.unbounded) ctx->overflow_armed = true;
+    for (int i = 0; i < f.count; ++i) {
+        Source* si = f.srcs[i];
+        si->cur = f.cur_of[i];
+        si->cur_fixed = f.fixed;
+        si->reduced = false; si->handed_off = false;
+    }
+}
+
+int frame_launch(fs_context* ctx, Frame& f) {
+    KParams& kp = f.kp;
+    SubpathState& st = f.st;
+    Source* s = f.srcs[0];
+    Source* const* srcs = f.srcs;
+    const int B = f.B, count = f.count;
+    const bool fixed = f.fixed, accumulate = f.accumulate;
+    unsigned* const scratch = f.scratch;
+    uint32_t* const perm_buf = f.perm_buf;
+    float* const* energy_tab = f.energy_tab;
+    unsigned long long* const* fixed_tab = f.fixed_tab;
+
+    TimedFrame tf{};
+    // level 1 may sample: events around every profile_interval-th frame only (an event pair costs the frame a few
+    // microseconds of queue bubbles — bench.py times every 8th frame of its timed region)
+    bool timed_frame = ctx->profiling && (ctx->profiling >= 2 || ctx->profile_interval <= 1 ||
+                                                (ctx->profile_tick++ % (unsigned)ctx->profile_interval) == 0);
+    if (timed_frame) {
+        resolve_completed_timings(ctx);
+        for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
+        tf.e[0] = take_event(ctx);
+        tf.e[1] = take_event(ctx);
+        if (ctx->profiling >= 2) tf.e[2] = take_event(ctx);
+    }
+    // FlushEnergyBuffer ARTS.cpp:157-161 is folded into the plan pass (one launch); plain memset otherwise.
+    // Deterministic mode zeroes the fixed-point histogram instead (the fp32 buffer is rewritten from it).
+    float* zero_ptr = accumulate ? nullptr : (fixed ? reinterpret_cast<float*>(s->d_fixed[s->cur]) : s->energy());
+    const int zero_words = (fixed ? 2 : 1) * B * ctx->num_bins;
+    float* const* zero_tab = nullptr;   // batched frame: the table of buffers the plan pass zeroes
+    if (f.batch) {
+        zero_ptr = nullptr;
+        if (!accumulate) zero_tab = fixed ? reinterpret_cast<float* const*>(fixed_tab) : energy_tab;
+    }
+    WalkLaunch wplan = ctx->walk;
+    wplan.queue_head = scratch;
+    wplan.perm = perm_buf;
+    if (f.unbounded) wplan.plan = 1;   // the second record tier relies on the schedule: the longest walks own the lowest slots
+    bool sort = false;
+    const bool plan_runs = plan_shape(kp, wplan, nullptr, &sort);   // the plan pass (and the flush with it) runs for this frame
+    const uint32_t* perm = plan_runs && sort ? perm_buf : nullptr;
+    if (!perm) st.slot_of = nullptr;   // no schedule: slot == subpath index
+    const bool plan_held = f.pipe_ok && ctx->pipelining >= 2 && plan_runs;   // depth 2: the pass joins the fused launch below
+    if (plan_runs && !plan_held)
+        (void)launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
+    if (!plan_runs) {
+        if (zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+        for (int i = 0; i < count && zero_tab; ++i) {
+            float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[srcs[i]->cur]) : srcs[i]->energy();
+            FS_HIP(ctx, hipMemsetAsync(zp, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
+        }
+    }
+    if (!kp.russian_roulette) ctx->host_segments += 2ull * kp.num_local * (unsigned long long)kp.depth;   // no plan pass to count them
+    if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
+    WalkLaunch wl = ctx->walk;
+    wl.queue_head = scratch;
+    wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
+    const int ppw = ctx->connect_pairs_per_wave > 0 ? ctx->connect_pairs_per_wave : auto_pairs_per_wave(kp.num_local);
+    if (f.pipe_ok) {   // (anything else has flushed the held frames before)
+        fs_context::PipeFrame me;
+        me.has = true; me.kp = kp; me.st = st; me.wl = wl; me.perm = perm; me.walked = false; me.fixed = fixed; me.ppw = ppw;
+        me.items.resize((size_t)count);
+        for (int i = 0; i < count; ++i) { me.items[(size_t)i].s = srcs[i]; me.items[(size_t)i].cur = srcs[i]->cur; }
+        me.energy_tab = energy_tab; me.fixed_tab = fixed_tab;
+        FrameParts fp;
+        fp.wl = wl;
+        const bool deep = ctx->pipelining >= 2;
+        // the held frames (copies: the slots are rewritten below): one that only owes its connect pass, one that was only planned
+        fs_context::PipeFrame to_connect, to_walk;
+        if (ctx->held[0].has && ctx->held[0].walked) to_connect = ctx->held[0];
+        if (ctx->held[1].has) to_walk = ctx->held[1];
+        else if (ctx->held[0].has && !ctx->held[0].walked) to_walk = ctx->held[0];
+        if (deep) {   // {plan of this frame, walk of the planned frame, connect of the walked one}
+            if (plan_held) {
+                fp.has_plan = true; fp.kpp = kp; fp.scratch_p = scratch; fp.perm_p = sort ? perm_buf : nullptr;
+                fp.zero_p = zero_ptr; fp.zero_words_p = (zero_ptr || zero_tab) ? zero_words : 0; fp.zero_tab_p = zero_tab; fp.zero_count_p = count;
+            }
+            if (to_walk.has) held_walk_part(to_walk, fp);
+        } else {      // {walk of this frame, connect of the walked one}
+            held_walk_part(me, fp);
+        }
+        if (to_connect.has) held_connect_part(to_connect, fp);
+        if (timed_frame && !(fp.has_walk && (fp.has_connect || !deep))) {
+            // a pipeline-fill launch (no walk, or depth 2 without its connect part yet) is not a sample of the frame kernel:
+            // take the first event back out of the stream's timing (it was recorded above; both go back to the pool unused)
+            for (int i = 0; i < 3; ++i) if (tf.e[i]) { ctx->free_events.push_back(tf.e[i]); tf.e[i] = nullptr; }
+            timed_frame = false;
+        }
+        if (fp.has_walk || fp.has_connect || fp.has_plan) {
+            if (!launch_frame(B, ctx->scene, fp, ctx->stream)) {   // no fused form: the same passes one after the other
+                if (fp.has_connect) launch_connect(B, ctx->scene, fp.kpc, fp.stc, fp.energy, fp.fixed, fp.scratch_c, fp.ppw, fp.energy_tab, fp.fixed_tab, ctx->stream);
+                if (fp.has_walk) launch_walk(ctx->scene, fp.kpw, fp.stw, fp.wl, fp.perm, ctx->stream);
+                if (fp.has_plan) (void)launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
+            }
+        }
+        if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+        FS_HIP(ctx, hipGetLastError());
+        ctx->held[0].has = false; ctx->held[1].has = false;
+        if (to_connect.has) { const int rc = finish_held_frame(ctx, to_connect); if (rc) return rc; }
+        if (deep) {   // the planned frame has been walked now; this one has only been planned
+            if (to_walk.has) { ctx->held[0] = to_walk; ctx->held[0].walked = true; ctx->held[1] = me; }
+            else ctx->held[0] = me;
+        } else {
+            me.walked = true;
+            ctx->held[0] = me;
+        }
+        if (timed_frame) { tf.has_trace = true; ctx->pending.push_back(tf); }
+        ctx->stats.frames++;
+        ctx->stats.pairs += kp.num_local;
+        ctx->stats.rays += 2ull * kp.num_local;
+        return FS_OK;
+    }
+    launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+    if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
+    if (f.all_conn)
+        launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, scratch, ctx->stream);
+    else
+        launch_connect(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, scratch, ppw,
+                       energy_tab, fixed_tab, ctx->stream);
+    if (fixed)
+        for (int i = 0; i < count; ++i)
+            launch_fixed_to_energy(srcs[i]->d_fixed[srcs[i]->cur], srcs[i]->energy(), B * ctx->num_bins, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    if (timed_frame) {
+        if (tf.e[2]) FS_HIP(ctx, hipEventRecord(tf.e[2], ctx->stream));
+        tf.has_trace = true;
+        ctx->pending.push_back(tf);
+    }
+    ctx->stats.frames++;
+    ctx->stats.pairs += kp.num_local;
+    ctx->stats.rays += 2ull * kp.num_local;
+    // multi-GPU: the sum over the ranks (ARTS.cpp:164-173 deposits ALL pairs into the one buffer) runs on the tail
+    // stream right behind the deposit, concurrently with whatever the compute stream traces next
+    if (ctx->comm)
+        for (int i = 0; i < count; ++i) { const int rr = reduce_energy(ctx, srcs[i]); if (rr) return rr; }
+    return FS_OK;
+}
+
+int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
+    { const int ir = maybe_install_refined(ctx); if (ir) return ir; }                     // fs_scene_commit_progressive: the better tree is ready
+    if (ctx->refit_pending) { const int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    Frame f;
+    f.srcs = srcs; f.count = count; f.p = p;
+    frame_describe(ctx, f);
+    if (!f.pipe_ok) FS_FLUSH(ctx);
+    rc = frame_resources(ctx, f);
+    if (rc) return rc;
+    frame_commit(ctx, f);
+    return frame_launch(ctx, f);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- sources / listener ------------------------------------------------------------------------------
+int fs_source_create(fs_context* ctx, fs_source* out) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    Source* s = new (std::nothrow) Source();
+    if (!s) return ctx->fail(FS_ERR_OUT_OF_MEMORY, "source");
+    const size_t eb = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    const size_t ib = sizeof(float) * (size_t)ctx->num_samples;
+    auto bail = [&](hipError_t e, const char* what) {
+        int rc = ctx->hip_fail(e, what);
+        s->alive = false;
+        free_source(ctx, s);
+        return rc;
+    };
+    hipError_t e;
+    for (int i = 0; i < kEnergyBufs; ++i) {
+        if ((e = hipMalloc((void**)&s->d_energy[i], eb)) != hipSuccess) return bail(e, "hipMalloc(energy)");
+        if ((e = hipMemsetAsync(s->d_energy[i], 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+        if ((e = hipEventCreateWithFlags(&s->ev_rec[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
+    if ((e = hipMalloc((void**)&s->d_ir_bands, ib * (size_t)ctx->cfg.num_bands)) != hipSuccess) return bail(e, "hipMalloc(ir_bands)");
+    if ((e = hipMalloc((void**)&s->d_ir_mono, ib)) != hipSuccess) return bail(e, "hipMalloc(ir_mono)");
+    if ((e = hipMemsetAsync(s->d_ir_bands, 0, ib * (size_t)ctx->cfg.num_bands, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    if ((e = hipMemsetAsync(s->d_ir_mono, 0, ib, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    for (int i = 0; i < kIrRing; ++i) {
+        if ((e = hipHostMalloc((void**)&s->h_ir[i], ib, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+        std::memset(s->h_ir[i], 0, ib);  // ImpulseBuffer[ch].Init(0, NumSamples) FSAC.cpp:24-28
+        if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    }
+    if ((e = hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    for (int i = 0; i < kEnergyBufs; ++i)
+        if ((e = hipEventCreateWithFlags(&s->ev_red[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&s->ev_rev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    // the initial fills above ran on the compute stream; the first reconstruct runs on the tail stream
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    s->alive = true;
+    // RegisterSource: ActiveSources.Add (ARTS.cpp:45-48); reuse a dead slot if any
+    for (size_t i = 0; i < ctx->sources.size(); ++i)
+        if (!ctx->sources[i]) { ctx->sources[i] = s; *out = (fs_source)i; return FS_OK; }
+    ctx->sources.push_back(s);
+    *out = (fs_source)(ctx->sources.size() - 1);
+    return FS_OK;
+}
+
+int fs_source_destroy(fs_context* ctx, fs_source h) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (ctx->device_ok) {
+        (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->rev_stream);
+    }
+    ctx->sources[(size_t)h] = nullptr;  // UnRegisterSource ARTS.cpp:50-53
+    free_source(ctx, s);
+    return FS_OK;
+}
+
+int fs_source_set_position(fs_context* ctx, fs_source h, const float xyz[3]) {
+    if (!ctx || !xyz) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    std::memcpy(s->pos, xyz, sizeof(float) * 3);
+    return FS_OK;
+}
+
+int fs_listener_set_position(fs_context* ctx, const float xyz[3]) {
+    if (!ctx || !xyz) return FS_ERR_INVALID_ARGUMENT;
+    std::memcpy(ctx->listener, xyz, sizeof(float) * 3);
+    return FS_OK;
+}
+
+// ---- hot path ------------------------------------------------------------------------------------------
+int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    return trace_sources(ctx, &s, 1, p);
+}
+
+int fs_compute_energy_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (count < 0 || (count > 0 && !sources)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad source list");
+    if (count == 0) return FS_OK;
+    if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    std::vector<Source*> srcs((size_t)count);
+    for (int32_t i = 0; i < count; ++i) {
+        srcs[(size_t)i] = get_source(ctx, sources[i]);
+        if (!srcs[(size_t)i]) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+        for (int32_t k = 0; k < i; ++k)
+            if (sources[k] == sources[i]) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a source appears twice in the batch");
+    }
+    // One launch sequence for all sources when the frame fits 32-bit subpath indices and the mode is the default
+    // connection strategy; the all-connections modes (one wave per pair already) and oversized batches go source by source
+    const uint64_t P = p ? p->num_rays / 2 : 0;
+    const bool one_launch = p && !(p->flags & (FS_FLAG_ALL_CONNECTIONS | FS_FLAG_MIS_BALANCE)) &&
+                            (uint64_t)count * P <= (1ull << 29);
+    if (one_launch) return trace_sources(ctx, srcs.data(), count, p);
+    for (int32_t i = 0; i < count; ++i) {
+        int rc = trace_sources(ctx, &srcs[(size_t)i], 1, p);
+        if (rc) return rc;
+    }
+    return FS_OK;
+}
+
+int fs_compute_energy_response(fs_context* ctx, fs_source h, const fs_params* p, float* energy_out) {
+    int rc = FS_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {   // depth = 0: a frame whose records overflowed is traced again
+        rc = fs_compute_energy_response_async(ctx, h, p);
+        if (rc) return rc;
+        FS_FLUSH(ctx);   // the caller waits for this frame: no point in holding its connect pass back
+        if (!ctx->overflow_armed) break;
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = check_overflow(ctx);
+        if (rc != FS_ERR_OVERFLOW) break;
+    }
+    if (rc) return rc;
+    Source* s = get_source(ctx, h);
+    if (energy_out) {
+        FS_HIP(ctx, hipMemcpyAsync(energy_out, s->energy(),
+                                   sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->pending.empty()) {
+        FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // reconstruct timings live on the tail stream
+        resolve_timings(ctx);
+    }
+    return FS_OK;
+}
+
+int fs_energy_device_ptr(fs_context* ctx, fs_source h, void** dptr, size_t* bytes) {
+    if (!ctx || !dptr) return FS_ERR_INVALID_ARGUMENT;
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    *dptr = s->energy();
+    if (bytes) *bytes = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    return FS_OK;
+}
+
+int fs_energy_handoff(fs_context* ctx, fs_source h, void** dptr, size_t* bytes, void** tail_stream) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, handoff_energy(ctx, s));
+    s->handed_off = true;
+    const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    if (dptr) *dptr = s->cur_fixed ? (void*)s->d_fixed[s->cur] : (void*)s->energy();
+    if (bytes) *bytes = (s->cur_fixed ? sizeof(unsigned long long) : sizeof(float)) * words;
+    if (tail_stream) *tail_stream = (void*)ctx->copy_stream;
+    return FS_OK;
+}
+
+int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    fs_params def;
+    if (!p) { fs_params_default(&def); p = &def; }
+    if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    // pipelined frames: the source's current frame still waits for its connect pass — the reconstruct goes with it
+    for (int k = 1; k >= 0; --k) {   // the source's CURRENT frame is the newest held one
+        fs_context::PipeFrame& q = ctx->held[k];
+        if (!q.has) continue;
+        fs_context::PipeFrame::Item* it = nullptr;
+        for (fs_context::PipeFrame::Item& c : q.items) if (c.s == s) it = &c;
+        if (!it) continue;
+        if (!it->want_recon && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && (ctx->cfg.world_size == 1 || ctx->comm)) {
+            it->want_recon = true;
+            it->recon = *p;
+            return FS_OK;
+        }
+        break;
+    }
+    FS_FLUSH(ctx);
+    return reconstruct_now(ctx, s, p);
+}
+
+int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32_t n) {
+    if (!ctx || !ir) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    poll_published(s);
+    if (s->enqueued >= 2) {   // never overwrite the front buffer: at most two publishes in flight
+        int slot = (int)((s->enqueued - 1) % kIrRing);
+        if (s->seq_of[slot] == s->enqueued - 1 && s->front.load(std::memory_order_relaxed) < s->enqueued - 1) {
+            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
+            poll_published(s);
+        }
+    }
+    hipStream_t tail = ctx->copy_stream;   // ordered with reconstructs and publishes of this source
+    const size_t bytes = sizeof(float) * (size_t)n;
+    {
+        std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
+        if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));
+        FS_HIP(ctx, hipMemcpyAsync(s->d_ir_mono, ir, bytes, hipMemcpyHostToDevice, tail));
+        for (int b = 0; b < ctx->cfg.num_bands; ++b)
+            FS_HIP(ctx, hipMemcpyAsync(s->d_ir_bands + (size_t)b * (size_t)n, s->d_ir_mono, bytes, hipMemcpyDeviceToDevice, tail));
+        const int cur = s->last_rec >= 0 ? s->last_rec : s->cur;
+        FS_HIP(ctx, hipEventRecord(s->ev_rec[cur], tail));   // the reverb waits on this before reading d_ir_mono
+        s->rec_recorded[cur] = true;
+        s->last_rec = cur;
+    }
+    uint64_t seq = s->enqueued + 1;
+    int slot = (int)(seq % kIrRing);
+    FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, bytes, hipMemcpyDeviceToHost, tail));
+    FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
+    s->seq_of[slot] = seq;
+    s->enqueued = seq;
+    FS_HIP(ctx, hipStreamSynchronize(tail));   // `ir` is the caller's memory
+    poll_published(s);
+    return FS_OK;
+}
+
+int fs_synchronize(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    for (Source* s : ctx->sources)
+        if (s && s->alive) poll_published(s);
+    resolve_timings(ctx);
+    return check_overflow(ctx);   // FS_ERR_OVERFLOW: the last depth = 0 frame must be traced again (see the header)
+}
+
+int fs_reconstruct_impulse_response(fs_context* ctx, fs_source h, const fs_params* p) {
+    int rc = fs_reconstruct_impulse_response_async(ctx, h, p);
+    if (rc) return rc;
+    return fs_synchronize(ctx);
+}
+
+int fs_get_impulse_response(fs_context* ctx, fs_source h, int32_t channel, const float** data, int32_t* n) {
+    if (!ctx || !data) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return FS_ERR_BAD_HANDLE;  // no err string write: may be called from the audio thread
+    if (channel < 0 || channel >= ctx->cfg.num_channels) return FS_ERR_INVALID_ARGUMENT;
+    uint64_t f = s->front.load(std::memory_order_acquire);
+    *data = s->h_ir[(int)(f % kIrRing)];  // f == 0: slot 0 still holds the zero-initialised IR
+    if (n) *n = ctx->num_samples;
+    return FS_OK;
+}
+
+int fs_copy_impulse_response(fs_context* ctx, fs_source h, int32_t channel, float* out, int32_t n) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
+    const float* p = nullptr;
+    int rc = fs_get_impulse_response(ctx, h, channel, &p, nullptr);
+    if (rc) return rc;
+    std::memcpy(out, p, sizeof(float) * (size_t)n);
+    return FS_OK;
+}
+
+int fs_copy_band_impulse_response(fs_context* ctx, fs_source h, int32_t band, float* out, int32_t n) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
+    if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // the reconstruct runs on the tail stream
+    FS_HIP(ctx, hipMemcpyAsync(out, s->d_ir_bands + (size_t)band * (size_t)ctx->num_samples, sizeof(float) * (size_t)n,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+// ---- energy-buffer helpers (FSAC.h:72-91) ---------------------------------------------------------------
+int fs_get_energy_buffer(fs_context* ctx, fs_source h, float* out, int32_t n) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // a collective on the tail stream may still be summing it
+    FS_HIP(ctx, hipMemcpyAsync(out, s->energy(), sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+int fs_flush_energy_buffer(fs_context* ctx, fs_source h) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
+    s->handed_off = true;   // the caller owns the content now
+    FS_HIP(ctx, wait_energy_readers(ctx, s));
+    FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
+                               ctx->stream));
+    return FS_OK;
+}
+
+int fs_add_energy_at_delay(fs_context* ctx, fs_source h, int32_t band, float delay_seconds, float energy) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (band < 0 || band >= ctx->cfg.num_bands) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "band out of range");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
+    s->handed_off = true;   // the caller owns the content now
+    FS_HIP(ctx, wait_energy_readers(ctx, s));
+    launch_add_energy(s->energy() + (size_t)band * (size_t)ctx->num_bins, ctx->num_bins, delay_seconds, energy,
+                      ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    return FS_OK;
+}
+
+int fs_update_energy_buffer(fs_context* ctx, fs_source h, const float* values, int32_t n) {
+    if (!ctx || !values) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    // check(NewEnergyValues.Num() == NumBins) FSAC.h:83 -> status instead of abort
+    if (n != ctx->cfg.num_bands * ctx->num_bins) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != bands * bins");
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
+    s->handed_off = true;   // the caller owns the content now
+    FS_HIP(ctx, wait_energy_readers(ctx, s));
+    FS_HIP(ctx, hipMemcpyAsync(s->energy(), values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+// ---- frame pipeline --------------------------------------------------------------------------------------
+int fs_set_pipelining(fs_context* ctx, int32_t on) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (on < 0 || on > 2) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_set_pipelining: 0 (off), 1 or 2 frames held back");
+    if (on != ctx->pipelining) FS_FLUSH(ctx);
+    ctx->pipelining = on;
+    return FS_OK;
+}
+
+int fs_submit(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    return flush_pending(ctx);
+}
+
+}  // extern "C"

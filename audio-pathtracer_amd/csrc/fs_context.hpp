@@ -1,0 +1,305 @@
+// fs_context.hpp — the context behind the C ABI (include/frequensee.h) and the helpers its translation units share.
+// Internal: included by fs_capi_context.cpp (lifetime, helpers, stats), fs_capi_scene.cpp (geometry, commits, refit),
+// fs_capi_frame.cpp (sources, the traced frame and its pipeline, reconstruct, energy / IR access), fs_capi_comm.cpp
+// (RCCL behind the ABI) and fs_capi_aux.cpp (legacy tracer, line trace, text interchange, reverb, material FD).
+//
+// Mirrors the roles of UAudioRayTracingSubsystem (context lifetime, geometry/source registries,
+// per-source update: AudioRayTracingSubsystem.cpp:32-53, 128-195) and of UFrequenSeeAudioComponent's
+// buffers (EnergyBuffer, ImpulseBuffer: FrequenSeeAudioComponent.h:69-91, 113, 133-143).  All compute
+// is HIP on the context's streams; there is no CPU fallback.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cmath>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is opened at run time (fs_comm_*), never linked
+
+#include "fs_internal.hpp"
+
+using namespace fs;
+
+namespace fsi {
+
+constexpr int kIrRing = 3;  // published IR ring: a returned pointer stays valid until the second-next publish
+
+// Energy buffers per source, used in rotation: frame f deposits into one while the tail stream still reduces /
+// reconstructs frame f - 1 from another; pipelined frames finish frame f - 2 only in the launch that plans frame f
+// (and flushes ITS buffer), so that a fourth one lets frame f + 1 start without waiting for that tail.
+constexpr int kEnergyBufs = 4;
+constexpr int kScratchSets = 3;   // frame scratch (plan counts, cursors, work counters): plan f, walk f-1, connect f-2 in one launch
+constexpr int kPermSets = 2;      // schedules: plan f writes one while walk f-1 reads the other
+
+struct Source {
+    bool alive = false;
+    float pos[3] = {0, 0, 0};
+    // Two energy buffers [B][bins], alternating per frame: while the tail stream still reduces /
+    // reconstructs frame f from one of them, the compute stream already traces frame f+1 into the other.
+    float* d_energy[kEnergyBufs] = {};
+    int cur = 0;                       // buffer of the current frame (rotates in fs_compute_energy_response*)
+    hipEvent_t ev_dep = nullptr;       // compute stream: everything that writes the current buffer is enqueued
+    hipEvent_t ev_rec[kEnergyBufs] = {};   // tail stream: the reconstruct that read buffer i is done
+    bool rec_recorded[kEnergyBufs] = {};
+    int last_rec = -1;                 // buffer the newest reconstruct read (its event also guards d_ir_*)
+    hipEvent_t ev_rev = nullptr;       // reverb stream: the newest reverb callback has read d_ir_mono
+    bool rev_recorded = false;
+    // fs_reverb_process runs on the AUDIO thread while the game thread reconstructs: ir_mu guards what both touch —
+    // last_rec / rec_recorded / ev_rec (written by the reconstruct, read by the callback) and rev_recorded / ev_rev
+    // (the other way round).  Held only while work is ENQUEUED (microseconds), never across a stream wait.
+    std::mutex ir_mu;
+    float* energy() const { return d_energy[cur]; }
+    // multi-GPU: the frame in the current buffer has been summed over the ranks (library collective), or handed to the
+    // caller's collective (fs_energy_handoff); a world_size > 1 context refuses to reconstruct a frame that is neither
+    bool reduced = false, handed_off = false;
+    hipEvent_t ev_red[kEnergyBufs] = {};   // tail stream: the library's all-reduce of buffer i is done
+    bool red_recorded[kEnergyBufs] = {};
+    // deterministic mode (FS_FLAG_DETERMINISTIC): u64 fixed-point histograms [B][bins], allocated on first use,
+    // alternating like the energy buffers; cur_fixed = the current frame deposited into d_fixed[cur]
+    unsigned long long* d_fixed[kEnergyBufs] = {};
+    bool cur_fixed = false;
+    float* d_ir_bands = nullptr;  // [B][samples]
+    float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
+    float* h_ir[kIrRing] = {nullptr, nullptr, nullptr};  // pinned host copies of the channel view
+    hipEvent_t ev[kIrRing] = {nullptr, nullptr, nullptr};
+    uint64_t seq_of[kIrRing] = {0, 0, 0};
+    uint64_t enqueued = 0;             // publishes enqueued so far
+    std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
+    // reverb (row f2): history rings [2][kReverbRing], staging buffers, write head
+    float* d_ring = nullptr; float* d_rev_in = nullptr; float* d_rev_cur = nullptr; float* d_rev_out = nullptr;
+    unsigned rev_head = 0; int rev_frame = 0;
+    float occlusion = 1.0f;            // OcclusionAttenuation FSAC.h:130 (1.f until the first UpdateSound)
+};
+
+struct TimedFrame {
+    hipEvent_t e[5];  // walk begin, walk end == connect begin, connect end | reconstruct begin, end
+    bool has_trace = false, has_recon = false;
+};
+
+}  // namespace fsi
+using namespace fsi;
+
+// fs_scene_commit_progressive: the host's SAH build of a snapshot of the registered triangles, on its own thread, while
+// the frames already trace through the device-built tree.  The thread touches nothing but this object.
+struct RefineJob {
+    std::vector<float> xyz; std::vector<uint16_t> mat; std::vector<uint32_t> obj;
+    int T = 0;
+    fs::HostBVH bvh;
+    std::mutex mu; std::condition_variable cv;
+    bool done = false;
+    std::atomic<bool> cancel{false};   // a newer registration made this build useless: the builder gives up at its next check
+};
+
+struct fs_context {
+    fs_config cfg{};
+    int num_bins = 0, num_samples = 0;
+    hipStream_t stream = nullptr;
+    // "tail" stream: [caller's all-reduce] -> reconstruct -> publish of frame f, concurrent with the tracing of
+    // frame f+1 on `stream`
+    hipStream_t copy_stream = nullptr;
+    hipStream_t rev_stream = nullptr;  // the reverb callbacks' own stream (audio thread): never queued behind a traced frame
+    bool own_stream = false;
+    bool device_ok = false;
+    std::string err;
+    std::string advice;                // what fs_context_create found worth telling the host (fs_context_advice); never an error
+    std::mutex err_mu;                 // the audio thread may fail too
+
+    // scene (host staging + device)
+    std::vector<float> h_xyz;
+    std::vector<uint16_t> h_mat;
+    std::vector<uint32_t> h_obj;   // actor id per triangle (empty = one actor per triangle)
+    std::vector<float> h_absorption, h_transmission, h_scattering;
+    int32_t T = 0, M = 0;
+    bool committed = false;
+    NodeQ4* d_nodes = nullptr;
+    Tri64* d_tris = nullptr;
+    float* d_absorption = nullptr;
+    SoundAccum* d_sound = nullptr;
+    // refit support (row f4, fs_refit.hip)
+    uint32_t* d_leaf_pos = nullptr;   // input triangle -> leaf-order position
+    float4* d_node_box = nullptr;     // [nodes][2] fp32 bounds scratch
+    float* d_move = nullptr;          // staging for moved triangles
+    size_t move_cap = 0;              // in triangles
+    float amax = 0.f;                 // largest |coordinate| seen (sets the box padding)
+    char* d_build = nullptr;          // fs_scene_commit_fast: device copies of the inputs + build scratch (grow-only)
+    size_t build_cap = 0;
+    size_t fast_cap_tris = 0;         // triangles the scene arrays of the last fast commit have room for (0: not reusable)
+    bool refit_pending = false;
+    DeviceScene scene{};
+    // ApplyMaterialFD work buffers (row f4), sized for the largest block seen
+    int fft_n = -1;              // log2 of the size the twiddle table was built for
+    int fft_cap_n = -1, fft_cap_l = 0;
+    float2 *d_fft_x = nullptr, *d_fft_y = nullptr, *d_fft_w = nullptr;
+    float *d_fft_in = nullptr, *d_fft_resp = nullptr, *d_fft_out = nullptr;
+    // the 2 copies + up to 2 log2(N) - 20 launches of one block size are captured once into a hipGraph and replayed:
+    // the sequence is launch-bound (16 launches for a 48 000-sample block)
+    float* h_fft_stage = nullptr;      // pinned: in [L] | curves [3][bins] | out [3][L]
+    size_t fft_stage_floats = 0;
+    hipGraphExec_t fft_graph = nullptr;
+    int fft_graph_n = -1, fft_graph_l = -1;
+    HostBVH bvh;
+
+    float listener[3] = {0, 0, 0};
+    std::vector<Source*> sources;
+
+    // multi-GPU: RCCL communicator over the ranks that share the pairs of every frame
+    ncclComm_t comm = nullptr;
+    // cfg5 (independent sources, one per GPU): a communicator that never touches a frame — only fs_gather_energy uses it
+    ncclComm_t peers = nullptr;
+    int peers_size = 0;
+    float* d_gather = nullptr; size_t gather_cap = 0;   // [peers][B][bins] fp32
+    // Pipelined frames (fs_set_pipelining).  depth 1: the connect pass of frame f is held back and launched together with
+    // the walk of frame f + 1 as ONE kernel; depth 2: the walk is held back as well — call f launches {plan of f, walk of
+    // f - 1, connect of f - 2} as one kernel.  Anything that needs a held frame's result lets it finish alone (flush_pending).
+    struct PipeFrame {
+        bool has = false;
+        KParams kp; SubpathState st;
+        WalkLaunch wl;               // queue_head = the frame's scratch set, rays_per_wave
+        const uint32_t* perm = nullptr;   // its schedule (nullptr: none)
+        bool walked = false;         // only the connect pass is owed
+        bool fixed = false;
+        int ppw = 64;
+        struct Item {                // one per source of the frame (a batched frame has several)
+            Source* s = nullptr;
+            int cur = 0;             // which of the source's energy buffers the frame deposits into
+            bool want_recon = false; // fs_reconstruct_impulse_response_async arrived while the frame was held
+            fs_params recon;
+        };
+        std::vector<Item> items;
+        float* const* energy_tab = nullptr;               // batched frame: the per-frame device tables (kBatchSlots of them
+        unsigned long long* const* fixed_tab = nullptr;   // rotate; a held frame is connected two calls later at most)
+    } held[2];                       // [0] the older frame, [1] the newer one (depth 2 only)
+    std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
+    std::vector<std::thread> refine_threads;   // every background build ever started (cancelled ones too): joined before the context goes
+    bool moved_since_refine = false;     // fs_scene_update_triangles since the snapshot: re-apply the positions after the swap
+    fs::HostBVH* prebuilt = nullptr;     // fs_scene_commit takes this tree instead of building one (install of a refined tree)
+    int pipelining = 0;              // 0 off, 1 / 2 = frames held back
+    unsigned frame_index = 0;        // consecutive traced frames rotate through the state / schedule / scratch sets
+    size_t perm_words = 0;           // words of ONE schedule set (walk.perm holds kPermSets)
+    bool comm_owned = false;           // created by fs_comm_init (destroyed with the context) vs attached by the caller
+
+    // subpath state (sized on demand)
+    SubpathState st{};
+    size_t cap_lanes = 0, cap_seg = 0;
+    float4* d_seg_pos = nullptr;   // node positions per walk step, all-connections mode only (row f3)
+    size_t cap_pos = 0;
+    // second record tier of depth = 0 frames (walk steps beyond FS_MAX_DEPTH): [kOverLevels][over_cap] each, grown when
+    // a frame raises the overflow word; d_overflow = that word
+    float2* d_over_np = nullptr; uint32_t* d_over_mat = nullptr; float4* d_over_pos = nullptr;
+    uint32_t over_cap = 0, over_cap_pos = 0;
+    unsigned* d_overflow = nullptr;
+    bool overflow_armed = false;   // an unbounded frame has been enqueued since the word was last read
+    // batched frames (fs_compute_energy_response_batch_async): per-frame tables of pointers and source positions
+    static constexpr int kBatchSlots = 4;   // frames the host may run ahead of the table copies
+    char* d_batch = nullptr; char* h_batch = nullptr; size_t batch_cap = 0;   // kBatchSlots blocks of batch_cap bytes
+    hipEvent_t ev_batch[kBatchSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool batch_pending[kBatchSlots] = {false, false, false, false};
+    unsigned batch_frame = 0;
+    unsigned long long host_segments = 0;   // walk segments of frames without a plan pass (roulette off), since the last reset
+
+    // walk kernel launch shape (tunable through FS_WALK_VARIANT / FS_WALK_BLOCKS_PER_CU / FS_REFILL_THRESHOLD)
+    WalkLaunch walk{2, 256, nullptr, 1, nullptr};   // variant 2 = wave work sharing
+    int hist_window = kHistWindow; // FS_HIST_WINDOW
+    size_t lds_limit = 64 * 1024;  // dynamic LDS a workgroup may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
+    int walk_rays_per_wave = 0;    // BDPT walk: subpaths per wave, 0 = by frame size (FS_WALK_RAYS_PER_WAVE; 64 = dense waves)
+    int connect_pairs_per_wave = 0;   // connect kernel: pairs per wave, 0 = by frame size (FS_CONNECT_PAIRS_PER_WAVE; 64 = dense)
+    int sound_rays_per_wave = 2;   // legacy tracer: rays per wave, the other lanes help (FS_SOUND_RAYS_PER_WAVE; 64 = no sharing; 2 vs 4: 0.259 vs 0.267 ms at 100 k triangles, 0.195 vs 0.212 at 5 k)
+
+    // measurement
+    int profiling = 0;   // 0 off, 1 = HIP events around the dominant (walk) kernel only, 2 = every kernel
+    int profile_interval = 1;   // level 1: every n-th frame carries the events (fs_set_profiling_interval)
+    unsigned profile_tick = 0;
+    std::vector<TimedFrame> pending;
+    std::vector<hipEvent_t> free_events;
+    fs_stats stats{};
+
+    int fail(int code, const std::string& m) {
+        std::lock_guard<std::mutex> g(err_mu);
+        err = m;
+        return code;
+    }
+    int hip_fail(hipError_t e, const char* what) {
+        std::lock_guard<std::mutex> g(err_mu);
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return FS_ERR_HIP;
+    }
+};
+
+#define FS_FLUSH(ctx)                       \
+    do {                                    \
+        int fr_ = fsi::flush_pending(ctx);  \
+        if (fr_) return fr_;                \
+    } while (0)
+
+#define FS_HIP(ctx, call)                                        \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return (ctx)->hip_fail(e_, #call); \
+    } while (0)
+
+#define FS_NCCL(ctx, call)                                               \
+    do {                                                                 \
+        ncclResult_t r_ = (call);                                        \
+        if (r_ != ncclSuccess) return fsi::nccl_fail((ctx), r_, #call);  \
+    } while (0)
+
+constexpr float kMaxUnboundedRr = 0.95f;   // depth = 0 (uncapped walks): the strongest survival probability the record store covers
+
+namespace fsi {
+
+// ---- fs_capi_context.cpp ------------------------------------------------------------------------------------------
+Source* get_source(fs_context* ctx, fs_source h);
+hipError_t wait_energy_readers(fs_context* ctx, Source* s);            // before the compute stream writes the current energy buffer
+hipError_t wait_energy_readers(fs_context* ctx, Source* s, int buf);   // ... or the buffer the next frame will use
+hipError_t handoff_energy(fs_context* ctx, Source* s);        // compute stream -> tail stream
+void free_source(fs_context* ctx, Source* s);
+void free_scene(fs_context* ctx);
+void free_state(fs_context* ctx);
+hipEvent_t take_event(fs_context* ctx);
+void resolve_timings(fs_context* ctx);
+void resolve_completed_timings(fs_context* ctx);
+void poll_published(Source* s);
+int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals);
+int auto_rays_per_wave(unsigned long long lanes, int depth);
+int auto_pairs_per_wave(unsigned long long pairs);
+int check_params(fs_context* ctx, const fs_params* p);
+
+// ---- fs_capi_scene.cpp --------------------------------------------------------------------------------------------
+// fs_scene_commit_progressive: swap the finished background tree in; drop / wait for a background build
+int maybe_install_refined(fs_context* ctx);
+void cancel_refine(fs_context* ctx);
+void wait_refine(const std::shared_ptr<RefineJob>& j);
+void join_refine_threads(fs_context* ctx);
+
+// ---- fs_capi_frame.cpp --------------------------------------------------------------------------------------------
+int flush_pending(fs_context* ctx);          // pipelined frames: let every held frame finish on its own kernels
+int check_overflow(fs_context* ctx);         // depth = 0: did a record miss both tiers?  (stream just synchronised)
+int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
+
+// ---- fs_capi_comm.cpp ---------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;   // why loading failed
+};
+RcclApi* rccl();   // nullptr: librccl is not loadable
+int nccl_fail(fs_context* ctx, ncclResult_t r, const char* what);
+int reduce_energy(fs_context* ctx, Source* s);   // sum the source's current energy buffer over the ranks (tail stream)
+
+}  // namespace fsi

@@ -1,32 +1,14 @@
-// fs_kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64) of the FrequenSee BDPT path.
-//
-//   plan_kernel        the length of a subpath under Russian roulette depends only on the RNG stream: bucket the
-//                      subpaths by length before tracing, so that every walk wave holds equal-length walks;
-//                      also FlushEnergyBuffer (:157-161).
-//   walk_kernel_*      GeneratePath (AudioRayTracingSubsystem.cpp:279-355) for every source and listener
-//                      subpath.  Only geometry happens here (RNG, direction, closest hit, hit point); each
-//                      walk step leaves a 12-byte segment record (scaled length, node probability, node
-//                      material) so that EvaluatePath needs no stored path.
-//                        _shared: one subpath per lane, length-sorted schedule, closest-hit queries shared within
-//                                 the wave (default);  _sparse: the same on waves that own only a few subpaths
-//                                 (small frames).  Round 1's slower variants (persistent waves, fused walk + connect,
-//                                 no sharing) are measured in DESIGN.md section 5 and no longer built.
-//   connect_kernel     ConnectSubpaths (:235-277) any-hit visibility ray per pair; for connected pairs
-//                      EvaluatePath (:360-420) over the segment records in exact path order, clamp/gain
-//                      (:410-413), normalisation (:164-170) and AddEnergyAtDelay
-//                      (FrequenSeeAudioComponent.h:87-91) into an LDS-privatised [bands][bins] histogram
-//                      flushed with global float atomics (or a u64 fixed-point histogram, deterministic mode).
-//   connect_all_kernel the same for every forward prefix x backward prefix of a pair (draft :518-546, row f3).
-//   reconstruct_kernel ReconstructImpulseResponse (FrequenSeeAudioComponent.cpp:320-380).
-//   update_sound_shared_kernel legacy forward tracer UpdateSound/CastAudioRay/CastDirectAudioRay (:132-306 of
-//                      FrequenSeeAudioComponent.cpp), reverb_*_kernel the reverb plugin's per-callback convolution
-//                      (FrequenSeeAudioReverbPlugin.cpp:118-213).
-//   trace_rays_kernel  the engine line trace itself (closest / any hit), for tests and tools.
-//   (fs_fft.hip: ApplyMaterialFD; fs_refit.hip: moving geometry.)
+// fs_device.hpp — device-side code of the FrequenSee BDPT path shared by the kernel translation units (gfx950, wave64):
+// RNG and sampling maps, ray / triangle / box arithmetic, the BVH traversal step and its wave work sharing, the walk
+// (GeneratePath, AudioRayTracingSubsystem.cpp:279-355), ConnectSubpaths + EvaluatePath + deposit (:235-277, :360-420),
+// the plan pass.  Everything is inline in an anonymous namespace: fs_walk.hip, fs_connect.hip, fs_frame.hip and
+// fs_aux_kernels.hip each instantiate the kernels they launch (built side by side; fs_kernels_all.hip is the same code as
+// one unit for the diagnostic builds, whose device-side debug symbols must be shared by all kernels).
 //
 // The triangle test, the hit point/normal/offset arithmetic and the sampling maps use a fixed
 // operation order with explicit fmaf and are compiled with -ffp-contract=off: the path geometry is a
 // pure function of (scene, seed, pair index) and does not depend on launch geometry or on the BVH.
+#pragma once
 #include <algorithm>
 #include <atomic>
 
@@ -501,9 +483,16 @@ __device__ __forceinline__ void hit_surface(const DeviceScene& sc, int leaf_inde
 
 // one EvaluatePath segment term on E[b] (ARTS.cpp:381-398), in the reference's operation order
 // LOBES: 0 / 1 = FS_FLAG_MATERIAL_LOBES known at compile time (the default connect kernel), -1 = read kp.lobes
+// Band count of the connect kernels: a template constant for the counts in use (1, 4, 8: fully unrolled loops, the
+// band energies stay in registers) or B = 0: kp.num_bands at run time (every other count: the same arithmetic, unrolled
+// to FS_MAX_BANDS under a predicate).
+template <int B> struct Bands { static constexpr int kMax = B ? B : FS_MAX_BANDS; };
+template <int B> __device__ __forceinline__ int band_count(const KParams& kp) { return B ? B : kp.num_bands; }
+
 template <int B, int LOBES = -1>
-__device__ __forceinline__ void apply_segment(float (&E)[B], float nd, uint32_t mat, float prob, const KParams& kp,
+__device__ __forceinline__ void apply_segment(float (&E)[Bands<B>::kMax], float nd, uint32_t mat, float prob, const KParams& kp,
                                               const DeviceScene& sc) {
+    const int NB = band_count<B>(kp);
     const bool lobes = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
     if (nd < kp.min_seg) return;  // ARTS.cpp:375-378
     float nd2 = nd * nd;
@@ -514,10 +503,11 @@ __device__ __forceinline__ void apply_segment(float (&E)[B], float nd, uint32_t 
     const uint32_t lobe = (lobes && mat != kNoMat) ? ((mat >> kLobeShift) & 3u) : 0u;
     if (lobes && mat != kNoMat) mat &= 0xFFFFu;
     bool has = (mat != kNoMat) && ((int32_t)mat < sc.num_materials);
-    const float* coeff = lobes ? sc.lobe_gain + ((size_t)mat * 3 + lobe) * B : sc.absorption + (size_t)mat * B;
+    const float* coeff = lobes ? sc.lobe_gain + ((size_t)mat * 3 + lobe) * NB : sc.absorption + (size_t)mat * NB;
     const bool over_pi = !lobes || lobe == kLobeDiffuse;
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
+    for (int b = 0; b < Bands<B>::kMax; ++b) {
+        if (B == 0 && b >= NB) break;
         float bsdf = 1.0f;                                            // ARTS.cpp:382-386
         if (has) bsdf = over_pi ? coeff[b] / kPi : coeff[b];
         float e = E[b];
@@ -792,12 +782,7 @@ __device__ __forceinline__ void plan_body(const uint32_t bid, const uint32_t nbl
     if (threadIdx.x == 0 && s_seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), (unsigned long long)s_seg);
 }
 
-__global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __restrict__ scratch,
-                                                      uint32_t* __restrict__ perm, float* __restrict__ energy,
-                                                      int energy_words, float* const* __restrict__ energy_tab,
-                                                      int energy_count) {
-    plan_body(blockIdx.x, gridDim.x, kp, scratch, perm, energy, energy_words, energy_tab, energy_count);
-}
+
 
 // launch slot -> subpath index through the buckets, longest walks first.  s_cnt = bucket counts in LDS.
 __device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, uint32_t total, const unsigned* s_cnt,
@@ -811,43 +796,7 @@ __device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, ui
     return perm[slot - acc];   // bucket 0
 }
 
-#ifdef FS_EXPERIMENTS   // diagnostic builds only (-DFS_TRAV_STATS, tests/trav_stats.py): no work sharing, per-lane step counts
-// ---------------------------------------------------------------------------------------------------
-// walk_kernel_simple: one subpath per lane (reference variant)
-// ---------------------------------------------------------------------------------------------------
-template <int LOBES>
-__global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st,
-                                                             const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
-    int* s_stack = s_dyn;
-    __shared__ unsigned s_cnt[kPlanBuckets];
-    if (perm) {   // wave-uniform: bucket counts of the plan pass
-        for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
-        __syncthreads();
-    }
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= 2u * kp.num_local) return;
-    // length-sorted schedule (plan pass) or identity
-    const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
-    int* stack = &s_stack[threadIdx.x];
-    Walker w;
-    walker_start(w, g, slot, kp, st);
-    Ray ray;
-    while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
-        Trav T;
-        trav_init(T, kp.max_trace_dist, sc.num_nodes > 0);
-#ifdef FS_TRAV_STATS
-        const unsigned steps = (unsigned)trav_run<false>(sc, ray, T, stack);
-        if (g_step_buf) g_step_buf[(size_t)w.k * (2u * (size_t)kp.num_local) + w.g] = (unsigned short)steps;
-#else
-        trav_run<false>(sc, ray, T, stack);
-#endif
-        walker_apply_hit(w, kp, sc, st, ray, T);
-    }
-    walker_finish(w, st);
-}
-#endif
+
 
 // ---------------------------------------------------------------------------------------------------
 // Wave work sharing for closest-hit AND any-hit queries (one implementation, three instantiations).
@@ -1100,12 +1049,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
 #endif
 }
 
-template <int LOBES, bool COUNT>
-__global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
-                                                             const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm) {
-    walk_shared_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm);
-}
+
 
 // Small frames on sparse waves: a frame of a few thousand subpaths is a handful of waves and takes the latency of
 // its longest chain of closest-hit queries.  Here a wave owns only `rays_per_wave` subpaths (its first lanes) and
@@ -1144,12 +1088,7 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 }
 
-template <int LOBES, bool COUNT>
-__global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
-                                                             const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm, int rays_per_wave) {
-    walk_sparse_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave);
-}
+
 
 // ---------------------------------------------------------------------------------------------------
 // connect_kernel: ConnectSubpaths + EvaluatePath + clamp/gain + deposit
@@ -1169,14 +1108,14 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][hist_window] histogram
     int* s_stack = s_dyn;
     float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
-    const int nb = kp.num_bins, W = kp.hist_window;   // LDS histogram = the first W bins of every band (see KParams)
-    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * W);   // work-sharing area of trav_any_shared
+    const int nb = kp.num_bins, W = kp.hist_window, NB = band_count<B>(kp);   // LDS histogram = the first W bins of every band (see KParams)
+    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)NB * W);   // work-sharing area of trav_any_shared
     __shared__ int s_lo, s_hi;
     __shared__ unsigned s_dep;
 #ifdef FS_WAVE_TIMELINE
     unsigned long long tl[6] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0};
 #endif
-    for (int i = threadIdx.x; i < B * W; i += kBlock) s_hist[i] = 0.0f;
+    for (int i = threadIdx.x; i < NB * W; i += kBlock) s_hist[i] = 0.0f;
     if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; }
     // this frame's walk is over: rearm the frame scratch (queue head, plan counts and cursors) for the next one
     if (bid == 0u)
@@ -1218,11 +1157,14 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
         if (!tl[2]) tl[2] = __builtin_amdgcn_s_memrealtime();   // first chunk: visibility queries done
 #endif
         if (!active || hit) return;
+        // depth = 0 only: a walk that outlived the record store has raised the overflow word — the frame is void and will
+        // be traced again (FS_ERR_OVERFLOW); its pair must not be evaluated, the records it would read do not exist
+        if (st.over_levels && !(rec_fits(st, (int)Fm.y - 1, sf) && rec_fits(st, (int)Lm.y - 1, sl))) return;
         ++my_deposits;
         // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
-        float E[B];
+        float E[Bands<B>::kMax];
 #pragma unroll
-        for (int b = 0; b < B; ++b) E[b] = 1.0f;
+        for (int b = 0; b < Bands<B>::kMax; ++b) E[b] = 1.0f;
         float sd = 0.0f;
         const int kf = (int)Fm.y, kl = (int)Lm.y;
         for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
@@ -1251,7 +1193,8 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
             atomicMax(&s_hi, bin);
         }
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
+        for (int b = 0; b < Bands<B>::kMax; ++b) {
+            if (B == 0 && b >= NB) break;
             float e = E[b];
             e = (e < kp.energy_clamp) ? e : kp.energy_clamp;          // FMath::Min ARTS.cpp:410
             e *= kp.energy_gain;                                      // ARTS.cpp:413
@@ -1270,7 +1213,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
         const int lo = s_lo, hi = s_hi;
         if (hi >= lo) {
             const int span = hi - lo + 1;
-            for (int i = threadIdx.x; i < B * span; i += kBlock) {
+            for (int i = threadIdx.x; i < NB * span; i += kBlock) {
                 int b = i / span, bin = lo + (i - b * span);
                 float v = s_hist[b * W + bin];
                 if (v != 0.0f) atomicAdd(&dst[b * nb + bin], v);      // global_atomic_add_f32
@@ -1321,7 +1264,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
         const int lo = s_lo, hi = s_hi;
         if (hi >= lo) {
             const int span = hi - lo + 1;
-            for (int i = threadIdx.x; i < B * span; i += kBlock) {
+            for (int i = threadIdx.x; i < NB * span; i += kBlock) {
                 int b = i / span, bin = lo + (i - b * span);
                 float v = s_hist[b * W + bin];
                 if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);       // global_atomic_add_f32
@@ -1337,627 +1280,9 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #endif
 }
 
-template <int B, int LOBES, bool BATCH, bool COUNT>
-__global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
-                                                         float* __restrict__ energy,
-                                                         unsigned long long* __restrict__ fixed, unsigned* queue_head,
-                                                         int pairs_per_wave, float* const* __restrict__ energy_tab,
-                                                         unsigned long long* const* __restrict__ fixed_tab) {
-    connect_body<B, LOBES, BATCH, COUNT>(blockIdx.x, gridDim.x, sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);
-}
 
-// One launch for up to three frames (pipelined frames, fs_capi.cpp): workgroups [0, walk_blocks) walk the subpaths of
-// frame f - 1 (planned by the previous launch), the next connect_blocks connect the pairs of frame f - 2 (walked by the
-// previous launch), the rest run the plan pass of frame f.  The thin single round of the connect pass, the thin tail of
-// the walk's longest waves and the short plan pass fill each other's idle wave slots — and two kernel boundaries per
-// frame disappear.  The frames share nothing but the scene: each has its own subpath state, schedule, frame scratch
-// and energy buffer.
-template <int B, bool BATCH>
-__global__ __launch_bounds__(kBlock) void frame_kernel(DeviceScene sc, uint32_t walk_blocks, uint32_t connect_blocks,
-                                                       KParams kpw, SubpathState stw, const unsigned* __restrict__ scratch_w,
-                                                       const uint32_t* __restrict__ perm, int rays_per_wave,
-                                                       KParams kpc, SubpathState stc, float* __restrict__ energy,
-                                                       unsigned long long* __restrict__ fixed, unsigned* scratch_c,
-                                                       int pairs_per_wave, float* const* __restrict__ energy_tab,
-                                                       unsigned long long* const* __restrict__ fixed_tab,
-                                                       KParams kpp, unsigned* __restrict__ scratch_p, uint32_t* __restrict__ perm_p,
-                                                       float* __restrict__ zero_p, int zero_words_p,
-                                                       float* const* __restrict__ zero_tab_p, int zero_count_p) {
-    const uint32_t b = blockIdx.x;
-    if (b < walk_blocks) {   // (walks first: starting the connect pass before the short walks measured slower)
-        if (rays_per_wave < 64) walk_sparse_body<0, false>(b, sc, kpw, stw, scratch_w, perm, rays_per_wave);
-        else walk_shared_body<0, false>(b, sc, kpw, stw, scratch_w, perm);
-    } else if (b < walk_blocks + connect_blocks) {
-        connect_body<B, 0, BATCH, false>(b - walk_blocks, connect_blocks, sc, kpc, stc, energy, fixed, scratch_c,
-                                         pairs_per_wave, energy_tab, fixed_tab);
-    } else {
-        plan_body(b - walk_blocks - connect_blocks, gridDim.x - walk_blocks - connect_blocks, kpp, scratch_p, perm_p, zero_p,
-                  zero_words_p, zero_tab_p, zero_count_p);
-    }
-}
 
-// ---------------------------------------------------------------------------------------------------
-// connect_all_kernel (row f3): the reference's unfinished "naive connections" (Is_NaiveConnections,
-// ARTS.cpp:518-546: every bounce of the forward sample x every bounce of the backward sample, "Equation 12").
-// For pair p with forward nodes F0..Fk and backward nodes B0..Bm every (i, j) in [0,k] x [0,m] is a
-// candidate path F0..Fi, Bj..B0: ConnectSubpaths' visibility test Fi -> Bj, EvaluatePath over the stored
-// segment records in path order, uniform multiple-importance weight 1 / N(i + j) with N(t) = number of
-// (i', j') in [0, D]^2, i' + j' = t (D = depth cap).  One WAVE per pair, one lane per (i, j): the up to
-// (D+1)^2 visibility rays of a pair start and end at neighbouring nodes, so the wave traverses coherently.
-// ---------------------------------------------------------------------------------------------------
-// Balance-heuristic weight of strategy i (vertices y_1..y_i generated from the source, y_t..y_{i+1} from the
-// listener, t = i + j) among the strategies [max(0, t-D), min(t, D)] that give the same path — the intent of the
-// draft's MISEnergy (ARTS.cpp:571-597); build-owned definition, DESIGN.md section 8: forward density of y_{k+1}
-// given y_k  pf_k = Pf(k) |n_{k+1}.d_k| / L_k^2 with Pf(0) = 1/4pi, Pf(k) = max(0, n_k.d_k)/pi; backward density of
-// y_k given y_{k+1}  pb_k = Pb(k+1) |n_k.d_k| / L_k^2 with Pb(t+1) = 1/4pi, Pb(k) = max(0, -n_k.d_{k-1})/pi;
-// p_s = prod_{k<s} pf_k prod_{k>s} pb_k, w_i = p_i / sum_s p_s.  One pass over the t + 1 segments in double:
-// T_k = T_{k-1} pb_k + [lo <= k <= hi] PF_k ends as sum_s p_s, Q likewise as p_i; uniform weight when a segment
-// is degenerate or the ratio is not finite and positive.
-// Vertex k of the connected path: 0 = source, 1..i = forward nodes, i+1..t = backward nodes j..1, t+1 = listener.
-struct MisVertex { double x, y, z, nx, ny, nz; };
-__device__ __forceinline__ MisVertex mis_vertex(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t sf,
-                                                uint32_t sl, int i, int t, int k) {
-    MisVertex v;
-    if (k == 0) { v.x = kp.src[0]; v.y = kp.src[1]; v.z = kp.src[2]; v.nx = v.ny = v.nz = 0.0; return v; }
-    if (k == t + 1) { v.x = kp.lis[0]; v.y = kp.lis[1]; v.z = kp.lis[2]; v.nx = v.ny = v.nz = 0.0; return v; }
-    const float4 q = k <= i ? load_pos(st, total, k - 1, sf) : load_pos(st, total, t - k, sl);
-    const float4 m = k <= i ? load_nrm(st, total, k - 1, sf) : load_nrm(st, total, t - k, sl);
-    v.x = q.x; v.y = q.y; v.z = q.z; v.nx = m.x; v.ny = m.y; v.nz = m.z;
-    return v;
-}
-__device__ float mis_weight(const KParams& kp, const SubpathState& st, uint32_t total, uint32_t sf, uint32_t sl, int i,
-                            int j) {
-    const int t = i + j, D = kp.mis_depth;
-    const int lo = t - D > 0 ? t - D : 0, hi = t < D ? t : D;
-    const double uniform = 1.0 / (double)(hi - lo + 1);
-    if (t <= 0) return (float)uniform;
-    const double inv4pi = 1.0 / (4.0 * 3.14159265358979323846), invpi = 1.0 / 3.14159265358979323846;
-    double PF = 1.0, T = 0.0, Q = 0.0;
-    MisVertex a = mis_vertex(kp, st, total, sf, sl, i, t, 0);
-    for (int k = 0; k <= t; ++k) {
-        const MisVertex b = mis_vertex(kp, st, total, sf, sl, i, t, k + 1);
-        double dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
-        const double l2 = dx * dx + dy * dy + dz * dz;
-        if (!(l2 > 1e-8)) return (float)uniform;
-        const double inv = 1.0 / sqrt(l2);
-        dx *= inv; dy *= inv; dz *= inv;
-        const double ca = k > 0 ? a.nx * dx + a.ny * dy + a.nz * dz : 0.0;
-        const double cb = k < t ? b.nx * dx + b.ny * dy + b.nz * dz : 0.0;
-        if (k >= 1) {
-            const double Pb = k == t ? inv4pi : (cb < 0.0 ? -cb : 0.0) * invpi;
-            const double pb = Pb * fabs(ca) / l2;
-            T *= pb;
-            if (k > i) Q *= pb;
-        }
-        if (k >= lo && k <= hi) T += PF;
-        if (k == i) Q = PF;
-        if (k < t) {
-            const double Pf = k == 0 ? inv4pi : (ca > 0.0 ? ca : 0.0) * invpi;
-            PF *= Pf * fabs(cb) / l2;
-        }
-        a = b;
-    }
-    const double w = Q / T;
-    if (!(Q > 0.0) || !(T > 0.0) || !(w <= 1.0)) return (float)uniform;
-    return (float)w;
-}
 
-template <int B>
-__global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KParams kp, SubpathState st,
-                                                             float* __restrict__ energy,
-                                                             unsigned long long* __restrict__ fixed,
-                                                             unsigned* queue_head) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] stack | [B][hist_window] histogram
-    int* s_stack = s_dyn;
-    float* s_hist = reinterpret_cast<float*>(s_dyn + (size_t)sc.stack_rows * kBlock);
-    const int nb = kp.num_bins, W = kp.hist_window;
-    int* s_share = reinterpret_cast<int*>(s_hist + (size_t)B * W);   // work-sharing area of trav_any_shared
-    __shared__ int s_lo, s_hi;
-    for (int i = threadIdx.x; i < B * W; i += kBlock) s_hist[i] = 0.0f;
-    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; }
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
-    __syncthreads();
-
-    const uint32_t n = kp.num_local;
-    const uint32_t total = 2u * n;
-    const int lane = (int)(threadIdx.x & 63u);
-    const uint32_t wave = threadIdx.x >> 6, waves = kBlock / 64;
-    unsigned my_deposits = 0, my_tests = 0;
-    for (uint32_t li = blockIdx.x * waves + wave; li < n; li += gridDim.x * waves) {
-        const uint32_t sf = slot_of(st, li), sl = slot_of(st, n + li);
-        const uint2 Fm = st.end_misc[sf];
-        const uint2 Lm = st.end_misc[sl];
-        const int kf = (int)Fm.y, kl = (int)Lm.y;
-        const int combos = (kf + 1) * (kl + 1);
-        for (int c0 = 0; c0 < combos; c0 += 64) {   // wave-uniform trip count: all lanes share the visibility queries
-            const bool active = c0 + lane < combos;
-            const int c = active ? c0 + lane : 0;
-            if (active) ++my_tests;
-            const int i = c / (kl + 1), j = c - i * (kl + 1);
-            // node Fi (position, material, probability) and node Bj (position)
-            float fx = kp.src[0], fy = kp.src[1], fz = kp.src[2];
-            if (i > 0) { const float4 q = load_pos(st, total, i - 1, sf); fx = q.x; fy = q.y; fz = q.z; }
-            float bx = kp.lis[0], by = kp.lis[1], bz = kp.lis[2];
-            if (j > 0) { const float4 q = load_pos(st, total, j - 1, sl); bx = q.x; by = q.y; bz = q.z; }
-            uint32_t fmat; float fprob;
-            if (i < kf) { fmat = load_mat(st, total, i, sf); fprob = load_np(st, total, i, sf).y; }
-            else { fmat = Fm.x; fprob = st.end_pos[sf].w; }
-            fmat &= 0xFFFFu;   // a connection vertex scatters diffusely whatever lobe the walk took there later (row f4)
-            float dx = bx - fx, dy = by - fy, dz = bz - fz;
-            float l2 = dx * dx + dy * dy + dz * dz;
-            float len = sqrtf(l2);
-            float inv = 1.0f / len;
-            float tmax = len - kp.connect_pullback;
-            const bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
-            Ray ray = make_ray(fx, fy, fz, dx * inv, dy * inv, dz * inv);
-            const bool hit = trav_any_shared(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share);
-            if (!active || hit) continue;
-            ++my_deposits;
-            float E[B];
-#pragma unroll
-            for (int b = 0; b < B; ++b) E[b] = 1.0f;
-            float sd = 0.0f;
-            for (int a = 0; a < i; ++a) {                                 // F_a -> F_a+1
-                const float2 np = load_np(st, total, a, sf);
-                sd += np.x;
-                apply_segment<B>(E, np.x, load_mat(st, total, a, sf), np.y, kp, sc);
-            }
-            {                                                             // Fi -> Bj
-                float nd = sqrtf(l2) / kp.dist_divisor;
-                sd += nd;
-                apply_segment<B>(E, nd, fmat, fprob, kp, sc);
-            }
-            for (int a = j - 1; a >= 0; --a) {                            // B_a+1 -> B_a
-                const float2 np = load_np(st, total, a, sl);
-                sd += np.x;
-                uint32_t bmat = load_mat(st, total, a, sl);
-                if (a == j - 1) bmat &= 0xFFFFu;                          // Bj is the other connection vertex
-                apply_segment<B>(E, np.x, bmat, np.y, kp, sc);
-            }
-            const int t = i + j, D = kp.mis_depth;
-            const int lo_t = t - D > 0 ? t - D : 0, hi_t = t < D ? t : D;
-            float w = 1.0f / (float)(hi_t - lo_t + 1);
-            if (kp.mis) w = mis_weight(kp, st, total, sf, sl, i, j);
-            float delay = sd / kp.sound_speed;
-            float x = (delay * 1000.f) / 1.0f;
-            float fl = floorf(x);
-            int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
-            const bool near = bin < W;
-            if (!fixed && near) {
-                atomicMin(&s_lo, bin);
-                atomicMax(&s_hi, bin);
-            }
-#pragma unroll
-            for (int b = 0; b < B; ++b) {
-                float e = E[b];
-                e = (e < kp.energy_clamp) ? e : kp.energy_clamp;
-                e *= kp.energy_gain;
-                e *= kp.norm;
-                e *= w;
-                if (fixed)
-                    atomicAdd(&fixed[b * nb + bin], (unsigned long long)__double2ll_rn((double)e * kFixedScale));
-                else if (near)
-                    atomicAdd(&s_hist[b * W + bin], e);   // ds_add_f32.  (Summing the equal-bin deposits of a wave first —
-                else                                      // ballot per distinct bin + butterfly per band — measured slower:
-                    atomicAdd(&energy[b * nb + bin], e);  // 2.12 -> 2.47 ms at cfg3; a pair's paths rarely share a bin.)
-            }
-        }
-    }
-    {   // work counters: one atomic per wave
-        unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
-        unsigned d = my_deposits, t = my_tests;
-        for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); t += __shfl_down(t, o); }
-        if (lane == 0) {
-            if (d) atomicAdd(&counters[2], (unsigned long long)d);
-            if (t) atomicAdd(&counters[1], (unsigned long long)t);
-        }
-    }
-    __syncthreads();
-    const int lo = s_lo, hi = s_hi;
-    if (hi < lo) return;
-    const int span = hi - lo + 1;
-    for (int i = threadIdx.x; i < B * span; i += kBlock) {
-        int b = i / span, bin = lo + (i - b * span);
-        float v = s_hist[b * W + bin];
-        if (v != 0.0f) atomicAdd(&energy[b * nb + bin], v);
-    }
-}
-
-// deterministic mode: fixed-point histogram -> the fp32 energy buffer (one rounding per bin, after all sums)
-__global__ __launch_bounds__(kBlock) void fixed_to_energy_kernel(const unsigned long long* __restrict__ fixed,
-                                                                 float* __restrict__ energy, int words) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < words) energy[i] = (float)((double)fixed[i] * (1.0 / kFixedScale));
-}
-
-// ---------------------------------------------------------------------------------------------------
-// reconstruct_kernel: ReconstructImpulseResponse (FSAC.cpp:320-380)
-//   rows 0..B-1 = bands, row B = band-mean energy -> the channel view (channels are identical,
-//   FSAC.cpp:331).  The one-pole filter y[i] = 0.25 x[i] + 0.75 y[i-1] (FSAC.cpp:366-375) is evaluated
-//   per kChunk-sample chunk after a kWarm-sample warm-up: 0.75^96 ~ 1e-12 is far below fp32 resolution.
-//   The interpolated sample x[i] is produced incrementally (bin / in-bin counters), no division by spb.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kChunk = 16;
-constexpr int kWarm = 96;
-
-__global__ __launch_bounds__(kBlock) void reconstruct_kernel(const float* __restrict__ energy, int B, int nb,
-                                                             int num_samples, int spb, float* __restrict__ ir_bands,
-                                                             float* __restrict__ ir_mono) {
-    extern __shared__ __attribute__((aligned(16))) float s_amp[];  // [nb] amplitude per bin of this row
-    const int row = blockIdx.y;
-    const float Pi4 = sqrtf(4.0f * kPi);                           // FSAC.cpp:323
-    for (int i = threadIdx.x; i < nb; i += kBlock) {
-        float e;
-        if (row < B) e = energy[row * nb + i];
-        else {
-            float s = 0.f;
-            for (int b = 0; b < B; ++b) s += energy[b * nb + i];
-            e = s / (float)B;
-        }
-        float a = 0.0f;
-        if (fabsf(e) >= 1e-6f) a = e / sqrtf(e * Pi4);             // FSAC.cpp:343-345
-        s_amp[i] = a;
-    }
-    __syncthreads();
-    const int chunk = blockIdx.x * kBlock + threadIdx.x;
-    const int s0 = chunk * kChunk;
-    if (s0 >= num_samples) return;
-    float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
-    const int s1 = min(s0 + kChunk, num_samples);
-    const int i0 = max(s0 - kWarm, 0);
-    int bin = i0 / spb;
-    int bs = i0 - bin * spb;
-    float cur = bin < nb ? s_amp[bin] : 0.0f;
-    float prev = bin == 0 ? cur : (bin - 1 < nb ? s_amp[bin - 1] : 0.0f);   // FSAC.cpp:347-355
-    const float fspb = (float)spb;
-    float y = 0.0f;
-    for (int i = i0; i < s1; ++i) {
-        float x = 0.0f;
-        if (bin < nb) {
-            float wgt = (float)bs / fspb;                           // FSAC.cpp:359
-            float a = (1.0f - wgt) * prev;
-            float b = wgt * cur;
-            x = a + b;                                              // FSAC.cpp:360
-        }
-        if (i == 0) {
-            y = x;                                                  // Filtered[0] = IR[0] FSAC.cpp:371
-        } else {
-            float a = 0.25f * x;
-            float b = (1.0f - 0.25f) * y;
-            y = a + b;                                              // FSAC.cpp:374
-        }
-        if (i >= s0) out[i] = y;
-        if (++bs == spb) {
-            bs = 0;
-            ++bin;
-            prev = cur;
-            cur = bin < nb ? s_amp[bin] : 0.0f;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// trace_rays_kernel: the engine line trace (tests / tools)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, const float* __restrict__ o,
-                                                            const float* __restrict__ d,
-                                                            const float* __restrict__ tmax, int N, int any_hit,
-                                                            int32_t* hit, float* t, int32_t* tri, float* normal) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
-    int* s_stack = s_dyn;
-    int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= N) return;
-    Ray r = make_ray(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    Trav T;
-    trav_init(T, tmax[i], sc.num_nodes > 0);
-    if (any_hit) {
-        trav_run<true>(sc, r, T, &s_stack[threadIdx.x]);
-        hit[i] = T.leaf_index >= 0;
-        return;
-    }
-    trav_run<false>(sc, r, T, &s_stack[threadIdx.x]);
-    hit[i] = T.leaf_index >= 0;
-    if (T.leaf_index >= 0) {
-        float nx, ny, nz;
-        uint32_t mat;
-        hit_surface(sc, T.leaf_index, r, nx, ny, nz, mat);
-        t[i] = T.t;
-        tri[i] = (int32_t)T.id;
-        normal[3 * i] = nx; normal[3 * i + 1] = ny; normal[3 * i + 2] = nz;
-    } else {
-        t[i] = tmax[i];
-        tri[i] = -1;
-        normal[3 * i] = 0.f; normal[3 * i + 1] = 0.f; normal[3 * i + 2] = 0.f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// update_sound_shared_kernel: the legacy per-frame forward tracer (UpdateSound FrequenSeeAudioComponent.cpp:283-306,
-// CastAudioRay :132-207, CastDirectAudioRay :209-280).  Ray i < N follows specular chain i (with the
-// listener-directed transmission ray at every bounce); ray N computes OcclusionAttenuation (:295-299).
-// Build-owned engine semantics: actors = object id per triangle, the player pawn = a sphere.
-// ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kNoObject = 0xFFFFFFFFu;
-constexpr uint32_t kPawnObject = 0xFFFFFFFEu;
-
-__device__ __forceinline__ bool sphere_hit(const Ray& r, const float c[3], float rad, float tmax, float& t_out) {
-    float ox = r.ox - c[0], oy = r.oy - c[1], oz = r.oz - c[2];
-    float b = fmaf(ox, r.dx, fmaf(oy, r.dy, oz * r.dz));
-    float cc = fmaf(ox, ox, fmaf(oy, oy, oz * oz)) - rad * rad;
-    float disc = fmaf(b, b, -cc);
-    if (!(disc >= 0.0f)) return false;
-    float sq = sqrtf(disc);
-    float t = -b - sq;
-    if (!(t > 0.0f)) t = sq - b;
-    if (!(t > 0.0f && t <= tmax)) return false;
-    t_out = t;
-    return true;
-}
-
-struct LegacyHit { float t; uint32_t object; float nx, ny, nz; };
-
-// ---------------------------------------------------------------------------------------------------
-// The legacy tracer on sparse waves.  UpdateSound is 1501 rays, each a CHAIN of up to ~20 dependent closest-hit
-// queries: on one lane per ray that is 24 waves on a 1024-SIMD chip and the call takes the latency of the longest
-// chain (0.9 ms at 100 000 triangles).  update_sound_shared_kernel gives every wave only `rays_per_wave` rays and
-// lets the other lanes help: every query of the wave is searched by all 64 lanes (the wave work sharing of
-// trav_run_shared, here with the per-ray ignored actor), so a query takes about as many steps as its deepest
-// root-to-leaf descent instead of its total node count.  Each lane runs CastAudioRay / CastDirectAudioRay as a
-// small state machine (main trace | direct trace | done) so that the whole wave meets at every query.
-//   LDS behind the stack rows: ShareArea<false, true>.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void update_sound_shared_kernel(DeviceScene sc, SoundKParams sp, SoundAccum* acc,
-                                                                     int rays_per_wave) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | share area
-    int* stack = &s_dyn[threadIdx.x];
-    int* share = s_dyn + (size_t)sc.stack_rows * kBlock;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int wave = (int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
-    const int N = sp.raycasts_per_tick;
-    const int i = wave * rays_per_wave + lane;
-    const bool mine = lane < rays_per_wave && i <= N;
-    enum { MAIN = 0, DIRECT = 1, DONE = 2 };
-    int mode = DONE;
-    bool is_occl = false;
-    unsigned long long traces = 0;
-    // CastAudioRay state (FSAC.cpp:132-207)
-    float px = 0.f, py = 0.f, pz = 0.f, ddx = 0.f, ddy = 0.f, ddz = 0.f;
-    float max_distance = sp.raycast_distance;
-    int bounces = sp.raycast_bounces;
-    const float energy = 1.0f;
-    float result = 0.0f, direct_sum = 0.0f;
-    unsigned direct_hits = 0;
-    // CastDirectAudioRay state (FSAC.cpp:209-280)
-    float qx = 0.f, qy = 0.f, qz = 0.f, ex = 0.f, ey = 0.f, ez = 0.f, dmax = 0.f, denergy = 0.f;
-    int dbounces = 0;
-    uint32_t dactor = kNoObject;
-
-    if (mine && i == N) {                                                  // FSAC.cpp:295-299
-        is_occl = true;
-        float dx = sp.lis[0] - sp.src[0], dy = sp.lis[1] - sp.src[1], dz = sp.lis[2] - sp.src[2];
-        float l2 = dx * dx + dy * dy + dz * dz;
-        if (l2 > 0.0f) {
-            float inv = 1.0f / sqrtf(l2);
-            ex = dx * inv; ey = dy * inv; ez = dz * inv;
-            qx = sp.src[0]; qy = sp.src[1]; qz = sp.src[2];
-            dmax = sp.raycast_distance; dbounces = 10; denergy = 1.0f; dactor = kNoObject;
-            mode = DIRECT;
-        } else {
-            acc->occlusion = 0.0f;
-        }
-    } else if (mine) {
-        // initial direction: FMath::VRandCone((0,-1,0), PI, PI) FSAC.cpp:291 == theta = 2 pi U, phi = acos(2V-1)
-        const uint4 rnd = philox((uint32_t)i, 0u, 0u, sp.seed_lo, sp.seed_hi, 0x46533032u);
-        const float U = u01(rnd.x), V = u01(rnd.y);
-        const float x = fmaf(V, 2.0f, -1.0f);
-        const float sphi = sqrtf(fmaxf(0.0f, fmaf(-x, x, 1.0f)));
-        float st, ct;
-        sincos2pi(U, st, ct);
-        const float nx = 0.0f, ny = -1.0f, nz = 0.0f;
-        float sg = copysignf(1.0f, nz);
-        float a = -1.0f / (sg + nz);
-        float b = nx * ny * a;
-        float t0 = fmaf(sg * nx * nx, a, 1.0f), t1 = sg * b, t2 = -sg * nx;
-        float b0 = b, b1 = fmaf(ny * ny, a, sg), b2 = -ny;
-        float lx = sphi * ct, ly = sphi * st;
-        float d0 = fmaf(lx, t0, fmaf(ly, b0, x * nx));
-        float d1 = fmaf(lx, t1, fmaf(ly, b1, x * ny));
-        float d2 = fmaf(lx, t2, fmaf(ly, b2, x * nz));
-        float l2 = d0 * d0 + d1 * d1 + d2 * d2;
-        float inv = 1.0f / sqrtf(l2);
-        ddx = d0 * inv; ddy = d1 * inv; ddz = d2 * inv;
-        px = sp.src[0]; py = sp.src[1]; pz = sp.src[2];
-        mode = MAIN;
-    }
-
-    while (true) {
-        // settle everything that needs no trace: a finished direct ray returns to its caller, a walk out of bounces ends
-        for (int guard = 0; guard < 2; ++guard) {
-            if (mode == DIRECT && (dbounces == 0 || denergy <= 0.0f)) {   // FSAC.cpp:212: the direct ray died
-                if (is_occl) { acc->occlusion = 0.0f; mode = DONE; } else { mode = MAIN; }
-            }
-            if (mode == MAIN && bounces == 0) mode = DONE;                // FSAC.cpp:134
-        }
-        const bool has = mode != DONE;
-        if (__ballot(has) == 0ull) break;
-        // the next query of this lane
-        Ray r;
-        float tmax = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-        uint32_t ign = kNoObject;
-        if (mode == MAIN) {
-            float l2 = ddx * ddx + ddy * ddy + ddz * ddz;                 // GetSafeNormal FSAC.cpp:141
-            float inv = 1.0f / sqrtf(l2);
-            dx = ddx * inv; dy = ddy * inv; dz = ddz * inv;
-            r = make_ray(px, py, pz, dx, dy, dz);
-            tmax = max_distance;
-        } else {
-            dx = ex; dy = ey; dz = ez;
-            r = make_ray(fmaf(ex, 0.1f, qx), fmaf(ey, 0.1f, qy), fmaf(ez, 0.1f, qz), ex, ey, ez);   // FSAC.cpp:232
-            tmax = dmax;
-            ign = dactor;
-        }
-        Trav T;
-        trav_shared<false, true>(sc, has, r, tmax, ign, T, stack, share);
-        if (!has) continue;
-        // legacy_trace: closest of the triangles and the pawn sphere
-        ++traces;
-        LegacyHit h;
-        bool hit;
-        {
-            float ts;
-            const bool hs = sphere_hit(r, sp.lis, sp.listener_radius, tmax, ts);
-            const bool ht = T.leaf_index >= 0;
-            hit = ht || hs;
-            if (hs && (!ht || ts <= T.t)) { h.t = ts; h.object = kPawnObject; h.nx = h.ny = h.nz = 0.f; }
-            else if (ht) {
-                uint32_t mat;
-                hit_surface(sc, T.leaf_index, r, h.nx, h.ny, h.nz, mat);
-                h.t = T.t;
-                h.object = __float_as_uint(reinterpret_cast<const float4*>(sc.tris)[4 * (size_t)T.leaf_index + 2].w);
-            }
-        }
-        if (mode == MAIN) {
-            if (!hit) { mode = DONE; continue; }                          // FSAC.cpp:192-196
-            const float ipx = fmaf(h.t, dx, px), ipy = fmaf(h.t, dy, py), ipz = fmaf(h.t, dz, pz);
-            const float left = max_distance - h.t;                        // DistanceLeft FSAC.cpp:167
-            const float tx = sp.lis[0] - ipx, ty = sp.lis[1] - ipy, tz = sp.lis[2] - ipz;
-            const float dist_to_player = sqrtf(tx * tx + ty * ty + tz * tz);
-            const float travel_time = (sp.raycast_distance - left + dist_to_player) * 0.01f / 343.0f;   // :171
-            if (travel_time > sp.simulated_duration) { mode = DONE; continue; }
-            if (h.object == kPawnObject) { result = energy; mode = DONE; continue; }   // FSAC.cpp:177-181
-            // the reflection (FSAC.cpp:186-187) does not depend on the direct ray: set the next main segment up now
-            const float dn = dx * h.nx + dy * h.ny + dz * h.nz;
-            ddx = fmaf(-2.0f * dn, h.nx, dx);
-            ddy = fmaf(-2.0f * dn, h.ny, dy);
-            ddz = fmaf(-2.0f * dn, h.nz, dz);
-            px = fmaf(h.nx, 0.5f, ipx); py = fmaf(h.ny, 0.5f, ipy); pz = fmaf(h.nz, 0.5f, ipz);
-            max_distance = left;
-            bounces -= 1;
-            if (dist_to_player > 0.0f) {                                  // FSAC.cpp:184-185: one direct ray to the listener
-                const float invp = 1.0f / dist_to_player;
-                ex = tx * invp; ey = ty * invp; ez = tz * invp;
-                qx = ipx; qy = ipy; qz = ipz;
-                dmax = left; dbounces = 1; denergy = energy; dactor = kNoObject;
-                mode = DIRECT;
-            }
-        } else {                                                          // CastDirectAudioRay FSAC.cpp:209-280
-            float de = 0.0f;
-            bool finished = true;
-            if (hit) {
-                if (h.object == kPawnObject) {                            // FSAC.cpp:253-270
-                    float travel = sp.raycast_distance - dmax + h.t;
-                    travel *= 0.01f;
-                    float time = travel / 343.0f;
-                    if (!(time > sp.simulated_duration)) de = denergy * expf(-0.0017f * travel);
-                } else {                                                  // through the obstacle, FSAC.cpp:272-276
-                    qx = fmaf(h.t, ex, r.ox); qy = fmaf(h.t, ey, r.oy); qz = fmaf(h.t, ez, r.oz);
-                    dmax = dmax - h.t;
-                    dbounces -= 1;
-                    dactor = h.object;
-                    finished = false;
-                }
-            }
-            if (finished) {
-                if (is_occl) { acc->occlusion = de; mode = DONE; }
-                else { if (de > 0.0f) { ++direct_hits; direct_sum += de; } mode = MAIN; }
-            }
-        }
-    }
-    if (mine && !is_occl) {
-        if (result > 0.0f) atomicAdd(&acc->reaching, 1u);
-        if (direct_hits) { atomicAdd(&acc->direct_hits, direct_hits); atomicAdd(&acc->direct_energy_sum, direct_sum); }
-    }
-    if (traces) atomicAdd(&acc->traces, traces);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Row f2 — the reverb plugin's per-callback convolution (FFrequenSeeAudioReverbPlugin::ProcessSourceAudio,
-// FrequenSeeAudioReverbPlugin.cpp:118-170, ConvolveFFT :172-213).  The reference zero-pads the last
-// 47 999 + 1 024 samples and the 48 000-tap IR to 65 536 and multiplies three KissFFT spectra; only output
-// samples [47 999, 49 023) are kept, for which the circular product equals the plain convolution
-//   out[s] = sum_k IR[k] * u[47 999 + s - k].
-// On this chip 2 x 1024 x 48 000 MACs are a few microseconds of fp32 FMA, so the kernel evaluates that sum
-// directly (no FFT, no 65 536-point scratch, deterministic order): thread t owns a contiguous 192-tap slice
-// and slides a 31-sample register window over it (47 loads per 256 FMAs), partial sums meet in LDS.
-//   u[j] = j < tail ? ring[(head - tail + j) & mask] : cur[j - tail]
-// ---------------------------------------------------------------------------------------------------
-constexpr int kRevOut = 16;      // outputs per workgroup
-constexpr int kRevRing = 65536;  // history ring length per channel (power of two >= 47 999)
-
-__global__ void reverb_prepare_kernel(const float* __restrict__ in, float* __restrict__ cur, int frame, int literal) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= frame) return;
-    // RVB.cpp:147-148 copies the first `frame` floats of the INTERLEAVED buffer into both mono tails
-    cur[i] = literal ? in[i] : in[2 * i];
-    cur[frame + i] = literal ? in[i] : in[2 * i + 1];
-}
-
-__global__ __launch_bounds__(kBlock) void reverb_conv_kernel(const float* __restrict__ ir, int ir_size,
-                                                             const float* __restrict__ ring, unsigned head,
-                                                             const float* __restrict__ cur, int frame,
-                                                             float* __restrict__ out_interleaved) {
-    __shared__ float s_part[kRevOut][kBlock + 1];
-    const int ch = blockIdx.y;
-    const int s0 = blockIdx.x * kRevOut;
-    const int tail = ir_size - 1;
-    const float* rg = ring + (size_t)ch * kRevRing;
-    const float* cu = cur + (size_t)ch * frame;
-    const unsigned base = head - (unsigned)tail;   // ring index of u[0]
-    const int slice = ((ir_size + kBlock - 1) / kBlock + 15) & ~15;
-    const int k0 = (int)threadIdx.x * slice;
-    const int k1 = min(k0 + slice, ir_size);
-    float acc[kRevOut];
-#pragma unroll
-    for (int o = 0; o < kRevOut; ++o) acc[o] = 0.0f;
-    for (int kb = k0; kb < k1; kb += 16) {
-        float w[31], h[16];
-        const int j0 = tail + s0 - kb - 15;   // u index of w[0]
-#pragma unroll
-        for (int i = 0; i < 31; ++i) {
-            const int j = j0 + i;
-            float v = 0.0f;
-            if (j >= 0 && j < tail + frame) v = j < tail ? rg[(base + (unsigned)j) & (unsigned)(kRevRing - 1)] : cu[j - tail];
-            w[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) h[i] = (kb + i) < ir_size ? ir[kb + i] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-            for (int o = 0; o < kRevOut; ++o) acc[o] = fmaf(h[i], w[15 - i + o], acc[o]);
-    }
-#pragma unroll
-    for (int o = 0; o < kRevOut; ++o) s_part[o][threadIdx.x] = acc[o];
-    __syncthreads();
-    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride)
-#pragma unroll
-            for (int o = 0; o < kRevOut; ++o) s_part[o][threadIdx.x] += s_part[o][threadIdx.x + stride];
-        __syncthreads();
-    }
-    if (threadIdx.x < kRevOut && s0 + (int)threadIdx.x < frame) {
-        float v = s_part[threadIdx.x][0];
-        v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);                 // FMath::Clamp RVB.cpp:165-167, MixAlpha = 1
-        out_interleaved[2 * (s0 + (int)threadIdx.x) + ch] = v;
-    }
-}
-
-// AudioTailBuffer{Left,Right}.AddSamples(in, frame, ch, 2)  RVB.cpp:144-145
-__global__ void reverb_push_kernel(const float* __restrict__ in, float* __restrict__ ring, unsigned head, int frame) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= frame) return;
-    ring[(head + (unsigned)i) & (unsigned)(kRevRing - 1)] = in[2 * i];
-    ring[kRevRing + ((head + (unsigned)i) & (unsigned)(kRevRing - 1))] = in[2 * i + 1];
-}
-
-// AddEnergyAtDelay on the device-resident buffer (FSAC.h:87-91)
-__global__ void add_energy_kernel(float* row, int nb, float delay, float e) {
-    float x = (delay * 1000.f) / 1.0f;
-    float fl = floorf(x);
-    int bin = !(fl > 0.0f) ? 0 : (fl >= (float)(nb - 1) ? nb - 1 : (int)fl);
-    row[bin] += e;
-}
 
 // dynamic LDS of a traversal kernel: the scene's stack rows (+ extra bytes behind them).  Sizes above the default
 // 48 KB limit are announced to the runtime once per (kernel instantiation, device); the host side has already
@@ -1981,254 +1306,5 @@ inline void allow_lds(K kernel, size_t bytes) {
         allowed[dev].store(bytes, std::memory_order_relaxed);
 }
 
-template <int B>
-void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                      unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, float* const* energy_tab,
-                      unsigned long long* const* fixed_tab, hipStream_t s) {
-    if (kp.num_local == 0) return;
-    if (pairs_per_wave < 1 || pairs_per_wave > 64) pairs_per_wave = 64;
-    const uint32_t per_block = (uint32_t)pairs_per_wave * (kBlock / 64);
-    const bool batch = energy_tab != nullptr;
-    uint32_t blocks = batch ? (kp.num_local / kp.pairs_per_source) * ((kp.pairs_per_source + per_block - 1) / per_block)
-                            : (kp.num_local + per_block - 1) / per_block;
-    if (blocks > 1024) blocks = 1024;
-    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.hist_window + kShareAnyLdsBytes;
-#define FS_LAUNCH_CONNECT(L, BT, CN)                                                                                 \
-    do {                                                                                                             \
-        allow_lds(connect_kernel<B, L, BT, CN>, lds);                                                                \
-        hipLaunchKernelGGL((connect_kernel<B, L, BT, CN>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy,   \
-                           fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);                                \
-    } while (0)
-    // record-fetch counting (fs_set_profiling level 3) exists for the default frame shape only
-    if (batch) { if (kp.lobes) FS_LAUNCH_CONNECT(1, true, false); else FS_LAUNCH_CONNECT(0, true, false); }
-    else if (kp.lobes) FS_LAUNCH_CONNECT(1, false, false);
-    else if (kp.count) FS_LAUNCH_CONNECT(0, false, true);
-    else FS_LAUNCH_CONNECT(0, false, false);
-#undef FS_LAUNCH_CONNECT
-}
-
 }  // namespace
-
-const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
-                            float* const* energy_tab, int energy_count, hipStream_t s) {
-    // Without roulette every walk takes kp.depth segments: nothing to sort, and the caller counts the segments on
-    // the host.  With roulette the pass always runs — it is also what counts the frame's walk segments — but it
-    // only produces the length-sorted schedule when that is enabled and can matter.
-    uint32_t full = 0;
-    bool sort = false;
-    if (!plan_shape(kp, wl, &full, &sort)) return nullptr;
-    hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, sort ? wl.perm : nullptr, energy,
-                       energy_words, energy_tab, energy_count);
-    return sort ? wl.perm : nullptr;
-}
-
-namespace {
-template <int B, bool BATCH>
-void launch_frame_tb(const DeviceScene& sc, uint32_t wb, uint32_t cb, uint32_t pb, size_t lds, const FrameParts& f, int rpw,
-                     bool sort, hipStream_t s) {
-    allow_lds(frame_kernel<B, BATCH>, lds);
-    hipLaunchKernelGGL((frame_kernel<B, BATCH>), dim3(wb + cb + pb), dim3(kBlock), lds, s, sc, wb, cb, f.kpw, f.stw,
-                       f.wl.queue_head, f.perm, rpw, f.kpc, f.stc, f.energy, f.fixed, f.scratch_c, f.ppw, f.energy_tab,
-                       f.fixed_tab, f.kpp, f.scratch_p, sort ? f.perm_p : nullptr, f.zero_p, f.zero_words_p, f.zero_tab_p,
-                       f.zero_count_p);
-}
-template <int B>
-void launch_frame_t(const DeviceScene& sc, uint32_t wb, uint32_t cb, uint32_t pb, size_t lds, const FrameParts& f, int rpw,
-                    bool sort, hipStream_t s) {
-    if (f.has_connect && f.energy_tab) launch_frame_tb<B, true>(sc, wb, cb, pb, lds, f, rpw, sort, s);
-    else launch_frame_tb<B, false>(sc, wb, cb, pb, lds, f, rpw, sort, s);
-}
-}  // namespace
-
-bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort) {
-    const uint32_t lanes = 2u * kp.num_local;
-    if (lanes == 0 || !kp.russian_roulette) return false;
-    if (blocks) *blocks = (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
-    if (sort) *sort = wl.plan && kp.depth > 1 && wl.perm;
-    return true;
-}
-
-bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s) {
-    if (!FS_SHARED_WALK(f.wl)) return false;
-    uint32_t wb = 0, cb = 0, pb = 0;
-    int rpw = 64;
-    bool sort = false;
-    size_t lds = 0;
-    if (f.has_walk) {
-        if (f.kpw.lobes || f.kpw.count || f.kpw.num_local == 0) return false;   // the default instantiations only
-        rpw = f.wl.rays_per_wave > 0 && f.wl.rays_per_wave < 64 ? f.wl.rays_per_wave : 64;
-        const uint32_t waves = (2u * f.kpw.num_local + (uint32_t)rpw - 1) / (uint32_t)rpw;
-        wb = (waves + kBlock / 64 - 1) / (kBlock / 64);
-        lds = std::max(lds, stack_bytes(sc) + kShareLdsBytes);
-    }
-    if (f.has_connect) {
-        if (f.kpc.lobes || f.kpc.count || f.kpc.num_local == 0 || f.ppw < 1 || f.ppw > 64) return false;
-        const uint32_t per_block = (uint32_t)f.ppw * (kBlock / 64);
-        const uint32_t want = f.energy_tab ? (f.kpc.num_local / f.kpc.pairs_per_source) * ((f.kpc.pairs_per_source + per_block - 1) / per_block)
-                                           : (f.kpc.num_local + per_block - 1) / per_block;
-        cb = std::min<uint32_t>(want, 1024u);
-        lds = std::max(lds, stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)f.kpc.hist_window + kShareAnyLdsBytes);
-    }
-    if (f.has_plan) {
-        if (!plan_shape(f.kpp, f.wl, &pb, nullptr)) return false;
-        sort = f.perm_p != nullptr;
-    }
-    if (wb + cb + pb == 0) return false;
-    switch (B) {
-#define FS_CASE(N) case N: launch_frame_t<N>(sc, wb, cb, pb, lds, f, rpw, sort, s); break;
-        FS_CASE(1) FS_CASE(2) FS_CASE(3) FS_CASE(4) FS_CASE(5) FS_CASE(6) FS_CASE(7)
-        default: launch_frame_t<8>(sc, wb, cb, pb, lds, f, rpw, sort, s); break;
-#undef FS_CASE
-    }
-    return true;
-}
-
-void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s) {
-    uint32_t lanes = 2u * kp.num_local;
-    if (lanes == 0) return;
-    uint32_t full = (lanes + kBlock - 1) / kBlock;
-    const bool shared = FS_SHARED_WALK(wl);
-    // record-fetch counting (fs_set_profiling level 3) exists for the default walk only (no lobes)
-#define FS_LAUNCH_WALK(K, GRID, ...)                                                                        \
-    do {                                                                                                    \
-        if (kp.lobes) { allow_lds(K<1, false>, lds); hipLaunchKernelGGL((K<1, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }        \
-        else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
-        else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \
-    } while (0)
-    if (shared && wl.rays_per_wave > 0 && wl.rays_per_wave < 64) {   // small frame: sparse waves, idle lanes help
-        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
-        const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
-        const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
-        FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave);
-        return;
-    }
-    if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
-        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
-        FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm);
-        return;
-    }
-#undef FS_LAUNCH_WALK
-#ifdef FS_EXPERIMENTS
-    if (kp.lobes) {
-        allow_lds(walk_kernel_simple<1>, stack_bytes(sc));
-        hipLaunchKernelGGL(walk_kernel_simple<1>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
-    } else {
-        allow_lds(walk_kernel_simple<0>, stack_bytes(sc));
-        hipLaunchKernelGGL(walk_kernel_simple<0>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
-    }
-#endif
-}
-
-template <int B>
-void launch_connect_all_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                          unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
-    if (kp.num_local == 0) return;
-    uint32_t blocks = (kp.num_local + 3) / 4;   // one wave per pair, 4 waves per workgroup
-    if (blocks > 4096) blocks = 4096;
-    size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)B * (size_t)kp.hist_window + kShareAnyLdsBytes;
-    allow_lds(connect_all_kernel<B>, lds);
-    hipLaunchKernelGGL(connect_all_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);
-}
-
-void launch_connect_all(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                        unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
-    switch (B) {
-        case 1: launch_connect_all_t<1>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 2: launch_connect_all_t<2>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 3: launch_connect_all_t<3>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 4: launch_connect_all_t<4>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 5: launch_connect_all_t<5>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 6: launch_connect_all_t<6>(sc, kp, st, energy, fixed, queue_head, s); break;
-        case 7: launch_connect_all_t<7>(sc, kp, st, energy, fixed, queue_head, s); break;
-        default: launch_connect_all_t<8>(sc, kp, st, energy, fixed, queue_head, s); break;
-    }
-}
-
-void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int words, hipStream_t s) {
-    if (words <= 0) return;
-    hipLaunchKernelGGL(fixed_to_energy_kernel, dim3((unsigned)((words + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, fixed,
-                       energy, words);
-}
-
-void launch_connect(int B, const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
-                    unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, float* const* energy_tab,
-                    unsigned long long* const* fixed_tab, hipStream_t s) {
-    switch (B) {
-        case 1: launch_connect_t<1>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-        case 2: launch_connect_t<2>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-        case 3: launch_connect_t<3>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-        case 4: launch_connect_t<4>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-        case 5: launch_connect_t<5>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-        case 6: launch_connect_t<6>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-        case 7: launch_connect_t<7>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-        default: launch_connect_t<8>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s); break;
-    }
-}
-
-void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,
-                        float* ir_bands, float* ir_mono, hipStream_t s) {
-    (void)sample_rate;
-    int chunks = (num_samples + kChunk - 1) / kChunk;
-    dim3 grid((chunks + kBlock - 1) / kBlock, B + 1);
-    hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(kBlock), sizeof(float) * (size_t)num_bins, s, energy, B,
-                       num_bins, num_samples, spb, ir_bands, ir_mono);
-}
-
-void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
-                       int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s) {
-    if (N <= 0) return;
-    allow_lds(trace_rays_kernel, stack_bytes(sc));
-    hipLaunchKernelGGL(trace_rays_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(sc), s, sc, o, d, tmax, N,
-                       any_hit, hit, t, tri, normal);
-}
-
-void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, int rays_per_wave, hipStream_t s) {
-    int lanes = sp.raycasts_per_tick + 1;
-    if (rays_per_wave > 64 || rays_per_wave <= 0) rays_per_wave = 64;   // 64 = one ray per lane (finished lanes still help)
-    const int waves = (lanes + rays_per_wave - 1) / rays_per_wave;
-    const size_t lds = stack_bytes(sc) + kShareIgnLdsBytes;
-    allow_lds(update_sound_shared_kernel, lds);
-    hipLaunchKernelGGL(update_sound_shared_kernel, dim3((waves + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), lds, s, sc, sp,
-                       acc, rays_per_wave);
-}
-
-void launch_reverb(const float* ir, int ir_size, float* ring, unsigned head, const float* in, float* cur, float* out,
-                   int frame, int literal_tail, hipStream_t s) {
-    const int tb = 256;
-    hipLaunchKernelGGL(reverb_prepare_kernel, dim3((frame + tb - 1) / tb), dim3(tb), 0, s, in, cur, frame, literal_tail);
-    hipLaunchKernelGGL(reverb_conv_kernel, dim3((frame + kRevOut - 1) / kRevOut, 2), dim3(kBlock), 0, s, ir, ir_size,
-                       ring, head, cur, frame, out);
-    hipLaunchKernelGGL(reverb_push_kernel, dim3((frame + tb - 1) / tb), dim3(tb), 0, s, in, ring, head, frame);
-}
-
-#ifdef FS_WAVE_TIMELINE
-extern "C" void fs_debug_wave_buffer(unsigned long long* device_ptr) {
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_buf), &device_ptr, sizeof(device_ptr));
-}
-extern "C" void fs_debug_connect_buffer(unsigned long long* device_ptr) {
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conn_buf), &device_ptr, sizeof(device_ptr));
-}
-#endif
-#ifdef FS_TRAV_STATS
-extern "C" void fs_debug_trav_stats(unsigned long long* out, int reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 32);
-    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof(z)); }
-}
-extern "C" void fs_debug_step_buffer(unsigned short* device_ptr) {
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_step_buf), &device_ptr, sizeof(device_ptr));
-}
-#endif
-
-size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins) {
-    const size_t stack = sizeof(int) * (size_t)stack_rows * (size_t)kBlock;
-    const size_t walk = stack + std::max(kShareLdsBytes, kShareIgnLdsBytes);
-    const size_t connect = stack + sizeof(float) * (size_t)bands * (size_t)std::min(num_bins, kHistWindow) + kShareAnyLdsBytes;
-    return std::max(walk, connect) + 1024;   // + the kernels' small static arrays
-}
-
-void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s) {
-    hipLaunchKernelGGL(add_energy_kernel, dim3(1), dim3(1), 0, s, energy_row, num_bins, delay_s, e);
-}
-
 }  // namespace fs

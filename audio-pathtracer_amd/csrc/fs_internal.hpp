@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -94,6 +95,7 @@ struct KParams {
     float src[3], lis[3];
     int32_t count;         // 1 = COUNT instantiations: the kernels also count the records they fetch (fs_set_profiling level 3)
     int32_t num_bins;
+    int32_t num_bands;     // bands of the context (the connect kernels are instantiated for 1, 4 and 8; any other count reads this)
     int32_t hist_window;   // the connect kernels privatise bins [0, hist_window) of every band in LDS; deposits beyond go
                            // straight to the energy buffer with global atomics (kHistWindow, or all bins if fewer)
 };
@@ -149,7 +151,10 @@ struct HostBVH {
     float pad = 0.01f;
 };
 // xyz [T][3][3], mat [T]; binned SAH BVH2 collapsed to a quantised 4-wide tree, <= 2 triangles per leaf.
-void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out);
+// cancel (optional): polled by the builder; once set it stops splitting and leaves `out` empty (background builds of
+// fs_scene_commit_progressive that a newer registration made useless)
+void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id, int32_t T, HostBVH& out,
+               const std::atomic<bool>* cancel = nullptr);
 
 // ---- kernel launchers (fs_kernels.hip) -----------------------------------------------------------------
 struct WalkLaunch {

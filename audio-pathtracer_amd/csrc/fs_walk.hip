@@ -1,0 +1,131 @@
+// fs_walk.hip — plan pass and walk kernels (GeneratePath, AudioRayTracingSubsystem.cpp:279-355) + their launchers.
+//   plan_kernel        the length of a subpath under Russian roulette depends only on the RNG stream: bucket the
+//                      subpaths by length before tracing, so that every walk wave holds equal-length walks;
+//                      also FlushEnergyBuffer (:157-161).
+//   walk_kernel_*      _shared: one subpath per lane, length-sorted schedule, closest-hit queries shared within the wave
+//                      (default);  _sparse: the same on waves that own only a few subpaths (small frames).
+#include "fs_device.hpp"
+
+namespace fs {
+namespace {
+
+__global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __restrict__ scratch,
+                                                      uint32_t* __restrict__ perm, float* __restrict__ energy,
+                                                      int energy_words, float* const* __restrict__ energy_tab,
+                                                      int energy_count) {
+    plan_body(blockIdx.x, gridDim.x, kp, scratch, perm, energy, energy_words, energy_tab, energy_count);
+}
+
+#ifdef FS_EXPERIMENTS   // diagnostic builds only (-DFS_TRAV_STATS, tests/trav_stats.py): no work sharing, per-lane step counts
+// ---------------------------------------------------------------------------------------------------
+// walk_kernel_simple: one subpath per lane (reference variant)
+// ---------------------------------------------------------------------------------------------------
+template <int LOBES>
+__global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
+                                                             const uint32_t* __restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock]
+    int* s_stack = s_dyn;
+    __shared__ unsigned s_cnt[kPlanBuckets];
+    if (perm) {   // wave-uniform: bucket counts of the plan pass
+        for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
+        __syncthreads();
+    }
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= 2u * kp.num_local) return;
+    // length-sorted schedule (plan pass) or identity
+    const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
+    int* stack = &s_stack[threadIdx.x];
+    Walker w;
+    walker_start(w, g, slot, kp, st);
+    Ray ray;
+    while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
+        Trav T;
+        trav_init(T, kp.max_trace_dist, sc.num_nodes > 0);
+#ifdef FS_TRAV_STATS
+        const unsigned steps = (unsigned)trav_run<false>(sc, ray, T, stack);
+        if (g_step_buf) g_step_buf[(size_t)w.k * (2u * (size_t)kp.num_local) + w.g] = (unsigned short)steps;
+#else
+        trav_run<false>(sc, ray, T, stack);
+#endif
+        walker_apply_hit(w, kp, sc, st, ray, T);
+    }
+    walker_finish(w, st);
+}
+#endif
+
+template <int LOBES, bool COUNT>
+__global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
+                                                             const uint32_t* __restrict__ perm) {
+    walk_shared_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm);
+}
+
+template <int LOBES, bool COUNT>
+__global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
+                                                             const unsigned* __restrict__ scratch,
+                                                             const uint32_t* __restrict__ perm, int rays_per_wave) {
+    walk_sparse_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave);
+}
+
+}  // namespace
+
+const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
+                            float* const* energy_tab, int energy_count, hipStream_t s) {
+    // Without roulette every walk takes kp.depth segments: nothing to sort, and the caller counts the segments on
+    // the host.  With roulette the pass always runs — it is also what counts the frame's walk segments — but it
+    // only produces the length-sorted schedule when that is enabled and can matter.
+    uint32_t full = 0;
+    bool sort = false;
+    if (!plan_shape(kp, wl, &full, &sort)) return nullptr;
+    hipLaunchKernelGGL(plan_kernel, dim3(full), dim3(kBlock), 0, s, kp, wl.queue_head, sort ? wl.perm : nullptr, energy,
+                       energy_words, energy_tab, energy_count);
+    return sort ? wl.perm : nullptr;
+}
+
+bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort) {
+    const uint32_t lanes = 2u * kp.num_local;
+    if (lanes == 0 || !kp.russian_roulette) return false;
+    if (blocks) *blocks = (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
+    if (sort) *sort = wl.plan && kp.depth > 1 && wl.perm;
+    return true;
+}
+
+void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
+                 const uint32_t* perm, hipStream_t s) {
+    uint32_t lanes = 2u * kp.num_local;
+    if (lanes == 0) return;
+    uint32_t full = (lanes + kBlock - 1) / kBlock;
+    const bool shared = FS_SHARED_WALK(wl);
+    // record-fetch counting (fs_set_profiling level 3) exists for the default walk only (no lobes)
+#define FS_LAUNCH_WALK(K, GRID, ...)                                                                        \
+    do {                                                                                                    \
+        if (kp.lobes) { allow_lds(K<1, false>, lds); hipLaunchKernelGGL((K<1, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }        \
+        else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
+        else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \
+    } while (0)
+    if (shared && wl.rays_per_wave > 0 && wl.rays_per_wave < 64) {   // small frame: sparse waves, idle lanes help
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
+        const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
+        const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
+        FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave);
+        return;
+    }
+    if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
+        FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm);
+        return;
+    }
+#undef FS_LAUNCH_WALK
+#ifdef FS_EXPERIMENTS
+    if (kp.lobes) {
+        allow_lds(walk_kernel_simple<1>, stack_bytes(sc));
+        hipLaunchKernelGGL(walk_kernel_simple<1>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
+    } else {
+        allow_lds(walk_kernel_simple<0>, stack_bytes(sc));
+        hipLaunchKernelGGL(walk_kernel_simple<0>, dim3(full), dim3(kBlock), stack_bytes(sc), s, sc, kp, st, wl.queue_head, perm);
+    }
+#endif
+}
+
+}  // namespace fs

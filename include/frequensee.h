@@ -31,8 +31,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(FS_BUILDING_LIBRARY) && defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header is exported */
+#endif
 
-#define FS_ABI_VERSION 3
+#define FS_ABI_VERSION 4
 #define FS_MAX_BANDS 8
 #define FS_NO_MATERIAL 0xFFFFu /* actor without UAcousticGeometryComponent / Material (ARTS.cpp:383) */
 #define FS_MAX_DEPTH 64        /* largest explicit depth cap.  depth == 0 means NO cap, like the reference's while (true)
@@ -165,6 +168,12 @@ int fs_abi_version(void);
 int fs_context_create(const fs_config* cfg, fs_context** out);
 int fs_context_destroy(fs_context* ctx);
 const char* fs_last_error(const fs_context* ctx); /* replaces UE_LOG warnings; "" if none */
+/* Advice of fs_context_create to the host, "" if none — never an error.  Today: GPU_MAX_HW_QUEUES.  The context overlaps
+ * the tail of a frame (all-reduce, reconstruct, publish) with the next frame's tracing on two HIP streams; the HIP
+ * runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the runtime initialises.  With
+ * other streams in the process the two can share a queue and serialise: export GPU_MAX_HW_QUEUES=16 before the
+ * process touches HIP.  The library does not set it for the host. */
+const char* fs_context_advice(const fs_context* ctx);
 
 /* ---- scene: RegisterGeometry/UnregisterGeometry (ARTS.h:99-100) + UAcousticMaterial (MAT.h:22-33) -- */
 /* xyz: [T][3][3] vertices, mat_id: [T] index into the material table or FS_NO_MATERIAL. Caller keeps ownership. */
@@ -403,6 +412,9 @@ int fs_set_profiling_interval(fs_context* ctx, int32_t frames);
 int fs_get_stats(fs_context* ctx, fs_stats* out);
 int fs_reset_stats(fs_context* ctx);
 
+#if defined(FS_BUILDING_LIBRARY) && defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

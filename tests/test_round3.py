@@ -1,0 +1,97 @@
+"""Round 3: regression tests for the advisor's findings (held batched frames across a table growth, overflowed walks in
+the connect pass, the roulette bound of uncapped walks, collective-consistent retries) and the round's new entry points."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import IR_TOL, TIGHT_TOL, check_energy, make_ctx, rel_rms  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+DET = 8   # FS_FLAG_DETERMINISTIC
+
+
+def test_context_advice_reports_the_hardware_queue_setting(pkg, scene_factory):
+    """fs_context_advice: the library no longer sets GPU_MAX_HW_QUEUES behind the host's back (a load-time setenv is too
+    late in a process that already uses HIP); it reports what it found.  The Python binding — the host here — exports 16
+    before the runtime starts, so a context created through it has nothing to say."""
+    assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
+    ctx = pkg.Context(num_bands=1)
+    assert ctx.advice() == ""
+    ctx.close()
+
+
+def test_batch_table_growth_lets_held_frames_finish_first(pkg, scene_factory):
+    """Pipelining on, a batch of 8 sources is held back, then a batch of 12 sources with FEWER rays each arrives: the
+    per-frame pointer tables must grow (the subpath state does not), and the held frame still reads the old block.  The
+    results equal those of an unpipelined context bit for bit (deterministic mode)."""
+    sc = scene_factory("starter_room", 4)
+    rng = np.random.default_rng(5)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    pos = [(sc.source + rng.uniform(-0.08, 0.08, 3) * (hi - lo)).astype(np.float32) for _ in range(12)]
+    out = {}
+    for mode in ("plain", "pipelined"):
+        ctx, _ = make_ctx(pkg, sc)
+        if mode == "pipelined":
+            ctx.set_pipelining(2)
+        srcs = [ctx.create_source(p) for p in pos]
+        p8 = pkg.default_params(num_rays=8192, depth=8, seed=11, flags=DET)
+        p12 = pkg.default_params(num_rays=2048, depth=8, seed=12, flags=DET)
+        ctx.compute_energy_response_batch_async(srcs[:8], p8)      # held (pipelined): tables sized for 8 sources
+        ctx.compute_energy_response_batch_async(srcs[:8], p8)      # a second held frame
+        ctx.compute_energy_response_batch_async(srcs, p12)         # 12 sources: the table block must grow
+        ctx.synchronize()
+        out[mode] = [ctx.energy_buffer(s).copy() for s in srcs]
+        ctx.close()
+    for a, b in zip(out["plain"], out["pipelined"]):
+        assert a.any() and np.array_equal(a, b)
+
+
+def test_uncapped_walks_bound_the_roulette(pkg, oracle_mod, scene_factory):
+    """depth = 0 (the reference's while (true), ARTS.cpp:294) walks until the roulette ends the walk; the record store
+    covers 512 steps, which a survival probability above 0.95 would leave too often: refused with a message.  At the
+    bound itself the second record tier is sized from rr^64 and the frame equals the oracle's."""
+    sc = scene_factory("starter_room", 2)
+    ctx, src = make_ctx(pkg, sc)
+    with pytest.raises(pkg.FrequenSeeError) as ei:
+        ctx.compute_energy_response(src, pkg.default_params(num_rays=1024, depth=0, rr_prob=0.97))
+    assert ei.value.code == pkg._capi.ERR_INVALID_ARGUMENT and "0.95" in str(ei.value)
+    ctx.compute_energy_response(src, pkg.default_params(num_rays=1024, depth=32, rr_prob=0.97))   # capped: fine
+    rays = 8192
+    ctx.reset_stats()
+    e = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=0, rr_prob=0.95, seed=4))
+    st = ctx.stats()
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=0, rr_prob=0.95, seed=4),
+                                       sc.source, sc.listener)
+    check_energy(e, e32, e64, 2)
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+    assert cnt.closest_rays > 18.0 * rays            # mean walk length 19
+    ctx.close()
+
+
+def test_overflowed_walks_are_not_connected(pkg, oracle_mod, scene_factory, monkeypatch):
+    """A walk whose record misses both tiers raises the overflow word and keeps walking; the connect pass must not read
+    records that were never written (out of bounds with a one-slot tier).  The async entry point reports the overflow, and
+    the energy it leaves holds no contribution of such a pair: every occupied bin is one the oracle occupies too."""
+    sc = scene_factory("starter_room", 4)
+    monkeypatch.setenv("FS_OVER_CAP", "1")
+    ctx, src = make_ctx(pkg, sc)
+    p = pkg.default_params(num_rays=65536, depth=0, seed=9)
+    for flags in (0, 16):
+        q = pkg.default_params(num_rays=65536 if not flags else 1024, depth=0, seed=9, flags=flags)
+        ctx.compute_energy_response_async(src, q)
+        try:
+            ctx.synchronize()
+            overflowed = False
+        except pkg.FrequenSeeError as e:
+            overflowed = e.code == pkg._capi.ERR_OVERFLOW
+        if not flags:
+            assert overflowed
+            partial = ctx.energy_buffer(src)
+            osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+            e32, e64, _ = osc.compute_energy_mt(oracle_mod.default_params(num_pairs=32768, depth=0, seed=9), sc.source, sc.listener, 8)
+            assert not np.any((partial != 0) & (e64 == 0))
+    e = ctx.compute_energy_response(src, p)       # the synchronous entry point traces again with a grown tier
+    assert e.any()
+    ctx.close()

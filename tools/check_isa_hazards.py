@@ -8,7 +8,7 @@ between, the kernel reads stale data (round 3: a build whose closest-hit loop co
 right behind the request returned wrong hits and faulted).  This script proves, per kernel, on the control-flow graph
 of the final ISA, that no instruction reads or writes a VGPR that an inline-asm load may still be writing.
 
-    python tools/check_isa_hazards.py audio-pathtracer_amd/csrc/fs_kernels.s        (exit code 1 on a hazard)
+    python tools/check_isa_hazards.py audio-pathtracer_amd/csrc/build/*gfx950.s     (exit code 1 on a hazard; run by the Makefile)
 
 Rules: a register range becomes IN FLIGHT at an asm `global_load_*` (between ;;#ASMSTART / ;;#ASMEND); every
 `s_waitcnt vmcnt(0)` (ours or the compiler's) lands everything; a later asm load to the same registers is allowed
@@ -117,32 +117,33 @@ def check_function(name: str, lines: list[str]) -> list[str]:
 
 
 def main() -> int:
-    path = sys.argv[1] if len(sys.argv) > 1 else "audio-pathtracer_amd/csrc/fs_kernels.s"
-    funcs: dict[str, list] = {}
-    cur = None
-    with open(path) as f:
-        for no, raw in enumerate(f, 1):
-            m = FUNC.match(raw)
-            if m:
-                cur = m.group(1)
-                funcs[cur] = []
-                continue
-            if cur is None:
-                continue
-            if raw.startswith(".Lfunc_end"):
-                cur = None
-                continue
-            funcs[cur].append((no, raw.rstrip("\n")))
+    paths = sys.argv[1:] or ["audio-pathtracer_amd/csrc/fs_kernels.s"]
     problems: list[str] = []
     checked = 0
-    for name, lines in funcs.items():
-        if not any("global_load" in t and True for _, t in lines):
-            continue
-        checked += 1
-        problems += check_function(name, lines)
+    for path in paths:
+        funcs: dict[str, list] = {}
+        cur = None
+        with open(path) as f:
+            for no, raw in enumerate(f, 1):
+                m = FUNC.match(raw)
+                if m:
+                    cur = m.group(1)
+                    funcs[cur] = []
+                    continue
+                if cur is None:
+                    continue
+                if raw.startswith(".Lfunc_end"):
+                    cur = None
+                    continue
+                funcs[cur].append((no, raw.rstrip("\n")))
+        for name, lines in funcs.items():
+            if not any("global_load" in t for _, t in lines):
+                continue
+            checked += 1
+            problems += [f"{path}: {p}" for p in check_function(name, lines)]
     for p in problems[:40]:
         print("HAZARD", p)
-    print(f"check_isa_hazards: {checked} kernels with loads checked, {len(problems)} hazards")
+    print(f"check_isa_hazards: {checked} kernels with loads checked in {len(paths)} file(s), {len(problems)} hazards")
     return 1 if problems else 0
 
 
