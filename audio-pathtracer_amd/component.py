@@ -110,6 +110,11 @@ class Context:
         is held back as well — one launch plans frame f, walks f - 1 and connects f - 2 (include/frequensee.h)"""
         self.check(self.lib.fs_set_pipelining(self.h, int(depth)))
 
+    def set_walk_stages(self, bounds):
+        """fs_set_walk_stages: the steps at which a pipelined depth = 0 walk moves on to the next launch ([] = such frames are not held)"""
+        arr = np.asarray(list(bounds), dtype=np.int32)
+        self.check(self.lib.fs_set_walk_stages(self.h, arr.ctypes.data_as(C.c_void_p) if arr.size else None, int(arr.size)))
+
     def submit(self):
         self.check(self.lib.fs_submit(self.h))
 

@@ -78,9 +78,9 @@ void free_state(fs_context* ctx) {
     if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
     ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
     if (ctx->st.slot_of) (void)hipFree(ctx->st.slot_of);
-    for (void* q : {(void*)ctx->d_over_np, (void*)ctx->d_over_mat, (void*)ctx->d_over_pos, (void*)ctx->d_overflow})
+    for (void* q : {(void*)ctx->d_over_np, (void*)ctx->d_over_mat, (void*)ctx->d_over_pos, (void*)ctx->d_overflow, (void*)ctx->d_cont})
         if (q) (void)hipFree(q);
-    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->d_overflow = nullptr;
+    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->d_overflow = nullptr; ctx->d_cont = nullptr;
     ctx->over_cap = ctx->over_cap_pos = 0;
     if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
     ctx->walk.perm = nullptr;
@@ -153,75 +153,94 @@ void poll_published(Source* s) {
     s->front.store(f, std::memory_order_release);
 }
 
-// levels = walk steps with a record in the main tier (min(depth, FS_MAX_DEPTH)); unbounded: also the second tier
-int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals) {
+// levels = walk steps with a record in the main tier (min(depth, FS_MAX_DEPTH)); unbounded: also the second tier.
+// sets = copies of the per-frame arrays (frames in flight + 1, fs_context::state_sets); staged: with continuation records.
+// Anything that must grow is reallocated at the new size — behind the held frames, which still use the old arrays.
+int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals,
+                 int sets, bool staged) {
     size_t lanes = 2 * (size_t)n_local;
     size_t seg = (size_t)levels * lanes;
+    sets = std::max(sets, ctx->state_sets);          // never shrinks: a later frame of the old shape finds its sets
+    staged = staged || ctx->state_cont;
     const size_t want = want_positions ? seg * (want_normals ? 2 : 1) : 0;   // positions, then normals
-    if (want > ctx->cap_pos) {
+    const double tail = std::pow(std::min(std::max(rr_prob, 0.0), 1.0), (double)FS_MAX_DEPTH);
+    // the schedule puts the longest walks first: slots below rr^64 * lanes (x4 for the spread, + 64) own a second tier
+    // (rr = 0.9, the reference's roulette: 1.2e-3 of the walks; check_params bounds rr for uncapped walks)
+    uint32_t want_cap = ctx->over_cap;
+    if (unbounded) {
+        want_cap = std::max(ctx->over_cap, (uint32_t)std::min<size_t>(lanes, (size_t)(4.0 * tail * (double)lanes) + 64));
+        if (const char* v = std::getenv("FS_OVER_CAP")) want_cap = std::max(ctx->over_cap, (uint32_t)std::max(1, std::atoi(v)));   // tests: force the regrow path
+    }
+    const bool new_sets = sets != ctx->state_sets || staged != ctx->state_cont;
+    const bool grow_lanes = lanes > ctx->cap_lanes || new_sets;
+    const bool grow_seg = seg > ctx->cap_seg || grow_lanes;
+    const bool grow_over = unbounded && (want_cap > ctx->over_cap || !ctx->d_over_np || new_sets);
+    const bool grow_over_pos = unbounded && want_positions && (want_cap > ctx->over_cap_pos || !ctx->d_over_pos);
+    const bool grow_pos = want > ctx->cap_pos;
+    if (grow_lanes || grow_seg || grow_over || grow_over_pos || grow_pos) {
+        FS_FLUSH(ctx);                                   // held frames still read the arrays that are about to go
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (grow_pos) {
         if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
         ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_seg_pos, sizeof(float4) * std::max<size_t>(want, 1)));
         ctx->cap_pos = want;
     }
-    if (lanes > ctx->cap_lanes) {
+    if (grow_lanes) {
+        lanes = std::max(lanes, ctx->cap_lanes);
         if (ctx->st.end_pos) (void)hipFree(ctx->st.end_pos);
         if (ctx->st.end_misc) (void)hipFree(ctx->st.end_misc);
         if (ctx->st.slot_of) (void)hipFree(ctx->st.slot_of);
         if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
-        ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr; ctx->st.slot_of = nullptr;
+        if (ctx->d_cont) (void)hipFree(ctx->d_cont);
+        ctx->st.end_pos = nullptr; ctx->st.end_misc = nullptr; ctx->st.slot_of = nullptr; ctx->d_cont = nullptr;
         ctx->walk.perm = nullptr;
         ctx->cap_lanes = 0;
-        // two sets of everything a frame's walk hands to its connect pass: pipelined frames overlap walk f + 1 with connect f
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * 2 * lanes));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * 2 * lanes));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.slot_of, sizeof(uint32_t) * 2 * lanes));
+        // `sets` sets of everything a frame's walk hands to its connect pass: pipelined frames overlap the walks of the
+        // frames behind with the connect pass of the oldest
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_pos, sizeof(float4) * (size_t)sets * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.end_misc, sizeof(uint2) * (size_t)sets * lanes));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.slot_of, sizeof(uint32_t) * (size_t)sets * lanes));
+        if (staged) FS_HIP(ctx, hipMalloc((void**)&ctx->d_cont, sizeof(float4) * 2 * (size_t)sets * lanes));
         ctx->cap_seg = 0;   // the bucket array is sized with the segment records below
         ctx->cap_lanes = lanes;
+        ctx->state_sets = sets;
+        ctx->state_cont = staged;
     }
-    if (seg > ctx->cap_seg) {
+    if (grow_seg) {
+        seg = std::max(seg, (size_t)levels * ctx->cap_lanes);
         if (ctx->st.seg_np) (void)hipFree(ctx->st.seg_np);
         if (ctx->st.seg_mat) (void)hipFree(ctx->st.seg_mat);
         ctx->st.seg_np = nullptr; ctx->st.seg_mat = nullptr;
         ctx->cap_seg = 0;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_np, sizeof(float2) * 2 * seg));
-        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_mat, sizeof(uint32_t) * 2 * seg));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_np, sizeof(float2) * (size_t)ctx->state_sets * seg));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->st.seg_mat, sizeof(uint32_t) * (size_t)ctx->state_sets * seg));
         if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
         ctx->walk.perm = nullptr;
         // [levels + 1][lanes] for every later frame shape that fits the two capacities without a reallocation:
         // levels' * lanes' <= cap_seg and lanes' <= cap_lanes  =>  (levels' + 1) * lanes' <= seg + cap_lanes
         ctx->perm_words = seg + ctx->cap_lanes;
-        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * kPermSets * ctx->perm_words));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->walk.perm, sizeof(uint32_t) * (size_t)ctx->state_sets * ctx->perm_words));
         ctx->cap_seg = seg;
     }
     if (!ctx->d_overflow) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_overflow, sizeof(unsigned)));
         FS_HIP(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(unsigned), ctx->stream));
     }
-    if (unbounded) {
-        // the schedule puts the longest walks first: slots below rr^64 * lanes (x4 for the spread, + 64) own a second tier
-        // (rr = 0.9, the reference's roulette: 1.2e-3 of the walks; check_params bounds rr for uncapped walks)
-        const double tail = std::pow(std::min(std::max(rr_prob, 0.0), 1.0), (double)FS_MAX_DEPTH);
-        uint32_t want_cap = std::max(ctx->over_cap, (uint32_t)std::min<size_t>(lanes, (size_t)(4.0 * tail * (double)lanes) + 64));
-        if (const char* v = std::getenv("FS_OVER_CAP")) want_cap = std::max(ctx->over_cap, (uint32_t)std::max(1, std::atoi(v)));   // tests: force the regrow path
-        const bool grow_main = want_cap > ctx->over_cap || !ctx->d_over_np;
-        const bool grow_pos = want_positions && (want_cap > ctx->over_cap_pos || !ctx->d_over_pos);
-        if (grow_main) {
-            FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);
-            if (ctx->d_over_mat) (void)hipFree(ctx->d_over_mat);
-            ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr;
-            FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_np, sizeof(float2) * (size_t)kOverLevels * want_cap));
-            FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_mat, sizeof(uint32_t) * (size_t)kOverLevels * want_cap));
-            ctx->over_cap = want_cap;
-        }
-        if (grow_pos) {
-            FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->d_over_pos) (void)hipFree(ctx->d_over_pos);
-            ctx->d_over_pos = nullptr;
-            FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_pos, sizeof(float4) * 2 * (size_t)kOverLevels * ctx->over_cap));   // positions | normals
-            ctx->over_cap_pos = ctx->over_cap;
-        }
+    if (grow_over) {
+        if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);
+        if (ctx->d_over_mat) (void)hipFree(ctx->d_over_mat);
+        ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_np, sizeof(float2) * (size_t)ctx->state_sets * kOverLevels * want_cap));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_mat, sizeof(uint32_t) * (size_t)ctx->state_sets * kOverLevels * want_cap));
+        ctx->over_cap = want_cap;
+    }
+    if (grow_over_pos) {   // all-connections frames are never held: one tier
+        if (ctx->d_over_pos) (void)hipFree(ctx->d_over_pos);
+        ctx->d_over_pos = nullptr;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_over_pos, sizeof(float4) * 2 * (size_t)kOverLevels * ctx->over_cap));   // positions | normals
+        ctx->over_cap_pos = ctx->over_cap;
     }
     return FS_OK;
 }
@@ -376,6 +395,23 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_HIST_WINDOW")) ctx->hist_window = std::max(1, std::min(4096, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_CONNECT_PAIRS_PER_WAVE")) ctx->connect_pairs_per_wave = std::max(0, std::min(64, std::atoi(v)));
+    // staged depth = 0 walks (pipelined frames): the steps at which a walk moves on to the next launch.  12-step stages
+    // (a launch carries one frame's worth of work, ~0.6 ms at 262 144 subpaths; a bounce of a wave on the full chip
+    // takes ~35 us, so longer stages make their chain the launch's length), longer ones for the few hundred walks beyond
+    // the main record tier (tools/stage_sweep.py, profiles/r03_stage_sweep.log)
+    ctx->stage_bounds = {12, 24, 36, 48, 64, 80, 104};
+    if (const char* v = std::getenv("FS_STAGE_DENSE_FROM")) ctx->stage_dense_from = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("FS_WALK_STAGES")) {
+        std::vector<int> b;
+        for (const char* q = v; *q;) {
+            char* end = nullptr;
+            const long x = std::strtol(q, &end, 10);
+            if (end == q) break;
+            if (x > (b.empty() ? 0 : b.back()) && x < FS_MAX_DEPTH + kOverLevels && (int)b.size() < kMaxWalkParts - 1) b.push_back((int)x);
+            q = *end ? end + 1 : end;
+        }
+        ctx->stage_bounds = b;   // empty: depth = 0 frames are not held
+    }
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
     e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchSets * kScratchAllocWords);   // each set with its counters
     if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchSets * kScratchAllocWords);

@@ -59,21 +59,36 @@ static void held_connect_part(const fs_context::PipeFrame& q, FrameParts& f) {
     f.fixed = q.fixed ? it.s->d_fixed[it.cur] : nullptr; f.scratch_c = q.wl.queue_head; f.ppw = q.ppw;
     f.energy_tab = q.energy_tab; f.fixed_tab = q.fixed_tab;
 }
-static void held_walk_part(const fs_context::PipeFrame& q, FrameParts& f) {
-    f.has_walk = true; f.kpw = q.kp; f.stw = q.st; f.wl = q.wl; f.perm = q.perm;
+// rays per wave of a walk stage: by the number of walks it still has and the steps they have left at most
+static WalkLaunch stage_launch(const fs_context* ctx, const fs_context::PipeFrame& q, int stage) {
+    WalkLaunch wl = q.wl;
+    const WalkStage& sr = q.stages[(size_t)stage];
+    // inside a fused launch the chip is full: dense waves for every stage that still has a few thousand walks, sparse
+    // waves (the other lanes help with every query) only for the few long walks of the late stages, whose chain of
+    // dependent bounces is what matters (profiles/r03_stage_sweep.log: the stand-alone frames' rule — ~4096 sparse waves
+    // for mid-size frames — costs 0.87 instead of 0.63 ms per frame here; raising the late stages' wave priority: nothing)
+    if (sr.begin > 0 && ctx->walk_rays_per_wave <= 0)
+        wl.rays_per_wave = walk_stage_slots(q.kp, sr.begin) >= (uint32_t)ctx->stage_dense_from ? 64 : 16;
+    return wl;
 }
-
-// Let every held frame finish on its own kernels, oldest first: something needs their results (or their buffers) now.
+// the next stage of a held frame's walk as a part of the fused launch; false: the launch has no room for more walk parts
+static bool held_walk_part(const fs_context* ctx, const fs_context::PipeFrame& q, FrameParts& f) {
+    if (f.num_walk >= kMaxWalkParts) return false;
+    WalkPart& w = f.walk[f.num_walk++];
+    w.kp = q.kp; w.st = q.st; w.wl = stage_launch(ctx, q, q.next_stage); w.perm = q.perm; w.stage = q.stages[(size_t)q.next_stage];
+    return true;
+}
 }  // namespace
 
+// Let every held frame finish on its own kernels, oldest first: something needs their results (or their buffers) now.
 int flush_pending(fs_context* ctx) {
-    if (!ctx->held[0].has && !ctx->held[1].has) return FS_OK;
+    if (ctx->held.empty()) return FS_OK;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    for (int k = 0; k < 2; ++k) {
-        if (!ctx->held[k].has) continue;
-        const fs_context::PipeFrame q = ctx->held[k];
-        ctx->held[k].has = false;
-        if (!q.walked) launch_walk(ctx->scene, q.kp, q.st, q.wl, q.perm, ctx->stream);
+    while (!ctx->held.empty()) {
+        const fs_context::PipeFrame q = ctx->held.front();
+        ctx->held.pop_front();
+        for (int k = q.next_stage; k < (int)q.stages.size(); ++k)
+            launch_walk(ctx->scene, q.kp, q.st, stage_launch(ctx, q, k), q.perm, ctx->stream, q.stages[(size_t)k]);
         launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.items[0].s->d_energy[q.items[0].cur],
                        q.fixed ? q.items[0].s->d_fixed[q.items[0].cur] : nullptr, q.wl.queue_head, q.ppw, q.energy_tab, q.fixed_tab,
                        ctx->stream);
@@ -172,6 +187,7 @@ struct Frame {
     KParams kp{};
     int B = 1, levels = 0;
     bool batch = false, unbounded = false, all_conn = false, mis = false, fixed = false, accumulate = false, pipe_ok = false;
+    std::vector<WalkStage> stages;      // the walk in one piece, or the stages of a pipelined depth = 0 frame
     // frame_resources
     unsigned fidx = 0;                  // the frame's index: which state / schedule / scratch set it uses
     SubpathState st{};
@@ -233,33 +249,50 @@ void frame_describe(fs_context* ctx, Frame& f) {
     f.fixed = (p->flags & FS_FLAG_DETERMINISTIC) != 0;
     f.accumulate = (p->flags & FS_FLAG_ACCUMULATE_ENERGY) != 0;
     // Pipelined frames: this frame's passes are held back (to be launched with the next frames') when the frame has the
-    // default shape; any other frame first lets the held-back ones finish on their own.
-    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && p->depth > 0 &&
-                !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY));
+    // default shape; any other frame first lets the held-back ones finish on their own.  A depth = 0 frame is held at
+    // pipeline depth 2 only, as a STAGED walk: its longest walk is a chain of ~ log(subpaths) / log(1 / rr) dependent
+    // bounces (118 at 262 144 subpaths) while 97 % of the walks end within 32 — launch s + 1 of the frame walks steps
+    // [bound[s - 1], bound[s]) of the walks still alive, next to the other stages of the frames around it, so that every
+    // launch carries one frame's worth of work and no chain longer than a stage.
+    const bool plain = !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY));
+    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && (p->depth > 0 || (f.unbounded && ctx->pipelining >= 2));
+    f.stages.clear();
+    if (f.pipe_ok && f.unbounded && !ctx->stage_bounds.empty()) {
+        int begin = 0;
+        for (int bound : ctx->stage_bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
+        WalkStage last; last.begin = begin; last.end = 1 << 30;
+        f.stages.push_back(last);
+    } else {
+        f.stages.push_back(WalkStage());
+    }
 }
 
 int frame_resources(fs_context* ctx, Frame& f) {
     KParams& kp = f.kp;
     const int B = f.B, count = f.count;
-    if (2 * (size_t)kp.num_local > ctx->cap_lanes || (size_t)f.levels * 2 * (size_t)kp.num_local > ctx->cap_seg)
-        FS_FLUSH(ctx);   // the state arrays are about to be reallocated: held frames still read them
-    int rc = ensure_state(ctx, kp.num_local, f.levels, f.unbounded, (double)f.p->rr_prob, f.all_conn, f.mis);
+    // a frame is in flight for (walk stages + 2) launches; the frames behind it use the other sets (ensure_state lets the
+    // held frames finish before it reallocates anything)
+    const bool staged = f.stages.size() > 1;
+    int rc = ensure_state(ctx, kp.num_local, f.levels, f.unbounded, (double)f.p->rr_prob, f.all_conn, f.mis,
+                          (int)f.stages.size() + 2, staged);
     if (rc) return rc;
     f.fidx = ctx->frame_index;   // consecutive frames rotate through the state / schedule / scratch sets
+    const size_t set = f.fidx % (unsigned)ctx->state_sets;
     SubpathState& st = f.st;
     st = ctx->st;
-    if (f.fidx & 1u) {
-        st.end_pos += ctx->cap_lanes; st.end_misc += ctx->cap_lanes; st.slot_of += ctx->cap_lanes;
-        st.seg_np += ctx->cap_seg; st.seg_mat += ctx->cap_seg;
-    }
+    st.end_pos += set * ctx->cap_lanes; st.end_misc += set * ctx->cap_lanes; st.slot_of += set * ctx->cap_lanes;
+    st.seg_np += set * ctx->cap_seg; st.seg_mat += set * ctx->cap_seg;
+    st.cont_a = staged ? ctx->d_cont + 2 * set * ctx->cap_lanes : nullptr;
+    st.cont_b = staged ? st.cont_a + ctx->cap_lanes : nullptr;
     f.scratch = ctx->walk.queue_head + (size_t)(f.fidx % kScratchSets) * kScratchAllocWords;
-    f.perm_buf = ctx->walk.perm ? ctx->walk.perm + (size_t)(f.fidx % kPermSets) * ctx->perm_words : nullptr;
+    f.perm_buf = ctx->walk.perm ? ctx->walk.perm + set * ctx->perm_words : nullptr;
     st.seg_pos = f.all_conn ? ctx->d_seg_pos : nullptr;
     st.seg_nrm = f.mis ? ctx->d_seg_pos + (size_t)f.levels * 2 * (size_t)kp.num_local : nullptr;
     st.main_levels = f.levels;
     st.over_levels = f.unbounded ? kOverLevels : 0;
     st.over_cap = f.unbounded ? ctx->over_cap : 0;
-    st.over_np = ctx->d_over_np; st.over_mat = ctx->d_over_mat;
+    st.over_np = ctx->d_over_np ? ctx->d_over_np + set * (size_t)kOverLevels * ctx->over_cap : nullptr;
+    st.over_mat = ctx->d_over_mat ? ctx->d_over_mat + set * (size_t)kOverLevels * ctx->over_cap : nullptr;
     st.over_pos = f.all_conn ? ctx->d_over_pos : nullptr;
     st.over_nrm = f.mis && ctx->d_over_pos ? ctx->d_over_pos + (size_t)kOverLevels * ctx->over_cap : nullptr;
     st.overflow = ctx->d_overflow;
@@ -388,56 +421,60 @@ int frame_launch(fs_context* ctx, Frame& f) {
     if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[0], ctx->stream));
     WalkLaunch wl = ctx->walk;
     wl.queue_head = scratch;
-    wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave : auto_rays_per_wave(2ull * kp.num_local, kp.depth);
+    // (a staged walk's first stage is a frame of walks of at most stages[0].end steps)
+    wl.rays_per_wave = ctx->walk_rays_per_wave > 0 ? ctx->walk_rays_per_wave
+                                                   : auto_rays_per_wave(2ull * kp.num_local, std::min(kp.depth, f.stages[0].end));
     const int ppw = ctx->connect_pairs_per_wave > 0 ? ctx->connect_pairs_per_wave : auto_pairs_per_wave(kp.num_local);
     if (f.pipe_ok) {   // (anything else has flushed the held frames before)
         fs_context::PipeFrame me;
-        me.has = true; me.kp = kp; me.st = st; me.wl = wl; me.perm = perm; me.walked = false; me.fixed = fixed; me.ppw = ppw;
+        me.kp = kp; me.st = st; me.wl = wl; me.perm = perm; me.stages = f.stages; me.next_stage = 0; me.fixed = fixed; me.ppw = ppw;
         me.items.resize((size_t)count);
         for (int i = 0; i < count; ++i) { me.items[(size_t)i].s = srcs[i]; me.items[(size_t)i].cur = srcs[i]->cur; }
         me.energy_tab = energy_tab; me.fixed_tab = fixed_tab;
         FrameParts fp;
-        fp.wl = wl;
-        const bool deep = ctx->pipelining >= 2;
-        // the held frames (copies: the slots are rewritten below): one that only owes its connect pass, one that was only planned
-        fs_context::PipeFrame to_connect, to_walk;
-        if (ctx->held[0].has && ctx->held[0].walked) to_connect = ctx->held[0];
-        if (ctx->held[1].has) to_walk = ctx->held[1];
-        else if (ctx->held[0].has && !ctx->held[0].walked) to_walk = ctx->held[0];
-        if (deep) {   // {plan of this frame, walk of the planned frame, connect of the walked one}
-            if (plan_held) {
-                fp.has_plan = true; fp.kpp = kp; fp.scratch_p = scratch; fp.perm_p = sort ? perm_buf : nullptr;
-                fp.zero_p = zero_ptr; fp.zero_words_p = (zero_ptr || zero_tab) ? zero_words : 0; fp.zero_tab_p = zero_tab; fp.zero_count_p = count;
-            }
-            if (to_walk.has) held_walk_part(to_walk, fp);
-        } else {      // {walk of this frame, connect of the walked one}
-            held_walk_part(me, fp);
+        // ONE launch: the plan pass of this frame (depth 2), the next walk stage of every held frame — oldest frame, i.e.
+        // latest stage, first: the few long walks that are left have the longest way to go — and the connect pass of the
+        // frame whose walk is complete.  Depth 1: the plan pass ran above, this frame's walk joins the launch right away.
+        if (plan_held) {
+            fp.has_plan = true; fp.kpp = kp; fp.wl_p = wplan; fp.scratch_p = scratch; fp.perm_p = sort ? perm_buf : nullptr;
+            fp.zero_p = zero_ptr; fp.zero_words_p = (zero_ptr || zero_tab) ? zero_words : 0; fp.zero_tab_p = zero_tab; fp.zero_count_p = count;
         }
-        if (to_connect.has) held_connect_part(to_connect, fp);
-        if (timed_frame && !(fp.has_walk && (fp.has_connect || !deep))) {
-            // a pipeline-fill launch (no walk, or depth 2 without its connect part yet) is not a sample of the frame kernel:
-            // take the first event back out of the stream's timing (it was recorded above; both go back to the pool unused)
+        if (!plan_held) ctx->held.push_back(me);   // its first stage goes now
+        bool connects = false;
+        std::vector<size_t> advanced;
+        for (size_t k = 0; k < ctx->held.size(); ++k) {
+            fs_context::PipeFrame& q = ctx->held[k];
+            if (q.next_stage < (int)q.stages.size()) {
+                if (held_walk_part(ctx, q, fp)) advanced.push_back(k);
+            } else if (k == 0 && !connects) {
+                held_connect_part(q, fp);
+                connects = true;
+            }
+        }
+        if (timed_frame && !(fp.num_walk > 0 && fp.has_connect)) {
+            // a pipeline-fill launch (not every part yet) is not a sample of the frame kernel: take the first event back out
+            // of the stream's timing (it was recorded above; both go back to the pool unused)
             for (int i = 0; i < 3; ++i) if (tf.e[i]) { ctx->free_events.push_back(tf.e[i]); tf.e[i] = nullptr; }
             timed_frame = false;
         }
-        if (fp.has_walk || fp.has_connect || fp.has_plan) {
+        if (fp.num_walk > 0 || fp.has_connect || fp.has_plan) {
             if (!launch_frame(B, ctx->scene, fp, ctx->stream)) {   // no fused form: the same passes one after the other
                 if (fp.has_connect) launch_connect(B, ctx->scene, fp.kpc, fp.stc, fp.energy, fp.fixed, fp.scratch_c, fp.ppw, fp.energy_tab, fp.fixed_tab, ctx->stream);
-                if (fp.has_walk) launch_walk(ctx->scene, fp.kpw, fp.stw, fp.wl, fp.perm, ctx->stream);
+                for (int i = 0; i < fp.num_walk; ++i)
+                    launch_walk(ctx->scene, fp.walk[i].kp, fp.walk[i].st, fp.walk[i].wl, fp.walk[i].perm, ctx->stream, fp.walk[i].stage);
                 if (fp.has_plan) (void)launch_plan(kp, wplan, zero_ptr, (zero_ptr || zero_tab) ? zero_words : 0, zero_tab, count, ctx->stream);
             }
         }
         if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
         FS_HIP(ctx, hipGetLastError());
-        ctx->held[0].has = false; ctx->held[1].has = false;
-        if (to_connect.has) { const int rc = finish_held_frame(ctx, to_connect); if (rc) return rc; }
-        if (deep) {   // the planned frame has been walked now; this one has only been planned
-            if (to_walk.has) { ctx->held[0] = to_walk; ctx->held[0].walked = true; ctx->held[1] = me; }
-            else ctx->held[0] = me;
-        } else {
-            me.walked = true;
-            ctx->held[0] = me;
+        for (size_t k : advanced) ctx->held[k].next_stage++;
+        if (connects) {
+            const fs_context::PipeFrame done = ctx->held.front();
+            ctx->held.pop_front();
+            const int rc = finish_held_frame(ctx, done);
+            if (rc) return rc;
         }
+        if (plan_held) ctx->held.push_back(me);   // planned by this launch, walked by the next ones
         if (timed_frame) { tf.has_trace = true; ctx->pending.push_back(tf); }
         ctx->stats.frames++;
         ctx->stats.pairs += kp.num_local;
@@ -660,9 +697,8 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
     // pipelined frames: the source's current frame still waits for its connect pass — the reconstruct goes with it
-    for (int k = 1; k >= 0; --k) {   // the source's CURRENT frame is the newest held one
+    for (size_t k = ctx->held.size(); k-- > 0;) {   // the source's CURRENT frame is the newest held one that has it
         fs_context::PipeFrame& q = ctx->held[k];
-        if (!q.has) continue;
         fs_context::PipeFrame::Item* it = nullptr;
         for (fs_context::PipeFrame::Item& c : q.items) if (c.s == s) it = &c;
         if (!it) continue;
@@ -843,6 +879,18 @@ int fs_set_pipelining(fs_context* ctx, int32_t on) {
     if (on < 0 || on > 2) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_set_pipelining: 0 (off), 1 or 2 frames held back");
     if (on != ctx->pipelining) FS_FLUSH(ctx);
     ctx->pipelining = on;
+    return FS_OK;
+}
+
+int fs_set_walk_stages(fs_context* ctx, const int32_t* bounds, int32_t count) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (count < 0 || count > kMaxWalkParts - 1 || (count > 0 && !bounds))
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_set_walk_stages: 0 .. 7 stage bounds");
+    for (int32_t i = 0; i < count; ++i)
+        if (bounds[i] <= (i ? bounds[i - 1] : 0) || bounds[i] >= FS_MAX_DEPTH + kOverLevels)
+            return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_set_walk_stages: bounds must ascend within 1 .. 511");
+    FS_FLUSH(ctx);
+    ctx->stage_bounds.assign(bounds, bounds + count);
     return FS_OK;
 }
 

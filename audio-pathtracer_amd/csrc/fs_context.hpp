@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -35,9 +36,17 @@ constexpr int kIrRing = 3;  // published IR ring: a returned pointer stays valid
 // Energy buffers per source, used in rotation: frame f deposits into one while the tail stream still reduces /
 // reconstructs frame f - 1 from another; pipelined frames finish frame f - 2 only in the launch that plans frame f
 // (and flushes ITS buffer), so that a fourth one lets frame f + 1 start without waiting for that tail.
-constexpr int kEnergyBufs = 4;
-constexpr int kScratchSets = 3;   // frame scratch (plan counts, cursors, work counters): plan f, walk f-1, connect f-2 in one launch
-constexpr int kPermSets = 2;      // schedules: plan f writes one while walk f-1 reads the other
+// Frames in flight.  A pipelined frame lives through several launches — plan, its walk (one launch, or one launch per
+// stage of a staged depth = 0 walk), connect — while the frames behind it are in their earlier steps; everything a
+// frame owns rotates with the frame index.  kMaxSets bounds the rotation: energy buffers per source (zeroed by the
+// plan pass of frame f, deposited into up to kMaxWalkParts + 1 launches later, then read by the tail), frame scratch
+// sets (plan counts, cursors, work counters), per-frame tables of batched frames.  The big per-frame arrays (subpath
+// state, segment records, schedules, continuation records) come in fs_context::state_sets sets, as many as the deepest
+// pipeline in use needs (3 until a staged walk is pipelined).
+constexpr int kMaxSets = 12;
+constexpr int kEnergyBufs = kMaxSets;
+constexpr int kScratchSets = kMaxSets;
+static_assert(kMaxSets >= kMaxWalkParts + 3, "a staged frame is in flight for stages + 2 launches and its buffer is read one more");
 
 struct Source {
     bool alive = false;
@@ -160,11 +169,11 @@ struct fs_context {
     // the walk of frame f + 1 as ONE kernel; depth 2: the walk is held back as well — call f launches {plan of f, walk of
     // f - 1, connect of f - 2} as one kernel.  Anything that needs a held frame's result lets it finish alone (flush_pending).
     struct PipeFrame {
-        bool has = false;
         KParams kp; SubpathState st;
-        WalkLaunch wl;               // queue_head = the frame's scratch set, rays_per_wave
+        WalkLaunch wl;               // queue_head = the frame's scratch set, rays_per_wave of its first stage
         const uint32_t* perm = nullptr;   // its schedule (nullptr: none)
-        bool walked = false;         // only the connect pass is owed
+        std::vector<WalkStage> stages;    // the walk in one piece ({0, depth}) or the stages of a staged depth = 0 walk
+        int next_stage = 0;          // stages [0, next_stage) have been launched; == stages.size(): only the connect pass is owed
         bool fixed = false;
         int ppw = 64;
         struct Item {                // one per source of the frame (a batched frame has several)
@@ -175,15 +184,20 @@ struct fs_context {
         };
         std::vector<Item> items;
         float* const* energy_tab = nullptr;               // batched frame: the per-frame device tables (kBatchSlots of them
-        unsigned long long* const* fixed_tab = nullptr;   // rotate; a held frame is connected two calls later at most)
-    } held[2];                       // [0] the older frame, [1] the newer one (depth 2 only)
+        unsigned long long* const* fixed_tab = nullptr;   // rotate; a held frame is connected kMaxWalkParts + 1 calls later at most)
+    };
+    std::deque<PipeFrame> held;      // oldest first
+    int state_sets = 3;              // sets of the per-frame arrays (subpath state, records, schedules): frames in flight + 1
+    bool state_cont = false;         // the sets include continuation records (staged walks)
+    std::vector<int> stage_bounds;   // staged depth = 0 walks: the steps at which a walk changes launch (FS_WALK_STAGES)
+    int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
     std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
     std::vector<std::thread> refine_threads;   // every background build ever started (cancelled ones too): joined before the context goes
     bool moved_since_refine = false;     // fs_scene_update_triangles since the snapshot: re-apply the positions after the swap
     fs::HostBVH* prebuilt = nullptr;     // fs_scene_commit takes this tree instead of building one (install of a refined tree)
     int pipelining = 0;              // 0 off, 1 / 2 = frames held back
     unsigned frame_index = 0;        // consecutive traced frames rotate through the state / schedule / scratch sets
-    size_t perm_words = 0;           // words of ONE schedule set (walk.perm holds kPermSets)
+    size_t perm_words = 0;           // words of ONE schedule set (walk.perm holds state_sets)
     bool comm_owned = false;           // created by fs_comm_init (destroyed with the context) vs attached by the caller
 
     // subpath state (sized on demand)
@@ -193,15 +207,16 @@ struct fs_context {
     size_t cap_pos = 0;
     // second record tier of depth = 0 frames (walk steps beyond FS_MAX_DEPTH): [kOverLevels][over_cap] each, grown when
     // a frame raises the overflow word; d_overflow = that word
-    float2* d_over_np = nullptr; uint32_t* d_over_mat = nullptr; float4* d_over_pos = nullptr;
+    float2* d_over_np = nullptr; uint32_t* d_over_mat = nullptr; float4* d_over_pos = nullptr;   // state_sets tiers each (positions: one)
+    float4* d_cont = nullptr;        // continuation records of staged walks: [state_sets][2][cap_lanes]
     uint32_t over_cap = 0, over_cap_pos = 0;
     unsigned* d_overflow = nullptr;
     bool overflow_armed = false;   // an unbounded frame has been enqueued since the word was last read
     // batched frames (fs_compute_energy_response_batch_async): per-frame tables of pointers and source positions
-    static constexpr int kBatchSlots = 4;   // frames the host may run ahead of the table copies
+    static constexpr int kBatchSlots = kMaxSets;   // frames the host may run ahead of the table copies (a held frame keeps its tables)
     char* d_batch = nullptr; char* h_batch = nullptr; size_t batch_cap = 0;   // kBatchSlots blocks of batch_cap bytes
-    hipEvent_t ev_batch[kBatchSlots] = {nullptr, nullptr, nullptr, nullptr};
-    bool batch_pending[kBatchSlots] = {false, false, false, false};
+    hipEvent_t ev_batch[kBatchSlots] = {};
+    bool batch_pending[kBatchSlots] = {};
     unsigned batch_frame = 0;
     unsigned long long host_segments = 0;   // walk segments of frames without a plan pass (roulette off), since the last reset
 
@@ -267,7 +282,8 @@ hipEvent_t take_event(fs_context* ctx);
 void resolve_timings(fs_context* ctx);
 void resolve_completed_timings(fs_context* ctx);
 void poll_published(Source* s);
-int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals);
+int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals,
+                 int sets, bool staged);
 int auto_rays_per_wave(unsigned long long lanes, int depth);
 int auto_pairs_per_wave(unsigned long long pairs);
 int check_params(fs_context* ctx, const fs_params* p);

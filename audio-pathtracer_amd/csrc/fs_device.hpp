@@ -697,6 +697,36 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
     ++w.k;
 }
 
+// staged walks: leave / pick up a walk between two stages (SubpathState::cont_a / cont_b)
+__device__ __forceinline__ void walker_suspend(const Walker& w, const SubpathState& st) {
+    st.cont_a[w.slot] = make_float4(w.px, w.py, w.pz, w.prob);
+    st.cont_b[w.slot] = make_float4(w.nx, w.ny, w.nz, __uint_as_float((w.mat & 0xFFFFu) | (w.has_normal ? kContHasNormal : 0u) |
+                                                                        (w.arrived ? kContArrived : 0u) | kContAlive));
+}
+__device__ __forceinline__ bool walker_resume(Walker& w, const SubpathState& st, int step) {   // false: the walk has ended before
+    const float4 a = st.cont_a[w.slot], c = st.cont_b[w.slot];
+    const uint32_t bits = __float_as_uint(c.w);
+    if (!(bits & kContAlive)) return false;
+    w.px = a.x; w.py = a.y; w.pz = a.z; w.prob = a.w; w.prob_new = a.w;
+    w.nx = c.x; w.ny = c.y; w.nz = c.z;
+    w.mat = bits & 0xFFFFu;
+    w.has_normal = (bits & kContHasNormal) != 0u;
+    w.arrived = (bits & kContArrived) != 0u;
+    w.k = step;
+    return true;
+}
+// slots a stage covers: the walks the previous stage suspended at step stage.begin, i.e. those of stage.begin steps or
+// more (one of exactly that length ends at its first roulette here) — buckets begin .. FS_MAX_DEPTH of the length-sorted
+// schedule (the last bucket holds every walk of FS_MAX_DEPTH steps or more: a stage that starts later than that visits
+// them all and the continuation record says which still walk)
+__device__ __forceinline__ uint32_t stage_slots(const WalkStage& sr, const SubpathState& st, uint32_t total, const unsigned* s_cnt) {
+    if (sr.begin <= 0) return total;
+    uint32_t n = 0;
+    for (int L = min(sr.begin, FS_MAX_DEPTH); L <= FS_MAX_DEPTH; ++L) n += s_cnt[L];
+    if (n > sr.slots_cap) { *st.overflow = 1u; n = sr.slots_cap; }   // more long walks than the launch has lanes for: the frame is traced again
+    return n;
+}
+
 __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathState& st) {
 #ifdef FS_NT_STORES
     __builtin_nontemporal_store(v4f{w.px, w.py, w.pz, w.prob}, reinterpret_cast<v4f*>(&st.end_pos[w.slot]));
@@ -995,7 +1025,7 @@ __device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_co
 template <int LOBES, bool COUNT>
 __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
-                                                 const uint32_t* __restrict__ perm) {
+                                                 const uint32_t* __restrict__ perm, const WalkStage sr = WalkStage()) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
@@ -1004,18 +1034,25 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     }
     if (perm) __syncthreads();
     const uint32_t slot = bid * kBlock + threadIdx.x;
-    if (slot >= 2u * kp.num_local) return;
+    if (slot >= stage_slots(sr, st, 2u * kp.num_local, s_cnt)) return;
     const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
     int* stack = &s_stack[threadIdx.x];
     Walker w;
-    walker_start(w, g, slot, kp, st);
+    walker_start(w, g, slot, kp, st, sr.begin == 0);
+    if (sr.begin > 0 && !walker_resume(w, st, sr.begin)) return;
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
 #ifdef FS_WAVE_TIMELINE
     const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
     unsigned long long tl_trav = 0, tl_seg = 0;
 #endif
-    while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
+    while (true) {
+        if (w.k >= sr.end) { walker_suspend(w, st); break; }          // staged walk: the next stage goes on from here
+        if (!walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
+            walker_finish(w, st);
+            if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
+            break;
+        }
         Trav T;
 #ifdef FS_WAVE_TIMELINE
         const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
@@ -1028,7 +1065,6 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         walker_apply_hit(w, kp, sc, st, ray, T);
     }
-    walker_finish(w, st);
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 #ifdef FS_WAVE_TIMELINE
     {
@@ -1058,7 +1094,8 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
 template <int LOBES, bool COUNT>
 __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
-                                                 const uint32_t* __restrict__ perm, const int rays_per_wave) {
+                                                 const uint32_t* __restrict__ perm, const int rays_per_wave,
+                                                 const WalkStage sr = WalkStage()) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
@@ -1069,16 +1106,27 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = bid * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
-    bool alive = lane < (uint32_t)rays_per_wave && slot < 2u * kp.num_local;
+    bool alive = lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
     int* stack = &s_stack[threadIdx.x];
     Walker w;
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
-                 slot, kp, st, alive);
+                 slot, kp, st, alive && sr.begin == 0);
+    if (alive && sr.begin > 0) alive = walker_resume(w, st, sr.begin);
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
     while (true) {
-        const bool go = alive && walker_next_ray<LOBES>(w, kp, sc, st, ray);
-        if (alive && !go) { walker_finish(w, st); alive = false; }
+        bool go = false;
+        if (alive) {
+            if (w.k >= sr.end) { walker_suspend(w, st); alive = false; }   // staged walk: the next stage goes on from here
+            else {
+                go = walker_next_ray<LOBES>(w, kp, sc, st, ray);
+                if (!go) {
+                    walker_finish(w, st);
+                    if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
+                    alive = false;
+                }
+            }
+        }
         if (__ballot(go) == 0ull) break;
         Trav T;
         trav_run_shared<COUNT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);

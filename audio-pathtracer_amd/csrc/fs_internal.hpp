@@ -136,6 +136,18 @@ struct SubpathState {
     unsigned* overflow;
     uint32_t over_cap;
     int32_t main_levels, over_levels;
+    // Staged walks (pipelined depth = 0 frames): a walk that reaches the last step of its stage leaves a continuation
+    // record by slot — cont_a = (position, probability of the current node), cont_b = (normal, material | kCont* flags) —
+    // and the next stage (one launch later) resumes from it.  Null for walks that run in one piece.
+    float4* cont_a; float4* cont_b;
+};
+constexpr uint32_t kContHasNormal = 1u << 16, kContArrived = 1u << 17, kContAlive = 1u << 18;   // cont_b.w above the 16-bit material
+
+// steps [begin, end) of a walk; slots_cap = the slots this launch has lanes for (a stage that starts at step begin > 0
+// only covers the walks longer than that — the first slots of the length-sorted schedule)
+struct WalkStage {
+    int32_t begin = 0, end = 1 << 30;
+    uint32_t slots_cap = 0xFFFFFFFFu;
 };
 
 // ---- host BVH builder ------------------------------------------------------------------------------
@@ -177,24 +189,33 @@ constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // buffers instead (batched frame).  Returns nullptr — and zeroes nothing — when there is no roulette to plan for.
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
                             float* const* energy_tab, int energy_count, hipStream_t s);
-// Pipelined frames: ONE launch with up to three parts — the walk of one frame (planned before), the connect pass of an
-// older one (walked before), the plan pass of the newest.  false = no fused form for this shape (lobes, counting
+// Pipelined frames: ONE launch with several parts — walks (or walk stages) of frames planned before, the connect pass
+// of an older one (walked before), the plan pass of the newest.  false = no fused form for this shape (lobes, counting
 // instantiations, experiment walk variants, nothing to do): the caller launches the kernels one after the other.
+constexpr int kMaxWalkParts = 8;   // walk parts of one fused launch = stages of a staged walk in flight
+struct WalkPart {   // a frame's walks from step stage.begin up to step stage.end
+    KParams kp; SubpathState st; WalkLaunch wl;   // wl.queue_head = the frame's scratch set, wl.rays_per_wave
+    const uint32_t* perm = nullptr;               // its schedule (nullptr: none)
+    WalkStage stage;
+};
 struct FrameParts {
-    bool has_walk = false;      // kpw, stw, wl (queue_head = the frame's scratch set, rays_per_wave), perm (nullptr: no schedule)
-    KParams kpw; SubpathState stw; WalkLaunch wl; const uint32_t* perm = nullptr;
+    int num_walk = 0;           // walk parts, in grid order
+    WalkPart walk[kMaxWalkParts];
     bool has_connect = false;   // kpc, stc, energy / fixed, scratch_c (re-armed by the pass), ppw
     KParams kpc; SubpathState stc; float* energy = nullptr; unsigned long long* fixed = nullptr; unsigned* scratch_c = nullptr; int ppw = 64;
     float* const* energy_tab = nullptr; unsigned long long* const* fixed_tab = nullptr;   // batched frame: per-source buffers
-    bool has_plan = false;      // kpp, scratch_p, perm_p (the schedule to write, nullptr: counts only), zero_p / zero_words_p (the flush)
-    KParams kpp; unsigned* scratch_p = nullptr; uint32_t* perm_p = nullptr; float* zero_p = nullptr; int zero_words_p = 0;
+    bool has_plan = false;      // kpp, wl_p (plan switch), scratch_p, perm_p (the schedule to write, nullptr: counts only), zero_p / zero_words_p (the flush)
+    KParams kpp; WalkLaunch wl_p; unsigned* scratch_p = nullptr; uint32_t* perm_p = nullptr; float* zero_p = nullptr; int zero_words_p = 0;
     float* const* zero_tab_p = nullptr; int zero_count_p = 0;                              // batched frame: the buffers to flush
 };
 bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s);
 // does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule
 bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s);
+                 const uint32_t* perm, hipStream_t s, const WalkStage& stage = WalkStage());
+// lanes a walk stage needs: all subpaths for a stage that starts at step 0, else the expected number of walks longer than
+// stage.begin under the roulette (x1.3 + 1024: the count is binomial, the margin is hundreds of standard deviations)
+uint32_t walk_stage_slots(const KParams& kp, int begin);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
 // energy_tab / fixed_tab: per-source buffers of a batched frame (device arrays of kp.num_local / kp.pairs_per_source
 // pointers), null for one source (`energy` / `fixed` are used)

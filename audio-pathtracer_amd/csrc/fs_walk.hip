@@ -57,15 +57,16 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
 template <int LOBES, bool COUNT>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm) {
-    walk_shared_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm);
+                                                             const uint32_t* __restrict__ perm, WalkStage stage) {
+    walk_shared_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, stage);
 }
 
 template <int LOBES, bool COUNT>
 __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm, int rays_per_wave) {
-    walk_sparse_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave);
+                                                             const uint32_t* __restrict__ perm, int rays_per_wave,
+                                                             WalkStage stage) {
+    walk_sparse_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave, stage);
 }
 
 }  // namespace
@@ -91,9 +92,18 @@ bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool*
     return true;
 }
 
+uint32_t walk_stage_slots(const KParams& kp, int begin) {
+    const uint32_t lanes = 2u * kp.num_local;
+    if (begin <= 0 || !kp.russian_roulette) return lanes;
+    const double expect = (double)lanes * std::pow((double)kp.rr_prob, (double)begin);
+    return (uint32_t)std::min<double>((double)lanes, 1.3 * expect + 1024.0);
+}
+
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s) {
-    uint32_t lanes = 2u * kp.num_local;
+                 const uint32_t* perm, hipStream_t s, const WalkStage& stage_in) {
+    WalkStage stage = stage_in;
+    if (stage.begin > 0 && stage.slots_cap == 0xFFFFFFFFu) stage.slots_cap = walk_stage_slots(kp, stage.begin);
+    uint32_t lanes = stage.begin > 0 ? stage.slots_cap : 2u * kp.num_local;   // a later stage only has lanes for the walks still alive
     if (lanes == 0) return;
     uint32_t full = (lanes + kBlock - 1) / kBlock;
     const bool shared = FS_SHARED_WALK(wl);
@@ -108,12 +118,12 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
-        FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave);
+        FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
         return;
     }
     if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
-        FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm);
+        FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm, stage);
         return;
     }
 #undef FS_LAUNCH_WALK

@@ -296,9 +296,17 @@ int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t
  * (many sources, offline rendering, bench.py) gains 12-14 % (36 % on 16 384-ray frames), a producer that issues one
  * frame per game tick should end the tick with fs_submit (or leave pipelining off) or the frame's IR is published one
  * or two ticks later.  Batched frames are held like any other (they gain little: a frame of several chip-fulls has no
- * thin tail to fill).  Frames with lobes, all-connections modes, depth = 0, FS_FLAG_ACCUMULATE_ENERGY and profiling
- * level >= 2 are never held. */
+ * thin tail to fill).  Frames with lobes, all-connections modes, FS_FLAG_ACCUMULATE_ENERGY and profiling level >= 2
+ * are never held.
+ * depth = 0 frames (the reference's uncapped walks, ARTS.cpp:294) are held at depth 2 as STAGED WALKS: the longest walk
+ * of a frame is a chain of log(subpaths) / log(1 / rr) dependent bounces (118 at 262 144 subpaths) while 97 % of the
+ * walks end within 32, so such a frame alone leaves the chip idle for most of its duration.  Launch s + 1 of the frame
+ * walks only steps [bound[s-1], bound[s]) of the walks still alive (a 32-byte continuation record per walk carries them
+ * from launch to launch), next to the other stages of the frames around it: every launch holds one frame's worth of
+ * work and no dependent chain longer than a stage; the frame's IR is published stages + 2 calls after its own (9 with
+ * the default bounds 12, 24, 36, 48, 64, 80, 104 — fs_set_walk_stages changes them, count 0 = do not hold such frames). */
 int fs_set_pipelining(fs_context* ctx, int32_t depth);   /* 0 = off, 1, 2 */
+int fs_set_walk_stages(fs_context* ctx, const int32_t* bounds /* ascending, 1..511 */, int32_t count /* 0..7 */);
 int fs_submit(fs_context* ctx);   /* hand everything requested so far to the GPU; does not wait */
 
 /* ReconstructImpulseResponse (FSAC.cpp:320-380, called at ARTS.cpp:192): energy -> per-band IR

@@ -311,9 +311,10 @@ class Scene:
                                     e32.ctypes.data, e64.ctypes.data if want_f64 else None, C.byref(c))
         return e32, e64, c
 
-    def compute_energy_mt(self, params, src, lis, threads, pair_begin=0, pair_end=None, num_bins=1000):
+    def compute_energy_mt(self, params, src, lis, threads, pair_begin=0, pair_end=None, num_bins=1000, pool=None):
         """All-cores CPU baseline: static partition of the pair range, private histograms, final sum.
-        ctypes releases the GIL during the foreign call, so plain Python threads run in parallel."""
+        ctypes releases the GIL during the foreign call, so plain Python threads run in parallel.
+        pool: a ThreadPoolExecutor the caller keeps (bench.py: the threads exist before the clock starts)."""
         if pair_end is None:
             pair_end = params.num_pairs
         n = pair_end - pair_begin
@@ -322,8 +323,11 @@ class Scene:
         def work(i):
             return self.compute_energy(params, src, lis, cuts[i], cuts[i + 1], num_bins, want_f64=True)
 
-        with ThreadPoolExecutor(max_workers=threads) as ex:
-            parts = list(ex.map(work, range(threads)))
+        if pool is not None:
+            parts = list(pool.map(work, range(threads)))
+        else:
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                parts = list(ex.map(work, range(threads)))
         e64 = sum(p[1] for p in parts)
         c = Counters()
         for p in parts:

@@ -15,8 +15,8 @@ def test_context_advice_reports_the_hardware_queue_setting(pkg, scene_factory):
     """fs_context_advice: the library no longer sets GPU_MAX_HW_QUEUES behind the host's back (a load-time setenv is too
     late in a process that already uses HIP); it reports what it found.  The Python binding — the host here — exports 16
     before the runtime starts, so a context created through it has nothing to say."""
-    assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
     ctx = pkg.Context(num_bands=1)
+    assert int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) >= 8
     assert ctx.advice() == ""
     ctx.close()
 
@@ -94,4 +94,89 @@ def test_overflowed_walks_are_not_connected(pkg, oracle_mod, scene_factory, monk
             assert not np.any((partial != 0) & (e64 == 0))
     e = ctx.compute_energy_response(src, p)       # the synchronous entry point traces again with a grown tier
     assert e.any()
+    ctx.close()
+
+
+# ---- staged walks: depth = 0 frames in the frame pipeline --------------------------------------------------------
+def _stream(pkg, ctx, src, params):
+    for p in params:
+        ctx.compute_energy_response_async(src, p)
+        ctx.reconstruct_impulse_response_async(src, p)
+
+
+@pytest.mark.parametrize("bounds", [None, [4], [3, 9, 30, 64, 65, 100], [64], [70, 90]], ids=["default", "one", "odd", "tier_edge", "beyond_tier"])
+def test_staged_uncapped_walks_equal_the_unpipelined_frames(pkg, oracle_mod, scene_factory, bounds):
+    """depth = 0 frames held at pipeline depth 2 walk in stages, one stage per launch, carried from launch to launch by
+    continuation records.  A stream of such frames (new seed each, a capped frame in between) leaves exactly the energy,
+    IR and work counters of an unpipelined context — bit for bit in deterministic mode — whatever the stage bounds are:
+    inside the main record tier, on its edge, beyond it; and the last frame equals the oracle's."""
+    sc = scene_factory("starter_room", 4)
+    plain, ps = make_ctx(pkg, sc)
+    pipe, qs = make_ctx(pkg, sc)
+    pipe.set_pipelining(2)
+    if bounds is not None:
+        pipe.set_walk_stages(bounds)
+    for flags in (DET, 0):
+        params = [pkg.default_params(num_rays=16384, depth=0, seed=500 + i, flags=flags) for i in range(11)]
+        params.insert(4, pkg.default_params(num_rays=8192, depth=8, seed=77, flags=flags))     # another shape mid-stream
+        plain.reset_stats(); pipe.reset_stats()
+        _stream(pkg, plain, ps, params)
+        _stream(pkg, pipe, qs, params)
+        plain.synchronize(); pipe.synchronize()
+        want_e, got_e = plain.energy_buffer(ps), pipe.energy_buffer(qs)
+        want_ir, got_ir = plain.impulse_response(ps, 0), pipe.impulse_response(qs, 0)
+        a, b = plain.stats(), pipe.stats()
+        assert all(a[k] == b[k] for k in ("segments", "connections_tested", "deposits", "frames", "rays"))
+        assert want_e.any()
+        if flags & DET:
+            assert np.array_equal(got_e, want_e) and np.array_equal(got_ir, want_ir)
+        else:
+            assert np.array_equal(got_e != 0, want_e != 0)
+            assert max(rel_rms(got_e[b_], want_e[b_]) for b_ in range(4)) <= TIGHT_TOL
+            assert np.abs(got_ir - want_ir).max() <= IR_TOL * np.abs(want_ir).max()
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=8192, depth=0, seed=510), sc.source, sc.listener)
+    check_energy(pipe.energy_buffer(qs), e32, e64, 4)
+    plain.close(); pipe.close()
+
+
+def test_staged_walks_with_reads_in_between_and_batches(pkg, scene_factory):
+    """Every call that observes a held frame lets it finish alone (its remaining stages one after the other): energy reads
+    between the frames of a staged stream see exactly what an unpipelined context holds; batched depth = 0 frames are
+    staged like single ones."""
+    sc = scene_factory("starter_room", 4)
+    rng = np.random.default_rng(21)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    pos = [(sc.source + rng.uniform(-0.08, 0.08, 3) * (hi - lo)).astype(np.float32) for _ in range(3)]
+    out = {}
+    for mode in ("plain", "pipelined"):
+        ctx, _ = make_ctx(pkg, sc)
+        if mode == "pipelined":
+            ctx.set_pipelining(2)
+        srcs = [ctx.create_source(p) for p in pos]
+        seen = []
+        for i in range(9):
+            p = pkg.default_params(num_rays=4096, depth=0, seed=900 + i, flags=DET)
+            ctx.compute_energy_response_batch_async(srcs, p)
+            if i in (2, 3, 7):
+                seen.append(ctx.energy_buffer(srcs[i % 3]).copy())     # flushes the pipeline mid-stream
+        ctx.synchronize()
+        seen += [ctx.energy_buffer(s).copy() for s in srcs]
+        out[mode] = seen
+        ctx.close()
+    for a, b in zip(out["plain"], out["pipelined"]):
+        assert a.any() and np.array_equal(a, b)
+
+
+def test_walk_stage_bounds_are_validated(pkg, scene_factory):
+    sc = scene_factory("shoebox", 1)
+    ctx, src = make_ctx(pkg, sc)
+    for bad in ([0, 5], [5, 5], [9, 3], [600], list(range(1, 9))):
+        with pytest.raises(pkg.FrequenSeeError):
+            ctx.set_walk_stages(bad)
+    ctx.set_walk_stages([])            # depth = 0 frames are not held: still correct
+    ctx.set_pipelining(2)
+    ctx.compute_energy_response_async(src, pkg.default_params(num_rays=1024, depth=0, seed=1))
+    ctx.synchronize()
+    assert ctx.energy_buffer(src).any()
     ctx.close()
