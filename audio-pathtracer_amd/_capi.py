@@ -32,6 +32,7 @@ FLAG_ALL_CONNECTIONS = 16
 FLAG_MIS_BALANCE = 32
 FLAG_MATERIAL_LOBES = 64
 FLAG_ACCUMULATE_ENERGY = 128
+FLAG_DOUBLE_POSITIONS = 256
 
 # every symbol include/frequensee.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -117,6 +118,8 @@ class Params(C.Structure):
         ("sound_speed", C.c_float),
         ("air_absorption", C.c_float * MAX_BANDS),
         ("samples_per_bin", C.c_int32),
+        ("listener_radius", C.c_float),
+        ("source_radius", C.c_float),
     ]
 
 

@@ -116,20 +116,6 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
 constexpr uint32_t kNoObject = 0xFFFFFFFFu;
 constexpr uint32_t kPawnObject = 0xFFFFFFFEu;
 
-__device__ __forceinline__ bool sphere_hit(const Ray& r, const float c[3], float rad, float tmax, float& t_out) {
-    float ox = r.ox - c[0], oy = r.oy - c[1], oz = r.oz - c[2];
-    float b = fmaf(ox, r.dx, fmaf(oy, r.dy, oz * r.dz));
-    float cc = fmaf(ox, ox, fmaf(oy, oy, oz * oz)) - rad * rad;
-    float disc = fmaf(b, b, -cc);
-    if (!(disc >= 0.0f)) return false;
-    float sq = sqrtf(disc);
-    float t = -b - sq;
-    if (!(t > 0.0f)) t = sq - b;
-    if (!(t > 0.0f && t <= tmax)) return false;
-    t_out = t;
-    return true;
-}
-
 struct LegacyHit { float t; uint32_t object; float nx, ny, nz; };
 
 // ---------------------------------------------------------------------------------------------------

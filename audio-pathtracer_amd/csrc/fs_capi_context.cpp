@@ -78,10 +78,10 @@ void free_state(fs_context* ctx) {
     if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
     ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
     if (ctx->st.slot_of) (void)hipFree(ctx->st.slot_of);
-    for (void* q : {(void*)ctx->d_over_np, (void*)ctx->d_over_mat, (void*)ctx->d_over_pos, (void*)ctx->d_overflow, (void*)ctx->d_cont})
+    for (void* q : {(void*)ctx->d_over_np, (void*)ctx->d_over_mat, (void*)ctx->d_over_pos, (void*)ctx->d_overflow, (void*)ctx->d_cont, (void*)ctx->d_end_posd})
         if (q) (void)hipFree(q);
-    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->d_overflow = nullptr; ctx->d_cont = nullptr;
-    ctx->over_cap = ctx->over_cap_pos = 0;
+    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->d_overflow = nullptr; ctx->d_cont = nullptr; ctx->d_end_posd = nullptr;
+    ctx->over_cap = ctx->over_cap_pos = 0; ctx->cap_posd = 0;
     if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
     ctx->walk.perm = nullptr;
     ctx->st = SubpathState{};
@@ -287,6 +287,10 @@ int check_params(fs_context* ctx, const fs_params* p) {
     // steps, which rr <= 0.95 leaves with probability < 4e-12 per walk.  A weaker roulette needs an explicit cap.
     if (p->depth == 0 && p->russian_roulette && p->rr_prob < 1.0f && p->rr_prob > kMaxUnboundedRr)
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "depth = 0 (uncapped walks) needs rr_prob <= 0.95: give a depth cap for a weaker roulette");
+    if ((p->flags & FS_FLAG_DOUBLE_POSITIONS) && (p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS)))
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "FS_FLAG_DOUBLE_POSITIONS cannot be combined with the lobe / all-connections modes");
+    if (!(p->listener_radius >= 0.f) || !(p->source_radius >= 0.f) || !std::isfinite(p->listener_radius) || !std::isfinite(p->source_radius))
+        return ctx->fail(FS_ERR_INVALID_ARGUMENT, "listener_radius / source_radius must be finite and >= 0");
     if (!(p->dist_divisor > 0.f) || !(p->sound_speed > 0.f))
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "dist_divisor and sound_speed must be positive");
     return FS_OK;
@@ -334,6 +338,8 @@ void fs_params_default(fs_params* p) {
     p->sound_speed = 343.0f;       // ARTS.cpp:362
     for (int b = 0; b < FS_MAX_BANDS; ++b) p->air_absorption[b] = 0.05f;  // ARTS.cpp:395
     p->samples_per_bin = 0;
+    p->listener_radius = 0.0f;     // the end points are points (34 cm reproduces HEAD's pawn collision)
+    p->source_radius = 0.0f;
 }
 
 int fs_context_create(const fs_config* cfg, fs_context** out) {

@@ -243,6 +243,9 @@ void frame_describe(fs_context* ctx, Frame& f) {
     kp.num_bands = f.B;
     kp.hist_window = std::min(ctx->num_bins, ctx->hist_window);
     kp.lobes = (p->flags & FS_FLAG_MATERIAL_LOBES) ? 1 : 0;
+    kp.dpos = (p->flags & FS_FLAG_DOUBLE_POSITIONS) ? 1 : 0;
+    kp.listener_radius = p->listener_radius;
+    kp.source_radius = p->source_radius;
     f.mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
     f.all_conn = f.mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
     kp.mis = f.mis ? 1 : 0;
@@ -254,8 +257,10 @@ void frame_describe(fs_context* ctx, Frame& f) {
     // bounces (118 at 262 144 subpaths) while 97 % of the walks end within 32 — launch s + 1 of the frame walks steps
     // [bound[s - 1], bound[s]) of the walks still alive, next to the other stages of the frames around it, so that every
     // launch carries one frame's worth of work and no chain longer than a stage.
-    const bool plain = !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY));
-    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && (p->depth > 0 || (f.unbounded && ctx->pipelining >= 2));
+    const bool plain = !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY |
+                                     FS_FLAG_DOUBLE_POSITIONS));
+    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) &&
+                (p->depth > 0 || (f.unbounded && ctx->pipelining >= 2));
     f.stages.clear();
     if (f.pipe_ok && f.unbounded && !ctx->stage_bounds.empty()) {
         int begin = 0;
@@ -284,6 +289,18 @@ int frame_resources(fs_context* ctx, Frame& f) {
     st.seg_np += set * ctx->cap_seg; st.seg_mat += set * ctx->cap_seg;
     st.cont_a = staged ? ctx->d_cont + 2 * set * ctx->cap_lanes : nullptr;
     st.cont_b = staged ? st.cont_a + ctx->cap_lanes : nullptr;
+    st.end_posd = nullptr;
+    if (kp.dpos) {   // (never held: the stream is only drained when the array must grow)
+        const size_t lanes = 2 * (size_t)kp.num_local;
+        if (lanes > ctx->cap_posd) {
+            FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_end_posd) (void)hipFree(ctx->d_end_posd);
+            ctx->d_end_posd = nullptr; ctx->cap_posd = 0;
+            FS_HIP(ctx, hipMalloc((void**)&ctx->d_end_posd, sizeof(double) * 3 * lanes));
+            ctx->cap_posd = lanes;
+        }
+        st.end_posd = ctx->d_end_posd;
+    }
     f.scratch = ctx->walk.queue_head + (size_t)(f.fidx % kScratchSets) * kScratchAllocWords;
     f.perm_buf = ctx->walk.perm ? ctx->walk.perm + set * ctx->perm_words : nullptr;
     st.seg_pos = f.all_conn ? ctx->d_seg_pos : nullptr;

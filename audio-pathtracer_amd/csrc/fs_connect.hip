@@ -5,13 +5,13 @@
 namespace fs {
 namespace {
 
-template <int B, int LOBES, bool BATCH, bool COUNT>
+template <int B, int LOBES, bool BATCH, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head,
                                                          int pairs_per_wave, float* const* __restrict__ energy_tab,
                                                          unsigned long long* const* __restrict__ fixed_tab) {
-    connect_body<B, LOBES, BATCH, COUNT>(blockIdx.x, gridDim.x, sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);
+    connect_body<B, LOBES, BATCH, COUNT, EXT>(blockIdx.x, gridDim.x, sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -129,10 +129,17 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
             float len = sqrtf(l2);
             float inv = 1.0f / len;
             float tmax = len - kp.connect_pullback;
-            const bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
+            bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
             Ray ray = make_ray(fx, fy, fz, dx * inv, dy * inv, dz * inv);
+            bool sphere_blocked = false;   // the end points' collision spheres: ConnectSubpaths ignores no actor
+            if (has_ray && (kp.listener_radius > 0.0f || kp.source_radius > 0.0f)) {
+                float ts;
+                sphere_blocked = (kp.listener_radius > 0.0f && sphere_hit(ray, kp.lis, kp.listener_radius, tmax, ts)) ||
+                                 (kp.source_radius > 0.0f && sphere_hit(ray, kp.src, kp.source_radius, tmax, ts));
+                if (sphere_blocked) has_ray = false;
+            }
             const bool hit = trav_any_shared(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share);
-            if (!active || hit) continue;
+            if (!active || hit || sphere_blocked) continue;
             ++my_deposits;
             float E[Bands<B>::kMax];
 #pragma unroll
@@ -230,6 +237,20 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
         hipLaunchKernelGGL((connect_kernel<B, L, BT, CN>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy,   \
                            fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);                                \
     } while (0)
+    // FS_FLAG_DOUBLE_POSITIONS / end-point collision spheres: one instantiation pair with the run-time band count
+    if (kp.dpos || kp.listener_radius > 0.0f || kp.source_radius > 0.0f) {
+        if (B != 0) return launch_connect_t<0>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s);
+        if (batch) {
+            allow_lds(connect_kernel<0, 0, true, false, true>, lds);
+            hipLaunchKernelGGL((connect_kernel<0, 0, true, false, true>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed,
+                               queue_head, pairs_per_wave, energy_tab, fixed_tab);
+        } else {
+            allow_lds(connect_kernel<0, 0, false, false, true>, lds);
+            hipLaunchKernelGGL((connect_kernel<0, 0, false, false, true>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed,
+                               queue_head, pairs_per_wave, energy_tab, fixed_tab);
+        }
+        return;
+    }
     // record-fetch counting (fs_set_profiling level 3) exists for the default frame shape only
     if (batch) { if (kp.lobes) FS_LAUNCH_CONNECT(1, true, false); else FS_LAUNCH_CONNECT(0, true, false); }
     else if (kp.lobes) FS_LAUNCH_CONNECT(1, false, false);

@@ -208,6 +208,7 @@ struct fs_context {
     // second record tier of depth = 0 frames (walk steps beyond FS_MAX_DEPTH): [kOverLevels][over_cap] each, grown when
     // a frame raises the overflow word; d_overflow = that word
     float2* d_over_np = nullptr; uint32_t* d_over_mat = nullptr; float4* d_over_pos = nullptr;   // state_sets tiers each (positions: one)
+    double* d_end_posd = nullptr; size_t cap_posd = 0;   // FS_FLAG_DOUBLE_POSITIONS: end points in double [lanes][3] (such frames are never held: one set)
     float4* d_cont = nullptr;        // continuation records of staged walks: [state_sets][2][cap_lanes]
     uint32_t over_cap = 0, over_cap_pos = 0;
     unsigned* d_overflow = nullptr;

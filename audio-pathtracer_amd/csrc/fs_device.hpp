@@ -526,6 +526,7 @@ struct Walker {          // ARTS.cpp:287-291 state + bookkeeping
     uint32_t g, slot, side, li, pair;   // subpath index, launch slot (where its records go), side, pair of the frame, RNG pair
     int k;
     float px, py, pz, nx, ny, nz;
+    double dpx, dpy, dpz;   // FS_FLAG_DOUBLE_POSITIONS: the node position as the reference's FVector holds it (px.. = its float rounding)
     bool has_normal;
     bool arrived;      // the current vertex was reached by a hit (lobes are picked only then)
     uint32_t mat;
@@ -579,6 +580,7 @@ __device__ __forceinline__ void walker_start(Walker& w, uint32_t g, uint32_t slo
         w.pair = kp.pair_begin + (w.li - sid * kp.pairs_per_source);
         if (!w.side) { w.px = kp.src_table[3 * sid]; w.py = kp.src_table[3 * sid + 1]; w.pz = kp.src_table[3 * sid + 2]; }
     }
+    w.dpx = (double)w.px; w.dpy = (double)w.py; w.dpz = (double)w.pz;
     w.nx = 0.f; w.ny = 0.f; w.nz = 0.f;
     w.has_normal = false;
     w.arrived = false;
@@ -649,23 +651,88 @@ __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, co
     return true;
 }
 
+// An end point's collision (the reference's traces query ECC_Pawn too): a sphere; a ray that starts inside
+// leaves through the far side.  The legacy tracer's pawn is the same sphere.
+__device__ __forceinline__ bool sphere_hit(const Ray& r, const float c[3], float rad, float tmax, float& t_out) {
+    float ox = r.ox - c[0], oy = r.oy - c[1], oz = r.oz - c[2];
+    float b = fmaf(ox, r.dx, fmaf(oy, r.dy, oz * r.dz));
+    float cc = fmaf(ox, ox, fmaf(oy, oy, oz * oz)) - rad * rad;
+    float disc = fmaf(b, b, -cc);
+    if (!(disc >= 0.0f)) return false;
+    float sq = sqrtf(disc);
+    float t = -b - sq;
+    if (!(t > 0.0f)) t = sq - b;
+    if (!(t > 0.0f && t <= tmax)) return false;
+    t_out = t;
+    return true;
+}
+// ImpactNormal of a sphere hit: unit (impact - centre), flipped to face the ray origin side like a triangle's
+__device__ __forceinline__ void sphere_normal(const Ray& r, float t, const float c[3], float& nx, float& ny, float& nz) {
+    float x = fmaf(t, r.dx, r.ox) - c[0], y = fmaf(t, r.dy, r.oy) - c[1], z = fmaf(t, r.dz, r.oz) - c[2];
+    float l2 = x * x + y * y + z * z;
+    float inv = 1.0f / sqrtf(l2);
+    x = x * inv; y = y * inv; z = z * inv;
+    float dn = fmaf(x, r.dx, fmaf(y, r.dy, z * r.dz));
+    if (dn > 0.0f) { x = -x; y = -y; z = -z; }
+    nx = x; ny = y; nz = z;
+}
+
 // bottom of the loop (ARTS.cpp:339-347): apply the closest hit (or the miss) and record the segment
+// EXT: the instantiation that knows FS_FLAG_DOUBLE_POSITIONS and the end points' collision spheres (both decided at run
+// time inside it); the default instantiation carries neither — not a register, not an instruction
+template <bool EXT = false>
 __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, const DeviceScene& sc,
                                                  const SubpathState& st, const Ray& ray, const Trav& T) {
     float qx = w.px, qy = w.py, qz = w.pz;
+    double dqx = w.dpx, dqy = w.dpy, dqz = w.dpz;
     uint32_t mat_new = w.mat;
-    if (T.leaf_index >= 0) {                                              // ARTS.cpp:345-347
-        hit_surface(sc, T.leaf_index, ray, w.nx, w.ny, w.nz, mat_new);
-        qx = fmaf(kp.surface_offset, w.nx, fmaf(T.t, ray.dx, ray.ox));   // ray origin = node position, except behind
-        qy = fmaf(kp.surface_offset, w.ny, fmaf(T.t, ray.dy, ray.oy));   // the surface for a transmitted segment
-        qz = fmaf(kp.surface_offset, w.nz, fmaf(T.t, ray.dz, ray.oz));
+    bool hit = T.leaf_index >= 0;
+    float t = T.t;
+    if (hit) hit_surface(sc, T.leaf_index, ray, w.nx, w.ny, w.nz, mat_new);
+    // the OTHER end point's collision sphere (the walk's own actor is ignored, ARTS.cpp:322-334); wins ties with a triangle
+    const float other_radius = !EXT ? 0.0f : (w.side ? kp.source_radius : kp.listener_radius);
+    if (EXT && other_radius > 0.0f) {
+        float c[3] = {w.side ? kp.src[0] : kp.lis[0], w.side ? kp.src[1] : kp.lis[1], w.side ? kp.src[2] : kp.lis[2]};
+        if (w.side && kp.src_table) {   // batched frame: this pair's source
+            const uint32_t sid = w.li / kp.pairs_per_source;
+            c[0] = kp.src_table[3 * sid]; c[1] = kp.src_table[3 * sid + 1]; c[2] = kp.src_table[3 * sid + 2];
+        }
+        float ts;
+        if (sphere_hit(ray, c, other_radius, kp.max_trace_dist, ts) && (!hit || ts <= t)) {
+            hit = true; t = ts;
+            sphere_normal(ray, ts, c, w.nx, w.ny, w.nz);
+            mat_new = kNoMat;                                             // a pawn has no UAcousticGeometryComponent
+        }
+    }
+    const bool DPOS = EXT && kp.dpos != 0;
+    if (hit) {                                                            // ARTS.cpp:345-347
+        if (DPOS) {   // Hit.ImpactPoint + 0.1 * Hit.ImpactNormal in FVector (double) arithmetic; the ray starts at the node's float rounding
+            const bool shifted = ray.ox != w.px || ray.oy != w.py || ray.oz != w.pz;   // (transmitted lobe only: never with this flag)
+            const double ipx = (shifted ? (double)ray.ox : w.dpx) + (double)t * (double)ray.dx;
+            const double ipy = (shifted ? (double)ray.oy : w.dpy) + (double)t * (double)ray.dy;
+            const double ipz = (shifted ? (double)ray.oz : w.dpz) + (double)t * (double)ray.dz;
+            dqx = ipx + (double)kp.surface_offset * (double)w.nx;
+            dqy = ipy + (double)kp.surface_offset * (double)w.ny;
+            dqz = ipz + (double)kp.surface_offset * (double)w.nz;
+            qx = (float)dqx; qy = (float)dqy; qz = (float)dqz;
+        } else {
+            qx = fmaf(kp.surface_offset, w.nx, fmaf(t, ray.dx, ray.ox));   // ray origin = node position, except behind
+            qy = fmaf(kp.surface_offset, w.ny, fmaf(t, ray.dy, ray.oy));   // the surface for a transmitted segment
+            qz = fmaf(kp.surface_offset, w.nz, fmaf(t, ray.dz, ray.oz));
+        }
         w.has_normal = true;
     }
-    w.arrived = T.leaf_index >= 0;
+    w.arrived = hit;
     // the segment just added (zero length on a miss: the duplicate node of ARTS.cpp:296)
-    float ddx = qx - w.px, ddy = qy - w.py, ddz = qz - w.pz;
-    float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);                // ARTS.cpp:372
-    float nd = dist / kp.dist_divisor;                                    // ARTS.cpp:373
+    float nd;
+    if (DPOS) {   // FVector::Dist(...) / 1000.f: a double, narrowed by the assignment to float NodeDistance (ARTS.cpp:372-373)
+        const double ex = dqx - w.dpx, ey = dqy - w.dpy, ez = dqz - w.dpz;
+        nd = (float)(sqrt(ex * ex + ey * ey + ez * ez) / (double)kp.dist_divisor);
+    } else {
+        float ddx = qx - w.px, ddy = qy - w.py, ddz = qz - w.pz;
+        float dist = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);            // ARTS.cpp:372
+        nd = dist / kp.dist_divisor;                                      // ARTS.cpp:373
+    }
     // Record for EvaluatePath (done by connect_kernel in path order): node i of the reference's loop is
     // the DEPARTURE node on the source side and — the listener subpath being reversed in the connected
     // path — the ARRIVAL node on the listener side.
@@ -692,6 +759,7 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
         *st.overflow = 1u;                                               // the host grows the tier and traces again
     }
     w.px = qx; w.py = qy; w.pz = qz;
+    if (DPOS) { w.dpx = dqx; w.dpy = dqy; w.dpz = dqz; }
     w.mat = mat_new;
     w.prob = w.prob_new;
     ++w.k;
@@ -727,7 +795,9 @@ __device__ __forceinline__ uint32_t stage_slots(const WalkStage& sr, const Subpa
     return n;
 }
 
+template <bool EXT = false>
 __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathState& st) {
+    if (EXT && st.end_posd) { st.end_posd[3 * (size_t)w.slot] = w.dpx; st.end_posd[3 * (size_t)w.slot + 1] = w.dpy; st.end_posd[3 * (size_t)w.slot + 2] = w.dpz; }
 #ifdef FS_NT_STORES
     __builtin_nontemporal_store(v4f{w.px, w.py, w.pz, w.prob}, reinterpret_cast<v4f*>(&st.end_pos[w.slot]));
     typedef uint32_t v2u __attribute__((ext_vector_type(2)));
@@ -1022,7 +1092,7 @@ __device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_co
     if (nt) atomicAdd(&counters[first_counter + 1], (unsigned long long)nt);
 }
 
-template <int LOBES, bool COUNT>
+template <int LOBES, bool COUNT, bool EXT = false>
 __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
                                                  const uint32_t* __restrict__ perm, const WalkStage sr = WalkStage()) {
@@ -1049,7 +1119,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     while (true) {
         if (w.k >= sr.end) { walker_suspend(w, st); break; }          // staged walk: the next stage goes on from here
         if (!walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
-            walker_finish(w, st);
+            walker_finish<EXT>(w, st);
             if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
             break;
         }
@@ -1063,7 +1133,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
         ++tl_seg;
 #endif
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
-        walker_apply_hit(w, kp, sc, st, ray, T);
+        walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 #ifdef FS_WAVE_TIMELINE
@@ -1091,7 +1161,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
 // its longest chain of closest-hit queries.  Here a wave owns only `rays_per_wave` subpaths (its first lanes) and
 // the other lanes help with every query — the legacy tracer's scheme (update_sound_shared_kernel).  The loop is
 // wave-uniform: lanes whose walk has ended (or that never had one) keep calling the shared traversal as helpers.
-template <int LOBES, bool COUNT>
+template <int LOBES, bool COUNT, bool EXT = false>
 __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
                                                  const uint32_t* __restrict__ perm, const int rays_per_wave,
@@ -1121,7 +1191,7 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
             else {
                 go = walker_next_ray<LOBES>(w, kp, sc, st, ray);
                 if (!go) {
-                    walker_finish(w, st);
+                    walker_finish<EXT>(w, st);
                     if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
                     alive = false;
                 }
@@ -1131,7 +1201,7 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
         Trav T;
         trav_run_shared<COUNT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
-        if (go) walker_apply_hit(w, kp, sc, st, ray, T);
+        if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 }
@@ -1147,7 +1217,7 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
 // BATCH: a batched frame (fs_compute_energy_response_batch): the pairs of several sources lie end to end
 // (kp.pairs_per_source each) and every source has its own energy buffer (energy_tab / fixed_tab); a workgroup
 // takes (source, chunk) items and flushes its LDS histogram whenever the source changes.
-template <int B, int LOBES, bool BATCH, bool COUNT>
+template <int B, int LOBES, bool BATCH, bool COUNT, bool EXT = false>
 __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t nblocks, const DeviceScene& sc,
                                              const KParams& kp, const SubpathState& st, float* __restrict__ energy,
                                              unsigned long long* __restrict__ fixed, unsigned* queue_head,
@@ -1195,8 +1265,33 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
         float len = sqrtf(l2);
         float inv = 1.0f / len;
         float tmax = len - kp.connect_pullback;
-        const bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
-        Ray ray = make_ray(F.x, F.y, F.z, dx * inv, dy * inv, dz * inv);
+        float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+        float conn_nd = 0.0f;       // FS_FLAG_DOUBLE_POSITIONS: the connection segment's scaled length, from the double end points
+        if (EXT && kp.dpos) {       // (wave-uniform) FVector end points: difference, length and unit direction in double
+            const double* Fd = st.end_posd + 3 * (size_t)sf;
+            const double* Ld = st.end_posd + 3 * (size_t)sl;
+            const double ex = Ld[0] - Fd[0], ey = Ld[1] - Fd[1], ez = Ld[2] - Fd[2];
+            const double e2 = ex * ex + ey * ey + ez * ez;
+            const double elen = sqrt(e2), einv = 1.0 / elen;
+            l2 = e2 > 1e-8f ? 1.0f : 0.0f;                       // only its comparison with 1e-8 is used below
+            ux = (float)(ex * einv); uy = (float)(ey * einv); uz = (float)(ez * einv);
+            tmax = (float)(elen - kp.connect_pullback);
+            conn_nd = (float)(elen / (double)kp.dist_divisor);
+        }
+        bool has_ray = active && (l2 > 1e-8f) && (tmax > 0.0f);
+        Ray ray = make_ray(F.x, F.y, F.z, ux, uy, uz);
+        // ConnectSubpaths ignores no actor (ARTS.cpp:252-254): the end points' collision spheres block
+        bool sphere_blocked = false;
+        if (EXT && has_ray && (kp.listener_radius > 0.0f || kp.source_radius > 0.0f)) {
+            float ts;
+            if (kp.listener_radius > 0.0f && sphere_hit(ray, kp.lis, kp.listener_radius, tmax, ts)) sphere_blocked = true;
+            if (kp.source_radius > 0.0f) {
+                float c[3] = {kp.src[0], kp.src[1], kp.src[2]};
+                if (kp.src_table) { const uint32_t sid = lc / kp.pairs_per_source; c[0] = kp.src_table[3 * sid]; c[1] = kp.src_table[3 * sid + 1]; c[2] = kp.src_table[3 * sid + 2]; }
+                if (sphere_hit(ray, c, kp.source_radius, tmax, ts)) sphere_blocked = true;
+            }
+            if (sphere_blocked) has_ray = false;   // settled without a traversal
+        }
 #ifdef FS_WAVE_TIMELINE
         if (!tl[1]) tl[1] = __builtin_amdgcn_s_memrealtime();   // first chunk: set-up and end-state loads done
 #endif
@@ -1204,7 +1299,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #ifdef FS_WAVE_TIMELINE
         if (!tl[2]) tl[2] = __builtin_amdgcn_s_memrealtime();   // first chunk: visibility queries done
 #endif
-        if (!active || hit) return;
+        if (!active || hit || sphere_blocked) return;
         // depth = 0 only: a walk that outlived the record store has raised the overflow word — the frame is void and will
         // be traced again (FS_ERR_OVERFLOW); its pair must not be evaluated, the records it would read do not exist
         if (st.over_levels && !(rec_fits(st, (int)Fm.y - 1, sf) && rec_fits(st, (int)Lm.y - 1, sl))) return;
@@ -1222,7 +1317,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
         }
         {                                                             // connection segment: F_k's material/prob
             float dist = sqrtf(l2);
-            float nd = dist / kp.dist_divisor;
+            float nd = (EXT && kp.dpos) ? conn_nd : dist / kp.dist_divisor;
             sd += nd;
             apply_segment<B, LOBES>(E, nd, Fm.x, F.w, kp, sc);
         }

@@ -71,7 +71,8 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
     for (int i = 0; i < f.num_walk; ++i) {
         const WalkPart& p = f.walk[i];
         if (!FS_SHARED_WALK(p.wl)) return false;
-        if (p.kp.lobes || p.kp.count || p.kp.num_local == 0) return false;   // the default instantiations only
+        if (p.kp.lobes || p.kp.count || p.kp.dpos || p.kp.listener_radius > 0.0f || p.kp.source_radius > 0.0f || p.kp.num_local == 0)
+            return false;   // the default instantiations only
         WalkArgs& w = a.walk[a.num_walk++];
         w.kp = p.kp; w.st = p.st; w.scratch = p.wl.queue_head; w.perm = p.perm; w.stage = p.stage;
         w.rays_per_wave = p.wl.rays_per_wave > 0 && p.wl.rays_per_wave < 64 ? p.wl.rays_per_wave : 64;
@@ -83,7 +84,7 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
         lds = std::max(lds, stack_bytes(sc) + kShareLdsBytes);
     }
     if (f.has_connect) {
-        if (f.kpc.lobes || f.kpc.count || f.kpc.num_local == 0 || f.ppw < 1 || f.ppw > 64) return false;
+        if (f.kpc.lobes || f.kpc.count || f.kpc.dpos || f.kpc.num_local == 0 || f.ppw < 1 || f.ppw > 64) return false;
         const uint32_t per_block = (uint32_t)f.ppw * (kBlock / 64);
         const uint32_t want = f.energy_tab ? (f.kpc.num_local / f.kpc.pairs_per_source) * ((f.kpc.pairs_per_source + per_block - 1) / per_block)
                                            : (f.kpc.num_local + per_block - 1) / per_block;

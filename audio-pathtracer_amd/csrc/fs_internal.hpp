@@ -93,6 +93,8 @@ struct KParams {
     float norm;            // 1/P or 1/1000 (ARTS.cpp:164)
     float air[FS_MAX_BANDS];
     float src[3], lis[3];
+    int32_t dpos;          // 1 = FS_FLAG_DOUBLE_POSITIONS: node positions, segment and connection lengths in double
+    float listener_radius, source_radius;   // collision spheres of the end points, 0 = points
     int32_t count;         // 1 = COUNT instantiations: the kernels also count the records they fetch (fs_set_profiling level 3)
     int32_t num_bins;
     int32_t num_bands;     // bands of the context (the connect kernels are instantiated for 1, 4 and 8; any other count reads this)
@@ -140,6 +142,8 @@ struct SubpathState {
     // record by slot — cont_a = (position, probability of the current node), cont_b = (normal, material | kCont* flags) —
     // and the next stage (one launch later) resumes from it.  Null for walks that run in one piece.
     float4* cont_a; float4* cont_b;
+    // FS_FLAG_DOUBLE_POSITIONS: the last node's position in double [total][3] by slot (end_pos keeps the float rounding)
+    double* end_posd;
 };
 constexpr uint32_t kContHasNormal = 1u << 16, kContArrived = 1u << 17, kContAlive = 1u << 18;   // cont_b.w above the 16-bit material
 

@@ -54,19 +54,19 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
 }
 #endif
 
-template <int LOBES, bool COUNT>
+template <int LOBES, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm, WalkStage stage) {
-    walk_shared_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, stage);
+    walk_shared_body<LOBES, COUNT, EXT>(blockIdx.x, sc, kp, st, scratch, perm, stage);
 }
 
-template <int LOBES, bool COUNT>
+template <int LOBES, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm, int rays_per_wave,
                                                              WalkStage stage) {
-    walk_sparse_body<LOBES, COUNT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave, stage);
+    walk_sparse_body<LOBES, COUNT, EXT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave, stage);
 }
 
 }  // namespace
@@ -110,7 +110,8 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
     // record-fetch counting (fs_set_profiling level 3) exists for the default walk only (no lobes)
 #define FS_LAUNCH_WALK(K, GRID, ...)                                                                        \
     do {                                                                                                    \
-        if (kp.lobes) { allow_lds(K<1, false>, lds); hipLaunchKernelGGL((K<1, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }        \
+        if (kp.dpos || kp.listener_radius > 0.0f || kp.source_radius > 0.0f) { allow_lds(K<0, false, true>, lds); hipLaunchKernelGGL((K<0, false, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); } \
+        else if (kp.lobes) { allow_lds(K<1, false>, lds); hipLaunchKernelGGL((K<1, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }   \
         else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
         else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \
     } while (0)

@@ -89,6 +89,13 @@ enum {
                                              * far side; EvaluatePath then uses that lobe's gain (diffuse / pi at a connection vertex)
                                              * instead of Absorption / pi.  The reference's walk is diffuse only ("FIXME assuming
                                              * diffuse", ARTS.cpp:304).  Not combinable with FS_FLAG_MIS_BALANCE. */
+#define FS_FLAG_DOUBLE_POSITIONS 256u       /* node positions in double like the reference's FVector (ARTS.h:61): hit point, surface
+                                             * offset, subpath end points, the connection ray's direction and length and every
+                                             * segment length are computed in double and narrowed where the reference narrows them
+                                             * (FVector::Dist(...) / 1000.f assigned to a float, ARTS.cpp:372-373); the line trace itself
+                                             * starts from the float-rounded node as before.  Bit-for-bit the oracle's double-position
+                                             * build (oracle/Makefile target dpos).  Costs a few % of the walk; such frames are never
+                                             * held by fs_set_pipelining.  Not combinable with the lobe / all-connections modes. */
 #define FS_FLAG_DETERMINISTIC 8u            /* deposits are summed as 64-bit integers of 2^-40 energy quanta: the
                                              * histogram no longer depends on the order of the atomics, so it is bit-identical
                                              * from run to run and for every split of the pairs over GPUs (sum-reduce the u64
@@ -132,6 +139,14 @@ typedef struct fs_params {
     float sound_speed;         /* 343       ARTS.cpp:362 */
     float air_absorption[FS_MAX_BANDS]; /* 0.05 per band, ARTS.cpp:395 */
     int32_t samples_per_bin;   /* 0 = reference's ceil(0.001f*48000) = 49 (FSAC.cpp:324) */
+    /* SURVEY A.6-h, HEAD literally: the traces of GeneratePath and ConnectSubpaths query ECC_Pawn as well (ARTS.cpp:243-246,
+     * 331-334).  A walk ignores the actor it starts from (AddIgnoredActor, :322-327) but can hit the OTHER end point's
+     * collision — and then goes on from there with no material; ConnectSubpaths ignores nothing (:252-254): a connection
+     * that starts or ends inside a collision sphere (every connection to B_0 or from F_0) is blocked.  Build-owned engine
+     * semantics: an end point's collision is a sphere around its position (ADefaultPawn: 34 cm), a ray that starts
+     * inside leaves through the far side.  0 (default) = the end point is a point, nothing collides with it. */
+    float listener_radius;     /* cm, 0 = off */
+    float source_radius;       /* cm, 0 = off */
 } fs_params;
 
 typedef struct fs_stats {

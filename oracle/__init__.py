@@ -48,6 +48,8 @@ class Params(C.Structure):
         ("sound_speed", C.c_float),
         ("air_absorption", C.c_float * MAX_BANDS),
         ("flags", C.c_uint32),
+        ("listener_radius", C.c_float),
+        ("source_radius", C.c_float),
     ]
 
 
@@ -143,6 +145,8 @@ def _bind(lib):
     lib.fso_generate_path.restype = C.c_int32
     lib.fso_connect.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Node), C.POINTER(Node), C.POINTER(Counters)]
     lib.fso_connect.restype = C.c_int32
+    lib.fso_connect_ep.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Node), C.POINTER(Node), _f3, _f3, C.POINTER(Counters)]
+    lib.fso_connect_ep.restype = C.c_int32
     lib.fso_evaluate_path.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Node), C.c_int32,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.fso_scene_set_lobes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -523,6 +523,33 @@ int32_t fso_trace_any(const fso_scene* s, const float o[3], const float d[3], fl
     return 0;
 }
 
+/* the end points' collision: a sphere; a ray that starts inside leaves through the far side (build-owned) */
+static int sphere_hit(const float o[3], const float d[3], const float c[3], float r, float tmax, float* t_out) {
+    float ox = o[0] - c[0], oy = o[1] - c[1], oz = o[2] - c[2];
+    float b = fmaf(ox, d[0], fmaf(oy, d[1], oz * d[2]));
+    float cc = fmaf(ox, ox, fmaf(oy, oy, oz * oz)) - r * r;
+    float disc = fmaf(b, b, -cc);
+    if (!(disc >= 0.0f)) return 0;
+    float sq = sqrtf(disc);
+    float t = -b - sq;
+    if (!(t > 0.0f)) t = sq - b;
+    if (!(t > 0.0f && t <= tmax)) return 0;
+    *t_out = t;
+    return 1;
+}
+
+
+/* ImpactNormal of a sphere hit: unit (impact - centre), flipped to face the ray origin side like a triangle's */
+static void sphere_normal(const float o[3], const float d[3], float t, const float c[3], float n[3]) {
+    float x = fmaf(t, d[0], o[0]) - c[0], y = fmaf(t, d[1], o[1]) - c[1], z = fmaf(t, d[2], o[2]) - c[2];
+    float l2 = x * x + y * y + z * z;
+    float inv = 1.0f / sqrtf(l2);
+    x = x * inv; y = y * inv; z = z * inv;
+    float dn = fmaf(x, d[0], fmaf(y, d[1], z * d[2]));
+    if (dn > 0.0f) { x = -x; y = -y; z = -z; }
+    n[0] = x; n[1] = y; n[2] = z;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* GeneratePath  ARTS.cpp:279-355                                                              */
 /* ------------------------------------------------------------------------------------------- */
@@ -537,7 +564,8 @@ static int32_t depth_cap(const fso_params* p) {
 /* The walk.  Nodes go to *nodes (capacity *cap); grow != 0: the buffer is realloc'ed as needed, else the walk is cut
  * at the capacity. */
 static int32_t generate_path(const fso_scene* s, const fso_params* p, uint32_t pair, uint32_t side,
-                             const float start[3], fso_node** nodes_io, int32_t* cap_io, int grow, fso_counters* c) {
+                             const float start[3], const float* other, float other_radius, fso_node** nodes_io,
+                             int32_t* cap_io, int grow, fso_counters* c) {
     fso_node* nodes = *nodes_io;
     int32_t max_nodes = *cap_io;
     const int32_t cap = depth_cap(p);
@@ -620,7 +648,16 @@ static int32_t generate_path(const fso_scene* s, const fso_params* p, uint32_t p
         /* 3. closest hit on [pos, pos + dir * MAX_RAYCAST_DIST] ARTS.cpp:339-342 */
         float t, hn[3]; int32_t tri;
         if (!shifted) for (int q = 0; q < 3; ++q) org[q] = (float)pos[q];
-        if (fso_trace_closest(s, org, dir, p->max_trace_dist, brute, &t, &tri, hn, c)) {
+        int hit = fso_trace_closest(s, org, dir, p->max_trace_dist, brute, &t, &tri, hn, c);
+        /* the OTHER end point's collision sphere (ECC_Pawn is queried, the walk's own actor is ignored: ARTS.cpp:322-334);
+         * it wins ties with a triangle, like the pawn in the legacy tracer */
+        int on_sphere = 0;
+        float ts = 0.f;
+        if (other && other_radius > 0.0f && sphere_hit(org, dir, other, other_radius, p->max_trace_dist, &ts) && (!hit || ts <= t)) {
+            hit = 1; on_sphere = 1; t = ts;
+            sphere_normal(org, dir, ts, other, hn);
+        }
+        if (hit) {
             /* 4. ARTS.cpp:345-347 */
             for (int q = 0; q < 3; ++q) {
 #ifdef FSO_DOUBLE_POSITIONS   /* Hit.ImpactPoint + Hit.ImpactNormal * 0.1f in FVector (double) arithmetic */
@@ -635,7 +672,7 @@ static int32_t generate_path(const fso_scene* s, const fso_params* p, uint32_t p
             }
             has_normal = 1;
             arrived = 1;
-            mat = s->tris_orig[tri].material;
+            mat = on_sphere ? FSO_NO_MATERIAL : s->tris_orig[tri].material;   /* a pawn has no UAcousticGeometryComponent */
         } else {
             arrived = 0;
         }
@@ -646,7 +683,7 @@ static int32_t generate_path(const fso_scene* s, const fso_params* p, uint32_t p
 
 int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair, uint32_t side,
                           const float start[3], fso_node* nodes, int32_t max_nodes, fso_counters* c) {
-    return generate_path(s, p, pair, side, start, &nodes, &max_nodes, 0, c);
+    return generate_path(s, p, pair, side, start, NULL, 0.0f, &nodes, &max_nodes, 0, c);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -654,6 +691,11 @@ int32_t fso_generate_path(const fso_scene* s, const fso_params* p, uint32_t pair
 /* ------------------------------------------------------------------------------------------- */
 int32_t fso_connect(const fso_scene* s, const fso_params* p, const fso_node* f, const fso_node* b,
                     fso_counters* c) {
+    return fso_connect_ep(s, p, f, b, NULL, NULL, c);
+}
+
+int32_t fso_connect_ep(const fso_scene* s, const fso_params* p, const fso_node* f, const fso_node* b, const float* src,
+                       const float* lis, fso_counters* c) {
     fso_pos_t dx = b->pos[0] - f->pos[0], dy = b->pos[1] - f->pos[1], dz = b->pos[2] - f->pos[2];
     fso_pos_t l2 = dx * dx + dy * dy + dz * dz;
     if (!(l2 > 1e-8f)) { /* GetSafeNormal() == 0: zero-length trace, nothing to hit */
@@ -670,6 +712,13 @@ int32_t fso_connect(const fso_scene* s, const fso_params* p, const fso_node* f, 
     float tmax = (float)(len - p->connect_pullback); /* End = B - 0.1 * unit(B - F), ARTS.cpp:253 */
     if (!(tmax > 0.0f)) { if (c) c->any_rays++; return 1; }
     const float o[3] = {(float)f->pos[0], (float)f->pos[1], (float)f->pos[2]};
+    /* ConnectSubpaths ignores no actor (ARTS.cpp:252-254): both end points' collision spheres block */
+    float ts;
+    if ((lis && p->listener_radius > 0.0f && sphere_hit(o, d, lis, p->listener_radius, tmax, &ts)) ||
+        (src && p->source_radius > 0.0f && sphere_hit(o, d, src, p->source_radius, tmax, &ts))) {
+        if (c) c->any_rays++;
+        return 0;
+    }
     return !fso_trace_any(s, o, d, tmax, (p->flags & FSO_FLAG_BRUTE_FORCE) != 0, c);
 }
 
@@ -824,8 +873,8 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
     /* NormalizationFactor ARTS.cpp:164 (quirk A.6-c: literally 1/1000) */
     float norm = (p->flags & FSO_FLAG_FIXED_NORM_1000) ? 1.0f / 1000.0f : 1.0f / (float)p->num_pairs;
     for (uint32_t i = pair_begin; i < pair_end; ++i) {     /* GenerateFullPaths ARTS.cpp:215-230 */
-        int32_t nf = generate_path(s, p, i, 0, src, &fwd, &cap_f, 1, c);
-        int32_t nb = generate_path(s, p, i, 1, lis, &bwd, &cap_b, 1, c);
+        int32_t nf = generate_path(s, p, i, 0, src, lis, p->listener_radius, &fwd, &cap_f, 1, c);
+        int32_t nb = generate_path(s, p, i, 1, lis, src, p->source_radius, &bwd, &cap_b, 1, c);
         if (nf + nb > cap_all) { cap_all = 2 * (nf + nb); all = (fso_node*)realloc(all, sizeof(fso_node) * (size_t)cap_all); }
         if (nf == 0 || nb == 0) continue;                  /* ARTS.cpp:237 */
         if (p->flags & (FSO_FLAG_ALL_CONNECTIONS | FSO_FLAG_MIS_BALANCE)) {
@@ -839,7 +888,7 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
             int32_t D = p->depth > 0 ? p->depth : (depth_cap(p) == INT32_MAX ? FSO_UNBOUNDED_DEPTH : FSO_MAX_DEPTH);
             for (int32_t fi = 0; fi < nf; ++fi)
                 for (int32_t bj = 0; bj < nb; ++bj) {
-                    if (!fso_connect(s, p, &fwd[fi], &bwd[bj], c)) continue;
+                    if (!fso_connect_ep(s, p, &fwd[fi], &bwd[bj], src, lis, c)) continue;
                     if (c) c->connected++;
                     memcpy(all, fwd, sizeof(fso_node) * (size_t)(fi + 1));
                     for (int32_t j = 0; j <= bj; ++j) all[fi + 1 + j] = bwd[bj - j];
@@ -864,7 +913,7 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
                 }
             continue;
         }
-        if (!fso_connect(s, p, &fwd[nf - 1], &bwd[nb - 1], c)) continue;
+        if (!fso_connect_ep(s, p, &fwd[nf - 1], &bwd[nb - 1], src, lis, c)) continue;
         if (c) c->connected++;
         /* node order F0..Fk, Bm..B0 ARTS.cpp:262-267 */
         memcpy(all, fwd, sizeof(fso_node) * (size_t)nf);
@@ -928,20 +977,6 @@ void fso_reconstruct(const float* energy, int32_t num_bins, int32_t sample_rate,
 /* id per triangle (fso_scene_set_objects); the player pawn is a sphere of listener_radius at the */
 /* listener position; the source's own actor has no geometry.                                    */
 /* ------------------------------------------------------------------------------------------- */
-static int sphere_hit(const float o[3], const float d[3], const float c[3], float r, float tmax, float* t_out) {
-    float ox = o[0] - c[0], oy = o[1] - c[1], oz = o[2] - c[2];
-    float b = fmaf(ox, d[0], fmaf(oy, d[1], oz * d[2]));
-    float cc = fmaf(ox, ox, fmaf(oy, oy, oz * oz)) - r * r;
-    float disc = fmaf(b, b, -cc);
-    if (!(disc >= 0.0f)) return 0;
-    float sq = sqrtf(disc);
-    float t = -b - sq;
-    if (!(t > 0.0f)) t = sq - b;
-    if (!(t > 0.0f && t <= tmax)) return 0;
-    *t_out = t;
-    return 1;
-}
-
 #define FSO_PAWN_OBJECT 0xFFFFFFFEu
 /* closest blocking hit among the triangles (minus one ignored actor) and the pawn sphere */
 static int legacy_trace(const fso_scene* s, const float o[3], const float d[3], float tmax, uint32_t ignore,

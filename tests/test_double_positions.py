@@ -35,3 +35,10 @@ def test_float_positions_stay_far_below_the_parity_bar(pkg, oracle_mod):
     far = compare(pkg, oracle_mod, "starter_room", 4, 8192, 8, offset=4.0e6)
     print("starter_room + 40 km:", far)
     assert far["segments_f32"] == far["segments_f64"]
+    # gates, not printouts: the deviation is a handful of visibility flips (each one path of several thousand) — bounded
+    # here; FS_FLAG_DOUBLE_POSITIONS removes it altogether (tests/test_round3.py checks the product against the double build)
+    assert far["rel_rms"] < 0.2 and abs(far["connected_f32"] - far["connected_f64"]) <= 0.05 * far["connected_f64"]
+    mine = compare(pkg, oracle_mod, "old_mine", 8, 16384, 8)
+    print("old_mine:", mine)
+    assert mine["segments_f32"] == mine["segments_f64"] and mine["rel_rms"] < 2e-2
+    assert abs(mine["connected_f32"] - mine["connected_f64"]) <= 4

@@ -551,3 +551,29 @@ def test_kat_lobe_gain_in_evaluate_path(oracle_mod):
     assert gain(0, p_on) == pytest.approx(base * 0.15 / math.pi, rel=1e-5)
     assert gain(1, p_on) == pytest.approx(base * 0.45, rel=1e-5)
     assert gain(2, p_on) == pytest.approx(base * 0.4, rel=1e-5)
+
+
+def test_connection_into_a_collision_sphere_is_blocked():
+    """SURVEY A.6-h by hand: ConnectSubpaths' trace runs from F to B - 0.1 cm * unit(B - F) and ignores no actor
+    (ARTS.cpp:252-254); with the listener pawn's collision sphere (radius R > 0.1 cm) around B_0 the trace ends inside the
+    sphere, so it crosses its surface: blocked.  Without the sphere the same connection through free air is open.  A walk
+    that starts at the listener ignores the pawn (AddIgnoredActor) — only the OTHER end point's sphere can be hit."""
+    import oracle
+    sc_tris = np.array([[[-5000, -5000, -100], [5000, -5000, -100], [0, 5000, -100]]], dtype=np.float32)   # a floor far below
+    s = oracle.Scene(sc_tris, np.zeros(1, np.uint16), np.full((1, 1), 0.5, np.float32))
+    lib = oracle.load()
+    f = oracle.Node(); b = oracle.Node()
+    for k, v in enumerate((0.0, 0.0, 100.0)): f.pos[k] = v
+    for k, v in enumerate((300.0, 0.0, 100.0)): b.pos[k] = v
+    src = (oracle.C.c_float * 3)(0.0, 0.0, 100.0)
+    lis = (oracle.C.c_float * 3)(300.0, 0.0, 100.0)
+    for radius, want in ((0.0, 1), (0.05, 1), (0.5, 0), (34.0, 0)):
+        p = oracle.default_params(listener_radius=radius)
+        assert lib.fso_connect_ep(s.h, oracle.C.byref(p), oracle.C.byref(f), oracle.C.byref(b), src, lis, None) == want, radius
+    # the source's own sphere blocks a connection that starts at F_0 just the same
+    p = oracle.default_params(source_radius=20.0)
+    assert lib.fso_connect_ep(s.h, oracle.C.byref(p), oracle.C.byref(f), oracle.C.byref(b), src, lis, None) == 0
+    # ... but not one that passes 40 cm beside it
+    for k, v in enumerate((0.0, 40.0, 100.0)): f.pos[k] = v
+    for k, v in enumerate((300.0, 40.0, 100.0)): b.pos[k] = v
+    assert lib.fso_connect_ep(s.h, oracle.C.byref(p), oracle.C.byref(f), oracle.C.byref(b), src, lis, None) == 1

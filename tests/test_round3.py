@@ -180,3 +180,99 @@ def test_walk_stage_bounds_are_validated(pkg, scene_factory):
     ctx.synchronize()
     assert ctx.energy_buffer(src).any()
     ctx.close()
+
+
+# ---- FS_FLAG_DOUBLE_POSITIONS: node positions like the reference's FVector -----------------------------------------
+DPOS = 256
+
+
+@pytest.mark.parametrize("name,bands,rays,depth,offset", [
+    ("starter_room", 4, 16384, 8, 0.0),
+    ("old_mine", 8, 65536, 8, 0.0),              # the cfg3 scene: coordinates to +-120 m
+    ("old_mine", 8, 65536, 8, 1.0e6),            # ... 10 km from the origin: fp32 positions resolve 0.06 cm there
+    ("starter_room", 2, 4096, 0, 4.0e6),         # uncapped walks, 40 km out
+], ids=["room", "mine", "mine_10km", "room_40km_uncapped"])
+def test_double_positions_match_the_double_position_oracle(pkg, oracle_mod, scene_factory, name, bands, rays, depth, offset):
+    """FS_FLAG_DOUBLE_POSITIONS carries hit points, end points, the connection and every segment length in double and
+    narrows where the reference narrows (ARTS.h:61, ARTS.cpp:372-373).  Its parity reference is the oracle's
+    -DFSO_DOUBLE_POSITIONS build: the same walks, the same connections (not one visibility flip), identical bins, energy to
+    the atomics' rounding — also where fp32 positions visibly fail (10 and 40 km from the origin)."""
+    sc = scene_factory(name, bands)
+    tri = (sc.triangles.astype(np.float64) + offset).astype(np.float32)
+    src_pos = (np.asarray(sc.source, np.float64) + offset).astype(np.float32)
+    lis_pos = (np.asarray(sc.listener, np.float64) + offset).astype(np.float32)
+    ctx = pkg.Context(num_bands=bands)
+    ctx.set_scene(tri, sc.material_ids, sc.absorption)
+    ctx.set_listener(lis_pos)
+    src = ctx.create_source(src_pos)
+    ctx.reset_stats()
+    e_gpu = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=0x5EED, flags=DPOS))
+    st = ctx.stats()
+    dlib = oracle_mod.load_dpos()
+    osc = oracle_mod.Scene(tri, sc.material_ids, sc.absorption, lib=dlib)
+    e32, e64, cnt = osc.compute_energy_mt(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=0x5EED), src_pos, lis_pos, 8)
+    assert cnt.connected > 0
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)   # 0 flips
+    assert np.array_equal(e_gpu != 0, e64 != 0)
+    worst = max(rel_rms(e_gpu[b], e64[b]) for b in range(bands))
+    assert worst <= 5e-6, worst
+    # and the flag is what makes the difference far from the origin: the float-position frame there is another frame
+    if offset >= 1.0e6:
+        e_f32 = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=0x5EED))
+        assert not np.array_equal(e_f32, e_gpu)
+    with pytest.raises(pkg.FrequenSeeError):
+        ctx.compute_energy_response(src, pkg.default_params(num_rays=1024, depth=4, flags=DPOS | 16))
+    ctx.close()
+
+
+# ---- SURVEY A.6-h: the end points' collision spheres (HEAD's ECC_Pawn traces) ------------------------------------------
+@pytest.mark.parametrize("name,bands,rays,depth,lr,sr,flags", [
+    ("shoebox", 1, 2048, 6, 34.0, 0.0, 0),
+    ("starter_room", 4, 16384, 8, 34.0, 20.0, 0),
+    ("starter_room", 2, 4096, 0, 60.0, 60.0, 0),       # uncapped walks, big spheres: many walks land on them
+    ("old_mine", 8, 32768, 8, 34.0, 34.0, 8),          # deterministic deposits
+    ("starter_room", 2, 2048, 5, 34.0, 25.0, 16),      # every forward prefix x every backward prefix
+    ("starter_room", 4, 8192, 8, 34.0, 20.0, 256),     # together with double positions
+], ids=["listener_only", "both", "uncapped_big", "mine_det", "all_connections", "with_double_positions"])
+def test_end_point_collision_spheres(pkg, oracle_mod, scene_factory, name, bands, rays, depth, lr, sr, flags):
+    """At HEAD GeneratePath's and ConnectSubpaths' traces include ECC_Pawn: a walk can land on the OTHER end point's
+    collision (and goes on from there, without a material), and every connection that starts or ends inside a sphere is
+    blocked.  fs_params.listener_radius / source_radius reproduce that (0 = points, the default): same walks, same
+    connections, same bins as the oracle; and the frame differs from the one without spheres."""
+    sc = scene_factory(name, bands)
+    ctx, src = make_ctx(pkg, sc)
+    ctx.reset_stats()
+    e_gpu = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=31, flags=flags,
+                                                                listener_radius=lr, source_radius=sr))
+    st = ctx.stats()
+    lib = oracle_mod.load_dpos() if flags & 256 else None
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption, lib=lib)
+    op = oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=31, flags=flags & ~(8 | 256), listener_radius=lr, source_radius=sr)
+    e32, e64, cnt = osc.compute_energy_mt(op, sc.source, sc.listener, 8)
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+    assert np.array_equal(e_gpu != 0, e64 != 0)
+    if cnt.connected:
+        assert max(rel_rms(e_gpu[b], e64[b]) for b in range(bands)) <= TIGHT_TOL
+    plain = ctx.compute_energy_response(src, pkg.default_params(num_rays=rays, depth=depth, seed=31, flags=flags))
+    assert not np.array_equal(plain, e_gpu)
+    ctx.close()
+
+
+def test_collision_spheres_in_batches_and_pipelines(pkg, scene_factory):
+    """Frames with spheres are never held by the frame pipeline and batch like any other frame (every source its own
+    sphere): equal to the separate, unpipelined frames bit for bit in deterministic mode."""
+    sc = scene_factory("starter_room", 4)
+    rng = np.random.default_rng(8)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    pos = [(sc.source + rng.uniform(-0.08, 0.08, 3) * (hi - lo)).astype(np.float32) for _ in range(3)]
+    p = pkg.default_params(num_rays=4096, depth=8, seed=5, flags=DET, listener_radius=34.0, source_radius=30.0)
+    ctx, _ = make_ctx(pkg, sc)
+    srcs = [ctx.create_source(q) for q in pos]
+    want = [ctx.compute_energy_response(s, p).copy() for s in srcs]
+    ctx.set_pipelining(2)
+    ctx.compute_energy_response_batch_async(srcs, p)
+    ctx.compute_energy_response_batch_async(srcs, p)
+    ctx.synchronize()
+    for s, w in zip(srcs, want):
+        assert w.any() and np.array_equal(ctx.energy_buffer(s), w)
+    ctx.close()
