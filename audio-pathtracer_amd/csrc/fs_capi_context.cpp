@@ -26,7 +26,9 @@ hipError_t wait_energy_readers(fs_context* ctx, Source* s) { return wait_energy_
 hipError_t handoff_energy(fs_context* ctx, Source* s) {
     hipError_t e = hipEventRecord(s->ev_dep, ctx->stream);
     if (e != hipSuccess) return e;
-    return hipStreamWaitEvent(ctx->copy_stream, s->ev_dep, 0);
+    e = hipStreamWaitEvent(ctx->copy_stream, s->ev_dep, 0);
+    if (e == hipSuccess) s->tail_ordered = true;   // until the compute stream writes the buffer again
+    return e;
 }
 
 void free_source(fs_context* ctx, Source* s) {

@@ -41,13 +41,13 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
         Source* s = it.s;
         const bool moved_on = s->cur != it.cur;
         const int cur = s->cur;
-        const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off;
-        s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
+        const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
+        s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false; s->tail_ordered = false;
         int rc = FS_OK;
         if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
         if (ctx->comm) rc = reduce_energy(ctx, s);
         if (!rc && it.want_recon) rc = reconstruct_now(ctx, s, &it.recon);
-        if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; }
+        if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered; }
         if (rc) return rc;
     }
     return FS_OK;
@@ -134,7 +134,10 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     // The tail stream takes over: it waits for this frame's deposit (and runs behind any collective the caller
     // put there after fs_energy_handoff), reconstructs and publishes while the compute stream goes on to the
     // next frame.  Reconstructs and publishes of one source are ordered among themselves by the tail stream.
-    FS_HIP(ctx, handoff_energy(ctx, s));
+    // (A frame the library has just summed over the ranks — or that the caller took over with fs_energy_handoff — is
+    // already ordered: a second event pair per frame on the compute stream is a second bubble between its launches,
+    // 2 % of a cfg3 frame: tools/rccl_tax.sh.)
+    if (!s->tail_ordered || (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)) FS_HIP(ctx, handoff_energy(ctx, s));
     hipStream_t tail = ctx->copy_stream;
     {
         std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
@@ -379,7 +382,7 @@ void frame_commit(fs_context* ctx, Frame& f) {
         Source* si = f.srcs[i];
         si->cur = f.cur_of[i];
         si->cur_fixed = f.fixed;
-        si->reduced = false; si->handed_off = false;
+        si->reduced = false; si->handed_off = false; si->tail_ordered = false;
     }
 }
 
@@ -850,6 +853,7 @@ int fs_flush_energy_buffer(fs_context* ctx, fs_source h) {
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
     s->handed_off = true;   // the caller owns the content now
+    s->tail_ordered = false;  // ... and writes it on the compute stream below
     FS_HIP(ctx, wait_energy_readers(ctx, s));
     FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
                                ctx->stream));
@@ -866,6 +870,7 @@ int fs_add_energy_at_delay(fs_context* ctx, fs_source h, int32_t band, float del
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
     s->handed_off = true;   // the caller owns the content now
+    s->tail_ordered = false;  // ... and writes it on the compute stream below
     FS_HIP(ctx, wait_energy_readers(ctx, s));
     launch_add_energy(s->energy() + (size_t)band * (size_t)ctx->num_bins, ctx->num_bins, delay_seconds, energy,
                       ctx->stream);
@@ -884,6 +889,7 @@ int fs_update_energy_buffer(fs_context* ctx, fs_source h, const float* values, i
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     s->cur_fixed = false;   // the fp32 buffer is the truth again (a deterministic frame left its fixed-point twin behind)
     s->handed_off = true;   // the caller owns the content now
+    s->tail_ordered = false;  // ... and writes it on the compute stream below
     FS_HIP(ctx, wait_energy_readers(ctx, s));
     FS_HIP(ctx, hipMemcpyAsync(s->energy(), values, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -69,6 +69,7 @@ struct Source {
     // multi-GPU: the frame in the current buffer has been summed over the ranks (library collective), or handed to the
     // caller's collective (fs_energy_handoff); a world_size > 1 context refuses to reconstruct a frame that is neither
     bool reduced = false, handed_off = false;
+    bool tail_ordered = false;         // the tail stream already waits for everything the compute stream wrote into the current buffer
     hipEvent_t ev_red[kEnergyBufs] = {};   // tail stream: the library's all-reduce of buffer i is done
     bool red_recorded[kEnergyBufs] = {};
     // deterministic mode (FS_FLAG_DETERMINISTIC): u64 fixed-point histograms [B][bins], allocated on first use,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""fs_scene_commit (host binned-SAH build) against fs_scene_commit_fast (device Morton / Karras build) at the cfg3
+"""fs_scene_commit (host binned-SAH build) against fs_scene_commit_fast (device build: Morton order + PLOC) at the cfg3
 scene, and what each tree costs per traced frame.  usage (GPU box): python tools/measure_commit.py"""
 import json
 import os
