@@ -82,6 +82,10 @@ class Context:
     def comm_attach(self, nccl_comm: int):
         self.check(self.lib.fs_comm_attach(self.h, C.c_void_p(int(nccl_comm))))
 
+    def comm_enable_oneshot(self):
+        """collective: the energy buffer's sum over the ranks as one peer-write exchange (HIP IPC mailboxes) instead of ncclAllReduce"""
+        self.check(self.lib.fs_comm_enable_oneshot(self.h))
+
     def comm_detach(self):
         self.check(self.lib.fs_comm_detach(self.h))
 

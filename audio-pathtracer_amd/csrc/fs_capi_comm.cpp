@@ -51,7 +51,13 @@ int reduce_energy(fs_context* ctx, Source* s) {
     if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
     FS_HIP(ctx, handoff_energy(ctx, s));
     const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
-    if (s->cur_fixed) {   // deterministic mode: integer sum of the fixed-point histogram, rounded to fp32 once, behind it
+    if (ctx->oneshot.on) {   // one exchange step through the peers' mailboxes (fs_comm_enable_oneshot)
+        const uint32_t seq = ++ctx->oneshot.seq;
+        launch_oneshot_reduce(ctx->oneshot.view, s->cur_fixed ? (void*)s->d_fixed[s->cur] : (void*)s->energy(), (int)words, s->cur_fixed,
+                              (int)(seq & 1u), seq, ctx->oneshot.d_err, ctx->copy_stream);
+        FS_HIP(ctx, hipGetLastError());
+        if (s->cur_fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), (int)words, ctx->copy_stream);
+    } else if (s->cur_fixed) {   // deterministic mode: integer sum of the fixed-point histogram, rounded to fp32 once, behind it
         FS_NCCL(ctx, a->AllReduce(s->d_fixed[s->cur], s->d_fixed[s->cur], words, ncclUint64, ncclSum, ctx->comm, ctx->copy_stream));
         launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), (int)words, ctx->copy_stream);
     } else
@@ -62,9 +68,100 @@ int reduce_energy(fs_context* ctx, Source* s) {
     return FS_OK;
 }
 
+// unmap the peers' mailboxes and free this rank's (fs_comm_detach; a no-op when the one-shot reduce was never enabled)
+void oneshot_release(fs_context* ctx) {
+    fs_context::OneShot& o = ctx->oneshot;
+    if (!o.own_mail && !o.d_err) return;
+    for (int r = 0; r < o.view.world; ++r)
+        if (r != o.view.rank && o.view.mail[r]) (void)hipIpcCloseMemHandle(o.view.mail[r]);
+    if (o.own_mail) (void)hipFree(o.own_mail);
+    if (o.d_err) (void)hipFree(o.d_err);
+    o = fs_context::OneShot{};
+}
+
+// did a one-shot sum give up waiting for a peer?  (called where the tail stream has been synchronised)
+int oneshot_check(fs_context* ctx) {
+    if (!ctx->oneshot.on || !ctx->oneshot.d_err) return FS_OK;
+    unsigned e = 0;
+    FS_HIP(ctx, hipMemcpy(&e, ctx->oneshot.d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (!e) return FS_OK;
+    FS_HIP(ctx, hipMemset(ctx->oneshot.d_err, 0, sizeof(e)));
+    return ctx->fail(FS_ERR_COMM, "one-shot reduce: a rank's contribution did not arrive in time (the frame's sum is incomplete)");
+}
+
 }  // namespace fsi
 
 extern "C" {
+
+int fs_comm_enable_oneshot(fs_context* ctx) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (!ctx->comm) return ctx->fail(FS_ERR_COMM, "fs_comm_enable_oneshot needs a communicator (fs_comm_init / fs_comm_attach) first");
+    if (ctx->oneshot.on) return FS_OK;
+    const int W = ctx->cfg.world_size, me = ctx->cfg.rank;
+    if (W > kOneShotMaxRanks) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "one-shot reduce: at most 16 ranks");
+    RcclApi* a = rccl();
+    if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
+    FS_FLUSH(ctx);
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    fs_context::OneShot& o = ctx->oneshot;
+    // Every step below is collective: a rank that fails locally still takes part in the exchanges and the ranks agree on
+    // the outcome at the end (MIN over an "ok" word) — either all of them use the mailboxes from now on or none does.
+    int ok = 1;
+    std::string why;                                   // this rank's first local failure, for the error text
+    auto hip_step = [&](hipError_t err, const char* what) {
+        if (err != hipSuccess && ok) { ok = 0; why = std::string(what) + ": " + hipGetErrorString(err); }
+        return err == hipSuccess;
+    };
+    const size_t slot = (sizeof(unsigned long long) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins + 255) & ~(size_t)255;   // room for the u64 histogram
+    const size_t bytes = kOneShotHeaderBytes + 2 * (size_t)W * slot;
+    hipIpcMemHandle_t mine{};
+    // The mailbox is written by other devices while this one polls it: fine-grained memory (no stale L2 lines on either
+    // side) where the runtime can share such an allocation; plain device memory otherwise (the accesses are system-scope
+    // atomics either way).
+    bool fine = hipExtMallocWithFlags(&o.own_mail, bytes, hipDeviceMallocFinegrained) == hipSuccess;
+    if (fine && hipIpcGetMemHandle(&mine, o.own_mail) != hipSuccess) { (void)hipFree(o.own_mail); o.own_mail = nullptr; fine = false; }
+    (void)hipGetLastError();
+    if ((fine || hip_step(hipMalloc(&o.own_mail, bytes), "hipMalloc(mailbox)")) && hip_step(hipMemset(o.own_mail, 0, bytes), "hipMemset(mailbox)") &&
+        hip_step(hipMalloc((void**)&o.d_err, sizeof(unsigned)), "hipMalloc(err)") && hip_step(hipMemset(o.d_err, 0, sizeof(unsigned)), "hipMemset(err)"))
+        (void)hip_step(hipIpcGetMemHandle(&mine, o.own_mail), "hipIpcGetMemHandle");
+    (void)hipGetLastError();
+    // all-gather of the 64-byte IPC handles over the communicator (device staging), then map every peer's mailbox
+    char* d_h = nullptr;
+    std::vector<hipIpcMemHandle_t> all((size_t)W);
+    if (hipMalloc((void**)&d_h, sizeof(hipIpcMemHandle_t) * (size_t)(W + 1)) != hipSuccess) return ctx->fail(FS_ERR_OUT_OF_MEMORY, "one-shot reduce: staging");
+    hipError_t e = hipMemcpyAsync(d_h + sizeof(mine) * (size_t)W, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->copy_stream);
+    ncclResult_t nr = a->AllGather(d_h + sizeof(mine) * (size_t)W, d_h, sizeof(mine), ncclUint8, ctx->comm, ctx->copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(all.data(), d_h, sizeof(mine) * (size_t)W, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+    if (nr != ncclSuccess && ok) { ok = 0; why = "ncclAllGather(IPC handles) failed"; }
+    (void)hip_step(e, "handle exchange");
+    o.view = OneShotView{};
+    o.view.world = W; o.view.rank = me; o.view.slot_bytes = slot;
+    for (int r = 0; r < W && ok; ++r) {
+        if (r == me) { o.view.mail[r] = o.own_mail; continue; }
+        if (!hip_step(hipIpcOpenMemHandle(&o.view.mail[r], all[(size_t)r], hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle")) o.view.mail[r] = nullptr;
+    }
+    (void)hipGetLastError();
+    // agreement
+    int* d_ok = reinterpret_cast<int*>(d_h);
+    e = hipMemcpyAsync(d_ok, &ok, sizeof(int), hipMemcpyHostToDevice, ctx->copy_stream);
+    nr = a->AllReduce(d_ok, d_ok, 1, ncclInt32, ncclMin, ctx->comm, ctx->copy_stream);
+    int all_ok = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&all_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+    (void)hipFree(d_h);
+    if (nr != ncclSuccess || e != hipSuccess) all_ok = 0;
+    if (!all_ok) {
+        oneshot_release(ctx);
+        return ctx->fail(FS_ERR_COMM, "one-shot reduce: the ranks could not map each other's mailboxes (HIP IPC); ncclAllReduce stays in use" +
+                         (why.empty() ? std::string(" (another rank failed)") : " (" + why + ")"));
+    }
+    o.seq = 0;
+    o.on = true;
+    return FS_OK;
+}
 
 int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t* pair_begin, uint32_t* pair_count) {
     if (world_size < 1 || rank < 0 || rank >= world_size || (num_rays & 1u)) return FS_ERR_INVALID_ARGUMENT;
@@ -129,6 +226,7 @@ int fs_comm_detach(fs_context* ctx) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(ctx->copy_stream);
     }
+    oneshot_release(ctx);
     RcclApi* a = rccl();
     if (ctx->comm_owned && a) (void)a->CommDestroy(ctx->comm);
     ctx->comm = nullptr;

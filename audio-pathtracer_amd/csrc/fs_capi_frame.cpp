@@ -669,6 +669,13 @@ int fs_compute_energy_response(fs_context* ctx, fs_source h, const fs_params* p,
     }
     if (rc) return rc;
     Source* s = get_source(ctx, h);
+    // sharded frame: the sum over the ranks runs on the tail stream — the caller gets the SUMMED buffer (found by the
+    // one-shot reduce's test: the RCCL test double works synchronously and hid the missing wait)
+    if (ctx->comm) {
+        FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        const int oc = oneshot_check(ctx);
+        if (oc) return oc;
+    }
     if (energy_out) {
         FS_HIP(ctx, hipMemcpyAsync(energy_out, s->energy(),
                                    sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins,
@@ -783,6 +790,7 @@ int fs_synchronize(fs_context* ctx) {
     for (Source* s : ctx->sources)
         if (s && s->alive) poll_published(s);
     resolve_timings(ctx);
+    { const int oc = oneshot_check(ctx); if (oc) return oc; }
     return check_overflow(ctx);   // FS_ERR_OVERFLOW: the last depth = 0 frame must be traced again (see the header)
 }
 

@@ -163,6 +163,14 @@ struct fs_context {
     // multi-GPU: RCCL communicator over the ranks that share the pairs of every frame
     ncclComm_t comm = nullptr;
     // cfg5 (independent sources, one per GPU): a communicator that never touches a frame — only fs_gather_energy uses it
+    // fs_comm_enable_oneshot: the energy buffer's sum as one peer-write exchange instead of ncclAllReduce (fs_oneshot.hip)
+    struct OneShot {
+        bool on = false;
+        OneShotView view{};
+        void* own_mail = nullptr;         // this rank's mailbox (hipMalloc); the others are IPC mappings
+        unsigned* d_err = nullptr;        // raised by a sum kernel that gave up waiting for a peer
+        uint32_t seq = 0;                 // reduces issued so far
+    } oneshot;
     ncclComm_t peers = nullptr;
     int peers_size = 0;
     float* d_gather = nullptr; size_t gather_cap = 0;   // [peers][B][bins] fp32
@@ -319,5 +327,7 @@ struct RcclApi {
 RcclApi* rccl();   // nullptr: librccl is not loadable
 int nccl_fail(fs_context* ctx, ncclResult_t r, const char* what);
 int reduce_energy(fs_context* ctx, Source* s);   // sum the source's current energy buffer over the ranks (tail stream)
+void oneshot_release(fs_context* ctx);
+int oneshot_check(fs_context* ctx);             // FS_ERR_COMM if a one-shot sum gave up waiting (tail stream synchronised)
 
 }  // namespace fsi

@@ -243,6 +243,19 @@ void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, 
 // dynamic LDS the traversal kernels of a frame need for a tree with `stack_rows` stack rows: the larger of the walk
 // kernel (stack + work-sharing area) and the connect kernels (stack + [bands][bins] histogram + work-sharing area)
 size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins);
+// fs_oneshot.hip: the sum of a [bands][bins] buffer over the ranks as one peer-write exchange (fs_comm_enable_oneshot).
+// A rank's mailbox: kOneShotHeaderBytes of flags ([2 sets][kOneShotMaxRanks] u32 sequence numbers), then
+// [2 sets][world] slots of slot_bytes each.  mail[r] = rank r's mailbox as mapped into this process.
+constexpr int kOneShotMaxRanks = 16;
+constexpr size_t kOneShotHeaderBytes = 256;
+struct OneShotView {
+    void* mail[kOneShotMaxRanks];
+    int32_t world, rank;
+    size_t slot_bytes;
+};
+// buffer: fp32 [words] (or u64 [words], deterministic mode), summed in place over the ranks; set = seq & 1
+void launch_oneshot_reduce(const OneShotView& v, void* buffer, int words, bool u64, int set, uint32_t seq, unsigned* err,
+                           hipStream_t s);
 // row f4 (fs_refit.hip): moving geometry without a rebuild.  xyz = `count` new triangles [count][3][3] on the
 // device, written to the leaf-order records through leaf_pos; then one refit launch per tree level, deepest
 // first (node_box = scratch [num_nodes][2] float4 holding each node's fp32 bounds).

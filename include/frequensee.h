@@ -278,6 +278,15 @@ int fs_energy_handoff(fs_context* ctx, fs_source src, void** dptr, size_t* bytes
 int fs_comm_unique_id(void* id_out, size_t bytes);
 int fs_comm_init(fs_context* ctx, const void* unique_id, size_t bytes);
 int fs_comm_attach(fs_context* ctx, void* nccl_comm /* ncclComm_t */);
+/* Optional, collective over the ranks, after fs_comm_init / fs_comm_attach: sum the 32 KB energy buffer in ONE exchange
+ * step instead of ncclAllReduce (a ring of that size is latency-bound on xGMI).  Every rank owns a mailbox with one slot per
+ * rank in its HBM, mapped into the other ranks' processes through HIP IPC (the 64-byte handles travel over the
+ * communicator); a reduce = every rank writes its histogram into its slot of every mailbox and raises a sequence flag,
+ * then sums the slots of its own mailbox in rank order (bit-identical on all ranks, fp32 or the deterministic mode's
+ * u64).  Same stream (the tail stream), same place in the frame as the all-reduce.  If any rank cannot map a peer, all
+ * ranks keep ncclAllReduce and the call returns FS_ERR_COMM.  A peer that stops sending makes the next fs_synchronize
+ * return FS_ERR_COMM after a bounded wait. */
+int fs_comm_enable_oneshot(fs_context* ctx);
 int fs_comm_detach(fs_context* ctx);   /* destroys a communicator made by fs_comm_init; fs_context_destroy calls it */
 /* cfg5 — independent sources, one per GPU ("optional ncclAllGather of 8 x 32 KB so any rank can serve any
  * source's IR").  Nothing of a frame is sharded or reduced there (fs_config.world_size stays 1); a PEER communicator

@@ -63,6 +63,8 @@ if mode == "gather":
     np.savez(out, **res)
     sys.exit(0)
 ctx.comm_init(uid)
+if os.environ.get("FS_TEST_ONESHOT") == "1":
+    ctx.comm_enable_oneshot()     # the sum over the ranks through the peers' IPC-mapped mailboxes instead of ncclAllReduce
 if os.environ.get("FS_TEST_PIPELINE") == "1":
     ctx.set_pipelining(2)         # held-back connect passes: the all-reduce and the reconstruct follow them
 # every rank registers the same triangles; rank 0 builds the tree, the others receive it (fs_scene_commit)

@@ -18,6 +18,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -122,12 +123,26 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
                            hipStream_t stream) {
     FakeComm* c = reinterpret_cast<FakeComm*>(comm);
     const size_t bytes = count * type_bytes(dt);
-    if (op != ncclSum || (dt != ncclFloat32 && dt != ncclUint64) || bytes > kSlotBytes) return ncclInvalidArgument;
+    const bool words32 = dt == ncclInt32 || dt == ncclUint32;     // the library's agreement / overflow words: sum, min or max
+    if (bytes > kSlotBytes || !((op == ncclSum && (dt == ncclFloat32 || dt == ncclUint64)) ||
+                                (words32 && (op == ncclSum || op == ncclMin || op == ncclMax))))
+        return ncclInvalidArgument;
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     if (hipMemcpy(c->slot(c->rank), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     if (!barrier(c)) return ncclSystemError;
     std::vector<unsigned char> acc(bytes, 0);
-    for (int r = 0; r < c->nranks; ++r) {
+    if (words32) {
+        for (size_t i = 0; i < count; ++i) {
+            long long v = 0;
+            for (int r = 0; r < c->nranks; ++r) {
+                const long long x = dt == ncclInt32 ? (long long)reinterpret_cast<const int32_t*>(c->slot(r))[i]
+                                                    : (long long)reinterpret_cast<const uint32_t*>(c->slot(r))[i];
+                v = r == 0 ? x : (op == ncclSum ? v + x : (op == ncclMin ? std::min(v, x) : std::max(v, x)));
+            }
+            reinterpret_cast<uint32_t*>(acc.data())[i] = (uint32_t)v;
+        }
+    }
+    for (int r = 0; r < c->nranks && !words32; ++r) {
         if (dt == ncclFloat32) sum_into(reinterpret_cast<float*>(acc.data()), reinterpret_cast<const float*>(c->slot(r)), count);
         else sum_into(reinterpret_cast<uint64_t*>(acc.data()), reinterpret_cast<const uint64_t*>(c->slot(r)), count);
     }

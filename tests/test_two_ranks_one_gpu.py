@@ -33,9 +33,14 @@ def test_fake_rccl_builds_and_exports_what_the_library_opens(fake_rccl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,pipelined", [(2, False), (3, False), (2, True)])
-def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world, pipelined):
-    env = dict(os.environ, FS_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="60", FS_TEST_PIPELINE="1" if pipelined else "0")
+@pytest.mark.parametrize("world,pipelined,oneshot", [(2, False, False), (3, False, False), (2, True, False), (2, False, True), (3, True, True)],
+                         ids=["two", "three", "two_pipelined", "two_oneshot", "three_pipelined_oneshot"])
+def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world, pipelined, oneshot):
+    """oneshot: fs_comm_enable_oneshot — the per-frame sum goes through the ranks' HIP-IPC mailboxes (one peer-write
+    exchange, fs_oneshot.hip) instead of the communicator's all-reduce; the communicator still carries the scene broadcast
+    and the handle exchange.  Everything a rank publishes must be what the all-reduce path publishes."""
+    env = dict(os.environ, FS_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="60", FS_TEST_PIPELINE="1" if pipelined else "0",
+               FS_TEST_ONESHOT="1" if oneshot else "0")
     id_file = str(tmp_path / "comm_id")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), str(r), str(world),
                                id_file, str(tmp_path / f"rank{r}.npz")], env=env, stdout=subprocess.PIPE,
