@@ -12,3 +12,5 @@ run --workload cfg3_old_mine --fixed-depth --steps 100 --warmup 10
 run --workload cfg3_old_mine --deterministic --steps 100 --warmup 10 --no-cpu-baseline
 run --workload cfg3_old_mine --all-connections --steps 30 --warmup 3
 run --workload cfg3_old_mine --mis-balance --steps 30 --warmup 3
+run --workload cfg3_old_mine --double-positions --steps 100 --warmup 10
+run --workload cfg3_old_mine --depth 0 --steps 100 --warmup 10
