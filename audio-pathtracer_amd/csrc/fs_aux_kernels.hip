@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void update_sound_shared_kernel(DeviceScene
                 uint32_t mat;
                 hit_surface(sc, T.leaf_index, r, h.nx, h.ny, h.nz, mat);
                 h.t = T.t;
-                h.object = __float_as_uint(reinterpret_cast<const float4*>(sc.tris)[4 * (size_t)T.leaf_index + 2].w);
+                h.object = __float_as_uint(sc.tris[T.leaf_index].c.w);
             }
         }
         if (mode == MAIN) {

@@ -60,6 +60,8 @@ void free_source(fs_context* ctx, Source* s) {
 void free_scene(fs_context* ctx) {
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_tris) (void)hipFree(ctx->d_tris);
+    if (ctx->d_tris48) (void)hipFree(ctx->d_tris48);
+    if (ctx->d_tri_nrm) (void)hipFree(ctx->d_tri_nrm);
     if (ctx->d_absorption) (void)hipFree(ctx->d_absorption);
     if (ctx->d_leaf_pos) (void)hipFree(ctx->d_leaf_pos);
     if (ctx->d_node_box) (void)hipFree(ctx->d_node_box);
@@ -68,6 +70,7 @@ void free_scene(fs_context* ctx) {
     ctx->move_cap = 0;
     ctx->refit_pending = false;
     ctx->d_nodes = nullptr; ctx->d_tris = nullptr; ctx->d_absorption = nullptr;
+    ctx->d_tris48 = nullptr; ctx->d_tri_nrm = nullptr;
     ctx->scene = DeviceScene{};
     ctx->committed = false;
 }

@@ -117,12 +117,25 @@ static int upload_materials(fs_context* ctx) {
     return FS_OK;
 }
 
+// the kernels' view of the triangle records (Tri48 + normals), derived on the device from the authoring records; `cap`
+// = records the arrays must have room for (the fast commit keeps its arrays for the next registration)
+static int pack_scene(fs_context* ctx, size_t count, size_t cap) {
+    if (!ctx->d_tris48) {
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_tris48, std::max<size_t>(cap, 1) * sizeof(Tri48)));
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_tri_nrm, std::max<size_t>(cap, 1) * sizeof(float4)));
+    }
+    launch_pack_triangles(ctx->d_tris, (int)count, ctx->d_tris48, ctx->d_tri_nrm, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    return FS_OK;
+}
+
 // what every kind of commit ends with: the kernels' view of the scene and the stats
 static void finish_commit(fs_context* ctx, size_t scene_bytes) {
     ctx->amax = 0.f;
     for (float v : ctx->h_xyz) ctx->amax = std::max(ctx->amax, std::fabs(v));
     ctx->scene.nodes = ctx->d_nodes;
-    ctx->scene.tris = ctx->d_tris;
+    ctx->scene.tris = ctx->d_tris48;
+    ctx->scene.tri_nrm = ctx->d_tri_nrm;
     ctx->scene.absorption = ctx->d_absorption;
     ctx->scene.lobe_gain = ctx->d_absorption ? ctx->d_absorption + (size_t)ctx->M * ctx->cfg.num_bands : nullptr;
     ctx->scene.lobe_prob = ctx->d_absorption ? ctx->scene.lobe_gain + (size_t)ctx->M * 3 * ctx->cfg.num_bands : nullptr;
@@ -236,7 +249,8 @@ int fs_scene_commit(fs_context* ctx) {
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_node_box, sizeof(float4) * 2 * std::max<size_t>(n_nodes, 1)));
     }
-    finish_commit(ctx, nb + tb + mb);
+    if (tb) { const int pr = pack_scene(ctx, n_tris, n_tris); if (pr) return pr; }
+    finish_commit(ctx, nb + n_tris * (sizeof(Tri48) + sizeof(float4)) + mb);
     return FS_OK;
 }
 
@@ -314,6 +328,7 @@ int fs_scene_commit_fast(fs_context* ctx) {
     launch_refit(ctx->d_nodes, ctx->d_tris, ctx->d_node_box, ctx->bvh.level_begin.data(), info.levels, ctx->bvh.pad, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     { int mr = upload_materials(ctx); if (mr) return mr; }
+    { const int pr = pack_scene(ctx, n, ctx->fast_cap_tris); if (pr) return pr; }
     finish_commit(ctx, (size_t)info.num_nodes * sizeof(NodeQ4) + tb + ctx->h_absorption.size() * sizeof(float));
     return FS_OK;
 }
@@ -378,7 +393,7 @@ int fs_scene_update_triangles(fs_context* ctx, int32_t first, int32_t count, con
     for (size_t i = 0; i < 9 * (size_t)count; ++i) ctx->amax = std::max(ctx->amax, std::fabs(xyz[i]));
     // the staging buffer may still be read by the previous update's kernel: same stream, so ordered
     FS_HIP(ctx, hipMemcpyAsync(ctx->d_move, xyz, sizeof(float) * 9 * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
-    launch_update_triangles(ctx->d_tris, ctx->d_leaf_pos, first, count, ctx->d_move, ctx->stream);
+    launch_update_triangles(ctx->d_tris, ctx->d_tris48, ctx->d_tri_nrm, ctx->d_leaf_pos, first, count, ctx->d_move, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // xyz is the caller's memory
     ctx->refit_pending = true;

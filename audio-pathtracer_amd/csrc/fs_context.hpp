@@ -130,7 +130,9 @@ struct fs_context {
     int32_t T = 0, M = 0;
     bool committed = false;
     NodeQ4* d_nodes = nullptr;
-    Tri64* d_tris = nullptr;
+    Tri64* d_tris = nullptr;          // authoring records (builders, refit, fs_scene_update_triangles)
+    Tri48* d_tris48 = nullptr;        // what the kernels traverse (fs_internal.hpp: Tri48), derived from d_tris
+    float4* d_tri_nrm = nullptr;      // unit normals, leaf order
     float* d_absorption = nullptr;
     SoundAccum* d_sound = nullptr;
     // refit support (row f4, fs_refit.hip)

@@ -262,7 +262,7 @@ __device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T,
     const unsigned long long mn = __ballot(T.cur >= 0), mt = __ballot(T.tri_i < T.tri_n);   // subsets of EXEC
     // (addresses of lanes that want nothing are never dereferenced)
     const char* np = reinterpret_cast<const char*>(sc.nodes) + (size_t)(uint32_t)T.cur * FS_NODE_STRIDE;
-    const Tri64* tp = sc.tris + (uint32_t)T.tri_i;
+    const Tri48* tp = sc.tris + (uint32_t)T.tri_i;
     unsigned long long sv;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "s_mov_b64 exec, %[mn]\n\t"
@@ -471,9 +471,8 @@ __device__ __forceinline__ int trav_run(const DeviceScene& sc, const Ray& r, Tra
 // ImpactNormal: the record's unit geometric normal, flipped to face the ray origin side; material of the hit
 __device__ __forceinline__ void hit_surface(const DeviceScene& sc, int leaf_index, const Ray& r, float& nx, float& ny,
                                             float& nz, uint32_t& mat) {
-    const float4* rec = reinterpret_cast<const float4*>(sc.tris) + 4 * (size_t)leaf_index;
-    const float4 c = rec[2];
-    const float4 d = rec[3];
+    const float4 c = sc.tris[leaf_index].c;
+    const float4 d = sc.tri_nrm[leaf_index];
     float x = d.x, y = d.y, z = d.z;
     float dn = fmaf(x, r.dx, fmaf(y, r.dy, z * r.dz));
     if (dn > 0.0f) { x = -x; y = -y; z = -z; }

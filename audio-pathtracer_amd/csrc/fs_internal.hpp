@@ -44,6 +44,15 @@ struct alignas(16) Tri64 {
 };
 static_assert(sizeof(Tri64) == 64, "Tri64 must be 64 B");
 
+// What the kernels read: the first 48 B of every Tri64 at a 48-B stride (the intersection test never sees the normal:
+// without it the records the traversal keeps pulling through L1/L2 take a quarter less room) and the unit normals in
+// an array of their own (read once per walk step, at the hit).  Tri64 stays the authoring format of the builders, the
+// refit and fs_scene_update_triangles; launch_pack_triangles / update_tris_kernel derive the kernels' view from it.
+struct alignas(16) Tri48 {
+    float4 a, b, c;
+};
+static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 B");
+
 // Per-lane traversal stack in LDS: DeviceScene.stack_rows rows of kBlock ints, sized at run time from the committed
 // tree (its worst-case need + kStackSlack), passed as dynamic shared memory.  A node visit that pushes writes its
 // three candidate entries at sp .. sp + hits - 2 — never above the new top — so the worst-case need itself would do;
@@ -63,7 +72,8 @@ constexpr int kOverLevels = 448;            // second-tier walk steps of depth =
 
 struct DeviceScene {
     const NodeQ4* nodes;
-    const Tri64* tris;
+    const Tri48* tris;        // traversal records, leaf order
+    const float4* tri_nrm;    // unit geometric normals, leaf order
     const float* absorption;  // [M][B]
     const float* lobe_gain;   // [M][3][B] diffuse / specular / transmitted gains (FS_FLAG_MATERIAL_LOBES)
     const float* lobe_prob;   // [M][3] probability of each lobe
@@ -259,7 +269,9 @@ void launch_oneshot_reduce(const OneShotView& v, void* buffer, int words, bool u
 // row f4 (fs_refit.hip): moving geometry without a rebuild.  xyz = `count` new triangles [count][3][3] on the
 // device, written to the leaf-order records through leaf_pos; then one refit launch per tree level, deepest
 // first (node_box = scratch [num_nodes][2] float4 holding each node's fp32 bounds).
-void launch_update_triangles(Tri64* tris, const uint32_t* leaf_pos, int first, int count, const float* xyz, hipStream_t s);
+void launch_update_triangles(Tri64* tris, Tri48* packed, float4* nrm, const uint32_t* leaf_pos, int first, int count,
+                             const float* xyz, hipStream_t s);
+void launch_pack_triangles(const Tri64* tris, int count, Tri48* packed, float4* nrm, hipStream_t s);
 void launch_refit(NodeQ4* nodes, const Tri64* tris, float4* node_box, const int32_t* level_begin, int levels, float pad,
                   hipStream_t s);
 // fs_build.hip: the acceleration structure built on the device (Morton codes, radix sort, Karras' binary radix tree,

@@ -19,13 +19,15 @@ constexpr int kRefitBlock = 256;
 
 // new vertex positions -> Tri64 {v0, e1, e2, unit normal}; material, input index and actor id are kept.
 // Same fp32 operation order as the host build (fs_bvh.cpp) — the normal is part of the hit-normal spec.
-__global__ __launch_bounds__(kRefitBlock) void update_tris_kernel(Tri64* __restrict__ tris,
+__global__ __launch_bounds__(kRefitBlock) void update_tris_kernel(Tri64* __restrict__ tris, Tri48* __restrict__ packed,
+                                                                  float4* __restrict__ nrm,
                                                                   const uint32_t* __restrict__ leaf_pos, int first,
                                                                   int count, const float* __restrict__ xyz) {
     const int i = blockIdx.x * kRefitBlock + threadIdx.x;
     if (i >= count) return;
     const float* p = xyz + 9 * (size_t)i;
-    Tri64& r = tris[leaf_pos[first + i]];
+    const uint32_t pos = leaf_pos[first + i];
+    Tri64& r = tris[pos];
     const float e1x = p[3] - p[0], e1y = p[4] - p[1], e1z = p[5] - p[2];
     const float e2x = p[6] - p[0], e2y = p[7] - p[1], e2z = p[8] - p[2];
     r.a = make_float4(p[0], p[1], p[2], e1x);
@@ -37,6 +39,18 @@ __global__ __launch_bounds__(kRefitBlock) void update_tris_kernel(Tri64* __restr
     const float l2 = nx * nx + ny * ny + nz * nz;
     const float inv = 1.0f / sqrtf(l2);
     r.d = make_float4(nx * inv, ny * inv, nz * inv, 0.f);
+    packed[pos] = Tri48{r.a, r.b, r.c};
+    nrm[pos] = r.d;
+}
+
+// the kernels' view of the records (fs_internal.hpp: Tri48 + normals) from the authoring records
+__global__ __launch_bounds__(kRefitBlock) void pack_tris_kernel(const Tri64* __restrict__ tris, int count,
+                                                                Tri48* __restrict__ packed, float4* __restrict__ nrm) {
+    const int i = blockIdx.x * kRefitBlock + threadIdx.x;
+    if (i >= count) return;
+    const Tri64 r = tris[i];
+    packed[i] = Tri48{r.a, r.b, r.c};
+    nrm[i] = r.d;
 }
 
 struct Box3 {
@@ -122,11 +136,17 @@ __global__ __launch_bounds__(kRefitBlock) void refit_level_kernel(NodeQ4* __rest
 
 }  // namespace
 
-void launch_update_triangles(Tri64* tris, const uint32_t* leaf_pos, int first, int count, const float* xyz,
-                             hipStream_t s) {
+void launch_update_triangles(Tri64* tris, Tri48* packed, float4* nrm, const uint32_t* leaf_pos, int first, int count,
+                             const float* xyz, hipStream_t s) {
     if (count <= 0) return;
     hipLaunchKernelGGL(update_tris_kernel, dim3((unsigned)((count + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock),
-                       0, s, tris, leaf_pos, first, count, xyz);
+                       0, s, tris, packed, nrm, leaf_pos, first, count, xyz);
+}
+
+void launch_pack_triangles(const Tri64* tris, int count, Tri48* packed, float4* nrm, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(pack_tris_kernel, dim3((unsigned)((count + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, s,
+                       tris, count, packed, nrm);
 }
 
 void launch_refit(NodeQ4* nodes, const Tri64* tris, float4* node_box, const int32_t* level_begin, int levels, float pad,
