@@ -439,8 +439,18 @@ extern "C" void fs_debug_step_buffer(unsigned short* device_ptr) {
 size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins) {
     const size_t stack = sizeof(int) * (size_t)stack_rows * (size_t)kBlock;
     const size_t walk = stack + std::max(kShareLdsBytes, kShareIgnLdsBytes);
-    const size_t connect = stack + sizeof(float) * (size_t)bands * (size_t)std::min(num_bins, kHistWindow) + kShareAnyLdsBytes;
+    const size_t connect = stack + sizeof(float) * (size_t)bands * (size_t)std::min(num_bins, default_hist_window(bands)) + kShareAnyLdsBytes;
     return std::max(walk, connect) + 1024;   // + the kernels' small static arrays
+}
+
+// Histogram bins the connect part keeps in LDS by default: as many as fit into what the walk part of the same launch
+// needs anyway (stack + its share area), so that the histogram never decides how many workgroups a CU holds — with a
+// 256-bin window at 8 bands a tree needing 33+ stack rows dropped from three resident workgroups to two (-20 %,
+// profiles/r03_ab_tree.log); bins beyond the window take global atomics, and a cfg3 frame touches bins 0..60.
+int default_hist_window(int bands) {
+    const size_t spare = kShareLdsBytes > kShareAnyLdsBytes ? kShareLdsBytes - kShareAnyLdsBytes : 0;
+    const int fit = (int)(spare / (sizeof(float) * (size_t)std::max(bands, 1))) & ~15;
+    return std::max(64, std::min(kHistWindow, fit));
 }
 
 void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, hipStream_t s) {

@@ -83,7 +83,8 @@ struct Builder {
 
     explicit Builder(BuildInput& i) : in(i), prims(i.prims) {}
 
-    static constexpr int kBins = 32;
+    static constexpr int kBinsMax = 256;
+    int kBins = std::getenv("FS_BVH_BINS") ? std::max(2, std::min(kBinsMax, std::atoi(std::getenv("FS_BVH_BINS")))) : 64;   // 32 -> 64 bins: -0.8 % node visits (tools/tree_cost.cpp), +0.6 % rays/s (profiles/r03_ab_tree.log)
     int kLeaf = 2;   // measured: a triangle test costs about as much as 2.5 child boxes, small leaves win
 
     int make(int first, int count, int depth) {
@@ -130,7 +131,7 @@ struct Builder {
         for (int ax = 0; ax < 3; ++ax) {
             float ext = cb.hi[ax] - cb.lo[ax];
             if (!(ext > 0.f)) continue;
-            Box bb[kBins]; int bc[kBins];
+            Box bb[kBinsMax]; int bc[kBinsMax];
             for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
             float scale = kBins / ext;
             for (int i = first; i < first + count; ++i) {
@@ -138,7 +139,7 @@ struct Builder {
                 int b = std::min(kBins - 1, std::max(0, (int)((p.cen[ax] - cb.lo[ax]) * scale)));
                 bb[b].grow(p.box); bc[b]++;
             }
-            float ra[kBins]; int rc[kBins];
+            float ra[kBinsMax]; int rc[kBinsMax];
             Box acc; acc.reset(); int c = 0;
             for (int b = kBins - 1; b >= 1; --b) {
                 acc.grow(bb[b]); c += bc[b];
@@ -188,8 +189,81 @@ struct Wide {
     int n;
 };
 
+// Which BVH2 nodes become 4-wide nodes.  Every 4-wide node visit costs the kernel the same (four boxes are tested
+// whatever the slots hold) and the leaves are given, so the expected cost of a collapse is the summed surface area of
+// the BVH2 nodes that end up as 4-wide nodes.  That has an exact minimum by dynamic programming over the BVH2
+// (as the wide-BVH construction of Ylitie, Karras, Laine 2017 does for 8-wide nodes):
+//   F(n, k) = least cost of covering n's subtree with at most k child slots
+//           = min( slot(n), min_i F(left, i) + F(right, k - i) ),   slot(leaf) = 0, slot(inner) = W(inner)
+//   W(n)    = area(n) + min_i F(left, i) + F(right, 4 - i)            (n is a 4-wide node: its 4 slots cover both children)
+// cut[n][k] remembers the arg min: 0 = n takes one slot itself, i > 0 = left gets i slots, right k - i.
+struct CollapsePlan {
+    std::vector<float> F;            // [node][k-1], k = 1..4
+    std::vector<unsigned char> cut;  // [node][k-1]
+    void solve(const std::vector<BuildNode>& bn, int root) {
+        F.assign(bn.size() * 4, 0.f);
+        cut.assign(bn.size() * 4, 0);
+        std::vector<int> order;   // parents before children
+        order.reserve(bn.size());
+        order.push_back(root);
+        for (size_t h = 0; h < order.size(); ++h) {
+            const BuildNode& n = bn[(size_t)order[h]];
+            if (n.left >= 0) { order.push_back(n.left); order.push_back(n.right); }
+        }
+        for (size_t h = order.size(); h-- > 0;) {
+            const int id = order[h];
+            const BuildNode& n = bn[(size_t)id];
+            float* f = &F[(size_t)id * 4];
+            unsigned char* c = &cut[(size_t)id * 4];
+            if (n.left < 0) continue;   // leaf: all zero
+            const float* fl = &F[(size_t)n.left * 4];
+            const float* fr = &F[(size_t)n.right * 4];
+            float split[5];             // split[k]: best of giving the two children k slots together
+            unsigned char arg[5];
+            for (int k = 2; k <= 4; ++k) {
+                split[k] = std::numeric_limits<float>::infinity(); arg[k] = 1;
+                for (int i = 1; i < k; ++i) {
+                    const float v = fl[i - 1] + fr[k - i - 1];
+                    if (v < split[k]) { split[k] = v; arg[k] = (unsigned char)i; }
+                }
+            }
+            const float w = n.box.half_area() + split[4];
+            f[0] = w; c[0] = 0;
+            for (int k = 2; k <= 4; ++k) {
+                if (split[k] < w) { f[k - 1] = split[k]; c[k - 1] = arg[k]; }
+                else { f[k - 1] = w; c[k - 1] = 0; }
+            }
+            // a wide node always opens itself: remember its own split in slot 0's neighbour (k = 4 forced)
+            own.resize(bn.size(), 1);
+            own[(size_t)id] = arg[4];
+        }
+    }
+    std::vector<unsigned char> own;   // [node]: slots its left child gets when the node is a 4-wide node
+    // the children (BVH2 nodes) of the 4-wide node rooted at `id`, in tree order
+    void children(const std::vector<BuildNode>& bn, int id, int* out, int& n) const {
+        n = 0;
+        const BuildNode& r = bn[(size_t)id];
+        const int i = own.empty() ? 1 : own[(size_t)id];
+        cover(bn, r.left, i, out, n);
+        cover(bn, r.right, 4 - i, out, n);
+    }
+    void cover(const std::vector<BuildNode>& bn, int id, int k, int* out, int& n) const {
+        const BuildNode& b = bn[(size_t)id];
+        const int c = b.left < 0 ? 0 : cut[(size_t)id * 4 + (size_t)(k - 1)];
+        if (c == 0) { out[n++] = id; return; }
+        cover(bn, b.left, c, out, n);
+        cover(bn, b.right, k - c, out, n);
+    }
+};
+
 void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wide, std::vector<int>& wide_of,
               std::vector<int>& level) {
+    // default: the greedy rule below.  FS_BVH_DP_COLLAPSE=1 takes the exact minimum instead: 16 % fewer nodes and 1.9 % fewer
+    // node visits per ray on old_mine (tools/tree_cost.cpp), but 3 more worst-case stack rows and no measurable gain on the
+    // GPU (profiles/r03_ab_tree.log), so it stays an experiment
+    static const bool greedy = std::getenv("FS_BVH_DP_COLLAPSE") == nullptr;
+    CollapsePlan plan;
+    if (!greedy) plan.solve(bn, root);
     // breadth-first so the top of the tree is a contiguous prefix of the node array
     wide.clear();
     wide_of.assign(bn.size(), -1);
@@ -204,6 +278,8 @@ void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wid
         w.n = 0;
         if (n.left < 0) {           // a leaf root: one child
             w.child[w.n++] = queue[h];
+        } else if (!greedy) {
+            plan.children(bn, queue[h], w.child, w.n);
         } else {
             w.child[w.n++] = n.left;
             w.child[w.n++] = n.right;

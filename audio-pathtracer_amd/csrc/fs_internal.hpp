@@ -253,6 +253,7 @@ void launch_add_energy(float* energy_row, int num_bins, float delay_s, float e, 
 // dynamic LDS the traversal kernels of a frame need for a tree with `stack_rows` stack rows: the larger of the walk
 // kernel (stack + work-sharing area) and the connect kernels (stack + [bands][bins] histogram + work-sharing area)
 size_t traversal_lds_bytes(int stack_rows, int bands, int num_bins);
+int default_hist_window(int bands);   // LDS histogram bins of the connect part when FS_HIST_WINDOW is not set
 // fs_oneshot.hip: the sum of a [bands][bins] buffer over the ranks as one peer-write exchange (fs_comm_enable_oneshot).
 // A rank's mailbox: kOneShotHeaderBytes of flags ([2 sets][kOneShotMaxRanks] u32 sequence numbers), then
 // [2 sets][world] slots of slot_bytes each.  mail[r] = rank r's mailbox as mapped into this process.
