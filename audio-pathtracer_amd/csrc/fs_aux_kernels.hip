@@ -86,6 +86,7 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
     Ray r = make_ray(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     Trav T;
     trav_init(T, tmax[i], sc.num_nodes > 0);
+    trav_deep_reset(sc, &s_stack[threadIdx.x]);
     if (any_hit) {
         trav_run<true>(sc, r, T, &s_stack[threadIdx.x]);
         hit[i] = T.leaf_index >= 0;
@@ -391,18 +392,22 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
                        num_bins, num_samples, spb, ir_bands, ir_mono);
 }
 
-void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
+void launch_trace_rays(const DeviceScene& sc_in, const float* o, const float* d, const float* tmax, int N, int any_hit,
                        int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s) {
     if (N <= 0) return;
+    DeviceScene sc = sc_in;
+    if (!attach_deep(sc, (uint32_t)((N + kBlock - 1) / kBlock))) return;
     allow_lds(trace_rays_kernel, stack_bytes(sc));
     hipLaunchKernelGGL(trace_rays_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(sc), s, sc, o, d, tmax, N,
                        any_hit, hit, t, tri, normal);
 }
 
-void launch_update_sound(const DeviceScene& sc, const SoundKParams& sp, SoundAccum* acc, int rays_per_wave, hipStream_t s) {
+void launch_update_sound(const DeviceScene& sc_in, const SoundKParams& sp, SoundAccum* acc, int rays_per_wave, hipStream_t s) {
     int lanes = sp.raycasts_per_tick + 1;
     if (rays_per_wave > 64 || rays_per_wave <= 0) rays_per_wave = 64;   // 64 = one ray per lane (finished lanes still help)
     const int waves = (lanes + rays_per_wave - 1) / rays_per_wave;
+    DeviceScene sc = sc_in;
+    if (!attach_deep(sc, (uint32_t)((waves + kBlock / 64 - 1) / (kBlock / 64)))) return;
     const size_t lds = stack_bytes(sc) + kShareIgnLdsBytes;
     allow_lds(update_sound_shared_kernel, lds);
     hipLaunchKernelGGL(update_sound_shared_kernel, dim3((waves + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), lds, s, sc, sp,

@@ -71,6 +71,9 @@ void free_scene(fs_context* ctx) {
     ctx->refit_pending = false;
     ctx->d_nodes = nullptr; ctx->d_tris = nullptr; ctx->d_absorption = nullptr;
     ctx->d_tris48 = nullptr; ctx->d_tri_nrm = nullptr;
+    if (ctx->deep.buf) (void)hipFree(ctx->deep.buf);
+    for (int32_t* b : ctx->deep.retired) (void)hipFree(b);
+    ctx->deep = DeepStore{};
     ctx->scene = DeviceScene{};
     ctx->committed = false;
 }
@@ -404,6 +407,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
     ctx->hist_window = default_hist_window(ctx->cfg.num_bands);
+    if (const char* v = std::getenv("FS_STACK_ROWS_CAP")) ctx->stack_rows_cap = std::max(kDeepChunk + 4, std::min(kStackDepth + 1, std::atoi(v)));
     if (const char* v = std::getenv("FS_HIST_WINDOW")) ctx->hist_window = std::max(1, std::min(4096, std::atoi(v)));
     if (const char* v = std::getenv("FS_WALK_RAYS_PER_WAVE")) ctx->walk_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_CONNECT_PAIRS_PER_WAVE")) ctx->connect_pairs_per_wave = std::max(0, std::min(64, std::atoi(v)));

@@ -142,10 +142,25 @@ static void finish_commit(fs_context* ctx, size_t scene_bytes) {
     ctx->scene.num_nodes = (int32_t)ctx->bvh.nodes.size();
     ctx->scene.num_tris = ctx->T;
     ctx->scene.num_materials = ctx->M;
-    ctx->scene.stack_rows = std::max(ctx->bvh.stack_need, 2) + kStackSlack;
-#ifdef FS_EXPERIMENTS   // occupancy experiments only: fewer rows than the tree's worst case (an overflowing lane corrupts the share area)
-    if (const char* v = std::getenv("FS_UNSAFE_STACK_ROWS")) ctx->scene.stack_rows = std::max(4, std::atoi(v));
-#endif
+    // LDS rows of the traversal stack: the tree's worst case + 1 if that is at most stack_rows_cap + 1 rows; else
+    // stack_rows_cap rows + one row of counters, and a deep store in HBM for the rare lane that needs more
+    // (fs_internal.hpp: DeviceScene.deep).  The bounded stack is what lets four workgroups share a CU.
+    const int worst = std::max(ctx->bvh.stack_need, 2) + kStackSlack;
+    int deep_rows = 0;
+    if (worst <= ctx->stack_rows_cap + 1) {
+        ctx->scene.stack_rows = worst; ctx->scene.stack_limit = worst;
+    } else {
+        ctx->scene.stack_rows = ctx->stack_rows_cap + 1; ctx->scene.stack_limit = ctx->stack_rows_cap;
+        deep_rows = ((worst + kDeepChunk - 1) / kDeepChunk) * kDeepChunk + kDeepChunk;
+    }
+    if (deep_rows != ctx->deep.rows) {   // (every commit has drained the stream: nothing reads the old store any more)
+        if (ctx->deep.buf) (void)hipFree(ctx->deep.buf);
+        for (int32_t* b : ctx->deep.retired) (void)hipFree(b);
+        ctx->deep = DeepStore{};
+        ctx->deep.rows = deep_rows;
+    }
+    ctx->scene.deep = nullptr; ctx->scene.deep_lanes = 0;
+    ctx->scene.deep_owner = &ctx->deep;
     ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
     ctx->stats.triangles = (uint32_t)ctx->T;
     ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;
@@ -204,7 +219,7 @@ int fs_scene_commit(fs_context* ctx) {
     if (ctx->bvh.stack_need > kStackDepth) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "BVH needs a deeper traversal stack");
     {   // the traversal kernels keep stack + energy histogram window + work-sharing area in LDS: fail here, with a
         // message, rather than with a launch error on every frame
-        const size_t need = traversal_lds_bytes(std::max(ctx->bvh.stack_need, 2) + kStackSlack, ctx->cfg.num_bands, ctx->num_bins);
+        const size_t need = traversal_lds_bytes(std::min(std::max(ctx->bvh.stack_need, 2) + kStackSlack, ctx->stack_rows_cap + 1), ctx->cfg.num_bands, ctx->num_bins);
         if (need > ctx->lds_limit)
             return ctx->fail(FS_ERR_INVALID_ARGUMENT, "scene + energy histogram need " + std::to_string(need) +
                              " B of LDS per workgroup, the device offers " + std::to_string(ctx->lds_limit));
@@ -317,7 +332,7 @@ int fs_scene_commit_fast(fs_context* ctx) {
     FS_HIP(ctx, hipMemcpyAsync(&info, d_info, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (info.levels < 1 || info.stack_need > kStackDepth ||
-        traversal_lds_bytes(std::max(info.stack_need, 2) + kStackSlack, ctx->cfg.num_bands, ctx->num_bins) > ctx->lds_limit)
+        traversal_lds_bytes(std::min(std::max(info.stack_need, 2) + kStackSlack, ctx->stack_rows_cap + 1), ctx->cfg.num_bands, ctx->num_bins) > ctx->lds_limit)
         return fs_scene_commit(ctx);   // a degenerate Morton tree (deeper than the LDS stack allows): take the host's SAH build
     ctx->bvh = HostBVH{};
     ctx->bvh.nodes.resize((size_t)info.num_nodes); ctx->bvh.tris.resize(n);   // sizes only: the records live on the device

@@ -220,16 +220,18 @@ __global__ __launch_bounds__(kBlock) void fixed_to_energy_kernel(const unsigned 
 }
 
 template <int B>
-void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
+void launch_connect_t(const DeviceScene& sc_in, const KParams& kp, const SubpathState& st, float* energy,
                       unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, float* const* energy_tab,
                       unsigned long long* const* fixed_tab, hipStream_t s) {
     if (kp.num_local == 0) return;
+    DeviceScene sc = sc_in;
     if (pairs_per_wave < 1 || pairs_per_wave > 64) pairs_per_wave = 64;
     const uint32_t per_block = (uint32_t)pairs_per_wave * (kBlock / 64);
     const bool batch = energy_tab != nullptr;
     uint32_t blocks = batch ? (kp.num_local / kp.pairs_per_source) * ((kp.pairs_per_source + per_block - 1) / per_block)
                             : (kp.num_local + per_block - 1) / per_block;
     if (blocks > 1024) blocks = 1024;
+    if (!attach_deep(sc, blocks)) return;
     size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)kp.num_bands * (size_t)kp.hist_window + kShareAnyLdsBytes;
 #define FS_LAUNCH_CONNECT(L, BT, CN)                                                                                 \
     do {                                                                                                             \
@@ -260,11 +262,13 @@ void launch_connect_t(const DeviceScene& sc, const KParams& kp, const SubpathSta
 }
 
 template <int B>
-void launch_connect_all_t(const DeviceScene& sc, const KParams& kp, const SubpathState& st, float* energy,
+void launch_connect_all_t(const DeviceScene& sc_in, const KParams& kp, const SubpathState& st, float* energy,
                           unsigned long long* fixed, unsigned* queue_head, hipStream_t s) {
     if (kp.num_local == 0) return;
+    DeviceScene sc = sc_in;
     uint32_t blocks = (kp.num_local + 3) / 4;   // one wave per pair, 4 waves per workgroup
     if (blocks > 4096) blocks = 4096;
+    if (!attach_deep(sc, blocks)) return;
     size_t lds = stack_bytes(sc) + sizeof(float) * (size_t)kp.num_bands * (size_t)kp.hist_window + kShareAnyLdsBytes;
     allow_lds(connect_all_kernel<B>, lds);
     hipLaunchKernelGGL(connect_all_kernel<B>, dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head);

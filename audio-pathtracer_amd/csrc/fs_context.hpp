@@ -130,6 +130,8 @@ struct fs_context {
     int32_t T = 0, M = 0;
     bool committed = false;
     NodeQ4* d_nodes = nullptr;
+    DeepStore deep;                   // HBM spill area of the bounded LDS traversal stacks (DeviceScene.deep)
+    int stack_rows_cap = kStackRowsCap;   // FS_STACK_ROWS_CAP
     Tri64* d_tris = nullptr;          // authoring records (builders, refit, fs_scene_update_triangles)
     Tri48* d_tris48 = nullptr;        // what the kernels traverse (fs_internal.hpp: Tri48), derived from d_tris
     float4* d_tri_nrm = nullptr;      // unit normals, leaf order
@@ -270,6 +272,10 @@ struct fs_context {
     do {                                                         \
         hipError_t e_ = (call);                                  \
         if (e_ != hipSuccess) return (ctx)->hip_fail(e_, #call); \
+        if ((ctx)->deep.failed) {   /* a launcher could not grow the traversal stacks' deep store and skipped its launch */ \
+            (ctx)->deep.failed = false;                          \
+            return (ctx)->fail(FS_ERR_OUT_OF_MEMORY, "no device memory for the traversal stacks' deep store"); \
+        }                                                        \
     } while (0)
 
 #define FS_NCCL(ctx, call)                                               \

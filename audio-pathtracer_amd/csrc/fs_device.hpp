@@ -241,12 +241,77 @@ struct TriRegs { v4f a, b, c; };
 #define FS_NODE_STRIDE 64
 #endif
 
-__device__ __forceinline__ void trav_settle(Trav& T, int* stack) {
+// ---- bounded LDS stack with a deep store in HBM (DeviceScene.deep, fs_internal.hpp) ---------------------------
+// The logical stack of a lane is  deep[0, count)  followed by  LDS rows [sb, sp).  Entries move between the two in
+// chunks of kDeepChunk, oldest first out, newest first back, so pops keep their order.  A lane with entries in the
+// deep store carries kDeepFlag in T.sb (its real bottom is row 0: it gives nothing away to idle lanes meanwhile), so
+// the ordinary pop test `sp > sb` fails for it and sends it down the slow path — the ordinary lanes pay one compare
+// on their way out of a traversal and no LDS access (reading the count there cost 7 % of the walk).
+constexpr int kDeepFlag = 1 << 20;
+__device__ __forceinline__ int* trav_deep_count(const DeviceScene& sc, int* stack) { return stack + (size_t)sc.stack_limit * kBlock; }
+__device__ __forceinline__ void trav_deep_reset(const DeviceScene& sc, int* stack) {
+    if (sc.deep != nullptr) *trav_deep_count(sc, stack) = 0;
+}
+// a node visit may write above row stack_limit - 1: close the gap left by donated entries, then move the oldest
+// entries out.  Afterwards sp + 2 < stack_limit.
+__device__ __forceinline__ void trav_make_room(const DeviceScene& sc, Trav& T, int* stack) {
+    const int R = sc.stack_limit;
+    if (sc.deep == nullptr) return;   // (without a deep store stack_limit covers the tree's worst case)
+    if (T.sb > 0 && T.sb < kDeepFlag) {
+        const int n = T.sp - T.sb;
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) stack[i * kBlock] = stack[(T.sb + i) * kBlock];
+        T.sb = 0; T.sp = n;
+    }
+    if (T.sp + 2 >= R) {
+        int* cnt = trav_deep_count(sc, stack);
+        const int have = *cnt;
+        int32_t* col = sc.deep + (size_t)blockIdx.x * kBlock + threadIdx.x;
+        // (rolled loops: these paths are as good as never taken, their code should stay small inside the traversal loop)
+#pragma unroll 1
+        for (int i = 0; i < kDeepChunk; ++i) col[(size_t)(have + i) * sc.deep_lanes] = stack[i * kBlock];
+#pragma unroll 1
+        for (int i = kDeepChunk; i < T.sp; ++i) stack[(i - kDeepChunk) * kBlock] = stack[i * kBlock];
+        T.sp -= kDeepChunk;
+        T.sb = kDeepFlag;
+        *cnt = have + kDeepChunk;
+    }
+}
+// pop of a lane that has entries in the deep store (T.sb == kDeepFlag): from its LDS rows while there are any, else
+// the newest chunk comes back first
+__device__ __forceinline__ void trav_pop_deep(const DeviceScene& sc, Trav& T, int* stack) {
+    if (T.sp == 0) {
+        int* cnt = trav_deep_count(sc, stack);
+        const int have = *cnt;
+        const int32_t* col = sc.deep + (size_t)blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll 1
+        for (int i = 0; i < kDeepChunk; ++i) stack[i * kBlock] = col[(size_t)(have - kDeepChunk + i) * sc.deep_lanes];
+        T.sp = kDeepChunk;
+        T.sb = have > kDeepChunk ? kDeepFlag : 0;
+        *cnt = have - kDeepChunk;
+    }
+    --T.sp;
+    T.cur = stack[T.sp * kBlock];
+}
+// next pending entry into T.cur (kDone: none left)
+__device__ __forceinline__ void trav_pop(const DeviceScene& sc, Trav& T, int* stack) {
+    if (T.sp > T.sb) { --T.sp; T.cur = stack[T.sp * kBlock]; }
+    else {
+        T.cur = kDone;
+#ifndef FS_DEEP_NO_POP   // timing experiments only
+        if (__builtin_expect(__ballot(T.sb >= kDeepFlag) != 0ull, 0)) {
+            if (T.sb >= kDeepFlag) trav_pop_deep(sc, T, stack);
+        }
+#endif
+    }
+}
+
+__device__ __forceinline__ void trav_settle(const DeviceScene& sc, Trav& T, int* stack) {
     if (T.tri_i >= T.tri_n && T.cur < 0 && T.cur != kDone) {
         const int code = ~T.cur;
         T.tri_i = code >> 2;
         T.tri_n = T.tri_i + (code & 3) + 1;
-        if (T.sp > T.sb) { --T.sp; T.cur = stack[T.sp * kBlock]; } else { T.cur = kDone; }
+        trav_pop(sc, T, stack);
     }
 }
 
@@ -315,7 +380,7 @@ __device__ __forceinline__ void trav_tri_part(const Ray& r, Trav& T, const TriRe
     if (ANY) {
         if (hit) {
             T.t = t; T.leaf_index = tested; T.id = id;
-            T.tri_i = 0; T.tri_n = 0; T.cur = kDone; T.sp = T.sb;  // first hit ends the query (records already requested are ignored)
+            T.tri_i = 0; T.tri_n = 0; T.cur = kDone; T.sp = 0; T.sb = 0;  // first hit ends the query (records already requested are ignored)
         }
     } else {
         // closest hit, ties to the lower input index — as selects, not branches.  (t, id) compares as ONE 64-bit
@@ -331,7 +396,7 @@ __device__ __forceinline__ void trav_tri_part(const Ray& r, Trav& T, const TriRe
 }
 
 // the lane's inner node (T.cur >= 0): 4 child boxes, near-first order, far children to the stack, next node
-__device__ __forceinline__ void trav_node_part(const Ray& r, Trav& T, int* stack, const NodeRegs& N) {
+__device__ __forceinline__ void trav_node_part(const DeviceScene& sc, const Ray& r, Trav& T, int* stack, const NodeRegs& N) {
     const float4 q0 = make_float4(N.q0.x, N.q0.y, N.q0.z, N.q0.w), q1 = make_float4(N.q1.x, N.q1.y, N.q1.z, N.q1.w),
                  q2 = make_float4(N.q2.x, N.q2.y, N.q2.z, N.q2.w), q3 = make_float4(N.q3.x, N.q3.y, N.q3.z, N.q3.w);
     // ---- 4-wide node, child boxes on the node's 8-bit grid: plane distance = fma(q, step*inv, (origin-o)*inv)
@@ -393,14 +458,8 @@ __device__ __forceinline__ void trav_node_part(const Ray& r, Trav& T, int* stack
     stack[p2 * kBlock] = ref2;
     stack[p1 * kBlock] = ref1;
     T.sp = p1 + (h2 ? 1 : 0);
-    if (h1) {
-        T.cur = ref0;
-    } else if (T.sp > T.sb) {
-        --T.sp;
-        T.cur = stack[T.sp * kBlock];
-    } else {
-        T.cur = kDone;
-    }
+    if (h1) T.cur = ref0;
+    else trav_pop(sc, T, stack);
 }
 
 // One whole step of a busy lane, in the pipelined order: node part, advance, request the next records (the
@@ -425,9 +484,17 @@ __device__ __forceinline__ void trav_advance(const DeviceScene& sc, const Ray& r
         }
     }
 #endif
-    if (has_node) trav_node_part(r, T, stack, N);
+    // bounded LDS stack: a node visit writes up to row sp + 2.  Checked here, ahead of the node arithmetic and as one
+    // scalar branch for the wave, so that the node part stays a single basic block; lanes of trees without a deep store
+    // (stack_limit = worst case + 1) may pass the test near their worst case and return at once.
+#ifndef FS_DEEP_NO_CHECK   // timing experiments only
+    if (__builtin_expect(__ballot(T.sp + 2 >= sc.stack_limit) != 0ull, 0)) {
+        if (T.sp + 2 >= sc.stack_limit) trav_make_room(sc, T, stack);
+    }
+#endif
+    if (has_node) trav_node_part(sc, r, T, stack, N);
     if (has_tri) ++T.tri_i;
-    trav_settle(T, stack);
+    trav_settle(sc, T, stack);
     trav_issue(sc, T, N, nxt);
     // the triangle test must stay BEHIND the requests: it is plain arithmetic on registers, which the compiler would
     // otherwise move in front of the (to it unrelated) load instructions — and then fold the two register sets into one
@@ -452,7 +519,7 @@ __device__ __forceinline__ int trav_run(const DeviceScene& sc, const Ray& r, Tra
     NodeRegs N;
     TriRegs X, Y;
     int steps = 0;
-    trav_settle(T, stack);
+    trav_settle(sc, T, stack);
     trav_issue(sc, T, N, X);
     // The loop is wave-uniform (lanes whose ray is finished idle along): a per-lane exit would make the compiler carry
     // every lane's register sets out of the loop through copies — of registers that may still be in flight.
@@ -968,6 +1035,7 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     uint32_t wign = ignore;
     Ray wr = own;
     trav_init(T, tmax, has_ray && sc.num_nodes > 0);
+    trav_deep_reset(sc, stack);
     // The records of the NEXT step are requested as soon as this step has decided what they are: behind the node part
     // of the step, before its triangle test (trav_advance) and before the work-sharing round below (ballots, donation
     // boxes, mailboxes: half a dozen LDS round trips), which both run in the shadow of the fetch.  A wave in the thin
@@ -976,7 +1044,7 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     // instantiated twice): the one being tested is still needed while the next one is already arriving.
     NodeRegs N;
     TriRegs X, Y;
-    trav_settle(T, stack);
+    trav_settle(sc, T, stack);
     trav_issue(sc, T, N, X);
     // one step of the wave; cur = the triangle registers that arrive with this step, nxt = the ones requested for the
     // next.  true = nothing is left anywhere in the wave.
@@ -1043,7 +1111,8 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
                     if (IGN) wign = A.rign[owner];
                     T.cur = e; T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
                     T.t = bound; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
-                    trav_settle(T, stack);
+                    trav_deep_reset(sc, stack);   // (an any-hit query that ended early may have left entries there)
+                    trav_settle(sc, T, stack);
                     trav_issue(sc, T, N, nxt);
                 }
             }
@@ -1436,6 +1505,24 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #define FS_SHARED_WALK(wl) true
 #endif
 inline size_t stack_bytes(const DeviceScene& sc) { return sizeof(int) * (size_t)sc.stack_rows * (size_t)kBlock; }
+// The deep store must have a column for every lane of the grid about to be launched (DeviceScene.deep).  Grows it if
+// not — a new buffer; the old one stays allocated for the launches already in the stream (DeepStore.retired).
+// false: the allocation failed, the launch must be skipped (DeepStore.failed is set; the host reports it).
+inline bool attach_deep(DeviceScene& sc, uint32_t blocks) {
+    DeepStore* d = sc.deep_owner;
+    if (d == nullptr || d->rows <= 0) { sc.deep = nullptr; sc.deep_lanes = 0; return true; }
+    const size_t lanes = (size_t)blocks * kBlock;
+    if (lanes > d->lanes) {
+        size_t want = std::max<size_t>(d->lanes * 2, 2048 * (size_t)kBlock);
+        while (want < lanes) want *= 2;
+        int32_t* nb = nullptr;
+        if (hipMalloc((void**)&nb, sizeof(int32_t) * want * (size_t)d->rows) != hipSuccess) { (void)hipGetLastError(); d->failed = true; return false; }
+        if (d->buf) d->retired.push_back(d->buf);
+        d->buf = nb; d->lanes = want;
+    }
+    sc.deep = d->buf; sc.deep_lanes = (uint32_t)d->lanes;
+    return true;
+}
 constexpr int kMaxDevices = 64;
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {

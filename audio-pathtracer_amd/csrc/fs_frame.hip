@@ -28,8 +28,13 @@ struct FrameArgs {
 };
 static_assert(sizeof(FrameArgs) + sizeof(DeviceScene) <= 4096, "kernel arguments are limited to 4 KB");
 
+// 4 waves per SIMD (at most 128 VGPRs; the walk part spills a dozen registers outside its loops): with the bounded LDS stack
+// (DeviceScene.stack_limit) four workgroups share a CU: 0.313 -> 0.296 ms per cfg3 launch (profiles/r03_occupancy_ab.log)
+#ifndef FS_FRAME_MIN_WAVES
+#define FS_FRAME_MIN_WAVES 4
+#endif
 template <int B, bool BATCH>
-__global__ __launch_bounds__(kBlock) void frame_kernel(DeviceScene sc, FrameArgs a) {
+__global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(DeviceScene sc, FrameArgs a) {
     const uint32_t b = blockIdx.x;
     uint32_t first = 0;
     for (int i = 0; i < a.num_walk; ++i) {   // (walks first: starting the connect pass before the short walks measured slower)
@@ -51,7 +56,9 @@ __global__ __launch_bounds__(kBlock) void frame_kernel(DeviceScene sc, FrameArgs
 }
 
 template <int B>
-void launch_frame_t(const DeviceScene& sc, uint32_t blocks, size_t lds, const FrameArgs& a, bool batch, hipStream_t s) {
+void launch_frame_t(const DeviceScene& sc_in, uint32_t blocks, size_t lds, const FrameArgs& a, bool batch, hipStream_t s) {
+    DeviceScene sc = sc_in;
+    if (!attach_deep(sc, blocks)) return;
     if (batch) {
         allow_lds(frame_kernel<B, true>, lds);
         hipLaunchKernelGGL((frame_kernel<B, true>), dim3(blocks), dim3(kBlock), lds, s, sc, a);

@@ -80,7 +80,18 @@ struct DeviceScene {
     int32_t num_nodes;        // 0 = empty scene
     int32_t num_tris;
     int32_t num_materials;
-    int32_t stack_rows;       // LDS stack rows per lane for this tree (see kStackDepth)
+    int32_t stack_rows;       // LDS rows of the traversal stack area per lane (see kStackDepth); with a deep store the last
+                              //   one holds the lanes' deep counts
+    int32_t stack_limit;      // rows a lane's pending entries may use in LDS: stack_rows without a deep store (the tree's
+                              //   worst case + 1, nothing can overflow), else kStackRowsCap (more goes to `deep`)
+    // Deep store (only for trees whose worst case exceeds kStackRowsCap rows): [deep_rows][deep_lanes] ints in HBM, column
+    // blockIdx.x * kBlock + threadIdx.x.  A lane whose LDS rows are full moves its oldest entries there in chunks and
+    // takes them back when its LDS rows run empty (fs_device.hpp: trav_make_room / trav_refill).  The worst case assumes
+    // that a ray hits every child box at every level of the deepest path; rays that need more than kStackRowsCap rows
+    // are rare enough that the trips to HBM do not show, and the bounded LDS stack lets four workgroups share a CU.
+    int32_t* deep;
+    uint32_t deep_lanes;
+    struct DeepStore* deep_owner;   // host bookkeeping (grows the store when a launch has more lanes); unused on the device
 };
 
 // per-update constants handed to the kernels by value
@@ -163,6 +174,19 @@ struct WalkStage {
     int32_t begin = 0, end = 1 << 30;
     uint32_t slots_cap = 0xFFFFFFFFu;
 };
+
+// host side of DeviceScene.deep: owned by the context, grown by the launchers (attach_deep) when a grid has more lanes
+// than the store has columns.  A replaced buffer stays allocated until the scene is freed: launches already in the
+// stream still point at it.
+struct DeepStore {
+    int32_t* buf = nullptr;
+    size_t lanes = 0;
+    int rows = 0;                       // 0: the committed tree cannot overflow its LDS rows, no store
+    std::vector<int32_t*> retired;
+    bool failed = false;                // an allocation failed: the launch that needed it was skipped (sticky; fs_synchronize reports it)
+};
+constexpr int kStackRowsCap = 21;       // LDS rows for pending entries when the tree's worst case needs more (+ 1 row of deep counts)
+constexpr int kDeepChunk = 8;           // entries moved per trip to / from the deep store
 
 // ---- host BVH builder ------------------------------------------------------------------------------
 struct HostBVH {

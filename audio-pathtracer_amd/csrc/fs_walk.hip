@@ -42,6 +42,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
     while (walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
         Trav T;
         trav_init(T, kp.max_trace_dist, sc.num_nodes > 0);
+        trav_deep_reset(sc, stack);
 #ifdef FS_TRAV_STATS
         const unsigned steps = (unsigned)trav_run<false>(sc, ray, T, stack);
         if (g_step_buf) g_step_buf[(size_t)w.k * (2u * (size_t)kp.num_local) + w.g] = (unsigned short)steps;
@@ -99,8 +100,9 @@ uint32_t walk_stage_slots(const KParams& kp, int begin) {
     return (uint32_t)std::min<double>((double)lanes, 1.3 * expect + 1024.0);
 }
 
-void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
+void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
                  const uint32_t* perm, hipStream_t s, const WalkStage& stage_in) {
+    DeviceScene sc = sc_in;
     WalkStage stage = stage_in;
     if (stage.begin > 0 && stage.slots_cap == 0xFFFFFFFFu) stage.slots_cap = walk_stage_slots(kp, stage.begin);
     uint32_t lanes = stage.begin > 0 ? stage.slots_cap : 2u * kp.num_local;   // a later stage only has lanes for the walks still alive
@@ -119,9 +121,11 @@ void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& s
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
+        if (!attach_deep(sc, blocks)) return;
         FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
         return;
     }
+    if (!attach_deep(sc, full)) return;
     if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
         const size_t lds = stack_bytes(sc) + kShareLdsBytes;
         FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm, stage);

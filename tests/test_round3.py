@@ -276,3 +276,43 @@ def test_collision_spheres_in_batches_and_pipelines(pkg, scene_factory):
     for s, w in zip(srcs, want):
         assert w.any() and np.array_equal(ctx.energy_buffer(s), w)
     ctx.close()
+
+
+@pytest.mark.parametrize("cap", [12, 14, 21])
+def test_bounded_lds_stack_spills_to_the_deep_store(pkg, scene_factory, monkeypatch, cap):
+    """The LDS traversal stack holds FS_STACK_ROWS_CAP rows (default 21) when the tree's worst case needs more; a lane
+    that fills them moves its oldest entries to the deep store in HBM and takes them back later (fs_device.hpp:
+    trav_make_room / trav_refill).  With 12 rows on the mine's tree (worst case 30+) that happens all the time: closest
+    hits, any hits, integer energy sums and the pipelined frames must not change by a bit."""
+    sc = scene_factory("old_mine", 8)
+    rng = np.random.default_rng(77)
+    n = 50000
+    o = np.tile(np.asarray(sc.source, np.float32), (n, 1)) + rng.normal(scale=5.0, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out = {}
+    for mode in ("worst_case_rows", "capped"):
+        if mode == "capped":
+            monkeypatch.setenv("FS_STACK_ROWS_CAP", str(cap))
+        else:
+            monkeypatch.setenv("FS_STACK_ROWS_CAP", "64")
+        ctx, src = make_ctx(pkg, sc)
+        need = ctx.stats()["bvh_stack_need"]
+        assert need + 1 > cap + 1, "the scene must need more rows than the cap for this test to mean anything"
+        hit, t, tri, nrm = ctx.trace_rays(o, d, 1e6)
+        anyhit = ctx.trace_rays(o, d, 3000.0, any_hit=True)[0]
+        p = pkg.default_params(num_rays=65536, depth=8, seed=4242, flags=DET)
+        e_plain = ctx.compute_energy_response(src, p).copy()
+        p0 = pkg.default_params(num_rays=32768, depth=0, seed=4243, flags=DET)
+        e_unbounded = ctx.compute_energy_response(src, p0).copy()
+        ctx.set_pipelining(2)
+        for _ in range(4):
+            ctx.compute_energy_response_async(src, p)
+        ctx.synchronize()
+        e_piped = ctx.energy_buffer(src).copy()
+        out[mode] = (hit.copy(), t.copy(), tri.copy(), nrm.copy(), anyhit.copy(), e_plain, e_unbounded, e_piped)
+        ctx.close()
+    assert out["capped"][0].any() and out["capped"][5].any() and out["capped"][6].any()
+    for a, b in zip(out["worst_case_rows"], out["capped"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out["capped"][5], out["capped"][7])     # the pipelined frames are the same frame four times
