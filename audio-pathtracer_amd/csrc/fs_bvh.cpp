@@ -5,16 +5,16 @@
 //
 //   1. top-down binned SAH BVH2 over triangle centroids, <= 2 triangles per leaf (a triangle test costs about
 //      as much as 2.5 child boxes on this kernel, so small leaves win: DESIGN.md section 5);
-//   2. greedy collapse to a 4-wide tree (the child with the largest surface area is opened until the node
-//      has 4 children);
+//   2. collapse to a 4-wide tree: the set of BVH2 nodes that become 4-wide nodes is chosen by dynamic programming so
+//      that their summed surface area — the expected number of node visits — is least (CollapsePlan);
 //   3. flatten breadth-first into 64-byte nodes: child boxes quantised to 8 bits per plane on a
 //      per-node power-of-two grid (rounded outwards), so one node = 4 child boxes = 4 x 16-byte loads.
 //
 // Leaf boxes are padded far beyond the float error of the slab and triangle tests and quantisation only
 // grows boxes, so the closest hit found through the tree equals the brute-force closest hit: results do
 // not depend on the tree.  The builder reports the traversal stack the tree needs (worst-case number of pending
-// entries along any root-to-leaf path; the kernels size their LDS stack from it) and rebuilds the BVH2 shallower
-// only if that exceeds kStackDepth.
+// entries along any root-to-leaf path; the kernels size their LDS stack and its deep store from it) and rebuilds the
+// BVH2 shallower only if that exceeds kStackDepth.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -258,10 +258,10 @@ struct CollapsePlan {
 
 void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wide, std::vector<int>& wide_of,
               std::vector<int>& level) {
-    // default: the greedy rule below.  FS_BVH_DP_COLLAPSE=1 takes the exact minimum instead: 16 % fewer nodes and 1.9 % fewer
-    // node visits per ray on old_mine (tools/tree_cost.cpp), but 3 more worst-case stack rows and no measurable gain on the
-    // GPU (profiles/r03_ab_tree.log), so it stays an experiment
-    static const bool greedy = std::getenv("FS_BVH_DP_COLLAPSE") == nullptr;
+    // default: the exact minimum (16 % fewer nodes and 1.9 % fewer node visits per ray on old_mine, tools/tree_cost.cpp;
+    // +0.7 % rays/s, profiles/r03_ab_tree.log).  Its fuller nodes raise the worst-case stack need by three rows, which
+    // the bounded LDS stack makes harmless.  FS_BVH_GREEDY_COLLAPSE=1: open the child of largest area instead.
+    static const bool greedy = std::getenv("FS_BVH_GREEDY_COLLAPSE") != nullptr;
     CollapsePlan plan;
     if (!greedy) plan.solve(bn, root);
     // breadth-first so the top of the tree is a contiguous prefix of the node array
