@@ -415,7 +415,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     // (a launch carries one frame's worth of work, ~0.6 ms at 262 144 subpaths; a bounce of a wave on the full chip
     // takes ~35 us, so longer stages make their chain the launch's length), longer ones for the few hundred walks beyond
     // the main record tier (tools/stage_sweep.py, profiles/r03_stage_sweep.log)
-    ctx->stage_bounds = {12, 24, 36, 48, 64, 80, 104};
+    ctx->stage_bounds = {8, 18, 30, 46, 64, 96};   // best of the sets tried on 262 144-ray frames at roulette 0.9 (profiles/r03_stage_sweep.log)
     if (const char* v = std::getenv("FS_STAGE_DENSE_FROM")) ctx->stage_dense_from = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("FS_WALK_STAGES")) {
         std::vector<int> b;
