@@ -49,9 +49,12 @@ def main(argv):
         doc["_tag"] = tag
         entry = {}
         for k in acc:
-            if "true>" in k.replace(" ", "") and not k.startswith("connect"):   # walk_kernel_*<0, true> = counting instantiation
+            # the counting instantiations (fs_set_profiling level 3: one untimed frame of the bench) are left out:
+            # walk_kernel_*<LOBES, COUNT, EXT>, connect_kernel<B, LOBES, BATCH, COUNT, EXT>
+            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k and ">" in k else []
+            if k.startswith("walk_kernel") and len(targs) > 1 and targs[1] == "true":
                 continue
-            if k.startswith("connect_kernel") and k.replace(" ", "").endswith(",true>"):
+            if k.startswith("connect_kernel") and len(targs) > 3 and targs[3] == "true":
                 continue
             base = "walk_kernel" if k.startswith("walk_kernel") else ("connect_kernel" if k.startswith("connect_kernel")
                                                                        else (k.split("<")[0] if k.endswith(">") else None))
