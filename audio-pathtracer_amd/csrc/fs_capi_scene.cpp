@@ -159,6 +159,7 @@ static void finish_commit(fs_context* ctx, size_t scene_bytes) {
         ctx->deep = DeepStore{};
         ctx->deep.rows = deep_rows;
     }
+    ctx->scene.stack_worst = traversal_lds_bytes(worst, ctx->cfg.num_bands, ctx->num_bins) <= ctx->lds_limit ? worst : 0;
     ctx->scene.deep = nullptr; ctx->scene.deep_lanes = 0;
     ctx->scene.deep_owner = &ctx->deep;
     ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();

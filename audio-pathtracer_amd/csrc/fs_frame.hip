@@ -1,5 +1,19 @@
 // fs_frame.hip — pipelined frames: ONE launch for the walk of one frame, the connect pass of an older one and the plan
 // pass of the newest (fs_set_pipelining; fs_capi_frame.cpp).
+//
+// Compiled twice (Makefile): as it stands — the kernel limited to 128 VGPRs and the LDS stack capped, so that four
+// workgroups share a CU, for launches that fill the chip — and through fs_frame_wide.hip with FS_FRAME_WIDE defined:
+// no register limit, the tree's worst-case stack rows in LDS and none of the deep-store logic in the traversal, for
+// launches too small for occupancy to matter (cfg2: 0.105 -> 0.097 ms, cfg4 at 131 072 rays: 400 -> 435 M rays/s).
+#ifdef FS_FRAME_WIDE
+#define FS_DEEP_NO_POP 1
+#define FS_DEEP_NO_CHECK 1
+#define FS_FRAME_MIN_WAVES 1
+#define frame_kernel frame_kernel_wide
+#define FS_LAUNCH_FRAME launch_frame_wide
+#else
+#define FS_LAUNCH_FRAME launch_frame_narrow
+#endif
 #include "fs_device.hpp"
 
 namespace fs {
@@ -70,7 +84,8 @@ void launch_frame_t(const DeviceScene& sc_in, uint32_t blocks, size_t lds, const
 
 }  // namespace
 
-bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s) {
+// blocks_only: report the grid this frame would be launched with and return (nothing is launched)
+bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s, uint32_t* blocks_only) {
     FrameArgs a{};
     uint32_t blocks = 0;
     size_t lds = 0;
@@ -110,6 +125,7 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
         blocks += pb;
     }
     if (blocks == 0) return false;
+    if (blocks_only) { *blocks_only = blocks; return true; }
     const bool batch = f.has_connect && f.energy_tab;
     switch (B) {   // the band counts in use; 0 = kp.num_bands at run time (fs_connect.hip)
         case 1: launch_frame_t<1>(sc, blocks, lds, a, batch, s); break;
@@ -119,5 +135,29 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
     }
     return true;
 }
+
+#ifndef FS_FRAME_WIDE
+bool launch_frame_wide(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s, uint32_t* blocks_only);   // fs_frame_wide.hip
+
+// Launches with fewer workgroups than the chip holds at four per CU take the wide flavour (see the top of the file), and
+// so do small frames that only reach that many workgroups because their walks run on sparse waves (a few subpaths per
+// wave, the other lanes help): there the fourth workgroup of a CU adds helpers, not work.
+constexpr uint32_t kFrameNarrowFromBlocks = 1024;
+bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s) {
+    uint32_t blocks = 0;
+    if (!launch_frame_narrow(B, sc, f, s, &blocks)) return false;
+    static const bool dbg = std::getenv("FS_DEBUG_FRAME") != nullptr;
+    if (dbg) std::fprintf(stderr, "[launch_frame] blocks %u stack_worst %d rows %d limit %d\n", blocks, sc.stack_worst, sc.stack_rows, sc.stack_limit);
+    bool dense = f.num_walk == 0;
+    for (int i = 0; i < f.num_walk; ++i) dense = dense || !(f.walk[i].wl.rays_per_wave > 0 && f.walk[i].wl.rays_per_wave < 64);
+    if (sc.stack_worst > 0 && (blocks < kFrameNarrowFromBlocks || !dense)) {
+        DeviceScene w = sc;
+        w.stack_rows = sc.stack_worst; w.stack_limit = sc.stack_worst;
+        w.deep = nullptr; w.deep_lanes = 0; w.deep_owner = nullptr;
+        return launch_frame_wide(B, w, f, s, nullptr);
+    }
+    return launch_frame_narrow(B, sc, f, s, nullptr);
+}
+#endif
 
 }  // namespace fs
