@@ -305,12 +305,19 @@ def test_bounded_lds_stack_spills_to_the_deep_store(pkg, scene_factory, monkeypa
         e_plain = ctx.compute_energy_response(src, p).copy()
         p0 = pkg.default_params(num_rays=32768, depth=0, seed=4243, flags=DET)
         e_unbounded = ctx.compute_energy_response(src, p0).copy()
+        pbig = pkg.default_params(num_rays=262144, depth=8, seed=4244, flags=DET)
+        e_big_plain = ctx.compute_energy_response(src, pbig).copy()
         ctx.set_pipelining(2)
         for _ in range(4):
-            ctx.compute_energy_response_async(src, p)
+            ctx.compute_energy_response_async(src, p)      # a small launch: the wide flavour of the frame kernel (fs_frame.hip)
         ctx.synchronize()
         e_piped = ctx.energy_buffer(src).copy()
-        out[mode] = (hit.copy(), t.copy(), tri.copy(), nrm.copy(), anyhit.copy(), e_plain, e_unbounded, e_piped)
+        for _ in range(3):
+            ctx.compute_energy_response_async(src, pbig)   # 1024+ workgroups: the 128-VGPR flavour with the bounded stack
+        ctx.synchronize()
+        e_big_piped = ctx.energy_buffer(src).copy()
+        assert np.array_equal(e_big_plain, e_big_piped)
+        out[mode] = (hit.copy(), t.copy(), tri.copy(), nrm.copy(), anyhit.copy(), e_plain, e_unbounded, e_piped, e_big_piped)
         ctx.close()
     assert out["capped"][0].any() and out["capped"][5].any() and out["capped"][6].any()
     for a, b in zip(out["worst_case_rows"], out["capped"]):
