@@ -148,9 +148,10 @@ static void finish_commit(fs_context* ctx, size_t scene_bytes) {
     const int worst = std::max(ctx->bvh.stack_need, 2) + kStackSlack;
     int deep_rows = 0;
     if (worst <= ctx->stack_rows_cap + 1) {
-        ctx->scene.stack_rows = worst; ctx->scene.stack_limit = worst;
+        ctx->scene.stack_rows = worst; ctx->scene.stack_limit = worst; ctx->scene.stack_attn = 0x7FFFFFFFu;
     } else {
         ctx->scene.stack_rows = ctx->stack_rows_cap + 1; ctx->scene.stack_limit = ctx->stack_rows_cap;
+        ctx->scene.stack_attn = (uint32_t)(ctx->stack_rows_cap - 4);
         deep_rows = ((worst + kDeepChunk - 1) / kDeepChunk) * kDeepChunk + kDeepChunk;
     }
     if (deep_rows != ctx->deep.rows) {   // (every commit has drained the stream: nothing reads the old store any more)

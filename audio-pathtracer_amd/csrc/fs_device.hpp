@@ -243,67 +243,60 @@ struct TriRegs { v4f a, b, c; };
 
 // ---- bounded LDS stack with a deep store in HBM (DeviceScene.deep, fs_internal.hpp) ---------------------------
 // The logical stack of a lane is  deep[0, count)  followed by  LDS rows [sb, sp).  Entries move between the two in
-// chunks of kDeepChunk, oldest first out, newest first back, so pops keep their order.  A lane with entries in the
-// deep store carries kDeepFlag in T.sb (its real bottom is row 0: it gives nothing away to idle lanes meanwhile), so
-// the ordinary pop test `sp > sb` fails for it and sends it down the slow path — the ordinary lanes pay one compare
-// on their way out of a traversal and no LDS access (reading the count there cost 7 % of the walk).
-constexpr int kDeepFlag = 1 << 20;
+// chunks of kDeepChunk, oldest first out, newest first back, so pops keep their order.  All of it happens in ONE place,
+// trav_maintain, called at the top of a step for the lanes that need it; the pops and pushes of the step are the plain
+// LDS ones.  A lane with entries in the deep store carries T.sb = kDeepSb (-2; its real bottom is row 0 and it gives
+// nothing away to idle lanes meanwhile) and is kept at >= 2 LDS entries at the top of every step — a step pops at most
+// twice — so its pop test `sp > sb` never fails while the deep store still holds something.  One unsigned compare finds
+// both kinds of lane:  (unsigned)(sp + sb) >= limit - 4  (DeviceScene.stack_attn) is true for a lane close to its last rows (sb >= 0; two rows
+// early, or earlier for a lane that has given entries away — trav_maintain looks again) and for a flagged lane with
+// sp < 2 (sp - 2 wraps) or close to its last rows.  (Tests in the pops themselves cost 2 % of the walk, a deep count
+// read from LDS on every empty pop 7 %: profiles/r03_occupancy_ab.log.)
+constexpr int kDeepSb = -2;
 __device__ __forceinline__ int* trav_deep_count(const DeviceScene& sc, int* stack) { return stack + (size_t)sc.stack_limit * kBlock; }
 __device__ __forceinline__ void trav_deep_reset(const DeviceScene& sc, int* stack) {
     if (sc.deep != nullptr) *trav_deep_count(sc, stack) = 0;
 }
-// a node visit may write above row stack_limit - 1: close the gap left by donated entries, then move the oldest
-// entries out.  Afterwards sp + 2 < stack_limit.
-__device__ __forceinline__ void trav_make_room(const DeviceScene& sc, Trav& T, int* stack) {
-    const int R = sc.stack_limit;
+__device__ __forceinline__ bool trav_needs_maintenance(const DeviceScene& sc, const Trav& T) {
+    return (unsigned)(T.sp + T.sb) >= sc.stack_attn;   // stack_limit - 4 with a deep store, else never
+}
+// (rolled loops: these paths are as good as never taken, their code should stay small inside the traversal loop)
+__device__ __forceinline__ void trav_maintain(const DeviceScene& sc, Trav& T, int* stack) {
     if (sc.deep == nullptr) return;   // (without a deep store stack_limit covers the tree's worst case)
-    if (T.sb > 0 && T.sb < kDeepFlag) {
+    int* cnt = trav_deep_count(sc, stack);
+    int32_t* col = sc.deep + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (T.sb < 0) {
+        if (T.sp < 2) {   // the newest chunk comes back, below the entry that may be left
+            const int have = *cnt;
+            if (T.sp == 1) stack[kDeepChunk * kBlock] = stack[0];
+#pragma unroll 1
+            for (int i = 0; i < kDeepChunk; ++i) stack[i * kBlock] = col[(size_t)(have - kDeepChunk + i) * sc.deep_lanes];
+            T.sp += kDeepChunk;
+            *cnt = have - kDeepChunk;
+            if (have == kDeepChunk) T.sb = 0;
+            return;
+        }
+    } else if (T.sb > 0) {   // close the gap left by donated entries
         const int n = T.sp - T.sb;
 #pragma unroll 1
         for (int i = 0; i < n; ++i) stack[i * kBlock] = stack[(T.sb + i) * kBlock];
         T.sb = 0; T.sp = n;
     }
-    if (T.sp + 2 >= R) {
-        int* cnt = trav_deep_count(sc, stack);
+    if (T.sp + 2 >= sc.stack_limit) {   // a node visit writes up to row sp + 2: the oldest chunk goes out
         const int have = *cnt;
-        int32_t* col = sc.deep + (size_t)blockIdx.x * kBlock + threadIdx.x;
-        // (rolled loops: these paths are as good as never taken, their code should stay small inside the traversal loop)
 #pragma unroll 1
         for (int i = 0; i < kDeepChunk; ++i) col[(size_t)(have + i) * sc.deep_lanes] = stack[i * kBlock];
 #pragma unroll 1
         for (int i = kDeepChunk; i < T.sp; ++i) stack[(i - kDeepChunk) * kBlock] = stack[i * kBlock];
         T.sp -= kDeepChunk;
-        T.sb = kDeepFlag;
+        T.sb = kDeepSb;
         *cnt = have + kDeepChunk;
     }
-}
-// pop of a lane that has entries in the deep store (T.sb == kDeepFlag): from its LDS rows while there are any, else
-// the newest chunk comes back first
-__device__ __forceinline__ void trav_pop_deep(const DeviceScene& sc, Trav& T, int* stack) {
-    if (T.sp == 0) {
-        int* cnt = trav_deep_count(sc, stack);
-        const int have = *cnt;
-        const int32_t* col = sc.deep + (size_t)blockIdx.x * kBlock + threadIdx.x;
-#pragma unroll 1
-        for (int i = 0; i < kDeepChunk; ++i) stack[i * kBlock] = col[(size_t)(have - kDeepChunk + i) * sc.deep_lanes];
-        T.sp = kDeepChunk;
-        T.sb = have > kDeepChunk ? kDeepFlag : 0;
-        *cnt = have - kDeepChunk;
-    }
-    --T.sp;
-    T.cur = stack[T.sp * kBlock];
 }
 // next pending entry into T.cur (kDone: none left)
 __device__ __forceinline__ void trav_pop(const DeviceScene& sc, Trav& T, int* stack) {
     if (T.sp > T.sb) { --T.sp; T.cur = stack[T.sp * kBlock]; }
-    else {
-        T.cur = kDone;
-#ifndef FS_DEEP_NO_POP   // timing experiments only
-        if (__builtin_expect(__ballot(T.sb >= kDeepFlag) != 0ull, 0)) {
-            if (T.sb >= kDeepFlag) trav_pop_deep(sc, T, stack);
-        }
-#endif
-    }
+    else T.cur = kDone;
 }
 
 __device__ __forceinline__ void trav_settle(const DeviceScene& sc, Trav& T, int* stack) {
@@ -487,9 +480,9 @@ __device__ __forceinline__ void trav_advance(const DeviceScene& sc, const Ray& r
     // bounded LDS stack: a node visit writes up to row sp + 2.  Checked here, ahead of the node arithmetic and as one
     // scalar branch for the wave, so that the node part stays a single basic block; lanes of trees without a deep store
     // (stack_limit = worst case + 1) may pass the test near their worst case and return at once.
-#ifndef FS_DEEP_NO_CHECK   // timing experiments only
-    if (__builtin_expect(__ballot(T.sp + 2 >= sc.stack_limit) != 0ull, 0)) {
-        if (T.sp + 2 >= sc.stack_limit) trav_make_room(sc, T, stack);
+#ifndef FS_DEEP_NO_CHECK   // compiled out in the wide flavour of the frame kernel (worst-case rows, fs_frame.hip)
+    if (__builtin_expect(__ballot(trav_needs_maintenance(sc, T)) != 0ull, 0)) {
+        if (trav_needs_maintenance(sc, T)) trav_maintain(sc, T, stack);
     }
 #endif
     if (has_node) trav_node_part(sc, r, T, stack, N);
@@ -1076,7 +1069,7 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
         if (busy_m == 0ull) return true;                // nothing left anywhere in the wave
         const unsigned long long idle_m = __ballot(idle);
         if (__popcll(idle_m) < kShareMinIdle) return false;
-        const bool can_give = !idle && T.sp > T.sb;
+        const bool can_give = !idle && T.sp > T.sb && T.sb >= 0;   // (a lane with entries in the deep store keeps what it has)
         const unsigned long long give_m = __ballot(can_give);
         if (idle_m != 0ull && give_m != 0ull) {
             const int n = min(__popcll(idle_m), __popcll(give_m));

@@ -6,7 +6,6 @@
 // no register limit, the tree's worst-case stack rows in LDS and none of the deep-store logic in the traversal, for
 // launches too small for occupancy to matter (cfg2: 0.105 -> 0.097 ms, cfg4 at 131 072 rays: 400 -> 435 M rays/s).
 #ifdef FS_FRAME_WIDE
-#define FS_DEEP_NO_POP 1
 #define FS_DEEP_NO_CHECK 1
 #define FS_FRAME_MIN_WAVES 1
 #define frame_kernel frame_kernel_wide
@@ -152,7 +151,7 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
     for (int i = 0; i < f.num_walk; ++i) dense = dense || !(f.walk[i].wl.rays_per_wave > 0 && f.walk[i].wl.rays_per_wave < 64);
     if (sc.stack_worst > 0 && (blocks < kFrameNarrowFromBlocks || !dense)) {
         DeviceScene w = sc;
-        w.stack_rows = sc.stack_worst; w.stack_limit = sc.stack_worst;
+        w.stack_rows = sc.stack_worst; w.stack_limit = sc.stack_worst; w.stack_attn = 0x7FFFFFFFu;
         w.deep = nullptr; w.deep_lanes = 0; w.deep_owner = nullptr;
         return launch_frame_wide(B, w, f, s, nullptr);
     }

@@ -89,6 +89,8 @@ struct DeviceScene {
     // takes them back when its LDS rows run empty (fs_device.hpp: trav_make_room / trav_refill).  The worst case assumes
     // that a ray hits every child box at every level of the deepest path; rays that need more than kStackRowsCap rows
     // are rare enough that the trips to HBM do not show, and the bounded LDS stack lets four workgroups share a CU.
+    uint32_t stack_attn;      // stack_limit - 4 with a deep store, else 0x7FFFFFFF: (unsigned)(sp + sb) >= stack_attn sends a
+                              //   lane to trav_maintain at the top of a step (fs_device.hpp)
     int32_t stack_worst;      // rows of a stack that cannot overflow (worst case + 1) if a workgroup may have that much LDS, else
                               //   0: what the wide flavour of the frame kernel runs with (fs_frame.hip)
     int32_t* deep;

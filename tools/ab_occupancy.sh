@@ -1,6 +1,6 @@
 #!/bin/bash
-# Occupancy experiment (timing only: fewer stack rows than the tree's worst case are UNSAFE): frame kernel limited to
-# 128 VGPRs (tools/tmp/w4, -DFS_FRAME_MIN_WAVES=4 -DFS_EXPERIMENTS) with LDS for 3 or 4 workgroups per CU
+# Occupancy experiment: the narrow frame kernel limited to 96 VGPRs (tools/tmp/w5, -DFS_FRAME_MIN_WAVES=5) with LDS stack
+# caps that let 4 or 5 workgroups share a CU (safe: the deep store takes the overflow)
 set -o pipefail
 cp audio-pathtracer_amd/libfrequensee.so /tmp/base.so
 run() {  # name env...
@@ -12,9 +12,9 @@ j=json.load(open('/tmp/o.json')); print(sys.argv[1], 'ms', round(j['ms_per_step'
 PY
 }
 run base FS_X=1 &&
-cp tools/tmp/w4/libfrequensee.so audio-pathtracer_amd/libfrequensee.so &&
-run w4_rows_default FS_X=1 &&
-run w4_rows24 FS_UNSAFE_STACK_ROWS=24 &&
-run w4_rows22 FS_UNSAFE_STACK_ROWS=22 &&
-run w4_rows20 FS_UNSAFE_STACK_ROWS=20
+run base_cap15 FS_STACK_ROWS_CAP=15 &&
+cp tools/tmp/w5/libfrequensee.so audio-pathtracer_amd/libfrequensee.so &&
+run w5_cap21 FS_X=1 &&
+run w5_cap15 FS_STACK_ROWS_CAP=15 &&
+run w5_cap13 FS_STACK_ROWS_CAP=13
 cp /tmp/base.so audio-pathtracer_amd/libfrequensee.so
