@@ -96,7 +96,9 @@ bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool*
 uint32_t walk_stage_slots(const KParams& kp, int begin) {
     const uint32_t lanes = 2u * kp.num_local;
     if (begin <= 0 || !kp.russian_roulette) return lanes;
-    const double expect = (double)lanes * std::pow((double)kp.rr_prob, (double)begin);
+    // (a stage that begins beyond FS_MAX_DEPTH visits every slot of the last schedule bucket — all walks of FS_MAX_DEPTH
+    // steps or more; pricing it at rr^begin overflowed frames of 900 000+ rays)
+    const double expect = (double)lanes * std::pow((double)kp.rr_prob, (double)std::min(begin, FS_MAX_DEPTH));
     return (uint32_t)std::min<double>((double)lanes, 1.3 * expect + 1024.0);
 }
 

@@ -323,3 +323,22 @@ def test_bounded_lds_stack_spills_to_the_deep_store(pkg, scene_factory, monkeypa
     for a, b in zip(out["worst_case_rows"], out["capped"]):
         assert np.array_equal(a, b)
     assert np.array_equal(out["capped"][5], out["capped"][7])     # the pipelined frames are the same frame four times
+
+
+def test_staged_walks_of_a_million_ray_frame(pkg, scene_factory):
+    """A stage that begins beyond step 64 visits every walk of the last schedule bucket (64 steps or more), not only the
+    rr^begin that are still alive: with 917 504 rays that is 1 082 slots against the 1 072 a launch used to provision —
+    every such frame ended in FS_ERR_OVERFLOW (found by tools/stage_sizes.py)."""
+    sc = scene_factory("old_mine", 8)
+    out = {}
+    for depth in (0, 2):
+        ctx, src = make_ctx(pkg, sc)
+        ctx.set_pipelining(depth)
+        p = pkg.default_params(num_rays=917504, depth=0, seed=31, flags=DET)
+        for k in range(3):
+            p.seed = 31 + k
+            ctx.compute_energy_response_async(src, p)
+        ctx.synchronize()                                   # used to raise status 9
+        out[depth] = ctx.energy_buffer(src).copy()
+        ctx.close()
+    assert out[0].any() and np.array_equal(out[0], out[2])
