@@ -176,7 +176,7 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
     // (rr = 0.9, the reference's roulette: 1.2e-3 of the walks; check_params bounds rr for uncapped walks)
     uint32_t want_cap = ctx->over_cap;
     if (unbounded) {
-        want_cap = std::max(ctx->over_cap, (uint32_t)std::min<size_t>(lanes, (size_t)(4.0 * tail * (double)lanes) + 64));
+        want_cap = (uint32_t)std::min<size_t>(lanes, std::max<size_t>(ctx->over_cap, (size_t)(4.0 * tail * (double)lanes) + 64));   // (a slot per lane is all a frame can use)
         if (const char* v = std::getenv("FS_OVER_CAP")) want_cap = std::max(ctx->over_cap, (uint32_t)std::max(1, std::atoi(v)));   // tests: force the regrow path
     }
     const bool new_sets = sets != ctx->state_sets || staged != ctx->state_cont;

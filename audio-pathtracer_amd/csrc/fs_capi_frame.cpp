@@ -21,7 +21,10 @@ int check_overflow(fs_context* ctx) {
     FS_HIP(ctx, hipMemcpy(&flag, ctx->d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
     if (!flag) return FS_OK;
     FS_HIP(ctx, hipMemset(ctx->d_overflow, 0, sizeof(flag)));
-    const uint32_t grown = std::max<uint32_t>(ctx->over_cap, 16) * 4;
+    // two things can overflow: the second record tier (more walks beyond FS_MAX_DEPTH steps than it has slots) and the
+    // lanes of a later stage of a staged walk (more survivors than provisioned) — the retry gets more of both
+    ctx->stage_margin = std::min(ctx->stage_margin * 2.0f, 64.0f);
+    const uint32_t grown = (uint32_t)std::min<uint64_t>((uint64_t)std::max<uint32_t>(ctx->over_cap, 16) * 4, 1u << 28);
     if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);
     if (ctx->d_over_mat) (void)hipFree(ctx->d_over_mat);
     if (ctx->d_over_pos) (void)hipFree(ctx->d_over_pos);
@@ -228,6 +231,7 @@ void frame_describe(fs_context* ctx, Frame& f) {
     kp.russian_roulette = p->russian_roulette;
     kp.cosine = (p->flags & FS_FLAG_COSINE_SAMPLING) ? 1 : 0;
     kp.rr_prob = p->rr_prob;
+    kp.stage_margin = ctx->stage_margin;
     kp.max_trace_dist = p->max_trace_dist;
     kp.surface_offset = p->surface_offset;
     kp.connect_pullback = p->connect_pullback;

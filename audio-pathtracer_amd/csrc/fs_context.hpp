@@ -130,6 +130,7 @@ struct fs_context {
     int32_t T = 0, M = 0;
     bool committed = false;
     NodeQ4* d_nodes = nullptr;
+    float stage_margin = 1.3f;        // KParams.stage_margin
     DeepStore deep;                   // HBM spill area of the bounded LDS traversal stacks (DeviceScene.deep)
     int stack_rows_cap = kStackRowsCap;   // FS_STACK_ROWS_CAP
     Tri64* d_tris = nullptr;          // authoring records (builders, refit, fs_scene_update_triangles)

@@ -114,6 +114,8 @@ struct KParams {
     int32_t lobes;         // 1 = FS_FLAG_MATERIAL_LOBES: the walk picks a specular / diffuse / transmitted lobe per vertex
     int32_t mis;           // all-connections mode: 1 = balance-heuristic weights, 0 = uniform
     float rr_prob, max_trace_dist, surface_offset, connect_pullback;
+    float stage_margin;    // staged walks: lanes a later stage is given = stage_margin x the expected survivors + 1024 (1.3; doubled
+                           //   by the overflow retry if a frame ever had more)
     float dist_divisor, min_seg, prob_exponent, energy_clamp, energy_gain, sound_speed;
     float norm;            // 1/P or 1/1000 (ARTS.cpp:164)
     float air[FS_MAX_BANDS];

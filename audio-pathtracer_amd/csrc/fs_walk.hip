@@ -99,7 +99,7 @@ uint32_t walk_stage_slots(const KParams& kp, int begin) {
     // (a stage that begins beyond FS_MAX_DEPTH visits every slot of the last schedule bucket — all walks of FS_MAX_DEPTH
     // steps or more; pricing it at rr^begin overflowed frames of 900 000+ rays)
     const double expect = (double)lanes * std::pow((double)kp.rr_prob, (double)std::min(begin, FS_MAX_DEPTH));
-    return (uint32_t)std::min<double>((double)lanes, 1.3 * expect + 1024.0);
+    return (uint32_t)std::min<double>((double)lanes, (double)std::max(kp.stage_margin, 1.3f) * expect + 1024.0);
 }
 
 void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
