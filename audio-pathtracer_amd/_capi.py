@@ -49,7 +49,7 @@ EXPORTS = [
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
     "fs_apply_material_fd", "fs_energy_handoff", "fs_scene_update_triangles", "fs_scene_refit", "fs_set_impulse_response",
     "fs_scene_commit_fast", "fs_comm_unique_id", "fs_comm_init", "fs_comm_attach", "fs_comm_detach", "fs_comm_enable_oneshot", "fs_shard_range",
-    "fs_peers_init", "fs_peers_detach", "fs_gather_energy", "fs_gather_energy_async", "fs_set_pipelining", "fs_set_walk_stages", "fs_submit", "fs_scene_commit_progressive", "fs_scene_refine_pending", "fs_scene_refine_wait",
+    "fs_peers_init", "fs_peers_detach", "fs_gather_energy", "fs_gather_energy_async", "fs_set_pipelining", "fs_set_walk_stages", "fs_set_frames_per_launch", "fs_submit", "fs_scene_commit_progressive", "fs_scene_refine_pending", "fs_scene_refine_wait",
 ]
 COMM_ID_BYTES = 128
 ERR_COMM = 8
@@ -238,6 +238,7 @@ def load():
         "fs_peers_detach": (C.c_int, [vp]),
         "fs_set_pipelining": (C.c_int, [vp, i32]),
         "fs_set_walk_stages": (C.c_int, [vp, vp, i32]),
+        "fs_set_frames_per_launch": (C.c_int, [vp, i32]),
         "fs_submit": (C.c_int, [vp]),
         "fs_scene_commit_progressive": (C.c_int, [vp]),
         "fs_scene_refine_pending": (C.c_int, [vp, C.POINTER(i32)]),

@@ -114,6 +114,11 @@ class Context:
         is held back as well — one launch plans frame f, walks f - 1 and connects f - 2 (include/frequensee.h)"""
         self.check(self.lib.fs_set_pipelining(self.h, int(depth)))
 
+    def set_frames_per_launch(self, n: int):
+        """fs_set_frames_per_launch: with pipelining on, plain frames wait until n have come and share one launch (every frame
+        keeps its seed, energy buffer and recorded reconstruct: the results are those of n single frames)"""
+        self.check(self.lib.fs_set_frames_per_launch(self.h, int(n)))
+
     def set_walk_stages(self, bounds):
         """fs_set_walk_stages: the steps at which a pipelined depth = 0 walk moves on to the next launch ([] = such frames are not held)"""
         arr = np.asarray(list(bounds), dtype=np.int32)

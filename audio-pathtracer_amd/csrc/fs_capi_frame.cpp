@@ -40,16 +40,21 @@ namespace {
 // the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
 // frames (cur rotated): the per-frame fields are switched back for the duration.
 static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
+    // the items of a frame were connected by ONE launch: once the tail stream waits behind it (the first item's handoff),
+    // the other items' reconstructs are ordered too — no further event pairs on the compute stream (each is a bubble
+    // between its launches).  Not in deterministic mode: every item's fixed-point rounding runs on the compute stream first.
+    bool tail_behind_launch = false;
     for (const fs_context::PipeFrame::Item& it : q.items) {
         Source* s = it.s;
         const bool moved_on = s->cur != it.cur;
         const int cur = s->cur;
         const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
-        s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false; s->tail_ordered = false;
+        s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
+        s->tail_ordered = tail_behind_launch && !q.fixed && !ctx->comm;
         int rc = FS_OK;
         if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
         if (ctx->comm) rc = reduce_energy(ctx, s);
-        if (!rc && it.want_recon) rc = reconstruct_now(ctx, s, &it.recon);
+        if (!rc && it.want_recon) { rc = reconstruct_now(ctx, s, &it.recon); if (!rc && s->tail_ordered) tail_behind_launch = true; }
         if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered; }
         if (rc) return rc;
     }
@@ -84,7 +89,10 @@ static bool held_walk_part(const fs_context* ctx, const fs_context::PipeFrame& q
 }  // namespace
 
 // Let every held frame finish on its own kernels, oldest first: something needs their results (or their buffers) now.
+int dispatch_group(fs_context* ctx);   // below: the frames collected by fs_set_frames_per_launch go first
+
 int flush_pending(fs_context* ctx) {
+    if (!ctx->group.empty()) { const int gr = dispatch_group(ctx); if (gr) return gr; }
     if (ctx->held.empty()) return FS_OK;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     while (!ctx->held.empty()) {
@@ -115,10 +123,12 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
                                      : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
 
     poll_published(s);
-    // never overwrite the front buffer: at most two publishes in flight
-    if (s->enqueued >= 2) {
-        int slot = (int)((s->enqueued - 1) % kIrRing);
-        if (s->seq_of[slot] == s->enqueued - 1 && s->front.load(std::memory_order_relaxed) < s->enqueued - 1) {
+    // never overwrite the front buffer: at most kIrRing - 1 publishes in flight (publish seq reuses the slot of
+    // seq - kIrRing, so publish seq - kIrRing + 1 must have completed before seq is enqueued)
+    if (s->enqueued + 1 >= (uint64_t)kIrRing) {
+        const uint64_t must = s->enqueued + 2 - (uint64_t)kIrRing;
+        const int slot = (int)(must % kIrRing);
+        if (s->seq_of[slot] == must && s->front.load(std::memory_order_relaxed) < must) {
             FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
             poll_published(s);
         }
@@ -189,6 +199,7 @@ struct Frame {
     Source* const* srcs = nullptr;
     int count = 0;
     const fs_params* p = nullptr;
+    const fs_context::GroupEntry* group = nullptr;   // grouped frames: one entry per item (own seed, recorded reconstruct)
     // frame_describe
     KParams kp{};
     int B = 1, levels = 0;
@@ -222,6 +233,11 @@ void frame_describe(fs_context* ctx, Frame& f) {
     kp.pairs_per_source = pn;
     kp.num_local = kp.pairs_per_source * (uint32_t)f.count;
     kp.src_table = nullptr;
+    kp.item_seeds = 0;
+    if (f.group) {   // (at most 4 items, all with the same high seed word: dispatch_group)
+        kp.item_seeds = f.count;
+        for (int i = 0; i < f.count && i < 4; ++i) kp.item_seed[i] = (uint32_t)f.group[i].p.seed;
+    }
     // depth = 0: no cap, like the reference's while (true) (ARTS.cpp:294) — the roulette ends every walk; the records of
     // steps beyond FS_MAX_DEPTH go to the second tier.  Without roulette an uncapped walk would never end: FS_MAX_DEPTH.
     f.unbounded = p->depth == 0 && p->russian_roulette && p->rr_prob < 1.0f;
@@ -332,7 +348,9 @@ int frame_resources(fs_context* ctx, Frame& f) {
         }
         // this frame deposits into the next buffer of the rotation; the tail may still be busy with it.  (FS_FLAG_ACCUMULATE_ENERGY
         // stays in the buffer of the previous frame — behind its reduce / reconstruct — and adds to what it holds.)
-        f.cur_of[i] = f.accumulate ? si->cur : (si->cur + 1) % kEnergyBufs;
+        int earlier = 0;   // grouped frames: the same source may own several items — consecutive buffers of its rotation
+        for (int k = 0; k < i; ++k) earlier += f.srcs[k] == si ? 1 : 0;
+        f.cur_of[i] = f.accumulate ? si->cur : (si->cur + 1 + earlier) % kEnergyBufs;
         FS_HIP(ctx, wait_energy_readers(ctx, si, f.cur_of[i]));
     }
     if (f.batch) {
@@ -437,7 +455,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
     if (!plan_runs) {
         if (zero_ptr) FS_HIP(ctx, hipMemsetAsync(zero_ptr, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
         for (int i = 0; i < count && zero_tab; ++i) {
-            float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[srcs[i]->cur]) : srcs[i]->energy();
+            float* zp = fixed ? reinterpret_cast<float*>(srcs[i]->d_fixed[f.cur_of[i]]) : srcs[i]->d_energy[f.cur_of[i]];
             FS_HIP(ctx, hipMemsetAsync(zp, 0, sizeof(float) * (size_t)zero_words, ctx->stream));
         }
     }
@@ -453,7 +471,10 @@ int frame_launch(fs_context* ctx, Frame& f) {
         fs_context::PipeFrame me;
         me.kp = kp; me.st = st; me.wl = wl; me.perm = perm; me.stages = f.stages; me.next_stage = 0; me.fixed = fixed; me.ppw = ppw;
         me.items.resize((size_t)count);
-        for (int i = 0; i < count; ++i) { me.items[(size_t)i].s = srcs[i]; me.items[(size_t)i].cur = srcs[i]->cur; }
+        for (int i = 0; i < count; ++i) {
+            me.items[(size_t)i].s = srcs[i]; me.items[(size_t)i].cur = f.cur_of[i];
+            if (f.group && f.group[i].want_recon) { me.items[(size_t)i].want_recon = true; me.items[(size_t)i].recon = f.group[i].recon; }
+        }
         me.energy_tab = energy_tab; me.fixed_tab = fixed_tab;
         FrameParts fp;
         // ONE launch: the plan pass of this frame (depth 2), the next walk stage of every held frame — oldest frame, i.e.
@@ -500,7 +521,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
         }
         if (plan_held) ctx->held.push_back(me);   // planned by this launch, walked by the next ones
         if (timed_frame) { tf.has_trace = true; ctx->pending.push_back(tf); }
-        ctx->stats.frames++;
+        ctx->stats.frames += f.group ? (uint64_t)count : 1;
         ctx->stats.pairs += kp.num_local;
         ctx->stats.rays += 2ull * kp.num_local;
         return FS_OK;
@@ -531,15 +552,17 @@ int frame_launch(fs_context* ctx, Frame& f) {
     return FS_OK;
 }
 
-int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
+int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_params* p, const fs_context::GroupEntry* group = nullptr) {
+    if (!ctx->group.empty()) { const int gr = dispatch_group(ctx); if (gr) return gr; }   // collected frames keep their place in the order
     { const int ir = maybe_install_refined(ctx); if (ir) return ir; }                     // fs_scene_commit_progressive: the better tree is ready
     if (ctx->refit_pending) { const int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     int rc = check_params(ctx, p);
     if (rc) return rc;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     Frame f;
-    f.srcs = srcs; f.count = count; f.p = p;
+    f.srcs = srcs; f.count = count; f.p = p; f.group = group;
     frame_describe(ctx, f);
+    if (group && !f.pipe_ok) return FS_ERR_INVALID_ARGUMENT;   // (dispatch_group only groups what can be held; it falls back itself)
     if (!f.pipe_ok) FS_FLUSH(ctx);
     rc = frame_resources(ctx, f);
     if (rc) return rc;
@@ -547,7 +570,55 @@ int trace_sources(fs_context* ctx, Source* const* srcs, int count, const fs_para
     return frame_launch(ctx, f);
 }
 
+// may a frame with these parameters wait in the group (fs_set_frames_per_launch)?  Exactly what frame_describe lets the
+// pipeline hold, and small enough for 32-bit subpath indices when frames_per_launch of them share a launch
+bool groupable(const fs_context* ctx, const fs_params* p) {
+    if (ctx->frames_per_launch < 2 || ctx->pipelining < 1 || ctx->profiling >= 2) return false;
+    if (p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY | FS_FLAG_DOUBLE_POSITIONS))
+        return false;
+    if (p->listener_radius > 0.0f || p->source_radius > 0.0f) return false;
+    const bool unbounded = p->depth == 0 && p->russian_roulette && p->rr_prob < 1.0f;
+    if (!(p->depth > 0 || (unbounded && ctx->pipelining >= 2))) return false;
+    return (uint64_t)ctx->frames_per_launch * (p->num_rays / 2) <= (1ull << 29);
+}
+// the same frame but for the low seed word?
+bool same_but_seed(const fs_params& a, const fs_params& b) {
+    fs_params x = a, y = b;
+    x.seed &= ~0xFFFFFFFFull; y.seed &= ~0xFFFFFFFFull;
+    return std::memcmp(&x, &y, sizeof(fs_params)) == 0;
+}
+
 }  // namespace
+
+namespace fsi {
+// The collected frames as ONE batched frame (every item its own seed, energy buffer and recorded reconstruct); a group
+// of one, or one that cannot be held after all, goes frame by frame.
+int dispatch_group(fs_context* ctx) {
+    std::vector<fs_context::GroupEntry> g;
+    g.swap(ctx->group);
+    if (g.empty()) return FS_OK;
+    if (g.size() > 1) {
+        Source* srcs[4];
+        for (size_t i = 0; i < g.size(); ++i) srcs[i] = g[i].s;
+        const int rc = trace_sources(ctx, srcs, (int)g.size(), &g[0].p, g.data());
+        if (rc != FS_ERR_INVALID_ARGUMENT) return rc;   // (FS_ERR_INVALID_ARGUMENT: not holdable any more — one by one below)
+    }
+    for (fs_context::GroupEntry& e : g) {
+        int rc = trace_sources(ctx, &e.s, 1, &e.p);
+        if (rc) return rc;
+        if (e.want_recon) {
+            bool recorded = false;
+            if (!ctx->held.empty()) {   // the frame is held: the reconstruct goes with it, as fs_reconstruct_impulse_response_async does
+                fs_context::PipeFrame& q = ctx->held.back();
+                for (fs_context::PipeFrame::Item& c : q.items)
+                    if (c.s == e.s && !c.want_recon) { c.want_recon = true; c.recon = e.recon; recorded = true; }
+            }
+            if (!recorded) { FS_FLUSH(ctx); rc = reconstruct_now(ctx, e.s, &e.recon); if (rc) return rc; }
+        }
+    }
+    return FS_OK;
+}
+}  // namespace fsi
 
 extern "C" {
 
@@ -631,7 +702,29 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     Source* s = get_source(ctx, h);
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (!ctx->committed) return ctx->fail(FS_ERR_NOT_COMMITTED, "scene not committed");
+    // fs_set_frames_per_launch: a plain pipelinable frame waits until enough of its kind have come (same parameters but
+    // for the low seed word); anything else sends the waiting ones off first (trace_sources does that)
+    fs_params def;
+    const fs_params* q = p;
+    if (!q) { fs_params_default(&def); q = &def; }
+    if (q->struct_size == sizeof(fs_params) && groupable(ctx, q)) {
+        if (!ctx->group.empty() && !same_but_seed(ctx->group[0].p, *q)) { const int gr = dispatch_group(ctx); if (gr) return gr; }
+        if (ctx->group.empty()) { const int cr = check_params(ctx, q); if (cr) return cr; }   // a bad frame fails at its own call
+        fs_context::GroupEntry e;
+        e.s = s; e.p = *q;
+        ctx->group.push_back(e);
+        if ((int)ctx->group.size() >= std::min(ctx->frames_per_launch, 4)) return dispatch_group(ctx);
+        return FS_OK;
+    }
     return trace_sources(ctx, &s, 1, p);
+}
+
+int fs_set_frames_per_launch(fs_context* ctx, int32_t n) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (n < 1 || n > 4) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_set_frames_per_launch: 1 .. 4");
+    if (n != ctx->frames_per_launch) FS_FLUSH(ctx);
+    ctx->frames_per_launch = n;
+    return FS_OK;
 }
 
 int fs_compute_energy_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* p) {
@@ -727,6 +820,18 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     fs_params def;
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    // grouped frames: the source's current frame still waits for its launch — the reconstruct is recorded with it
+    for (size_t k = ctx->group.size(); k-- > 0;) {
+        fs_context::GroupEntry& e = ctx->group[k];
+        if (e.s != s) continue;
+        if (!e.want_recon && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && (ctx->cfg.world_size == 1 || ctx->comm)) {
+            e.want_recon = true;
+            e.recon = *p;
+            return FS_OK;
+        }
+        break;
+    }
+    if (!ctx->group.empty()) FS_FLUSH(ctx);   // (a second reconstruct of the same frame, or one of another kind: the frames go first)
     // pipelined frames: the source's current frame still waits for its connect pass — the reconstruct goes with it
     for (size_t k = ctx->held.size(); k-- > 0;) {   // the source's CURRENT frame is the newest held one that has it
         fs_context::PipeFrame& q = ctx->held[k];
@@ -753,9 +858,10 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
     if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     poll_published(s);
-    if (s->enqueued >= 2) {   // never overwrite the front buffer: at most two publishes in flight
-        int slot = (int)((s->enqueued - 1) % kIrRing);
-        if (s->seq_of[slot] == s->enqueued - 1 && s->front.load(std::memory_order_relaxed) < s->enqueued - 1) {
+    if (s->enqueued + 1 >= (uint64_t)kIrRing) {   // never overwrite the front buffer: at most kIrRing - 1 publishes in flight
+        const uint64_t must = s->enqueued + 2 - (uint64_t)kIrRing;
+        const int slot = (int)(must % kIrRing);
+        if (s->seq_of[slot] == must && s->front.load(std::memory_order_relaxed) < must) {
             FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
             poll_published(s);
         }

@@ -31,7 +31,8 @@ using namespace fs;
 
 namespace fsi {
 
-constexpr int kIrRing = 3;  // published IR ring: a returned pointer stays valid until the second-next publish
+constexpr int kIrRing = 8;  // published IR ring: up to 7 publishes of a source in flight (grouped frames of one source finish
+                            // together); a returned pointer stays valid until the 7th-next publish (3 and "second-next" until round 3)
 
 // Energy buffers per source, used in rotation: frame f deposits into one while the tail stream still reduces /
 // reconstructs frame f - 1 from another; pipelined frames finish frame f - 2 only in the launch that plans frame f
@@ -78,9 +79,9 @@ struct Source {
     bool cur_fixed = false;
     float* d_ir_bands = nullptr;  // [B][samples]
     float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
-    float* h_ir[kIrRing] = {nullptr, nullptr, nullptr};  // pinned host copies of the channel view
-    hipEvent_t ev[kIrRing] = {nullptr, nullptr, nullptr};
-    uint64_t seq_of[kIrRing] = {0, 0, 0};
+    float* h_ir[kIrRing] = {};  // pinned host copies of the channel view
+    hipEvent_t ev[kIrRing] = {};
+    uint64_t seq_of[kIrRing] = {};
     uint64_t enqueued = 0;             // publishes enqueued so far
     std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
     // reverb (row f2): history rings [2][kReverbRing], staging buffers, write head
@@ -200,7 +201,14 @@ struct fs_context {
         float* const* energy_tab = nullptr;               // batched frame: the per-frame device tables (kBatchSlots of them
         unsigned long long* const* fixed_tab = nullptr;   // rotate; a held frame is connected kMaxWalkParts + 1 calls later at most)
     };
-    std::deque<PipeFrame> held;      // oldest first
+    std::deque<PipeFrame> held;
+    // fs_set_frames_per_launch(n > 1): plain pipelinable frames are collected until n are waiting, then traced as ONE
+    // batched frame in which every item keeps its own seed (and its own energy buffer, also for the same source twice) —
+    // a 262 144-ray frame leaves a tenth of the chip idle that a launch of two such frames fills.  Everything that
+    // flushes held frames dispatches a partial group first.
+    struct GroupEntry { Source* s = nullptr; fs_params p; bool want_recon = false; fs_params recon; };
+    std::vector<GroupEntry> group;
+    int frames_per_launch = 1;      // oldest first
     int state_sets = 3;              // sets of the per-frame arrays (subpath state, records, schedules): frames in flight + 1
     bool state_cont = false;         // the sets include continuation records (staged walks)
     std::vector<int> stage_bounds;   // staged depth = 0 walks: the steps at which a walk changes launch (FS_WALK_STAGES)

@@ -593,6 +593,18 @@ struct Walker {          // ARTS.cpp:287-291 state + bookkeeping
     float prob, prob_new;
 };
 
+// low seed word of item `sid` of a batched frame (grouped frames carry one seed per item; kp.item_seeds <= 4)
+__device__ __forceinline__ uint32_t item_seed_lo(const KParams& kp, uint32_t sid) {
+    uint32_t s = kp.seed_lo;
+    if (kp.item_seeds > 0) {   // (wave-uniform)
+        s = kp.item_seed[0];
+        s = sid == 1u ? kp.item_seed[1] : s;
+        s = sid == 2u ? kp.item_seed[2] : s;
+        s = sid == 3u ? kp.item_seed[3] : s;
+    }
+    return s;
+}
+
 // ---- segment records: [step][slot] in the main tier, (step - main_levels, slot) in the overflow tier ------------
 __device__ __forceinline__ bool rec_in_main(const SubpathState& st, int k) { return k < st.main_levels; }
 __device__ __forceinline__ size_t rec_main(uint32_t total, int k, uint32_t slot) { return (size_t)k * total + slot; }
@@ -658,12 +670,15 @@ __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, co
     const bool lobes_on = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
     if (w.k >= kp.depth && st.over_levels == 0) return false;             // the depth cap
     const uint32_t bs = ((uint32_t)w.k << 1) | w.side;
-    const uint4 r = philox(w.pair, bs, 0, kp.seed_lo, kp.seed_hi);
+    // (grouped frames: the item's own low seed word — recomputed from the pair index here, once per bounce, rather than
+    // carried in a register through the traversal: one more live VGPR cost the 128-register frame kernel 3 %)
+    const uint32_t seed = kp.item_seeds > 0 ? item_seed_lo(kp, w.li / kp.pairs_per_source) : kp.seed_lo;
+    const uint4 r = philox(w.pair, bs, 0, seed, kp.seed_hi);
     if (kp.russian_roulette && !(u01(r.x) < kp.rr_prob)) return false;    // ARTS.cpp:300-301, 349-353
     if (w.k >= kp.depth) { *st.overflow = 1u; return false; }             // depth = 0 and the walk outlives both tiers
     float dx, dy, dz;
     if (!w.has_normal) {                                                  // ARTS.cpp:306-310
-        sample_sphere(w.pair, bs, r, kp.seed_lo, kp.seed_hi, dx, dy, dz);
+        sample_sphere(w.pair, bs, r, seed, kp.seed_hi, dx, dy, dz);
         float pdf = 1.0f / (4.0f * kPi);
         w.prob_new = pdf * kp.rr_prob;
     } else {                                                              // ARTS.cpp:311-318
@@ -883,10 +898,12 @@ constexpr int kPlanItems = 4;   // subpaths per plan-kernel thread
 __device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
     const uint32_t n = kp.num_local;
     const uint32_t side = g >= n ? 1u : 0u;
-    const uint32_t pair = kp.pair_begin + (g - side * n) % kp.pairs_per_source;   // batched frame: per-source pair index
+    const uint32_t li = g - side * n, sid = li / kp.pairs_per_source;
+    const uint32_t pair = kp.pair_begin + (li - sid * kp.pairs_per_source);       // batched frame: per-source pair index
+    const uint32_t seed = item_seed_lo(kp, sid);
     int k = 0;
     for (; k < kp.depth; ++k) {
-        const uint4 r = philox(pair, ((uint32_t)k << 1) | side, 0, kp.seed_lo, kp.seed_hi);
+        const uint4 r = philox(pair, ((uint32_t)k << 1) | side, 0, seed, kp.seed_hi);
         if (!(u01(r.x) < kp.rr_prob)) break;   // ARTS.cpp:300-301
     }
     return k;

@@ -106,6 +106,8 @@ struct KParams {
     uint32_t pairs_per_source;   // == num_local for one source; a batched frame lays its sources' pairs end to end:
                                  // pair li belongs to source li / pairs_per_source, RNG pair index li % pairs_per_source
     const float* src_table;      // [sources][3] source positions of a batched frame (device), else null (kp.src)
+    uint32_t item_seed[4];       // grouped frames (fs_set_frames_per_launch): the low seed word of each item of the batched
+    int32_t item_seeds;          //   frame (item_seeds of them; 0 = every item uses seed_lo, the batch of one call)
     int32_t depth;         // max segments per subpath: 1..FS_MAX_DEPTH, or main_levels + over_levels for depth = 0 (a bound the
                            //   roulette practically never reaches: 0.9^512 ~ 4e-24)
     int32_t mis_depth;     // depth cap D of the all-connections weights (kUnboundedDepth for depth = 0)

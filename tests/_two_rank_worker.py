@@ -67,6 +67,9 @@ if os.environ.get("FS_TEST_ONESHOT") == "1":
     ctx.comm_enable_oneshot()     # the sum over the ranks through the peers' IPC-mapped mailboxes instead of ncclAllReduce
 if os.environ.get("FS_TEST_PIPELINE") == "1":
     ctx.set_pipelining(2)         # held-back connect passes: the all-reduce and the reconstruct follow them
+FPL = int(os.environ.get("FS_TEST_FPL", "1"))
+if FPL > 1:
+    ctx.set_frames_per_launch(FPL)   # same-kind frames share a launch; each item is reduced and reconstructed on its own
 # every rank registers the same triangles; rank 0 builds the tree, the others receive it (fs_scene_commit)
 ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
 ctx.set_listener(sc.listener)
@@ -81,6 +84,14 @@ for k, (flags, seed) in enumerate(frames):
         ctx.compute_energy_response_async(src, pkg.default_params(num_rays=4096, depth=8, seed=5))
     ctx.synchronize()
     res[f"ir{k}"] = ctx.impulse_response(src, 0).copy()
+# a run of same-kind frames (what fs_set_frames_per_launch groups): every frame's sum over the ranks and IR
+for k, seed in enumerate((911, 912, 913, 914)):
+    pg = pkg.default_params(num_rays=8192, depth=8, seed=seed, flags=8)
+    ctx.compute_energy_response_async(src, pg)
+    ctx.reconstruct_impulse_response_async(src, pg)
+ctx.synchronize()
+res["ir_run"] = ctx.impulse_response(src, 0).copy()
+res["energy_run"] = ctx.energy_buffer(src).copy()
 p = pkg.default_params(num_rays=16384, depth=8, seed=77)
 res["energy"] = ctx.compute_energy_response(src, p).copy()        # the helpers read the summed buffer
 rng = np.random.default_rng(5)

@@ -342,3 +342,70 @@ def test_staged_walks_of_a_million_ray_frame(pkg, scene_factory):
         out[depth] = ctx.energy_buffer(src).copy()
         ctx.close()
     assert out[0].any() and np.array_equal(out[0], out[2])
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_frames_per_launch_gives_the_single_frames_results(pkg, scene_factory, n):
+    """fs_set_frames_per_launch(n): plain pipelinable frames wait until n have come and are traced as ONE batched frame in
+    which every item keeps its own seed, energy buffer and recorded reconstruct — also the same source several times.
+    Energies (deterministic mode: bit for bit), published IRs, counters and the frame count must be those of the same calls
+    with one frame per launch; reads in between send a partial group off."""
+    sc = scene_factory("starter_room", 4)
+    out = {}
+    for per_launch in (1, n):
+        ctx, s = make_ctx(pkg, sc)
+        s2 = ctx.create_source(np.asarray(sc.source, np.float32) + np.float32(25.0))
+        ctx.set_pipelining(2)
+        ctx.set_frames_per_launch(per_launch)
+        p = pkg.default_params(num_rays=16384, depth=8, flags=DET)
+        got = []
+        for i in range(11):
+            p.seed = 900 + i
+            src = s2 if i % 4 == 1 else s
+            ctx.compute_energy_response_async(src, p)
+            ctx.reconstruct_impulse_response_async(src, p)
+            if i in (3, 8):                                   # an observer in the middle of a group
+                got.append(ctx.energy_buffer(src).copy())
+                ctx.synchronize()
+                got.append(ctx.impulse_response(src, 0).copy())
+        ctx.synchronize()
+        for src in (s, s2):
+            got.append(ctx.energy_buffer(src).copy())
+            got.append(ctx.impulse_response(src, 0).copy())
+        st = ctx.stats()
+        got.append(np.asarray([st["frames"], st["segments"], st["connections_tested"], st["deposits"]], np.int64))
+        out[per_launch] = got
+        ctx.close()
+    assert out[1][0].any() and np.abs(out[1][1]).max() > 0
+    for a, b in zip(out[1], out[n]):
+        assert np.array_equal(a, b)
+
+
+def test_frames_per_launch_with_uncapped_walks_other_kinds_and_seed_words(pkg, scene_factory):
+    """Groups of depth = 0 frames go through the staged walks; a frame of another kind (other parameters, a lobes frame, a
+    different high seed word) sends the waiting ones off first and goes its own way; fs_submit and
+    fs_set_frames_per_launch flush."""
+    sc = scene_factory("starter_room", 4)
+    tr, scat = pkg.scenes.material_lobes(sc)
+    out = {}
+    for per_launch in (1, 3):
+        ctx = pkg.Context(num_bands=sc.num_bands)
+        ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tr, scattering=scat)
+        ctx.set_listener(sc.listener)
+        s = ctx.create_source(sc.source)
+        ctx.set_pipelining(2)
+        ctx.set_frames_per_launch(per_launch)
+        p0 = pkg.default_params(num_rays=8192, depth=0, flags=DET)
+        p8 = pkg.default_params(num_rays=4096, depth=8, flags=DET)
+        pl = pkg.default_params(num_rays=4096, depth=8, flags=DET | pkg._capi.FLAG_MATERIAL_LOBES)
+        for i, p in enumerate([p0, p0, p8, p0, pl, p8, p8, p8, p0]):
+            p.seed = (7 << 32) + 40 + i if i == 6 else 40 + i
+            ctx.compute_energy_response_async(s, p)
+            if i == 5:
+                ctx.submit()
+        ctx.set_frames_per_launch(1)
+        out[per_launch] = [ctx.energy_buffer(s).copy(), np.asarray([ctx.stats()[k] for k in ("frames", "segments", "deposits")], np.int64)]
+        ctx.close()
+    assert out[1][0].any()
+    for a, b in zip(out[1], out[3]):
+        assert np.array_equal(a, b)

@@ -33,14 +33,16 @@ def test_fake_rccl_builds_and_exports_what_the_library_opens(fake_rccl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,pipelined,oneshot", [(2, False, False), (3, False, False), (2, True, False), (2, False, True), (3, True, True)],
-                         ids=["two", "three", "two_pipelined", "two_oneshot", "three_pipelined_oneshot"])
-def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world, pipelined, oneshot):
+@pytest.mark.parametrize("world,pipelined,oneshot,fpl", [(2, False, False, 1), (3, False, False, 1), (2, True, False, 1), (2, False, True, 1),
+                                                         (3, True, True, 1), (2, True, False, 3), (2, True, True, 2)],
+                         ids=["two", "three", "two_pipelined", "two_oneshot", "three_pipelined_oneshot", "two_pipelined_3_per_launch",
+                              "two_pipelined_oneshot_2_per_launch"])
+def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world, pipelined, oneshot, fpl):
     """oneshot: fs_comm_enable_oneshot — the per-frame sum goes through the ranks' HIP-IPC mailboxes (one peer-write
     exchange, fs_oneshot.hip) instead of the communicator's all-reduce; the communicator still carries the scene broadcast
     and the handle exchange.  Everything a rank publishes must be what the all-reduce path publishes."""
     env = dict(os.environ, FS_RCCL_LIB=fake_rccl, FAKE_RCCL_TIMEOUT_S="60", FS_TEST_PIPELINE="1" if pipelined else "0",
-               FS_TEST_ONESHOT="1" if oneshot else "0")
+               FS_TEST_ONESHOT="1" if oneshot else "0", FS_TEST_FPL=str(fpl))
     id_file = str(tmp_path / "comm_id")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), str(r), str(world),
                                id_file, str(tmp_path / f"rank{r}.npz")], env=env, stdout=subprocess.PIPE,
@@ -77,6 +79,13 @@ def test_every_rank_publishes_the_single_rank_ir(pkg, fake_rccl, tmp_path, world
             else:
                 assert np.abs(got - want).max() <= IR_TOL * np.abs(want).max(), (k, r)
             assert np.array_equal(got, ranks[0][f"ir{k}"]), (k, r)    # and all ranks publish the same samples
+    for seed in (911, 912, 913, 914):   # the run of same-kind frames (grouped on the ranks when fpl > 1)
+        pg = pkg.default_params(num_rays=8192, depth=8, seed=seed, flags=8)
+        ctx.compute_energy_response(src, pg)
+        ctx.reconstruct_impulse_response(src, pg)
+    for r, rk in enumerate(ranks):
+        assert np.array_equal(rk["energy_run"], ctx.energy_buffer(src)), r
+        assert np.array_equal(rk["ir_run"], ctx.impulse_response(src, 0)), r
     p = pkg.default_params(num_rays=16384, depth=8, seed=77)
     want_e = ctx.compute_energy_response(src, p)
     rng = np.random.default_rng(5)
