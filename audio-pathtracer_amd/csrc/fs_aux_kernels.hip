@@ -13,7 +13,10 @@ namespace {
 //   per kChunk-sample chunk after a kWarm-sample warm-up: 0.75^96 ~ 1e-12 is far below fp32 resolution.
 //   The interpolated sample x[i] is produced incrementally (bin / in-bin counters), no division by spb.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kChunk = 16;
+#ifndef FS_RECON_CHUNK
+#define FS_RECON_CHUNK 16
+#endif
+constexpr int kChunk = FS_RECON_CHUNK;
 constexpr int kWarm = 96;
 
 __global__ __launch_bounds__(kBlock) void reconstruct_kernel(const float* __restrict__ energy, int B, int nb,

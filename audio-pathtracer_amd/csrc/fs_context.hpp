@@ -240,6 +240,8 @@ struct fs_context {
     char* d_batch = nullptr; char* h_batch = nullptr; size_t batch_cap = 0;   // kBatchSlots blocks of batch_cap bytes
     hipEvent_t ev_batch[kBatchSlots] = {};
     bool batch_pending[kBatchSlots] = {};
+    size_t batch_bytes[kBatchSlots] = {};   // bytes of the table the slot's device copy holds (0: none) — same table again: no copy
+    std::vector<char> batch_build;
     unsigned batch_frame = 0;
     unsigned long long host_segments = 0;   // walk segments of frames without a plan pass (roulette off), since the last reset
 
