@@ -60,7 +60,12 @@ def main(argv):
                                                                        else (k.split("<")[0] if k.endswith(">") else None))
             if base is None:
                 continue
-            entry.setdefault(base, {"instantiation": k})
+            # several instantiations of one family may have run (frame_kernel<8, true> for the launches of grouped frames,
+            # <8, false> for a pipeline-fill launch or two): the one with the most launches is the workload's
+            n = max(len(v) for v in acc[k].values())
+            if base in entry and entry[base]["_launches"] >= n:
+                continue
+            entry[base] = {"instantiation": k, "_launches": n}
             for c, v in acc[k].items():
                 entry[base][c] = sum(v) / len(v)
         doc[workload] = entry

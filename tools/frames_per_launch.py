@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""fs_set_frames_per_launch: results against one frame per launch (deterministic mode, bit for bit) and the rate of a stream of cfg3
+frames for 1 .. 4 frames per launch.  usage (GPU box): python tools/frames_per_launch.py"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
@@ -19,7 +22,7 @@ for n in (1, 2, 3, 4):
         src = s if i % 3 else s2
         c.compute_energy_response_async(src, p); c.reconstruct_impulse_response_async(src, p)
         if i in (2, 5):
-            es.append(c.energy_buffer(src).copy()); irs.append(c.impulse_response(src, 0).copy())
+            es.append(c.energy_buffer(src).copy()); c.synchronize(); irs.append(c.impulse_response(src, 0).copy())   # (the accessor returns the newest PUBLISHED IR: wait for it)
     c.synchronize()
     es.append(c.energy_buffer(s).copy()); es.append(c.energy_buffer(s2).copy())
     irs.append(c.impulse_response(s, 0).copy()); irs.append(c.impulse_response(s2, 0).copy())
