@@ -546,6 +546,11 @@ class AudioRayTracingSubsystem:
         self.ctx.set_pipelining(depth)
         self._streamed = bool(depth)
 
+    def SetFramesPerLaunch(self, n):
+        """fs_set_frames_per_launch: the streamed sources of a Tick share launches n at a time (every source keeps its own
+        seed, energy buffer and IR; Tick's closing fs_submit sends a partial group off)"""
+        self.ctx.set_frames_per_launch(n)
+
     def Tick(self, DeltaTime):  # ARTS.cpp:55-85 without the 1 s warm-up: the caller drives every frame
         if not self.ActiveSources:
             return

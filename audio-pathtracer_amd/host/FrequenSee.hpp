@@ -175,6 +175,8 @@ public:
     }
     // fs_set_pipelining (0 off, 1, 2): Tick streams the sources instead of batching them
     void SetPipelining(int Depth) { Check(fs_set_pipelining(Ctx_, Depth)); Streamed_ = Depth != 0; }
+    // fs_set_frames_per_launch (1 .. 4): consecutive streamed frames share a launch (each keeps its seed, buffer and IR)
+    void SetFramesPerLaunch(int N) { Check(fs_set_frames_per_launch(Ctx_, N)); }
     void Synchronize() { Check(fs_synchronize(Ctx_)); }
 
     int NumBands() const { return NumBands_; }
