@@ -686,7 +686,7 @@ def test_tail_stream_overlap_and_handoff(pkg, oracle_mod, scene_factory):
             own = ref_ctx.compute_energy_response(ref_src, params(100 + f + 1))
             now = ctx.energy_buffer(src)
             assert np.array_equal(now != 0, own != 0) and max(rel_rms(now[b], own[b]) for b in range(4)) <= TIGHT_TOL
-    assert len(ptrs) == frames                                      # every frame deposits into the next of the source's energy buffers (a rotation of 12)
+    assert len(ptrs) == frames                                      # every frame deposits into the next of the source's energy buffers (a rotation of 24)
     # energy helpers act on the current buffer and stay ordered against the tail: flush + one deposit + reconstruct
     ctx.check(ctx.lib.fs_flush_energy_buffer(ctx.h, src))
     ctx.check(ctx.lib.fs_add_energy_at_delay(ctx.h, src, 0, 0.0105, 4.0))
