@@ -259,8 +259,8 @@ void frame_describe(fs_context* ctx, Frame& f) {
     kp.sound_speed = p->sound_speed;
     kp.norm = (p->flags & FS_FLAG_FIXED_NORM_1000) ? 1.0f / 1000.0f : (P ? 1.0f / (float)P : 0.f);  // ARTS.cpp:164
     for (int b = 0; b < FS_MAX_BANDS; ++b) kp.air[b] = p->air_absorption[b];
-    std::memcpy(kp.src, s->pos, sizeof(kp.src));
-    std::memcpy(kp.lis, ctx->listener, sizeof(kp.lis));
+    std::memcpy(kp.src, f.group ? f.group[0].pos : s->pos, sizeof(kp.src));
+    std::memcpy(kp.lis, f.group ? f.group[0].lis : ctx->listener, sizeof(kp.lis));   // (grouped frames: the positions at their calls)
     kp.count = ctx->profiling >= 3 ? 1 : 0;
     kp.num_bins = ctx->num_bins;
     kp.num_bands = f.B;
@@ -387,7 +387,7 @@ int frame_resources(fs_context* ctx, Frame& f) {
             for (int i = 0; i < count; ++i) {
                 t_en[i] = f.srcs[i]->d_energy[f.cur_of[i]];
                 t_fx[i] = f.fixed ? (void*)f.srcs[i]->d_fixed[f.cur_of[i]] : nullptr;
-                std::memcpy(t_pos + 3 * i, f.srcs[i]->pos, sizeof(float) * 3);
+                std::memcpy(t_pos + 3 * i, f.group ? f.group[i].pos : f.srcs[i]->pos, sizeof(float) * 3);
             }
         }
         if (!(ctx->batch_bytes[slot] == bytes && std::memcmp(hb, ctx->batch_build.data(), bytes) == 0)) {
@@ -616,7 +616,12 @@ int dispatch_group(fs_context* ctx) {
         if (rc != FS_ERR_INVALID_ARGUMENT) return rc;   // (FS_ERR_INVALID_ARGUMENT: not holdable any more — one by one below)
     }
     for (fs_context::GroupEntry& e : g) {
+        // traced with the positions of its call: they are swapped in for the duration
+        float pos_now[3], lis_now[3];
+        std::memcpy(pos_now, e.s->pos, sizeof(pos_now)); std::memcpy(lis_now, ctx->listener, sizeof(lis_now));
+        std::memcpy(e.s->pos, e.pos, sizeof(e.pos)); std::memcpy(ctx->listener, e.lis, sizeof(e.lis));
         int rc = trace_sources(ctx, &e.s, 1, &e.p);
+        std::memcpy(e.s->pos, pos_now, sizeof(pos_now)); std::memcpy(ctx->listener, lis_now, sizeof(lis_now));
         if (rc) return rc;
         if (e.want_recon) {
             bool recorded = false;
@@ -720,10 +725,15 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     const fs_params* q = p;
     if (!q) { fs_params_default(&def); q = &def; }
     if (q->struct_size == sizeof(fs_params) && groupable(ctx, q)) {
-        if (!ctx->group.empty() && !same_but_seed(ctx->group[0].p, *q)) { const int gr = dispatch_group(ctx); if (gr) return gr; }
+        if (!ctx->group.empty() && (!same_but_seed(ctx->group[0].p, *q) || std::memcmp(ctx->group[0].lis, ctx->listener, sizeof(ctx->listener)) != 0)) {
+            const int gr = dispatch_group(ctx);   // (a batched frame has ONE listener position)
+            if (gr) return gr;
+        }
         if (ctx->group.empty()) { const int cr = check_params(ctx, q); if (cr) return cr; }   // a bad frame fails at its own call
         fs_context::GroupEntry e;
         e.s = s; e.p = *q;
+        std::memcpy(e.pos, s->pos, sizeof(e.pos));
+        std::memcpy(e.lis, ctx->listener, sizeof(e.lis));
         ctx->group.push_back(e);
         if ((int)ctx->group.size() >= std::min(ctx->frames_per_launch, 4)) return dispatch_group(ctx);
         return FS_OK;

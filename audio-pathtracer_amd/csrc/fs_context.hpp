@@ -206,7 +206,10 @@ struct fs_context {
     // batched frame in which every item keeps its own seed (and its own energy buffer, also for the same source twice) —
     // a 262 144-ray frame leaves a tenth of the chip idle that a launch of two such frames fills.  Everything that
     // flushes held frames dispatches a partial group first.
-    struct GroupEntry { Source* s = nullptr; fs_params p; bool want_recon = false; fs_params recon; };
+    struct GroupEntry {
+        Source* s = nullptr; fs_params p; bool want_recon = false; fs_params recon;
+        float pos[3] = {}, lis[3] = {};   // source and listener position AT THE CALL (either may move before the group is sent off)
+    };
     std::vector<GroupEntry> group;
     int frames_per_launch = 1;      // oldest first
     int state_sets = 3;              // sets of the per-frame arrays (subpath state, records, schedules): frames in flight + 1

@@ -409,3 +409,34 @@ def test_frames_per_launch_with_uncapped_walks_other_kinds_and_seed_words(pkg, s
     assert out[1][0].any()
     for a, b in zip(out[1], out[3]):
         assert np.array_equal(a, b)
+
+
+def test_frames_per_launch_keeps_the_positions_of_each_call(pkg, scene_factory):
+    """A frame that waits in the group is traced with the source and listener positions of ITS call, not those at the time the
+    group is sent off: a moving source stays in the group (per-item positions), a moving listener sends the group off (a
+    batched frame has one listener)."""
+    sc = scene_factory("starter_room", 4)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    out = {}
+    for per_launch in (1, 3):
+        ctx, s = make_ctx(pkg, sc)
+        ctx.set_pipelining(2)
+        ctx.set_frames_per_launch(per_launch)
+        p = pkg.default_params(num_rays=8192, depth=8, flags=DET)
+        got = []
+        for i in range(7):
+            p.seed = 70 + i
+            ctx.set_source_position(s, np.asarray(sc.source, np.float32) + np.float32(3.0 * i) * np.asarray([1, 0.5, 0], np.float32))
+            if i in (3, 4):
+                ctx.set_listener(np.asarray(sc.listener, np.float32) + np.float32(10.0 * (i - 2)))
+            ctx.compute_energy_response_async(s, p)
+            ctx.reconstruct_impulse_response_async(s, p)
+            if i in (1, 4):   # moved away again before the group goes: the waiting frames must not see this
+                ctx.set_source_position(s, (0.5 * (lo + hi)).astype(np.float32))
+        ctx.synchronize()
+        out[per_launch] = [ctx.energy_buffer(s).copy(), ctx.impulse_response(s, 0).copy(),
+                           np.asarray([ctx.stats()[k] for k in ("segments", "connections_tested", "deposits")], np.int64)]
+        ctx.close()
+    assert out[1][0].any()
+    for a, b in zip(out[1], out[3]):
+        assert np.array_equal(a, b)

@@ -24,11 +24,11 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" \
 done
 python3 profiles/summarize_pmc.py $out/${tag}_pmc > $out/${tag}_pmc_summary.txt
 python3 profiles/summarize_pmc.py $out/${tag}_pmc --json cfg3_old_mine $tag
-# the small configuration (bench.py reports it under "extra"): the counters its fractions need
+# the small configuration (bench.py reports it under "extra", a launch per frame): the counters its fractions need
 rm -rf $out/${tag}_pmc_cfg2
 for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   n=$(echo $c | tr " " "_" | cut -c1-30)
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_cfg2/$n -- python3 bench.py --workload cfg2_starter_room --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_cfg2_$n.log 2>&1 || { echo "cfg2 pmc pass $n failed"; tail -3 $out/${tag}_pmc_cfg2_$n.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_cfg2/$n -- python3 bench.py --workload cfg2_starter_room --frames-per-launch 1 --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_cfg2_$n.log 2>&1 || { echo "cfg2 pmc pass $n failed"; tail -3 $out/${tag}_pmc_cfg2_$n.log; exit 1; }
 done
 python3 profiles/summarize_pmc.py $out/${tag}_pmc_cfg2 --json cfg2_starter_room $tag
 timeout -k 10 600 python3 bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err || { echo "bench failed"; tail -5 $out/${tag}_bench_default.err; exit 1; }
