@@ -317,7 +317,16 @@ def test_bounded_lds_stack_spills_to_the_deep_store(pkg, scene_factory, monkeypa
         ctx.synchronize()
         e_big_piped = ctx.energy_buffer(src).copy()
         assert np.array_equal(e_big_plain, e_big_piped)
-        out[mode] = (hit.copy(), t.copy(), tri.copy(), nrm.copy(), anyhit.copy(), e_plain, e_unbounded, e_piped, e_big_piped)
+        ctx.set_pipelining(0)
+        p0big = pkg.default_params(num_rays=262144, depth=0, seed=4245, flags=DET)
+        e_staged_plain = ctx.compute_energy_response(src, p0big).copy()
+        ctx.set_pipelining(2)
+        ctx.set_frames_per_launch(2)
+        for _ in range(4):
+            ctx.compute_energy_response_async(src, p0big)  # staged walks, two frames per launch, through the same kernel
+        ctx.synchronize()
+        assert np.array_equal(e_staged_plain, ctx.energy_buffer(src))
+        out[mode] = (hit.copy(), t.copy(), tri.copy(), nrm.copy(), anyhit.copy(), e_plain, e_unbounded, e_piped, e_big_piped, e_staged_plain)
         ctx.close()
     assert out["capped"][0].any() and out["capped"][5].any() and out["capped"][6].any()
     for a, b in zip(out["worst_case_rows"], out["capped"]):
