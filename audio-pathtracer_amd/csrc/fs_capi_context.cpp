@@ -427,6 +427,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
             q = *end ? end + 1 : end;
         }
         ctx->stage_bounds = b;   // empty: depth = 0 frames are not held
+        ctx->stage_bounds_default = false;
     }
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
     e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchSets * kScratchAllocWords);   // each set with its counters

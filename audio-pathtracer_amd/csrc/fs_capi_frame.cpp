@@ -287,7 +287,11 @@ void frame_describe(fs_context* ctx, Frame& f) {
     f.stages.clear();
     if (f.pipe_ok && f.unbounded && !ctx->stage_bounds.empty()) {
         int begin = 0;
-        for (int bound : ctx->stage_bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
+        // launches of two or more frames have thicker late stages: fewer, longer stages measure 3 % faster there
+        // (profiles/r03_stage_sweep.log, last sweep: 0.595 -> 0.571 ms per frame at two frames per launch)
+        static const std::vector<int> kGroupedStageBounds = {12, 24, 40, 64, 96};
+        const std::vector<int>& bounds = (ctx->stage_bounds_default && f.group && f.count >= 2) ? kGroupedStageBounds : ctx->stage_bounds;
+        for (int bound : bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
     } else {
@@ -1054,6 +1058,7 @@ int fs_set_walk_stages(fs_context* ctx, const int32_t* bounds, int32_t count) {
             return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_set_walk_stages: bounds must ascend within 1 .. 511");
     FS_FLUSH(ctx);
     ctx->stage_bounds.assign(bounds, bounds + count);
+    ctx->stage_bounds_default = false;
     return FS_OK;
 }
 

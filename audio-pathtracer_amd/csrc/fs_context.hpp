@@ -215,6 +215,7 @@ struct fs_context {
     int state_sets = 3;              // sets of the per-frame arrays (subpath state, records, schedules): frames in flight + 1
     bool state_cont = false;         // the sets include continuation records (staged walks)
     std::vector<int> stage_bounds;   // staged depth = 0 walks: the steps at which a walk changes launch (FS_WALK_STAGES)
+    bool stage_bounds_default = true; // not set by the host: grouped frames (two or more per launch) take kGroupedStageBounds
     int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
     std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
     std::vector<std::thread> refine_threads;   // every background build ever started (cancelled ones too): joined before the context goes

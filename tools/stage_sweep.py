@@ -34,6 +34,8 @@ for name, depth, bounds in SETTINGS:
     c.set_listener(sc.listener)
     s = c.create_source(sc.source)
     c.set_pipelining(depth)
+    if depth and os.environ.get("FS_SWEEP_FPL"):
+        c.set_frames_per_launch(int(os.environ["FS_SWEEP_FPL"]))   # frames that share a launch (fs_set_frames_per_launch)
     if bounds is not None:
         c.set_walk_stages(bounds)
     p = pkg.default_params(num_rays=rays, depth=0)
