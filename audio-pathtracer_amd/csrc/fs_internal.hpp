@@ -86,7 +86,7 @@ struct DeviceScene {
                               //   worst case + 1, nothing can overflow), else kStackRowsCap (more goes to `deep`)
     // Deep store (only for trees whose worst case exceeds kStackRowsCap rows): [deep_rows][deep_lanes] ints in HBM, column
     // blockIdx.x * kBlock + threadIdx.x.  A lane whose LDS rows are full moves its oldest entries there in chunks and
-    // takes them back when its LDS rows run empty (fs_device.hpp: trav_make_room / trav_refill).  The worst case assumes
+    // takes them back when its LDS rows run low (fs_device.hpp: trav_maintain).  The worst case assumes
     // that a ray hits every child box at every level of the deepest path; rays that need more than kStackRowsCap rows
     // are rare enough that the trips to HBM do not show, and the bounded LDS stack lets four workgroups share a CU.
     uint32_t stack_attn;      // stack_limit - 4 with a deep store, else 0x7FFFFFFF: (unsigned)(sp + sb) >= stack_attn sends a

@@ -282,7 +282,7 @@ def test_collision_spheres_in_batches_and_pipelines(pkg, scene_factory):
 def test_bounded_lds_stack_spills_to_the_deep_store(pkg, scene_factory, monkeypatch, cap):
     """The LDS traversal stack holds FS_STACK_ROWS_CAP rows (default 21) when the tree's worst case needs more; a lane
     that fills them moves its oldest entries to the deep store in HBM and takes them back later (fs_device.hpp:
-    trav_make_room / trav_refill).  With 12 rows on the mine's tree (worst case 30+) that happens all the time: closest
+    trav_maintain).  With 12 rows on the mine's tree (worst case 30+) that happens all the time: closest
     hits, any hits, integer energy sums and the pipelined frames must not change by a bit."""
     sc = scene_factory("old_mine", 8)
     rng = np.random.default_rng(77)
