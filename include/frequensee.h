@@ -338,7 +338,8 @@ int fs_set_walk_stages(fs_context* ctx, const int32_t* bounds /* ascending, 1..5
  * source several times — and traces them as ONE batched frame in which every item keeps its own seed, energy buffer and
  * recorded fs_reconstruct_impulse_response_async: results are exactly those of n single frames.  Everything that observes
  * or synchronises (and a frame of another kind, and fs_submit) sends a partial group off first.  The price is latency:
- * the IR of a frame is published up to n - 1 calls later than with n = 1. */
+ * the IR of a frame is published up to n - 1 calls later than with n = 1.  A waiting frame is traced with the source and
+ * listener positions of ITS call (a moved listener sends the group off: a batched frame has one listener). */
 int fs_set_frames_per_launch(fs_context* ctx, int32_t n /* 1..4 */);
 int fs_submit(fs_context* ctx);   /* hand everything requested so far to the GPU; does not wait */
 
