@@ -45,7 +45,9 @@ constexpr int kIrRing = 8;  // published IR ring: up to 7 publishes of a source 
 // state, segment records, schedules, continuation records) come in fs_context::state_sets sets, as many as the deepest
 // pipeline in use needs (3 until a staged walk is pipelined).
 constexpr int kMaxSets = 12;
-constexpr int kEnergyBufs = 2 * kMaxSets;   // (x2: grouped frames of ONE source take several buffers per launch — 4 per launch x 3 launches in flight)
+constexpr int kEnergyBufs = 2 * kMaxSets;   // (x2: grouped frames of ONE source take several buffers per launch — 4 per launch x 3 launches in flight;
+                                            //  not more: with 2 or 3 frames per launch the rotation then repeats every kBatchSlots launches, which is what lets
+                                            //  a batched frame find its table already on the device — 48 buffers: 928 -> 914 M rays/s)
 constexpr int kScratchSets = kMaxSets;
 static_assert(kMaxSets >= kMaxWalkParts + 3, "a staged frame is in flight for stages + 2 launches and its buffer is read one more");
 
