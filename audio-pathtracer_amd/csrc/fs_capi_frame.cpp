@@ -379,9 +379,7 @@ int frame_resources(fs_context* ctx, Frame& f) {
                 ctx->batch_bytes[k] = 0;
             }
         }
-        const int slot = (int)(ctx->batch_frame % fs_context::kBatchSlots);
-        char* hb = ctx->h_batch + (size_t)slot * ctx->batch_cap;
-        char* db = ctx->d_batch + (size_t)slot * ctx->batch_cap;
+        int slot = (int)(ctx->batch_frame % fs_context::kBatchSlots);
         // A stream of grouped frames rotates through the same few tables (energy buffers and table slots both cycle): a slot
         // whose device copy already holds exactly this table is used as it is — no in-stream copy between the launches
         // (an H2D copy on the compute stream is a bubble of ~10 us per launch).
@@ -396,7 +394,28 @@ int frame_resources(fs_context* ctx, Frame& f) {
                 std::memcpy(t_pos + 3 * i, f.group ? f.group[i].pos : f.srcs[i]->pos, sizeof(float) * 3);
             }
         }
-        if (!(ctx->batch_bytes[slot] == bytes && std::memcmp(hb, ctx->batch_build.data(), bytes) == 0)) {
+        bool found = false;   // any slot that already holds exactly this table will do (it is only read)
+        for (int k = 0; k < fs_context::kBatchSlots && !found; ++k)
+            if (ctx->batch_bytes[k] == bytes && std::memcmp(ctx->h_batch + (size_t)k * ctx->batch_cap, ctx->batch_build.data(), bytes) == 0) {
+                slot = k; found = true;
+            }
+        char* hb = ctx->h_batch + (size_t)slot * ctx->batch_cap;
+        char* db = ctx->d_batch + (size_t)slot * ctx->batch_cap;
+        if (!found) {
+            // a slot that a held frame still reads (it may have found it by its content long after it was written) is skipped:
+            // at most kMaxWalkParts + 1 frames are held, there are kBatchSlots > that many slots
+            auto in_use = [&](int k) {
+                const char* dk = ctx->d_batch + (size_t)k * ctx->batch_cap;
+                for (const fs_context::PipeFrame& q : ctx->held)
+                    if (reinterpret_cast<const char*>(q.energy_tab) == dk) return true;
+                return false;
+            };
+            for (int tries = 0; tries < fs_context::kBatchSlots && in_use(slot); ++tries) {
+                ctx->batch_frame++;
+                slot = (int)(ctx->batch_frame % fs_context::kBatchSlots);
+            }
+            hb = ctx->h_batch + (size_t)slot * ctx->batch_cap;
+            db = ctx->d_batch + (size_t)slot * ctx->batch_cap;
             if (ctx->batch_pending[slot]) FS_HIP(ctx, hipEventSynchronize(ctx->ev_batch[slot]));   // its last copy has left the block
             std::memcpy(hb, ctx->batch_build.data(), bytes);
             ctx->batch_bytes[slot] = 0;   // (until the copy is enqueued)
@@ -405,7 +424,7 @@ int frame_resources(fs_context* ctx, Frame& f) {
             ctx->batch_pending[slot] = true;
             ctx->batch_bytes[slot] = bytes;
         }
-        f.used_batch_slot = true;
+        f.used_batch_slot = !found;   // (the rotation advances only when a slot was written)
         f.energy_tab = reinterpret_cast<float* const*>(db);
         f.fixed_tab = f.fixed ? reinterpret_cast<unsigned long long* const*>(db + (size_t)count * sizeof(void*)) : nullptr;
         kp.src_table = reinterpret_cast<const float*>(db + 2 * (size_t)count * sizeof(void*));
