@@ -3,7 +3,7 @@
 sources), moving geometry, energy
 helpers, installed IRs, reverb callbacks and stats on one context, with checkpoints where the energy of a frame is
 compared with the same frame computed synchronously on a second, freshly synchronised context that saw the same
-geometry.  usage: [FS_STRESS_PIPELINE=1] python tools/stress.py [iterations=400] [seed=1]"""
+geometry.  usage: [FS_STRESS_PIPELINE=1|2] [FS_STRESS_FPL=2..4] [FS_STACK_ROWS_CAP=12] python tools/stress.py [iterations=400] [seed=1]"""
 import os
 import sys
 
@@ -39,6 +39,8 @@ def main(iters=400, seed=1):
     a.reverb_init(sa, 1024)
     if os.environ.get("FS_STRESS_PIPELINE") in ("1", "2"):   # context a holds connect passes back; b (the reference) never does
         a.set_pipelining(int(os.environ["FS_STRESS_PIPELINE"]))
+        if os.environ.get("FS_STRESS_FPL"):                        # ... and lets same-kind frames share launches
+            a.set_frames_per_launch(int(os.environ["FS_STRESS_FPL"]))
     F = pkg._capi
     flags_pool = [0, 0, 0, F.FLAG_DETERMINISTIC, F.FLAG_ALL_CONNECTIONS, F.FLAG_ALL_CONNECTIONS | F.FLAG_DETERMINISTIC,
                   F.FLAG_COSINE_SAMPLING, F.FLAG_MIS_BALANCE, F.FLAG_MATERIAL_LOBES, F.FLAG_MATERIAL_LOBES | F.FLAG_ALL_CONNECTIONS,
