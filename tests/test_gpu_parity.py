@@ -1480,3 +1480,17 @@ def test_api_state_machine_stress():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(400, 7) == 0
+
+
+def test_api_state_machine_stress_with_grouped_pipelined_frames(monkeypatch):
+    """The same random sequence with pipelined frames, three frames per launch (fs_set_frames_per_launch) and a 12-row LDS
+    traversal stack (the deep store at work): every checkpoint still equals the synchronous context's frame."""
+    import importlib.util
+    monkeypatch.setenv("FS_STRESS_PIPELINE", "2")
+    monkeypatch.setenv("FS_STRESS_FPL", "3")
+    monkeypatch.setenv("FS_STACK_ROWS_CAP", "12")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fs_stress_grouped", os.path.join(root, "tools", "stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(300, 11) == 0
