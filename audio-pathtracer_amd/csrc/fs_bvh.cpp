@@ -200,7 +200,9 @@ struct Wide {
 struct CollapsePlan {
     std::vector<float> F;            // [node][k-1], k = 1..4
     std::vector<unsigned char> cut;  // [node][k-1]
-    void solve(const std::vector<BuildNode>& bn, int root) {
+    // pad: what the flattening adds around every box — the cost of a node is the area of the box the traversal tests, never
+    // zero (colinear or coincident triangles have flat boxes: with exact areas every collapse of them costs the same 0)
+    void solve(const std::vector<BuildNode>& bn, int root, float pad) {
         F.assign(bn.size() * 4, 0.f);
         cut.assign(bn.size() * 4, 0);
         std::vector<int> order;   // parents before children
@@ -227,7 +229,9 @@ struct CollapsePlan {
                     if (v < split[k]) { split[k] = v; arg[k] = (unsigned char)i; }
                 }
             }
-            const float w = n.box.half_area() + split[4];
+            const float dx = n.box.hi[0] - n.box.lo[0] + 2.f * pad, dy = n.box.hi[1] - n.box.lo[1] + 2.f * pad,
+                        dz = n.box.hi[2] - n.box.lo[2] + 2.f * pad;
+            const float w = (dx * dy + dy * dz + dz * dx) + split[4];
             f[0] = w; c[0] = 0;
             for (int k = 2; k <= 4; ++k) {
                 if (split[k] < w) { f[k - 1] = split[k]; c[k - 1] = arg[k]; }
@@ -257,13 +261,13 @@ struct CollapsePlan {
 };
 
 void collapse(const std::vector<BuildNode>& bn, int root, std::vector<Wide>& wide, std::vector<int>& wide_of,
-              std::vector<int>& level) {
+              std::vector<int>& level, float pad) {
     // default: the exact minimum (16 % fewer nodes and 1.9 % fewer node visits per ray on old_mine, tools/tree_cost.cpp;
     // +0.7 % rays/s, profiles/r03_ab_tree.log).  Its fuller nodes raise the worst-case stack need by three rows, which
     // the bounded LDS stack makes harmless.  FS_BVH_GREEDY_COLLAPSE=1: open the child of largest area instead.
     static const bool greedy = std::getenv("FS_BVH_GREEDY_COLLAPSE") != nullptr;
     CollapsePlan plan;
-    if (!greedy) plan.solve(bn, root);
+    if (!greedy) plan.solve(bn, root, pad);
     // breadth-first so the top of the tree is a contiguous prefix of the node array
     wide.clear();
     wide_of.assign(bn.size(), -1);
@@ -410,7 +414,7 @@ void build_bvh(const float* xyz, const uint16_t* mat, const uint32_t* object_id,
             }
         }
         if (cancel && cancel->load(std::memory_order_relaxed)) { out = HostBVH{}; return; }
-        collapse(b.nodes, root, wide, wide_of, level);
+        collapse(b.nodes, root, wide, wide_of, level, pad);
         out.stack_need = stack_need(b.nodes, wide, wide_of);
         if (out.stack_need <= kStackDepth) break;
     }

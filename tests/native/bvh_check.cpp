@@ -113,7 +113,20 @@ static void run(const char* name, const std::vector<float>& xyz) {
                 CHECK(lvl[(size_t)q.child[c]] == lvl[i] + 1, "%s: node %zu (level %d) has child %d on level %d", name, i,
                       lvl[i], q.child[c], lvl[(size_t)q.child[c]]);
         }
-    std::printf("%-22s T=%-6d nodes=%-6zu depth=%-3d stack_need=%-3d ok\n", name, T, bvh.nodes.size(), bvh.max_depth, bvh.stack_need);
+    // what the collapse minimises: the summed half-area of the 4-wide nodes (the union of a node's decoded child boxes)
+    double area = 0.0;
+    for (const NodeQ4& q : bvh.nodes) {
+        Box u; for (int k = 0; k < 3; ++k) { u.lo[k] = INFINITY; u.hi[k] = -INFINITY; }
+        for (int c = 0; c < 4; ++c) {
+            Box b; decode(q, c, b);
+            if (b.lo[0] > b.hi[0]) continue;
+            for (int k = 0; k < 3; ++k) { u.lo[k] = std::fmin(u.lo[k], b.lo[k]); u.hi[k] = std::fmax(u.hi[k], b.hi[k]); }
+        }
+        const double dx = u.hi[0] - u.lo[0], dy = u.hi[1] - u.lo[1], dz = u.hi[2] - u.lo[2];
+        if (dx >= 0 && dy >= 0 && dz >= 0) area += dx * dy + dy * dz + dz * dx;
+    }
+    std::printf("%-22s T=%-6d nodes=%-6zu depth=%-3d stack_need=%-3d wide_area=%.6e ok\n", name, T, bvh.nodes.size(), bvh.max_depth,
+                bvh.stack_need, area);
 }
 
 int main() {

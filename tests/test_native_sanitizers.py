@@ -27,3 +27,17 @@ def test_bvh_builder_invariants_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=ENV, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all BVH invariants hold" in r.stdout and "runtime error" not in r.stderr
+    # the exact-minimum 4-wide collapse (CollapsePlan) against the greedy rule it replaced: same invariants, and never a
+    # larger summed node area (what it minimises) — scene by scene
+    g = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(ENV, FS_BVH_GREEDY_COLLAPSE="1"), timeout=600)
+    assert g.returncode == 0 and "all BVH invariants hold" in g.stdout, g.stdout + g.stderr
+
+    def areas(out):   # per scene, in the program's order: (name, summed area of the 4-wide nodes' decoded boxes, nodes)
+        return [(ln.split(" T=")[0].strip(), float(ln.split("wide_area=")[1].split()[0]), int(ln.split("nodes=")[1].split()[0]))
+                for ln in out.splitlines() if "wide_area=" in ln]
+    a_dp, a_gr = areas(r.stdout), areas(g.stdout)
+    assert len(a_dp) >= 8 and [x[0] for x in a_dp] == [x[0] for x in a_gr]
+    for (name, area_dp, n_dp), (_, area_gr, n_gr) in zip(a_dp, a_gr):
+        # (the decoded boxes sit on each node's 8-bit grid: equal up to that grid where the two collapses tie)
+        assert area_dp <= area_gr * 1.002 and n_dp <= n_gr, (name, area_dp, area_gr, n_dp, n_gr)
+    assert sum(x[2] for x in a_dp) < sum(x[2] for x in a_gr)     # and fewer nodes over all
