@@ -49,7 +49,7 @@ int reduce_energy(fs_context* ctx, Source* s) {
     if (!ctx->comm || s->reduced) return FS_OK;
     RcclApi* a = rccl();
     if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
-    FS_HIP(ctx, handoff_energy(ctx, s));
+    if (!s->tail_ordered) FS_HIP(ctx, handoff_energy(ctx, s));   // (a later item of the launch the tail already waits behind: no second event)
     const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
     if (ctx->oneshot.on) {   // one exchange step through the peers' mailboxes (fs_comm_enable_oneshot)
         const uint32_t seq = ++ctx->oneshot.seq;

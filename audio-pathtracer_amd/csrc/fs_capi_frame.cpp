@@ -50,10 +50,10 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
         const int cur = s->cur;
         const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
         s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
-        s->tail_ordered = tail_behind_launch && !q.fixed && !ctx->comm;
+        s->tail_ordered = tail_behind_launch && !q.fixed;
         int rc = FS_OK;
         if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
-        if (ctx->comm) rc = reduce_energy(ctx, s);
+        if (ctx->comm) { rc = reduce_energy(ctx, s); if (!rc && s->tail_ordered) tail_behind_launch = true; }
         if (!rc && it.want_recon) { rc = reconstruct_now(ctx, s, &it.recon); if (!rc && s->tail_ordered) tail_behind_launch = true; }
         if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered; }
         if (rc) return rc;
