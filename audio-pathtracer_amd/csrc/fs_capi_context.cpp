@@ -406,6 +406,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_FUSED_RECON")) ctx->fused_recon = std::atoi(v) != 0;
     ctx->hist_window = default_hist_window(ctx->cfg.num_bands);
     if (const char* v = std::getenv("FS_STACK_ROWS_CAP")) ctx->stack_rows_cap = std::max(kDeepChunk + 4, std::min(kStackDepth + 1, std::atoi(v)));
     if (const char* v = std::getenv("FS_HIST_WINDOW")) ctx->hist_window = std::max(1, std::min(4096, std::atoi(v)));
@@ -479,6 +480,11 @@ int fs_context_destroy(fs_context* ctx) {
         if (ctx->d_build) (void)hipFree(ctx->d_build);
         if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
         for (hipEvent_t e : ctx->ev_batch) if (e) (void)hipEventDestroy(e);
+        for (int k = 0; k < fs_context::kIrTmp; ++k) {
+            if (ctx->d_ir_tmp[k]) (void)hipFree(ctx->d_ir_tmp[k]);
+            if (ctx->ev_ir_tmp[k]) (void)hipEventDestroy(ctx->ev_ir_tmp[k]);
+        }
+        if (ctx->ev_recon_launch) (void)hipEventDestroy(ctx->ev_recon_launch);
     }
     join_refine_threads(ctx);   // no background build may outlive the context (the library may be unloaded next)
     for (Source* s : ctx->sources) free_source(ctx, s);

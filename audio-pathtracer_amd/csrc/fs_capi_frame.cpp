@@ -39,7 +39,7 @@ namespace {
 // What a held frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum over
 // the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
 // frames (cur rotated): the per-frame fields are switched back for the duration.
-static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
+static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false) {
     // the items of a frame were connected by ONE launch: once the tail stream waits behind it (the first item's handoff),
     // the other items' reconstructs are ordered too — no further event pairs on the compute stream (each is a bubble
     // between its launches).  Not in deterministic mode: every item's fixed-point rounding runs on the compute stream first.
@@ -54,10 +54,111 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q) {
         int rc = FS_OK;
         if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
         if (ctx->comm) { rc = reduce_energy(ctx, s); if (!rc && s->tail_ordered) tail_behind_launch = true; }
-        if (!rc && it.want_recon) { rc = reconstruct_now(ctx, s, &it.recon); if (!rc && s->tail_ordered) tail_behind_launch = true; }
+        if (!rc && it.want_recon) {
+            // single GPU, plain reconstruct: it rides in the next fused launch (fs_context::recon_owed)
+            if (may_defer_recon && ctx->fused_recon && !ctx->comm && ctx->cfg.world_size == 1 && ctx->profiling < 2 &&
+                !(it.recon.flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && (int)ctx->recon_owed.size() < kMaxReconParts) {
+                fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon;
+                ctx->recon_owed.push_back(o);
+            } else {
+                rc = reconstruct_now(ctx, s, &it.recon);
+                if (!rc && s->tail_ordered) tail_behind_launch = true;
+            }
+        }
         if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered; }
         if (rc) return rc;
     }
+    return FS_OK;
+}
+
+// ---- reconstructs inside the fused launch ------------------------------------------------------------------------
+// The owed reconstructs become parts of the launch that is being assembled; their sources' IR mutexes are held from here
+// until the publishes are enqueued (a reverb callback must not slip a read of d_ir_mono between the two).
+struct OwedLaunch {
+    std::vector<fs_context::ReconOwed> owed;
+    std::vector<int> tmp;                                  // index into ctx->d_ir_tmp, or -1: the source's own d_ir_*
+    std::vector<std::unique_lock<std::mutex>> locks;
+};
+static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
+    if (ctx->recon_owed.empty()) return FS_OK;
+    ol.owed.swap(ctx->recon_owed);
+    const int B = ctx->cfg.num_bands;
+    const size_t row = (size_t)ctx->num_samples;
+    std::vector<Source*> distinct;
+    for (const fs_context::ReconOwed& o : ol.owed)
+        if (std::find(distinct.begin(), distinct.end(), o.s) == distinct.end()) distinct.push_back(o.s);
+    std::sort(distinct.begin(), distinct.end());           // one locking order for every thread
+    for (Source* s : distinct) ol.locks.emplace_back(s->ir_mu);
+    fp.num_recon = 0; fp.recon_B = B; fp.recon_nb = ctx->num_bins; fp.recon_samples = ctx->num_samples;
+    for (size_t i = 0; i < ol.owed.size(); ++i) {
+        const fs_context::ReconOwed& o = ol.owed[i];
+        Source* s = o.s;
+        bool later = false;                                // a later frame of the same source in this launch?
+        for (size_t k = i + 1; k < ol.owed.size(); ++k) later = later || ol.owed[k].s == s;
+        int t = -1;
+        float* bands = s->d_ir_bands; float* mono = s->d_ir_mono;
+        if (later) {   // its IR is superseded within the launch: produced in, and published from, a temporary buffer
+            t = (int)(ctx->ir_tmp_next++ % fs_context::kIrTmp);
+            if (!ctx->d_ir_tmp[t]) {
+                FS_HIP(ctx, hipMalloc((void**)&ctx->d_ir_tmp[t], sizeof(float) * (size_t)(B + 1) * row));
+                FS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ir_tmp[t], hipEventDisableTiming));
+            }
+            if (ctx->ir_tmp_pending[t]) FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ir_tmp[t], 0));   // its last publish has read it
+            bands = ctx->d_ir_tmp[t]; mono = ctx->d_ir_tmp[t] + (size_t)B * row;
+        } else if (s->rev_recorded) {
+            FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
+        }
+        ol.tmp.push_back(t);
+        FrameParts::Recon& r = fp.recon[fp.num_recon++];
+        r.energy = s->d_energy[o.cur]; r.ir_bands = bands; r.ir_mono = mono;
+        r.spb = o.p.samples_per_bin > 0 ? o.p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);   // FSAC.cpp:324
+    }
+    return FS_OK;
+}
+// behind the launch: the reconstruct of buffer `cur` is done (energy buffer reuse, reverb), the tail stream waits for the
+// launch once and publishes every IR in frame order
+static int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
+    if (ol.owed.empty()) return FS_OK;
+    const int B = ctx->cfg.num_bands;
+    if (!launched_fused)   // no fused form for this launch: the same reconstructs as kernels of their own, on the compute stream
+        for (size_t i = 0; i < ol.owed.size(); ++i) {
+            const fs_context::ReconOwed& o = ol.owed[i];
+            float* bands = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] : o.s->d_ir_bands;
+            float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * (size_t)ctx->num_samples : o.s->d_ir_mono;
+            const int spb = o.p.samples_per_bin > 0 ? o.p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);
+            launch_reconstruct(o.s->d_energy[o.cur], B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, bands, mono, ctx->stream);
+        }
+    if (!ctx->ev_recon_launch) FS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_recon_launch, hipEventDisableTiming));
+    FS_HIP(ctx, hipEventRecord(ctx->ev_recon_launch, ctx->stream));
+    FS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_recon_launch, 0));
+    for (size_t i = 0; i < ol.owed.size(); ++i) {
+        const fs_context::ReconOwed& o = ol.owed[i];
+        Source* s = o.s;
+        FS_HIP(ctx, hipEventRecord(s->ev_rec[o.cur], ctx->copy_stream));   // (behind the one wait above: every reconstruct of the launch is done)
+        s->rec_recorded[o.cur] = true;
+        if (ol.tmp[i] < 0) s->last_rec = o.cur;
+        poll_published(s);
+        if (s->enqueued + 1 >= (uint64_t)kIrRing) {   // never overwrite the front buffer (as reconstruct_now)
+            const uint64_t must = s->enqueued + 2 - (uint64_t)kIrRing;
+            const int slot0 = (int)(must % kIrRing);
+            if (s->seq_of[slot0] == must && s->front.load(std::memory_order_relaxed) < must) {
+                FS_HIP(ctx, hipEventSynchronize(s->ev[slot0]));
+                poll_published(s);
+            }
+        }
+        const float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * (size_t)ctx->num_samples : s->d_ir_mono;
+        const uint64_t seq = s->enqueued + 1;
+        const int slot = (int)(seq % kIrRing);
+        FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], mono, sizeof(float) * (size_t)ctx->num_samples, hipMemcpyDeviceToHost, ctx->copy_stream));
+        FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->copy_stream));
+        s->seq_of[slot] = seq;
+        s->enqueued = seq;
+        if (ol.tmp[i] >= 0) {
+            FS_HIP(ctx, hipEventRecord(ctx->ev_ir_tmp[ol.tmp[i]], ctx->copy_stream));
+            ctx->ir_tmp_pending[ol.tmp[i]] = true;
+        }
+    }
+    ol.locks.clear();
     return FS_OK;
 }
 
@@ -91,8 +192,27 @@ static bool held_walk_part(const fs_context* ctx, const fs_context::PipeFrame& q
 // Let every held frame finish on its own kernels, oldest first: something needs their results (or their buffers) now.
 int dispatch_group(fs_context* ctx);   // below: the frames collected by fs_set_frames_per_launch go first
 
+// the reconstructs that were waiting for the next fused launch, on the tail stream after all (a flush, or a reconstruct
+// that must not overtake them)
+static int run_owed_reconstructs(fs_context* ctx) {
+    if (ctx->recon_owed.empty()) return FS_OK;
+    std::vector<fs_context::ReconOwed> owed;
+    owed.swap(ctx->recon_owed);
+    for (const fs_context::ReconOwed& o : owed) {
+        Source* s = o.s;
+        const int cur = s->cur;
+        const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
+        s->cur = o.cur; s->cur_fixed = o.fixed; s->reduced = false; s->handed_off = false; s->tail_ordered = false;
+        const int rc = reconstruct_now(ctx, s, &o.p);
+        s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered;
+        if (rc) return rc;
+    }
+    return FS_OK;
+}
+
 int flush_pending(fs_context* ctx) {
     if (!ctx->group.empty()) { const int gr = dispatch_group(ctx); if (gr) return gr; }
+    { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // (older than every held frame)
     if (ctx->held.empty()) return FS_OK;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     while (!ctx->held.empty()) {
@@ -111,6 +231,7 @@ int flush_pending(fs_context* ctx) {
 }
 
 int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
+    { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // IRs are published in frame order
     // ReconstructImpulseResponse is not linear in the energy (a = e / sqrt(e * Pi4)): the IR of a rank's PARTIAL
     // histogram is not a partial IR.  A sharded context only reconstructs a frame that was summed over the ranks — by
     // the library (fs_comm_init / fs_comm_attach) or by the caller's collective on the tail stream (fs_energy_handoff).
@@ -539,8 +660,12 @@ int frame_launch(fs_context* ctx, Frame& f) {
             for (int i = 0; i < 3; ++i) if (tf.e[i]) { ctx->free_events.push_back(tf.e[i]); tf.e[i] = nullptr; }
             timed_frame = false;
         }
-        if (fp.num_walk > 0 || fp.has_connect || fp.has_plan) {
-            if (!launch_frame(B, ctx->scene, fp, ctx->stream)) {   // no fused form: the same passes one after the other
+        OwedLaunch owed;   // the reconstructs of the frames the previous launch connected ride in this one
+        { const int orc = owed_prepare(ctx, fp, owed); if (orc) return orc; }
+        bool fused_launch = false;
+        if (fp.num_walk > 0 || fp.has_connect || fp.has_plan || fp.num_recon > 0) {
+            fused_launch = launch_frame(B, ctx->scene, fp, ctx->stream);
+            if (!fused_launch) {   // no fused form: the same passes one after the other
                 if (fp.has_connect) launch_connect(B, ctx->scene, fp.kpc, fp.stc, fp.energy, fp.fixed, fp.scratch_c, fp.ppw, fp.energy_tab, fp.fixed_tab, ctx->stream);
                 for (int i = 0; i < fp.num_walk; ++i)
                     launch_walk(ctx->scene, fp.walk[i].kp, fp.walk[i].st, fp.walk[i].wl, fp.walk[i].perm, ctx->stream, fp.walk[i].stage);
@@ -549,11 +674,12 @@ int frame_launch(fs_context* ctx, Frame& f) {
         }
         if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
         FS_HIP(ctx, hipGetLastError());
+        { const int prc = owed_publish(ctx, owed, fused_launch); if (prc) return prc; }
         for (size_t k : advanced) ctx->held[k].next_stage++;
         if (connects) {
             const fs_context::PipeFrame done = ctx->held.front();
             ctx->held.pop_front();
-            const int rc = finish_held_frame(ctx, done);
+            const int rc = finish_held_frame(ctx, done, /*may_defer_recon=*/true);
             if (rc) return rc;
         }
         if (plan_held) ctx->held.push_back(me);   // planned by this launch, walked by the next ones

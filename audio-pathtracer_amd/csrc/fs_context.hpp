@@ -213,7 +213,21 @@ struct fs_context {
         float pos[3] = {}, lis[3] = {};   // source and listener position AT THE CALL (either may move before the group is sent off)
     };
     std::vector<GroupEntry> group;
-    int frames_per_launch = 1;      // oldest first
+    int frames_per_launch = 1;
+    // Reconstructs that ride in the NEXT fused launch (single GPU): the frames the last launch connected owe their IR; a
+    // reconstruct part behind the plan part produces it (fs_frame.hip) instead of a kernel on the tail stream that has to
+    // squeeze into a chip the frame kernel fills (2 % of the frame kernel's time for 0.5 % of its work).  Everything that
+    // flushes runs what is owed on the tail stream as before.  A frame that is not the source's last in the launch writes
+    // its IR into a temporary buffer (two frames of one source would write the same d_ir_* at once) and is published from there.
+    struct ReconOwed { Source* s = nullptr; int cur = 0; bool fixed = false; fs_params p; };
+    std::vector<ReconOwed> recon_owed;
+    bool fused_recon = true;                       // FS_FUSED_RECON=0: always the tail stream
+    static constexpr int kIrTmp = 2 * kMaxReconParts;
+    float* d_ir_tmp[kIrTmp] = {};                  // [(B + 1)][samples]: bands, then the channel view
+    hipEvent_t ev_ir_tmp[kIrTmp] = {};             // tail stream: the publish that read buffer k is done
+    bool ir_tmp_pending[kIrTmp] = {};
+    unsigned ir_tmp_next = 0;
+    hipEvent_t ev_recon_launch = nullptr;          // compute stream: the launch with the reconstruct parts is done      // oldest first
     int state_sets = 3;              // sets of the per-frame arrays (subpath state, records, schedules): frames in flight + 1
     bool state_cont = false;         // the sets include continuation records (staged walks)
     std::vector<int> stage_bounds;   // staged depth = 0 walks: the steps at which a walk changes launch (FS_WALK_STAGES)

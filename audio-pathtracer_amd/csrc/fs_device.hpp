@@ -1505,6 +1505,68 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 
 
 
+// ReconstructImpulseResponse (FSAC.cpp:320-380) for one row (band, or row B = the band mean = the channel view) and one block
+// of kBlock chunks of kChunk samples; s_amp: [nb] floats of LDS.  Shared by reconstruct_kernel (tail stream) and the
+// reconstruct part of the fused frame kernel (fs_frame.hip).
+#ifndef FS_RECON_CHUNK
+#define FS_RECON_CHUNK 16
+#endif
+constexpr int kChunk = FS_RECON_CHUNK;
+constexpr int kWarm = 96;
+__device__ __forceinline__ void reconstruct_body(const int row, const int chunk_block, const float* __restrict__ energy, int B, int nb,
+                                                 int num_samples, int spb, float* __restrict__ ir_bands,
+                                                 float* __restrict__ ir_mono, float* s_amp) {
+    const float Pi4 = sqrtf(4.0f * kPi);                           // FSAC.cpp:323
+    for (int i = threadIdx.x; i < nb; i += kBlock) {
+        float e;
+        if (row < B) e = energy[row * nb + i];
+        else {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += energy[b * nb + i];
+            e = s / (float)B;
+        }
+        float a = 0.0f;
+        if (fabsf(e) >= 1e-6f) a = e / sqrtf(e * Pi4);             // FSAC.cpp:343-345
+        s_amp[i] = a;
+    }
+    __syncthreads();
+    const int chunk = chunk_block * kBlock + threadIdx.x;
+    const int s0 = chunk * kChunk;
+    if (s0 >= num_samples) return;
+    float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
+    const int s1 = min(s0 + kChunk, num_samples);
+    const int i0 = max(s0 - kWarm, 0);
+    int bin = i0 / spb;
+    int bs = i0 - bin * spb;
+    float cur = bin < nb ? s_amp[bin] : 0.0f;
+    float prev = bin == 0 ? cur : (bin - 1 < nb ? s_amp[bin - 1] : 0.0f);   // FSAC.cpp:347-355
+    const float fspb = (float)spb;
+    float y = 0.0f;
+    for (int i = i0; i < s1; ++i) {
+        float x = 0.0f;
+        if (bin < nb) {
+            float wgt = (float)bs / fspb;                           // FSAC.cpp:359
+            float a = (1.0f - wgt) * prev;
+            float b = wgt * cur;
+            x = a + b;                                              // FSAC.cpp:360
+        }
+        if (i == 0) {
+            y = x;                                                  // Filtered[0] = IR[0] FSAC.cpp:371
+        } else {
+            float a = 0.25f * x;
+            float b = (1.0f - 0.25f) * y;
+            y = a + b;                                              // FSAC.cpp:374
+        }
+        if (i >= s0) out[i] = y;
+        if (++bs == spb) {
+            bs = 0;
+            ++bin;
+            prev = cur;
+            cur = bin < nb ? s_amp[bin] : 0.0f;
+        }
+    }
+}
+
 // dynamic LDS of a traversal kernel: the scene's stack rows (+ extra bytes behind them).  Sizes above the default
 // 48 KB limit are announced to the runtime once per (kernel instantiation, device); the host side has already
 // checked the worst case against the device's LDS (fs_capi.cpp: lds_budget_ok), so a failure here is unexpected

@@ -38,6 +38,10 @@ struct FrameArgs {
     KParams kpc; SubpathState stc; float* energy; unsigned long long* fixed; unsigned* scratch_c; int pairs_per_wave;
     float* const* energy_tab; unsigned long long* const* fixed_tab;
     KParams kpp; unsigned* scratch_p; uint32_t* perm_p; float* zero_p; int zero_words_p; float* const* zero_tab_p; int zero_count_p;
+    uint32_t plan_blocks;
+    // reconstruct parts (behind the plan part): (B + 1) rows x recon_cb blocks of chunks per item
+    int num_recon; FrameParts::Recon recon[kMaxReconParts];
+    int recon_B, recon_nb, recon_samples; uint32_t recon_cb;
 };
 static_assert(sizeof(FrameArgs) + sizeof(DeviceScene) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -62,9 +66,16 @@ __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(Devic
     if (b < first + a.connect_blocks) {
         connect_body<B, 0, BATCH, false>(b - first, a.connect_blocks, sc, a.kpc, a.stc, a.energy, a.fixed, a.scratch_c,
                                          a.pairs_per_wave, a.energy_tab, a.fixed_tab);
-    } else {
-        plan_body(b - first - a.connect_blocks, gridDim.x - first - a.connect_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p,
+    } else if (b < first + a.connect_blocks + a.plan_blocks) {
+        plan_body(b - first - a.connect_blocks, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p,
                   a.zero_words_p, a.zero_tab_p, a.zero_count_p);
+    } else {   // reconstruct part: item, row, block of chunks
+        extern __shared__ __attribute__((aligned(16))) int s_dyn_r[];
+        const uint32_t rb = b - first - a.connect_blocks - a.plan_blocks, per_item = (uint32_t)(a.recon_B + 1) * a.recon_cb;
+        const uint32_t item = rb / per_item, in_item = rb - item * per_item;
+        const FrameParts::Recon& r = a.recon[item];
+        reconstruct_body((int)(in_item / a.recon_cb), (int)(in_item % a.recon_cb), r.energy, a.recon_B, a.recon_nb, a.recon_samples, r.spb,
+                         r.ir_bands, r.ir_mono, reinterpret_cast<float*>(s_dyn_r));
     }
 }
 
@@ -121,7 +132,18 @@ bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStrea
         if (!plan_shape(f.kpp, f.wl_p, &pb, &sort)) return false;
         a.kpp = f.kpp; a.scratch_p = f.scratch_p; a.perm_p = f.perm_p; a.zero_p = f.zero_p; a.zero_words_p = f.zero_words_p;
         a.zero_tab_p = f.zero_tab_p; a.zero_count_p = f.zero_count_p;
+        a.plan_blocks = pb;
         blocks += pb;
+    }
+    if (f.num_recon > 0) {
+        if (f.num_recon > kMaxReconParts || f.recon_B < 1 || f.recon_nb < 1 || f.recon_samples < 1) return false;
+        a.num_recon = f.num_recon;
+        for (int i = 0; i < f.num_recon; ++i) a.recon[i] = f.recon[i];
+        a.recon_B = f.recon_B; a.recon_nb = f.recon_nb; a.recon_samples = f.recon_samples;
+        const uint32_t chunks = (uint32_t)((f.recon_samples + kChunk - 1) / kChunk);
+        a.recon_cb = (chunks + kBlock - 1) / kBlock;
+        blocks += (uint32_t)f.num_recon * (uint32_t)(f.recon_B + 1) * a.recon_cb;
+        lds = std::max(lds, sizeof(float) * (size_t)f.recon_nb);
     }
     if (blocks == 0) return false;
     if (blocks_only) { *blocks_only = blocks; return true; }

@@ -195,6 +195,7 @@ struct DeepStore {
 };
 constexpr int kStackRowsCap = 21;       // LDS rows for pending entries when the tree's worst case needs more (+ 1 row of deep counts)
 constexpr int kDeepChunk = 8;           // entries moved per trip to / from the deep store
+constexpr int kMaxReconParts = 4;       // reconstruct parts of a fused launch (= the frames a launch may carry)
 
 // ---- host BVH builder ------------------------------------------------------------------------------
 struct HostBVH {
@@ -253,6 +254,11 @@ struct FrameParts {
     bool has_plan = false;      // kpp, wl_p (plan switch), scratch_p, perm_p (the schedule to write, nullptr: counts only), zero_p / zero_words_p (the flush)
     KParams kpp; WalkLaunch wl_p; unsigned* scratch_p = nullptr; uint32_t* perm_p = nullptr; float* zero_p = nullptr; int zero_words_p = 0;
     float* const* zero_tab_p = nullptr; int zero_count_p = 0;                              // batched frame: the buffers to flush
+    // reconstruct parts: ReconstructImpulseResponse of the frames the PREVIOUS launch connected (single GPU; a sharded
+    // frame is reduced on the tail stream first and reconstructed there)
+    int num_recon = 0;
+    struct Recon { const float* energy; float* ir_bands; float* ir_mono; int spb; } recon[kMaxReconParts];
+    int recon_B = 0, recon_nb = 0, recon_samples = 0;
 };
 bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s);
 // does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule
