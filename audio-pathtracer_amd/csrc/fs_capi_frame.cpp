@@ -44,6 +44,11 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bo
     // the other items' reconstructs are ordered too — no further event pairs on the compute stream (each is a bubble
     // between its launches).  Not in deterministic mode: every item's fixed-point rounding runs on the compute stream first.
     bool tail_behind_launch = false;
+    // the reconstructs of a frame ride in the next launch all together or not at all (a tail-stream reconstruct in between
+    // would have to run the deferred ones first, to keep the IRs in frame order)
+    int wanted = 0;
+    for (const fs_context::PipeFrame::Item& it : q.items) wanted += it.want_recon ? 1 : 0;
+    if (wanted + (int)ctx->recon_owed.size() > kMaxReconParts) may_defer_recon = false;
     for (const fs_context::PipeFrame::Item& it : q.items) {
         Source* s = it.s;
         const bool moved_on = s->cur != it.cur;
@@ -57,7 +62,7 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bo
         if (!rc && it.want_recon) {
             // single GPU, plain reconstruct: it rides in the next fused launch (fs_context::recon_owed)
             if (may_defer_recon && ctx->fused_recon && !ctx->comm && ctx->cfg.world_size == 1 && ctx->profiling < 2 &&
-                !(it.recon.flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && (int)ctx->recon_owed.size() < kMaxReconParts) {
+                !(it.recon.flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)) {
                 fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon;
                 ctx->recon_owed.push_back(o);
             } else {

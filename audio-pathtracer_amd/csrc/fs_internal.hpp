@@ -195,7 +195,7 @@ struct DeepStore {
 };
 constexpr int kStackRowsCap = 21;       // LDS rows for pending entries when the tree's worst case needs more (+ 1 row of deep counts)
 constexpr int kDeepChunk = 8;           // entries moved per trip to / from the deep store
-constexpr int kMaxReconParts = 4;       // reconstruct parts of a fused launch (= the frames a launch may carry)
+constexpr int kMaxReconParts = 4;       // reconstruct parts of a fused launch (the frames of a group, the sources of a small batch; the 4 KB of kernel arguments are full)
 
 // ---- host BVH builder ------------------------------------------------------------------------------
 struct HostBVH {
