@@ -449,3 +449,37 @@ def test_frames_per_launch_keeps_the_positions_of_each_call(pkg, scene_factory):
     assert out[1][0].any()
     for a, b in zip(out[1], out[3]):
         assert np.array_equal(a, b)
+
+
+def test_reverb_hears_the_irs_of_grouped_pipelined_frames(pkg, scene_factory):
+    """The reverb callback convolves with the source's DEVICE-resident IR (fs_reverb_process).  With pipelined frames, several
+    per launch and their reconstructs riding in the launches (fs_frame.hip: reconstruct parts; the frames of one source
+    but the last write temporaries), that IR must at every callback be the one of the last frame issued — as it is with
+    plain frames.  Callbacks are interleaved with the stream; every block must equal the plain context's block bit for bit."""
+    sc = scene_factory("starter_room", 4)
+    rng = np.random.default_rng(12)
+    blocks = [np.clip(rng.normal(0, 0.2, 2048), -1, 1).astype(np.float32) for _ in range(6)]
+    out = {}
+    for mode in ("plain", "grouped"):
+        ctx, s = make_ctx(pkg, sc)
+        ctx.reverb_init(s, 1024)
+        if mode == "grouped":
+            ctx.set_pipelining(2)
+            ctx.set_frames_per_launch(3)
+        p = pkg.default_params(num_rays=8192, depth=8, flags=DET, dist_divisor=100.0)
+        got, k = [], 0
+        for i in range(14):
+            p.seed = 300 + i
+            ctx.compute_energy_response_async(s, p)
+            ctx.reconstruct_impulse_response_async(s, p)
+            if i in (0, 3, 4, 8, 12, 13):
+                ctx.synchronize()                       # the IR of frame i is the source's IR now
+                got.append(np.asarray(ctx.reverb_process(s, blocks[k])).copy())
+                k += 1
+        ctx.synchronize()
+        got.append(ctx.impulse_response(s, 0).copy())
+        out[mode] = got
+        ctx.close()
+    assert max(np.abs(a).max() for a in out["plain"][:-1]) > 0          # (the first block may precede the first arrival)
+    for a, b in zip(out["plain"], out["grouped"]):
+        assert np.array_equal(a, b)
