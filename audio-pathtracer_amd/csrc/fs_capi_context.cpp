@@ -266,7 +266,10 @@ int auto_rays_per_wave(unsigned long long lanes, int depth) {
     // frames do better at ~4096 waves — 65 536 subpaths 16 per wave, 131 072 subpaths 32 per wave (0.244 -> 0.233 ms at
     // depth 8, 0.355 -> 0.309 ms at depth 12; unpipelined 0.300 -> 0.267 ms); 262 144 and more stay dense
     const unsigned long long target_waves = depth > 16 ? 16384ull : (lanes >= 65536ull ? 4096ull : 2048ull);
-    int rpw = 4;
+    // round 3 (tools/ref_defaults_breakdown.py, profiles/r03_ref_defaults_rpw.log): the reference's own update — 2 000
+    // subpaths, uncapped — is fastest with ONE subpath per wave (0.88 -> 0.71 ms starter_room, 1.11 -> 0.92 ms old_mine; 2: 0.79,
+    // 4: 0.85, 16: 0.90): the floor of 4 per wave went
+    int rpw = 1;
     while (rpw < 64 && (unsigned long long)rpw * 2 * target_waves <= lanes) rpw *= 2;   // largest power of two <= lanes / target
     return rpw;
 }
@@ -275,7 +278,7 @@ int auto_rays_per_wave(unsigned long long lanes, int depth) {
 // About 2048 waves (tools/connect_sparse_sweep.py): 8 192 pairs 0.065 -> 0.031 ms with 4 per wave, 32 768 pairs
 // 0.067 -> 0.043 ms with 16, dense waves from 131 072 pairs on.
 int auto_pairs_per_wave(unsigned long long pairs) {
-    int ppw = 4;
+    int ppw = 1;   // (round 3: 1 000 pairs, one per wave: 0.056 -> 0.044 ms; profiles/r03_ref_defaults_rpw.log)
     while (ppw < 64 && (unsigned long long)ppw * 2 * 2048ull <= pairs) ppw *= 2;
     return ppw;
 }
