@@ -390,10 +390,24 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
         if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         ctx->own_stream = true;
     }
-    e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate(copy): ") + hipGetErrorString(e));
-    e = hipStreamCreateWithFlags(&ctx->rev_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate(reverb): ") + hipGetErrorString(e));
+    {
+        // The tail stream (all-reduce, reconstructs, publishes) and the reverb callback's stream are created with the highest
+        // priority: what they carry is small and somebody waits for it — and a priority stream gets hardware queues of its own.
+        // With three ordinary streams the rate of a pipelined stream of frames depended on how many streams the process
+        // had created before (which hardware queues the compute and the tail stream were given): 965 – 970 M rays/s or
+        // 880 M, 995 or 900 M at four frames per launch, by the count of earlier streams (profiles/r03_stream_queues.log;
+        // without publishes 990 / 1 015 M whatever the history).  FS_TAIL_STREAM_PRIORITY=0: ordinary streams again; 2: lowest.
+        int prio_lo = 0, prio_hi = 0;   // (numerically lower = higher priority)
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const int mode = std::getenv("FS_TAIL_STREAM_PRIORITY") ? std::atoi(std::getenv("FS_TAIL_STREAM_PRIORITY")) : 1;
+        const int prio = mode == 2 ? prio_lo : prio_hi;
+        if (mode != 0) e = hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio);
+        else e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate(copy): ") + hipGetErrorString(e));
+        if (mode != 0) e = hipStreamCreateWithPriority(&ctx->rev_stream, hipStreamNonBlocking, prio_hi);
+        else e = hipStreamCreateWithFlags(&ctx->rev_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipStreamCreate(reverb): ") + hipGetErrorString(e));
+    }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0)
         ctx->walk.num_cus = cus;

@@ -42,6 +42,7 @@ struct FrameArgs {
     // reconstruct parts (behind the plan part): (B + 1) rows x recon_cb blocks of chunks per item
     int num_recon; FrameParts::Recon recon[kMaxReconParts];
     int recon_B, recon_nb, recon_samples; uint32_t recon_cb;
+    uint32_t connect_first;   // the connect part takes the FIRST workgroups of the grid (see FS_LAUNCH_FRAME)
 };
 static_assert(sizeof(FrameArgs) + sizeof(DeviceScene) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -52,9 +53,18 @@ static_assert(sizeof(FrameArgs) + sizeof(DeviceScene) <= 4096, "kernel arguments
 #endif
 template <int B, bool BATCH>
 __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(DeviceScene sc, FrameArgs a) {
-    const uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x;
+    if (a.connect_first) {
+        if (b < a.connect_blocks) {
+            connect_body<B, 0, BATCH, false>(b, a.connect_blocks, sc, a.kpc, a.stc, a.energy, a.fixed, a.scratch_c,
+                                             a.pairs_per_wave, a.energy_tab, a.fixed_tab);
+            return;
+        }
+        b -= a.connect_blocks;
+    }
+    const uint32_t cb = a.connect_first ? 0u : a.connect_blocks;   // connect workgroups behind the walk parts
     uint32_t first = 0;
-    for (int i = 0; i < a.num_walk; ++i) {   // (walks first: starting the connect pass before the short walks measured slower)
+    for (int i = 0; i < a.num_walk; ++i) {
         const WalkArgs& w = a.walk[i];
         if (b < w.block_end) {
             if (w.rays_per_wave < 64) walk_sparse_body<0, false>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.rays_per_wave, w.stage);
@@ -63,15 +73,15 @@ __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(Devic
         }
         first = w.block_end;
     }
-    if (b < first + a.connect_blocks) {
+    if (b < first + cb) {
         connect_body<B, 0, BATCH, false>(b - first, a.connect_blocks, sc, a.kpc, a.stc, a.energy, a.fixed, a.scratch_c,
                                          a.pairs_per_wave, a.energy_tab, a.fixed_tab);
-    } else if (b < first + a.connect_blocks + a.plan_blocks) {
-        plan_body(b - first - a.connect_blocks, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p,
+    } else if (b < first + cb + a.plan_blocks) {
+        plan_body(b - first - cb, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p,
                   a.zero_words_p, a.zero_tab_p, a.zero_count_p);
     } else {   // reconstruct part: item, row, block of chunks
         extern __shared__ __attribute__((aligned(16))) int s_dyn_r[];
-        const uint32_t rb = b - first - a.connect_blocks - a.plan_blocks, per_item = (uint32_t)(a.recon_B + 1) * a.recon_cb;
+        const uint32_t rb = b - first - cb - a.plan_blocks, per_item = (uint32_t)(a.recon_B + 1) * a.recon_cb;
         const uint32_t item = rb / per_item, in_item = rb - item * per_item;
         const FrameParts::Recon& r = a.recon[item];
         reconstruct_body((int)(in_item / a.recon_cb), (int)(in_item % a.recon_cb), r.energy, a.recon_B, a.recon_nb, a.recon_samples, r.spb,
@@ -121,6 +131,19 @@ bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStrea
         const uint32_t want = f.energy_tab ? (f.kpc.num_local / f.kpc.pairs_per_source) * ((f.kpc.pairs_per_source + per_block - 1) / per_block)
                                            : (f.kpc.num_local + per_block - 1) / per_block;
         a.connect_blocks = std::min<uint32_t>(want, 1024u);
+        // Where the connect workgroups sit in the grid (tools/launch_timeline.py, profiles/r03_launch_timeline_*.json,
+        // profiles/r03_connect_first.log).  Behind the walks, the connect pass starts when the last walk workgroup has been
+        // dispatched and is the launch's tail: 55 of 597 us at 40 % of the wave slots when two frames share the launch.  A
+        // launch whose walk workgroups need the chip's 1 024 workgroup slots twice over starts 384 connect workgroups FIRST
+        // instead (they step through all the pairs): they finish while the long walks run and the tail is the
+        // shortest walks (950 -> 965 M rays/s; 256: 962, 512: 946, 1 024: 921).  A launch whose walks fit the chip once
+        // keeps the connect pass behind them: there every long walk has to start at t = 0 (858 -> 815 M with 384 first).
+        // FS_FRAME_CONNECT_FIRST = n > 0: always n first; < 0: never.  (cfg5's eight sources 894 -> 912 M, deterministic mode
+        // 835 -> 870 M, three frames per launch 818 -> 852 M; cfg4 and staged walks unchanged.)
+        static const int cap_env = std::getenv("FS_FRAME_CONNECT_FIRST") ? std::atoi(std::getenv("FS_FRAME_CONNECT_FIRST")) : 0;
+        // (walks of one length — Russian roulette off — leave no short walks for the tail: 660 -> 606 M with connect first)
+        const int cap_first = cap_env != 0 ? cap_env : (blocks >= 2048u && f.walk[0].kp.russian_roulette ? 384 : -1);
+        if (cap_first > 0 && f.num_walk > 0) { a.connect_blocks = std::min<uint32_t>(a.connect_blocks, (uint32_t)cap_first); a.connect_first = 1u; }
         a.kpc = f.kpc; a.stc = f.stc; a.energy = f.energy; a.fixed = f.fixed; a.scratch_c = f.scratch_c; a.pairs_per_wave = f.ppw;
         a.energy_tab = f.energy_tab; a.fixed_tab = f.fixed_tab;
         blocks += a.connect_blocks;
