@@ -483,3 +483,36 @@ def test_reverb_hears_the_irs_of_grouped_pipelined_frames(pkg, scene_factory):
     assert max(np.abs(a).max() for a in out["plain"][:-1]) > 0          # (the first block may precede the first arrival)
     for a, b in zip(out["plain"], out["grouped"]):
         assert np.array_equal(a, b)
+
+
+def test_headline_launch_shape_with_the_connect_part_first(pkg, scene_factory):
+    """A launch whose walks need the chip's workgroup slots twice over (two 262 144-ray frames of roulette walks: 2 048 walk
+    workgroups) puts 384 connect workgroups FIRST in the grid and lets them step through all the pairs (fs_frame.hip,
+    FS_LAUNCH_FRAME).  Energies (deterministic mode: bit for bit), IRs and counters must be those of unpipelined frames."""
+    sc = scene_factory("old_mine", 8)
+    out = {}
+    for mode in ("plain", "grouped"):
+        ctx, s = make_ctx(pkg, sc)
+        if mode == "grouped":
+            ctx.set_pipelining(2)
+            ctx.set_frames_per_launch(2)
+        p = pkg.default_params(num_rays=262144, depth=8, flags=DET)
+        got = []
+        for i in range(8):
+            p.seed = 4100 + i
+            ctx.compute_energy_response_async(s, p)
+            ctx.reconstruct_impulse_response_async(s, p)
+            if i == 5:
+                ctx.synchronize()
+                got.append(ctx.energy_buffer(s).copy())
+                got.append(ctx.impulse_response(s, 0).copy())
+        ctx.synchronize()
+        got.append(ctx.energy_buffer(s).copy())
+        got.append(ctx.impulse_response(s, 0).copy())
+        st = ctx.stats()
+        got.append(np.asarray([st["frames"], st["segments"], st["connections_tested"], st["deposits"]], np.int64))
+        out[mode] = got
+        ctx.close()
+    assert out["plain"][0].any()
+    for a, b in zip(out["plain"], out["grouped"]):
+        assert np.array_equal(a, b)
