@@ -334,7 +334,7 @@ int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t
 int fs_set_pipelining(fs_context* ctx, int32_t depth);   /* 0 = off, 1, 2 */
 int fs_set_walk_stages(fs_context* ctx, const int32_t* bounds /* ascending, 1..511 */, int32_t count /* 0..7 */);
 /* Frames per launch (with pipelining on; default 1): a 262 144-ray frame leaves a tenth of an MI355X idle that a launch of
- * two such frames fills (871 -> 950 M rays/s).  With n > 1 fs_compute_energy_response_async lets a plain pipelinable frame
+ * two such frames fills (866 -> 965 M rays/s).  With n > 1 fs_compute_energy_response_async lets a plain pipelinable frame
  * WAIT until n of its kind have come — the same fs_params but for the low 32 bits of the seed, any sources, the same
  * source several times — and traces them as ONE batched frame in which every item keeps its own seed, energy buffer and
  * recorded fs_reconstruct_impulse_response_async: results are exactly those of n single frames.  Everything that observes
