@@ -516,3 +516,33 @@ def test_headline_launch_shape_with_the_connect_part_first(pkg, scene_factory):
     assert out["plain"][0].any()
     for a, b in zip(out["plain"], out["grouped"]):
         assert np.array_equal(a, b)
+
+
+def test_batched_sources_with_the_connect_part_first(pkg, scene_factory):
+    """The same launch shape through the batched frame (cfg5: several sources' pairs end to end, one energy buffer each):
+    8 sources x 65 536 subpaths are 2 048 walk workgroups, so the 384 connect workgroups at the head of the grid step
+    through (source, chunk) items and flush their LDS histogram at every change of source (connect_body, BATCH).  Energies
+    of pipelined batches, bit for bit those of the sources traced one by one without pipelining."""
+    sc = scene_factory("old_mine", 8)
+    pos = [np.asarray(sc.source, np.float32) + np.asarray([40.0 * k, -25.0 * k, 6.0 * k], np.float32) for k in range(8)]
+    out = {}
+    for mode in ("one by one", "batched"):
+        ctx, s0 = make_ctx(pkg, sc)
+        srcs = [ctx.create_source(q) for q in pos]
+        p = pkg.default_params(num_rays=65536, depth=8, flags=DET)
+        if mode == "batched":
+            ctx.set_pipelining(2)
+        for i in range(4):
+            p.seed = 5200 + i
+            if mode == "batched":
+                ctx.compute_energy_response_batch_async(srcs, p)
+            else:
+                for s in srcs:
+                    ctx.compute_energy_response_async(s, p)
+        ctx.synchronize()
+        out[mode] = [ctx.energy_buffer(s).copy() for s in srcs]
+        ctx.close()
+    assert all(e.any() for e in out["one by one"])
+    assert len({e.tobytes() for e in out["one by one"]}) == 8          # eight different sources
+    for a, b in zip(out["one by one"], out["batched"]):
+        assert np.array_equal(a, b)
