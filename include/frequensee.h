@@ -18,6 +18,8 @@
  * one producer thread (the game thread) calls compute/reconstruct; concurrently with it any number of threads may
  * read published impulse responses (fs_get_impulse_response), and ONE audio render thread may run the reverb callback
  * (fs_reverb_process) — it has a HIP stream of its own and is never queued behind a traced frame.
+ * The tail stream and the reverb stream are created with the highest HIP stream priority (small work somebody waits for;
+ * priority streams have hardware queues of their own); FS_TAIL_STREAM_PRIORITY=0 in the environment makes them ordinary.
  *
  * There is no CPU fallback: if no HIP device is usable every compute entry point fails with
  * FS_ERR_NO_DEVICE.
