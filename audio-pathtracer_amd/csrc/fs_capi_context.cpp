@@ -12,13 +12,23 @@ Source* get_source(fs_context* ctx, fs_source h) {
 
 // Before the compute stream writes the current energy buffer: the tail-stream reconstruct that last read it
 // must be done (two frames back in steady state, i.e. long finished).
+// The compute stream waits for `ev` — unless the event has completed already, which is the rule for these waits (the
+// reader of a buffer that comes round again after 24 frames, the all-reduce enqueued two launches ago): a wait for a
+// finished event is still a barrier packet between two launches of the compute stream (tools/rccl_tax.sh: 23 us between the
+// launches of a context with a communicator, 4 such waits each).
+hipError_t compute_waits_for(fs_context* ctx, hipEvent_t ev) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();   // hipErrorNotReady is not an error
+    return hipStreamWaitEvent(ctx->stream, ev, 0);
+}
 hipError_t wait_energy_readers(fs_context* ctx, Source* s, int buf) {
     if (s->red_recorded[buf]) {   // the tail stream may still be summing this buffer over the ranks
-        hipError_t e = hipStreamWaitEvent(ctx->stream, s->ev_red[buf], 0);
+        hipError_t e = compute_waits_for(ctx, s->ev_red[buf]);
         if (e != hipSuccess) return e;
     }
     if (!s->rec_recorded[buf]) return hipSuccess;
-    return hipStreamWaitEvent(ctx->stream, s->ev_rec[buf], 0);
+    return compute_waits_for(ctx, s->ev_rec[buf]);
 }
 hipError_t wait_energy_readers(fs_context* ctx, Source* s) { return wait_energy_readers(ctx, s, s->cur); }
 // Hand the current energy buffer over to the tail stream: what the compute stream has enqueued so far
@@ -424,6 +434,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_FUSED_RECON")) ctx->fused_recon = std::atoi(v) != 0;
+    if (const char* v = std::getenv("FS_FUSED_RECON_COMM")) ctx->fused_recon_comm = std::atoi(v) != 0;
     ctx->hist_window = default_hist_window(ctx->cfg.num_bands);
     if (const char* v = std::getenv("FS_STACK_ROWS_CAP")) ctx->stack_rows_cap = std::max(kDeepChunk + 4, std::min(kStackDepth + 1, std::atoi(v)));
     if (const char* v = std::getenv("FS_HIST_WINDOW")) ctx->hist_window = std::max(1, std::min(4096, std::atoi(v)));

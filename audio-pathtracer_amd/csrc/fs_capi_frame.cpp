@@ -39,11 +39,12 @@ namespace {
 // What a held frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum over
 // the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
 // frames (cur rotated): the per-frame fields are switched back for the duration.
-static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false) {
+static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false, bool tail_waits_already = false) {
     // the items of a frame were connected by ONE launch: once the tail stream waits behind it (the first item's handoff),
     // the other items' reconstructs are ordered too — no further event pairs on the compute stream (each is a bubble
     // between its launches).  Not in deterministic mode: every item's fixed-point rounding runs on the compute stream first.
-    bool tail_behind_launch = false;
+    // (tail_waits_already: the publishes of this very launch's reconstruct parts made the tail stream wait behind it)
+    bool tail_behind_launch = tail_waits_already;
     // the reconstructs of a frame ride in the next launch all together or not at all (a tail-stream reconstruct in between
     // would have to run the deferred ones first, to keep the IRs in frame order)
     int wanted = 0;
@@ -60,10 +61,13 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bo
         if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
         if (ctx->comm) { rc = reduce_energy(ctx, s); if (!rc && s->tail_ordered) tail_behind_launch = true; }
         if (!rc && it.want_recon) {
-            // single GPU, plain reconstruct: it rides in the next fused launch (fs_context::recon_owed)
-            if (may_defer_recon && ctx->fused_recon && !ctx->comm && ctx->cfg.world_size == 1 && ctx->profiling < 2 &&
+            // plain reconstruct: it rides in the next fused launch (fs_context::recon_owed) — on one GPU; with the library's
+            // collective, in the launch after next, behind the all-reduce just enqueued on the tail stream
+            const bool single = !ctx->comm && ctx->cfg.world_size == 1;
+            const bool summed = ctx->comm != nullptr && ctx->fused_recon_comm && s->reduced && s->red_recorded[it.cur];
+            if (may_defer_recon && ctx->fused_recon && (single || summed) && ctx->profiling < 2 &&
                 !(it.recon.flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)) {
-                fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon;
+                fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon; o.reduced = summed;
                 ctx->recon_owed.push_back(o);
             } else {
                 rc = reconstruct_now(ctx, s, &it.recon);
@@ -86,7 +90,15 @@ struct OwedLaunch {
 };
 static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
     if (ctx->recon_owed.empty()) return FS_OK;
-    ol.owed.swap(ctx->recon_owed);
+    {   // the oldest entries that are due (frame order: a prefix); summed entries wait one launch (ReconOwed::reduced)
+        size_t take = 0;
+        while (take < ctx->recon_owed.size() && take < (size_t)kMaxReconParts &&
+               (!ctx->recon_owed[take].reduced || ctx->recon_owed[take].age >= 1)) ++take;
+        for (size_t k = take; k < ctx->recon_owed.size(); ++k) ctx->recon_owed[k].age++;
+        if (take == 0) return FS_OK;
+        ol.owed.assign(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
+        ctx->recon_owed.erase(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
+    }
     const int B = ctx->cfg.num_bands;
     const size_t row = (size_t)ctx->num_samples;
     std::vector<Source*> distinct;
@@ -108,11 +120,12 @@ static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
                 FS_HIP(ctx, hipMalloc((void**)&ctx->d_ir_tmp[t], sizeof(float) * (size_t)(B + 1) * row));
                 FS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ir_tmp[t], hipEventDisableTiming));
             }
-            if (ctx->ir_tmp_pending[t]) FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ir_tmp[t], 0));   // its last publish has read it
+            if (ctx->ir_tmp_pending[t]) FS_HIP(ctx, compute_waits_for(ctx, ctx->ev_ir_tmp[t]));   // its last publish has read it
             bands = ctx->d_ir_tmp[t]; mono = ctx->d_ir_tmp[t] + (size_t)B * row;
         } else if (s->rev_recorded) {
-            FS_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
+            FS_HIP(ctx, compute_waits_for(ctx, s->ev_rev));   // a reverb callback may be reading d_ir_mono
         }
+        if (o.reduced && s->red_recorded[o.cur]) FS_HIP(ctx, compute_waits_for(ctx, s->ev_red[o.cur]));   // the sum over the ranks (done a launch ago)
         ol.tmp.push_back(t);
         FrameParts::Recon& r = fp.recon[fp.num_recon++];
         r.energy = s->d_energy[o.cur]; r.ir_bands = bands; r.ir_mono = mono;
@@ -207,7 +220,8 @@ static int run_owed_reconstructs(fs_context* ctx) {
         Source* s = o.s;
         const int cur = s->cur;
         const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
-        s->cur = o.cur; s->cur_fixed = o.fixed; s->reduced = false; s->handed_off = false; s->tail_ordered = false;
+        s->cur = o.cur; s->cur_fixed = o.fixed; s->reduced = o.reduced; s->handed_off = false;
+        s->tail_ordered = o.reduced;   // (the tail stream is behind the all-reduce, which is behind the launch)
         const int rc = reconstruct_now(ctx, s, &o.p);
         s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered;
         if (rc) return rc;
@@ -679,12 +693,13 @@ int frame_launch(fs_context* ctx, Frame& f) {
         }
         if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
         FS_HIP(ctx, hipGetLastError());
+        const bool tail_behind = !owed.owed.empty();   // owed_publish makes the tail stream wait for this launch
         { const int prc = owed_publish(ctx, owed, fused_launch); if (prc) return prc; }
         for (size_t k : advanced) ctx->held[k].next_stage++;
         if (connects) {
             const fs_context::PipeFrame done = ctx->held.front();
             ctx->held.pop_front();
-            const int rc = finish_held_frame(ctx, done, /*may_defer_recon=*/true);
+            const int rc = finish_held_frame(ctx, done, /*may_defer_recon=*/true, tail_behind);
             if (rc) return rc;
         }
         if (plan_held) ctx->held.push_back(me);   // planned by this launch, walked by the next ones

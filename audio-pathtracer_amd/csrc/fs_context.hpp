@@ -219,9 +219,13 @@ struct fs_context {
     // squeeze into a chip the frame kernel fills (2 % of the frame kernel's time for 0.5 % of its work).  Everything that
     // flushes runs what is owed on the tail stream as before.  A frame that is not the source's last in the launch writes
     // its IR into a temporary buffer (two frames of one source would write the same d_ir_* at once) and is published from there.
-    struct ReconOwed { Source* s = nullptr; int cur = 0; bool fixed = false; fs_params p; };
+    // reduced: the library has summed the buffer over the ranks on the tail stream (ev_red[cur]); such an entry rides in the
+    // launch AFTER next (age >= 1 when a launch is assembled): the all-reduce runs behind the launch that connected the
+    // frame, i.e. while the next one executes — a launch that waited for it would leave the GPU idle meanwhile
+    struct ReconOwed { Source* s = nullptr; int cur = 0; bool fixed = false; fs_params p; bool reduced = false; int age = 0; };
     std::vector<ReconOwed> recon_owed;
     bool fused_recon = true;                       // FS_FUSED_RECON=0: always the tail stream
+    bool fused_recon_comm = true;                  // FS_FUSED_RECON_COMM=0: with a communicator, always the tail stream
     static constexpr int kIrTmp = 2 * kMaxReconParts;
     float* d_ir_tmp[kIrTmp] = {};                  // [(B + 1)][samples]: bands, then the channel view
     hipEvent_t ev_ir_tmp[kIrTmp] = {};             // tail stream: the publish that read buffer k is done
@@ -322,6 +326,7 @@ namespace fsi {
 // ---- fs_capi_context.cpp ------------------------------------------------------------------------------------------
 Source* get_source(fs_context* ctx, fs_source h);
 hipError_t wait_energy_readers(fs_context* ctx, Source* s);            // before the compute stream writes the current energy buffer
+hipError_t compute_waits_for(fs_context* ctx, hipEvent_t ev);   // hipStreamWaitEvent on the compute stream unless ev has completed
 hipError_t wait_energy_readers(fs_context* ctx, Source* s, int buf);   // ... or the buffer the next frame will use
 hipError_t handoff_energy(fs_context* ctx, Source* s);        // compute stream -> tail stream
 void free_source(fs_context* ctx, Source* s);

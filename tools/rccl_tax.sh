@@ -38,5 +38,15 @@ if nc:
     print("frame us overlapping an rccl kernel: n", len(ov), "median", st.median(ov) if ov else None, "| not overlapping: n", len(no), "median", st.median(no) if no else None)
 gaps=[(int(fr[i+1]["Start_Timestamp"])-int(fr[i]["End_Timestamp"]))/1e3 for i in range(5,len(fr)-1)]
 print("gap between frame kernels us: median", st.median(gaps), "p90", sorted(gaps)[9*len(gaps)//10])
+# what ran between two launches in the steady state (kernels that START after launch k has ended, and the ones of the launch's last 60 us)
+idx=[i for i,r in enumerate(rows) if "frame_kernel<8, true>" in r["Kernel_Name"]]
+for k in (40, 41):
+    a, b = rows[idx[k]], rows[idx[k+1]]
+    ea, sb = int(a["End_Timestamp"]), int(b["Start_Timestamp"])
+    print("gap", round((sb-ea)/1e3,1), "us; queue of the launches", a.get("Queue_Id"), b.get("Queue_Id"))
+    for r in rows:
+        s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if r is a or r is b or e0 < ea - 60000 or s0 > sb: continue
+        print("    queue", r.get("Queue_Id"), r["Kernel_Name"][:70], "start %+.1f us" % ((s0-ea)/1e3), "dur %.1f us" % ((e0-s0)/1e3))
 PY
 rm -rf $out/rccl_trace
