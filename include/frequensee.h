@@ -322,7 +322,8 @@ int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t
  * (many sources, offline rendering, bench.py) gains 12-14 % (36 % on 16 384-ray frames), a producer that issues one
  * frame per game tick should end the tick with fs_submit (or leave pipelining off) or the frame's IR is published one
  * or two ticks later (three on a single GPU: there the reconstruct of a held frame is itself a part of the launch after
- * the one that connects it, instead of a kernel on the tail stream).  Batched frames are held like any other (they gain little: a frame of several chip-fulls has no
+ * the one that connects it, instead of a kernel on the tail stream; four with the library's collective: the launch after
+ * next, behind the all-reduce — FS_FUSED_RECON=0 / FS_FUSED_RECON_COMM=0 keep the reconstructs on the tail stream).  Batched frames are held like any other (they gain little: a frame of several chip-fulls has no
  * thin tail to fill).  Frames with lobes, all-connections modes, FS_FLAG_ACCUMULATE_ENERGY and profiling level >= 2
  * are never held.
  * depth = 0 frames (the reference's uncapped walks, ARTS.cpp:294) are held at depth 2 as STAGED WALKS: the longest walk
