@@ -430,9 +430,10 @@ void frame_describe(fs_context* ctx, Frame& f) {
         // launches of two or more frames have thicker late stages: fewer, longer stages measure 3 % faster there
         // (profiles/r03_stage_sweep.log, last sweep: 0.595 -> 0.571 ms per frame at two frames per launch)
         // (two per launch: 0.595 -> 0.571 ms per frame; four per launch: 0.559 -> 0.544 ms with one stage fewer still)
-        static const std::vector<int> kStageBounds2 = {12, 24, 40, 64, 96}, kStageBounds3 = {16, 36, 64, 96};
-        const std::vector<int>& bounds = !(ctx->stage_bounds_default && f.group && f.count >= 2) ? ctx->stage_bounds
-                                         : (f.count >= 3 ? kStageBounds3 : kStageBounds2);
+        // (end of round 3, streams of 600 frames: 16, 36, 64, 96 also at two per launch — 505 -> 509 M rays/s through bench.py,
+        // 481 -> 488 M through tools/stage_sweep.py; 12, 24, 40, 64, 96 until then; profiles/r03_unbounded_600_frames.log)
+        static const std::vector<int> kGroupedStageBounds = {16, 36, 64, 96};
+        const std::vector<int>& bounds = !(ctx->stage_bounds_default && f.group && f.count >= 2) ? ctx->stage_bounds : kGroupedStageBounds;
         for (int bound : bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);

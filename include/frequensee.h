@@ -332,7 +332,7 @@ int fs_shard_range(uint32_t num_rays, int32_t rank, int32_t world_size, uint32_t
  * walks only steps [bound[s-1], bound[s]) of the walks still alive (a 32-byte continuation record per walk carries them
  * from launch to launch), next to the other stages of the frames around it: every launch holds one frame's worth of
  * work and no dependent chain longer than a stage; the frame's IR is published stages + 2 calls after its own (9 with
- * the default bounds 8, 18, 30, 46, 64, 96 — 12, 24, 40, 64, 96 for launches of two frames and 16, 36, 64, 96 for three or four, fs_set_frames_per_launch —;
+ * the default bounds 8, 18, 30, 46, 64, 96 — 16, 36, 64, 96 for launches of two to four frames, fs_set_frames_per_launch —;
  * fs_set_walk_stages changes them, count 0 = do not hold such frames). */
 int fs_set_pipelining(fs_context* ctx, int32_t depth);   /* 0 = off, 1, 2 */
 int fs_set_walk_stages(fs_context* ctx, const int32_t* bounds /* ascending, 1..511 */, int32_t count /* 0..7 */);
