@@ -247,6 +247,12 @@ class Context:
         self.check(self.lib.fs_get_impulse_response(self.h, src, channel, C.byref(p), C.byref(n)))
         return np.ctypeslib.as_array(p, shape=(n.value,))
 
+    def impulse_response_sequence(self, src):
+        """publishes of this source completed so far (the front buffer holds publish number `this` or a newer one)"""
+        n = C.c_uint64()
+        self.check(self.lib.fs_get_impulse_response_sequence(self.h, src, C.byref(n)))
+        return int(n.value)
+
     def band_impulse_response(self, src, band):
         out = np.empty(self.num_samples, dtype=np.float32)
         self.check(self.lib.fs_copy_band_impulse_response(self.h, src, band, out.ctypes.data, out.shape[0]))
@@ -263,6 +269,7 @@ class Context:
         return out
 
     def trace_rays(self, origins, dirs, tmax, any_hit=False):
+        """any_hit: False / 0 closest hit, True / 1 any hit, 2 / 3 / 4 closest hit by the cooperative traversal (1 / 2 / 4 rays per wave)"""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
         n = o.shape[0]

@@ -76,7 +76,8 @@ int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, cons
     { int ir = maybe_install_refined(ctx); if (ir) return ir; }                     // fs_scene_commit_progressive: the better tree is ready
     if (ctx->refit_pending) { int rr = fs_scene_refit(ctx); if (rr) return rr; }   // moved triangles: refit before tracing
     if (N < 0 || (N > 0 && (!origins || !dirs || !tmax || !hit))) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad ray arrays");
-    if (!any_hit && N > 0 && (!t || !tri || !normal)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "closest-hit outputs required");
+    if (any_hit != 1 && N > 0 && (!t || !tri || !normal)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "closest-hit outputs required");
+    if (any_hit < 0 || any_hit > 8) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "any_hit: 0 closest, 1 any, 2 .. 8 closest by the cooperative traversal");
     if (N == 0) return FS_OK;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     float *d_o = nullptr, *d_d = nullptr, *d_tm = nullptr, *d_t = nullptr, *d_n = nullptr;
@@ -97,7 +98,8 @@ int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, cons
     FS_TRY(hipMalloc((void**)&d_tm, n1));
     FS_TRY(hipMalloc((void**)&d_t, n1));
     FS_TRY(hipMalloc((void**)&d_n, n3));
-    FS_TRY(hipMalloc((void**)&d_hit, n1));
+    FS_TRY(hipMalloc((void**)&d_hit, n1 + sizeof(int32_t)));   // (+ the cooperative traversal's overflow word)
+    FS_TRY(hipMemsetAsync(d_hit + N, 0, sizeof(int32_t), ctx->stream));
     FS_TRY(hipMalloc((void**)&d_tri, n1));
     FS_TRY(hipMemcpyAsync(d_o, origins, n3, hipMemcpyHostToDevice, ctx->stream));
     FS_TRY(hipMemcpyAsync(d_d, dirs, n3, hipMemcpyHostToDevice, ctx->stream));
@@ -105,7 +107,9 @@ int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, cons
     launch_trace_rays(ctx->scene, d_o, d_d, d_tm, N, any_hit, d_hit, d_t, d_tri, d_n, ctx->stream);
     FS_TRY(hipGetLastError());
     FS_TRY(hipMemcpyAsync(hit, d_hit, n1, hipMemcpyDeviceToHost, ctx->stream));
-    if (!any_hit) {
+    int32_t coop_overflow = 0;
+    FS_TRY(hipMemcpyAsync(&coop_overflow, d_hit + N, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (any_hit != 1) {
         FS_TRY(hipMemcpyAsync(t, d_t, n1, hipMemcpyDeviceToHost, ctx->stream));
         FS_TRY(hipMemcpyAsync(tri, d_tri, n1, hipMemcpyDeviceToHost, ctx->stream));
         FS_TRY(hipMemcpyAsync(normal, d_n, n3, hipMemcpyDeviceToHost, ctx->stream));
@@ -113,6 +117,7 @@ int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, cons
     FS_TRY(hipStreamSynchronize(ctx->stream));
 #undef FS_TRY
     cleanup();
+    if (coop_overflow) return ctx->fail(FS_ERR_OVERFLOW, "cooperative traversal: a group's node stack overflowed");
     return FS_OK;
 }
 

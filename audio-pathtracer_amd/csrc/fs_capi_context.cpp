@@ -55,6 +55,8 @@ void free_source(fs_context* ctx, Source* s) {
         if (s->ev_rev) (void)hipEventDestroy(s->ev_rev);
         if (s->d_ir_bands) (void)hipFree(s->d_ir_bands);
         if (s->d_ir_mono) (void)hipFree(s->d_ir_mono);
+        if (s->d_ir_spare_bands) (void)hipFree(s->d_ir_spare_bands);
+        if (s->d_ir_spare_mono) (void)hipFree(s->d_ir_spare_mono);
         for (int i = 0; i < kIrRing; ++i) {
             if (s->h_ir[i]) (void)hipHostFree(s->h_ir[i]);
             if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -69,6 +71,8 @@ void free_source(fs_context* ctx, Source* s) {
 
 void free_scene(fs_context* ctx) {
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+    if (ctx->d_coop) (void)hipFree(ctx->d_coop);
+    ctx->d_coop = nullptr; ctx->coop_cap = 0;
     if (ctx->d_tris) (void)hipFree(ctx->d_tris);
     if (ctx->d_tris48) (void)hipFree(ctx->d_tris48);
     if (ctx->d_tri_nrm) (void)hipFree(ctx->d_tri_nrm);
@@ -158,17 +162,22 @@ void resolve_completed_timings(fs_context* ctx) {
     if (done) ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + (long)done);
 }
 
-// advance `front` over publishes whose D2H copy has completed (producer thread only)
+// advance `front` over publishes whose D2H copy has completed.  Any thread: the producer calls it where it enqueues, a
+// consumer through fs_get_impulse_response_sequence.  `front` only ever grows (compare-exchange to the maximum): a thread
+// that looked at a slot just before the producer recycled it for a later publish can only conclude less, never more.
 void poll_published(Source* s) {
-    uint64_t f = s->front.load(std::memory_order_relaxed);
-    while (f < s->enqueued) {
+    uint64_t f = s->front.load(std::memory_order_acquire);
+    const uint64_t enq = s->enqueued.load(std::memory_order_acquire);
+    while (f < enq) {
         uint64_t next = f + 1;
         int slot = (int)(next % kIrRing);
-        if (s->seq_of[slot] != next) break;
-        if (hipEventQuery(s->ev[slot]) != hipSuccess) break;
+        if (s->seq_of[slot].load(std::memory_order_acquire) != next) break;
+        if (hipEventQuery(s->ev[slot]) != hipSuccess) { (void)hipGetLastError(); break; }   // (hipErrorNotReady is not an error)
+        if (s->seq_of[slot].load(std::memory_order_acquire) != next) break;   // recycled meanwhile: the answer was about a later publish
         f = next;
     }
-    s->front.store(f, std::memory_order_release);
+    uint64_t cur = s->front.load(std::memory_order_relaxed);
+    while (cur < f && !s->front.compare_exchange_weak(cur, f, std::memory_order_release, std::memory_order_relaxed)) {}
 }
 
 // levels = walk steps with a record in the main tier (min(depth, FS_MAX_DEPTH)); unbounded: also the second tier.
@@ -433,6 +442,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_WALK_COOP")) ctx->walk.coop = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_FUSED_RECON")) ctx->fused_recon = std::atoi(v) != 0;
     if (const char* v = std::getenv("FS_FUSED_RECON_COMM")) ctx->fused_recon_comm = std::atoi(v) != 0;
     ctx->hist_window = default_hist_window(ctx->cfg.num_bands);

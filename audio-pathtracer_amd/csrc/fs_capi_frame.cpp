@@ -88,23 +88,51 @@ struct OwedLaunch {
     std::vector<int> tmp;                                  // index into ctx->d_ir_tmp, or -1: the source's own d_ir_*
     std::vector<std::unique_lock<std::mutex>> locks;
 };
+// never overwrite the front buffer of the source's IR ring: at most kIrRing - 1 publishes in flight (publish seq reuses the
+// slot of seq - kIrRing, so publish seq - kIrRing + 1 must have completed before seq is enqueued).  `more`: publishes about
+// to be enqueued.  May block the host (the ring is the producer's only throttle) — call it without holding ir_mu.
+static int ir_ring_backpressure(fs_context* ctx, Source* s, int more) {
+    poll_published(s);
+    for (int j = 1; j <= more; ++j) {
+        if (s->enqueued + (uint64_t)j < (uint64_t)kIrRing) continue;
+        const uint64_t must = s->enqueued + (uint64_t)j + 1 - (uint64_t)kIrRing;
+        const int slot = (int)(must % kIrRing);
+        if (s->seq_of[slot] == must && s->front.load(std::memory_order_relaxed) < must) {
+            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
+            poll_published(s);
+        }
+    }
+    return FS_OK;
+}
+// a publish of the source's current IR set has been enqueued on the tail stream as number `seq`
+static void note_publish(Source* s, uint64_t seq, int slot) { s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq; }
+
 static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
     if (ctx->recon_owed.empty()) return FS_OK;
-    {   // the oldest entries that are due (frame order: a prefix); summed entries wait one launch (ReconOwed::reduced)
-        size_t take = 0;
-        while (take < ctx->recon_owed.size() && take < (size_t)kMaxReconParts &&
-               (!ctx->recon_owed[take].reduced || ctx->recon_owed[take].age >= 1)) ++take;
-        for (size_t k = take; k < ctx->recon_owed.size(); ++k) ctx->recon_owed[k].age++;
-        if (take == 0) return FS_OK;
-        ol.owed.assign(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
-        ctx->recon_owed.erase(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
-    }
+    size_t take = 0;   // the oldest entries that are due (frame order: a prefix); summed entries wait one launch (ReconOwed::reduced)
+    while (take < ctx->recon_owed.size() && take < (size_t)kMaxReconParts &&
+           (!ctx->recon_owed[take].reduced || ctx->recon_owed[take].age >= 1)) ++take;
+    for (size_t k = take; k < ctx->recon_owed.size(); ++k) ctx->recon_owed[k].age++;
+    if (take == 0) return FS_OK;
+    // (the entries leave recon_owed only when everything that can fail here has succeeded: on an error they are still owed
+    // and the next flush reconstructs them on the tail stream)
+    ol.owed.assign(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
     const int B = ctx->cfg.num_bands;
     const size_t row = (size_t)ctx->num_samples;
     std::vector<Source*> distinct;
     for (const fs_context::ReconOwed& o : ol.owed)
         if (std::find(distinct.begin(), distinct.end(), o.s) == distinct.end()) distinct.push_back(o.s);
     std::sort(distinct.begin(), distinct.end());           // one locking order for every thread
+    // the ring's back-pressure BEFORE the IR mutexes are taken: it may wait for the GPU, and fs_reverb_process on the audio
+    // thread must never queue behind such a wait
+    for (Source* s : distinct) {
+        int more = 0;
+        for (const fs_context::ReconOwed& o : ol.owed) more += o.s == s ? 1 : 0;
+        const int br = ir_ring_backpressure(ctx, s, more);
+        if (br) { ol.owed.clear(); return br; }
+    }
+    auto bail = [&](int rc) { ol.owed.clear(); ol.tmp.clear(); ol.locks.clear(); fp.num_recon = 0; return rc; };
+#define FS_OWED_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(ctx->hip_fail(e_, #call)); } while (0)
     for (Source* s : distinct) ol.locks.emplace_back(s->ir_mu);
     fp.num_recon = 0; fp.recon_B = B; fp.recon_nb = ctx->num_bins; fp.recon_samples = ctx->num_samples;
     for (size_t i = 0; i < ol.owed.size(); ++i) {
@@ -113,24 +141,39 @@ static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
         bool later = false;                                // a later frame of the same source in this launch?
         for (size_t k = i + 1; k < ol.owed.size(); ++k) later = later || ol.owed[k].s == s;
         int t = -1;
-        float* bands = s->d_ir_bands; float* mono = s->d_ir_mono;
+        float* bands = nullptr; float* mono = nullptr;
         if (later) {   // its IR is superseded within the launch: produced in, and published from, a temporary buffer
             t = (int)(ctx->ir_tmp_next++ % fs_context::kIrTmp);
             if (!ctx->d_ir_tmp[t]) {
-                FS_HIP(ctx, hipMalloc((void**)&ctx->d_ir_tmp[t], sizeof(float) * (size_t)(B + 1) * row));
-                FS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ir_tmp[t], hipEventDisableTiming));
+                FS_OWED_HIP(hipMalloc((void**)&ctx->d_ir_tmp[t], sizeof(float) * (size_t)(B + 1) * row));
+                FS_OWED_HIP(hipEventCreateWithFlags(&ctx->ev_ir_tmp[t], hipEventDisableTiming));
             }
-            if (ctx->ir_tmp_pending[t]) FS_HIP(ctx, compute_waits_for(ctx, ctx->ev_ir_tmp[t]));   // its last publish has read it
+            if (ctx->ir_tmp_pending[t]) FS_OWED_HIP(compute_waits_for(ctx, ctx->ev_ir_tmp[t]));   // its last publish has read it
             bands = ctx->d_ir_tmp[t]; mono = ctx->d_ir_tmp[t] + (size_t)B * row;
-        } else if (s->rev_recorded) {
-            FS_HIP(ctx, compute_waits_for(ctx, s->ev_rev));   // a reverb callback may be reading d_ir_mono
+        } else {
+            // The source's newest IR of the launch goes into its SPARE set (and the sets swap when the publish is enqueued):
+            // the publish of the previous frame — a D2H copy on the tail stream, enqueued a launch ago — may still be reading
+            // the current set when this launch's reconstruct workgroups start (small launches: microseconds after the
+            // previous launch ends).  What last read the spare set is two publishes back: its event has long completed.
+            if (!s->d_ir_spare_bands) {
+                FS_OWED_HIP(hipMalloc((void**)&s->d_ir_spare_bands, sizeof(float) * (size_t)B * row));
+                FS_OWED_HIP(hipMalloc((void**)&s->d_ir_spare_mono, sizeof(float) * row));
+            }
+            if (s->spare_pub_seq) {
+                const int slot = (int)(s->spare_pub_seq % kIrRing);
+                if (s->seq_of[slot] == s->spare_pub_seq) FS_OWED_HIP(compute_waits_for(ctx, s->ev[slot]));   // (a reused slot: that publish completed long ago)
+            }
+            if (s->rev_recorded) FS_OWED_HIP(compute_waits_for(ctx, s->ev_rev));   // a reverb callback may be reading either set
+            bands = s->d_ir_spare_bands; mono = s->d_ir_spare_mono;
         }
-        if (o.reduced && s->red_recorded[o.cur]) FS_HIP(ctx, compute_waits_for(ctx, s->ev_red[o.cur]));   // the sum over the ranks (done a launch ago)
+        if (o.reduced && s->red_recorded[o.cur]) FS_OWED_HIP(compute_waits_for(ctx, s->ev_red[o.cur]));   // the sum over the ranks (done a launch ago)
         ol.tmp.push_back(t);
         FrameParts::Recon& r = fp.recon[fp.num_recon++];
         r.energy = s->d_energy[o.cur]; r.ir_bands = bands; r.ir_mono = mono;
         r.spb = o.p.samples_per_bin > 0 ? o.p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);   // FSAC.cpp:324
     }
+#undef FS_OWED_HIP
+    ctx->recon_owed.erase(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
     return FS_OK;
 }
 // behind the launch: the reconstruct of buffer `cur` is done (energy buffer reuse, reverb), the tail stream waits for the
@@ -138,11 +181,12 @@ static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
 static int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
     if (ol.owed.empty()) return FS_OK;
     const int B = ctx->cfg.num_bands;
+    const size_t row = (size_t)ctx->num_samples;
     if (!launched_fused)   // no fused form for this launch: the same reconstructs as kernels of their own, on the compute stream
         for (size_t i = 0; i < ol.owed.size(); ++i) {
             const fs_context::ReconOwed& o = ol.owed[i];
-            float* bands = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] : o.s->d_ir_bands;
-            float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * (size_t)ctx->num_samples : o.s->d_ir_mono;
+            float* bands = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] : o.s->d_ir_spare_bands;
+            float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * row : o.s->d_ir_spare_mono;
             const int spb = o.p.samples_per_bin > 0 ? o.p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);
             launch_reconstruct(o.s->d_energy[o.cur], B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, bands, mono, ctx->stream);
         }
@@ -154,23 +198,19 @@ static int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
         Source* s = o.s;
         FS_HIP(ctx, hipEventRecord(s->ev_rec[o.cur], ctx->copy_stream));   // (behind the one wait above: every reconstruct of the launch is done)
         s->rec_recorded[o.cur] = true;
-        if (ol.tmp[i] < 0) s->last_rec = o.cur;
-        poll_published(s);
-        if (s->enqueued + 1 >= (uint64_t)kIrRing) {   // never overwrite the front buffer (as reconstruct_now)
-            const uint64_t must = s->enqueued + 2 - (uint64_t)kIrRing;
-            const int slot0 = (int)(must % kIrRing);
-            if (s->seq_of[slot0] == must && s->front.load(std::memory_order_relaxed) < must) {
-                FS_HIP(ctx, hipEventSynchronize(s->ev[slot0]));
-                poll_published(s);
-            }
-        }
-        const float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * (size_t)ctx->num_samples : s->d_ir_mono;
-        const uint64_t seq = s->enqueued + 1;
+        const uint64_t seq = s->enqueued + 1;   // (the ring's back-pressure was applied in owed_prepare, before the mutexes)
         const int slot = (int)(seq % kIrRing);
-        FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], mono, sizeof(float) * (size_t)ctx->num_samples, hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (ol.tmp[i] < 0) {   // the spare set holds the source's newest IR: it becomes the current one (ir_mu is held)
+            std::swap(s->d_ir_bands, s->d_ir_spare_bands);
+            std::swap(s->d_ir_mono, s->d_ir_spare_mono);
+            s->spare_pub_seq = s->cur_pub_seq;
+            s->last_rec = o.cur;
+        }
+        const float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * row : s->d_ir_mono;
+        FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], mono, sizeof(float) * row, hipMemcpyDeviceToHost, ctx->copy_stream));
         FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->copy_stream));
-        s->seq_of[slot] = seq;
-        s->enqueued = seq;
+        if (ol.tmp[i] < 0) note_publish(s, seq, slot);
+        else { s->seq_of[slot] = seq; s->enqueued = seq; }
         if (ol.tmp[i] >= 0) {
             FS_HIP(ctx, hipEventRecord(ctx->ev_ir_tmp[ol.tmp[i]], ctx->copy_stream));
             ctx->ir_tmp_pending[ol.tmp[i]] = true;
@@ -262,17 +302,7 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     int spb = p->samples_per_bin > 0 ? p->samples_per_bin
                                      : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
 
-    poll_published(s);
-    // never overwrite the front buffer: at most kIrRing - 1 publishes in flight (publish seq reuses the slot of
-    // seq - kIrRing, so publish seq - kIrRing + 1 must have completed before seq is enqueued)
-    if (s->enqueued + 1 >= (uint64_t)kIrRing) {
-        const uint64_t must = s->enqueued + 2 - (uint64_t)kIrRing;
-        const int slot = (int)(must % kIrRing);
-        if (s->seq_of[slot] == must && s->front.load(std::memory_order_relaxed) < must) {
-            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
-            poll_published(s);
-        }
-    }
+    { const int br = ir_ring_backpressure(ctx, s, 1); if (br) return br; }
     TimedFrame tf{};
     bool timed = ctx->profiling >= 2;
     if (timed) {
@@ -310,8 +340,7 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
                                hipMemcpyDeviceToHost, tail));
     FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
-    s->seq_of[slot] = seq;
-    s->enqueued = seq;
+    note_publish(s, seq, slot);
     if (timed) {
         FS_HIP(ctx, hipEventRecord(tf.e[4], tail));
         tf.has_recon = true;
@@ -319,6 +348,8 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     }
     return FS_OK;
 }
+
+int ir_ring_backpressure_for(fs_context* ctx, Source* s) { return ir_ring_backpressure(ctx, s, 1); }
 
 }  // namespace fsi
 
@@ -334,6 +365,17 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
 //   frame_commit     the rotation: frame index, the sources' current energy buffer, batch table slot (cannot fail)
 //   frame_launch     the passes (or the fused launch of pipelined frames) and the bookkeeping
 namespace {
+
+// energy buffer b of the source exists (those beyond kEnergyBufsBase are allocated when the rotation first reaches them)
+int ensure_energy_buffer(fs_context* ctx, Source* s, int b) {
+    if (s->d_energy[b]) return FS_OK;
+    const size_t eb = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    FS_HIP(ctx, hipMalloc((void**)&s->d_energy[b], eb));
+    FS_HIP(ctx, hipMemsetAsync(s->d_energy[b], 0, eb, ctx->stream));
+    if (!s->ev_rec[b]) FS_HIP(ctx, hipEventCreateWithFlags(&s->ev_rec[b], hipEventDisableTiming));
+    if (!s->ev_red[b]) FS_HIP(ctx, hipEventCreateWithFlags(&s->ev_red[b], hipEventDisableTiming));
+    return FS_OK;
+}
 
 struct Frame {
     Source* const* srcs = nullptr;
@@ -485,20 +527,43 @@ int frame_resources(fs_context* ctx, Frame& f) {
     st.overflow = ctx->d_overflow;
 
     if (count > 64) { f.next_cur_heap.resize((size_t)count); f.cur_of = f.next_cur_heap.data(); } else f.cur_of = f.next_cur;
+    // A frame owns its energy buffer from the launch that plans it to the launch that reconstructs it; the rotation must not
+    // come round to a buffer whose frame is still on its way (held: planned / walking / waiting for its connect pass;
+    // recon_owed: connected, its reconstruct rides in a later launch).  Up to two frames per launch the first
+    // kEnergyBufsBase buffers are always enough; three and four per launch rotate through all kEnergyBufs.
+    const int ring = ctx->frames_per_launch > 2 ? kEnergyBufs : kEnergyBufsBase;
+    auto owned = [&](const Source* s, int b, int upto) {
+        for (const fs_context::PipeFrame& q : ctx->held)
+            for (const fs_context::PipeFrame::Item& it : q.items) if (it.s == s && it.cur == b) return true;
+        for (const fs_context::ReconOwed& o : ctx->recon_owed) if (o.s == s && o.cur == b) return true;
+        for (int k = 0; k < upto; ++k) if (f.srcs[k] == s && f.cur_of[k] == b) return true;
+        return false;
+    };
     for (int i = 0; i < count; ++i) {
         Source* si = f.srcs[i];
-        if (f.fixed && !si->d_fixed[0]) {
-            for (int k = 0; k < kEnergyBufs; ++k) {
-                FS_HIP(ctx, hipMalloc((void**)&si->d_fixed[k], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
-                FS_HIP(ctx, hipMemsetAsync(si->d_fixed[k], 0, sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+        // this frame deposits into the next free buffer of the rotation; the tail may still be busy with it.  (FS_FLAG_ACCUMULATE_ENERGY
+        // stays in the buffer of the previous frame — behind its reduce / reconstruct — and adds to what it holds.)
+        int b = si->cur;
+        if (!f.accumulate) {
+            int from = si->cur;   // grouped frames: the same source may own several items — the buffers behind its previous item's
+            for (int k = 0; k < i; ++k) if (f.srcs[k] == si) from = f.cur_of[k];
+            b = (from + 1) % ring;
+            int tries = 0;
+            while (tries < ring && owned(si, b, i)) { b = (b + 1) % ring; ++tries; }
+            if (tries == ring) {   // every buffer belongs to a frame in flight: those finish on their own kernels first
+                FS_FLUSH(ctx);
+                b = (from + 1) % ring;
+                for (tries = 0; tries < ring && owned(si, b, i); ++tries) b = (b + 1) % ring;
+                if (tries == ring) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "more frames of one source in a launch than it has energy buffers");
             }
         }
-        // this frame deposits into the next buffer of the rotation; the tail may still be busy with it.  (FS_FLAG_ACCUMULATE_ENERGY
-        // stays in the buffer of the previous frame — behind its reduce / reconstruct — and adds to what it holds.)
-        int earlier = 0;   // grouped frames: the same source may own several items — consecutive buffers of its rotation
-        for (int k = 0; k < i; ++k) earlier += f.srcs[k] == si ? 1 : 0;
-        f.cur_of[i] = f.accumulate ? si->cur : (si->cur + 1 + earlier) % kEnergyBufs;
-        FS_HIP(ctx, wait_energy_readers(ctx, si, f.cur_of[i]));
+        { const int er = ensure_energy_buffer(ctx, si, b); if (er) return er; }
+        if (f.fixed && !si->d_fixed[b]) {
+            FS_HIP(ctx, hipMalloc((void**)&si->d_fixed[b], sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins));
+            FS_HIP(ctx, hipMemsetAsync(si->d_fixed[b], 0, sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+        }
+        f.cur_of[i] = b;
+        FS_HIP(ctx, wait_energy_readers(ctx, si, b));
     }
     if (f.batch) {
         // per-frame tables in one pinned staging block: energy pointers [count] | fixed-point buffer pointers [count] |
@@ -827,7 +892,7 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         return rc;
     };
     hipError_t e;
-    for (int i = 0; i < kEnergyBufs; ++i) {
+    for (int i = 0; i < kEnergyBufsBase; ++i) {   // (the rest of the rotation: at first use, ensure_energy_buffer)
         if ((e = hipMalloc((void**)&s->d_energy[i], eb)) != hipSuccess) return bail(e, "hipMalloc(energy)");
         if ((e = hipMemsetAsync(s->d_energy[i], 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
         if ((e = hipEventCreateWithFlags(&s->ev_rec[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -842,7 +907,7 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
     if ((e = hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    for (int i = 0; i < kEnergyBufs; ++i)
+    for (int i = 0; i < kEnergyBufsBase; ++i)
         if ((e = hipEventCreateWithFlags(&s->ev_red[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreateWithFlags(&s->ev_rev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     // the initial fills above ran on the compute stream; the first reconstruct runs on the tail stream
@@ -1051,15 +1116,7 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
     if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
     if (n != ctx->num_samples) return ctx->fail(FS_ERR_SIZE_MISMATCH, "n != num_samples");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    poll_published(s);
-    if (s->enqueued + 1 >= (uint64_t)kIrRing) {   // never overwrite the front buffer: at most kIrRing - 1 publishes in flight
-        const uint64_t must = s->enqueued + 2 - (uint64_t)kIrRing;
-        const int slot = (int)(must % kIrRing);
-        if (s->seq_of[slot] == must && s->front.load(std::memory_order_relaxed) < must) {
-            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
-            poll_published(s);
-        }
-    }
+    { const int br = fsi::ir_ring_backpressure_for(ctx, s); if (br) return br; }
     hipStream_t tail = ctx->copy_stream;   // ordered with reconstructs and publishes of this source
     const size_t bytes = sizeof(float) * (size_t)n;
     {
@@ -1077,8 +1134,7 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
     int slot = (int)(seq % kIrRing);
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, bytes, hipMemcpyDeviceToHost, tail));
     FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
-    s->seq_of[slot] = seq;
-    s->enqueued = seq;
+    s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq;
     FS_HIP(ctx, hipStreamSynchronize(tail));   // `ir` is the caller's memory
     poll_published(s);
     return FS_OK;
@@ -1112,6 +1168,15 @@ int fs_get_impulse_response(fs_context* ctx, fs_source h, int32_t channel, const
     uint64_t f = s->front.load(std::memory_order_acquire);
     *data = s->h_ir[(int)(f % kIrRing)];  // f == 0: slot 0 still holds the zero-initialised IR
     if (n) *n = ctx->num_samples;
+    return FS_OK;
+}
+
+int fs_get_impulse_response_sequence(fs_context* ctx, fs_source h, uint64_t* completed) {
+    if (!ctx || !completed) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return FS_ERR_BAD_HANDLE;  // no err string write: may be called from the audio thread
+    poll_published(s);   // also notices publishes that completed since the producer's last call
+    *completed = s->front.load(std::memory_order_acquire);
     return FS_OK;
 }
 

@@ -130,7 +130,24 @@ static int pack_scene(fs_context* ctx, size_t count, size_t cap) {
 }
 
 // what every kind of commit ends with: the kernels' view of the scene and the stats
-static void finish_commit(fs_context* ctx, size_t scene_bytes) {
+// the cooperative traversal's records, derived from the node array as it stands in the stream (behind an upload, a device
+// build's refit, a refit of moved triangles)
+static int refresh_coop_nodes(fs_context* ctx) {
+    const size_t n = ctx->bvh.nodes.size();
+    if (n == 0) return FS_OK;
+    if (n > ctx->coop_cap) {
+        if (ctx->d_coop) { FS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_coop); }
+        ctx->d_coop = nullptr; ctx->coop_cap = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_coop, sizeof(CoopChild) * 4 * n));
+        ctx->coop_cap = n;
+    }
+    launch_coop_nodes(ctx->d_nodes, (int)n, ctx->d_coop, ctx->stream);
+    FS_HIP(ctx, hipGetLastError());
+    ctx->scene.coop = ctx->d_coop;
+    return FS_OK;
+}
+
+static int finish_commit(fs_context* ctx, size_t scene_bytes) {
     ctx->amax = 0.f;
     for (float v : ctx->h_xyz) ctx->amax = std::max(ctx->amax, std::fabs(v));
     ctx->scene.nodes = ctx->d_nodes;
@@ -161,6 +178,7 @@ static void finish_commit(fs_context* ctx, size_t scene_bytes) {
         ctx->deep.rows = deep_rows;
     }
     ctx->scene.stack_worst = traversal_lds_bytes(worst, ctx->cfg.num_bands, ctx->num_bins) <= ctx->lds_limit ? worst : 0;
+    ctx->scene.stack_need = std::max(ctx->bvh.stack_need, 2);
     ctx->scene.deep = nullptr; ctx->scene.deep_lanes = 0;
     ctx->scene.deep_owner = &ctx->deep;
     ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
@@ -168,7 +186,10 @@ static void finish_commit(fs_context* ctx, size_t scene_bytes) {
     ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;
     ctx->stats.bvh_depth = (uint32_t)ctx->bvh.max_depth;
     ctx->stats.scene_bytes = scene_bytes;
+    ctx->scene.coop = nullptr; ctx->scene.lds_nodes = 0;
+    { const int cr = refresh_coop_nodes(ctx); if (cr) return cr; }
     ctx->committed = true;
+    return FS_OK;
 }
 
 int fs_scene_commit(fs_context* ctx) {
@@ -267,8 +288,7 @@ int fs_scene_commit(fs_context* ctx) {
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_node_box, sizeof(float4) * 2 * std::max<size_t>(n_nodes, 1)));
     }
     if (tb) { const int pr = pack_scene(ctx, n_tris, n_tris); if (pr) return pr; }
-    finish_commit(ctx, nb + n_tris * (sizeof(Tri48) + sizeof(float4)) + mb);
-    return FS_OK;
+    return finish_commit(ctx, nb + n_tris * (sizeof(Tri48) + sizeof(float4)) + mb);
 }
 
 // RegisterGeometry / UnregisterGeometry at run time (ARTS.h:99-100): a changed triangle set needs a new tree NOW.
@@ -346,8 +366,7 @@ int fs_scene_commit_fast(fs_context* ctx) {
     FS_HIP(ctx, hipGetLastError());
     { int mr = upload_materials(ctx); if (mr) return mr; }
     { const int pr = pack_scene(ctx, n, ctx->fast_cap_tris); if (pr) return pr; }
-    finish_commit(ctx, (size_t)info.num_nodes * sizeof(NodeQ4) + tb + ctx->h_absorption.size() * sizeof(float));
-    return FS_OK;
+    return finish_commit(ctx, (size_t)info.num_nodes * sizeof(NodeQ4) + tb + ctx->h_absorption.size() * sizeof(float));
 }
 
 // The tree of fs_scene_commit_fast now, the host's SAH tree as soon as it is built (header).
@@ -429,7 +448,7 @@ int fs_scene_refit(fs_context* ctx) {
     launch_refit(ctx->d_nodes, ctx->d_tris, ctx->d_node_box, ctx->bvh.level_begin.data(),
                  (int)ctx->bvh.level_begin.size() - 1, pad, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
-    return FS_OK;
+    return refresh_coop_nodes(ctx);
 }
 
 int fs_scene_set_objects(fs_context* ctx, const uint32_t* object_id, int32_t T) {

@@ -45,11 +45,19 @@ constexpr int kIrRing = 8;  // published IR ring: up to 7 publishes of a source 
 // state, segment records, schedules, continuation records) come in fs_context::state_sets sets, as many as the deepest
 // pipeline in use needs (3 until a staged walk is pipelined).
 constexpr int kMaxSets = 12;
-constexpr int kEnergyBufs = 2 * kMaxSets;   // (x2: grouped frames of ONE source take several buffers per launch — 4 per launch x 3 launches in flight;
-                                            //  not more: with 2 or 3 frames per launch the rotation then repeats every kBatchSlots launches, which is what lets
-                                            //  a batched frame find its table already on the device — 48 buffers: 928 -> 914 M rays/s)
+// Energy buffers of a source.  A frame OWNS its buffer from the launch that plans it (and zeroes the buffer) to the launch
+// that reconstructs it: stages + 3 launches for a staged depth = 0 frame, times the frames of the source per launch
+// (fs_set_frames_per_launch).  Up to two frames per launch rotate through the first kEnergyBufsBase (11 launches x 2 at
+// most; with 2 or 3 frames per launch the rotation then repeats every kBatchSlots launches or sooner, which is what lets a
+// batched frame find its table already on the device — 48 buffers at two per launch: 928 -> 914 M rays/s); three and four
+// per launch rotate through all kEnergyBufs (11 launches x 4), the buffers beyond the base allocated at their first use.
+// frame_resources never hands out a buffer that a frame in flight still owns, whatever the rotation says (round 3 did:
+// four staged frames per launch wrapped the 24-buffer rotation after six launches and zeroed buffers still being deposited into).
+constexpr int kEnergyBufsBase = 2 * kMaxSets;
+constexpr int kEnergyBufs = 4 * kMaxSets;
 constexpr int kScratchSets = kMaxSets;
 static_assert(kMaxSets >= kMaxWalkParts + 3, "a staged frame is in flight for stages + 2 launches and its buffer is read one more");
+static_assert(kEnergyBufs >= 4 * (kMaxWalkParts + 3), "four frames of one source per launch, each owning its buffer for stages + 3 launches");
 
 struct Source {
     bool alive = false;
@@ -81,10 +89,15 @@ struct Source {
     bool cur_fixed = false;
     float* d_ir_bands = nullptr;  // [B][samples]
     float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
+    // The spare IR set: a reconstruct that rides in a fused launch (compute stream) writes here while the tail stream may still be
+    // publishing the current set; the two swap when that reconstruct's publish is enqueued (under ir_mu).  Allocated at first use.
+    float* d_ir_spare_bands = nullptr; float* d_ir_spare_mono = nullptr;
+    uint64_t cur_pub_seq = 0;          // newest publish that reads the current set (0: none)
+    uint64_t spare_pub_seq = 0;        // newest publish that read what is now the spare set: a writer of the spare set waits for it
     float* h_ir[kIrRing] = {};  // pinned host copies of the channel view
     hipEvent_t ev[kIrRing] = {};
-    uint64_t seq_of[kIrRing] = {};
-    uint64_t enqueued = 0;             // publishes enqueued so far
+    std::atomic<uint64_t> seq_of[kIrRing] = {};   // (atomics: fs_get_impulse_response_sequence may look from another thread)
+    std::atomic<uint64_t> enqueued{0};            // publishes enqueued so far
     std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
     // reverb (row f2): history rings [2][kReverbRing], staging buffers, write head
     float* d_ring = nullptr; float* d_rev_in = nullptr; float* d_rev_cur = nullptr; float* d_rev_out = nullptr;
@@ -133,6 +146,8 @@ struct fs_context {
     int32_t T = 0, M = 0;
     bool committed = false;
     NodeQ4* d_nodes = nullptr;
+    CoopChild* d_coop = nullptr;      // the cooperative traversal's view of the nodes (fs_internal.hpp), rebuilt behind every commit and refit
+    size_t coop_cap = 0;              // nodes it has room for
     float stage_margin = 1.3f;        // KParams.stage_margin
     DeepStore deep;                   // HBM spill area of the bounded LDS traversal stacks (DeviceScene.deep)
     int stack_rows_cap = kStackRowsCap;   // FS_STACK_ROWS_CAP
@@ -260,7 +275,8 @@ struct fs_context {
     unsigned* d_overflow = nullptr;
     bool overflow_armed = false;   // an unbounded frame has been enqueued since the word was last read
     // batched frames (fs_compute_energy_response_batch_async): per-frame tables of pointers and source positions
-    static constexpr int kBatchSlots = kMaxSets;   // frames the host may run ahead of the table copies (a held frame keeps its tables)
+    static constexpr int kBatchSlots = 2 * kMaxSets;   // frames the host may run ahead of the table copies (a held frame keeps its tables); >= the
+                                                       //   launches after which the energy-buffer rotation of grouped frames repeats (24 / 2, 48 / 3, 48 / 4)
     char* d_batch = nullptr; char* h_batch = nullptr; size_t batch_cap = 0;   // kBatchSlots blocks of batch_cap bytes
     hipEvent_t ev_batch[kBatchSlots] = {};
     bool batch_pending[kBatchSlots] = {};
@@ -353,6 +369,7 @@ void join_refine_threads(fs_context* ctx);
 int flush_pending(fs_context* ctx);          // pipelined frames: let every held frame finish on its own kernels
 int check_overflow(fs_context* ctx);         // depth = 0: did a record miss both tiers?  (stream just synchronised)
 int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
+int ir_ring_backpressure_for(fs_context* ctx, Source* s);   // the IR ring's throttle before one more publish (may block; not under ir_mu)
 
 // ---- fs_capi_comm.cpp ---------------------------------------------------------------------------------------------
 struct RcclApi {

@@ -1287,6 +1287,363 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
 
 
 // ---------------------------------------------------------------------------------------------------
+// Cooperative traversal (round 4): the frames a game actually issues — the reference's 1000 pairs per source, walks without
+// a depth cap (ARTS.h:176, ARTS.cpp:294) — are a CHAIN of ~70 dependent closest-hit queries; their time is the latency of
+// one query times the length of the longest walk, and nothing else.  On sparse waves (a wave owns 1, 2 or 4 subpaths) the
+// lane-private descent with work stealing above spends ~10 us per query: every step is a 64-B node per LANE, a 4-way
+// sort, three stack pushes and a round of ballots / donation boxes / mailboxes, and the parallelism only doubles per step.
+// Here the G = 64 / R lanes of a group search ONE ray together, breadth first:
+//   * the group keeps ONE stack of pending inner nodes in LDS; a step pops up to G / 4 of them, lane j takes child j & 3 of
+//     node j >> 2 and fetches exactly that child's 16-byte record (CoopChild, fs_internal.hpp: the box as fp16, rounded
+//     outwards, + the reference) — with ONE ds_read_b128 if the node is among the first DeviceScene.lds_nodes of the
+//     breadth-first array, which every workgroup stages in its LDS, else with one global_load_dwordx4 — and tests that box;
+//   * the children that are hit and inner go back on the stack by a ballot + prefix count (no sort, no donation protocol);
+//   * a lane whose child is a hit LEAF requests that leaf's triangles right away and tests them itself in the NEXT step,
+//     in the shadow of that step's node fetch; a closer hit goes into the group's mailbox with ds_min_u64 on the
+//     (t bits << 32 | triangle id) key — the (t, id) order of the closest-hit rule — and the mailbox's t is the bound every
+//     lane prunes with from the next step on.
+// Without pruning order this visits more boxes than the sorted descent, with lanes that would idle anyway; a step is one
+// record fetch + ~50 instructions, and a query takes about as many steps as the tree has levels.  The closest hit
+// is the minimum of the key over ALL triangles the ray hits within tmax (boxes only prune, and these are supersets of the
+// quantised ones), so the result is the one of trav_shared and of the oracle's brute-force scan, bit for bit, whatever
+// the visiting order.
+// The stack cannot overflow: a step pops k nodes and pushes at most 4 k; k is the full G / 4 only while that leaves room
+// for the tree's worst-case one-node-at-a-time descent (DeviceScene.stack_need) on top, else the group descends one
+// node per step (LIFO: from a stack of n entries such a descent never holds more than n + stack_need).
+// LDS of a workgroup: [lds_nodes][4] CoopChild | per wave: kCoopCap pending-node words (divided among the R groups), R rays
+// of 8 words, R mailboxes (u64 key, leaf).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kCoopCap = 1024;
+constexpr int kCoopMaxGroups = 4;
+constexpr int kCoopWaveWords = kCoopCap + kCoopMaxGroups * 8 + kCoopMaxGroups * 4;
+constexpr size_t kCoopWaveBytes = sizeof(int) * (size_t)kCoopWaveWords;
+static_assert(kCoopCap / kCoopMaxGroups >= 3 * (kStackDepth + 8), "a group's share of the node stack must hold the worst-case descent");
+// dynamic LDS of a cooperative kernel launched with `waves` waves per workgroup and `lds_nodes` resident nodes
+inline size_t coop_lds_bytes(int waves, int lds_nodes) { return (size_t)lds_nodes * 64u + kCoopWaveBytes * (size_t)waves; }
+// the first words of the workgroup's dynamic LDS: the resident records.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void coop_stage_nodes(const DeviceScene& sc, int* s_dyn) {
+    const uint4* src = reinterpret_cast<const uint4*>(sc.coop);
+    uint4* dst = reinterpret_cast<uint4*>(s_dyn);
+    for (int i = threadIdx.x; i < 4 * sc.lds_nodes; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// LDS words other lanes of the wave write: typed address-space-3 accesses (ds_read / ds_write; a `volatile` generic pointer
+// makes the compiler emit flat loads with system scope and a full s_waitcnt vmcnt(0) behind each — which also waits for
+// every triangle record in flight), relaxed wave-scope atomics so that nothing is cached in a register across a step.
+typedef __attribute__((address_space(3))) int LdsInt;
+typedef __attribute__((address_space(3))) unsigned long long LdsU64;
+__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load((const LdsInt*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store((LdsInt*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ unsigned long long lds_ld64(const unsigned long long* p) { return __hip_atomic_load((const LdsU64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ void lds_st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store((LdsU64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ void lds_min64(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_min((LdsU64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+
+// one triangle (leaf-order index `leaf`) against the group's ray; a closer hit updates the lane's own best
+template <bool IGN>
+__device__ __forceinline__ bool coop_tri(const float4 a, const float4 b, const float4 c, const Ray& r, const float bound, const uint32_t ign,
+                                         const int leaf, unsigned long long& best_key, int& best_leaf) {
+    float t = 0.0f;
+    bool hit = tri_hit(a, b, c, r, bound, t);
+    if (IGN) hit = hit & (__float_as_uint(c.w) != ign);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | __float_as_uint(c.z);
+    const bool better = hit & (key < best_key);
+    best_key = better ? key : best_key;
+    best_leaf = better ? leaf : best_leaf;
+    return better;
+}
+
+// The records are requested by hand, like the lane-private traversal's (trav_issue: one asm statement executed by every
+// lane, the lanes that want a record selected by EXEC inside it, every destination tied in and out).  Left to the
+// compiler, the loop's loads are waited for with s_waitcnt vmcnt(0) at the top of every step (its counter bookkeeping
+// gives up at the loop's back edge) — i.e. the triangles requested at the end of a step land before the next step's
+// node records are even requested.  By hand a step is: pop -> request the records -> s_waitcnt vmcnt(1): the triangle
+// records of the previous step have landed (loads return in order and exactly the one record request is younger) -> test
+// them while the records are in flight -> s_waitcnt vmcnt(0) -> boxes -> push -> request the hit leaves' triangles.
+// tools/check_isa_hazards.py proves on the final ISA that nothing touches a register that is still in flight (it knows
+// counted waits inside a basic block).
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4u LdsV4u;
+struct CoopTris { v4f a0, b0, c0, a1, b1, c1; };
+// m: the lanes that fetch from global memory (not zero).  ONE vector memory instruction, always.
+__device__ __forceinline__ void coop_issue_node(const DeviceScene& sc, const uint32_t rec, const unsigned long long m, v4u& N) {
+    const CoopChild* np = sc.coop + rec;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[m]\n\t"
+                 "global_load_dwordx4 %[q], %[np], off\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [q] "+&v"(N), [sv] "=&s"(sv)
+                 : [np] "v"(np), [m] "s"(m)
+                 : "memory");
+}
+// m1: lanes with a hit leaf (its first triangle), m2: those whose leaf has a second one
+__device__ __forceinline__ void coop_issue_tris(const DeviceScene& sc, const int first, const unsigned long long m1, const unsigned long long m2,
+                                                CoopTris& X) {
+    const Tri48* tp = sc.tris + (uint32_t)first;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "s_cbranch_execz 2f\n\t"
+                 "global_load_dwordx4 %[a0], %[tp], off\n\t"
+                 "global_load_dwordx4 %[b0], %[tp], off offset:16\n\t"
+                 "global_load_dwordx4 %[c0], %[tp], off offset:32\n\t"
+                 "s_mov_b64 exec, %[m2]\n\t"
+                 "s_cbranch_execz 2f\n\t"
+                 "global_load_dwordx4 %[a1], %[tp], off offset:48\n\t"
+                 "global_load_dwordx4 %[b1], %[tp], off offset:64\n\t"
+                 "global_load_dwordx4 %[c1], %[tp], off offset:80\n"
+                 "2:\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [a0] "+&v"(X.a0), [b0] "+&v"(X.b0), [c0] "+&v"(X.c0), [a1] "+&v"(X.a1), [b1] "+&v"(X.b1), [c1] "+&v"(X.c1), [sv] "=&s"(sv)
+                 : [tp] "v"(tp), [m1] "s"(m1), [m2] "s"(m2)
+                 : "memory");
+}
+// the triangle records of the previous step have landed: exactly the one record request of coop_issue_node is younger
+__device__ __forceinline__ void coop_wait_tris_behind_node(CoopTris& X) {
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(X.a0), "+v"(X.b0), "+v"(X.c0), "+v"(X.a1), "+v"(X.b1), "+v"(X.c1));
+}
+__device__ __forceinline__ void coop_wait_all(v4u& N, CoopTris& X) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(N), "+v"(X.a0), "+v"(X.b0), "+v"(X.c0), "+v"(X.a1), "+v"(X.b1), "+v"(X.c1));
+}
+__device__ __forceinline__ float4 f4(const v4f v) { return make_float4(v.x, v.y, v.z, v.w); }
+typedef _Float16 h2f __attribute__((ext_vector_type(2)));
+
+// R = 1, 2 or 4 rays per wave: lane r < R owns ray r (has_ray: it has one), group r = lanes [r G, (r + 1) G) searches it.
+// Every lane of the wave must call it.  Returns (owner lanes): a hit was found, T.t / T.id / T.leaf_index describe it.
+// lds_nodes_base: the workgroup's staged records (coop_stage_nodes), wl: this wave's words behind them.
+template <bool IGN, bool COUNT>
+__device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const int R, const bool has_ray, const Ray& own, const float tmax,
+                                          const uint32_t ignore, Trav& T, const int* lds_nodes_base, int* wl, unsigned* overflow) {
+    const unsigned lane = threadIdx.x & 63u;
+    const int gshift = R == 1 ? 6 : (R == 2 ? 5 : 4);
+    const int G = 1 << gshift;
+    const int g = (int)(lane >> gshift), j = (int)(lane & (unsigned)(G - 1));
+    const int cap = kCoopCap >> (6 - gshift);
+    int* stk = wl + g * cap;
+    int* rayw = wl + kCoopCap;                                                                 // [group][8]
+    unsigned long long* keyw = reinterpret_cast<unsigned long long*>(wl + kCoopCap + kCoopMaxGroups * 8);   // [group][2]: key | (leaf, -)
+    T.nv = 0u; T.nt = 0u; T.sp = 0;
+    T.t = tmax; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
+    if (sc.num_nodes <= 0) return false;                   // empty scene (wave-uniform)
+#ifdef FS_WAVE_TIMELINE   // diagnostic build: T.cur = cycles before the loop, T.tri_i = in the triangle sections (wait + tests), T.tri_n = waiting for the records, T.sb = behind the loop
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+    T.cur = 0; T.tri_i = 0; T.tri_n = 0; T.sb = 0;
+#endif
+    if (lane < (unsigned)R) {   // the owners publish their rays, clear their mailboxes and put the root on their group's stack
+        int* rw = rayw + lane * 8;
+        lds_st(rw + 0, __float_as_int(own.ox)); lds_st(rw + 1, __float_as_int(own.oy)); lds_st(rw + 2, __float_as_int(own.oz));
+        lds_st(rw + 3, __float_as_int(own.dx)); lds_st(rw + 4, __float_as_int(own.dy)); lds_st(rw + 5, __float_as_int(own.dz));
+        lds_st(rw + 6, __float_as_int(has_ray ? tmax : -1.0f));
+        lds_st(rw + 7, (int)ignore);
+        lds_st64(keyw + 2 * lane, ((unsigned long long)__float_as_uint(tmax) << 32) | 0xFFFFFFFFull);
+        lds_st(reinterpret_cast<int*>(keyw + 2 * lane + 1), -1);
+        lds_st(wl + lane * cap, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int* rw = rayw + g * 8;
+    const Ray r = make_ray(__int_as_float(lds_ld(rw + 0)), __int_as_float(lds_ld(rw + 1)), __int_as_float(lds_ld(rw + 2)),
+                           __int_as_float(lds_ld(rw + 3)), __int_as_float(lds_ld(rw + 4)), __int_as_float(lds_ld(rw + 5)));
+    const uint32_t ign = (uint32_t)lds_ld(rw + 7);
+    int n = __int_as_float(lds_ld(rw + 6)) > 0.0f ? 1 : 0;   // pending nodes of this group (the same number in all its lanes)
+    const unsigned long long gmask = R == 1 ? ~0ull : (((1ull << G) - 1ull) << (g * G));
+    const unsigned long long below = gmask & ((1ull << lane) - 1ull);
+    const int kfull = G >> 2;
+    const int theta = cap - (sc.stack_need + 8);           // the stack may grow to here by wide steps
+    const int wide_to = theta - 3 * kfull;                 // with n <= wide_to a full step cannot pass theta
+    const int* bound_w = reinterpret_cast<const int*>(keyw + 2 * g) + 1;   // high word of the mailbox key = closest t so far
+    const bool negx = r.ix < 0.0f, negy = r.iy < 0.0f, negz = r.iz < 0.0f;
+    unsigned long long best_key = ~0ull;                   // this lane's own closest hit
+    int best_leaf = -1;
+    int pfirst = 0, pcnt = 0;                              // the leaf whose triangles this lane requested in the previous step
+    v4u N = {0u, 0u, 0u, 0u};
+    CoopTris X;
+    X.a0 = v4f{0.f, 0.f, 0.f, 0.f}; X.b0 = X.a0; X.c0 = X.a0; X.a1 = X.a0; X.b1 = X.a0; X.c1 = X.a0;
+    const int q = j >> 2, c = j & 3;
+    const int resident = sc.lds_nodes;
+#ifdef FS_WAVE_TIMELINE
+    T.cur = (int)(__builtin_amdgcn_s_memtime() - dbg_t0);
+#endif
+    while (true) {
+#ifdef FS_WAVE_TIMELINE
+        ++T.sp;                                            // diagnostic build: steps of this query (T.sp is not used here otherwise)
+#endif
+        const float bound = __int_as_float(lds_ld(bound_w));
+        // ---- pop: up to G / 4 nodes, fewer when the stack is close to the room the worst-case descent needs
+        int kw = kfull;
+        if (n > wide_to) { const int room = theta - n; kw = room >= 3 ? room / 3 : 1; }
+        const int k = n < kw ? n : kw;
+        const bool act = q < k;
+        const int ref = act ? lds_ld(stk + (n - 1 - q)) : 0;
+        const uint32_t rec = 4u * (uint32_t)ref + (uint32_t)c;
+        const bool in_lds = ref < resident;
+        // (exactly one request in every step, whatever the lanes need — the counted wait below relies on it: when every
+        // record is resident, or only triangles are left, lane 0 fetches record 0 once more)
+        const unsigned long long m_glob = __ballot(act && !in_lds);
+        coop_issue_node(sc, rec, m_glob != 0ull ? m_glob : 1ull, N);
+        v4u L = {0u, 0u, 0u, 0u};
+        if (act && in_lds) {
+            L = *reinterpret_cast<const LdsV4u*>((const LdsInt*)lds_nodes_base + 4u * rec);   // ds_read_b128
+        }
+#ifdef FS_WAVE_TIMELINE
+        const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        coop_wait_tris_behind_node(X);
+        if (COUNT) T.nv += (act && c == 0) ? 1u : 0u;
+        // ---- the triangles requested in the previous step, tested while this step's records are in flight
+        if (pcnt > 0) {
+            bool better = coop_tri<IGN>(f4(X.a0), f4(X.b0), f4(X.c0), r, bound, ign, pfirst, best_key, best_leaf);
+            if (pcnt > 1) better = coop_tri<IGN>(f4(X.a1), f4(X.b1), f4(X.c1), r, bound, ign, pfirst + 1, best_key, best_leaf) | better;
+            for (int i = 2; i < pcnt; ++i) {                // leaves of three and four triangles (FS_BVH_LEAF > 2 only)
+                const Tri48 x = sc.tris[pfirst + i];
+                better = coop_tri<IGN>(x.a, x.b, x.c, r, bound, ign, pfirst + i, best_key, best_leaf) | better;
+            }
+            if (COUNT) T.nt += (uint32_t)pcnt;
+            if (better) lds_min64(keyw + 2 * g, best_key);  // ds_min_u64: the group's closest hit so far
+            pcnt = 0;
+        }
+        // ---- this lane's child box: fp16 planes, entry / exit distances as one fma per plane
+#ifdef FS_WAVE_TIMELINE
+        const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
+        T.tri_i += (int)(dbg_t2 - dbg_t1);
+#endif
+        coop_wait_all(N, X);
+#ifdef FS_WAVE_TIMELINE
+        T.tri_n += (int)(__builtin_amdgcn_s_memtime() - dbg_t2);
+#endif
+        const v4u rc = in_lds ? L : N;
+        const uint32_t w0 = rc.x, w1 = rc.y, w2 = rc.z;   // (scalars first: __builtin_bit_cast of a vector ELEMENT reads the vector's first word for each of them)
+        const h2f lxy = __builtin_bit_cast(h2f, w0), lzhx = __builtin_bit_cast(h2f, w1), hyz = __builtin_bit_cast(h2f, w2);
+        const float lox = (float)lxy.x, loy = (float)lxy.y, loz = (float)lzhx.x, hix = (float)lzhx.y, hiy = (float)hyz.x, hiz = (float)hyz.y;
+        const float tnx = fmaf(negx ? hix : lox, r.ix, r.nox), tfx = fmaf(negx ? lox : hix, r.ix, r.nox);
+        const float tny = fmaf(negy ? hiy : loy, r.iy, r.noy), tfy = fmaf(negy ? loy : hiy, r.iy, r.noy);
+        const float tnz = fmaf(negz ? hiz : loz, r.iz, r.noz), tfz = fmaf(negz ? loz : hiz, r.iz, r.noz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bound));
+        const bool h = act & (tn <= tf);
+        const int cref = (int)rc.w;
+        const bool inner = h & (cref >= 0), leaf = h & (cref < 0);
+        // ---- the hit inner children go back on the stack, in lane order
+        const unsigned long long m_in = __ballot(inner) & gmask;
+        const int pos = (n - k) + (int)__popcll(m_in & below);
+        if (inner) {
+            if (pos < cap) lds_st(stk + pos, cref);
+            else *overflow = 1u;                            // (cannot happen while DeviceScene.stack_need is the tree's; the frame would be traced again)
+        }
+        n = n - k + (int)__popcll(m_in);
+        n = n < cap ? n : cap;
+        // ---- a hit leaf: request its triangles now, test them in the next step
+        if (leaf) {
+            const int code = ~cref;
+            pfirst = code >> 2;
+            pcnt = (code & 3) + 1;
+        }
+        const unsigned long long m_leaf = __ballot(leaf);
+        if (m_leaf != 0ull) coop_issue_tris(sc, leaf ? pfirst : 0, m_leaf, __ballot(leaf && pcnt > 1), X);
+        if (__ballot(n > 0 || pcnt > 0) == 0ull) break;
+    }
+    coop_wait_all(N, X);                                    // (nothing is in flight here; the compiler must know the registers are free)
+#ifdef FS_WAVE_TIMELINE
+    const unsigned long long dbg_t3 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- the mailbox holds the closest hit of the group's ray; the lane that found it says which triangle it was
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long fin = lds_ld64(keyw + 2 * g);
+    if (best_leaf >= 0 && best_key == fin) lds_st(reinterpret_cast<int*>(keyw + 2 * g + 1), best_leaf);
+    __builtin_amdgcn_wave_barrier();
+    bool found = false;
+    if (lane < (unsigned)R) {
+        const unsigned long long key = lds_ld64(keyw + 2 * lane);
+        if ((uint32_t)key != 0xFFFFFFFFu) {
+            T.t = __uint_as_float((uint32_t)(key >> 32));
+            T.id = (uint32_t)key;
+            T.leaf_index = lds_ld(reinterpret_cast<const int*>(keyw + 2 * lane + 1));
+            found = true;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                        // (the next query's owners rewrite the rays and mailboxes)
+#ifdef FS_WAVE_TIMELINE
+    T.sb = (int)(__builtin_amdgcn_s_memtime() - dbg_t3);
+#endif
+    return found;
+}
+
+// The walk on cooperative waves: a wave owns R = 1, 2 or 4 subpaths (its first lanes), every query is searched by the
+// whole group of 64 / R lanes (trav_coop).  Same walker, records, stages and schedule as walk_sparse_body; the workgroup
+// has blockDim.x / 64 waves (4 or 16: the more waves share the staged records, the more of them fit).
+template <int LOBES, bool COUNT, bool EXT = false>
+__device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
+                                               const SubpathState& st, const unsigned* __restrict__ scratch,
+                                               const uint32_t* __restrict__ perm, const int rays_per_wave,
+                                               const WalkStage sr = WalkStage()) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [lds_nodes][16] records | [waves][kCoopWaveWords]
+    __shared__ unsigned s_cnt[kPlanBuckets];
+    if (perm) {
+        for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += blockDim.x) s_cnt[i] = scratch[1 + i];
+    }
+    coop_stage_nodes(sc, s_dyn);                            // (with the barrier the bucket counts need)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
+    int* wl = s_dyn + 16 * (size_t)sc.lds_nodes + (size_t)(threadIdx.x >> 6) * kCoopWaveWords;
+    bool alive = lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
+    Walker w;
+    walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
+                 slot, kp, st, alive && sr.begin == 0);
+    if (alive && sr.begin > 0) alive = walker_resume(w, st, sr.begin);
+    Ray ray = make_ray(0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
+    uint32_t cnt_nv = 0u, cnt_nt = 0u;
+#ifdef FS_WAVE_TIMELINE
+    const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tl_trav = 0, tl_seg = 0, tl_next = 0, tl_steps = 0, tl_pro = 0, tl_tri = 0, tl_nodewait = 0, tl_epi = 0;
+#endif
+    while (true) {
+        bool go = false;
+#ifdef FS_WAVE_TIMELINE
+        const unsigned long long tl_n = __builtin_amdgcn_s_memtime();
+#endif
+        if (alive) {
+            if (w.k >= sr.end) { walker_suspend(w, st); alive = false; }   // staged walk: the next stage goes on from here
+            else {
+                go = walker_next_ray<LOBES>(w, kp, sc, st, ray);
+                if (!go) {
+                    walker_finish<EXT>(w, st);
+                    if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
+                    alive = false;
+                }
+            }
+        }
+        if (__ballot(go) == 0ull) break;
+        Trav T;
+#ifdef FS_WAVE_TIMELINE
+        const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
+        tl_next += tl_a - tl_n;
+#endif
+        trav_coop<false, COUNT>(sc, rays_per_wave, go, ray, kp.max_trace_dist, 0xFFFFFFFFu, T, s_dyn, wl, st.overflow);
+#ifdef FS_WAVE_TIMELINE
+        tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
+        tl_steps += (unsigned long long)T.sp;
+        tl_pro += (unsigned long long)T.cur; tl_tri += (unsigned long long)T.tri_i; tl_nodewait += (unsigned long long)T.tri_n; tl_epi += (unsigned long long)T.sb;
+        ++tl_seg;
+#endif
+        if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
+        if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
+    }
+    if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
+#ifdef FS_WAVE_TIMELINE
+    if (lane == 0u && g_wave_buf) {   // [0] start, [1] end (100 MHz) | cycles: [2] in queries, [3] in all, [6] in the loop head | [4] traversal steps, [5] queries
+        unsigned long long* o = g_wave_buf + 8ull * wave;
+        o[0] = tl_r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tl_trav;
+        o[3] = __builtin_amdgcn_s_memtime() - tl_c0; o[4] = tl_steps; o[5] = tl_seg; o[6] = tl_next;
+        o[7] = (tl_pro & 0xFFFFull) | ((tl_tri / 16) & 0xFFFFull) << 16 | ((tl_nodewait / 16) & 0xFFFFull) << 32 | ((tl_epi / 16) & 0xFFFFull) << 48;   // (/16, 16 bits each)
+        o[7] = (tl_pro / 16 & 0xFFFFull) | (o[7] & ~0xFFFFull);
+    }
+#endif
+}
+
+
+
+// ---------------------------------------------------------------------------------------------------
 // connect_kernel: ConnectSubpaths + EvaluatePath + clamp/gain + deposit
 // ---------------------------------------------------------------------------------------------------
 // pairs_per_wave < 64: sparse waves for small frames — a wave owns that many pairs (its first lanes), the other
@@ -1596,6 +1953,27 @@ inline bool attach_deep(DeviceScene& sc, uint32_t blocks) {
     return true;
 }
 constexpr int kMaxDevices = 64;
+// LDS one workgroup may have on the current device (MI355X: all 160 KB of its CU)
+inline size_t device_lds_per_block() {
+    static std::atomic<int> cached[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+        cached[dev].store(v, std::memory_order_relaxed);
+    }
+    return (size_t)v;
+}
+// How many nodes of the breadth-first array a cooperative kernel stages in every workgroup's LDS: all of the tree if it
+// fits, else its top.  A launch whose workgroups all fit the chip at once (one per CU) may take the CU's whole LDS; one
+// that comes in rounds leaves room for a second workgroup per CU.
+inline int coop_resident_nodes(const DeviceScene& sc, int waves_per_block, uint32_t blocks, int num_cus) {
+    const size_t cu_lds = 160 * 1024, per_block = std::min(device_lds_per_block(), blocks <= (uint32_t)std::max(num_cus, 1) ? cu_lds : cu_lds / 2);
+    const size_t fixed = kCoopWaveBytes * (size_t)waves_per_block + 1024;   // + the kernels' small static arrays
+    if (per_block <= fixed || !sc.coop) return 0;
+    return (int)std::min<size_t>((size_t)std::max(sc.num_nodes, 0), (per_block - fixed) / 64);
+}
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
     static std::atomic<size_t> allowed[kMaxDevices];   // per kernel instantiation; 0 = the default limit

@@ -53,6 +53,19 @@ struct alignas(16) Tri48 {
 };
 static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 B");
 
+// What the cooperative traversal of small frames reads (fs_device.hpp: trav_coop): one 16-byte record per CHILD — a lane
+// tests one child box per step and fetches exactly its own record, with one ds_read_b128 (the first DeviceScene.lds_nodes
+// nodes of the breadth-first array are staged in LDS by every workgroup) or one global_load_dwordx4 — derived from the
+// NodeQ4 array after every commit and refit (fs_refit.hip: coop_nodes_kernel):
+//   lo.x lo.y | lo.z hi.x | hi.y hi.z   the child's box as fp16, rounded outwards (conservative; an empty slot is the
+//                                       inverted box +inf / -inf), ref = NodeQ4.child[c]
+// Record 4 * node + child; 64 B per node like NodeQ4.
+struct alignas(16) CoopChild {
+    uint32_t lo_xy, loz_hix, hi_yz;
+    int32_t ref;
+};
+static_assert(sizeof(CoopChild) == 16, "CoopChild must be 16 B");
+
 // Per-lane traversal stack in LDS: DeviceScene.stack_rows rows of kBlock ints, sized at run time from the committed
 // tree (its worst-case need + kStackSlack), passed as dynamic shared memory.  A node visit that pushes writes its
 // three candidate entries at sp .. sp + hits - 2 — never above the new top — so the worst-case need itself would do;
@@ -93,6 +106,10 @@ struct DeviceScene {
                               //   lane to trav_maintain at the top of a step (fs_device.hpp)
     int32_t stack_worst;      // rows of a stack that cannot overflow (worst case + 1) if a workgroup may have that much LDS, else
                               //   0: what the wide flavour of the frame kernel runs with (fs_frame.hip)
+    const CoopChild* coop;    // [4 * num_nodes] the cooperative traversal's records (above)
+    int32_t lds_nodes;        // nodes [0, lds_nodes) are resident in the workgroup's LDS (set by the launcher of a cooperative kernel: what fits)
+    int32_t stack_need;       // the tree's worst-case number of pending entries of a one-node-at-a-time descent (HostBVH.stack_need):
+                              //   what the cooperative traversal keeps free in a group's node stack before it widens (trav_coop)
     int32_t* deep;
     uint32_t deep_lanes;
     struct DeepStore* deep_owner;   // host bookkeeping (grows the store when a launch has more lanes); unused on the device
@@ -223,7 +240,11 @@ struct WalkLaunch {
     int plan;            // 1 = sort subpaths by their (RNG-determined) length before walking
     uint32_t* perm;      // [depth + 1][total] subpath indices bucketed by planned length
     int rays_per_wave = 64;   // < 64: sparse waves for small frames (variant 2): a wave owns this many subpaths, the other lanes help
+    int coop = 1;             // 1: waves of 1, 2 or 4 subpaths search every ray with ALL the lanes of its group (walk_kernel_coop) instead of
+                              //    lane-private descents that hand subtrees to idle lanes; 0: the sparse kernel for every rays_per_wave < 64
 };
+// subpaths per wave the cooperative walk exists for (groups of 64, 32, 16 lanes)
+inline bool coop_rays_per_wave(int r) { return r == 1 || r == 2 || r == 4; }
 constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
 // frame scratch allocation: kScratchWords rearmed every frame, then (8-byte aligned) kNumCounters u64 work
 // counters that accumulate until fs_reset_stats: walk segments, connections tested, deposits
@@ -313,6 +334,7 @@ void launch_update_triangles(Tri64* tris, Tri48* packed, float4* nrm, const uint
 void launch_pack_triangles(const Tri64* tris, int count, Tri48* packed, float4* nrm, hipStream_t s);
 void launch_refit(NodeQ4* nodes, const Tri64* tris, float4* node_box, const int32_t* level_begin, int levels, float pad,
                   hipStream_t s);
+void launch_coop_nodes(const NodeQ4* nodes, int n, CoopChild* out, hipStream_t s);   // the cooperative traversal's records from the current nodes
 // fs_build.hip: the acceleration structure built on the device (Morton codes, radix sort, Karras' binary radix tree,
 // breadth-first collapse to 4-wide nodes); launch_refit then derives the quantised boxes.  DeviceBuildInfo is what the
 // host reads back: levels < 0 = the tree is deeper than kMaxBuildLevels or ran out of node space (use the host build).

@@ -134,7 +134,62 @@ __global__ __launch_bounds__(kRefitBlock) void refit_level_kernel(NodeQ4* __rest
     nodes[i] = q;
 }
 
+// ---- the cooperative traversal's view of the nodes (fs_internal.hpp: CoopChild) --------------------------------
+// fp16 next below / next above by bit pattern (0x7C00 = +inf, 0xFC00 = -inf)
+__device__ __forceinline__ uint16_t h_dec(uint16_t b) {   // toward -inf
+    if ((b & 0x7FFFu) == 0u) return 0x8001u;
+    return (b & 0x8000u) ? (uint16_t)(b + 1u) : (uint16_t)(b - 1u);
+}
+__device__ __forceinline__ uint16_t h_inc(uint16_t b) {   // toward +inf
+    if ((b & 0x7FFFu) == 0u) return 0x0001u;
+    return (b & 0x8000u) ? (uint16_t)(b - 1u) : (uint16_t)(b + 1u);
+}
+__device__ __forceinline__ float h_val(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+// an fp16 strictly below x (two steps below the nearest one at most: the box only has to be conservative)
+__device__ __forceinline__ uint16_t h_below(float x) {
+    if (!(x == x)) return 0xFC00u;
+    uint16_t b = __builtin_bit_cast(uint16_t, (_Float16)x);
+    if (b == 0xFC00u) return b;
+    if (h_val(b) > x) b = h_dec(b);
+    return b == 0xFC00u ? b : h_dec(b);
+}
+__device__ __forceinline__ uint16_t h_above(float x) {
+    if (!(x == x)) return 0x7C00u;
+    uint16_t b = __builtin_bit_cast(uint16_t, (_Float16)x);
+    if (b == 0x7C00u) return b;
+    if (h_val(b) < x) b = h_inc(b);
+    return b == 0x7C00u ? b : h_inc(b);
+}
+// one thread per (node, child): the child's box off the node's 8-bit grid, rounded outwards to fp16, + its reference.
+// An empty slot (lo = 255 > hi = 0) becomes the inverted box (+inf, -inf), which no ray enters.
+__global__ __launch_bounds__(kRefitBlock) void coop_nodes_kernel(const NodeQ4* __restrict__ nodes, int n, CoopChild* __restrict__ out) {
+    const int i = blockIdx.x * kRefitBlock + threadIdx.x;
+    if (i >= 4 * n) return;
+    const NodeQ4 q = nodes[i >> 2];
+    const int c = i & 3, sh = 8 * c;
+    const uint32_t ql[3] = {(q.lox >> sh) & 0xFFu, (q.loy >> sh) & 0xFFu, (q.loz >> sh) & 0xFFu};
+    const uint32_t qh[3] = {(q.hix >> sh) & 0xFFu, (q.hiy >> sh) & 0xFFu, (q.hiz >> sh) & 0xFFu};
+    const float o[3] = {q.ox, q.oy, q.oz}, st[3] = {q.sx, q.sy, q.sz};
+    uint16_t lo[3], hi[3];
+    const bool used = ql[0] <= qh[0] && ql[1] <= qh[1] && ql[2] <= qh[2];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = used ? h_below(fmaf((float)ql[k], st[k], o[k])) : (uint16_t)0x7C00u;
+        hi[k] = used ? h_above(fmaf((float)qh[k], st[k], o[k])) : (uint16_t)0xFC00u;
+    }
+    CoopChild r;
+    r.lo_xy = (uint32_t)lo[0] | ((uint32_t)lo[1] << 16);
+    r.loz_hix = (uint32_t)lo[2] | ((uint32_t)hi[0] << 16);
+    r.hi_yz = (uint32_t)hi[1] | ((uint32_t)hi[2] << 16);
+    r.ref = used ? q.child[c] : 0;
+    out[i] = r;
+}
+
 }  // namespace
+
+void launch_coop_nodes(const NodeQ4* nodes, int n, CoopChild* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(coop_nodes_kernel, dim3((unsigned)((4 * n + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, s, nodes, n, out);
+}
 
 void launch_update_triangles(Tri64* tris, Tri48* packed, float4* nrm, const uint32_t* leaf_pos, int first, int count,
                              const float* xyz, hipStream_t s) {

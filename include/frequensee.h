@@ -358,6 +358,13 @@ int fs_synchronize(fs_context* ctx);
  * until the second-next publish; lock-free for the audio thread (RVB.cpp:136). */
 int fs_get_impulse_response(fs_context* ctx, fs_source src, int32_t channel, const float** data, int32_t* n);
 int fs_copy_impulse_response(fs_context* ctx, fs_source src, int32_t channel, float* out, int32_t n);
+/* Number of IRs of this source published so far (0: the zero-initialised buffer of FSAC.cpp:24-28 is in front): the k-th
+ * reconstruct / fs_set_impulse_response of a source is publish k, and fs_get_impulse_response returns publish
+ * `*completed` or a newer one.  Any thread, no lock; it also notices publishes that completed since the producer's last
+ * call into the library (one event query per publish in flight), which fs_get_impulse_response alone does not.  A consumer that reads it before and after
+ * copying the buffer knows that the copy is whole (the pointer stays valid for 7 publishes), and the reverb callback can
+ * keep the IR's spectrum while the number stands still instead of transforming the IR every callback (RVB.cpp:188). */
+int fs_get_impulse_response_sequence(fs_context* ctx, fs_source src, uint64_t* completed);
 int fs_copy_band_impulse_response(fs_context* ctx, fs_source src, int32_t band, float* out, int32_t n);
 /* GetImpulseResponse() returns a MUTABLE reference in the reference (FSAC.h:113): consumers may install an IR of their
  * own (the authors' convolver checks used synthetic and downloaded IRs: GenerateDummyImpulseResponse FSAC.cpp:408-452,
@@ -409,7 +416,10 @@ int fs_get_occlusion_attenuation(fs_context* ctx, fs_source src, float* out);
 /* ---- engine line trace the BVH kernel replaces (UWorld::LineTraceSingleByObjectType; call sites
  *      ARTS.cpp:252-254 any-hit, :340-342 closest-hit). Batch query, host arrays. ------------------- */
 /* origins/dirs: [N][3] (dirs unit), tmax: [N]; out: hit[N] (0/1), t[N], tri[N] (input triangle index or -1),
- * normal[N][3] (unit, facing the ray origin side). any_hit != 0: only hit[] is written. */
+ * normal[N][3] (unit, facing the ray origin side). any_hit == 1: only hit[] is written; any_hit == 2 .. 8: the closest
+ * hit again, found by the cooperative traversal the small frames' walks use (2, 3, 4: 1, 2, 4 rays per wave — a group of
+ * 64, 32, 16 lanes searches each ray — with every node record fetched from memory; 5, 6, 7: the same with the top of the
+ * tree resident in LDS; 8: four rays per wave, as much of the tree resident as fits) — same answers, for tests and tools. */
 int fs_trace_rays(fs_context* ctx, const float* origins, const float* dirs, const float* tmax, int32_t N,
                   int32_t any_hit, int32_t* hit, float* t, int32_t* tri, float* normal);
 

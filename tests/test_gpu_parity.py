@@ -148,6 +148,11 @@ def test_line_trace_fuzz_soups(pkg, oracle_mod, kind, build):
     any_hit, *_ = ctx.trace_rays(o, d, tm, any_hit=True)
     for i in range(n):
         assert bool(any_hit[i]) == osc.trace_any(o[i], d[i], float(tm[i]), brute=True), (kind, i)
+    # the cooperative traversal of small frames (round 4; its boxes are the quantised ones rounded outwards to fp16 —
+    # infinite beyond the fp16 range): 1 ray per wave from memory, 4 per wave with the tree's top / all that fits in LDS
+    for mode in (2, 7, 8):
+        got = ctx.trace_rays(o, d, 1e7, any_hit=mode)
+        assert all(np.array_equal(a, b) for a, b in zip(got, (hit, t, idx, nrm))), (kind, mode)
     st = ctx.stats()
     assert st["bvh_stack_need"] <= 64 and st["triangles"] == T
     ctx.close()

@@ -546,3 +546,57 @@ def test_batched_sources_with_the_connect_part_first(pkg, scene_factory):
     assert len({e.tobytes() for e in out["one by one"]}) == 8          # eight different sources
     for a, b in zip(out["one by one"], out["batched"]):
         assert np.array_equal(a, b)
+
+
+# ---- round 4: ADVICE r3 -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("per_launch,bounds", [(4, None), (3, [6, 12, 20, 30, 44, 64, 96]), (2, [6, 12, 20, 30, 44, 64, 96])],
+                         ids=["four_default_stages", "three_with_eight_stages", "two_with_eight_stages"])
+def test_long_streams_of_staged_frames_never_share_an_energy_buffer(pkg, scene_factory, per_launch, bounds):
+    """a staged depth = 0 frame owns its energy buffer from the launch that plans it to the launch that
+    reconstructs it — stages + 3 launches.  Four such frames of ONE source per launch wrapped round 3's 24-buffer rotation
+    after six launches: the plan part of a launch zeroed buffers its connect part was depositing an older frame into, and
+    the next launch reconstructed the mix.  The tests of round 3 streamed at most 11 grouped frames.  Here 56 frames of one
+    source stream through; every IR the stream publishes is picked up by its publish number and must be the IR of that frame
+    from a context that traces one frame at a time — bit for bit (deterministic mode); at least every other launch must be seen
+    (the collision hit all frames of a launch)."""
+    sc = scene_factory("starter_room", 4)
+    N = 56
+    params = [pkg.default_params(num_rays=8192, depth=0, seed=7000 + i, flags=DET) for i in range(N)]
+    ref, rs = make_ctx(pkg, sc)
+    want_ir, want_e = [], []
+    for p in params:
+        ref.compute_energy_response_async(rs, p)
+        ref.reconstruct_impulse_response_async(rs, p)
+        ref.synchronize()
+        want_ir.append(ref.impulse_response(rs, 0).copy())
+        want_e.append(ref.energy_buffer(rs).copy())
+    ref.close()
+    assert len({a.tobytes() for a in want_ir}) == N      # every frame has an IR of its own
+    ctx, s = make_ctx(pkg, sc)
+    ctx.set_pipelining(2)
+    ctx.set_frames_per_launch(per_launch)
+    if bounds is not None:
+        ctx.set_walk_stages(bounds)
+    seen = {}
+
+    def pick_up():
+        k0 = ctx.impulse_response_sequence(s)
+        if k0 == 0 or k0 in seen:
+            return
+        a = ctx.impulse_response_view(s, 0).copy()
+        k1 = ctx.impulse_response_sequence(s)
+        if k1 == k0:                                       # nothing was published meanwhile: the copy is publish k0
+            seen[k0] = a
+
+    for p in params:
+        ctx.compute_energy_response_async(s, p)
+        ctx.reconstruct_impulse_response_async(s, p)
+        pick_up()
+    ctx.synchronize()
+    pick_up()
+    assert ctx.impulse_response_sequence(s) == N
+    assert np.array_equal(ctx.energy_buffer(s), want_e[-1])
+    assert len(seen) >= N // (2 * per_launch), sorted(seen)   # (a launch's IRs complete together: one of them is in front when the producer looks)
+    bad = [k for k, a in sorted(seen.items()) if not np.array_equal(a, want_ir[k - 1])]
+    assert not bad, f"published IRs {bad} are not those of their frames (seen: {sorted(seen)})"
+    ctx.close()

@@ -1,0 +1,87 @@
+"""Round 4: the cooperative traversal of small frames (a whole group of lanes searches one ray), the reference's tick,
+staged walks of frames that are waited for, observed work counters, the walker's own actor."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import IR_TOL, TIGHT_TOL, check_energy, make_ctx, rel_rms  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+DET = 8   # FS_FLAG_DETERMINISTIC
+
+
+# ---- cooperative traversal ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("build", ["host_sah", "device_morton"])
+@pytest.mark.parametrize("name", ["shoebox", "starter_room", "old_mine"])
+def test_cooperative_line_trace_matches_brute_force(pkg, oracle_mod, scene_factory, name, build):
+    """trav_coop — the G = 64 / R lanes of a group search one ray breadth first — must return the closest hit of the
+    oracle's BRUTE-FORCE scan (t bit for bit, the triangle, the normal) for R = 1, 2, 4 rays per wave, on both builders'
+    trees, and exactly what the lane-private traversal returns."""
+    sc = scene_factory(name)
+    ctx, _ = make_ctx(pkg, sc, fast=build == "device_morton")
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    rng = np.random.default_rng(11)
+    n = 1500 if name != "old_mine" else 500
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    o = np.where(rng.random((n, 1)) < 0.5, sc.source + rng.normal(0, 60, (n, 3)), rng.uniform(lo, hi, (n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tm = np.where(rng.random(n) < 0.3, rng.uniform(50, 900, n), 1e6).astype(np.float32)    # short segments too
+    ref = ctx.trace_rays(o, d, tm)
+    for i in range(0, n, 7):     # the brute-force scan is slow: a sample
+        h, t, tri, _nrm = osc.trace_closest(o[i], d[i], float(tm[i]), brute=True)
+        assert bool(ref[0][i]) == bool(h)
+        if h:
+            assert ref[1][i] == np.float32(t) and ref[2][i] == tri
+    for mode in (2, 3, 4, 5, 6, 7, 8):   # 1 / 2 / 4 rays per wave; records from memory, the top of the tree in LDS, all that fits in LDS
+        got = ctx.trace_rays(o, d, tm, any_hit=mode)
+        assert np.array_equal(got[0], ref[0]), mode
+        assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), mode
+    assert ref[0].sum() > n // 3
+    ctx.close()
+
+
+@pytest.mark.parametrize("leaf", ["1", "4"])
+def test_cooperative_line_trace_with_other_leaf_sizes(pkg, scene_factory, monkeypatch, leaf):
+    """leaves of one triangle, and of up to four (FS_BVH_LEAF): a lane requests the first two triangles of its hit leaf
+    when it finds it and fetches the others when it tests them"""
+    monkeypatch.setenv("FS_BVH_LEAF", leaf)
+    sc = scene_factory("starter_room")
+    ctx, _ = make_ctx(pkg, sc)
+    rng = np.random.default_rng(5)
+    n = 1200
+    o = (sc.source + rng.normal(0, 80, (n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ref = ctx.trace_rays(o, d, 1e6)
+    for mode in (2, 3, 4, 6, 8):
+        got = ctx.trace_rays(o, d, 1e6, any_hit=mode)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), mode
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,bands,rays,depth", [("shoebox", 1, 1024, 4), ("starter_room", 4, 2000, 0), ("starter_room", 4, 6000, 8),
+                                                   ("old_mine", 8, 2000, 0), ("old_mine", 8, 4096, 12)])
+@pytest.mark.parametrize("rpw", [1, 2, 4])
+def test_cooperative_walk_equals_the_sparse_walk_and_the_oracle(pkg, oracle_mod, scene_factory, monkeypatch, name, bands, rays, depth, rpw):
+    """walk_kernel_coop (FS_WALK_COOP, default on for 1 / 2 / 4 subpaths per wave) against the sparse-wave kernel it
+    replaces there: the same energies bit for bit in deterministic mode, the same work counters; and against the oracle."""
+    sc = scene_factory(name, bands)
+    out = {}
+    for coop in ("0", "1"):
+        monkeypatch.setenv("FS_WALK_COOP", coop)
+        monkeypatch.setenv("FS_WALK_RAYS_PER_WAVE", str(rpw))
+        ctx, s = make_ctx(pkg, sc)
+        e = ctx.compute_energy_response(s, pkg.default_params(num_rays=rays, depth=depth, seed=321, flags=DET))
+        st = ctx.stats()
+        e2 = ctx.compute_energy_response(s, pkg.default_params(num_rays=rays, depth=depth, seed=321))
+        out[coop] = (e.copy(), [st[k] for k in ("segments", "connections_tested", "deposits")], e2.copy())
+        ctx.close()
+    assert out["0"][0].any()
+    assert np.array_equal(out["0"][0], out["1"][0]) and out["0"][1] == out["1"][1]
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=321), sc.source, sc.listener)
+    check_energy(out["1"][2], e32, e64, bands)
+    assert out["1"][1][2] == cnt.connected
+

@@ -14,6 +14,11 @@ Rules: a register range becomes IN FLIGHT at an asm `global_load_*` (between ;;#
 `s_waitcnt vmcnt(0)` (ours or the compiler's) lands everything; a later asm load to the same registers is allowed
 (loads return in order); any other instruction that names an in-flight register is a hazard.  The in-flight set is
 propagated over the CFG (union over predecessors, to a fixed point).
+Counted waits (round 4, the cooperative traversal): vector memory operations complete in issue order, so
+`s_waitcnt vmcnt(N)` lands everything but the N youngest.  The checker keeps the ORDER of the vector memory instructions
+of the current basic block (asm or not: loads, stores, atomics all count); a counted wait that has at least N of them
+behind it in its own block keeps only the destinations of those N youngest in flight — everything older, including
+whatever was in flight at the block's entry, has landed.  With fewer than N in the block nothing is concluded.
 """
 from __future__ import annotations
 
@@ -25,6 +30,8 @@ REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LABEL = re.compile(r"^(\.LBB\d+_\d+):")
 FUNC = re.compile(r"^(_Z\w+):")
 BRANCH = re.compile(r"^\s+s_(cbranch_\w+|branch)\s+(\.LBB\d+_\d+)")
+VMCNT = re.compile(r"vmcnt\((\d+)\)")
+VMEM = re.compile(r"^(global|buffer|scratch)_(load|store|atomic)")
 
 
 def regs_of(text: str) -> set[int]:
@@ -80,9 +87,20 @@ def check_function(name: str, lines: list[str]) -> list[str]:
 
     def transfer(bi: int, inflight: frozenset, report: list | None):
         cur = set(inflight)
+        recent: list[set[int]] = []     # vector memory instructions of this block so far, in issue order: the asm loads' destinations
+        ordered = True                  # False behind a flat_* operation (those complete out of order)
         for no, ins, asm in blocks[bi]["ins"]:
             if ins.startswith("s_waitcnt") and "vmcnt(0)" in ins:
                 cur.clear()
+                recent.clear()
+                ordered = True
+                continue
+            mw = VMCNT.search(ins) if ins.startswith("s_waitcnt") else None
+            if mw:
+                n = int(mw.group(1))
+                if ordered and 0 < n <= len(recent):
+                    cur = set().union(*recent[-n:])
+                    recent = recent[-n:]
                 continue
             touched = regs_of(ins)
             if asm and ins.startswith("global_load"):
@@ -92,7 +110,12 @@ def check_function(name: str, lines: list[str]) -> list[str]:
                 if bad and report is not None:
                     report.append(f"{name}: line {no}: address of `{ins}` uses in-flight v{sorted(bad)}")
                 cur |= dst
+                recent.append(set(dst))
                 continue
+            if VMEM.match(ins):
+                recent.append(set())
+            elif ins.startswith("flat_"):
+                ordered = False
             bad = touched & cur
             if bad and report is not None:
                 report.append(f"{name}: line {no}: `{ins}` touches in-flight v{sorted(bad)}")
