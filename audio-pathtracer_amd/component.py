@@ -209,6 +209,11 @@ class Context:
         arr = (C.c_int32 * len(sources))(*[int(x) for x in sources])
         self.check(self.lib.fs_compute_energy_response_batch_async(self.h, arr, len(sources), C.byref(params)))
 
+    def reconstruct_impulse_response_batch_async(self, sources, params=None):
+        """the tick's reconstructs as one launch with one completion event (same result per source as separate calls)"""
+        arr = (C.c_int32 * len(sources))(*[int(x) for x in sources])
+        self.check(self.lib.fs_reconstruct_impulse_response_batch_async(self.h, arr, len(sources), C.byref(params) if params else None))
+
     def reconstruct_impulse_response(self, src, params=None):
         self.check(self.lib.fs_reconstruct_impulse_response(self.h, src, C.byref(params) if params else None))
 
@@ -542,8 +547,7 @@ class AudioRayTracingSubsystem:
             return
         self._commit()
         self.ctx.compute_energy_response_batch_async([s._src for s in srcs], self.params)
-        for s in srcs:
-            self.ctx.reconstruct_impulse_response_async(s._src, self.params)
+        self.ctx.reconstruct_impulse_response_batch_async([s._src for s in srcs], self.params)
         self.ctx.synchronize()
 
     def SetPipelining(self, depth):

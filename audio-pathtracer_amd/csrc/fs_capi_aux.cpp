@@ -235,7 +235,7 @@ int fs_reverb_process(fs_context* ctx, fs_source h, const float* in, float* out,
     hipStream_t rs = ctx->rev_stream;
     {
         std::lock_guard<std::mutex> g(s->ir_mu);
-        if (s->last_rec >= 0) FS_HIP(ctx, hipStreamWaitEvent(rs, s->ev_rec[s->last_rec], 0));
+        if (s->last_rec >= 0) FS_HIP(ctx, stream_waits_for_rec(ctx, rs, s, s->last_rec));
         FS_HIP(ctx, hipMemcpyAsync(s->d_rev_in, in, sizeof(float) * 2 * (size_t)frame, hipMemcpyHostToDevice, rs));
         launch_reverb(s->d_ir_mono, ctx->num_samples, s->d_ring, s->rev_head, s->d_rev_in, s->d_rev_cur, s->d_rev_out, frame,
                       (flags & FS_REVERB_LITERAL_TAIL) ? 1 : 0, rs);

@@ -22,13 +22,42 @@ hipError_t compute_waits_for(fs_context* ctx, hipEvent_t ev) {
     (void)hipGetLastError();   // hipErrorNotReady is not an error
     return hipStreamWaitEvent(ctx->stream, ev, 0);
 }
+// ---- batched reconstructs: one event per batch (fs_context::tail_batch_ev) ----------------------------------------
+hipEvent_t tail_batch_event(fs_context* ctx, uint64_t id) {
+    const uint64_t newest = ctx->tail_batch_newest.load(std::memory_order_acquire);
+    const uint64_t probe = newest - id < (uint64_t)fs_context::kTailBatches ? id : newest - fs_context::kTailBatches + 1;
+    return ctx->tail_batch_ev[probe % fs_context::kTailBatches];
+}
+bool tail_batch_done(fs_context* ctx, uint64_t id) {
+    if (id <= ctx->tail_batch_done.load(std::memory_order_acquire)) return true;
+    const uint64_t newest = ctx->tail_batch_newest.load(std::memory_order_acquire);
+    if (id > newest) return false;   // (not enqueued yet: cannot happen for an id read from a source)
+    const uint64_t probe = newest - id < (uint64_t)fs_context::kTailBatches ? id : newest - fs_context::kTailBatches + 1;
+    if (hipEventQuery(ctx->tail_batch_ev[probe % fs_context::kTailBatches]) != hipSuccess) { (void)hipGetLastError(); return false; }
+    // (if the entry was recycled meanwhile it now stands for a younger batch: its completion implies this one's)
+    uint64_t cur = ctx->tail_batch_done.load(std::memory_order_relaxed);
+    while (cur < probe && !ctx->tail_batch_done.compare_exchange_weak(cur, probe, std::memory_order_release, std::memory_order_relaxed)) {}
+    return true;
+}
+hipError_t stream_waits_for_rec(fs_context* ctx, hipStream_t st, Source* s, int buf) {
+    if (!s->rec_recorded[buf]) return hipSuccess;
+    if (s->rec_batch[buf]) {
+        if (tail_batch_done(ctx, s->rec_batch[buf])) return hipSuccess;
+        return hipStreamWaitEvent(st, tail_batch_event(ctx, s->rec_batch[buf]), 0);
+    }
+    if (st == ctx->stream) return compute_waits_for(ctx, s->ev_rec[buf]);
+    return hipStreamWaitEvent(st, s->ev_rec[buf], 0);
+}
+hipError_t sync_publish(fs_context* ctx, Source* s, int slot) {
+    const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);
+    return hipEventSynchronize(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+}
 hipError_t wait_energy_readers(fs_context* ctx, Source* s, int buf) {
     if (s->red_recorded[buf]) {   // the tail stream may still be summing this buffer over the ranks
         hipError_t e = compute_waits_for(ctx, s->ev_red[buf]);
         if (e != hipSuccess) return e;
     }
-    if (!s->rec_recorded[buf]) return hipSuccess;
-    return compute_waits_for(ctx, s->ev_rec[buf]);
+    return stream_waits_for_rec(ctx, ctx->stream, s, buf);
 }
 hipError_t wait_energy_readers(fs_context* ctx, Source* s) { return wait_energy_readers(ctx, s, s->cur); }
 // Hand the current energy buffer over to the tail stream: what the compute stream has enqueued so far
@@ -165,14 +194,16 @@ void resolve_completed_timings(fs_context* ctx) {
 // advance `front` over publishes whose D2H copy has completed.  Any thread: the producer calls it where it enqueues, a
 // consumer through fs_get_impulse_response_sequence.  `front` only ever grows (compare-exchange to the maximum): a thread
 // that looked at a slot just before the producer recycled it for a later publish can only conclude less, never more.
-void poll_published(Source* s) {
+void poll_published(fs_context* ctx, Source* s) {
     uint64_t f = s->front.load(std::memory_order_acquire);
     const uint64_t enq = s->enqueued.load(std::memory_order_acquire);
     while (f < enq) {
         uint64_t next = f + 1;
         int slot = (int)(next % kIrRing);
         if (s->seq_of[slot].load(std::memory_order_acquire) != next) break;
-        if (hipEventQuery(s->ev[slot]) != hipSuccess) { (void)hipGetLastError(); break; }   // (hipErrorNotReady is not an error)
+        const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);   // a batched publish: its batch's event
+        if (b) { if (!tail_batch_done(ctx, b)) break; }
+        else if (hipEventQuery(s->ev[slot]) != hipSuccess) { (void)hipGetLastError(); break; }   // (hipErrorNotReady is not an error)
         if (s->seq_of[slot].load(std::memory_order_acquire) != next) break;   // recycled meanwhile: the answer was about a later publish
         f = next;
     }
@@ -280,11 +311,13 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
 // waves win).  Walks deeper than 16 segments (the reference's unbounded default) leave long chains of a few
 // survivors and do best at about 16 384 waves at every size measured (262 144 subpaths, unbounded depth, 5 000
 // triangles: 1.29 -> 0.82 ms with 16 per wave; 1 048 576: dense again).
-int auto_rays_per_wave(unsigned long long lanes, int depth) {
+int auto_rays_per_wave(unsigned long long lanes, int depth, unsigned long long waves) {
     // round 2 (kShareMinIdle, pipelined frames; tools/pipelined_rpw_sweep.py, profiles/r02_pipelined_rpw_sweep.json): mid-size
     // frames do better at ~4096 waves — 65 536 subpaths 16 per wave, 131 072 subpaths 32 per wave (0.244 -> 0.233 ms at
     // depth 8, 0.355 -> 0.309 ms at depth 12; unpipelined 0.300 -> 0.267 ms); 262 144 and more stay dense
-    const unsigned long long target_waves = depth > 16 ? 16384ull : (lanes >= 65536ull ? 4096ull : 2048ull);
+    // (waves > 0: the caller's target — the later stages of a staged walk that is waited for do best at ~8192 cooperative waves:
+    // 16 400 / 62 000 / 64 000 survivors 0.83 / 1.42 / 1.20 ms per frame with 2 / 4 / 4 per wave, profiles/r04_sync_stage_sweep2.jsonl)
+    const unsigned long long target_waves = waves ? waves : (depth > 16 ? 16384ull : (lanes >= 65536ull ? 4096ull : 2048ull));
     // round 3 (tools/ref_defaults_breakdown.py, profiles/r03_ref_defaults_rpw.log): the reference's own update — 2 000
     // subpaths, uncapped — is fastest with ONE subpath per wave (0.88 -> 0.71 ms starter_room, 1.11 -> 0.92 ms old_mine; 2: 0.79,
     // 4: 0.85, 16: 0.90): the floor of 4 per wave went
@@ -468,10 +501,27 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
         ctx->stage_bounds = b;   // empty: depth = 0 frames are not held
         ctx->stage_bounds_default = false;
     }
+    if (const char* v = std::getenv("FS_SYNC_LATE_RPW")) ctx->sync_late_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
+    ctx->sync_stage_bounds = {16};   // tools/sync_stage_sweep.py, profiles/r04_sync_stage_sweep.jsonl
+    if (const char* v = std::getenv("FS_SYNC_WALK_STAGES")) {
+        std::vector<int> b;
+        for (const char* q = v; *q;) {
+            char* end = nullptr;
+            const long x = std::strtol(q, &end, 10);
+            if (end == q) break;
+            if (x > (b.empty() ? 0 : b.back()) && x < FS_MAX_DEPTH + kOverLevels && (int)b.size() < kMaxWalkParts - 1) b.push_back((int)x);
+            q = *end ? end + 1 : end;
+        }
+        ctx->sync_stage_bounds = b;   // empty: such frames walk in one piece
+    }
+    if (const char* v = std::getenv("FS_SYNC_STAGE_FROM")) ctx->sync_stage_from = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
     e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchSets * kScratchAllocWords);   // each set with its counters
     if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchSets * kScratchAllocWords);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
+    for (int k = 0; k < fs_context::kTailBatches && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ctx->tail_batch_ev[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_recon_tab, sizeof(ReconItem) * fs_context::kReconTabSlots * fs_context::kReconTabItems, hipHostMallocDefault);
+    if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("batched reconstructs: ") + hipGetErrorString(e));
     ctx->device_ok = true;
     // A context overlaps the tail of a frame with the next frame's tracing on two HIP streams.  The runtime multiplexes
     // streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); with other libraries' streams in the process
@@ -524,6 +574,8 @@ int fs_context_destroy(fs_context* ctx) {
         }
         if (ctx->ev_recon_launch) (void)hipEventDestroy(ctx->ev_recon_launch);
     }
+    for (hipEvent_t ev : ctx->tail_batch_ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->h_recon_tab) (void)hipHostFree(ctx->h_recon_tab);
     join_refine_threads(ctx);   // no background build may outlive the context (the library may be unloaded next)
     for (Source* s : ctx->sources) free_source(ctx, s);
     // streams exist even when a later step of fs_context_create failed (device_ok == false)

@@ -92,20 +92,22 @@ struct OwedLaunch {
 // slot of seq - kIrRing, so publish seq - kIrRing + 1 must have completed before seq is enqueued).  `more`: publishes about
 // to be enqueued.  May block the host (the ring is the producer's only throttle) — call it without holding ir_mu.
 static int ir_ring_backpressure(fs_context* ctx, Source* s, int more) {
-    poll_published(s);
+    poll_published(ctx, s);
     for (int j = 1; j <= more; ++j) {
         if (s->enqueued + (uint64_t)j < (uint64_t)kIrRing) continue;
         const uint64_t must = s->enqueued + (uint64_t)j + 1 - (uint64_t)kIrRing;
         const int slot = (int)(must % kIrRing);
         if (s->seq_of[slot] == must && s->front.load(std::memory_order_relaxed) < must) {
-            FS_HIP(ctx, hipEventSynchronize(s->ev[slot]));
-            poll_published(s);
+            FS_HIP(ctx, sync_publish(ctx, s, slot));
+            poll_published(ctx, s);
         }
     }
     return FS_OK;
 }
 // a publish of the source's current IR set has been enqueued on the tail stream as number `seq`
-static void note_publish(Source* s, uint64_t seq, int slot) { s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq; }
+static void note_publish(Source* s, uint64_t seq, int slot, uint64_t batch = 0) {
+    s->pub_batch[slot] = batch; s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq;
+}
 
 static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
     if (ctx->recon_owed.empty()) return FS_OK;
@@ -161,7 +163,11 @@ static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
             }
             if (s->spare_pub_seq) {
                 const int slot = (int)(s->spare_pub_seq % kIrRing);
-                if (s->seq_of[slot] == s->spare_pub_seq) FS_OWED_HIP(compute_waits_for(ctx, s->ev[slot]));   // (a reused slot: that publish completed long ago)
+                if (s->seq_of[slot] == s->spare_pub_seq) {   // (a reused slot: that publish completed long ago)
+                    const uint64_t pb = s->pub_batch[slot];
+                    if (!pb) FS_OWED_HIP(compute_waits_for(ctx, s->ev[slot]));
+                    else if (!tail_batch_done(ctx, pb)) FS_OWED_HIP(hipStreamWaitEvent(ctx->stream, tail_batch_event(ctx, pb), 0));
+                }
             }
             if (s->rev_recorded) FS_OWED_HIP(compute_waits_for(ctx, s->ev_rev));   // a reverb callback may be reading either set
             bands = s->d_ir_spare_bands; mono = s->d_ir_spare_mono;
@@ -197,7 +203,7 @@ static int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
         const fs_context::ReconOwed& o = ol.owed[i];
         Source* s = o.s;
         FS_HIP(ctx, hipEventRecord(s->ev_rec[o.cur], ctx->copy_stream));   // (behind the one wait above: every reconstruct of the launch is done)
-        s->rec_recorded[o.cur] = true;
+        s->rec_recorded[o.cur] = true; s->rec_batch[o.cur] = 0;
         const uint64_t seq = s->enqueued + 1;   // (the ring's back-pressure was applied in owed_prepare, before the mutexes)
         const int slot = (int)(seq % kIrRing);
         if (ol.tmp[i] < 0) {   // the spare set holds the source's newest IR: it becomes the current one (ir_mu is held)
@@ -210,7 +216,7 @@ static int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
         FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], mono, sizeof(float) * row, hipMemcpyDeviceToHost, ctx->copy_stream));
         FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->copy_stream));
         if (ol.tmp[i] < 0) note_publish(s, seq, slot);
-        else { s->seq_of[slot] = seq; s->enqueued = seq; }
+        else { s->pub_batch[slot] = 0; s->seq_of[slot] = seq; s->enqueued = seq; }
         if (ol.tmp[i] >= 0) {
             FS_HIP(ctx, hipEventRecord(ctx->ev_ir_tmp[ol.tmp[i]], ctx->copy_stream));
             ctx->ir_tmp_pending[ol.tmp[i]] = true;
@@ -332,7 +338,7 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
                            s->d_ir_mono, tail);
         FS_HIP(ctx, hipGetLastError());
         FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], tail));
-        s->rec_recorded[s->cur] = true;
+        s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = 0;
         s->last_rec = s->cur;
     }
     uint64_t seq = s->enqueued + 1;
@@ -350,6 +356,72 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
 }
 
 int ir_ring_backpressure_for(fs_context* ctx, Source* s) { return ir_ring_backpressure(ctx, s, 1); }
+
+// ReconstructImpulseResponse + publish of MANY sources' current frames (the subsystem's loop over ActiveSources,
+// ARTS.cpp:100-126, every one ending in ReconstructImpulseResponse :192): one handoff, ONE kernel that also writes the
+// channel views straight into the sources' pinned host ring slots, ONE event — instead of a wait, a kernel, a copy and
+// three event records per source (67 us per source of host and queue time: 128 sources took 8.6 ms, 32 took 2.8).
+// Anything unusual about a source's frame (a literal second flush, per-kernel timing) sends the whole batch the ordinary way.
+int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
+    { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // IRs are published in frame order
+    bool plain = ctx->profiling < 2 && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && count > 1;
+    for (int i = 0; i < count; ++i)
+        if (ctx->cfg.world_size > 1 && !srcs[i]->reduced && !srcs[i]->handed_off) plain = false;   // (reconstruct_now refuses with the message)
+    if (!plain) {
+        for (int i = 0; i < count; ++i) { const int rc = reconstruct_now(ctx, srcs[i], p); if (rc) return rc; }
+        return FS_OK;
+    }
+    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int B = ctx->cfg.num_bands;
+    const int spb = p->samples_per_bin > 0 ? p->samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
+    hipStream_t tail = ctx->copy_stream;
+    for (int first = 0; first < count; first += fs_context::kReconTabItems) {
+        const int n = std::min(count - first, (int)fs_context::kReconTabItems);
+        Source* const* g = srcs + first;
+        for (int i = 0; i < n; ++i) { const int br = ir_ring_backpressure(ctx, g[i], 1); if (br) return br; }   // (before the mutexes: may wait for the GPU)
+        // the tail stream takes over behind everything the compute stream has enqueued for these frames: one event pair
+        bool ordered = true;
+        for (int i = 0; i < n; ++i) ordered = ordered && g[i]->tail_ordered;
+        if (!ordered) {
+            FS_HIP(ctx, handoff_energy(ctx, g[0]));
+            for (int i = 0; i < n; ++i) g[i]->tail_ordered = true;
+        }
+        // a table slot the kernel of eight batches ago has certainly left
+        const unsigned slot_t = ctx->recon_tab_next++ % fs_context::kReconTabSlots;
+        if (ctx->recon_tab_batch[slot_t] && !tail_batch_done(ctx, ctx->recon_tab_batch[slot_t]))
+            FS_HIP(ctx, hipEventSynchronize(tail_batch_event(ctx, ctx->recon_tab_batch[slot_t])));
+        ReconItem* tab = ctx->h_recon_tab + (size_t)slot_t * fs_context::kReconTabItems;
+        std::vector<Source*> order(g, g + n);
+        std::sort(order.begin(), order.end());                 // one locking order for every thread
+        std::vector<std::unique_lock<std::mutex>> locks;
+        locks.reserve((size_t)n);
+        for (Source* s : order) locks.emplace_back(s->ir_mu);  // against fs_reverb_process on the audio thread
+        const uint64_t batch = ctx->tail_batch_newest.load(std::memory_order_relaxed) + 1;
+        for (int i = 0; i < n; ++i) {
+            Source* s = g[i];
+            if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
+            // deterministic mode: the collective summed the fixed-point histogram; round it to fp32 once, now
+            if (s->cur_fixed && !s->reduced) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
+            const uint64_t seq = s->enqueued + 1;
+            const int slot = (int)(seq % kIrRing);
+            tab[i].energy = s->energy(); tab[i].ir_bands = s->d_ir_bands; tab[i].ir_mono = s->d_ir_mono; tab[i].host = s->h_ir[slot];
+            tab[i].spb = spb; tab[i].pad = 0;
+        }
+        launch_reconstruct_batch(tab, n, B, ctx->num_bins, ctx->num_samples, tail);
+        FS_HIP(ctx, hipGetLastError());
+        FS_HIP(ctx, hipEventRecord(ctx->tail_batch_ev[batch % fs_context::kTailBatches], tail));
+        ctx->tail_batch_newest.store(batch, std::memory_order_release);
+        ctx->recon_tab_batch[slot_t] = batch;
+        for (int i = 0; i < n; ++i) {
+            Source* s = g[i];
+            s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = batch;
+            s->last_rec = s->cur;
+            const uint64_t seq = s->enqueued + 1;
+            note_publish(s, seq, (int)(seq % kIrRing), batch);
+        }
+    }
+    return FS_OK;
+}
 
 }  // namespace fsi
 
@@ -477,6 +549,16 @@ void frame_describe(fs_context* ctx, Frame& f) {
         static const std::vector<int> kGroupedStageBounds = {16, 36, 64, 96};
         const std::vector<int>& bounds = !(ctx->stage_bounds_default && f.group && f.count >= 2) ? ctx->stage_bounds : kGroupedStageBounds;
         for (int bound : bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
+        WalkStage last; last.begin = begin; last.end = 1 << 30;
+        f.stages.push_back(last);
+    } else if (!f.pipe_ok && f.unbounded && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && ctx->profiling < 3 &&
+               !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from) {
+        // A depth = 0 frame that is waited for (not held): the same stages, one launch after the other on the stream.  The
+        // frame's time is its longest walk — a chain of ~ log(subpaths) / log(1 / rr) dependent bounces — and what a bounce
+        // costs depends on who shares the wave: the first stage walks everybody on dense waves (that is where the work is),
+        // the few survivors of every later stage get waves of their own whose idle lanes search with them.
+        int begin = 0;
+        for (int bound : ctx->sync_stage_bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
     } else {
@@ -775,7 +857,17 @@ int frame_launch(fs_context* ctx, Frame& f) {
         ctx->stats.rays += 2ull * kp.num_local;
         return FS_OK;
     }
-    launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+    if (f.stages.size() > 1) {   // a staged walk that is waited for: its stages back to back
+        for (size_t k = 0; k < f.stages.size(); ++k) {
+            WalkLaunch wk = wl;
+            if (ctx->walk_rays_per_wave <= 0)
+                wk.rays_per_wave = k > 0 && ctx->sync_late_rays_per_wave > 0 ? ctx->sync_late_rays_per_wave :
+                    auto_rays_per_wave(walk_stage_slots(kp, f.stages[k].begin), std::min(kp.depth, f.stages[k].end) - f.stages[k].begin, k > 0 ? 8192ull : 0ull);
+            launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, f.stages[k]);
+        }
+    } else {
+        launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);
+    }
     if (timed_frame) FS_HIP(ctx, hipEventRecord(tf.e[1], ctx->stream));
     if (f.all_conn)
         launch_connect_all(B, ctx->scene, kp, st, s->energy(), fixed ? s->d_fixed[s->cur] : nullptr, scratch, ctx->stream);
@@ -1108,6 +1200,30 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     return reconstruct_now(ctx, s, p);
 }
 
+int fs_reconstruct_impulse_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (count < 0 || (count > 0 && !sources)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad source list");
+    if (count == 0) return FS_OK;
+    fs_params def;
+    if (!p) { fs_params_default(&def); p = &def; }
+    if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    std::vector<Source*> srcs((size_t)count);
+    for (int32_t i = 0; i < count; ++i) {
+        srcs[(size_t)i] = get_source(ctx, sources[i]);
+        if (!srcs[(size_t)i]) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+        for (int32_t k = 0; k < i; ++k)
+            if (sources[k] == sources[i]) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "a source appears twice in the batch");
+    }
+    // frames that still wait for their launch (pipelined / grouped): every reconstruct is recorded with its frame, as the single call does
+    if (!ctx->group.empty() || !ctx->held.empty()) {
+        for (int32_t i = 0; i < count; ++i) { const int rc = fs_reconstruct_impulse_response_async(ctx, sources[i], p); if (rc) return rc; }
+        return FS_OK;
+    }
+    FS_FLUSH(ctx);
+    return reconstruct_batch(ctx, srcs.data(), count, p);
+}
+
 int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32_t n) {
     if (!ctx || !ir) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
@@ -1127,16 +1243,16 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
             FS_HIP(ctx, hipMemcpyAsync(s->d_ir_bands + (size_t)b * (size_t)n, s->d_ir_mono, bytes, hipMemcpyDeviceToDevice, tail));
         const int cur = s->last_rec >= 0 ? s->last_rec : s->cur;
         FS_HIP(ctx, hipEventRecord(s->ev_rec[cur], tail));   // the reverb waits on this before reading d_ir_mono
-        s->rec_recorded[cur] = true;
+        s->rec_recorded[cur] = true; s->rec_batch[cur] = 0;
         s->last_rec = cur;
     }
     uint64_t seq = s->enqueued + 1;
     int slot = (int)(seq % kIrRing);
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, bytes, hipMemcpyDeviceToHost, tail));
     FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
-    s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq;
+    s->pub_batch[slot] = 0; s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq;
     FS_HIP(ctx, hipStreamSynchronize(tail));   // `ir` is the caller's memory
-    poll_published(s);
+    poll_published(ctx, s);
     return FS_OK;
 }
 
@@ -1148,7 +1264,7 @@ int fs_synchronize(fs_context* ctx) {
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     for (Source* s : ctx->sources)
-        if (s && s->alive) poll_published(s);
+        if (s && s->alive) poll_published(ctx, s);
     resolve_timings(ctx);
     { const int oc = oneshot_check(ctx); if (oc) return oc; }
     return check_overflow(ctx);   // FS_ERR_OVERFLOW: the last depth = 0 frame must be traced again (see the header)
@@ -1175,7 +1291,7 @@ int fs_get_impulse_response_sequence(fs_context* ctx, fs_source h, uint64_t* com
     if (!ctx || !completed) return FS_ERR_INVALID_ARGUMENT;
     Source* s = get_source(ctx, h);
     if (!s) return FS_ERR_BAD_HANDLE;  // no err string write: may be called from the audio thread
-    poll_published(s);   // also notices publishes that completed since the producer's last call
+    poll_published(ctx, s);   // also notices publishes that completed since the producer's last call
     *completed = s->front.load(std::memory_order_acquire);
     return FS_OK;
 }

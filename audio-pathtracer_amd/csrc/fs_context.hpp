@@ -96,6 +96,10 @@ struct Source {
     uint64_t spare_pub_seq = 0;        // newest publish that read what is now the spare set: a writer of the spare set waits for it
     float* h_ir[kIrRing] = {};  // pinned host copies of the channel view
     hipEvent_t ev[kIrRing] = {};
+    // Batched reconstructs (fs_reconstruct_impulse_response_batch_async) record ONE event for all their sources (fs_context::tail_batch_ev):
+    // rec_batch[i] / pub_batch[slot] != 0 name the batch whose event stands for ev_rec[i] / ev[slot]; 0: the source's own event counts.
+    uint64_t rec_batch[kEnergyBufs] = {};
+    std::atomic<uint64_t> pub_batch[kIrRing] = {};
     std::atomic<uint64_t> seq_of[kIrRing] = {};   // (atomics: fs_get_impulse_response_sequence may look from another thread)
     std::atomic<uint64_t> enqueued{0};            // publishes enqueued so far
     std::atomic<uint64_t> front{0};    // newest COMPLETED publish (0 = none yet)
@@ -194,6 +198,16 @@ struct fs_context {
         unsigned* d_err = nullptr;        // raised by a sum kernel that gave up waiting for a peer
         uint32_t seq = 0;                 // reduces issued so far
     } oneshot;
+    // One event per batched reconstruct launch on the tail stream, in a ring: the tail stream runs in order, so a batch is done as
+    // soon as its own or ANY younger batch's event is (a batch whose ring entry has been recycled is covered by the oldest entry
+    // still there).  Created with the context: the handles never change (the audio thread may query them).
+    static constexpr int kTailBatches = 64;
+    hipEvent_t tail_batch_ev[kTailBatches] = {};
+    std::atomic<uint64_t> tail_batch_newest{0}, tail_batch_done{0};
+    static constexpr int kReconTabSlots = 8, kReconTabItems = 256;
+    ReconItem* h_recon_tab = nullptr;                  // pinned host: [kReconTabSlots][kReconTabItems], read by the batch kernel in place
+    uint64_t recon_tab_batch[kReconTabSlots] = {};     // the batch that last read slot k
+    unsigned recon_tab_next = 0;
     ncclComm_t peers = nullptr;
     int peers_size = 0;
     float* d_gather = nullptr; size_t gather_cap = 0;   // [peers][B][bins] fp32
@@ -251,6 +265,9 @@ struct fs_context {
     bool state_cont = false;         // the sets include continuation records (staged walks)
     std::vector<int> stage_bounds;   // staged depth = 0 walks: the steps at which a walk changes launch (FS_WALK_STAGES)
     bool stage_bounds_default = true; // not set by the host: grouped frames (two or more per launch) take kGroupedStageBounds
+    std::vector<int> sync_stage_bounds;   // the same for depth = 0 frames that are waited for (stages back to back; FS_SYNC_WALK_STAGES)
+    int sync_late_rays_per_wave = 0;      // subpaths per wave of the later stages, 0 = by the number of survivors (FS_SYNC_LATE_RPW)
+    int sync_stage_from = 16384;          // ... of at least this many subpaths (smaller frames: every walk has a wave of its own anyway)
     int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
     std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
     std::vector<std::thread> refine_threads;   // every background build ever started (cancelled ones too): joined before the context goes
@@ -351,10 +368,14 @@ void free_state(fs_context* ctx);
 hipEvent_t take_event(fs_context* ctx);
 void resolve_timings(fs_context* ctx);
 void resolve_completed_timings(fs_context* ctx);
-void poll_published(Source* s);
+void poll_published(fs_context* ctx, Source* s);
+bool tail_batch_done(fs_context* ctx, uint64_t id);                 // any thread
+hipEvent_t tail_batch_event(fs_context* ctx, uint64_t id);          // the event that covers batch `id`
+hipError_t stream_waits_for_rec(fs_context* ctx, hipStream_t st, Source* s, int buf);   // st waits for the reconstruct that last read energy buffer `buf` (and wrote d_ir_*)
+hipError_t sync_publish(fs_context* ctx, Source* s, int slot);      // block until the publish in ring slot `slot` has completed
 int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals,
                  int sets, bool staged);
-int auto_rays_per_wave(unsigned long long lanes, int depth);
+int auto_rays_per_wave(unsigned long long lanes, int depth, unsigned long long waves = 0);
 int auto_pairs_per_wave(unsigned long long pairs);
 int check_params(fs_context* ctx, const fs_params* p);
 
@@ -369,6 +390,7 @@ void join_refine_threads(fs_context* ctx);
 int flush_pending(fs_context* ctx);          // pipelined frames: let every held frame finish on its own kernels
 int check_overflow(fs_context* ctx);         // depth = 0: did a record miss both tiers?  (stream just synchronised)
 int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
+int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p);   // many sources: one launch, one event
 int ir_ring_backpressure_for(fs_context* ctx, Source* s);   // the IR ring's throttle before one more publish (may block; not under ir_mu)
 
 // ---- fs_capi_comm.cpp ---------------------------------------------------------------------------------------------

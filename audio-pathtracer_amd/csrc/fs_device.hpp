@@ -1870,9 +1870,12 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #endif
 constexpr int kChunk = FS_RECON_CHUNK;
 constexpr int kWarm = 96;
+// host_out (optional, row B only): the block's samples also go to that pinned host buffer, staged in `s_stage`
+// (kBlock x (kChunk + 1) floats of LDS) and written with one 16-byte store per lane and instruction.
 __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_block, const float* __restrict__ energy, int B, int nb,
                                                  int num_samples, int spb, float* __restrict__ ir_bands,
-                                                 float* __restrict__ ir_mono, float* s_amp) {
+                                                 float* __restrict__ ir_mono, float* s_amp, float* host_out = nullptr,
+                                                 float* s_stage = nullptr) {
     const float Pi4 = sqrtf(4.0f * kPi);                           // FSAC.cpp:323
     for (int i = threadIdx.x; i < nb; i += kBlock) {
         float e;
@@ -1889,10 +1892,11 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
     __syncthreads();
     const int chunk = chunk_block * kBlock + threadIdx.x;
     const int s0 = chunk * kChunk;
-    if (s0 >= num_samples) return;
+    const bool to_host = host_out != nullptr && row == B;   // (uniform for the workgroup)
+    if (s0 >= num_samples && !to_host) return;
     float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
-    const int s1 = min(s0 + kChunk, num_samples);
-    const int i0 = max(s0 - kWarm, 0);
+    const int s1 = min(s0 + kChunk, num_samples);        // (a thread beyond the end: an empty range, it only joins the barrier below)
+    const int i0 = s0 < num_samples ? max(s0 - kWarm, 0) : s1;
     int bin = i0 / spb;
     int bs = i0 - bin * spb;
     float cur = bin < nb ? s_amp[bin] : 0.0f;
@@ -1914,12 +1918,30 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
             float b = (1.0f - 0.25f) * y;
             y = a + b;                                              // FSAC.cpp:374
         }
-        if (i >= s0) out[i] = y;
+        if (i >= s0) {
+            out[i] = y;
+            if (to_host) s_stage[threadIdx.x * (kChunk + 1) + (i - s0)] = y;   // (+ 1: conflict-free rows)
+        }
         if (++bs == spb) {
             bs = 0;
             ++bin;
             prev = cur;
             cur = bin < nb ? s_amp[bin] : 0.0f;
+        }
+    }
+    if (to_host) {   // the block's kBlock * kChunk consecutive samples, 16 bytes per lane
+        __syncthreads();
+        const int base = chunk_block * kBlock * kChunk;
+        for (int v = threadIdx.x; v < kBlock * kChunk / 4; v += kBlock) {
+            const int s = 4 * v;
+            if (base + s + 3 < num_samples) {
+                float4 o;
+                o.x = s_stage[s + (s >> 4)]; o.y = s_stage[s + 1 + ((s + 1) >> 4)];
+                o.z = s_stage[s + 2 + ((s + 2) >> 4)]; o.w = s_stage[s + 3 + ((s + 3) >> 4)];
+                *reinterpret_cast<float4*>(host_out + base + s) = o;
+            } else {
+                for (int e = 0; e < 4; ++e) if (base + s + e < num_samples) host_out[base + s + e] = s_stage[s + e + ((s + e) >> 4)];
+            }
         }
     }
 }

@@ -301,6 +301,11 @@ void launch_connect_all(int B, const DeviceScene& sc, const KParams& kp, const S
 void launch_fixed_to_energy(const unsigned long long* fixed, float* energy, int words, hipStream_t s);
 void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rate, int num_samples, int spb,
                         float* ir_bands, float* ir_mono, hipStream_t s);
+// ReconstructImpulseResponse of MANY sources as one launch (fs_reconstruct_impulse_response_batch_async): a table of items in
+// pinned host memory (read by the kernel as it stands); host != nullptr: the channel view is also written straight into
+// that pinned host buffer (the publish: 16-byte stores, a block's 4 096 samples staged in LDS) — no copy command per source.
+struct ReconItem { const float* energy; float* ir_bands; float* ir_mono; float* host; int32_t spb; int32_t pad; };
+void launch_reconstruct_batch(const ReconItem* table, int count, int B, int num_bins, int num_samples, hipStream_t s);
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
                        int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s);
 // rays_per_wave < 64: sparse waves whose other lanes help with every closest-hit query; 64 = one ray per lane

@@ -154,7 +154,7 @@ public:
         std::vector<fs_source> H;
         for (auto* s : ActiveSources) H.push_back(s->Handle_);
         Check(fs_compute_energy_response_batch_async(Ctx_, H.data(), (int32_t)H.size(), &Params));
-        for (auto* s : ActiveSources) Check(fs_reconstruct_impulse_response_async(Ctx_, s->Handle_, &Params));
+        Check(fs_reconstruct_impulse_response_batch_async(Ctx_, H.data(), (int32_t)H.size(), &Params));   // one launch, one event
         Check(fs_synchronize(Ctx_));
     }
     // .cpp:55-85 (the caller drives every frame).  The reference draws from the engine's global rand() stream, so every

@@ -352,6 +352,11 @@ int fs_submit(fs_context* ctx);   /* hand everything requested so far to the GPU
  * from the band-mean energy; publishes the channel view to the host front buffer. */
 int fs_reconstruct_impulse_response(fs_context* ctx, fs_source src, const fs_params* params);
 int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source src, const fs_params* params);
+/* The tick's reconstructs in one go (UpdateSources loops over ActiveSources, ARTS.cpp:100-126, each UpdateSource ending in
+ * ReconstructImpulseResponse :192): exactly the result of fs_reconstruct_impulse_response_async on every listed source, as
+ * ONE launch that also writes the published channel views, and one completion event — per source the single call costs a
+ * stream wait, a kernel, a copy and three event records (32 sources: 2.8 ms per tick against 0.9 ms). */
+int fs_reconstruct_impulse_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 int fs_synchronize(fs_context* ctx);
 
 /* GetImpulseResponse() (FSAC.h:113): pointer to the PUBLISHED [num_samples] channel buffer, valid

@@ -596,7 +596,10 @@ def test_long_streams_of_staged_frames_never_share_an_energy_buffer(pkg, scene_f
     pick_up()
     assert ctx.impulse_response_sequence(s) == N
     assert np.array_equal(ctx.energy_buffer(s), want_e[-1])
-    assert len(seen) >= N // (2 * per_launch), sorted(seen)   # (a launch's IRs complete together: one of them is in front when the producer looks)
+    # a launch's IRs complete together (one of them is in front when the producer looks), and the first IR appears
+    # stages + 3 launches after its call: at least half of the launches that publish while the stream runs must be seen
+    stages = (len(bounds) if bounds is not None else 4) + 1
+    assert len(seen) >= max(3, (N // per_launch - (stages + 2)) // 2), sorted(seen)
     bad = [k for k, a in sorted(seen.items()) if not np.array_equal(a, want_ir[k - 1])]
     assert not bad, f"published IRs {bad} are not those of their frames (seen: {sorted(seen)})"
     ctx.close()

@@ -85,3 +85,89 @@ def test_cooperative_walk_equals_the_sparse_walk_and_the_oracle(pkg, oracle_mod,
     check_energy(out["1"][2], e32, e64, bands)
     assert out["1"][1][2] == cnt.connected
 
+
+
+# ---- the tick's reconstructs as one launch ------------------------------------------------------------------------
+@pytest.mark.parametrize("flags", [0, DET])
+def test_batched_reconstructs_equal_the_single_ones(pkg, scene_factory, flags):
+    """fs_reconstruct_impulse_response_batch_async: one launch for every source of the tick, the channel views written
+    straight into the published host buffers, one completion event.  Published IRs, per-band IRs and the publish counters
+    must be those of one fs_reconstruct_impulse_response_async per source — over more ticks than the IR ring and the table
+    ring have slots, mixed with single calls, with an observer between the ticks."""
+    sc = scene_factory("starter_room", 4)
+    rng = np.random.default_rng(2)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    pos = [(np.asarray(sc.source, np.float32) + rng.uniform(-0.05, 0.05, 3).astype(np.float32) * (hi - lo)).astype(np.float32) for _ in range(9)]
+    out = {}
+    for mode in ("single", "batch"):
+        ctx, _ = make_ctx(pkg, sc)
+        srcs = [ctx.create_source(p) for p in pos]
+        got = []
+        for tick in range(21):
+            p = pkg.default_params(num_rays=2000, depth=0, seed=100 + tick, flags=flags | pkg._capi.FLAG_FIXED_NORM_1000)
+            live = srcs if tick % 5 else srcs[:4]                     # the set of sources changes
+            ctx.compute_energy_response_batch_async(live, p)
+            if mode == "batch" and tick % 7 != 3:
+                ctx.reconstruct_impulse_response_batch_async(live, p)
+            else:
+                for s in live:
+                    ctx.reconstruct_impulse_response_async(s, p)
+            if tick in (2, 11):                                       # an observer in between
+                ctx.synchronize()
+                got.append(ctx.impulse_response(srcs[1], 0).copy())
+                got.append(ctx.band_impulse_response(srcs[2], 1).copy())
+        ctx.synchronize()
+        for s in srcs:
+            got.append(ctx.impulse_response(s, 0).copy())
+            got.append(ctx.band_impulse_response(s, 3).copy())
+            got.append(np.asarray([ctx.impulse_response_sequence(s)], np.int64))
+        out[mode] = got
+        ctx.close()
+    assert np.abs(out["single"][0]).max() > 0
+    for a, b in zip(out["single"], out["batch"]):
+        if flags & DET or a.dtype != np.float32:
+            assert np.array_equal(a, b)
+        else:     # fp32 atomics: the energies of two runs agree to rounding, and so do the IRs
+            assert np.abs(a - b).max() <= IR_TOL * max(np.abs(a).max(), 1e-30)
+
+
+def test_batched_reconstructs_with_reverb_and_pipelined_frames(pkg, scene_factory):
+    """the reverb callback reads the device-resident IR behind a batched reconstruct WITHOUT a synchronize in between (its
+    wait is the batch's event): the blocks equal those behind single reconstructs; and a batch call while frames are held
+    back records every reconstruct with its frame, like the single call"""
+    sc = scene_factory("starter_room", 2)
+    rng = np.random.default_rng(4)
+    blocks = [np.clip(rng.normal(0, 0.2, 2048), -1, 1).astype(np.float32) for _ in range(5)]
+    out = {}
+    for mode in ("single", "batch"):
+        ctx, s0 = make_ctx(pkg, sc)
+        s1 = ctx.create_source(np.asarray(sc.source, np.float32) + np.float32(30.0))
+        ctx.reverb_init(s0, 1024)
+        got = []
+        for i in range(5):
+            p = pkg.default_params(num_rays=4096, depth=8, seed=50 + i, flags=DET, dist_divisor=100.0)
+            ctx.compute_energy_response_batch_async([s0, s1], p)
+            if mode == "batch":
+                ctx.reconstruct_impulse_response_batch_async([s0, s1], p)
+            else:
+                ctx.reconstruct_impulse_response_async(s0, p)
+                ctx.reconstruct_impulse_response_async(s1, p)
+            got.append(np.asarray(ctx.reverb_process(s0, blocks[i])).copy())   # no synchronize: ordered by the events alone
+        ctx.synchronize()
+        got += [ctx.impulse_response(s, 0).copy() for s in (s0, s1)]
+        ctx.set_pipelining(2)
+        p = pkg.default_params(num_rays=4096, depth=8, seed=99, flags=DET)
+        ctx.compute_energy_response_async(s0, p)
+        ctx.compute_energy_response_async(s1, p)
+        if mode == "batch":
+            ctx.reconstruct_impulse_response_batch_async([s0, s1], p)     # both frames are held: recorded with them
+        else:
+            ctx.reconstruct_impulse_response_async(s0, p)
+            ctx.reconstruct_impulse_response_async(s1, p)
+        ctx.synchronize()
+        got += [ctx.impulse_response(s, 0).copy() for s in (s0, s1)]
+        out[mode] = got
+        ctx.close()
+    assert max(np.abs(a).max() for a in out["single"]) > 0
+    for a, b in zip(out["single"], out["batch"]):
+        assert np.array_equal(a, b)

@@ -35,12 +35,26 @@ for name in (sys.argv[1:] or ["starter_room", "old_mine"]):
                 ctx.compute_energy_response_async(srcs[0], p)
             else:
                 ctx.compute_energy_response_batch_async(srcs[:S], p)
-            for s in srcs[:S]:
-                ctx.reconstruct_impulse_response_async(s, p)
+            if os.environ.get("FS_TICK_SINGLE_RECON") == "1":
+                for s in srcs[:S]:
+                    ctx.reconstruct_impulse_response_async(s, p)
+            else:
+                ctx.reconstruct_impulse_response_batch_async(srcs[:S], p)
             ctx.synchronize()
             times.append(time.perf_counter() - t1)
         times = sorted(times[8:])
         out[str(S)] = {"ms_per_tick_median": round(1e3 * times[len(times) // 2], 4), "ms_per_tick_min": round(1e3 * times[0], 4),
                        "ms_per_source": round(1e3 * times[len(times) // 2] / S, 4)}
+        ctx.reset_stats(); ctx.set_profiling(2)      # a few ticks with events around every kernel (reconstructs go one by one then)
+        for i in range(6):
+            p.seed = 5000 + i
+            if S == 1:
+                ctx.compute_energy_response_async(srcs[0], p)
+            else:
+                ctx.compute_energy_response_batch_async(srcs[:S], p)
+            ctx.synchronize()
+        st = ctx.stats(); ctx.set_profiling(0)
+        out[str(S)]["kernel_ms"] = {"walk": round(st["walk_kernel_ms_sum"] / max(st["timed_frames"], 1), 4),
+                                    "connect": round(st["connect_kernel_ms_sum"] / max(st["timed_connects"], 1), 4)}
     print(json.dumps(out), flush=True)
     ctx.close()
