@@ -860,7 +860,9 @@ __device__ __forceinline__ bool walker_resume(Walker& w, const SubpathState& st,
 // slots a stage covers: the walks the previous stage suspended at step stage.begin, i.e. those of stage.begin steps or
 // more (one of exactly that length ends at its first roulette here) — buckets begin .. FS_MAX_DEPTH of the length-sorted
 // schedule (the last bucket holds every walk of FS_MAX_DEPTH steps or more: a stage that starts later than that visits
-// them all and the continuation record says which still walk)
+// them all and the continuation record says which still walk: a walk of that bucket that ENDS — in whatever stage, also one that
+// began before FS_MAX_DEPTH — clears its record; round 3 cleared it only in stages that begin at FS_MAX_DEPTH or later, so
+// that a walk of 64 .. 69 steps under bounds like 9, 70 kept the record of its suspension at step 9 and walked on from it)
 __device__ __forceinline__ uint32_t stage_slots(const WalkStage& sr, const SubpathState& st, uint32_t total, const unsigned* s_cnt) {
     if (sr.begin <= 0) return total;
     uint32_t n = 0;
@@ -1198,7 +1200,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
         if (w.k >= sr.end) { walker_suspend(w, st); break; }          // staged walk: the next stage goes on from here
         if (!walker_next_ray<LOBES>(w, kp, sc, st, ray)) {
             walker_finish<EXT>(w, st);
-            if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
+            if (st.cont_b && w.k >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // a walk of the last schedule bucket: later stages visit this slot again
             break;
         }
         Trav T;
@@ -1270,7 +1272,7 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
                 go = walker_next_ray<LOBES>(w, kp, sc, st, ray);
                 if (!go) {
                     walker_finish<EXT>(w, st);
-                    if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
+                    if (st.cont_b && w.k >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // a walk of the last schedule bucket: later stages visit this slot again
                     alive = false;
                 }
             }
@@ -1608,7 +1610,7 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
                 go = walker_next_ray<LOBES>(w, kp, sc, st, ray);
                 if (!go) {
                     walker_finish<EXT>(w, st);
-                    if (sr.begin >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // later stages visit this slot again
+                    if (st.cont_b && w.k >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // a walk of the last schedule bucket: later stages visit this slot again
                     alive = false;
                 }
             }

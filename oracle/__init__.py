@@ -165,6 +165,9 @@ def _bind(lib):
     lib.fso_samples_per_bin.restype = C.c_int32
     lib.fso_compute_energy.argtypes = [C.c_void_p, C.POINTER(Params), _f3, _f3, C.c_uint32, C.c_uint32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+    lib.fso_compute_energy_mt.argtypes = [C.c_void_p, C.POINTER(Params), _f3, _f3, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.POINTER(Counters)]
+    lib.fso_compute_energy_mt.restype = C.c_int32
     lib.fso_reconstruct.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_void_p]
     lib.fso_sanitize_float.argtypes = [C.c_double, C.c_char_p, C.c_int32]
     lib.fso_sanitize_float.restype = C.c_int32
@@ -337,6 +340,18 @@ class Scene:
         for p in parts:
             c.add(p[2])
         return e64.astype(np.float32), e64, c
+
+    def compute_energy_native_mt(self, params, src, lis, threads, pair_begin=0, pair_end=None, num_bins=1000):
+        """All-cores CPU baseline inside the C library (fso_compute_energy_mt): pthreads with a static partition of the pair
+        range and private double histograms — no interpreter between the threads.  Returns (e32, e64, counters, threads used)."""
+        if pair_end is None:
+            pair_end = params.num_pairs
+        e32 = np.zeros((self.B, num_bins), dtype=np.float32)
+        e64 = np.zeros((self.B, num_bins), dtype=np.float64)
+        c = Counters()
+        used = self.lib.fso_compute_energy_mt(self.h, C.byref(params), _vec3(src), _vec3(lis), pair_begin, pair_end, num_bins,
+                                              int(threads), e32.ctypes.data, e64.ctypes.data, C.byref(c))
+        return e32, e64, c, int(used)
 
     def set_objects(self, object_ids):
         """actor id per triangle (None = every triangle its own actor)"""

@@ -932,6 +932,70 @@ void fso_compute_energy(const fso_scene* s, const fso_params* p, const float src
     free(fwd); free(bwd); free(all);
 }
 
+/* All-cores CPU baseline: the pair range cut into `threads` static shares, every thread with
+ * PRIVATE [B][num_bins] double histograms and counters (nothing shared but the read-only scene), one final sum — plain
+ * pthreads, no interpreter between the threads.  energy_f64 [B][num_bins] = the sum of the private histograms in thread
+ * order (deterministic for a given thread count); energy_f32 = its rounding (the sequential fp32 accumulation of the
+ * reference exists per thread only and is not returned).  Returns the number of threads that ran. */
+#include <pthread.h>
+typedef struct mt_job {
+    const fso_scene* s; const fso_params* p; const float* src; const float* lis;
+    uint32_t begin, end; int32_t num_bins;
+    float* e32; double* e64; fso_counters c;
+} mt_job;
+static void* mt_run(void* arg) {
+    mt_job* j = (mt_job*)arg;
+    fso_params q = *j->p;
+    q.flags &= ~(uint32_t)FSO_FLAG_ACCUMULATE_ENERGY;   /* the private histograms start at zero; the caller adds */
+    fso_compute_energy(j->s, &q, j->src, j->lis, j->begin, j->end, j->num_bins, j->e32, j->e64, &j->c);
+    return NULL;
+}
+int32_t fso_compute_energy_mt(const fso_scene* s, const fso_params* p, const float src[3], const float lis[3],
+                              uint32_t pair_begin, uint32_t pair_end, int32_t num_bins, int32_t threads,
+                              float* energy_f32, double* energy_f64, fso_counters* c) {
+    if (threads < 1) threads = 1;
+    if (pair_end < pair_begin) pair_end = pair_begin;
+    const uint32_t n = pair_end - pair_begin;
+    if ((uint32_t)threads > n && n > 0) threads = (int32_t)n;
+    const size_t words = (size_t)s->B * (size_t)num_bins;
+    mt_job* jobs = (mt_job*)calloc((size_t)threads, sizeof(mt_job));
+    pthread_t* tid = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    float* e32 = (float*)calloc(words * (size_t)threads, sizeof(float));
+    double* e64 = (double*)calloc(words * (size_t)threads, sizeof(double));
+    int32_t started = 0;
+    for (int32_t t = 0; t < threads; ++t) {
+        mt_job* j = &jobs[t];
+        j->s = s; j->p = p; j->src = src; j->lis = lis; j->num_bins = num_bins;
+        j->begin = pair_begin + (uint32_t)(((uint64_t)n * (uint64_t)t) / (uint64_t)threads);
+        j->end = pair_begin + (uint32_t)(((uint64_t)n * (uint64_t)(t + 1)) / (uint64_t)threads);
+        j->e32 = e32 + words * (size_t)t; j->e64 = e64 + words * (size_t)t;
+        if (t + 1 == threads || pthread_create(&tid[t], NULL, mt_run, j) != 0) {   /* the last share (and any share whose thread */
+            mt_run(j);                                                               /* could not be started) runs here */
+            tid[t] = 0;
+        } else {
+            ++started;
+        }
+    }
+    for (int32_t t = 0; t < threads; ++t) if (tid[t]) pthread_join(tid[t], NULL);
+    if (!(p->flags & FSO_FLAG_ACCUMULATE_ENERGY)) {
+        if (energy_f64) memset(energy_f64, 0, sizeof(double) * words);
+        memset(energy_f32, 0, sizeof(float) * words);
+    }
+    double* sum = energy_f64 ? energy_f64 : (double*)calloc(words, sizeof(double));
+    if (!energy_f64 && (p->flags & FSO_FLAG_ACCUMULATE_ENERGY)) for (size_t i = 0; i < words; ++i) sum[i] = (double)energy_f32[i];
+    for (int32_t t = 0; t < threads; ++t) {
+        for (size_t i = 0; i < words; ++i) sum[i] += jobs[t].e64[i];
+        if (c) {   /* the counters are sums of uint64 fields */
+            uint64_t* dst = (uint64_t*)c; const uint64_t* srcw = (const uint64_t*)&jobs[t].c;
+            for (size_t k = 0; k < sizeof(fso_counters) / sizeof(uint64_t); ++k) dst[k] += srcw[k];
+        }
+    }
+    for (size_t i = 0; i < words; ++i) energy_f32[i] = (float)sum[i];
+    if (!energy_f64) free(sum);
+    free(jobs); free(tid); free(e32); free(e64);
+    return started + 1;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* ReconstructImpulseResponse  FSAC.cpp:320-380 (one channel / one band row)                   */
 /* ------------------------------------------------------------------------------------------- */

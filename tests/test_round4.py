@@ -171,3 +171,65 @@ def test_batched_reconstructs_with_reverb_and_pipelined_frames(pkg, scene_factor
     assert max(np.abs(a).max() for a in out["single"]) > 0
     for a, b in zip(out["single"], out["batch"]):
         assert np.array_equal(a, b)
+
+
+# ---- staged walks of frames that are waited for -------------------------------------------------------------------
+@pytest.mark.parametrize("bounds", ["16", "5,9,70", "64", "100"])
+def test_staged_walks_of_waited_frames_equal_the_walk_in_one_piece(pkg, oracle_mod, scene_factory, monkeypatch, bounds):
+    """A depth = 0 frame that is waited for (no pipelining) walks in stages too, one launch after the other on the stream —
+    everybody on dense waves first, the survivors on cooperative waves (fs_capi_frame.cpp: frame_launch).  Energies
+    (deterministic mode: bit for bit), counters and IRs are those of the walk in one piece, for bounds inside the main
+    record tier, on its edge and beyond it; batched sources too; and the frame equals the oracle's."""
+    sc = scene_factory("starter_room", 4)
+    out = {}
+    for mode in ("whole", "staged"):
+        monkeypatch.setenv("FS_SYNC_WALK_STAGES", bounds if mode == "staged" else "")
+        monkeypatch.setenv("FS_SYNC_STAGE_FROM", "1")
+        ctx, s = make_ctx(pkg, sc)
+        s2 = ctx.create_source(np.asarray(sc.source, np.float32) + np.float32(40.0))
+        p = pkg.default_params(num_rays=24576, depth=0, seed=77, flags=DET)
+        e = ctx.compute_energy_response(s, p).copy()
+        ctx.reconstruct_impulse_response(s, p)
+        got = [e, ctx.impulse_response(s, 0).copy()]
+        ctx.compute_energy_response_batch_async([s, s2], pkg.default_params(num_rays=6000, depth=0, seed=78, flags=DET))
+        ctx.synchronize()
+        got += [ctx.energy_buffer(s).copy(), ctx.energy_buffer(s2).copy()]
+        st = ctx.stats()
+        got.append(np.asarray([st[k] for k in ("segments", "connections_tested", "deposits", "frames", "rays")], np.int64))
+        got.append(ctx.compute_energy_response(s, pkg.default_params(num_rays=24576, depth=0, seed=77)).copy())
+        out[mode] = got
+        ctx.close()
+    assert out["whole"][0].any() and out["whole"][3].any()
+    for a, b in zip(out["whole"][:-1], out["staged"][:-1]):
+        assert np.array_equal(a, b)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=12288, depth=0, seed=77), sc.source, sc.listener)
+    check_energy(out["staged"][-1], e32, e64, 4)
+
+
+# ---- cfg5 at its full size ---------------------------------------------------------------------------------------
+def test_cfg5_full_size_batched_frame_equals_eight_frames(pkg, scene_factory):
+    """BASELINE.json configs[4] at full size: 8 sources x 131 072 rays, one listener, depth 8, 8 bands, as ONE batched
+    frame (what bench.py times for cfg5 on one GPU) must give every source exactly the histogram and IR of its own frame —
+    bit for bit in deterministic mode — also pipelined, and with the batched reconstruct."""
+    sc = scene_factory("old_mine", 8)
+    pos = [np.asarray(x, np.float32) for x in sc.extra_sources[:8]]
+    p = pkg.default_params(num_rays=131072, depth=8, seed=0x5EED, flags=DET)
+    ctx, _ = make_ctx(pkg, sc)
+    srcs = [ctx.create_source(x) for x in pos]
+    want_e, want_ir = [], []
+    for s in srcs:
+        want_e.append(ctx.compute_energy_response(s, p).copy())
+        ctx.reconstruct_impulse_response(s, p)
+        want_ir.append(ctx.impulse_response(s, 0).copy())
+    assert all(e.any() for e in want_e) and not np.array_equal(want_e[0], want_e[1])
+    for pipelined in (0, 2):
+        ctx.set_pipelining(pipelined)
+        ctx.compute_energy_response_batch_async(srcs, p)
+        ctx.reconstruct_impulse_response_batch_async(srcs, p)
+        ctx.synchronize()
+        for s, e, ir in zip(srcs, want_e, want_ir):
+            assert np.array_equal(ctx.energy_buffer(s), e) and np.array_equal(ctx.impulse_response(s, 0), ir)
+    st = ctx.stats()
+    assert st["rays"] == 3 * 8 * 131072
+    ctx.close()
