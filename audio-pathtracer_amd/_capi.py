@@ -33,12 +33,13 @@ FLAG_MIS_BALANCE = 32
 FLAG_MATERIAL_LOBES = 64
 FLAG_ACCUMULATE_ENERGY = 128
 FLAG_DOUBLE_POSITIONS = 256
+NO_OBJECT = 0xFFFFFFFF
 
 # every symbol include/frequensee.h declares (tests check the library exports all of them)
 EXPORTS = [
     "fs_config_default", "fs_params_default", "fs_abi_version", "fs_context_create", "fs_context_destroy",
     "fs_last_error", "fs_context_advice", "fs_scene_set_triangles", "fs_scene_set_materials", "fs_scene_commit", "fs_source_create",
-    "fs_source_destroy", "fs_source_set_position", "fs_listener_set_position", "fs_compute_energy_response",
+    "fs_source_destroy", "fs_source_set_position", "fs_listener_set_position", "fs_source_set_object", "fs_listener_set_object", "fs_compute_energy_response",
     "fs_compute_energy_response_async", "fs_compute_energy_response_batch_async", "fs_energy_device_ptr", "fs_reconstruct_impulse_response",
     "fs_reconstruct_impulse_response_async", "fs_reconstruct_impulse_response_batch_async", "fs_synchronize", "fs_get_impulse_response", "fs_get_impulse_response_sequence",
     "fs_copy_impulse_response", "fs_copy_band_impulse_response", "fs_get_energy_buffer", "fs_flush_energy_buffer",
@@ -147,6 +148,7 @@ class Stats(C.Structure):
         ("walk_tri_fetches", C.c_uint64),
         ("any_node_fetches", C.c_uint64),
         ("any_tri_fetches", C.c_uint64),
+        ("planned_segments", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -192,6 +194,8 @@ def load():
         "fs_source_destroy": (C.c_int, [vp, i32]),
         "fs_source_set_position": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
         "fs_listener_set_position": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "fs_source_set_object": (C.c_int, [vp, i32, C.c_uint32]),
+        "fs_listener_set_object": (C.c_int, [vp, C.c_uint32]),
         "fs_compute_energy_response": (C.c_int, [vp, i32, C.POINTER(Params), f32p]),
         "fs_compute_energy_response_async": (C.c_int, [vp, i32, C.POINTER(Params)]),
         "fs_compute_energy_response_batch_async": (C.c_int, [vp, C.POINTER(C.c_int32), i32, C.POINTER(Params)]),

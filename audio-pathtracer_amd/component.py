@@ -204,6 +204,13 @@ class Context:
     def compute_energy_response_async(self, src, params):
         self.check(self.lib.fs_compute_energy_response_async(self.h, src, C.byref(params)))
 
+    def set_source_object(self, src, object_id=_capi.NO_OBJECT):
+        """the actor the source belongs to (ids of set_objects): its own walks ignore it (AddIgnoredActor, ARTS.cpp:322-327)"""
+        self.check(self.lib.fs_source_set_object(self.h, int(src), int(object_id)))
+
+    def set_listener_object(self, object_id=_capi.NO_OBJECT):
+        self.check(self.lib.fs_listener_set_object(self.h, int(object_id)))
+
     def compute_energy_response_batch_async(self, sources, params):
         """several sources in one traced frame (UpdateSource over ActiveSources): same result per source as separate calls"""
         arr = (C.c_int32 * len(sources))(*[int(x) for x in sources])

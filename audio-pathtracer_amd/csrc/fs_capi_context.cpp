@@ -632,7 +632,8 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < kScratchSets; ++k)
             for (int i = 0; i < kNumCounters; ++i) c[i] += cs[k][i];
-        ctx->stats.segments = c[0] + ctx->host_segments;
+        ctx->stats.segments = c[0];                              // counted by the walkers
+        ctx->stats.planned_segments = c[7] + ctx->host_segments;  // the plan pass's prediction (roulette off: depth x subpaths, on the host)
         ctx->stats.connections_tested = c[1];
         ctx->stats.deposits = c[2];
         ctx->stats.walk_node_fetches = c[3];

@@ -523,6 +523,9 @@ void frame_describe(fs_context* ctx, Frame& f) {
     kp.dpos = (p->flags & FS_FLAG_DOUBLE_POSITIONS) ? 1 : 0;
     kp.listener_radius = p->listener_radius;
     kp.source_radius = p->source_radius;
+    kp.src_object = s->object; kp.lis_object = ctx->listener_object;   // AddIgnoredActor ARTS.cpp:322-327
+    kp.ignore_on = ctx->listener_object != FS_NO_OBJECT ? 1 : 0;
+    for (int i = 0; i < f.count; ++i) if (f.srcs[i]->object != FS_NO_OBJECT) kp.ignore_on = 1;
     f.mis = (p->flags & FS_FLAG_MIS_BALANCE) != 0;
     f.all_conn = f.mis || (p->flags & FS_FLAG_ALL_CONNECTIONS) != 0;
     kp.mis = f.mis ? 1 : 0;
@@ -536,7 +539,7 @@ void frame_describe(fs_context* ctx, Frame& f) {
     // launch carries one frame's worth of work and no chain longer than a stage.
     const bool plain = !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY |
                                      FS_FLAG_DOUBLE_POSITIONS));
-    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) &&
+    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on &&
                 (p->depth > 0 || (f.unbounded && ctx->pipelining >= 2));
     f.stages.clear();
     if (f.pipe_ok && f.unbounded && !ctx->stage_bounds.empty()) {
@@ -551,7 +554,7 @@ void frame_describe(fs_context* ctx, Frame& f) {
         for (int bound : bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
-    } else if (!f.pipe_ok && f.unbounded && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && ctx->profiling < 3 &&
+    } else if (!f.pipe_ok && f.unbounded && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on && ctx->profiling < 3 &&
                !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from) {
         // A depth = 0 frame that is waited for (not held): the same stages, one launch after the other on the stream.  The
         // frame's time is its longest walk — a chain of ~ log(subpaths) / log(1 / rr) dependent bounces — and what a bounce
@@ -649,8 +652,8 @@ int frame_resources(fs_context* ctx, Frame& f) {
     }
     if (f.batch) {
         // per-frame tables in one pinned staging block: energy pointers [count] | fixed-point buffer pointers [count] |
-        // source positions [count][3].  The block is rewritten only after the previous frame's copy has left it.
-        const size_t bytes = 2 * (size_t)count * sizeof(void*) + (size_t)count * 3 * sizeof(float);
+        // source positions + actor ids [count][4].  The block is rewritten only after the previous frame's copy has left it.
+        const size_t bytes = 2 * (size_t)count * sizeof(void*) + (size_t)count * 4 * sizeof(float);
         if (bytes > ctx->batch_cap) {
             FS_FLUSH(ctx);   // a held batched frame still carries pointers into the block that is about to be freed
             FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -679,7 +682,8 @@ int frame_resources(fs_context* ctx, Frame& f) {
             for (int i = 0; i < count; ++i) {
                 t_en[i] = f.srcs[i]->d_energy[f.cur_of[i]];
                 t_fx[i] = f.fixed ? (void*)f.srcs[i]->d_fixed[f.cur_of[i]] : nullptr;
-                std::memcpy(t_pos + 3 * i, f.group ? f.group[i].pos : f.srcs[i]->pos, sizeof(float) * 3);
+                std::memcpy(t_pos + 4 * i, f.group ? f.group[i].pos : f.srcs[i]->pos, sizeof(float) * 3);
+                std::memcpy(t_pos + 4 * i + 3, &f.srcs[i]->object, sizeof(uint32_t));   // the source's actor (its walks ignore it)
             }
         }
         bool found = false;   // any slot that already holds exactly this table will do (it is only read)
@@ -918,6 +922,7 @@ bool groupable(const fs_context* ctx, const fs_params* p) {
     if (p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY | FS_FLAG_DOUBLE_POSITIONS))
         return false;
     if (p->listener_radius > 0.0f || p->source_radius > 0.0f) return false;
+    if (ctx->listener_object != FS_NO_OBJECT) return false;   // (a source with an actor of its own is checked by the caller)
     const bool unbounded = p->depth == 0 && p->russian_roulette && p->rr_prob < 1.0f;
     if (!(p->depth > 0 || (unbounded && ctx->pipelining >= 2))) return false;
     return (uint64_t)ctx->frames_per_launch * (p->num_rays / 2) <= (1ull << 29);
@@ -1035,6 +1040,22 @@ int fs_source_set_position(fs_context* ctx, fs_source h, const float xyz[3]) {
     return FS_OK;
 }
 
+int fs_source_set_object(fs_context* ctx, fs_source h, uint32_t object_id) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    Source* s = get_source(ctx, h);
+    if (!s) return ctx->fail(FS_ERR_BAD_HANDLE, "bad source handle");
+    if (object_id != s->object) FS_FLUSH(ctx);   // frames that wait for their launch were asked for with the old setting
+    s->object = object_id;
+    return FS_OK;
+}
+
+int fs_listener_set_object(fs_context* ctx, uint32_t object_id) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (object_id != ctx->listener_object) FS_FLUSH(ctx);
+    ctx->listener_object = object_id;
+    return FS_OK;
+}
+
 int fs_listener_set_position(fs_context* ctx, const float xyz[3]) {
     if (!ctx || !xyz) return FS_ERR_INVALID_ARGUMENT;
     std::memcpy(ctx->listener, xyz, sizeof(float) * 3);
@@ -1053,7 +1074,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     fs_params def;
     const fs_params* q = p;
     if (!q) { fs_params_default(&def); q = &def; }
-    if (q->struct_size == sizeof(fs_params) && groupable(ctx, q)) {
+    if (q->struct_size == sizeof(fs_params) && s->object == FS_NO_OBJECT && groupable(ctx, q)) {
         if (!ctx->group.empty() && (!same_but_seed(ctx->group[0].p, *q) || std::memcmp(ctx->group[0].lis, ctx->listener, sizeof(ctx->listener)) != 0)) {
             const int gr = dispatch_group(ctx);   // (a batched frame has ONE listener position)
             if (gr) return gr;

@@ -62,6 +62,7 @@ static_assert(kEnergyBufs >= 4 * (kMaxWalkParts + 3), "four frames of one source
 struct Source {
     bool alive = false;
     float pos[3] = {0, 0, 0};
+    uint32_t object = FS_NO_OBJECT;    // the actor this source belongs to: its own walks ignore it (fs_source_set_object)
     // Two energy buffers [B][bins], alternating per frame: while the tail stream still reduces /
     // reconstructs frame f from one of them, the compute stream already traces frame f+1 into the other.
     float* d_energy[kEnergyBufs] = {};
@@ -185,6 +186,7 @@ struct fs_context {
     HostBVH bvh;
 
     float listener[3] = {0, 0, 0};
+    uint32_t listener_object = FS_NO_OBJECT;   // fs_listener_set_object
     std::vector<Source*> sources;
 
     // multi-GPU: RCCL communicator over the ranks that share the pairs of every frame
@@ -240,6 +242,7 @@ struct fs_context {
     struct GroupEntry {
         Source* s = nullptr; fs_params p; bool want_recon = false; fs_params recon;
         float pos[3] = {}, lis[3] = {};   // source and listener position AT THE CALL (either may move before the group is sent off)
+        uint32_t object = FS_NO_OBJECT;
     };
     std::vector<GroupEntry> group;
     int frames_per_launch = 1;

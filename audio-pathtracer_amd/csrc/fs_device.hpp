@@ -591,6 +591,7 @@ struct Walker {          // ARTS.cpp:287-291 state + bookkeeping
     uint32_t mat;
     uint32_t lobe;     // lobe picked at the current vertex << kLobeShift (FS_FLAG_MATERIAL_LOBES), else 0
     float prob, prob_new;
+    uint32_t ign;      // the actor this walk ignores (EXT instantiations; FS_NO_OBJECT: none)
 };
 
 // low seed word of item `sid` of a batched frame (grouped frames carry one seed per item; kp.item_seeds <= 4)
@@ -649,8 +650,10 @@ __device__ __forceinline__ void walker_start(Walker& w, uint32_t g, uint32_t slo
     if (kp.src_table) {   // batched frame (wave-uniform): several sources' pairs end to end, same RNG pairs for each
         const uint32_t sid = w.li / kp.pairs_per_source;
         w.pair = kp.pair_begin + (w.li - sid * kp.pairs_per_source);
-        if (!w.side) { w.px = kp.src_table[3 * sid]; w.py = kp.src_table[3 * sid + 1]; w.pz = kp.src_table[3 * sid + 2]; }
+        if (!w.side) { w.px = kp.src_table[4 * sid]; w.py = kp.src_table[4 * sid + 1]; w.pz = kp.src_table[4 * sid + 2]; }
     }
+    w.ign = w.side ? kp.lis_object : kp.src_object;   // AddIgnoredActor ARTS.cpp:322-327 (used by the EXT instantiations only)
+    if (kp.src_table && !w.side) w.ign = __float_as_uint(kp.src_table[4 * (w.li / kp.pairs_per_source) + 3]);
     w.dpx = (double)w.px; w.dpy = (double)w.py; w.dpz = (double)w.pz;
     w.nx = 0.f; w.ny = 0.f; w.nz = 0.f;
     w.has_normal = false;
@@ -769,7 +772,7 @@ __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, c
         float c[3] = {w.side ? kp.src[0] : kp.lis[0], w.side ? kp.src[1] : kp.lis[1], w.side ? kp.src[2] : kp.lis[2]};
         if (w.side && kp.src_table) {   // batched frame: this pair's source
             const uint32_t sid = w.li / kp.pairs_per_source;
-            c[0] = kp.src_table[3 * sid]; c[1] = kp.src_table[3 * sid + 1]; c[2] = kp.src_table[3 * sid + 2];
+            c[0] = kp.src_table[4 * sid]; c[1] = kp.src_table[4 * sid + 1]; c[2] = kp.src_table[4 * sid + 2];
         }
         float ts;
         if (sphere_hit(ray, c, other_radius, kp.max_trace_dist, ts) && (!hit || ts <= t)) {
@@ -957,7 +960,7 @@ __device__ __forceinline__ void plan_body(const uint32_t bid, const uint32_t nbl
         if (perm && g < total) perm[(size_t)L[it] * total + s_base[L[it]] + rank[it]] = g;
     }
     // work counter: walk segments of this frame (a walk of length L traces L rays), one atomic per workgroup
-    if (threadIdx.x == 0 && s_seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord), (unsigned long long)s_seg);
+    if (threadIdx.x == 0 && s_seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord) + 7, (unsigned long long)s_seg);   // fs_stats.planned_segments
 }
 
 
@@ -1151,10 +1154,10 @@ __device__ __forceinline__ bool trav_shared(const DeviceScene& sc, bool has_ray,
     return false;
 }
 // the three uses: BDPT walk, ConnectSubpaths' visibility ray, legacy tracer
-template <bool COUNT = false>
+template <bool COUNT = false, bool IGN = false>
 __device__ __forceinline__ void trav_run_shared(const DeviceScene& sc, const Ray& own, Trav& T, int* stack, int* s_dyn,
-                                                float tmax, bool has_ray = true) {
-    trav_shared<false, false, COUNT>(sc, has_ray, own, tmax, 0xFFFFFFFFu, T, stack, s_dyn + (size_t)sc.stack_rows * kBlock);
+                                                float tmax, bool has_ray = true, uint32_t ignore = 0xFFFFFFFFu) {
+    trav_shared<false, IGN, COUNT>(sc, has_ray, own, tmax, ignore, T, stack, s_dyn + (size_t)sc.stack_rows * kBlock);
 }
 template <bool COUNT = false>
 __device__ __forceinline__ bool trav_any_shared(const DeviceScene& sc, bool has_ray, const Ray& own, float tmax,
@@ -1172,6 +1175,20 @@ __device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_co
     if (nt) atomicAdd(&counters[first_counter + 1], (unsigned long long)nt);
 }
 
+// Work counter "walk segments" (fs_stats.segments): what the walkers of this wave actually traced — every applied hit or
+// miss is one closest-hit query — summed in LDS (ds_add_u32) by the lanes that are still there and added to the frame
+// scratch by one of them: one global atomic per wave.  (The plan pass predicts the same number from the RNG stream alone:
+// fs_stats.planned_segments; the tests assert that the two agree.)  s_seg: one word per wave, zeroed by the wave's first
+// lane before anything can leave the kernel.
+__device__ __forceinline__ void count_walk_segments(unsigned* s_seg, const unsigned mine, const unsigned* scratch) {
+    if (mine) atomicAdd(s_seg, mine);
+    const unsigned long long here = __ballot(true);
+    if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)here) - 1)) {
+        const unsigned total = *reinterpret_cast<volatile unsigned*>(s_seg);
+        if (total) atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(scratch) + kCounterWord), (unsigned long long)total);
+    }
+}
+
 template <int LOBES, bool COUNT, bool EXT = false>
 __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
@@ -1179,6 +1196,8 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
+    __shared__ unsigned s_seg[kBlock / 64];
+    if ((threadIdx.x & 63u) == 0u) s_seg[threadIdx.x >> 6] = 0u;
     if (perm) {
         for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
     }
@@ -1190,6 +1209,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     Walker w;
     walker_start(w, g, slot, kp, st, sr.begin == 0);
     if (sr.begin > 0 && !walker_resume(w, st, sr.begin)) return;
+    const int k_first = w.k;
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
 #ifdef FS_WAVE_TIMELINE
@@ -1207,7 +1227,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
 #ifdef FS_WAVE_TIMELINE
         const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
 #endif
-        trav_run_shared<COUNT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist);
+        trav_run_shared<COUNT, EXT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, true, w.ign);   // (EXT: the walk's own actor is ignored)
 #ifdef FS_WAVE_TIMELINE
         tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
         ++tl_seg;
@@ -1215,6 +1235,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
+    count_walk_segments(&s_seg[threadIdx.x >> 6], (unsigned)(w.k - k_first), scratch);
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 #ifdef FS_WAVE_TIMELINE
     {
@@ -1258,10 +1279,14 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
     bool alive = lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
     int* stack = &s_stack[threadIdx.x];
+    __shared__ unsigned s_seg[kBlock / 64];
+    if (lane == 0u) s_seg[threadIdx.x >> 6] = 0u;
     Walker w;
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
                  slot, kp, st, alive && sr.begin == 0);
     if (alive && sr.begin > 0) alive = walker_resume(w, st, sr.begin);
+    const int k_first = w.k;
+    const bool mine = alive;
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
     while (true) {
@@ -1279,10 +1304,11 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
         }
         if (__ballot(go) == 0ull) break;
         Trav T;
-        trav_run_shared<COUNT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go);
+        trav_run_shared<COUNT, EXT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go, w.ign);
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
+    count_walk_segments(&s_seg[threadIdx.x >> 6], mine ? (unsigned)(w.k - k_first) : 0u, scratch);
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 }
 
@@ -1593,6 +1619,10 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
                  slot, kp, st, alive && sr.begin == 0);
     if (alive && sr.begin > 0) alive = walker_resume(w, st, sr.begin);
+    __shared__ unsigned s_seg[16];                          // (up to 16 waves per workgroup)
+    if (lane == 0u) s_seg[threadIdx.x >> 6] = 0u;
+    const int k_first = w.k;
+    const bool mine = alive;
     Ray ray = make_ray(0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
 #ifdef FS_WAVE_TIMELINE
@@ -1621,7 +1651,7 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
         const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
         tl_next += tl_a - tl_n;
 #endif
-        trav_coop<false, COUNT>(sc, rays_per_wave, go, ray, kp.max_trace_dist, 0xFFFFFFFFu, T, s_dyn, wl, st.overflow);
+        trav_coop<EXT, COUNT>(sc, rays_per_wave, go, ray, kp.max_trace_dist, w.ign, T, s_dyn, wl, st.overflow);
 #ifdef FS_WAVE_TIMELINE
         tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
         tl_steps += (unsigned long long)T.sp;
@@ -1631,6 +1661,7 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
+    count_walk_segments(&s_seg[threadIdx.x >> 6], mine ? (unsigned)(w.k - k_first) : 0u, scratch);
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 #ifdef FS_WAVE_TIMELINE
     if (lane == 0u && g_wave_buf) {   // [0] start, [1] end (100 MHz) | cycles: [2] in queries, [3] in all, [6] in the loop head | [4] traversal steps, [5] queries
@@ -1666,12 +1697,12 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
     const int nb = kp.num_bins, W = kp.hist_window, NB = band_count<B>(kp);   // LDS histogram = the first W bins of every band (see KParams)
     int* s_share = reinterpret_cast<int*>(s_hist + (size_t)NB * W);   // work-sharing area of trav_any_shared
     __shared__ int s_lo, s_hi;
-    __shared__ unsigned s_dep;
+    __shared__ unsigned s_dep, s_tst;
 #ifdef FS_WAVE_TIMELINE
     unsigned long long tl[6] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0};
 #endif
     for (int i = threadIdx.x; i < NB * W; i += kBlock) s_hist[i] = 0.0f;
-    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; }
+    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; s_tst = 0u; }
     // this frame's walk is over: rearm the frame scratch (queue head, plan counts and cursors) for the next one
     if (bid == 0u)
         for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
@@ -1679,7 +1710,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 
     const uint32_t n = kp.num_local;
     const uint32_t total = 2u * n;
-    unsigned my_deposits = 0;
+    unsigned my_deposits = 0, my_tested = 0;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
     // whole workgroups step through the pairs: every lane of a wave takes part in the shared visibility queries,
     // also the ones without a pair or without a segment to test
@@ -1724,7 +1755,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
             if (kp.listener_radius > 0.0f && sphere_hit(ray, kp.lis, kp.listener_radius, tmax, ts)) sphere_blocked = true;
             if (kp.source_radius > 0.0f) {
                 float c[3] = {kp.src[0], kp.src[1], kp.src[2]};
-                if (kp.src_table) { const uint32_t sid = lc / kp.pairs_per_source; c[0] = kp.src_table[3 * sid]; c[1] = kp.src_table[3 * sid + 1]; c[2] = kp.src_table[3 * sid + 2]; }
+                if (kp.src_table) { const uint32_t sid = lc / kp.pairs_per_source; c[0] = kp.src_table[4 * sid]; c[1] = kp.src_table[4 * sid + 1]; c[2] = kp.src_table[4 * sid + 2]; }
                 if (sphere_hit(ray, c, kp.source_radius, tmax, ts)) sphere_blocked = true;
             }
             if (sphere_blocked) has_ray = false;   // settled without a traversal
@@ -1732,6 +1763,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #ifdef FS_WAVE_TIMELINE
         if (!tl[1]) tl[1] = __builtin_amdgcn_s_memrealtime();   // first chunk: set-up and end-state loads done
 #endif
+        my_tested += active ? 1u : 0u;                                // one ConnectSubpaths per pair (ARTS.cpp:232 counts the connected ones)
         const bool hit = trav_any_shared<COUNT>(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share, &cnt_nv, &cnt_nt);
 #ifdef FS_WAVE_TIMELINE
         if (!tl[2]) tl[2] = __builtin_amdgcn_s_memrealtime();   // first chunk: visibility queries done
@@ -1830,15 +1862,16 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
     if (COUNT) add_fetch_counts(queue_head, 5, cnt_nv, cnt_nt);
     {   // work counters: summed per wave, then per workgroup in LDS — one global atomic per workgroup (thousands of
         // atomics on one address cost the kernel ~10 %)
-        unsigned d = my_deposits;
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+        unsigned d = my_deposits, t = my_tested;
+        for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); t += __shfl_down(t, o); }
         if ((threadIdx.x & 63u) == 0u && d) atomicAdd(&s_dep, d);
+        if ((threadIdx.x & 63u) == 0u && t) atomicAdd(&s_tst, t);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
         if (s_dep) atomicAdd(&counters[2], (unsigned long long)s_dep);
-        if (bid == 0u) atomicAdd(&counters[1], (unsigned long long)n);   // one test per pair
+        if (s_tst) atomicAdd(&counters[1], (unsigned long long)s_tst);   // the pairs this workgroup's lanes tested
     }
     if (!BATCH) {
         const int lo = s_lo, hi = s_hi;

@@ -113,7 +113,7 @@ bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStrea
     for (int i = 0; i < f.num_walk; ++i) {
         const WalkPart& p = f.walk[i];
         if (!FS_SHARED_WALK(p.wl)) return false;
-        if (p.kp.lobes || p.kp.count || p.kp.dpos || p.kp.listener_radius > 0.0f || p.kp.source_radius > 0.0f || p.kp.num_local == 0)
+        if (p.kp.lobes || p.kp.count || p.kp.dpos || p.kp.ignore_on || p.kp.listener_radius > 0.0f || p.kp.source_radius > 0.0f || p.kp.num_local == 0)
             return false;   // the default instantiations only
         WalkArgs& w = a.walk[a.num_walk++];
         w.kp = p.kp; w.st = p.st; w.scratch = p.wl.queue_head; w.perm = p.perm; w.stage = p.stage;

@@ -122,14 +122,16 @@ struct KParams {
     uint32_t num_local;    // pairs traced by this rank (all sources of a batched frame together)
     uint32_t pairs_per_source;   // == num_local for one source; a batched frame lays its sources' pairs end to end:
                                  // pair li belongs to source li / pairs_per_source, RNG pair index li % pairs_per_source
-    const float* src_table;      // [sources][3] source positions of a batched frame (device), else null (kp.src)
+    const float* src_table;      // [sources][4] source positions (+ the source's actor id as bits) of a batched frame (device), else null (kp.src)
+    uint32_t src_object, lis_object;   // the actors the walks ignore (fs_source_set_object / fs_listener_set_object), FS_NO_OBJECT: none
     uint32_t item_seed[4];       // grouped frames (fs_set_frames_per_launch): the low seed word of each item of the batched
     int32_t item_seeds;          //   frame (item_seeds of them; 0 = every item uses seed_lo, the batch of one call)
     int32_t depth;         // max segments per subpath: 1..FS_MAX_DEPTH, or main_levels + over_levels for depth = 0 (a bound the
                            //   roulette practically never reaches: 0.9^512 ~ 4e-24)
     int32_t mis_depth;     // depth cap D of the all-connections weights (kUnboundedDepth for depth = 0)
     int32_t russian_roulette;
-    int32_t cosine;
+    int16_t cosine;
+    int16_t ignore_on;     // some walk of the frame ignores an actor: the EXT instantiations run (16 bits each: the fused launch's 4 KB of arguments are full)
     int32_t lobes;         // 1 = FS_FLAG_MATERIAL_LOBES: the walk picks a specular / diffuse / transmitted lobe per vertex
     int32_t mis;           // all-connections mode: 1 = balance-heuristic weights, 0 = uniform
     float rr_prob, max_trace_dist, surface_offset, connect_pullback;
@@ -249,7 +251,7 @@ constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
 // frame scratch allocation: kScratchWords rearmed every frame, then (8-byte aligned) kNumCounters u64 work
 // counters that accumulate until fs_reset_stats: walk segments, connections tested, deposits
 constexpr int kCounterWord = (kScratchWords + 1) & ~1;
-constexpr int kNumCounters = 8;   // walk segments, connections tested, deposits | level 3: walk node / triangle records, any-hit node / triangle records | spare
+constexpr int kNumCounters = 8;   // walk segments (observed), connections tested, deposits | level 3: walk node / triangle records, any-hit node / triangle records | planned segments
 constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
 // nullptr when no plan applies (the caller then clears the energy buffer itself)

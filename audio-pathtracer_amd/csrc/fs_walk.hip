@@ -131,19 +131,19 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
     // record-fetch counting (fs_set_profiling level 3) exists for the default walk only (no lobes)
 #define FS_LAUNCH_WALK(K, GRID, ...)                                                                        \
     do {                                                                                                    \
-        if (kp.dpos || kp.listener_radius > 0.0f || kp.source_radius > 0.0f) { allow_lds(K<0, false, true>, lds); hipLaunchKernelGGL((K<0, false, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); } \
+        if (kp.dpos || kp.ignore_on || kp.listener_radius > 0.0f || kp.source_radius > 0.0f) { allow_lds(K<0, false, true>, lds_ext); hipLaunchKernelGGL((K<0, false, true>), dim3(GRID), dim3(kBlock), lds_ext, s, __VA_ARGS__); } \
         else if (kp.lobes) { allow_lds(K<1, false>, lds); hipLaunchKernelGGL((K<1, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }   \
         else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
         else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \
     } while (0)
     if (shared && wl.coop && sc.coop && coop_rays_per_wave(wl.rays_per_wave)) {   // a handful of subpaths per wave: every query searched by a whole group of lanes
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
-        const bool plain = !(kp.dpos || kp.listener_radius > 0.0f || kp.source_radius > 0.0f || kp.lobes || kp.count);
+        const bool plain = !(kp.dpos || kp.ignore_on || kp.listener_radius > 0.0f || kp.source_radius > 0.0f || kp.lobes || kp.count);
         // workgroups of eight waves when the frame needs more than four waves per CU (and the instantiation exists)
         const int W = plain && waves > 4u * (uint32_t)std::max(wl.num_cus, 1) ? kCoopBigWaves : kBlock / 64;
         const uint32_t blocks = (waves + (uint32_t)W - 1) / (uint32_t)W;
         sc.lds_nodes = coop_resident_nodes(sc, W, blocks, wl.num_cus);
-        const size_t lds = coop_lds_bytes(W, sc.lds_nodes);
+        const size_t lds = coop_lds_bytes(W, sc.lds_nodes), lds_ext = lds;
         if (W == kCoopBigWaves) {
             allow_lds(walk_kernel_coop_big, lds);
             hipLaunchKernelGGL(walk_kernel_coop_big, dim3(blocks), dim3(64 * W), lds, s, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
@@ -153,7 +153,7 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
         return;
     }
     if (shared && wl.rays_per_wave > 0 && wl.rays_per_wave < 64) {   // small frame: sparse waves, idle lanes help
-        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes, lds_ext = stack_bytes(sc) + kShareIgnLdsBytes;   // (EXT: + the ignored actor per ray)
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
         if (!attach_deep(sc, blocks)) return;
@@ -162,7 +162,7 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
     }
     if (!attach_deep(sc, full)) return;
     if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
-        const size_t lds = stack_bytes(sc) + kShareLdsBytes;
+        const size_t lds = stack_bytes(sc) + kShareLdsBytes, lds_ext = stack_bytes(sc) + kShareIgnLdsBytes;
         FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm, stage);
         return;
     }

@@ -37,7 +37,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: only this header is exported */
 #endif
 
-#define FS_ABI_VERSION 4
+#define FS_ABI_VERSION 5
 #define FS_MAX_BANDS 8
 #define FS_NO_MATERIAL 0xFFFFu /* actor without UAcousticGeometryComponent / Material (ARTS.cpp:383) */
 #define FS_MAX_DEPTH 64        /* largest explicit depth cap.  depth == 0 means NO cap, like the reference's while (true)
@@ -168,7 +168,7 @@ typedef struct fs_stats {
     uint32_t bvh_depth;          /* depth of the binary tree before the 4-wide collapse */
     uint64_t scene_bytes;        /* device bytes of BVH + triangles + materials */
     /* work counters kept on the device since the last fs_reset_stats */
-    uint64_t segments;           /* walk segments = closest-hit queries (counted by the length plan; 0 when it is off) */
+    uint64_t segments;           /* walk segments = closest-hit queries, counted by the walkers as they apply each hit or miss */
     uint64_t connections_tested; /* any-hit queries: one per pair, or one per (i, j) in all-connections mode */
     uint64_t deposits;           /* unobstructed connections = paths evaluated and deposited */
     /* profiling level 3 only (counting instantiations of the kernels, not for timed frames): records the traversal
@@ -176,6 +176,9 @@ typedef struct fs_stats {
      * by the any-hit queries of the connections: the kernel's OWN algorithmic bytes (SURVEY.md 8d prices the oracle's
      * BVH2 instead) */
     uint64_t walk_node_fetches, walk_tri_fetches, any_node_fetches, any_tri_fetches;
+    uint64_t planned_segments;   /* walk segments as the plan pass predicts them from the RNG stream alone (the roulette does not
+                                  * depend on geometry); `segments`, `connections_tested` and `deposits` are what the walk and the
+                                  * connect kernels counted as they worked: both must agree (the tests assert it) */
 } fs_stats;
 
 /* ---- lifecycle: UAudioRayTracingSubsystem::Initialize/Deinitialize (ARTS.cpp:32-42) ------------- */
@@ -232,6 +235,14 @@ int fs_source_create(fs_context* ctx, fs_source* out);
 int fs_source_destroy(fs_context* ctx, fs_source src);
 int fs_source_set_position(fs_context* ctx, fs_source src, const float xyz[3]);
 int fs_listener_set_position(fs_context* ctx, const float xyz[3]);
+/* The actor a walk starts from is ignored by that walk's traces (FCollisionQueryParams::AddIgnoredActor, ARTS.cpp:322-327): a
+ * source whose own mesh is registered geometry does not trap its walks inside it.  object_id = the actor's id among the
+ * ids of fs_scene_set_objects; FS_NO_OBJECT (the default) = the end point belongs to no registered actor.  The walks from
+ * the source skip the source's actor, the walks from the listener the listener's; ConnectSubpaths ignores nothing
+ * (:252-254).  Takes effect with the next traced frame; such frames are not held by fs_set_pipelining. */
+#define FS_NO_OBJECT 0xFFFFFFFFu
+int fs_source_set_object(fs_context* ctx, fs_source src, uint32_t object_id);
+int fs_listener_set_object(fs_context* ctx, uint32_t object_id);
 
 /* ---- the hot path ------------------------------------------------------------------------------- */
 /* ComputeEnergyResponse() == UpdateSource up to the deposit (ARTS.cpp:128-173): GenerateFullPaths

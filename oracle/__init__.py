@@ -50,6 +50,8 @@ class Params(C.Structure):
         ("flags", C.c_uint32),
         ("listener_radius", C.c_float),
         ("source_radius", C.c_float),
+        ("source_object", C.c_uint32),
+        ("listener_object", C.c_uint32),
     ]
 
 

@@ -40,6 +40,7 @@ void fso_params_default(fso_params* p) {
     p->sound_speed = 343.0f;    /* ARTS.cpp:362 */
     for (int b = 0; b < FSO_MAX_BANDS; ++b) p->air_absorption[b] = 0.05f; /* ARTS.cpp:395 */
     p->flags = 0;
+    p->source_object = FSO_NO_OBJECT; p->listener_object = FSO_NO_OBJECT;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -423,7 +424,6 @@ static void hit_normal(const fso_tri* tr, const float d[3], float n[3]) {
     n[0] = nx; n[1] = ny; n[2] = nz;
 }
 
-#define FSO_NO_OBJECT 0xFFFFFFFFu
 static int32_t closest_impl(const fso_scene* s, const float o[3], const float d[3], float tmax, int32_t brute,
                             uint32_t ignore_object, float* t_out, int32_t* tri_out, float n_out[3],
                             fso_counters* c) {
@@ -648,7 +648,8 @@ static int32_t generate_path(const fso_scene* s, const fso_params* p, uint32_t p
         /* 3. closest hit on [pos, pos + dir * MAX_RAYCAST_DIST] ARTS.cpp:339-342 */
         float t, hn[3]; int32_t tri;
         if (!shifted) for (int q = 0; q < 3; ++q) org[q] = (float)pos[q];
-        int hit = fso_trace_closest(s, org, dir, p->max_trace_dist, brute, &t, &tri, hn, c);
+        /* the walk ignores the actor it starts from (AddIgnoredActor ARTS.cpp:322-327) */
+        int hit = closest_impl(s, org, dir, p->max_trace_dist, brute, side == 0 ? p->source_object : p->listener_object, &t, &tri, hn, c);
         /* the OTHER end point's collision sphere (ECC_Pawn is queried, the walk's own actor is ignored: ARTS.cpp:322-334);
          * it wins ties with a triangle, like the pawn in the legacy tracer */
         int on_sphere = 0;

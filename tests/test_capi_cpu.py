@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_struct_layouts_match_header(pkg):
     lib = pkg._capi.load()
-    assert lib.fs_abi_version() == 4
+    assert lib.fs_abi_version() == 5
     p = pkg.default_params()
     c = pkg.default_config()
     assert p.struct_size == C.sizeof(pkg._capi.Params)

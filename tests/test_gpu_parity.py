@@ -225,8 +225,12 @@ def test_energy_parity_baseline_configs(pkg, oracle_mod, scene_factory, name, ba
     e32, e64, cnt = osc.compute_energy_mt(op, sc.source, sc.listener, 8) if rays > 100000 else \
         osc.compute_energy(op, sc.source, sc.listener)
     assert cnt.connected > 0
-    st = ctx.stats()                                  # device-side work counters == the oracle's, exactly
+    # device-side work counters == the oracle's, exactly.  All three are OBSERVED work since round 4: the walkers count every
+    # hit or miss they apply, the connect lanes every pair they test and every deposit; the plan pass's prediction from the
+    # RNG stream alone (planned_segments) must agree with what the walk then did
+    st = ctx.stats()
     assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+    assert st["planned_segments"] == st["segments"]
     if rays > 100000:
         assert np.array_equal(e_gpu != 0, e64 != 0)
         for b in range(bands):

@@ -577,3 +577,28 @@ def test_connection_into_a_collision_sphere_is_blocked():
     for k, v in enumerate((0.0, 40.0, 100.0)): f.pos[k] = v
     for k, v in enumerate((300.0, 40.0, 100.0)): b.pos[k] = v
     assert lib.fso_connect_ep(s.h, oracle.C.byref(p), oracle.C.byref(f), oracle.C.byref(b), src, lis, None) == 1
+
+
+def test_kat_a_walk_ignores_its_own_actor(oracle_mod):
+    """AddIgnoredActor (ARTS.cpp:322-327) by hand: a source at the origin inside a box of half-width 30 (actor 7) inside a
+    big box of half-width 1000 (other actors).  A source walk's first hit is on the small box (t <= 30 * sqrt(3)) without the
+    actor set, and on the big one (t >= 1000 - 0.1) with source_object = 7; a listener-side walk from the same point still
+    hits the small box (the listener's actor is another one)."""
+    def box(h):
+        v = np.array([[x, y, z] for x in (-h, h) for y in (-h, h) for z in (-h, h)], np.float64)
+        quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+        return np.array([[v[a], v[b], v[c]] for a, b, c, d in quads] + [[v[a], v[c], v[d]] for a, b, c, d in quads], np.float32)
+    tris = np.concatenate([box(1000.0), box(30.0)])
+    obj = np.concatenate([np.arange(12, dtype=np.uint32) + 100, np.full(12, 7, np.uint32)])
+    osc = oracle_mod.Scene(tris, np.zeros(24, np.uint16), np.full((1, 1), 0.5, np.float32))
+    osc.set_objects(obj)
+    o = np.zeros(3, np.float32)
+    for pair in range(40):
+        plain = osc.generate_path(oracle_mod.default_params(depth=1, russian_roulette=0), pair, 0, o)
+        own = osc.generate_path(oracle_mod.default_params(depth=1, russian_roulette=0, source_object=7), pair, 0, o)
+        lis = osc.generate_path(oracle_mod.default_params(depth=1, russian_roulette=0, source_object=7), pair, 1, o)
+        d_plain = np.linalg.norm(np.asarray(plain[1].pos[:], np.float64))
+        d_own = np.linalg.norm(np.asarray(own[1].pos[:], np.float64))
+        d_lis = np.linalg.norm(np.asarray(lis[1].pos[:], np.float64))
+        assert d_plain <= 30.0 * np.sqrt(3.0) + 1e-3 and d_lis <= 30.0 * np.sqrt(3.0) + 1e-3
+        assert 1000.0 - 0.2 <= d_own <= 1000.0 * np.sqrt(3.0)

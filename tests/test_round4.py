@@ -233,3 +233,58 @@ def test_cfg5_full_size_batched_frame_equals_eight_frames(pkg, scene_factory):
     st = ctx.stats()
     assert st["rays"] == 3 * 8 * 131072
     ctx.close()
+
+
+# ---- the walk's own actor -----------------------------------------------------------------------------------------
+def _room_with_a_box_around_the_source(pkg):
+    """the shoebox room + a closed 60 cm box (actor 7) around the source: the source sits INSIDE its own mesh"""
+    sc = pkg.scenes.shoebox(1)
+    c = np.asarray(sc.source, np.float64)
+    h = 30.0
+    v = np.array([[x, y, z] for x in (-h, h) for y in (-h, h) for z in (-h, h)]) + c
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    box = np.array([[v[a], v[b], v[cc]] for a, b, cc, d in quads] + [[v[a], v[cc], v[d]] for a, b, cc, d in quads], np.float32)
+    tris = np.concatenate([np.asarray(sc.triangles, np.float32).reshape(-1, 3, 3), box])
+    mats = np.concatenate([np.asarray(sc.material_ids, np.uint16), np.zeros(len(box), np.uint16)])
+    obj = np.concatenate([np.arange(len(tris) - len(box), dtype=np.uint32) + 100, np.full(len(box), 7, np.uint32)])
+    return sc, tris, mats, obj
+
+
+@pytest.mark.parametrize("rays,depth", [(2000, 0), (32768, 6)])
+def test_a_walk_ignores_the_actor_it_starts_from(pkg, oracle_mod, rays, depth):
+    """GeneratePath ignores the walking actor and its mesh (AddIgnoredActor, ARTS.cpp:322-327); ConnectSubpaths ignores
+    nothing (:252-254).  A source inside its own registered box mesh: without the actor set every source walk is trapped in
+    the box and every connection from inside it is blocked by it — no energy; with fs_source_set_object the walks leave,
+    the connections from F_1.. (outside) see the listener, and the frame equals the oracle's with the same source_object;
+    a batched frame carries each source's own actor."""
+    sc, tris, mats, obj = _room_with_a_box_around_the_source(pkg)
+    ctx = pkg.Context(num_bands=1)
+    ctx.set_scene(tris, mats, sc.absorption, object_ids=obj)
+    ctx.set_listener(sc.listener)
+    s = ctx.create_source(sc.source)
+    p = pkg.default_params(num_rays=rays, depth=depth, seed=31)
+    trapped = ctx.compute_energy_response(s, p).copy()
+    assert not trapped.any()
+    ctx.set_source_object(s, 7)
+    free = ctx.compute_energy_response(s, p).copy()
+    st = ctx.stats()
+    osc = oracle_mod.Scene(tris, mats, sc.absorption)
+    osc.set_objects(obj)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=31), sc.source, sc.listener)
+    assert cnt.connected == 0 and not e32.any()                       # the oracle's source is trapped too
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=31, source_object=7), sc.source, sc.listener)
+    assert cnt.connected > 0
+    check_energy(free, e32, e64, 1)
+    assert st["deposits"] == cnt.connected
+    # a batch: the first source with its actor, a second one (outside the box) without
+    s2 = ctx.create_source(np.asarray(sc.source, np.float32) + np.float32(120.0))
+    pd = pkg.default_params(num_rays=rays, depth=depth, seed=31, flags=DET)
+    want = [ctx.compute_energy_response(q, pd).copy() for q in (s, s2)]
+    ctx.compute_energy_response_batch_async([s, s2], pd)
+    ctx.synchronize()
+    assert np.array_equal(ctx.energy_buffer(s), want[0]) and np.array_equal(ctx.energy_buffer(s2), want[1]) and want[1].any()
+    # the listener's actor: its walks ignore it, the source's walks do not
+    ctx.set_source_object(s)                                           # back to none: trapped again
+    ctx.set_listener_object(7)
+    assert not ctx.compute_energy_response(s, p).any()
+    ctx.close()
