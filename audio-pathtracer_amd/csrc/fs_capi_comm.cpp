@@ -51,6 +51,9 @@ int reduce_energy(fs_context* ctx, Source* s) {
     if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
     if (!s->tail_ordered) FS_HIP(ctx, handoff_energy(ctx, s));   // (a later item of the launch the tail already waits behind: no second event)
     const size_t words = (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
+    if (ctx->oneshot.broken)
+        return ctx->fail(FS_ERR_COMM, "one-shot reduce: a peer did not arrive within the time limit of an earlier frame — the mailboxes are no "
+                                      "longer in step; detach the communicator (fs_comm_detach) and attach it again");
     if (ctx->oneshot.on) {   // one exchange step through the peers' mailboxes (fs_comm_enable_oneshot)
         const uint32_t seq = ++ctx->oneshot.seq;
         launch_oneshot_reduce(ctx->oneshot.view, s->cur_fixed ? (void*)s->d_fixed[s->cur] : (void*)s->energy(), (int)words, s->cur_fixed,
@@ -86,7 +89,9 @@ int oneshot_check(fs_context* ctx) {
     FS_HIP(ctx, hipMemcpy(&e, ctx->oneshot.d_err, sizeof(e), hipMemcpyDeviceToHost));
     if (!e) return FS_OK;
     FS_HIP(ctx, hipMemset(ctx->oneshot.d_err, 0, sizeof(e)));
-    return ctx->fail(FS_ERR_COMM, "one-shot reduce: a rank's contribution did not arrive in time (the frame's sum is incomplete)");
+    ctx->oneshot.broken = true;   // the mailbox sets are no longer in step with the peers': every later reduce is refused (reduce_energy)
+    return ctx->fail(FS_ERR_COMM, "one-shot reduce: a rank's contribution did not arrive within the time limit (FS_ONESHOT_TIMEOUT_MS, 10 s): "
+                                  "the frame's sum is incomplete and the communicator must be detached and attached again");
 }
 
 }  // namespace fsi
@@ -120,17 +125,24 @@ int fs_comm_enable_oneshot(fs_context* ctx) {
     // The mailbox is written by other devices while this one polls it: fine-grained memory (no stale L2 lines on either
     // side) where the runtime can share such an allocation; plain device memory otherwise (the accesses are system-scope
     // atomics either way).
+    // ... and it MUST be fine-grained: peer writes over xGMI into coarse-grained memory are not guaranteed visible to a kernel
+    // that polls it on the owner's device (its L2 may hold stale lines), system-scope atomics or not.  A rank that cannot
+    // get (or export) such an allocation votes against the one-shot path and every rank keeps ncclAllReduce.
+    // (FS_ONESHOT_COARSE_OK=1: plain device memory is accepted — ranks that share ONE device, i.e. tests, see one L2.)
     bool fine = hipExtMallocWithFlags(&o.own_mail, bytes, hipDeviceMallocFinegrained) == hipSuccess;
     if (fine && hipIpcGetMemHandle(&mine, o.own_mail) != hipSuccess) { (void)hipFree(o.own_mail); o.own_mail = nullptr; fine = false; }
     (void)hipGetLastError();
-    if ((fine || hip_step(hipMalloc(&o.own_mail, bytes), "hipMalloc(mailbox)")) && hip_step(hipMemset(o.own_mail, 0, bytes), "hipMemset(mailbox)") &&
+    static const bool coarse_ok = std::getenv("FS_ONESHOT_COARSE_OK") && std::atoi(std::getenv("FS_ONESHOT_COARSE_OK")) != 0;
+    if (!fine && !coarse_ok) { ok = 0; why = "no fine-grained device memory that HIP IPC can share for the mailbox"; }
+    if (ok && (fine || hip_step(hipMalloc(&o.own_mail, bytes), "hipMalloc(mailbox)")) && hip_step(hipMemset(o.own_mail, 0, bytes), "hipMemset(mailbox)") &&
         hip_step(hipMalloc((void**)&o.d_err, sizeof(unsigned)), "hipMalloc(err)") && hip_step(hipMemset(o.d_err, 0, sizeof(unsigned)), "hipMemset(err)"))
         (void)hip_step(hipIpcGetMemHandle(&mine, o.own_mail), "hipIpcGetMemHandle");
     (void)hipGetLastError();
-    // all-gather of the 64-byte IPC handles over the communicator (device staging), then map every peer's mailbox
-    char* d_h = nullptr;
+    // all-gather of the 64-byte IPC handles over the communicator, then map every peer's mailbox.  The staging buffer was
+    // allocated with the context (fs_context::d_comm_stage): a rank that is out of memory NOW still takes part in both
+    // collectives below — returning before them would leave the other ranks blocked in the all-gather for ever.
+    char* d_h = ctx->d_comm_stage;
     std::vector<hipIpcMemHandle_t> all((size_t)W);
-    if (hipMalloc((void**)&d_h, sizeof(hipIpcMemHandle_t) * (size_t)(W + 1)) != hipSuccess) return ctx->fail(FS_ERR_OUT_OF_MEMORY, "one-shot reduce: staging");
     hipError_t e = hipMemcpyAsync(d_h + sizeof(mine) * (size_t)W, &mine, sizeof(mine), hipMemcpyHostToDevice, ctx->copy_stream);
     ncclResult_t nr = a->AllGather(d_h + sizeof(mine) * (size_t)W, d_h, sizeof(mine), ncclUint8, ctx->comm, ctx->copy_stream);
     if (e == hipSuccess) e = hipMemcpyAsync(all.data(), d_h, sizeof(mine) * (size_t)W, hipMemcpyDeviceToHost, ctx->copy_stream);
@@ -151,7 +163,6 @@ int fs_comm_enable_oneshot(fs_context* ctx) {
     int all_ok = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&all_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, ctx->copy_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
-    (void)hipFree(d_h);
     if (nr != ncclSuccess || e != hipSuccess) all_ok = 0;
     if (!all_ok) {
         oneshot_release(ctx);
@@ -160,6 +171,7 @@ int fs_comm_enable_oneshot(fs_context* ctx) {
     }
     o.seq = 0;
     o.on = true;
+    o.broken = false;
     return FS_OK;
 }
 

@@ -227,7 +227,7 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
     uint32_t want_cap = ctx->over_cap;
     if (unbounded) {
         want_cap = (uint32_t)std::min<size_t>(lanes, std::max<size_t>(ctx->over_cap, (size_t)(4.0 * tail * (double)lanes) + 64));   // (a slot per lane is all a frame can use)
-        if (const char* v = std::getenv("FS_OVER_CAP")) want_cap = std::max(ctx->over_cap, (uint32_t)std::max(1, std::atoi(v)));   // tests: force the regrow path
+        if (ctx->over_cap_forced > 0) want_cap = std::max(ctx->over_cap, (uint32_t)ctx->over_cap_forced);   // FS_OVER_CAP (tests: force the regrow path)
     }
     const bool new_sets = sets != ctx->state_sets || staged != ctx->state_cont;
     const bool grow_lanes = lanes > ctx->cap_lanes || new_sets;
@@ -475,6 +475,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_OVER_CAP")) ctx->over_cap_forced = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("FS_WALK_COOP")) ctx->walk.coop = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_FUSED_RECON")) ctx->fused_recon = std::atoi(v) != 0;
     if (const char* v = std::getenv("FS_FUSED_RECON_COMM")) ctx->fused_recon_comm = std::atoi(v) != 0;
@@ -520,6 +521,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchSets * kScratchAllocWords);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("hipMalloc(queue): ") + hipGetErrorString(e));
     for (int k = 0; k < fs_context::kTailBatches && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ctx->tail_batch_ev[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_comm_stage, 2048);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_recon_tab, sizeof(ReconItem) * fs_context::kReconTabSlots * fs_context::kReconTabItems, hipHostMallocDefault);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("batched reconstructs: ") + hipGetErrorString(e));
     ctx->device_ok = true;
@@ -576,6 +578,7 @@ int fs_context_destroy(fs_context* ctx) {
     }
     for (hipEvent_t ev : ctx->tail_batch_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_recon_tab) (void)hipHostFree(ctx->h_recon_tab);
+    if (ctx->d_comm_stage) (void)hipFree(ctx->d_comm_stage);
     join_refine_threads(ctx);   // no background build may outlive the context (the library may be unloaded next)
     for (Source* s : ctx->sources) free_source(ctx, s);
     // streams exist even when a later step of fs_context_create failed (device_ok == false)

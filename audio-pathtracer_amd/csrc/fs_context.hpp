@@ -199,7 +199,10 @@ struct fs_context {
         void* own_mail = nullptr;         // this rank's mailbox (hipMalloc); the others are IPC mappings
         unsigned* d_err = nullptr;        // raised by a sum kernel that gave up waiting for a peer
         uint32_t seq = 0;                 // reduces issued so far
+        bool broken = false;              // a sum gave up waiting for a peer: the sets are out of step, every later reduce is refused
     } oneshot;
+    char* d_comm_stage = nullptr;         // 2 KB of device staging for the small collectives of fs_comm_enable_oneshot, allocated with the
+                                          //   context: a rank that is out of memory later can still take part in them
     // One event per batched reconstruct launch on the tail stream, in a ring: the tail stream runs in order, so a batch is done as
     // soon as its own or ANY younger batch's event is (a batch whose ring entry has been recycled is covered by the oldest entry
     // still there).  Created with the context: the handles never change (the audio thread may query them).
@@ -292,6 +295,7 @@ struct fs_context {
     double* d_end_posd = nullptr; size_t cap_posd = 0;   // FS_FLAG_DOUBLE_POSITIONS: end points in double [lanes][3] (such frames are never held: one set)
     float4* d_cont = nullptr;        // continuation records of staged walks: [state_sets][2][cap_lanes]
     uint32_t over_cap = 0, over_cap_pos = 0;
+    int over_cap_forced = 0;       // FS_OVER_CAP, read at fs_context_create
     unsigned* d_overflow = nullptr;
     bool overflow_armed = false;   // an unbounded frame has been enqueued since the word was last read
     // batched frames (fs_compute_energy_response_batch_async): per-frame tables of pointers and source positions

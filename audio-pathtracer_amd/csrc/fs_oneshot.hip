@@ -9,10 +9,17 @@
 // a rank pushes reduce k + 2 only after its own sum k + 1 has finished, which needed every peer's push k + 1, which every
 // peer enqueued behind its own sum k — so nobody still reads set k % 2 when it is overwritten.
 // Payload and flags cross devices while kernels run on both sides: they are written and read with system-scope atomics
-// (no caching on either side), the flag store is a release behind a system-scope fence.  The wait is bounded: a peer
-// that never shows up costs the waiting rank a fraction of a second, sets the error word and lets the kernel end —
-// nothing spins for ever.
+// (no caching on either side), the flag store is a release behind a system-scope fence.  The wait is bounded so that no
+// kernel spins for ever: a peer that has not shown up after `spins` polls (~1 us each; 10 s by default,
+// FS_ONESHOT_TIMEOUT_MS — a legitimate straggler, a first-launch code-object load, a descheduled host thread must never
+// trip it: ncclAllReduce would simply wait) sets the error word and lets the kernel end.  After that the two-set argument
+// above no longer holds (a late push could land in a set that is being reused), so the host treats it as fatal for the
+// communicator: every later reduce fails with FS_ERR_COMM until the host detaches and attaches again (oneshot_check).
+// Flags are compared wrap-safe: a flag AT OR BEYOND the awaited sequence number ends the wait.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
 
 #include "fs_internal.hpp"
 
@@ -20,7 +27,6 @@ namespace fs {
 namespace {
 
 constexpr int kOneShotBlock = 1024;
-constexpr unsigned kOneShotSpins = 400000;     // x ~1 us of s_sleep: a missing peer is given up after ~0.4 s
 
 __device__ __forceinline__ uint32_t* flag_of(char* mail, int set, int r) {
     return reinterpret_cast<uint32_t*>(mail) + set * kOneShotMaxRanks + r;
@@ -42,13 +48,13 @@ __global__ __launch_bounds__(kOneShotBlock) void oneshot_push_kernel(OneShotView
 
 template <typename T>
 __global__ __launch_bounds__(kOneShotBlock) void oneshot_sum_kernel(OneShotView v, T* __restrict__ dst, int words, int set,
-                                                                    uint32_t seq, unsigned* __restrict__ err) {
+                                                                    uint32_t seq, unsigned* __restrict__ err, unsigned max_spins) {
     char* mail = static_cast<char*>(v.mail[v.rank]);
     if ((int)threadIdx.x < v.world) {
         uint32_t* f = flag_of(mail, set, (int)threadIdx.x);
         unsigned spins = 0;
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (++spins > kOneShotSpins) { *err = 1u; break; }      // the host reports FS_ERR_COMM; the kernel ends either way
+        while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (++spins > max_spins) { *err = 1u; break; }          // the host reports FS_ERR_COMM; the kernel ends either way
             __builtin_amdgcn_s_sleep(32);
         }
     }
@@ -74,15 +80,20 @@ __global__ __launch_bounds__(kOneShotBlock) void oneshot_sum_kernel(OneShotView 
 
 void launch_oneshot_reduce(const OneShotView& v, void* buffer, int words, bool u64, int set, uint32_t seq, unsigned* err,
                            hipStream_t s) {
+    static const unsigned max_spins = [] {   // ~1 us per poll
+        const char* e = std::getenv("FS_ONESHOT_TIMEOUT_MS");
+        const long ms = e ? std::atol(e) : 10000;
+        return (unsigned)std::max(1000L, std::min(ms, 3600000L)) * 1000u;
+    }();
     const int words32 = u64 ? 2 * words : words;
     hipLaunchKernelGGL(oneshot_push_kernel, dim3((unsigned)v.world), dim3(kOneShotBlock), 0, s, v,
                        static_cast<const uint32_t*>(buffer), words32, set, seq);
     if (u64)
         hipLaunchKernelGGL(oneshot_sum_kernel<unsigned long long>, dim3(1), dim3(kOneShotBlock), 0, s, v,
-                           static_cast<unsigned long long*>(buffer), words, set, seq, err);
+                           static_cast<unsigned long long*>(buffer), words, set, seq, err, max_spins);
     else
         hipLaunchKernelGGL(oneshot_sum_kernel<float>, dim3(1), dim3(kOneShotBlock), 0, s, v, static_cast<float*>(buffer), words,
-                           set, seq, err);
+                           set, seq, err, max_spins);
 }
 
 }  // namespace fs

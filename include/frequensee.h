@@ -23,6 +23,35 @@
  *
  * There is no CPU fallback: if no HIP device is usable every compute entry point fails with
  * FS_ERR_NO_DEVICE.
+ *
+ * TWO TIERS.  CORE = the drop-in boundary itself: what a UE shim inside UpdateSource / TickComponent
+ * binds, and nothing a host has to know beyond the reference's own interface —
+ *   CORE:     fs_abi_version fs_config_default fs_params_default fs_context_create fs_context_destroy fs_last_error
+ *             fs_scene_set_triangles fs_scene_set_materials fs_scene_set_objects fs_scene_commit
+ *             fs_source_create fs_source_destroy fs_source_set_position fs_source_set_object
+ *             fs_listener_set_position fs_listener_set_object
+ *             fs_compute_energy_response fs_reconstruct_impulse_response
+ *             fs_get_impulse_response fs_copy_impulse_response fs_get_impulse_response_sequence
+ *             fs_get_energy_buffer fs_flush_energy_buffer fs_add_energy_at_delay fs_update_energy_buffer
+ *             fs_num_bins fs_num_samples fs_get_occlusion_attenuation fs_update_sound fs_sound_params_default
+ *             fs_get_stats fs_reset_stats
+ * EXTENDED = everything else: the asynchronous / batched / pipelined forms of the two hot calls, multi-GPU plumbing,
+ * run-time scene changes, the rows SURVEY.md 8(f) ranks next (text interchange, reverb, material filter), measurement
+ * and tools.  A host can ignore all of it and still be correct; it is there for throughput and for the tests —
+ *   EXTENDED: fs_context_advice fs_scene_commit_fast fs_scene_commit_progressive fs_scene_refine_pending
+ *             fs_scene_refine_wait fs_scene_update_triangles fs_scene_refit
+ *             fs_compute_energy_response_async fs_compute_energy_response_batch_async
+ *             fs_reconstruct_impulse_response_async fs_reconstruct_impulse_response_batch_async fs_synchronize fs_submit
+ *             fs_set_pipelining fs_set_walk_stages fs_set_frames_per_launch
+ *             fs_energy_device_ptr fs_energy_handoff fs_shard_range fs_comm_unique_id fs_comm_init fs_comm_attach
+ *             fs_comm_enable_oneshot fs_comm_detach fs_peers_init fs_peers_detach fs_gather_energy fs_gather_energy_async
+ *             fs_copy_band_impulse_response fs_set_impulse_response fs_trace_rays
+ *             fs_save_array_to_file fs_load_float_array fs_save_impulse_response
+ *             fs_reverb_init fs_reverb_process fs_reverb_release fs_apply_material_fd
+ *             fs_set_profiling fs_set_profiling_interval
+ * (tests/test_capi_cpu.py checks that every exported symbol is in exactly one of the two lists.)
+ * Environment variables (FS_*) are tuning and diagnostic knobs only; all of them are read ONCE — at fs_context_create, at a
+ * scene commit (builder knobs) or at the first launch of a kernel family — never per frame.
  */
 #ifndef FREQUENSEE_H
 #define FREQUENSEE_H

@@ -25,6 +25,36 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg._capi.EXPORTS) == syms
 
 
+def test_every_export_is_core_or_extended():
+    """include/frequensee.h sorts its entry points into the CORE boundary and the EXTENDED tier: every
+    declared symbol appears in exactly one of the two lists of the header's opening comment."""
+    src = open(os.path.join(ROOT, "include", "frequensee.h")).read()
+    head = src[:src.index("#ifndef FREQUENSEE_H")]
+    core = set(re.findall(r"fs_[a-z0-9_]+", head[head.index("CORE:"):head.index("EXTENDED =")]))
+    ext = set(re.findall(r"fs_[a-z0-9_]+", head[head.index("EXTENDED:"):head.index("(tests/test_capi_cpu.py")]))
+    assert not (core & ext), sorted(core & ext)
+    syms = set(header_symbols())
+    assert core | ext == syms, (sorted(syms - core - ext), sorted((core | ext) - syms))
+    assert 25 <= len(core) <= 35
+
+
+def test_no_getenv_on_a_per_frame_path():
+    """the library reads its FS_* knobs once (context creation, scene commit, first launch of a kernel family): every getenv
+    outside fs_context_create / the builders is a function-local static initialiser"""
+    csrc = os.path.join(ROOT, "audio-pathtracer_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".cpp", ".hip", ".hpp")) or f in ("fs_bvh.cpp",):
+            continue
+        txt = open(os.path.join(csrc, f)).read()
+        if f == "fs_capi_context.cpp":      # everything inside fs_context_create
+            body = txt[txt.index("int fs_context_create("):txt.index("const char* fs_context_advice(")]
+            assert txt.count("getenv") == body.count("getenv"), f
+            continue
+        for line in txt.splitlines():
+            if "getenv" in line and not line.lstrip().startswith("//"):
+                assert "static const" in line or "const char* env = std::getenv(\"FS_RCCL_LIB\")" in line or "const char* e = std::getenv" in line, (f, line.strip())
+
+
 def test_struct_layouts_match_header(pkg):
     lib = pkg._capi.load()
     assert lib.fs_abi_version() == 5
