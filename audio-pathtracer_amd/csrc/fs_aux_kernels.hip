@@ -68,19 +68,19 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DeviceScene sc, cons
 }
 
 // the same query through the cooperative traversal (trav_coop): a wave takes R = 1, 2 or 4 rays, each searched by a group of 64 / R lanes
-__global__ __launch_bounds__(kBlock) void trace_rays_coop_kernel(DeviceScene sc, const float* __restrict__ o,
+__global__ __launch_bounds__(kBlock) void trace_rays_coop_kernel(DeviceScene sc, CoopView cv, const float* __restrict__ o,
                                                                  const float* __restrict__ d,
                                                                  const float* __restrict__ tmax, int N, int R,
                                                                  int32_t* hit, float* t, int32_t* tri, float* normal, unsigned* overflow) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [lds_nodes][16] records | [waves][kCoopWaveWords]
-    coop_stage_nodes(sc, s_dyn);
+    coop_stage_nodes(cv, s_dyn);
     const int lane = threadIdx.x & 63, wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const int i = wave * R + lane;
     const bool own = lane < R && i < N;
     const int ic = own ? i : 0;
     Ray r = make_ray(o[3 * ic], o[3 * ic + 1], o[3 * ic + 2], d[3 * ic], d[3 * ic + 1], d[3 * ic + 2]);
     Trav T;
-    trav_coop<false, false>(sc, R, own, r, tmax[ic], 0xFFFFFFFFu, T, s_dyn, s_dyn + 16 * (size_t)sc.lds_nodes + (size_t)(threadIdx.x >> 6) * kCoopWaveWords, overflow);
+    trav_coop<false, false>(sc, cv, R, own, r, tmax[ic], 0xFFFFFFFFu, T, s_dyn, coop_wave_words(cv, s_dyn), overflow);
     if (!own) return;
     hit[i] = T.leaf_index >= 0;
     if (T.leaf_index >= 0) {
@@ -395,16 +395,19 @@ void launch_trace_rays(const DeviceScene& sc_in, const float* o, const float* d,
     if (N <= 0) return;
     DeviceScene sc = sc_in;
     if (any_hit >= 2) {   // closest hit through the cooperative traversal: 2 / 3 / 4 = 1, 2, 4 rays per wave, every record from global memory;
-        //                   5 / 6 / 7 = the same with the top of the tree resident in LDS (37 nodes: both kinds of fetch in one query) ; 8: all that fit.
+        //                   5 / 6 / 7 = the same with the top of the tree resident in LDS (5 sixteen-wide nodes: both kinds of fetch in one query) ; 8: all that fit.
         //                   `hit` doubles as the overflow word's home (hit[N])
         const int m = any_hit >= 8 ? 2 : (any_hit - 2) % 3;
         const int R = m == 0 ? 1 : (m == 1 ? 2 : 4);
         const int waves = (N + R - 1) / R;
         const uint32_t blocks = (uint32_t)((waves + kBlock / 64 - 1) / (kBlock / 64));
-        sc.lds_nodes = any_hit < 5 || !sc.coop ? 0 : (any_hit < 8 ? std::min(sc.num_nodes, 37) : coop_resident_nodes(sc, kBlock / 64, blocks, 0));
-        const size_t lds = coop_lds_bytes(kBlock / 64, sc.lds_nodes);
+        const CoopView* cvp = coop_view(sc, R);
+        if (!cvp) { launch_trace_rays(sc_in, o, d, tmax, N, 0, hit, t, tri, normal, s); return; }   // (a tree the cooperative stack cannot hold: the lane-private traversal)
+        CoopView cv = *cvp;
+        cv.lds_nodes = any_hit < 5 ? 0 : (any_hit < 8 ? std::min(cv.nodes, 5) : coop_resident_nodes(cv, kBlock / 64, blocks, 0));
+        const size_t lds = coop_lds_bytes(kBlock / 64, cv);
         allow_lds(trace_rays_coop_kernel, lds);
-        hipLaunchKernelGGL(trace_rays_coop_kernel, dim3(blocks), dim3(kBlock), lds, s, sc, o, d, tmax, N, R,
+        hipLaunchKernelGGL(trace_rays_coop_kernel, dim3(blocks), dim3(kBlock), lds, s, sc, cv, o, d, tmax, N, R,
                            hit, t, tri, normal, reinterpret_cast<unsigned*>(hit + N));
         return;
     }

@@ -101,7 +101,10 @@ void free_source(fs_context* ctx, Source* s) {
 void free_scene(fs_context* ctx) {
     if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
     if (ctx->d_coop) (void)hipFree(ctx->d_coop);
-    ctx->d_coop = nullptr; ctx->coop_cap = 0;
+    if (ctx->d_coop16) (void)hipFree(ctx->d_coop16);
+    if (ctx->d_coop_levels) (void)hipFree(ctx->d_coop_levels);
+    ctx->d_coop = nullptr; ctx->coop_cap = 0; ctx->d_coop16 = nullptr; ctx->coop16_cap = 0; ctx->d_coop_levels = nullptr;
+    ctx->coop16_nodes = 0; ctx->coop_levels = 0;
     if (ctx->d_tris) (void)hipFree(ctx->d_tris);
     if (ctx->d_tris48) (void)hipFree(ctx->d_tris48);
     if (ctx->d_tri_nrm) (void)hipFree(ctx->d_tri_nrm);

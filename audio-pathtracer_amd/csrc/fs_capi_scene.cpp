@@ -132,18 +132,44 @@ static int pack_scene(fs_context* ctx, size_t count, size_t cap) {
 // what every kind of commit ends with: the kernels' view of the scene and the stats
 // the cooperative traversal's records, derived from the node array as it stands in the stream (behind an upload, a device
 // build's refit, a refit of moved triangles)
-static int refresh_coop_nodes(fs_context* ctx) {
+static int refresh_coop_nodes(fs_context* ctx, bool topology_changed) {
     const size_t n = ctx->bvh.nodes.size();
-    if (n == 0) return FS_OK;
+    const int levels = (int)ctx->bvh.level_begin.size() - 1;
+    ctx->coop_info = CoopInfo{};
+    ctx->scene.coop_info = &ctx->coop_info;
+    if (n == 0 || levels < 1 || levels > kMaxBuildLevels) return FS_OK;
     if (n > ctx->coop_cap) {
         if (ctx->d_coop) { FS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_coop); }
         ctx->d_coop = nullptr; ctx->coop_cap = 0;
         FS_HIP(ctx, hipMalloc((void**)&ctx->d_coop, sizeof(CoopChild) * 4 * n));
         ctx->coop_cap = n;
     }
+    if (topology_changed || !ctx->d_coop_levels) {   // the level table and the dense numbering of the even levels (a refit keeps both)
+        std::vector<int32_t> tab(2 * (size_t)(kMaxBuildLevels + 2), -1);
+        int32_t n16 = 0;
+        for (int l = 0; l <= levels; ++l) tab[(size_t)l] = ctx->bvh.level_begin[(size_t)l];
+        for (int l = 0; l < levels; ++l) {
+            if (l & 1) continue;
+            tab[(size_t)(kMaxBuildLevels + 2) + (size_t)l] = n16;
+            n16 += ctx->bvh.level_begin[(size_t)l + 1] - ctx->bvh.level_begin[(size_t)l];
+        }
+        if (!ctx->d_coop_levels) FS_HIP(ctx, hipMalloc((void**)&ctx->d_coop_levels, sizeof(int32_t) * tab.size()));
+        FS_HIP(ctx, hipMemcpyAsync(ctx->d_coop_levels, tab.data(), sizeof(int32_t) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (tab is a local; commits drain the stream anyway)
+        ctx->coop16_nodes = n16; ctx->coop_levels = levels;
+    }
+    if ((size_t)ctx->coop16_nodes > ctx->coop16_cap) {
+        if (ctx->d_coop16) { FS_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_coop16); }
+        ctx->d_coop16 = nullptr; ctx->coop16_cap = 0;
+        FS_HIP(ctx, hipMalloc((void**)&ctx->d_coop16, sizeof(CoopChild) * 16 * (size_t)ctx->coop16_nodes));
+        ctx->coop16_cap = (size_t)ctx->coop16_nodes;
+    }
     launch_coop_nodes(ctx->d_nodes, (int)n, ctx->d_coop, ctx->stream);
+    launch_coop16(ctx->d_coop, ctx->d_coop_levels, ctx->d_coop_levels + (kMaxBuildLevels + 2), ctx->coop_levels, ctx->coop16_nodes, ctx->d_coop16, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
-    ctx->scene.coop = ctx->d_coop;
+    // one-node-at-a-time descents: 15 new entries per 16-wide level at most; the 4-wide tree's bound is the builder's (+ the popped node's four)
+    ctx->coop_info.wide16 = CoopView{ctx->d_coop16, 0, ctx->coop16_nodes, 4, (int16_t)(15 * ((ctx->coop_levels + 1) / 2) + 1)};
+    ctx->coop_info.wide4 = CoopView{ctx->d_coop, 0, (int32_t)n, 2, (int16_t)(std::max(ctx->bvh.stack_need, 2) + 4)};
     return FS_OK;
 }
 
@@ -178,7 +204,6 @@ static int finish_commit(fs_context* ctx, size_t scene_bytes) {
         ctx->deep.rows = deep_rows;
     }
     ctx->scene.stack_worst = traversal_lds_bytes(worst, ctx->cfg.num_bands, ctx->num_bins) <= ctx->lds_limit ? worst : 0;
-    ctx->scene.stack_need = std::max(ctx->bvh.stack_need, 2);
     ctx->scene.deep = nullptr; ctx->scene.deep_lanes = 0;
     ctx->scene.deep_owner = &ctx->deep;
     ctx->stats.bvh_nodes = (uint32_t)ctx->bvh.nodes.size();
@@ -186,8 +211,8 @@ static int finish_commit(fs_context* ctx, size_t scene_bytes) {
     ctx->stats.bvh_stack_need = (uint32_t)ctx->bvh.stack_need;
     ctx->stats.bvh_depth = (uint32_t)ctx->bvh.max_depth;
     ctx->stats.scene_bytes = scene_bytes;
-    ctx->scene.coop = nullptr; ctx->scene.lds_nodes = 0;
-    { const int cr = refresh_coop_nodes(ctx); if (cr) return cr; }
+    ctx->scene.coop_info = nullptr;
+    { const int cr = refresh_coop_nodes(ctx, true); if (cr) return cr; }
     ctx->committed = true;
     return FS_OK;
 }
@@ -448,7 +473,7 @@ int fs_scene_refit(fs_context* ctx) {
     launch_refit(ctx->d_nodes, ctx->d_tris, ctx->d_node_box, ctx->bvh.level_begin.data(),
                  (int)ctx->bvh.level_begin.size() - 1, pad, ctx->stream);
     FS_HIP(ctx, hipGetLastError());
-    return refresh_coop_nodes(ctx);
+    return refresh_coop_nodes(ctx, false);
 }
 
 int fs_scene_set_objects(fs_context* ctx, const uint32_t* object_id, int32_t T) {

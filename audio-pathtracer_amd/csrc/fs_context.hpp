@@ -151,8 +151,13 @@ struct fs_context {
     int32_t T = 0, M = 0;
     bool committed = false;
     NodeQ4* d_nodes = nullptr;
-    CoopChild* d_coop = nullptr;      // the cooperative traversal's view of the nodes (fs_internal.hpp), rebuilt behind every commit and refit
+    CoopChild* d_coop = nullptr;      // per-child records of the 4-wide nodes (fs_internal.hpp), rebuilt behind every commit and refit ...
     size_t coop_cap = 0;              // nodes it has room for
+    CoopChild* d_coop16 = nullptr;    // ... and folded into the 16-wide nodes the cooperative traversal walks
+    size_t coop16_cap = 0;
+    int32_t* d_coop_levels = nullptr; // [2][kMaxBuildLevels + 2]: level_begin | dense index of every even level (uploaded at commit)
+    int coop16_nodes = 0, coop_levels = 0;
+    CoopInfo coop_info;               // what DeviceScene.coop_info points at
     float stage_margin = 1.3f;        // KParams.stage_margin
     DeepStore deep;                   // HBM spill area of the bounded LDS traversal stacks (DeviceScene.deep)
     int stack_rows_cap = kStackRowsCap;   // FS_STACK_ROWS_CAP

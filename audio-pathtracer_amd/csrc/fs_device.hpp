@@ -667,16 +667,18 @@ __device__ __forceinline__ void walker_start(Walker& w, uint32_t g, uint32_t slo
 // top of GeneratePath's loop (ARTS.cpp:294-319): depth cap, roulette, direction.  false = the walk ends.
 // `ray` still holds the previous segment's ray on entry: its direction is the arrival direction at this vertex.
 // LOBES: 0 / 1 = FS_FLAG_MATERIAL_LOBES known at compile time, -1 = read kp.lobes.
+// pre: the Philox words of this bounce, computed ahead by another lane (cooperative walk: the roulette and the sample of a
+// bounce depend on (seed, pair, side, bounce) only) — the same words, so the same walk
 template <int LOBES = -1>
 __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, const DeviceScene& sc,
-                                                const SubpathState& st, Ray& ray) {
+                                                const SubpathState& st, Ray& ray, const uint4* pre = nullptr) {
     const bool lobes_on = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
     if (w.k >= kp.depth && st.over_levels == 0) return false;             // the depth cap
     const uint32_t bs = ((uint32_t)w.k << 1) | w.side;
     // (grouped frames: the item's own low seed word — recomputed from the pair index here, once per bounce, rather than
     // carried in a register through the traversal: one more live VGPR cost the 128-register frame kernel 3 %)
     const uint32_t seed = kp.item_seeds > 0 ? item_seed_lo(kp, w.li / kp.pairs_per_source) : kp.seed_lo;
-    const uint4 r = philox(w.pair, bs, 0, seed, kp.seed_hi);
+    const uint4 r = pre ? *pre : philox(w.pair, bs, 0, seed, kp.seed_hi);
     if (kp.russian_roulette && !(u01(r.x) < kp.rr_prob)) return false;    // ARTS.cpp:300-301, 349-353
     if (w.k >= kp.depth) { *st.overflow = 1u; return false; }             // depth = 0 and the walk outlives both tiers
     float dx, dy, dz;
@@ -757,15 +759,23 @@ __device__ __forceinline__ void sphere_normal(const Ray& r, float t, const float
 // bottom of the loop (ARTS.cpp:339-347): apply the closest hit (or the miss) and record the segment
 // EXT: the instantiation that knows FS_FLAG_DOUBLE_POSITIONS and the end points' collision spheres (both decided at run
 // time inside it); the default instantiation carries neither — not a register, not an instruction
+// surf (cooperative walk): the hit triangle's unit normal (as stored, not yet flipped) and material bits, handed over by the
+// lane that tested it — the loads of hit_surface are saved
 template <bool EXT = false>
 __device__ __forceinline__ void walker_apply_hit(Walker& w, const KParams& kp, const DeviceScene& sc,
-                                                 const SubpathState& st, const Ray& ray, const Trav& T) {
+                                                 const SubpathState& st, const Ray& ray, const Trav& T, const float4* surf = nullptr) {
     float qx = w.px, qy = w.py, qz = w.pz;
     double dqx = w.dpx, dqy = w.dpy, dqz = w.dpz;
     uint32_t mat_new = w.mat;
     bool hit = T.leaf_index >= 0;
     float t = T.t;
-    if (hit) hit_surface(sc, T.leaf_index, ray, w.nx, w.ny, w.nz, mat_new);
+    if (hit && surf) {
+        float x = surf->x, y = surf->y, z = surf->z;
+        const float dn = fmaf(x, ray.dx, fmaf(y, ray.dy, z * ray.dz));
+        if (dn > 0.0f) { x = -x; y = -y; z = -z; }
+        w.nx = x; w.ny = y; w.nz = z;
+        mat_new = __float_as_uint(surf->w);
+    } else if (hit) hit_surface(sc, T.leaf_index, ray, w.nx, w.ny, w.nz, mat_new);
     // the OTHER end point's collision sphere (the walk's own actor is ignored, ARTS.cpp:322-334); wins ties with a triangle
     const float other_radius = !EXT ? 0.0f : (w.side ? kp.source_radius : kp.listener_radius);
     if (EXT && other_radius > 0.0f) {
@@ -1321,10 +1331,12 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
 // lane-private descent with work stealing above spends ~10 us per query: every step is a 64-B node per LANE, a 4-way
 // sort, three stack pushes and a round of ballots / donation boxes / mailboxes, and the parallelism only doubles per step.
 // Here the G = 64 / R lanes of a group search ONE ray together, breadth first:
-//   * the group keeps ONE stack of pending inner nodes in LDS; a step pops up to G / 4 of them, lane j takes child j & 3 of
-//     node j >> 2 and fetches exactly that child's 16-byte record (CoopChild, fs_internal.hpp: the box as fp16, rounded
+//   * the tree it walks is the 4-wide one folded two levels at a time into 16-WIDE nodes (fs_refit.hip: coop16_kernel) — half
+//     the levels, and a query takes about as many steps as the tree has levels;
+//   * the group keeps ONE stack of pending inner nodes in LDS; a step pops up to G / 16 of them, lane j takes child j & 15 of
+//     node j >> 4 and fetches exactly that child's 16-byte record (CoopChild, fs_internal.hpp: the box as fp16, rounded
 //     outwards, + the reference) — with ONE ds_read_b128 if the node is among the first DeviceScene.lds_nodes of the
-//     breadth-first array, which every workgroup stages in its LDS, else with one global_load_dwordx4 — and tests that box;
+//     array, which every workgroup stages in its LDS, else with one global_load_dwordx4 — and tests that box;
 //   * the children that are hit and inner go back on the stack by a ballot + prefix count (no sort, no donation protocol);
 //   * a lane whose child is a hit LEAF requests that leaf's triangles right away and tests them itself in the NEXT step,
 //     in the shadow of that step's node fetch; a closer hit goes into the group's mailbox with ds_min_u64 on the
@@ -1335,25 +1347,45 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
 // is the minimum of the key over ALL triangles the ray hits within tmax (boxes only prune, and these are supersets of the
 // quantised ones), so the result is the one of trav_shared and of the oracle's brute-force scan, bit for bit, whatever
 // the visiting order.
-// The stack cannot overflow: a step pops k nodes and pushes at most 4 k; k is the full G / 4 only while that leaves room
+// The stack cannot overflow: a step pops k nodes and pushes at most 16 k; k is the full G / 16 only while that leaves room
 // for the tree's worst-case one-node-at-a-time descent (DeviceScene.stack_need) on top, else the group descends one
 // node per step (LIFO: from a stack of n entries such a descent never holds more than n + stack_need).
-// LDS of a workgroup: [lds_nodes][4] CoopChild | per wave: kCoopCap pending-node words (divided among the R groups), R rays
+// LDS of a workgroup: [lds_nodes][16] CoopChild | per wave: kCoopCap pending-node words (divided among the R groups), R rays
 // of 8 words, R mailboxes (u64 key, leaf).
 // ---------------------------------------------------------------------------------------------------
 constexpr int kCoopCap = 1024;
 constexpr int kCoopMaxGroups = 4;
-constexpr int kCoopWaveWords = kCoopCap + kCoopMaxGroups * 8 + kCoopMaxGroups * 4;
+constexpr int kCoopRayWords = 12;    // origin, direction, reciprocals, tmax, ignored actor, -
+constexpr int kCoopBoxWords = 8;     // mailbox: key (u64), hit leaf, - | unit normal of the hit triangle, its material
+constexpr int kCoopRngWords = 64 * 4 + kCoopMaxGroups * 4;   // the walk's Philox words of the next bounces, one uint4 per lane | (pair, side, seed, first bounce) per group
+constexpr int kCoopWaveWords = kCoopCap + kCoopMaxGroups * kCoopRayWords + kCoopMaxGroups * kCoopBoxWords + kCoopRngWords;
 constexpr size_t kCoopWaveBytes = sizeof(int) * (size_t)kCoopWaveWords;
-static_assert(kCoopCap / kCoopMaxGroups >= 3 * (kStackDepth + 8), "a group's share of the node stack must hold the worst-case descent");
-// dynamic LDS of a cooperative kernel launched with `waves` waves per workgroup and `lds_nodes` resident nodes
-inline size_t coop_lds_bytes(int waves, int lds_nodes) { return (size_t)lds_nodes * 64u + kCoopWaveBytes * (size_t)waves; }
+// may R rays share a wave on this tree?  (a group's share of the node stack must hold the worst-case descent + one wide step)
+inline bool coop_fits(const CoopView& cv, int R) {
+    const int per = (1 << cv.wshift) - 1, kfull = std::max(1, (64 / R) >> cv.wshift);
+    return cv.rec != nullptr && cv.nodes > 0 && (64 / R) >= (1 << cv.wshift) && cv.stack_need + 8 + per * kfull <= kCoopCap / R;
+}
+// the node array waves of R rays walk (FS_COOP_WIDE: bit r set = 16-wide nodes for 2^r rays per wave; default 1 and 2 rays)
+inline const CoopView* coop_view(const DeviceScene& sc, int R) {
+    static const int wide_mask = std::getenv("FS_COOP_WIDE") ? std::atoi(std::getenv("FS_COOP_WIDE")) : 3;
+    if (!sc.coop_info) return nullptr;
+    const int bit = R == 1 ? 1 : (R == 2 ? 2 : 4);
+    const CoopView* v = (wide_mask & bit) ? &sc.coop_info->wide16 : &sc.coop_info->wide4;
+    if (!coop_fits(*v, R)) v = v == &sc.coop_info->wide16 ? &sc.coop_info->wide4 : &sc.coop_info->wide16;
+    return coop_fits(*v, R) ? v : nullptr;
+}
+// dynamic LDS of a cooperative kernel launched with `waves` waves per workgroup and the view's resident nodes
+inline size_t coop_lds_bytes(int waves, const CoopView& cv) { return ((size_t)cv.lds_nodes << cv.wshift) * 16u + kCoopWaveBytes * (size_t)waves; }
 // the first words of the workgroup's dynamic LDS: the resident records.  Every thread of the workgroup must call it.
-__device__ __forceinline__ void coop_stage_nodes(const DeviceScene& sc, int* s_dyn) {
-    const uint4* src = reinterpret_cast<const uint4*>(sc.coop);
+__device__ __forceinline__ void coop_stage_nodes(const CoopView& cv, int* s_dyn) {
+    const uint4* src = reinterpret_cast<const uint4*>(cv.rec);
     uint4* dst = reinterpret_cast<uint4*>(s_dyn);
-    for (int i = threadIdx.x; i < 4 * sc.lds_nodes; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (cv.lds_nodes << cv.wshift); i += blockDim.x) dst[i] = src[i];
     __syncthreads();
+}
+// this wave's words behind the staged records
+__device__ __forceinline__ int* coop_wave_words(const CoopView& cv, int* s_dyn) {
+    return s_dyn + (((size_t)cv.lds_nodes << cv.wshift) * 4) + (size_t)(threadIdx.x >> 6) * kCoopWaveWords;
 }
 
 // LDS words other lanes of the wave write: typed address-space-3 accesses (ds_read / ds_write; a `volatile` generic pointer
@@ -1368,9 +1400,12 @@ __device__ __forceinline__ void lds_st64(unsigned long long* p, unsigned long lo
 __device__ __forceinline__ void lds_min64(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_min((LdsU64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 
 // one triangle (leaf-order index `leaf`) against the group's ray; a closer hit updates the lane's own best
+// best_surf: the unit normal and the material of the lane's best triangle — computed from the record in hand with the
+// builders' own operation sequence (fs_bvh.cpp / fs_build.hip / update_tris_kernel: the stored normal is exactly this), so
+// that the walker needs neither the normal array nor the record again
 template <bool IGN>
 __device__ __forceinline__ bool coop_tri(const float4 a, const float4 b, const float4 c, const Ray& r, const float bound, const uint32_t ign,
-                                         const int leaf, unsigned long long& best_key, int& best_leaf) {
+                                         const int leaf, unsigned long long& best_key, int& best_leaf, float4& best_surf) {
     float t = 0.0f;
     bool hit = tri_hit(a, b, c, r, bound, t);
     if (IGN) hit = hit & (__float_as_uint(c.w) != ign);
@@ -1378,6 +1413,15 @@ __device__ __forceinline__ bool coop_tri(const float4 a, const float4 b, const f
     const bool better = hit & (key < best_key);
     best_key = better ? key : best_key;
     best_leaf = better ? leaf : best_leaf;
+    if (better) {
+        const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+        const float nx = fmaf(e1y, e2z, -(e1z * e2y));
+        const float ny = fmaf(e1z, e2x, -(e1x * e2z));
+        const float nz = fmaf(e1x, e2y, -(e1y * e2x));
+        const float l2 = nx * nx + ny * ny + nz * nz;
+        const float inv = 1.0f / sqrtf(l2);
+        best_surf = make_float4(nx * inv, ny * inv, nz * inv, c.y);
+    }
     return better;
 }
 
@@ -1394,8 +1438,8 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4u LdsV4u;
 struct CoopTris { v4f a0, b0, c0, a1, b1, c1; };
 // m: the lanes that fetch from global memory (not zero).  ONE vector memory instruction, always.
-__device__ __forceinline__ void coop_issue_node(const DeviceScene& sc, const uint32_t rec, const unsigned long long m, v4u& N) {
-    const CoopChild* np = sc.coop + rec;
+__device__ __forceinline__ void coop_issue_node(const CoopView& cv, const uint32_t rec, const unsigned long long m, v4u& N) {
+    const CoopChild* np = cv.rec + rec;
     unsigned long long sv;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "s_mov_b64 exec, %[m]\n\t"
@@ -1440,17 +1484,20 @@ typedef _Float16 h2f __attribute__((ext_vector_type(2)));
 // R = 1, 2 or 4 rays per wave: lane r < R owns ray r (has_ray: it has one), group r = lanes [r G, (r + 1) G) searches it.
 // Every lane of the wave must call it.  Returns (owner lanes): a hit was found, T.t / T.id / T.leaf_index describe it.
 // lds_nodes_base: the workgroup's staged records (coop_stage_nodes), wl: this wave's words behind them.
+// surf_out (owner lanes, on a hit): the hit triangle's stored unit normal and material bits (walker_apply_hit).
 template <bool IGN, bool COUNT>
-__device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const int R, const bool has_ray, const Ray& own, const float tmax,
-                                          const uint32_t ignore, Trav& T, const int* lds_nodes_base, int* wl, unsigned* overflow) {
+__device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView& cv, const int R, const bool has_ray, const Ray& own, const float tmax,
+                                          const uint32_t ignore, Trav& T, const int* lds_nodes_base, int* wl, unsigned* overflow,
+                                          float4* surf_out = nullptr) {
     const unsigned lane = threadIdx.x & 63u;
     const int gshift = R == 1 ? 6 : (R == 2 ? 5 : 4);
     const int G = 1 << gshift;
     const int g = (int)(lane >> gshift), j = (int)(lane & (unsigned)(G - 1));
     const int cap = kCoopCap >> (6 - gshift);
     int* stk = wl + g * cap;
-    int* rayw = wl + kCoopCap;                                                                 // [group][8]
-    unsigned long long* keyw = reinterpret_cast<unsigned long long*>(wl + kCoopCap + kCoopMaxGroups * 8);   // [group][2]: key | (leaf, -)
+    int* rayw = wl + kCoopCap;                                                                 // [group][kCoopRayWords]
+    int* boxw = wl + kCoopCap + kCoopMaxGroups * kCoopRayWords;                                // [group][kCoopBoxWords]: key | leaf, - | normal, material
+    unsigned long long* keyw = reinterpret_cast<unsigned long long*>(boxw);                    // (group g's key: keyw[4 g])
     T.nv = 0u; T.nt = 0u; T.sp = 0;
     T.t = tmax; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
     if (sc.num_nodes <= 0) return false;                   // empty scene (wave-uniform)
@@ -1459,36 +1506,43 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const int R, co
     T.cur = 0; T.tri_i = 0; T.tri_n = 0; T.sb = 0;
 #endif
     if (lane < (unsigned)R) {   // the owners publish their rays, clear their mailboxes and put the root on their group's stack
-        int* rw = rayw + lane * 8;
+        // (the ray's reciprocals travel too: the owner has them from make_ray; three v_rcp_f32 and their guards per lane and query saved)
+        int* rw = rayw + lane * kCoopRayWords;
         lds_st(rw + 0, __float_as_int(own.ox)); lds_st(rw + 1, __float_as_int(own.oy)); lds_st(rw + 2, __float_as_int(own.oz));
         lds_st(rw + 3, __float_as_int(own.dx)); lds_st(rw + 4, __float_as_int(own.dy)); lds_st(rw + 5, __float_as_int(own.dz));
-        lds_st(rw + 6, __float_as_int(has_ray ? tmax : -1.0f));
-        lds_st(rw + 7, (int)ignore);
-        lds_st64(keyw + 2 * lane, ((unsigned long long)__float_as_uint(tmax) << 32) | 0xFFFFFFFFull);
-        lds_st(reinterpret_cast<int*>(keyw + 2 * lane + 1), -1);
+        lds_st(rw + 6, __float_as_int(own.ix)); lds_st(rw + 7, __float_as_int(own.iy)); lds_st(rw + 8, __float_as_int(own.iz));
+        lds_st(rw + 9, __float_as_int(has_ray ? tmax : -1.0f));
+        lds_st(rw + 10, (int)ignore);
+        lds_st64(keyw + 4 * lane, ((unsigned long long)__float_as_uint(tmax) << 32) | 0xFFFFFFFFull);
+        lds_st(boxw + lane * kCoopBoxWords + 2, -1);
         lds_st(wl + lane * cap, 0);
     }
     __builtin_amdgcn_wave_barrier();
-    const int* rw = rayw + g * 8;
-    const Ray r = make_ray(__int_as_float(lds_ld(rw + 0)), __int_as_float(lds_ld(rw + 1)), __int_as_float(lds_ld(rw + 2)),
-                           __int_as_float(lds_ld(rw + 3)), __int_as_float(lds_ld(rw + 4)), __int_as_float(lds_ld(rw + 5)));
-    const uint32_t ign = (uint32_t)lds_ld(rw + 7);
-    int n = __int_as_float(lds_ld(rw + 6)) > 0.0f ? 1 : 0;   // pending nodes of this group (the same number in all its lanes)
+    const int* rw = rayw + g * kCoopRayWords;
+    Ray r;
+    r.ox = __int_as_float(lds_ld(rw + 0)); r.oy = __int_as_float(lds_ld(rw + 1)); r.oz = __int_as_float(lds_ld(rw + 2));
+    r.dx = __int_as_float(lds_ld(rw + 3)); r.dy = __int_as_float(lds_ld(rw + 4)); r.dz = __int_as_float(lds_ld(rw + 5));
+    r.ix = __int_as_float(lds_ld(rw + 6)); r.iy = __int_as_float(lds_ld(rw + 7)); r.iz = __int_as_float(lds_ld(rw + 8));
+    r.nox = -(r.ox * r.ix); r.noy = -(r.oy * r.iy); r.noz = -(r.oz * r.iz);   // as make_ray
+    const uint32_t ign = (uint32_t)lds_ld(rw + 10);
+    int n = __int_as_float(lds_ld(rw + 9)) > 0.0f ? 1 : 0;   // pending nodes of this group (the same number in all its lanes)
     const unsigned long long gmask = R == 1 ? ~0ull : (((1ull << G) - 1ull) << (g * G));
     const unsigned long long below = gmask & ((1ull << lane) - 1ull);
-    const int kfull = G >> 2;
-    const int theta = cap - (sc.stack_need + 8);           // the stack may grow to here by wide steps
-    const int wide_to = theta - 3 * kfull;                 // with n <= wide_to a full step cannot pass theta
-    const int* bound_w = reinterpret_cast<const int*>(keyw + 2 * g) + 1;   // high word of the mailbox key = closest t so far
+    const int wshift = cv.wshift, per = (1 << wshift) - 1; // 16 (or 4) lanes per node: lane j takes child j & per of node j >> wshift
+    const int kfull = G >> wshift;
+    const int theta = cap - (cv.stack_need + 8);           // the stack may grow to here by wide steps
+    const int wide_to = theta - per * kfull;               // with n <= wide_to a full step cannot pass theta
+    const int* bound_w = boxw + g * kCoopBoxWords + 1;      // high word of the mailbox key = closest t so far
     const bool negx = r.ix < 0.0f, negy = r.iy < 0.0f, negz = r.iz < 0.0f;
     unsigned long long best_key = ~0ull;                   // this lane's own closest hit
     int best_leaf = -1;
+    float4 best_surf = make_float4(0.f, 0.f, 0.f, 0.f);
     int pfirst = 0, pcnt = 0;                              // the leaf whose triangles this lane requested in the previous step
     v4u N = {0u, 0u, 0u, 0u};
     CoopTris X;
     X.a0 = v4f{0.f, 0.f, 0.f, 0.f}; X.b0 = X.a0; X.c0 = X.a0; X.a1 = X.a0; X.b1 = X.a0; X.c1 = X.a0;
-    const int q = j >> 2, c = j & 3;
-    const int resident = sc.lds_nodes;
+    const int q = j >> wshift, c = j & per;
+    const int resident = cv.lds_nodes;
 #ifdef FS_WAVE_TIMELINE
     T.cur = (int)(__builtin_amdgcn_s_memtime() - dbg_t0);
 #endif
@@ -1499,16 +1553,16 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const int R, co
         const float bound = __int_as_float(lds_ld(bound_w));
         // ---- pop: up to G / 4 nodes, fewer when the stack is close to the room the worst-case descent needs
         int kw = kfull;
-        if (n > wide_to) { const int room = theta - n; kw = room >= 3 ? room / 3 : 1; }
+        if (n > wide_to) { const int room = theta - n; kw = room >= per ? room / per : 1; }
         const int k = n < kw ? n : kw;
         const bool act = q < k;
         const int ref = act ? lds_ld(stk + (n - 1 - q)) : 0;
-        const uint32_t rec = 4u * (uint32_t)ref + (uint32_t)c;
+        const uint32_t rec = ((uint32_t)ref << wshift) + (uint32_t)c;
         const bool in_lds = ref < resident;
         // (exactly one request in every step, whatever the lanes need — the counted wait below relies on it: when every
         // record is resident, or only triangles are left, lane 0 fetches record 0 once more)
         const unsigned long long m_glob = __ballot(act && !in_lds);
-        coop_issue_node(sc, rec, m_glob != 0ull ? m_glob : 1ull, N);
+        coop_issue_node(cv, rec, m_glob != 0ull ? m_glob : 1ull, N);
         v4u L = {0u, 0u, 0u, 0u};
         if (act && in_lds) {
             L = *reinterpret_cast<const LdsV4u*>((const LdsInt*)lds_nodes_base + 4u * rec);   // ds_read_b128
@@ -1520,14 +1574,14 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const int R, co
         if (COUNT) T.nv += (act && c == 0) ? 1u : 0u;
         // ---- the triangles requested in the previous step, tested while this step's records are in flight
         if (pcnt > 0) {
-            bool better = coop_tri<IGN>(f4(X.a0), f4(X.b0), f4(X.c0), r, bound, ign, pfirst, best_key, best_leaf);
-            if (pcnt > 1) better = coop_tri<IGN>(f4(X.a1), f4(X.b1), f4(X.c1), r, bound, ign, pfirst + 1, best_key, best_leaf) | better;
+            bool better = coop_tri<IGN>(f4(X.a0), f4(X.b0), f4(X.c0), r, bound, ign, pfirst, best_key, best_leaf, best_surf);
+            if (pcnt > 1) better = coop_tri<IGN>(f4(X.a1), f4(X.b1), f4(X.c1), r, bound, ign, pfirst + 1, best_key, best_leaf, best_surf) | better;
             for (int i = 2; i < pcnt; ++i) {                // leaves of three and four triangles (FS_BVH_LEAF > 2 only)
                 const Tri48 x = sc.tris[pfirst + i];
-                better = coop_tri<IGN>(x.a, x.b, x.c, r, bound, ign, pfirst + i, best_key, best_leaf) | better;
+                better = coop_tri<IGN>(x.a, x.b, x.c, r, bound, ign, pfirst + i, best_key, best_leaf, best_surf) | better;
             }
             if (COUNT) T.nt += (uint32_t)pcnt;
-            if (better) lds_min64(keyw + 2 * g, best_key);  // ds_min_u64: the group's closest hit so far
+            if (better) lds_min64(keyw + 4 * g, best_key);  // ds_min_u64: the group's closest hit so far
             pcnt = 0;
         }
         // ---- this lane's child box: fp16 planes, entry / exit distances as one fma per plane
@@ -1576,16 +1630,24 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const int R, co
 #endif
     // ---- the mailbox holds the closest hit of the group's ray; the lane that found it says which triangle it was
     __builtin_amdgcn_wave_barrier();
-    const unsigned long long fin = lds_ld64(keyw + 2 * g);
-    if (best_leaf >= 0 && best_key == fin) lds_st(reinterpret_cast<int*>(keyw + 2 * g + 1), best_leaf);
+    const unsigned long long fin = lds_ld64(keyw + 4 * g);
+    if (best_leaf >= 0 && best_key == fin) {               // (one lane: a triangle is tested once per query)
+        int* bw = boxw + g * kCoopBoxWords;
+        lds_st(bw + 2, best_leaf);
+        lds_st(bw + 4, __float_as_int(best_surf.x)); lds_st(bw + 5, __float_as_int(best_surf.y));
+        lds_st(bw + 6, __float_as_int(best_surf.z)); lds_st(bw + 7, __float_as_int(best_surf.w));
+    }
     __builtin_amdgcn_wave_barrier();
     bool found = false;
     if (lane < (unsigned)R) {
-        const unsigned long long key = lds_ld64(keyw + 2 * lane);
+        const int* bw = boxw + lane * kCoopBoxWords;
+        const unsigned long long key = lds_ld64(keyw + 4 * lane);
         if ((uint32_t)key != 0xFFFFFFFFu) {
             T.t = __uint_as_float((uint32_t)(key >> 32));
             T.id = (uint32_t)key;
-            T.leaf_index = lds_ld(reinterpret_cast<const int*>(keyw + 2 * lane + 1));
+            T.leaf_index = lds_ld(bw + 2);
+            if (surf_out) *surf_out = make_float4(__int_as_float(lds_ld(bw + 4)), __int_as_float(lds_ld(bw + 5)), __int_as_float(lds_ld(bw + 6)),
+                                                  __int_as_float(lds_ld(bw + 7)));
             found = true;
         }
     }
@@ -1600,20 +1662,20 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const int R, co
 // whole group of 64 / R lanes (trav_coop).  Same walker, records, stages and schedule as walk_sparse_body; the workgroup
 // has blockDim.x / 64 waves (4 or 16: the more waves share the staged records, the more of them fit).
 template <int LOBES, bool COUNT, bool EXT = false>
-__device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
+__device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceScene& sc, const CoopView& cv, const KParams& kp,
                                                const SubpathState& st, const unsigned* __restrict__ scratch,
                                                const uint32_t* __restrict__ perm, const int rays_per_wave,
                                                const WalkStage sr = WalkStage()) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [lds_nodes][16] records | [waves][kCoopWaveWords]
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [lds_nodes][16] records of 4 words | [waves][kCoopWaveWords]
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {
         for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += blockDim.x) s_cnt[i] = scratch[1 + i];
     }
-    coop_stage_nodes(sc, s_dyn);                            // (with the barrier the bucket counts need)
+    coop_stage_nodes(cv, s_dyn);                            // (with the barrier the bucket counts need)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
-    int* wl = s_dyn + 16 * (size_t)sc.lds_nodes + (size_t)(threadIdx.x >> 6) * kCoopWaveWords;
+    int* wl = coop_wave_words(cv, s_dyn);
     bool alive = lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
     Walker w;
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
@@ -1625,6 +1687,14 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
     const bool mine = alive;
     Ray ray = make_ray(0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
+    // The Philox words of a walk's bounces depend on (seed, pair, side, bounce) alone: the 64 / R lanes of the walk's group
+    // compute the words of the next 64 / R bounces at once (ten rounds of four quarter-rate multiplies each, per bounce and
+    // walk otherwise: a sixth of the time between two queries), the owner picks its bounce's words out of LDS.
+    const int rshift = rays_per_wave == 1 ? 6 : (rays_per_wave == 2 ? 5 : 4);
+    const int RG = 1 << rshift;
+    int* rngw = wl + kCoopCap + kCoopMaxGroups * (kCoopRayWords + kCoopBoxWords);   // [64] uint4 | [group] (pair, side, seed, first bounce)
+    int* rngb = rngw + 64 * 4;
+    int rng_k0 = -(1 << 20);                               // owner lanes: the first bounce their group's cache holds
 #ifdef FS_WAVE_TIMELINE
     const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
     unsigned long long tl_trav = 0, tl_seg = 0, tl_next = 0, tl_steps = 0, tl_pro = 0, tl_tri = 0, tl_nodewait = 0, tl_epi = 0;
@@ -1634,10 +1704,32 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
 #ifdef FS_WAVE_TIMELINE
         const unsigned long long tl_n = __builtin_amdgcn_s_memtime();
 #endif
+        {   // refill the Philox cache of the groups whose walk has left it (every group recomputes: the others get the words they had)
+            const bool need = alive && w.k < sr.end && (w.k < rng_k0 || w.k >= rng_k0 + RG);
+            if (__ballot(need) != 0ull) {
+                if (lane < (uint32_t)rays_per_wave) {
+                    if (need) rng_k0 = w.k;
+                    int* b = rngb + lane * 4;
+                    lds_st(b + 0, (int)w.pair); lds_st(b + 1, (int)w.side);
+                    lds_st(b + 2, (int)(kp.item_seeds > 0 ? item_seed_lo(kp, w.li / kp.pairs_per_source) : kp.seed_lo));
+                    lds_st(b + 3, rng_k0);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int* b = rngb + (lane >> rshift) * 4;
+                const uint32_t bounce = (uint32_t)(lds_ld(b + 3) + (int)(lane & (uint32_t)(RG - 1)));
+                const uint4 pr = philox((uint32_t)lds_ld(b + 0), (bounce << 1) | (uint32_t)lds_ld(b + 1), 0, (uint32_t)lds_ld(b + 2), kp.seed_hi);
+                lds_st(rngw + 4 * lane + 0, (int)pr.x); lds_st(rngw + 4 * lane + 1, (int)pr.y);
+                lds_st(rngw + 4 * lane + 2, (int)pr.z); lds_st(rngw + 4 * lane + 3, (int)pr.w);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         if (alive) {
             if (w.k >= sr.end) { walker_suspend(w, st); alive = false; }   // staged walk: the next stage goes on from here
             else {
-                go = walker_next_ray<LOBES>(w, kp, sc, st, ray);
+                const int ri = 4 * (((int)lane << rshift) + (w.k - rng_k0));   // owner lane g: its group's lanes start at g * RG
+                const uint4 pre = make_uint4((uint32_t)lds_ld(rngw + ri), (uint32_t)lds_ld(rngw + ri + 1), (uint32_t)lds_ld(rngw + ri + 2),
+                                             (uint32_t)lds_ld(rngw + ri + 3));
+                go = walker_next_ray<LOBES>(w, kp, sc, st, ray, &pre);
                 if (!go) {
                     walker_finish<EXT>(w, st);
                     if (st.cont_b && w.k >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // a walk of the last schedule bucket: later stages visit this slot again
@@ -1651,7 +1743,8 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
         const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
         tl_next += tl_a - tl_n;
 #endif
-        trav_coop<EXT, COUNT>(sc, rays_per_wave, go, ray, kp.max_trace_dist, w.ign, T, s_dyn, wl, st.overflow);
+        float4 surf = make_float4(0.f, 0.f, 0.f, 0.f);
+        trav_coop<EXT, COUNT>(sc, cv, rays_per_wave, go, ray, kp.max_trace_dist, w.ign, T, s_dyn, wl, st.overflow, &surf);
 #ifdef FS_WAVE_TIMELINE
         tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
         tl_steps += (unsigned long long)T.sp;
@@ -1659,7 +1752,7 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
         ++tl_seg;
 #endif
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
-        if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
+        if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T, &surf);
     }
     count_walk_segments(&s_seg[threadIdx.x >> 6], mine ? (unsigned)(w.k - k_first) : 0u, scratch);
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
@@ -2025,11 +2118,11 @@ inline size_t device_lds_per_block() {
 // How many nodes of the breadth-first array a cooperative kernel stages in every workgroup's LDS: all of the tree if it
 // fits, else its top.  A launch whose workgroups all fit the chip at once (one per CU) may take the CU's whole LDS; one
 // that comes in rounds leaves room for a second workgroup per CU.
-inline int coop_resident_nodes(const DeviceScene& sc, int waves_per_block, uint32_t blocks, int num_cus) {
+inline int coop_resident_nodes(const CoopView& cv, int waves_per_block, uint32_t blocks, int num_cus) {
     const size_t cu_lds = 160 * 1024, per_block = std::min(device_lds_per_block(), blocks <= (uint32_t)std::max(num_cus, 1) ? cu_lds : cu_lds / 2);
     const size_t fixed = kCoopWaveBytes * (size_t)waves_per_block + 1024;   // + the kernels' small static arrays
-    if (per_block <= fixed || !sc.coop) return 0;
-    return (int)std::min<size_t>((size_t)std::max(sc.num_nodes, 0), (per_block - fixed) / 64);
+    if (per_block <= fixed || !cv.rec) return 0;
+    return (int)std::min<size_t>((size_t)std::max(cv.nodes, 0), (per_block - fixed) / ((size_t)16 << cv.wshift));
 }
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {

@@ -59,12 +59,28 @@ static_assert(sizeof(Tri48) == 48, "Tri48 must be 48 B");
 // NodeQ4 array after every commit and refit (fs_refit.hip: coop_nodes_kernel):
 //   lo.x lo.y | lo.z hi.x | hi.y hi.z   the child's box as fp16, rounded outwards (conservative; an empty slot is the
 //                                       inverted box +inf / -inf), ref = NodeQ4.child[c]
-// Record 4 * node + child; 64 B per node like NodeQ4.
+// Record 4 * node + child (an intermediate array), then folded TWO LEVELS AT A TIME into 16-wide nodes — record
+// 16 * dense node + slot, 256 B per node, inner references = dense indices of the even levels (fs_refit.hip:
+// coop16_kernel): a query takes half as many steps.  DeviceScene.coop points at the 16-wide array.
 struct alignas(16) CoopChild {
     uint32_t lo_xy, loz_hix, hi_yz;
     int32_t ref;
 };
 static_assert(sizeof(CoopChild) == 16, "CoopChild must be 16 B");
+
+// What a cooperative kernel is given beside the scene: one of the two node arrays of that traversal.
+//   wshift 4: the 16-wide nodes (two levels of the 4-wide tree folded together, dense order of the even levels): half the
+//             steps per query — what waves of one or two rays walk (a group of 64 / 32 lanes takes 4 / 2 nodes per step);
+//   wshift 2: the per-child records of the 4-wide nodes as they are — what waves of FOUR rays walk: a group of 16 lanes
+//             takes four of those nodes per step but only one 16-wide one (old_mine, 128 sources: 1.76 against 1.99 ms per tick).
+// lds_nodes: nodes [0, lds_nodes) are resident in the workgroup's LDS (set by the launcher: what fits).
+// stack_need: worst-case pending entries of a one-node-at-a-time descent (what trav_coop keeps free before it widens).
+struct CoopView {
+    const CoopChild* rec;     // [nodes << wshift]
+    int32_t lds_nodes, nodes;
+    int16_t wshift, stack_need;
+};
+struct CoopInfo { CoopView wide16{}, wide4{}; };
 
 // Per-lane traversal stack in LDS: DeviceScene.stack_rows rows of kBlock ints, sized at run time from the committed
 // tree (its worst-case need + kStackSlack), passed as dynamic shared memory.  A node visit that pushes writes its
@@ -106,10 +122,7 @@ struct DeviceScene {
                               //   lane to trav_maintain at the top of a step (fs_device.hpp)
     int32_t stack_worst;      // rows of a stack that cannot overflow (worst case + 1) if a workgroup may have that much LDS, else
                               //   0: what the wide flavour of the frame kernel runs with (fs_frame.hip)
-    const CoopChild* coop;    // [4 * num_nodes] the cooperative traversal's records (above)
-    int32_t lds_nodes;        // nodes [0, lds_nodes) are resident in the workgroup's LDS (set by the launcher of a cooperative kernel: what fits)
-    int32_t stack_need;       // the tree's worst-case number of pending entries of a one-node-at-a-time descent (HostBVH.stack_need):
-                              //   what the cooperative traversal keeps free in a group's node stack before it widens (trav_coop)
+    const struct CoopInfo* coop_info;   // host bookkeeping: the cooperative traversal's node arrays (CoopView below); unused on the device
     int32_t* deep;
     uint32_t deep_lanes;
     struct DeepStore* deep_owner;   // host bookkeeping (grows the store when a launch has more lanes); unused on the device
@@ -341,7 +354,9 @@ void launch_update_triangles(Tri64* tris, Tri48* packed, float4* nrm, const uint
 void launch_pack_triangles(const Tri64* tris, int count, Tri48* packed, float4* nrm, hipStream_t s);
 void launch_refit(NodeQ4* nodes, const Tri64* tris, float4* node_box, const int32_t* level_begin, int levels, float pad,
                   hipStream_t s);
-void launch_coop_nodes(const NodeQ4* nodes, int n, CoopChild* out, hipStream_t s);   // the cooperative traversal's records from the current nodes
+void launch_coop_nodes(const NodeQ4* nodes, int n, CoopChild* out, hipStream_t s);   // per-child records of the current 4-wide nodes
+// ... folded two levels at a time into 16-wide nodes in the dense order of the even levels (fs_refit.hip)
+void launch_coop16(const CoopChild* in, const int32_t* level_begin_dev, const int32_t* dense_dev, int levels, int n16, CoopChild* out, hipStream_t s);
 // fs_build.hip: the acceleration structure built on the device (Morton codes, radix sort, Karras' binary radix tree,
 // breadth-first collapse to 4-wide nodes); launch_refit then derives the quantised boxes.  DeviceBuildInfo is what the
 // host reads back: levels < 0 = the tree is deeper than kMaxBuildLevels or ran out of node space (use the host build).

@@ -184,11 +184,50 @@ __global__ __launch_bounds__(kRefitBlock) void coop_nodes_kernel(const NodeQ4* _
     out[i] = r;
 }
 
+// Two levels of the 4-wide tree folded into one 16-wide node (what the cooperative traversal walks: half the steps per
+// query).  Node X of an EVEN level becomes 16 records: for each child c of X — a leaf: its own record (and three empty
+// ones); an inner node Y: the records of Y's four children.  The inner references among them (nodes of level + 2) are
+// renumbered into the DENSE order of the even levels (dense[l] = first dense index of level l, -1 for odd levels), so that
+// the array — and its LDS-resident prefix — holds nothing but nodes the traversal can reach.  One thread per (dense node, slot).
+__global__ __launch_bounds__(kRefitBlock) void coop16_kernel(const CoopChild* __restrict__ in, const int32_t* __restrict__ level_begin,
+                                                             const int32_t* __restrict__ dense, int levels, int n16,
+                                                             CoopChild* __restrict__ out) {
+    const int i = blockIdx.x * kRefitBlock + threadIdx.x;
+    if (i >= 16 * n16) return;
+    const int d = i >> 4, slot = i & 15, c = slot >> 2, g = slot & 3;
+    int l = 0;
+    for (int k = 0; k < levels; k += 2)                      // the even level that holds dense node d
+        if (dense[k] >= 0 && dense[k] <= d) l = k;
+    const int X = level_begin[l] + (d - dense[l]);
+    CoopChild r;
+    r.lo_xy = 0x7C007C00u; r.loz_hix = 0xFC007C00u; r.hi_yz = 0xFC00FC00u; r.ref = 0;     // empty: the inverted box
+    const CoopChild xc = in[4 * X + c];
+    const bool x_empty = xc.lo_xy == 0x7C007C00u && xc.loz_hix == 0xFC007C00u;
+    if (!x_empty) {
+        if (xc.ref < 0) {                                     // a leaf child of X: its own record in the group's first slot
+            if (g == 0) r = xc;
+        } else {                                              // an inner child Y: Y's child g
+            const CoopChild yc = in[4 * xc.ref + g];
+            const bool y_empty = yc.lo_xy == 0x7C007C00u && yc.loz_hix == 0xFC007C00u;
+            if (!y_empty) {
+                r = yc;
+                if (yc.ref >= 0) r.ref = dense[l + 2] + (yc.ref - level_begin[l + 2]);   // a node of level l + 2, renumbered
+            }
+        }
+    }
+    out[i] = r;
+}
+
 }  // namespace
 
 void launch_coop_nodes(const NodeQ4* nodes, int n, CoopChild* out, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(coop_nodes_kernel, dim3((unsigned)((4 * n + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, s, nodes, n, out);
+}
+void launch_coop16(const CoopChild* in, const int32_t* level_begin_dev, const int32_t* dense_dev, int levels, int n16, CoopChild* out, hipStream_t s) {
+    if (n16 <= 0) return;
+    hipLaunchKernelGGL(coop16_kernel, dim3((unsigned)((16 * n16 + kRefitBlock - 1) / kRefitBlock)), dim3(kRefitBlock), 0, s, in, level_begin_dev, dense_dev,
+                       levels, n16, out);
 }
 
 void launch_update_triangles(Tri64* tris, Tri48* packed, float4* nrm, const uint32_t* leaf_pos, int first, int count,

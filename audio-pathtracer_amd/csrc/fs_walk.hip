@@ -71,20 +71,20 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KPa
 }
 
 template <int LOBES, bool COUNT, bool EXT = false>
-__global__ __launch_bounds__(kBlock) void walk_kernel_coop(DeviceScene sc, KParams kp, SubpathState st,
+__global__ __launch_bounds__(kBlock) void walk_kernel_coop(DeviceScene sc, CoopView cv, KParams kp, SubpathState st,
                                                            const unsigned* __restrict__ scratch,
                                                            const uint32_t* __restrict__ perm, int rays_per_wave,
                                                            WalkStage stage) {
-    walk_coop_body<LOBES, COUNT, EXT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave, stage);
+    walk_coop_body<LOBES, COUNT, EXT>(blockIdx.x, sc, cv, kp, st, scratch, perm, rays_per_wave, stage);
 }
 // the default instantiation with eight waves per workgroup: one workgroup per CU keeps sixteen hundred more resident
 // records in its LDS than two workgroups of four waves could (fs_device.hpp: coop_lds_bytes)
 constexpr int kCoopBigWaves = 8;
-__global__ __launch_bounds__(64 * kCoopBigWaves) void walk_kernel_coop_big(DeviceScene sc, KParams kp, SubpathState st,
+__global__ __launch_bounds__(64 * kCoopBigWaves) void walk_kernel_coop_big(DeviceScene sc, CoopView cv, KParams kp, SubpathState st,
                                                                            const unsigned* __restrict__ scratch,
                                                                            const uint32_t* __restrict__ perm, int rays_per_wave,
                                                                            WalkStage stage) {
-    walk_coop_body<0, false, false>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave, stage);
+    walk_coop_body<0, false, false>(blockIdx.x, sc, cv, kp, st, scratch, perm, rays_per_wave, stage);
 }
 
 }  // namespace
@@ -136,19 +136,21 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
         else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
         else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \
     } while (0)
-    if (shared && wl.coop && sc.coop && coop_rays_per_wave(wl.rays_per_wave)) {   // a handful of subpaths per wave: every query searched by a whole group of lanes
+    const CoopView* cvp = shared && wl.coop && coop_rays_per_wave(wl.rays_per_wave) ? coop_view(sc, wl.rays_per_wave) : nullptr;
+    if (cvp) {   // a handful of subpaths per wave: every query searched by a whole group of lanes
+        CoopView cv = *cvp;
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const bool plain = !(kp.dpos || kp.ignore_on || kp.listener_radius > 0.0f || kp.source_radius > 0.0f || kp.lobes || kp.count);
         // workgroups of eight waves when the frame needs more than four waves per CU (and the instantiation exists)
         const int W = plain && waves > 4u * (uint32_t)std::max(wl.num_cus, 1) ? kCoopBigWaves : kBlock / 64;
         const uint32_t blocks = (waves + (uint32_t)W - 1) / (uint32_t)W;
-        sc.lds_nodes = coop_resident_nodes(sc, W, blocks, wl.num_cus);
-        const size_t lds = coop_lds_bytes(W, sc.lds_nodes), lds_ext = lds;
+        cv.lds_nodes = coop_resident_nodes(cv, W, blocks, wl.num_cus);
+        const size_t lds = coop_lds_bytes(W, cv), lds_ext = lds;
         if (W == kCoopBigWaves) {
             allow_lds(walk_kernel_coop_big, lds);
-            hipLaunchKernelGGL(walk_kernel_coop_big, dim3(blocks), dim3(64 * W), lds, s, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
+            hipLaunchKernelGGL(walk_kernel_coop_big, dim3(blocks), dim3(64 * W), lds, s, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
         } else {
-            FS_LAUNCH_WALK(walk_kernel_coop, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
+            FS_LAUNCH_WALK(walk_kernel_coop, blocks, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
         }
         return;
     }
