@@ -364,7 +364,7 @@ int ir_ring_backpressure_for(fs_context* ctx, Source* s) { return ir_ring_backpr
 // Anything unusual about a source's frame (a literal second flush, per-kernel timing) sends the whole batch the ordinary way.
 int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
     { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // IRs are published in frame order
-    bool plain = ctx->profiling < 2 && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) && count > 1;
+    bool plain = ctx->profiling < 2 && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT);   // (also for ONE source: no copy command, one event)
     for (int i = 0; i < count; ++i)
         if (ctx->cfg.world_size > 1 && !srcs[i]->reduced && !srcs[i]->handed_off) plain = false;   // (reconstruct_now refuses with the message)
     if (!plain) {

@@ -578,6 +578,34 @@ __device__ __forceinline__ void apply_segment(float (&E)[Bands<B>::kMax], float 
     }
 }
 
+// The factors apply_segment multiplies in, computed apart from the running product: one lane per SEGMENT of a connected path
+// evaluates them (the pow, the exponentials, the divisions), and the product over the path — strictly in the reference's
+// order — is then four multiplications and a division per segment and band (connect_body, one pair per wave: a path of
+// 160 segments took 40 us of one lane's time).  The same expressions as apply_segment, so the same bits.
+template <int B>
+struct SegFactors { float geo, pw; bool live; float bsdf[Bands<B>::kMax], ex[Bands<B>::kMax]; };
+template <int B, int LOBES = -1>
+__device__ __forceinline__ void segment_factors(SegFactors<B>& f, float nd, uint32_t mat, float prob, const KParams& kp, const DeviceScene& sc) {
+    const int NB = band_count<B>(kp);
+    const bool lobes = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
+    f.live = !(nd < kp.min_seg);                   // ARTS.cpp:375-378
+    float nd2 = nd * nd;
+    f.geo = 1.0f / (4 * kPi * nd2);                // ARTS.cpp:391
+    f.pw = powf(prob, kp.prob_exponent);           // ARTS.cpp:398
+    const uint32_t lobe = (lobes && mat != kNoMat) ? ((mat >> kLobeShift) & 3u) : 0u;
+    if (lobes && mat != kNoMat) mat &= 0xFFFFu;
+    bool has = (mat != kNoMat) && ((int32_t)mat < sc.num_materials);
+    const float* coeff = lobes ? sc.lobe_gain + ((size_t)mat * 3 + lobe) * NB : sc.absorption + (size_t)mat * NB;
+    const bool over_pi = !lobes || lobe == kLobeDiffuse;
+#pragma unroll
+    for (int b = 0; b < Bands<B>::kMax; ++b) {
+        f.bsdf[b] = 1.0f; f.ex[b] = 1.0f;
+        if (B == 0 && b >= NB) continue;
+        if (has) f.bsdf[b] = over_pi ? coeff[b] / kPi : coeff[b];      // ARTS.cpp:382-386
+        f.ex[b] = expf(-kp.air[b] * nd);           // ARTS.cpp:395-397
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the walk, shared by both kernel variants
 // ---------------------------------------------------------------------------------------------------
@@ -1861,16 +1889,66 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #ifdef FS_WAVE_TIMELINE
         if (!tl[2]) tl[2] = __builtin_amdgcn_s_memrealtime();   // first chunk: visibility queries done
 #endif
+        float E[Bands<B>::kMax];
+#pragma unroll
+        for (int b = 0; b < Bands<B>::kMax; ++b) E[b] = 1.0f;
+        float sd = 0.0f;
+        if (ppw == 1u) {
+            // ONE pair per wave (the reference's own frames): the wave's 64 lanes evaluate the connected path together — lane i
+            // the factors of segment i (64 segments per round), then every lane runs the same product over them in path
+            // order, the factors read across with v_readlane.  Lane 0 owns the pair and deposits.
+            bool go = active && !hit && !sphere_blocked;
+            if (go && st.over_levels && !(rec_fits(st, (int)Fm.y - 1, sf) && rec_fits(st, (int)Lm.y - 1, sl))) go = false;
+            if (!__builtin_amdgcn_readfirstlane((int)go)) return;      // (lane 0 is the first lane: whole waves step through the pairs)
+            const int kf = __builtin_amdgcn_readfirstlane((int)Fm.y), kl = __builtin_amdgcn_readfirstlane((int)Lm.y);
+            const uint32_t usf = (uint32_t)__builtin_amdgcn_readfirstlane((int)sf), usl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
+            const float c_nd = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((EXT && kp.dpos) ? conn_nd : sqrtf(l2) / kp.dist_divisor)));
+            const uint32_t c_mat = (uint32_t)__builtin_amdgcn_readfirstlane((int)Fm.x);
+            const float c_prob = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(F.w)));
+            const int segs = kf + 1 + kl;
+            for (int base = 0; base < segs; base += 64) {
+                const int i = base + (int)lane;
+                float nd = 0.0f, prob = 1.0f;
+                uint32_t mat = kNoMat;
+                if (i < kf) {                                            // source-side segment F_i -> F_i+1
+                    const float2 np = load_np(st, total, i, usf);
+                    nd = np.x; prob = np.y; mat = load_mat(st, total, i, usf);
+                } else if (i == kf) {                                    // connection segment: F_k's material / prob
+                    nd = c_nd; prob = c_prob; mat = c_mat;
+                } else if (i < segs) {                                   // listener-side segment B_j+1 -> B_j, j = kl - 1 .. 0
+                    const int j = kl - 1 - (i - kf - 1);
+                    const float2 np = load_np(st, total, j, usl);
+                    nd = np.x; prob = np.y; mat = load_mat(st, total, j, usl);
+                }
+                SegFactors<B> f;
+                segment_factors<B, LOBES>(f, nd, mat, prob, kp, sc);
+                const int cnt = min(64, segs - base);
+                for (int q = 0; q < cnt; ++q) {                          // (wave-uniform: the product in path order, in every lane alike)
+                    sd += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), q));                  // ARTS.cpp:374
+                    if (!__builtin_amdgcn_readlane((int)f.live, q)) continue;
+                    const float geo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.geo), q));
+                    const float pw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.pw), q));
+#pragma unroll
+                    for (int b = 0; b < Bands<B>::kMax; ++b) {
+                        if (B == 0 && b >= NB) break;
+                        float e = E[b];
+                        e *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.bsdf[b]), q));
+                        e *= geo;
+                        e *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.ex[b]), q));
+                        e /= pw;
+                        E[b] = e;
+                    }
+                }
+            }
+            if (lane != 0u) return;
+            ++my_deposits;
+        } else {
         if (!active || hit || sphere_blocked) return;
         // depth = 0 only: a walk that outlived the record store has raised the overflow word — the frame is void and will
         // be traced again (FS_ERR_OVERFLOW); its pair must not be evaluated, the records it would read do not exist
         if (st.over_levels && !(rec_fits(st, (int)Fm.y - 1, sf) && rec_fits(st, (int)Lm.y - 1, sl))) return;
         ++my_deposits;
         // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
-        float E[Bands<B>::kMax];
-#pragma unroll
-        for (int b = 0; b < Bands<B>::kMax; ++b) E[b] = 1.0f;
-        float sd = 0.0f;
         const int kf = (int)Fm.y, kl = (int)Lm.y;
         for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
             const float2 np = load_np(st, total, j, sf);
@@ -1887,6 +1965,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
             const float2 np = load_np(st, total, j, sl);
             sd += np.x;
             apply_segment<B, LOBES>(E, np.x, load_mat(st, total, j, sl), np.y, kp, sc);
+        }
         }
         float delay = sd / kp.sound_speed;                            // ARTS.cpp:419
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
