@@ -148,6 +148,9 @@ class Stats(C.Structure):
         ("walk_tri_fetches", C.c_uint64),
         ("any_node_fetches", C.c_uint64),
         ("any_tri_fetches", C.c_uint64),
+        ("node_request_insts", C.c_uint64),
+        ("node_request_lanes", C.c_uint64),
+        ("node_request_distinct", C.c_uint64),
         ("planned_segments", C.c_uint64),
     ]
 

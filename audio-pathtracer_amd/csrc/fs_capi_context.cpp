@@ -478,6 +478,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
+    if (const char* v = std::getenv("FS_DEBUG_COHERENT_WAVES")) ctx->debug_coherent = std::atoi(v) != 0;   // timing experiments only: results are void
     if (const char* v = std::getenv("FS_OVER_CAP")) ctx->over_cap_forced = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("FS_WALK_COOP")) ctx->walk.coop = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_FUSED_RECON")) ctx->fused_recon = std::atoi(v) != 0;
@@ -646,6 +647,7 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         ctx->stats.walk_tri_fetches = c[4];
         ctx->stats.any_node_fetches = c[5];
         ctx->stats.any_tri_fetches = c[6];
+        ctx->stats.node_request_insts = c[8]; ctx->stats.node_request_lanes = c[9]; ctx->stats.node_request_distinct = c[10];
     }
     *out = ctx->stats;
     return FS_OK;

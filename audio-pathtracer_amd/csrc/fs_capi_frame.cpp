@@ -498,7 +498,8 @@ void frame_describe(fs_context* ctx, Frame& f) {
     f.levels = p->depth > 0 ? p->depth : FS_MAX_DEPTH;
     kp.depth = f.unbounded ? FS_MAX_DEPTH + kOverLevels : f.levels;
     kp.mis_depth = f.unbounded ? kUnboundedDepth : f.levels;
-    kp.russian_roulette = p->russian_roulette;
+    kp.russian_roulette = p->russian_roulette ? 1 : 0;
+    kp.debug_coherent = ctx->debug_coherent ? 1 : 0;
     kp.cosine = (p->flags & FS_FLAG_COSINE_SAMPLING) ? 1 : 0;
     kp.rr_prob = p->rr_prob;
     kp.stage_margin = ctx->stage_margin;

@@ -300,6 +300,7 @@ struct fs_context {
     double* d_end_posd = nullptr; size_t cap_posd = 0;   // FS_FLAG_DOUBLE_POSITIONS: end points in double [lanes][3] (such frames are never held: one set)
     float4* d_cont = nullptr;        // continuation records of staged walks: [state_sets][2][cap_lanes]
     uint32_t over_cap = 0, over_cap_pos = 0;
+    bool debug_coherent = false;   // FS_DEBUG_COHERENT_WAVES (KParams.debug_coherent)
     int over_cap_forced = 0;       // FS_OVER_CAP, read at fs_context_create
     unsigned* d_overflow = nullptr;
     bool overflow_armed = false;   // an unbounded frame has been enqueued since the word was last read

@@ -202,13 +202,14 @@ struct Trav {
     int leaf_index; // hit triangle (leaf order), -1 = none
     uint32_t id;    // its input index (tie-break key)
     uint32_t nv, nt;   // COUNT instantiations only (fs_set_profiling level 3): node records / triangle records this lane fetched
+    uint32_t ni, nl, nd;   // ... and (one lane per wave) node-request instructions, their active lanes, the distinct records among those
 };
 
 __device__ __forceinline__ void trav_init(Trav& T, float tmax, bool scene_nonempty) {
     T.cur = scene_nonempty ? 0 : kDone;
     T.sp = 0; T.sb = 0; T.tri_i = 0; T.tri_n = 0;
     T.t = tmax; T.leaf_index = -1; T.id = 0xFFFFFFFFu;
-    T.nv = 0u; T.nt = 0u;
+    T.nv = 0u; T.nt = 0u; T.ni = 0u; T.nl = 0u; T.nd = 0u;
 }
 __device__ __forceinline__ bool trav_busy(const Trav& T) { return T.tri_i < T.tri_n || T.cur != kDone; }
 
@@ -488,6 +489,21 @@ __device__ __forceinline__ void trav_advance(const DeviceScene& sc, const Ray& r
     if (has_node) trav_node_part(sc, r, T, stack, N);
     if (has_tri) ++T.tri_i;
     trav_settle(sc, T, stack);
+    if (COUNT) {   // counting instantiation only: how coherent is this wave's node request?  lanes that take part, distinct 64-B records among them
+        const unsigned long long mn = __ballot(T.cur >= 0);
+        if (mn != 0ull) {
+            unsigned distinct = 0;
+            for (unsigned long long rest = mn; rest != 0ull; rest &= rest - 1ull) {
+                const int l = __ffsll((long long)rest) - 1;
+                const int v = __builtin_amdgcn_readlane(T.cur, l);
+                const unsigned long long same = __ballot(T.cur == v) & mn;
+                distinct += (__ffsll((long long)same) - 1) == l ? 1u : 0u;
+            }
+            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)__ballot(true)) - 1)) {
+                T.ni += 1u; T.nl += (uint32_t)__popcll(mn); T.nd += distinct;
+            }
+        }
+    }
     trav_issue(sc, T, N, nxt);
     // the triangle test must stay BEHIND the requests: it is plain arithmetic on registers, which the compiler would
     // otherwise move in front of the (to it unrelated) load instructions — and then fold the two register sets into one
@@ -1242,14 +1258,16 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     if (perm) __syncthreads();
     const uint32_t slot = bid * kBlock + threadIdx.x;
     if (slot >= stage_slots(sr, st, 2u * kp.num_local, s_cnt)) return;
-    const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
+    // (FS_DEBUG_COHERENT_WAVES: every lane of the wave walks the subpath of the wave's first slot — timing experiments only)
+    const uint32_t gslot = kp.debug_coherent ? (slot & ~63u) : slot;
+    const uint32_t g = perm ? planned_subpath(gslot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : gslot;
     int* stack = &s_stack[threadIdx.x];
     Walker w;
     walker_start(w, g, slot, kp, st, sr.begin == 0);
     if (sr.begin > 0 && !walker_resume(w, st, sr.begin)) return;
     const int k_first = w.k;
     Ray ray;
-    uint32_t cnt_nv = 0u, cnt_nt = 0u;
+    uint32_t cnt_nv = 0u, cnt_nt = 0u, cnt_ni = 0u, cnt_nl = 0u, cnt_nd = 0u;
 #ifdef FS_WAVE_TIMELINE
     const unsigned long long tl_r0 = __builtin_amdgcn_s_memrealtime(), tl_c0 = __builtin_amdgcn_s_memtime();
     unsigned long long tl_trav = 0, tl_seg = 0;
@@ -1270,11 +1288,15 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
         tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
         ++tl_seg;
 #endif
-        if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
+        if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; cnt_ni += T.ni; cnt_nl += T.nl; cnt_nd += T.nd; }
         walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
     count_walk_segments(&s_seg[threadIdx.x >> 6], (unsigned)(w.k - k_first), scratch);
-    if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
+    if (COUNT) {
+        add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
+        unsigned long long* counters = reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(scratch) + kCounterWord);
+        if (cnt_ni) { atomicAdd(&counters[8], (unsigned long long)cnt_ni); atomicAdd(&counters[9], (unsigned long long)cnt_nl); atomicAdd(&counters[10], (unsigned long long)cnt_nd); }
+    }
 #ifdef FS_WAVE_TIMELINE
     {
         unsigned long long seg_max = tl_seg, trav_max = tl_trav;   // lanes of a wave leave the loop at different bounces

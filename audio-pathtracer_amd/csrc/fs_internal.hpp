@@ -142,7 +142,9 @@ struct KParams {
     int32_t depth;         // max segments per subpath: 1..FS_MAX_DEPTH, or main_levels + over_levels for depth = 0 (a bound the
                            //   roulette practically never reaches: 0.9^512 ~ 4e-24)
     int32_t mis_depth;     // depth cap D of the all-connections weights (kUnboundedDepth for depth = 0)
-    int32_t russian_roulette;
+    int16_t russian_roulette;
+    int16_t debug_coherent;   // FS_DEBUG_COHERENT_WAVES (timing experiments only, results are void): all 64 lanes of a dense walk wave walk the SAME subpath
+                              //   — the ceiling of what re-binning subpaths for coherence could buy
     int16_t cosine;
     int16_t ignore_on;     // some walk of the frame ignores an actor: the EXT instantiations run (16 bits each: the fused launch's 4 KB of arguments are full)
     int32_t lobes;         // 1 = FS_FLAG_MATERIAL_LOBES: the walk picks a specular / diffuse / transmitted lobe per vertex
@@ -264,7 +266,8 @@ constexpr int kScratchWords = 1 + 2 * (FS_MAX_DEPTH + 1);
 // frame scratch allocation: kScratchWords rearmed every frame, then (8-byte aligned) kNumCounters u64 work
 // counters that accumulate until fs_reset_stats: walk segments, connections tested, deposits
 constexpr int kCounterWord = (kScratchWords + 1) & ~1;
-constexpr int kNumCounters = 8;   // walk segments (observed), connections tested, deposits | level 3: walk node / triangle records, any-hit node / triangle records | planned segments
+constexpr int kNumCounters = 12;  // walk segments (observed), connections tested, deposits | level 3: walk node / triangle records, any-hit node / triangle records |
+                                  // planned segments | level 3: node-record request instructions of the walk, their active lanes, the distinct 64-B records among those | spare
 constexpr int kScratchAllocWords = kCounterWord + 2 * kNumCounters;
 // plan pass (length-bucketed schedule + FlushEnergyBuffer); returns the bucket array to walk through, or
 // nullptr when no plan applies (the caller then clears the energy buffer itself)

@@ -205,6 +205,9 @@ typedef struct fs_stats {
      * by the any-hit queries of the connections: the kernel's OWN algorithmic bytes (SURVEY.md 8d prices the oracle's
      * BVH2 instead) */
     uint64_t walk_node_fetches, walk_tri_fetches, any_node_fetches, any_tri_fetches;
+    uint64_t node_request_insts, node_request_lanes, node_request_distinct;   /* profiling level 3, the dense walk: node-record request
+                                  * instructions of its waves, the lanes that took part in them, the distinct 64-B records among those
+                                  * lanes — how coherent the requests are (lanes / insts of 64; distinct / lanes: 1 = no two lanes share) */
     uint64_t planned_segments;   /* walk segments as the plan pass predicts them from the RNG stream alone (the roulette does not
                                   * depend on geometry); `segments`, `connections_tested` and `deposits` are what the walk and the
                                   * connect kernels counted as they worked: both must agree (the tests assert it) */
