@@ -506,8 +506,9 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
         ctx->stage_bounds = b;   // empty: depth = 0 frames are not held
         ctx->stage_bounds_default = false;
     }
+    if (const char* v = std::getenv("FS_SYNC_FIRST_RPW")) ctx->sync_first_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
     if (const char* v = std::getenv("FS_SYNC_LATE_RPW")) ctx->sync_late_rays_per_wave = std::max(0, std::min(64, std::atoi(v)));
-    ctx->sync_stage_bounds = {16};   // tools/sync_stage_sweep.py, profiles/r04_sync_stage_sweep.jsonl
+    ctx->sync_stage_bounds = {24};   // tools/sync_stage_sweep.py, profiles/r04_sync_stage_sweep*.jsonl
     if (const char* v = std::getenv("FS_SYNC_WALK_STAGES")) {
         std::vector<int> b;
         for (const char* q = v; *q;) {

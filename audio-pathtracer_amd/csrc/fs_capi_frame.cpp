@@ -866,7 +866,11 @@ int frame_launch(fs_context* ctx, Frame& f) {
         for (size_t k = 0; k < f.stages.size(); ++k) {
             WalkLaunch wk = wl;
             if (ctx->walk_rays_per_wave <= 0)
-                wk.rays_per_wave = k > 0 && ctx->sync_late_rays_per_wave > 0 ? ctx->sync_late_rays_per_wave :
+                // (profiles/r04_sync_stage_sweep4.jsonl: the first stage — everybody, at most `bound` steps — does best on waves of 16
+                // subpaths up to 64 000 of them and of 32 beyond: 0.80 / 0.94 ms per tick of 32 sources, 1.37 / 1.65 ms of 128,
+                // 1.19 / 1.49 ms per 262 144-ray frame; dense waves 0.89 / 1.18, 1.41 / 1.71, 1.20 / 1.64)
+                wk.rays_per_wave = k == 0 ? (ctx->sync_first_rays_per_wave > 0 ? ctx->sync_first_rays_per_wave : (2ull * kp.num_local >= 131072ull ? 32 : 16)) :
+                                   ctx->sync_late_rays_per_wave > 0 ? ctx->sync_late_rays_per_wave :
                     auto_rays_per_wave(walk_stage_slots(kp, f.stages[k].begin), std::min(kp.depth, f.stages[k].end) - f.stages[k].begin, k > 0 ? 8192ull : 0ull);
             launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, f.stages[k]);
         }

@@ -277,6 +277,7 @@ struct fs_context {
     std::vector<int> stage_bounds;   // staged depth = 0 walks: the steps at which a walk changes launch (FS_WALK_STAGES)
     bool stage_bounds_default = true; // not set by the host: grouped frames (two or more per launch) take kGroupedStageBounds
     std::vector<int> sync_stage_bounds;   // the same for depth = 0 frames that are waited for (stages back to back; FS_SYNC_WALK_STAGES)
+    int sync_first_rays_per_wave = 0;     // subpaths per wave of the first stage, 0 = by frame size (FS_SYNC_FIRST_RPW)
     int sync_late_rays_per_wave = 0;      // subpaths per wave of the later stages, 0 = by the number of survivors (FS_SYNC_LATE_RPW)
     int sync_stage_from = 16384;          // ... of at least this many subpaths (smaller frames: every walk has a wave of its own anyway)
     int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
