@@ -41,7 +41,7 @@ EXPORTS = [
     "fs_last_error", "fs_context_advice", "fs_scene_set_triangles", "fs_scene_set_materials", "fs_scene_commit", "fs_source_create",
     "fs_source_destroy", "fs_source_set_position", "fs_listener_set_position", "fs_source_set_object", "fs_listener_set_object", "fs_compute_energy_response",
     "fs_compute_energy_response_async", "fs_compute_energy_response_batch_async", "fs_energy_device_ptr", "fs_reconstruct_impulse_response",
-    "fs_reconstruct_impulse_response_async", "fs_reconstruct_impulse_response_batch_async", "fs_synchronize", "fs_get_impulse_response", "fs_get_impulse_response_sequence",
+    "fs_reconstruct_impulse_response_async", "fs_reconstruct_impulse_response_batch_async", "fs_update_sources", "fs_synchronize", "fs_get_impulse_response", "fs_get_impulse_response_sequence",
     "fs_copy_impulse_response", "fs_copy_band_impulse_response", "fs_get_energy_buffer", "fs_flush_energy_buffer",
     "fs_add_energy_at_delay", "fs_update_energy_buffer", "fs_num_bins", "fs_num_samples", "fs_trace_rays",
     "fs_set_profiling", "fs_set_profiling_interval", "fs_get_stats", "fs_reset_stats",
@@ -210,6 +210,7 @@ def load():
         "fs_reconstruct_impulse_response": (C.c_int, [vp, i32, C.POINTER(Params)]),
         "fs_reconstruct_impulse_response_async": (C.c_int, [vp, i32, C.POINTER(Params)]),
         "fs_reconstruct_impulse_response_batch_async": (C.c_int, [vp, C.POINTER(C.c_int32), i32, C.POINTER(Params)]),
+        "fs_update_sources": (C.c_int, [vp, C.POINTER(C.c_int32), i32, C.POINTER(Params)]),
         "fs_synchronize": (C.c_int, [vp]),
         "fs_get_impulse_response": (C.c_int, [vp, i32, i32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(i32)]),
         "fs_copy_impulse_response": (C.c_int, [vp, i32, i32, f32p, i32]),

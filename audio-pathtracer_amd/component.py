@@ -221,6 +221,11 @@ class Context:
         arr = (C.c_int32 * len(sources))(*[int(x) for x in sources])
         self.check(self.lib.fs_reconstruct_impulse_response_batch_async(self.h, arr, len(sources), C.byref(params) if params else None))
 
+    def update_sources(self, sources, params=None):
+        """UpdateSources (ARTS.cpp:100-126): trace + reconstruct every listed source, return when every IR is published"""
+        arr = (C.c_int32 * len(sources))(*[int(x) for x in sources])
+        self.check(self.lib.fs_update_sources(self.h, arr, len(sources), C.byref(params) if params else None))
+
     def reconstruct_impulse_response(self, src, params=None):
         self.check(self.lib.fs_reconstruct_impulse_response(self.h, src, C.byref(params) if params else None))
 
@@ -553,9 +558,7 @@ class AudioRayTracingSubsystem:
         if not srcs:
             return
         self._commit()
-        self.ctx.compute_energy_response_batch_async([s._src for s in srcs], self.params)
-        self.ctx.reconstruct_impulse_response_batch_async([s._src for s in srcs], self.params)
-        self.ctx.synchronize()
+        self.ctx.update_sources([s._src for s in srcs], self.params)
 
     def SetPipelining(self, depth):
         """fs_set_pipelining: Tick then updates the sources one after the other like the reference's loop (ARTS.cpp:60-68),

@@ -132,8 +132,10 @@ void free_state(fs_context* ctx) {
     if (ctx->d_seg_pos) (void)hipFree(ctx->d_seg_pos);
     ctx->d_seg_pos = nullptr; ctx->cap_pos = 0;
     if (ctx->st.slot_of) (void)hipFree(ctx->st.slot_of);
-    for (void* q : {(void*)ctx->d_over_np, (void*)ctx->d_over_mat, (void*)ctx->d_over_pos, (void*)ctx->d_overflow, (void*)ctx->d_cont, (void*)ctx->d_end_posd})
+    for (void* q : {(void*)ctx->d_over_np, (void*)ctx->d_over_mat, (void*)ctx->d_over_pos, (void*)ctx->d_cont, (void*)ctx->d_end_posd})
         if (q) (void)hipFree(q);
+    if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
+    ctx->h_overflow = nullptr;
     ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->d_overflow = nullptr; ctx->d_cont = nullptr; ctx->d_end_posd = nullptr;
     ctx->over_cap = ctx->over_cap_pos = 0; ctx->cap_posd = 0;
     if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
@@ -286,8 +288,12 @@ int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, 
         ctx->cap_seg = seg;
     }
     if (!ctx->d_overflow) {
-        FS_HIP(ctx, hipMalloc((void**)&ctx->d_overflow, sizeof(unsigned)));
-        FS_HIP(ctx, hipMemsetAsync(ctx->d_overflow, 0, sizeof(unsigned), ctx->stream));
+        // the overflow word lives in pinned HOST memory, written by the kernels across the bus in the (rare) event: the host reads it
+        // behind a synchronize without a copy — a hipMemcpy of four bytes per fs_synchronize cost an uncapped frame that is waited
+        // for 25 us (a copy kernel, its launch gap and a second wait: profiles/r04_tick_trace_*.json)
+        FS_HIP(ctx, hipHostMalloc((void**)&ctx->h_overflow, 64, hipHostMallocDefault));
+        *ctx->h_overflow = 0u;
+        FS_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->d_overflow, ctx->h_overflow, 0));
     }
     if (grow_over) {
         if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);

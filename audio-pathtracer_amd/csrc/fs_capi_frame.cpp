@@ -7,20 +7,23 @@ namespace fsi {
 // depth = 0 frames: did a walk's record miss both tiers?  (Called where the compute stream has just been synchronised.)
 // Then the frame's energy is incomplete: the tier is grown for the next attempt and the caller is told.
 int check_overflow(fs_context* ctx) {
-    if (!ctx->overflow_armed || !ctx->d_overflow) return FS_OK;
+    if (!ctx->overflow_armed || !ctx->h_overflow) return FS_OK;
     ctx->overflow_armed = false;
-    unsigned flag = 0;
+    unsigned flag = *reinterpret_cast<volatile unsigned*>(ctx->h_overflow);   // (pinned host word, the stream has been synchronised)
     if (ctx->comm) {
         // sharded frame: the ranks must agree — a rank that traced the frame again alone would issue one all-reduce more
-        // than the others.  Every rank armed the word for the same frames, so every rank gets here: MAX over the ranks.
+        // than the others.  Every rank armed the word for the same frames, so every rank gets here: MAX over the ranks
+        // (through the context's device staging: the communicator sums device memory).
         RcclApi* a = rccl();
         if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
-        FS_NCCL(ctx, a->AllReduce(ctx->d_overflow, ctx->d_overflow, 1, ncclUint32, ncclMax, ctx->comm, ctx->stream));
+        unsigned* d = reinterpret_cast<unsigned*>(ctx->d_comm_stage);
+        FS_HIP(ctx, hipMemcpyAsync(d, &flag, sizeof(flag), hipMemcpyHostToDevice, ctx->stream));
+        FS_NCCL(ctx, a->AllReduce(d, d, 1, ncclUint32, ncclMax, ctx->comm, ctx->stream));
+        FS_HIP(ctx, hipMemcpyAsync(&flag, d, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    FS_HIP(ctx, hipMemcpy(&flag, ctx->d_overflow, sizeof(flag), hipMemcpyDeviceToHost));
     if (!flag) return FS_OK;
-    FS_HIP(ctx, hipMemset(ctx->d_overflow, 0, sizeof(flag)));
+    *reinterpret_cast<volatile unsigned*>(ctx->h_overflow) = 0u;
     // two things can overflow: the second record tier (more walks beyond FS_MAX_DEPTH steps than it has slots) and the
     // lanes of a later stage of a staged walk (more survivors than provisioned) — the retry gets more of both
     ctx->stage_margin = std::min(ctx->stage_margin * 2.0f, 64.0f);
@@ -362,7 +365,9 @@ int ir_ring_backpressure_for(fs_context* ctx, Source* s) { return ir_ring_backpr
 // channel views straight into the sources' pinned host ring slots, ONE event — instead of a wait, a kernel, a copy and
 // three event records per source (67 us per source of host and queue time: 128 sources took 8.6 ms, 32 took 2.8).
 // Anything unusual about a source's frame (a literal second flush, per-kernel timing) sends the whole batch the ordinary way.
-int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p) {
+// on_compute (fs_update_sources: the caller waits for the tick anyway): the launch goes onto the COMPUTE stream, right behind
+// the frame's connect pass — no event pair, no second stream to wake (12 us between the two kernels of a one-source tick).
+int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p, bool on_compute) {
     { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // IRs are published in frame order
     bool plain = ctx->profiling < 2 && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT);   // (also for ONE source: no copy command, one event)
     for (int i = 0; i < count; ++i)
@@ -374,14 +379,27 @@ int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     const int B = ctx->cfg.num_bands;
     const int spb = p->samples_per_bin > 0 ? p->samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
-    hipStream_t tail = ctx->copy_stream;
+    hipStream_t tail = on_compute ? ctx->stream : ctx->copy_stream;
+    if (on_compute) {
+        // the batch events stand for "this and every older batch": a batch on the compute stream must not finish before an older
+        // one on the tail stream — nor write d_ir_* under a publish the tail stream still copies from
+        const uint64_t newest = ctx->tail_batch_newest.load(std::memory_order_relaxed);
+        if (newest && !tail_batch_done(ctx, newest)) FS_HIP(ctx, hipStreamWaitEvent(tail, tail_batch_event(ctx, newest), 0));
+        for (int i = 0; i < count; ++i) {
+            Source* s = srcs[i];
+            if (!s->cur_pub_seq) continue;
+            const int slot = (int)(s->cur_pub_seq % kIrRing);
+            if (s->seq_of[slot] != s->cur_pub_seq || s->pub_batch[slot]) continue;   // (a batched publish: covered above)
+            FS_HIP(ctx, compute_waits_for(ctx, s->ev[slot]));
+        }
+    }
     for (int first = 0; first < count; first += fs_context::kReconTabItems) {
         const int n = std::min(count - first, (int)fs_context::kReconTabItems);
         Source* const* g = srcs + first;
         for (int i = 0; i < n; ++i) { const int br = ir_ring_backpressure(ctx, g[i], 1); if (br) return br; }   // (before the mutexes: may wait for the GPU)
         // the tail stream takes over behind everything the compute stream has enqueued for these frames: one event pair
-        bool ordered = true;
-        for (int i = 0; i < n; ++i) ordered = ordered && g[i]->tail_ordered;
+        bool ordered = true;   // (on_compute: the compute stream is behind its own kernels)
+        for (int i = 0; i < n && !on_compute; ++i) ordered = ordered && g[i]->tail_ordered;
         if (!ordered) {
             FS_HIP(ctx, handoff_energy(ctx, g[0]));
             for (int i = 0; i < n; ++i) g[i]->tail_ordered = true;
@@ -1247,7 +1265,34 @@ int fs_reconstruct_impulse_response_batch_async(fs_context* ctx, const fs_source
         return FS_OK;
     }
     FS_FLUSH(ctx);
-    return reconstruct_batch(ctx, srcs.data(), count, p);
+    return reconstruct_batch(ctx, srcs.data(), count, p, false);
+}
+
+// UpdateSources (ARTS.cpp:100-126) as the game thread runs it: every listed source gets its UpdateSource and the call returns
+// when every IR is in its published host buffer.
+int fs_update_sources(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* p) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (count < 0 || (count > 0 && !sources)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad source list");
+    if (count == 0) return FS_OK;
+    fs_params def;
+    if (!p) { fs_params_default(&def); p = &def; }
+    std::vector<Source*> srcs((size_t)count);
+    int rc = FS_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        rc = fs_compute_energy_response_batch_async(ctx, sources, count, p);
+        if (rc) return rc;
+        FS_FLUSH(ctx);                                 // the caller waits: nothing is held back
+        for (int32_t i = 0; i < count; ++i) srcs[(size_t)i] = get_source(ctx, sources[i]);
+        // single GPU: the reconstructs ride on the compute stream; a sharded frame's sum lives on the tail stream, so do they then
+        rc = reconstruct_batch(ctx, srcs.data(), count, p, /*on_compute=*/ctx->comm == nullptr && ctx->cfg.world_size == 1);
+        if (rc) return rc;
+        // ONE wait for the tick.  depth = 0: a frame whose records overflowed is found here, after its reconstruct — it is
+        // traced and reconstructed again (the IR published in between came from an incomplete frame and is replaced)
+        rc = fs_synchronize(ctx);
+        if (rc != FS_ERR_OVERFLOW) break;
+    }
+    return rc;
 }
 
 int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32_t n) {

@@ -303,7 +303,8 @@ struct fs_context {
     uint32_t over_cap = 0, over_cap_pos = 0;
     bool debug_coherent = false;   // FS_DEBUG_COHERENT_WAVES (KParams.debug_coherent)
     int over_cap_forced = 0;       // FS_OVER_CAP, read at fs_context_create
-    unsigned* d_overflow = nullptr;
+    unsigned* d_overflow = nullptr;   // the device's address of ...
+    unsigned* h_overflow = nullptr;   // ... this pinned host word
     bool overflow_armed = false;   // an unbounded frame has been enqueued since the word was last read
     // batched frames (fs_compute_energy_response_batch_async): per-frame tables of pointers and source positions
     static constexpr int kBatchSlots = 2 * kMaxSets;   // frames the host may run ahead of the table copies (a held frame keeps its tables); >= the
@@ -404,7 +405,7 @@ void join_refine_threads(fs_context* ctx);
 int flush_pending(fs_context* ctx);          // pipelined frames: let every held frame finish on its own kernels
 int check_overflow(fs_context* ctx);         // depth = 0: did a record miss both tiers?  (stream just synchronised)
 int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
-int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p);   // many sources: one launch, one event
+int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p, bool on_compute);   // many sources: one launch, one event
 int ir_ring_backpressure_for(fs_context* ctx, Source* s);   // the IR ring's throttle before one more publish (may block; not under ir_mu)
 
 // ---- fs_capi_comm.cpp ---------------------------------------------------------------------------------------------

@@ -1019,6 +1019,69 @@ __device__ __forceinline__ void plan_body(const uint32_t bid, const uint32_t nbl
 
 
 
+// The same pass for SMALL frames (at most kPlanCoopMax subpaths): the roulette of one subpath is a serial chain of Philox
+// evaluations — up to ~85 for the longest of 2 000 uncapped walks, 42 us with a subpath per thread, a tenth of the reference's
+// tick — but its bounces are independent: a wave takes kPlanCoopItems subpaths and evaluates 64 bounces of one at a time,
+// lane j the roulette of bounce j; the first lane whose draw ends the walk gives its length (ballot + find-first).
+constexpr uint32_t kPlanCoopMax = 32768;
+constexpr int kPlanCoopItems = 8;   // subpaths per wave
+__device__ __forceinline__ void plan_coop_body(const uint32_t bid, const uint32_t nblocks, const KParams& kp,
+                                               unsigned* __restrict__ scratch, uint32_t* __restrict__ perm,
+                                               float* __restrict__ energy, const int energy_words,
+                                               float* const* __restrict__ energy_tab, const int energy_count) {
+    __shared__ unsigned s_hist[kPlanBuckets];
+    __shared__ unsigned s_base[kPlanBuckets];
+    __shared__ unsigned s_seg;
+    if (threadIdx.x == 0) s_seg = 0u;
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock) s_hist[i] = 0u;
+    if (energy_tab) {
+        for (int k = 0; k < energy_count; ++k) {
+            float* e = energy_tab[k];
+            for (int i = bid * kBlock + threadIdx.x; i < energy_words; i += nblocks * kBlock) e[i] = 0.0f;
+        }
+    } else {
+        for (int i = bid * kBlock + threadIdx.x; i < energy_words; i += nblocks * kBlock) energy[i] = 0.0f;
+    }
+    __syncthreads();
+    const uint32_t total = 2u * kp.num_local, n = kp.num_local;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t first = (bid * (kBlock / 64) + (threadIdx.x >> 6)) * (uint32_t)kPlanCoopItems;   // this wave's subpaths [first, first + 8)
+    int my_len = 0;
+    for (int it = 0; it < kPlanCoopItems; ++it) {            // (wave-uniform)
+        const uint32_t g = first + (uint32_t)it;
+        if (g >= total) break;
+        const uint32_t side = g >= n ? 1u : 0u;
+        const uint32_t li = g - side * n, sid = li / kp.pairs_per_source;
+        const uint32_t pair = kp.pair_begin + (li - sid * kp.pairs_per_source);
+        const uint32_t seed = item_seed_lo(kp, sid);
+        int len = kp.depth;
+        for (int k0 = 0; k0 < kp.depth; k0 += 64) {
+            const int k = k0 + (int)lane;
+            bool ends = k >= kp.depth;
+            if (!ends) {
+                const uint4 r = philox(pair, ((uint32_t)k << 1) | side, 0, seed, kp.seed_hi);
+                ends = !(u01(r.x) < kp.rr_prob);              // ARTS.cpp:300-301
+            }
+            const unsigned long long m = __ballot(ends);
+            if (m != 0ull) { len = k0 + __ffsll((long long)m) - 1; break; }
+        }
+        if (lane == (uint32_t)it) my_len = len;
+    }
+    const bool mine = lane < (uint32_t)kPlanCoopItems && first + lane < total;
+    const int L = min(my_len, FS_MAX_DEPTH);
+    unsigned rank = 0;
+    if (mine) {
+        rank = atomicAdd(&s_hist[L], 1u);
+        if (my_len) atomicAdd(&s_seg, (unsigned)my_len);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kPlanBuckets; i += kBlock)
+        if (s_hist[i]) s_base[i] = atomicAdd(&scratch[1 + i], s_hist[i]);
+    __syncthreads();
+    if (mine && perm) perm[(size_t)L * total + s_base[L] + rank] = first + lane;
+    if (threadIdx.x == 0 && s_seg) atomicAdd(reinterpret_cast<unsigned long long*>(scratch + kCounterWord) + 7, (unsigned long long)s_seg);   // fs_stats.planned_segments
+}
+
 // launch slot -> subpath index through the buckets, longest walks first.  s_cnt = bucket counts in LDS.
 __device__ __forceinline__ uint32_t planned_subpath(uint32_t slot, int depth, uint32_t total, const unsigned* s_cnt,
                                                     const uint32_t* __restrict__ perm) {

@@ -77,8 +77,10 @@ __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(Devic
         connect_body<B, 0, BATCH, false>(b - first, a.connect_blocks, sc, a.kpc, a.stc, a.energy, a.fixed, a.scratch_c,
                                          a.pairs_per_wave, a.energy_tab, a.fixed_tab);
     } else if (b < first + cb + a.plan_blocks) {
-        plan_body(b - first - cb, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p,
-                  a.zero_words_p, a.zero_tab_p, a.zero_count_p);
+        if (2u * a.kpp.num_local <= kPlanCoopMax)
+            plan_coop_body(b - first - cb, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p, a.zero_words_p, a.zero_tab_p, a.zero_count_p);
+        else
+            plan_body(b - first - cb, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p, a.zero_words_p, a.zero_tab_p, a.zero_count_p);
     } else {   // reconstruct part: item, row, block of chunks
         extern __shared__ __attribute__((aligned(16))) int s_dyn_r[];
         const uint32_t rb = b - first - cb - a.plan_blocks, per_item = (uint32_t)(a.recon_B + 1) * a.recon_cb;

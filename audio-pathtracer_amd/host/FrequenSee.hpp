@@ -153,9 +153,7 @@ public:
         Commit();
         std::vector<fs_source> H;
         for (auto* s : ActiveSources) H.push_back(s->Handle_);
-        Check(fs_compute_energy_response_batch_async(Ctx_, H.data(), (int32_t)H.size(), &Params));
-        Check(fs_reconstruct_impulse_response_batch_async(Ctx_, H.data(), (int32_t)H.size(), &Params));   // one launch, one event
-        Check(fs_synchronize(Ctx_));
+        Check(fs_update_sources(Ctx_, H.data(), (int32_t)H.size(), &Params));   // one batched frame, one reconstruct launch, one wait
     }
     // .cpp:55-85 (the caller drives every frame).  The reference draws from the engine's global rand() stream, so every
     // frame sees fresh samples: the seed advances.

@@ -30,7 +30,7 @@
  *             fs_scene_set_triangles fs_scene_set_materials fs_scene_set_objects fs_scene_commit
  *             fs_source_create fs_source_destroy fs_source_set_position fs_source_set_object
  *             fs_listener_set_position fs_listener_set_object
- *             fs_compute_energy_response fs_reconstruct_impulse_response
+ *             fs_compute_energy_response fs_reconstruct_impulse_response fs_update_sources
  *             fs_get_impulse_response fs_copy_impulse_response fs_get_impulse_response_sequence
  *             fs_get_energy_buffer fs_flush_energy_buffer fs_add_energy_at_delay fs_update_energy_buffer
  *             fs_num_bins fs_num_samples fs_get_occlusion_attenuation fs_update_sound fs_sound_params_default
@@ -401,6 +401,11 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source src, const 
  * stream wait, a kernel, a copy and three event records (32 sources: 2.8 ms per tick against 0.9 ms). */
 int fs_reconstruct_impulse_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 int fs_synchronize(fs_context* ctx);
+/* UpdateSources (ARTS.cpp:100-126) as the game thread runs it: one UpdateSource (:128-195) for every listed source — trace,
+ * deposit, reconstruct — and every IR is in its published host buffer when the call returns.  = the batched compute call +
+ * the batched reconstruct + fs_synchronize, with the reconstructs riding on the compute stream (nothing else to overlap
+ * with when the caller waits); a depth = 0 frame whose records overflowed is traced again like fs_compute_energy_response. */
+int fs_update_sources(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 
 /* GetImpulseResponse() (FSAC.h:113): pointer to the PUBLISHED [num_samples] channel buffer, valid
  * until the second-next publish; lock-free for the audio thread (RVB.cpp:136). */

@@ -173,6 +173,51 @@ def test_batched_reconstructs_with_reverb_and_pipelined_frames(pkg, scene_factor
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("depth", [0, 6])
+def test_update_sources_equals_the_three_calls(pkg, scene_factory, depth):
+    """fs_update_sources (UpdateSources, ARTS.cpp:100-126) = the batched frame + the batched reconstruct + the wait, with the
+    reconstruct on the compute stream: the published IRs, per-band IRs, reverb blocks and publish counters over 20 ticks are
+    those of the three calls — also when asynchronous ticks (their reconstructs on the tail stream, not waited for) and a
+    tick of held-back pipelined frames sit between two fs_update_sources ticks"""
+    sc = scene_factory("starter_room", 4)
+    rng = np.random.default_rng(6)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    pos = [(np.asarray(sc.source, np.float32) + rng.uniform(-0.05, 0.05, 3).astype(np.float32) * (hi - lo)).astype(np.float32) for _ in range(5)]
+    block = np.clip(rng.normal(0, 0.2, 2048), -1, 1).astype(np.float32)
+    out = {}
+    for mode in ("three", "one"):
+        ctx, _ = make_ctx(pkg, sc)
+        srcs = [ctx.create_source(p) for p in pos]
+        ctx.reverb_init(srcs[0], 1024)
+        got = []
+        for tick in range(20):
+            p = pkg.default_params(num_rays=3000, depth=depth, seed=300 + tick, flags=DET | pkg._capi.FLAG_FIXED_NORM_1000)
+            live = srcs if tick % 4 else srcs[:2]
+            if tick == 13:
+                ctx.set_pipelining(2)                                  # the frames of this tick are held back when the tick begins
+            if mode == "one" and tick % 3 != 1:
+                ctx.update_sources(live, p)
+            else:
+                ctx.compute_energy_response_batch_async(live, p)
+                ctx.reconstruct_impulse_response_batch_async(live, p)
+                if mode == "three" or tick % 6 == 1:                   # (mode "one": some ticks are left in flight)
+                    ctx.synchronize()
+            if tick == 13:
+                ctx.set_pipelining(1)
+            if tick % 5 == 2:
+                got.append(np.asarray(ctx.reverb_process(srcs[0], block)).copy())
+        ctx.synchronize()
+        for s in srcs:
+            got.append(ctx.impulse_response(s, 0).copy())
+            got.append(ctx.band_impulse_response(s, 2).copy())
+            got.append(np.asarray([ctx.impulse_response_sequence(s)], np.int64))
+        out[mode] = got
+        ctx.close()
+    assert np.abs(out["three"][0]).max() > 0
+    for a, b in zip(out["three"], out["one"]):
+        assert np.array_equal(a, b)
+
+
 # ---- staged walks of frames that are waited for -------------------------------------------------------------------
 @pytest.mark.parametrize("bounds", ["16", "5,9,70", "64", "100"])
 def test_staged_walks_of_waited_frames_equal_the_walk_in_one_piece(pkg, oracle_mod, scene_factory, monkeypatch, bounds):

@@ -31,16 +31,12 @@ for name in (sys.argv[1:] or ["starter_room", "old_mine"]):
         for i in range(40):
             p.seed = 1000 + i
             t1 = time.perf_counter()
-            if S == 1:
-                ctx.compute_energy_response_async(srcs[0], p)
-            else:
+            if os.environ.get("FS_TICK_SEPARATE_CALLS") == "1":
                 ctx.compute_energy_response_batch_async(srcs[:S], p)
-            if os.environ.get("FS_TICK_SINGLE_RECON") == "1":
-                for s in srcs[:S]:
-                    ctx.reconstruct_impulse_response_async(s, p)
-            else:
                 ctx.reconstruct_impulse_response_batch_async(srcs[:S], p)
-            ctx.synchronize()
+                ctx.synchronize()
+            else:
+                ctx.update_sources(srcs[:S], p)
             times.append(time.perf_counter() - t1)
         times = sorted(times[8:])
         out[str(S)] = {"ms_per_tick_median": round(1e3 * times[len(times) // 2], 4), "ms_per_tick_min": round(1e3 * times[0], 4),

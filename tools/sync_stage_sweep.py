@@ -35,9 +35,7 @@ for name, bands in (("starter_room", 1), ("old_mine", 1)):
             for i in range(24):
                 p.seed = 1000 + i
                 t1 = time.perf_counter()
-                ctx.compute_energy_response_batch_async(srcs[:S], p)
-                ctx.reconstruct_impulse_response_batch_async(srcs[:S], p)
-                ctx.synchronize()
+                ctx.update_sources(srcs[:S], p)
                 times.append(time.perf_counter() - t1)
             times = sorted(times[6:])
             out[f"tick_{S}_ms"] = round(1e3 * times[len(times) // 2], 4)

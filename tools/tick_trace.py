@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""One-source reference ticks for a kernel trace: rocprofv3 --kernel-trace -- python3 tools/tick_trace.py [scene]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as graft  # noqa: E402
+pkg = graft.load_package()
+name = sys.argv[1] if len(sys.argv) > 1 else "starter_room"
+sc = pkg.scenes.by_name(name, 1)
+ctx = pkg.Context(num_bands=1)
+ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
+ctx.set_listener(sc.listener)
+s = ctx.create_source(sc.source)
+p = pkg.default_params(num_rays=2000, depth=0, seed=1, flags=pkg._capi.FLAG_FIXED_NORM_1000)
+tt = []
+for i in range(60):
+    p.seed = 100 + i
+    t1 = time.perf_counter()
+    ctx.update_sources([s], p)
+    tt.append(time.perf_counter() - t1)
+tt = sorted(tt[10:])
+print("median tick ms", 1e3 * tt[len(tt) // 2], file=sys.stderr)
+ctx.close()
