@@ -573,7 +573,7 @@ void frame_describe(fs_context* ctx, Frame& f) {
         for (int bound : bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
-    } else if (!f.pipe_ok && f.unbounded && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on && ctx->profiling < 3 &&
+    } else if (!f.pipe_ok && (f.unbounded || (ctx->debug_rebin && p->russian_roulette && p->depth > 1)) && plain &&   // (FS_DEBUG_REBIN: the experiment also stages capped walks) !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on && (ctx->profiling < 3 || ctx->debug_rebin) &&
                !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from) {
         // A depth = 0 frame that is waited for (not held): the same stages, one launch after the other on the stream.  The
         // frame's time is its longest walk — a chain of ~ log(subpaths) / log(1 / rr) dependent bounces — and what a bounce
@@ -792,7 +792,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
     WalkLaunch wplan = ctx->walk;
     wplan.queue_head = scratch;
     wplan.perm = perm_buf;
-    if (f.unbounded) wplan.plan = 1;   // the second record tier relies on the schedule: the longest walks own the lowest slots
+    if (f.unbounded || f.stages.size() > 1) wplan.plan = 1;   // the second record tier relies on the schedule: the longest walks own the lowest slots
     bool sort = false;
     const bool plan_runs = plan_shape(kp, wplan, nullptr, &sort);   // the plan pass (and the flush with it) runs for this frame
     const uint32_t* perm = plan_runs && sort ? perm_buf : nullptr;
@@ -890,7 +890,26 @@ int frame_launch(fs_context* ctx, Frame& f) {
                 wk.rays_per_wave = k == 0 ? (ctx->sync_first_rays_per_wave > 0 ? ctx->sync_first_rays_per_wave : (2ull * kp.num_local >= 131072ull ? 32 : 16)) :
                                    ctx->sync_late_rays_per_wave > 0 ? ctx->sync_late_rays_per_wave :
                     auto_rays_per_wave(walk_stage_slots(kp, f.stages[k].begin), std::min(kp.depth, f.stages[k].end) - f.stages[k].begin, k > 0 ? 8192ull : 0ull);
-            launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, f.stages[k]);
+            WalkStage sr = f.stages[k];
+            const uint32_t* rebin = nullptr;
+            if ((ctx->debug_rebin == 1 || ctx->debug_rebin == 2) && k > 0 && wk.rays_per_wave >= 64) {   // (experiment: DESIGN.md section 5)
+                const size_t lanes = 2 * (size_t)kp.num_local;
+                if (lanes > ctx->rebin_cap) {
+                    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    if (ctx->d_rebin) (void)hipFree(ctx->d_rebin);
+                    if (ctx->d_rebin_hist) (void)hipFree(ctx->d_rebin_hist);
+                    ctx->d_rebin = nullptr; ctx->d_rebin_hist = nullptr; ctx->rebin_cap = 0;
+                    FS_HIP(ctx, hipMalloc((void**)&ctx->d_rebin, sizeof(uint32_t) * lanes));
+                    FS_HIP(ctx, hipMalloc((void**)&ctx->d_rebin_hist, sizeof(unsigned) * 2 * (kRebinKeys + 1)));
+                    FS_HIP(ctx, hipMemsetAsync(ctx->d_rebin_hist, 0, sizeof(unsigned) * 2 * (kRebinKeys + 1), ctx->stream));
+                    ctx->rebin_cap = lanes;
+                }
+                sr.slots_cap = walk_stage_slots(kp, sr.begin);
+                launch_rebin(ctx->scene, st, wl.queue_head, sr.begin, sr.slots_cap, ctx->d_rebin, ctx->d_rebin_hist,
+                             ctx->d_rebin_hist + (kRebinKeys + 1), ctx->stream);
+                if (ctx->debug_rebin == 1) rebin = ctx->d_rebin;
+            }
+            launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, sr, rebin);
         }
     } else {
         launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);

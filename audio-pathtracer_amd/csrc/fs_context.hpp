@@ -302,6 +302,8 @@ struct fs_context {
     float4* d_cont = nullptr;        // continuation records of staged walks: [state_sets][2][cap_lanes]
     uint32_t over_cap = 0, over_cap_pos = 0;
     bool debug_coherent = false;   // FS_DEBUG_COHERENT_WAVES (KParams.debug_coherent)
+    int debug_rebin = 0;           // FS_DEBUG_REBIN (experiment, tools/rebin_experiment.py): 1 = the later stages of a waited-for staged walk on dense waves walk their slots in the order of the walks' positions; 2 = the order is computed but not used (its cost alone); 3 = neither (staged walks under the counting instantiation)
+    uint32_t* d_rebin = nullptr; unsigned* d_rebin_hist = nullptr; size_t rebin_cap = 0;
     int over_cap_forced = 0;       // FS_OVER_CAP, read at fs_context_create
     unsigned* d_overflow = nullptr;   // the device's address of ...
     unsigned* h_overflow = nullptr;   // ... this pinned host word

@@ -1309,18 +1309,20 @@ __device__ __forceinline__ void count_walk_segments(unsigned* s_seg, const unsig
 template <int LOBES, bool COUNT, bool EXT = false>
 __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
-                                                 const uint32_t* __restrict__ perm, const WalkStage sr = WalkStage()) {
+                                                 const uint32_t* __restrict__ perm, const WalkStage sr = WalkStage(),
+                                                 const uint32_t* __restrict__ rebin = nullptr) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
     __shared__ unsigned s_seg[kBlock / 64];
     if ((threadIdx.x & 63u) == 0u) s_seg[threadIdx.x >> 6] = 0u;
     if (perm) {
-        for (int i = threadIdx.x; i <= min(kp.depth, FS_MAX_DEPTH); i += kBlock) s_cnt[i] = scratch[1 + i];
+        for (int i = threadIdx.x; i <= FS_MAX_DEPTH; i += kBlock) s_cnt[i] = i <= min(kp.depth, FS_MAX_DEPTH) ? scratch[1 + i] : 0u;
     }
     if (perm) __syncthreads();
-    const uint32_t slot = bid * kBlock + threadIdx.x;
-    if (slot >= stage_slots(sr, st, 2u * kp.num_local, s_cnt)) return;
+    const uint32_t li = bid * kBlock + threadIdx.x;
+    if (li >= stage_slots(sr, st, 2u * kp.num_local, s_cnt)) return;
+    const uint32_t slot = rebin ? rebin[li] : li;   // (FS_DEBUG_REBIN: the stage's slots in the order of the walks' positions)
     // (FS_DEBUG_COHERENT_WAVES: every lane of the wave walks the subpath of the wave's first slot — timing experiments only)
     const uint32_t gslot = kp.debug_coherent ? (slot & ~63u) : slot;
     const uint32_t g = perm ? planned_subpath(gslot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : gslot;

@@ -303,10 +303,17 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
 // does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule
 bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s, const WalkStage& stage = WalkStage());
+                 const uint32_t* perm, hipStream_t s, const WalkStage& stage = WalkStage(), const uint32_t* rebin = nullptr);
+// (rebin — FS_DEBUG_REBIN, the re-binning experiment of DESIGN.md section 5, dense waves only: lane i of the stage walks slot
+// rebin[i], the stage's slots ordered by (cell of the walk's position, octant of its surface normal); null: lane i = slot i)
 // lanes a walk stage needs: all subpaths for a stage that starts at step 0, else the expected number of walks longer than
 // stage.begin under the roulette (x1.3 + 1024: the count is binomial, the margin is hundreds of standard deviations)
 uint32_t walk_stage_slots(const KParams& kp, int begin);
+// FS_DEBUG_REBIN: the slots of the stage that begins at step `begin`, ordered by where their walks are (counting sort over
+// kRebinKeys keys: histogram, scan, scatter) -> rebin[0 .. n); hist / offs: kRebinKeys + 1 words each, hist zero on entry (and on exit)
+constexpr int kRebinKeys = 1 << 15;
+void launch_rebin(const DeviceScene& sc, const SubpathState& st, const unsigned* scratch, int begin, uint32_t slots_cap,
+                  uint32_t* rebin, unsigned* hist, unsigned* offs, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
 // energy_tab / fixed_tab: per-source buffers of a batched frame (device arrays of kp.num_local / kp.pairs_per_source
 // pointers), null for one source (`energy` / `fixed` are used)

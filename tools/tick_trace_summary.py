@@ -27,7 +27,10 @@ spans = []
 for t in ticks:
     spans.append((t[-1][1] - t[0][0]) / 1e3)
     prev_end = None
+    seen = {}
     for st, en, name in t:
+        seen[name] = seen.get(name, 0) + 1
+        if seen[name] > 1: name = "%s #%d" % (name, seen[name])   # (the stages of a staged walk)
         a = agg.setdefault(name, {"us": [], "gap_before_us": []})
         a["us"].append((en - st) / 1e3)
         if prev_end is not None:
