@@ -560,6 +560,7 @@ void frame_describe(fs_context* ctx, Frame& f) {
                                      FS_FLAG_DOUBLE_POSITIONS));
     f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on &&
                 (p->depth > 0 || (f.unbounded && ctx->pipelining >= 2));
+    kp.plan_coop = (2ull * kp.num_local <= kPlanCoopMax || (f.unbounded && !f.pipe_ok && 2ull * kp.num_local <= kPlanCoopMaxUncapped)) ? 1 : 0;
     f.stages.clear();
     if (f.pipe_ok && f.unbounded && !ctx->stage_bounds.empty()) {
         int begin = 0;

@@ -1019,11 +1019,12 @@ __device__ __forceinline__ void plan_body(const uint32_t bid, const uint32_t nbl
 
 
 
-// The same pass for SMALL frames (at most kPlanCoopMax subpaths): the roulette of one subpath is a serial chain of Philox
+// The same pass for SMALL frames (at most kPlanCoopMax subpaths) and for uncapped walks somebody waits for (at most
+// kPlanCoopMaxUncapped: KParams.plan_coop, set by frame_describe): the roulette of one subpath is a serial chain of Philox
 // evaluations — up to ~85 for the longest of 2 000 uncapped walks, 42 us with a subpath per thread, a tenth of the reference's
 // tick — but its bounces are independent: a wave takes kPlanCoopItems subpaths and evaluates 64 bounces of one at a time,
-// lane j the roulette of bounce j; the first lane whose draw ends the walk gives its length (ballot + find-first).
-constexpr uint32_t kPlanCoopMax = 32768;
+// lane j the roulette of bounce j; the first lane whose draw ends the walk gives its length (ballot + find-first).  (64 draws
+// per subpath where the chain makes 10 on average: for capped walks of a chip-filling frame the chain is the cheaper one.)
 constexpr int kPlanCoopItems = 8;   // subpaths per wave
 __device__ __forceinline__ void plan_coop_body(const uint32_t bid, const uint32_t nblocks, const KParams& kp,
                                                unsigned* __restrict__ scratch, uint32_t* __restrict__ perm,
@@ -1980,54 +1981,71 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #pragma unroll
         for (int b = 0; b < Bands<B>::kMax; ++b) E[b] = 1.0f;
         float sd = 0.0f;
-        if (ppw == 1u) {
-            // ONE pair per wave (the reference's own frames): the wave's 64 lanes evaluate the connected path together — lane i
-            // the factors of segment i (64 segments per round), then every lane runs the same product over them in path
-            // order, the factors read across with v_readlane.  Lane 0 owns the pair and deposits.
+        if (ppw == 1u || (ppw <= 8u && st.over_levels != 0)) {
+            // Few pairs per wave (the reference's own frames: one; ticks of several sources with uncapped walks: up to eight, of
+            // which a fifth connect — and a connected path of uncapped walks has up to a few hundred segments, 40 us of ONE
+            // lane's time at 160): the wave's 64 lanes evaluate a connected path together — lane i the factors of segment i
+            // (64 segments per round), then every lane runs the same product over them in path order, the factors read across
+            // with v_readlane — one connected pair of the wave after the other; the pair's own lane keeps the result and deposits.
             bool go = active && !hit && !sphere_blocked;
             if (go && st.over_levels && !(rec_fits(st, (int)Fm.y - 1, sf) && rec_fits(st, (int)Lm.y - 1, sl))) go = false;
-            if (!__builtin_amdgcn_readfirstlane((int)go)) return;      // (lane 0 is the first lane: whole waves step through the pairs)
-            const int kf = __builtin_amdgcn_readfirstlane((int)Fm.y), kl = __builtin_amdgcn_readfirstlane((int)Lm.y);
-            const uint32_t usf = (uint32_t)__builtin_amdgcn_readfirstlane((int)sf), usl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
-            const float c_nd = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((EXT && kp.dpos) ? conn_nd : sqrtf(l2) / kp.dist_divisor)));
-            const uint32_t c_mat = (uint32_t)__builtin_amdgcn_readfirstlane((int)Fm.x);
-            const float c_prob = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(F.w)));
-            const int segs = kf + 1 + kl;
-            for (int base = 0; base < segs; base += 64) {
-                const int i = base + (int)lane;
-                float nd = 0.0f, prob = 1.0f;
-                uint32_t mat = kNoMat;
-                if (i < kf) {                                            // source-side segment F_i -> F_i+1
-                    const float2 np = load_np(st, total, i, usf);
-                    nd = np.x; prob = np.y; mat = load_mat(st, total, i, usf);
-                } else if (i == kf) {                                    // connection segment: F_k's material / prob
-                    nd = c_nd; prob = c_prob; mat = c_mat;
-                } else if (i < segs) {                                   // listener-side segment B_j+1 -> B_j, j = kl - 1 .. 0
-                    const int j = kl - 1 - (i - kf - 1);
-                    const float2 np = load_np(st, total, j, usl);
-                    nd = np.x; prob = np.y; mat = load_mat(st, total, j, usl);
-                }
-                SegFactors<B> f;
-                segment_factors<B, LOBES>(f, nd, mat, prob, kp, sc);
-                const int cnt = min(64, segs - base);
-                for (int q = 0; q < cnt; ++q) {                          // (wave-uniform: the product in path order, in every lane alike)
-                    sd += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), q));                  // ARTS.cpp:374
-                    if (!__builtin_amdgcn_readlane((int)f.live, q)) continue;
-                    const float geo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.geo), q));
-                    const float pw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.pw), q));
+            unsigned long long todo = __ballot(go);
+            if (todo == 0ull) return;
+            const float my_nd = (EXT && kp.dpos) ? conn_nd : sqrtf(l2) / kp.dist_divisor;
+            while (todo != 0ull) {                                       // (wave-uniform)
+                const int o = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const int kf = __builtin_amdgcn_readlane((int)Fm.y, o), kl = __builtin_amdgcn_readlane((int)Lm.y, o);
+                const uint32_t usf = (uint32_t)__builtin_amdgcn_readlane((int)sf, o), usl = (uint32_t)__builtin_amdgcn_readlane((int)sl, o);
+                const float c_nd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_nd), o));
+                const uint32_t c_mat = (uint32_t)__builtin_amdgcn_readlane((int)Fm.x, o);
+                const float c_prob = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(F.w), o));
+                const int segs = kf + 1 + kl;
+                float Et[Bands<B>::kMax];
 #pragma unroll
-                    for (int b = 0; b < Bands<B>::kMax; ++b) {
-                        if (B == 0 && b >= NB) break;
-                        float e = E[b];
-                        e *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.bsdf[b]), q));
-                        e *= geo;
-                        e *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.ex[b]), q));
-                        e /= pw;
-                        E[b] = e;
+                for (int b = 0; b < Bands<B>::kMax; ++b) Et[b] = 1.0f;
+                float sdt = 0.0f;
+                for (int base = 0; base < segs; base += 64) {
+                    const int i = base + (int)lane;
+                    float nd = 0.0f, prob = 1.0f;
+                    uint32_t mat = kNoMat;
+                    if (i < kf) {                                            // source-side segment F_i -> F_i+1
+                        const float2 np = load_np(st, total, i, usf);
+                        nd = np.x; prob = np.y; mat = load_mat(st, total, i, usf);
+                    } else if (i == kf) {                                    // connection segment: F_k's material / prob
+                        nd = c_nd; prob = c_prob; mat = c_mat;
+                    } else if (i < segs) {                                   // listener-side segment B_j+1 -> B_j, j = kl - 1 .. 0
+                        const int j = kl - 1 - (i - kf - 1);
+                        const float2 np = load_np(st, total, j, usl);
+                        nd = np.x; prob = np.y; mat = load_mat(st, total, j, usl);
+                    }
+                    SegFactors<B> f;
+                    segment_factors<B, LOBES>(f, nd, mat, prob, kp, sc);
+                    const int cnt = min(64, segs - base);
+                    for (int q = 0; q < cnt; ++q) {                          // (wave-uniform: the product in path order, in every lane alike)
+                        sdt += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nd), q));                 // ARTS.cpp:374
+                        if (!__builtin_amdgcn_readlane((int)f.live, q)) continue;
+                        const float geo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.geo), q));
+                        const float pw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.pw), q));
+#pragma unroll
+                        for (int b = 0; b < Bands<B>::kMax; ++b) {
+                            if (B == 0 && b >= NB) break;
+                            float e = Et[b];
+                            e *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.bsdf[b]), q));
+                            e *= geo;
+                            e *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.ex[b]), q));
+                            e /= pw;
+                            Et[b] = e;
+                        }
                     }
                 }
+                if ((int)lane == o) {
+#pragma unroll
+                    for (int b = 0; b < Bands<B>::kMax; ++b) E[b] = Et[b];
+                    sd = sdt;
+                }
             }
-            if (lane != 0u) return;
+            if (!go) return;
             ++my_deposits;
         } else {
         if (!active || hit || sphere_blocked) return;

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(Devic
         connect_body<B, 0, BATCH, false>(b - first, a.connect_blocks, sc, a.kpc, a.stc, a.energy, a.fixed, a.scratch_c,
                                          a.pairs_per_wave, a.energy_tab, a.fixed_tab);
     } else if (b < first + cb + a.plan_blocks) {
-        if (2u * a.kpp.num_local <= kPlanCoopMax)
+        if (a.kpp.plan_coop)
             plan_coop_body(b - first - cb, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p, a.zero_words_p, a.zero_tab_p, a.zero_count_p);
         else
             plan_body(b - first - cb, a.plan_blocks, a.kpp, a.scratch_p, a.perm_p, a.zero_p, a.zero_words_p, a.zero_tab_p, a.zero_count_p);

@@ -148,7 +148,9 @@ struct KParams {
     int16_t cosine;
     int16_t ignore_on;     // some walk of the frame ignores an actor: the EXT instantiations run (16 bits each: the fused launch's 4 KB of arguments are full)
     int32_t lobes;         // 1 = FS_FLAG_MATERIAL_LOBES: the walk picks a specular / diffuse / transmitted lobe per vertex
-    int32_t mis;           // all-connections mode: 1 = balance-heuristic weights, 0 = uniform
+    int16_t mis;           // all-connections mode: 1 = balance-heuristic weights, 0 = uniform
+    int16_t plan_coop;     // the plan pass evaluates 64 bounces of a subpath at once, a wave per 8 subpaths (plan_coop_body): frames of <= 32 768 subpaths, and uncapped walks
+                           //   that are waited for (the host decides: frame_describe)
     float rr_prob, max_trace_dist, surface_offset, connect_pullback;
     float stage_margin;    // staged walks: lanes a later stage is given = stage_margin x the expected survivors + 1024 (1.3; doubled
                            //   by the overflow retry if a frame ever had more)
@@ -164,6 +166,8 @@ struct KParams {
     int32_t hist_window;   // the connect kernels privatise bins [0, hist_window) of every band in LDS; deposits beyond go
                            // straight to the energy buffer with global atomics (kHistWindow, or all bins if fewer)
 };
+
+constexpr uint32_t kPlanCoopMax = 32768, kPlanCoopMaxUncapped = 1u << 17;   // KParams.plan_coop (fs_device.hpp: plan_coop_body)
 
 // legacy forward tracer (UpdateSound) constants and device-side accumulators
 struct SoundKParams {

@@ -13,7 +13,7 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(KParams kp, unsigned* __re
                                                       uint32_t* __restrict__ perm, float* __restrict__ energy,
                                                       int energy_words, float* const* __restrict__ energy_tab,
                                                       int energy_count) {
-    if (2u * kp.num_local <= kPlanCoopMax) plan_coop_body(blockIdx.x, gridDim.x, kp, scratch, perm, energy, energy_words, energy_tab, energy_count);
+    if (kp.plan_coop) plan_coop_body(blockIdx.x, gridDim.x, kp, scratch, perm, energy, energy_words, energy_tab, energy_count);
     else plan_body(blockIdx.x, gridDim.x, kp, scratch, perm, energy, energy_words, energy_tab, energy_count);
 }
 
@@ -178,7 +178,7 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
 bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort) {
     const uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0 || !kp.russian_roulette) return false;
-    if (blocks) *blocks = lanes <= kPlanCoopMax ? (lanes + (kBlock / 64) * kPlanCoopItems - 1) / ((kBlock / 64) * kPlanCoopItems)   // small frames: a wave per 8 subpaths
+    if (blocks) *blocks = kp.plan_coop ? (lanes + (kBlock / 64) * kPlanCoopItems - 1) / ((kBlock / 64) * kPlanCoopItems)   // small frames: a wave per 8 subpaths
                                                 : (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
     if (sort) *sort = wl.plan && kp.depth > 1 && wl.perm;
     return true;
