@@ -170,6 +170,9 @@ static int refresh_coop_nodes(fs_context* ctx, bool topology_changed) {
     // one-node-at-a-time descents: 15 new entries per 16-wide level at most; the 4-wide tree's bound is the builder's (+ the popped node's four)
     ctx->coop_info.wide16 = CoopView{ctx->d_coop16, 0, ctx->coop16_nodes, 4, (int16_t)(15 * ((ctx->coop_levels + 1) / 2) + 1)};
     ctx->coop_info.wide4 = CoopView{ctx->d_coop, 0, (int32_t)n, 2, (int16_t)(std::max(ctx->bvh.stack_need, 2) + 4)};
+    static const bool dbg_info = std::getenv("FS_DEBUG_SCENE_INFO") != nullptr;   // (what DESIGN.md quotes)
+    if (dbg_info)
+        std::fprintf(stderr, "[frequensee] tree: %zu 4-wide nodes in %d levels -> %d 16-wide nodes\n", n, levels, ctx->coop16_nodes);
     return FS_OK;
 }
 

@@ -220,6 +220,9 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
         const uint32_t blocks = (waves + (uint32_t)W - 1) / (uint32_t)W;
         cv.lds_nodes = coop_resident_nodes(cv, W, blocks, wl.num_cus);
         const size_t lds = coop_lds_bytes(W, cv), lds_ext = lds;
+        static const bool dbg = std::getenv("FS_DEBUG_SCENE_INFO") != nullptr;   // (read once)
+        if (dbg) std::fprintf(stderr, "[frequensee] cooperative walk: %u lanes, %d per wave, %u workgroups of %d waves, %d-wide nodes, %d of %d resident in LDS (%zu bytes)\n",
+                              lanes, wl.rays_per_wave, blocks, W, 1 << cv.wshift, cv.lds_nodes, cv.nodes, lds);
         if (W == kCoopBigWaves) {
             allow_lds(walk_kernel_coop_big, lds);
             hipLaunchKernelGGL(walk_kernel_coop_big, dim3(blocks), dim3(64 * W), lds, s, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
