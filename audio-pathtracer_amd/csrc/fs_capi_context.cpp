@@ -650,7 +650,7 @@ int fs_get_stats(fs_context* ctx, fs_stats* out) {
         FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < kScratchSets; ++k)
             for (int i = 0; i < kNumCounters; ++i) c[i] += cs[k][i];
-        ctx->stats.segments = c[0];                              // counted by the walkers
+        ctx->stats.segments = c[0];                              // the walkers' own step counts, summed by the connect pass
         ctx->stats.planned_segments = c[7] + ctx->host_segments;  // the plan pass's prediction (roulette off: depth x subpaths, on the host)
         ctx->stats.connections_tested = c[1];
         ctx->stats.deposits = c[2];

@@ -6,7 +6,7 @@ namespace fs {
 namespace {
 
 template <int B, int LOBES, bool BATCH, bool COUNT, bool EXT = false>
-__global__ __launch_bounds__(kBlock) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
+__global__ __launch_bounds__(kBlock, 4) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head,
                                                          int pairs_per_wave, float* const* __restrict__ energy_tab,
@@ -101,12 +101,13 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
     const uint32_t total = 2u * n;
     const int lane = (int)(threadIdx.x & 63u);
     const uint32_t wave = threadIdx.x >> 6, waves = kBlock / 64;
-    unsigned my_deposits = 0, my_tests = 0;
+    unsigned my_deposits = 0, my_tests = 0, my_segments = 0;
     for (uint32_t li = blockIdx.x * waves + wave; li < n; li += gridDim.x * waves) {
         const uint32_t sf = slot_of(st, li), sl = slot_of(st, n + li);
         const uint2 Fm = st.end_misc[sf];
         const uint2 Lm = st.end_misc[sl];
         const int kf = (int)Fm.y, kl = (int)Lm.y;
+        if (lane == 0) my_segments += (unsigned)(kf + kl);   // fs_stats.segments: the steps the two walks took
         // depth = 0 only: a walk that outlived the record store (overflow word raised, the frame is traced again)
         if (st.over_levels && !(rec_fits(st, kf - 1, sf) && rec_fits(st, kl - 1, sl))) continue;
         const int combos = (kf + 1) * (kl + 1);
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(kBlock) void connect_all_kernel(DeviceScene sc, KPa
         unsigned d = my_deposits, t = my_tests;
         for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); t += __shfl_down(t, o); }
         if (lane == 0) {
+            if (my_segments) atomicAdd(&counters[0], (unsigned long long)my_segments);
             if (d) atomicAdd(&counters[2], (unsigned long long)d);
             if (t) atomicAdd(&counters[1], (unsigned long long)t);
         }

@@ -1293,19 +1293,6 @@ __device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_co
     if (nt) atomicAdd(&counters[first_counter + 1], (unsigned long long)nt);
 }
 
-// Work counter "walk segments" (fs_stats.segments): what the walkers of this wave actually traced — every applied hit or
-// miss is one closest-hit query — summed in LDS (ds_add_u32) by the lanes that are still there and added to the frame
-// scratch by one of them: one global atomic per wave.  (The plan pass predicts the same number from the RNG stream alone:
-// fs_stats.planned_segments; the tests assert that the two agree.)  s_seg: one word per wave, zeroed by the wave's first
-// lane before anything can leave the kernel.
-__device__ __forceinline__ void count_walk_segments(unsigned* s_seg, const unsigned mine, const unsigned* scratch) {
-    if (mine) atomicAdd(s_seg, mine);
-    const unsigned long long here = __ballot(true);
-    if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)here) - 1)) {
-        const unsigned total = *reinterpret_cast<volatile unsigned*>(s_seg);
-        if (total) atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(scratch) + kCounterWord), (unsigned long long)total);
-    }
-}
 
 template <int LOBES, bool COUNT, bool EXT = false>
 __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
@@ -1315,8 +1302,6 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
-    __shared__ unsigned s_seg[kBlock / 64];
-    if ((threadIdx.x & 63u) == 0u) s_seg[threadIdx.x >> 6] = 0u;
     if (perm) {
         for (int i = threadIdx.x; i <= FS_MAX_DEPTH; i += kBlock) s_cnt[i] = i <= min(kp.depth, FS_MAX_DEPTH) ? scratch[1 + i] : 0u;
     }
@@ -1331,7 +1316,6 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     Walker w;
     walker_start(w, g, slot, kp, st, sr.begin == 0);
     if (sr.begin > 0 && !walker_resume(w, st, sr.begin)) return;
-    const int k_first = w.k;
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u, cnt_ni = 0u, cnt_nl = 0u, cnt_nd = 0u;
 #ifdef FS_WAVE_TIMELINE
@@ -1357,7 +1341,6 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; cnt_ni += T.ni; cnt_nl += T.nl; cnt_nd += T.nd; }
         walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
-    count_walk_segments(&s_seg[threadIdx.x >> 6], (unsigned)(w.k - k_first), scratch);
     if (COUNT) {
         add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(scratch) + kCounterWord);
@@ -1405,14 +1388,10 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
     bool alive = lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
     int* stack = &s_stack[threadIdx.x];
-    __shared__ unsigned s_seg[kBlock / 64];
-    if (lane == 0u) s_seg[threadIdx.x >> 6] = 0u;
     Walker w;
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
                  slot, kp, st, alive && sr.begin == 0);
     if (alive && sr.begin > 0) alive = walker_resume(w, st, sr.begin);
-    const int k_first = w.k;
-    const bool mine = alive;
     Ray ray;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
     while (true) {
@@ -1434,7 +1413,6 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }
-    count_walk_segments(&s_seg[threadIdx.x >> 6], mine ? (unsigned)(w.k - k_first) : 0u, scratch);
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 }
 
@@ -1797,10 +1775,6 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
                  slot, kp, st, alive && sr.begin == 0);
     if (alive && sr.begin > 0) alive = walker_resume(w, st, sr.begin);
-    __shared__ unsigned s_seg[16];                          // (up to 16 waves per workgroup)
-    if (lane == 0u) s_seg[threadIdx.x >> 6] = 0u;
-    const int k_first = w.k;
-    const bool mine = alive;
     Ray ray = make_ray(0.f, 0.f, 0.f, 0.f, 0.f, 1.f);
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
     // The Philox words of a walk's bounces depend on (seed, pair, side, bounce) alone: the 64 / R lanes of the walk's group
@@ -1870,7 +1844,6 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T, &surf);
     }
-    count_walk_segments(&s_seg[threadIdx.x >> 6], mine ? (unsigned)(w.k - k_first) : 0u, scratch);
     if (COUNT) add_fetch_counts(const_cast<unsigned*>(scratch), 3, cnt_nv, cnt_nt);
 #ifdef FS_WAVE_TIMELINE
     if (lane == 0u && g_wave_buf) {   // [0] start, [1] end (100 MHz) | cycles: [2] in queries, [3] in all, [6] in the loop head | [4] traversal steps, [5] queries
@@ -1906,12 +1879,12 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
     const int nb = kp.num_bins, W = kp.hist_window, NB = band_count<B>(kp);   // LDS histogram = the first W bins of every band (see KParams)
     int* s_share = reinterpret_cast<int*>(s_hist + (size_t)NB * W);   // work-sharing area of trav_any_shared
     __shared__ int s_lo, s_hi;
-    __shared__ unsigned s_dep, s_tst;
+    __shared__ unsigned s_dep, s_tst, s_sgs;
 #ifdef FS_WAVE_TIMELINE
     unsigned long long tl[6] = {__builtin_amdgcn_s_memrealtime(), 0, 0, 0, 0, 0};
 #endif
     for (int i = threadIdx.x; i < NB * W; i += kBlock) s_hist[i] = 0.0f;
-    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; s_tst = 0u; }
+    if (threadIdx.x == 0) { s_lo = nb; s_hi = -1; s_dep = 0u; s_tst = 0u; s_sgs = 0u; }
     // this frame's walk is over: rearm the frame scratch (queue head, plan counts and cursors) for the next one
     if (bid == 0u)
         for (int i = threadIdx.x; i < 1 + 2 * kPlanBuckets; i += kBlock) queue_head[i] = 0u;
@@ -1919,7 +1892,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 
     const uint32_t n = kp.num_local;
     const uint32_t total = 2u * n;
-    unsigned my_deposits = 0, my_tested = 0;
+    unsigned my_deposits = 0, my_tested = 0, my_segments = 0;
     uint32_t cnt_nv = 0u, cnt_nt = 0u;
     // whole workgroups step through the pairs: every lane of a wave takes part in the shared visibility queries,
     // also the ones without a pair or without a segment to test
@@ -1973,6 +1946,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
         if (!tl[1]) tl[1] = __builtin_amdgcn_s_memrealtime();   // first chunk: set-up and end-state loads done
 #endif
         my_tested += active ? 1u : 0u;                                // one ConnectSubpaths per pair (ARTS.cpp:232 counts the connected ones)
+        my_segments += active ? Fm.y + Lm.y : 0u;                     // the steps the two walks TOOK (each wrote its own count with its end state)
         const bool hit = trav_any_shared<COUNT>(sc, has_ray, ray, tmax, &s_stack[threadIdx.x], s_share, &cnt_nv, &cnt_nt);
 #ifdef FS_WAVE_TIMELINE
         if (!tl[2]) tl[2] = __builtin_amdgcn_s_memrealtime();   // first chunk: visibility queries done
@@ -2139,16 +2113,18 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
     if (COUNT) add_fetch_counts(queue_head, 5, cnt_nv, cnt_nt);
     {   // work counters: summed per wave, then per workgroup in LDS — one global atomic per workgroup (thousands of
         // atomics on one address cost the kernel ~10 %)
-        unsigned d = my_deposits, t = my_tested;
-        for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); t += __shfl_down(t, o); }
+        unsigned d = my_deposits, t = my_tested, g = my_segments;
+        for (int o = 32; o > 0; o >>= 1) { d += __shfl_down(d, o); t += __shfl_down(t, o); g += __shfl_down(g, o); }
         if ((threadIdx.x & 63u) == 0u && d) atomicAdd(&s_dep, d);
         if ((threadIdx.x & 63u) == 0u && t) atomicAdd(&s_tst, t);
+        if ((threadIdx.x & 63u) == 0u && g) atomicAdd(&s_sgs, g);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long* counters = reinterpret_cast<unsigned long long*>(queue_head + kCounterWord);
         if (s_dep) atomicAdd(&counters[2], (unsigned long long)s_dep);
         if (s_tst) atomicAdd(&counters[1], (unsigned long long)s_tst);   // the pairs this workgroup's lanes tested
+        if (s_sgs) atomicAdd(&counters[0], (unsigned long long)s_sgs);   // fs_stats.segments: observed (planned: counters[7], by the plan pass)
     }
     if (!BATCH) {
         const int lo = s_lo, hi = s_hi;

@@ -197,7 +197,9 @@ typedef struct fs_stats {
     uint32_t bvh_depth;          /* depth of the binary tree before the 4-wide collapse */
     uint64_t scene_bytes;        /* device bytes of BVH + triangles + materials */
     /* work counters kept on the device since the last fs_reset_stats */
-    uint64_t segments;           /* walk segments = closest-hit queries, counted by the walkers as they apply each hit or miss */
+    uint64_t segments;           /* walk segments = closest-hit queries the walks TOOK: every walker counts its applied hits and misses and
+                                  * leaves the count with its end state; the connect pass, which reads both of a pair's, sums them (a sum
+                                  * inside the walk kernel cost the fused launch 20 spilled registers and 3 % of the headline) */
     uint64_t connections_tested; /* any-hit queries: one per pair, or one per (i, j) in all-connections mode */
     uint64_t deposits;           /* unobstructed connections = paths evaluated and deposited */
     /* profiling level 3 only (counting instantiations of the kernels, not for timed frames): records the traversal
