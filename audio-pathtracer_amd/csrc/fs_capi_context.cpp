@@ -2,6 +2,8 @@
 // (C ABI: include/frequensee.h; subsystem Initialize / Deinitialize, ARTS.cpp:32-42).
 #include "fs_context.hpp"
 
+#include <chrono>
+
 namespace fsi {
 
 Source* get_source(fs_context* ctx, fs_source h) {
@@ -18,8 +20,9 @@ Source* get_source(fs_context* ctx, fs_source h) {
 // launches of a context with a communicator, 4 such waits each).
 hipError_t compute_waits_for(fs_context* ctx, hipEvent_t ev) {
     const hipError_t q = hipEventQuery(ev);
-    if (q == hipSuccess) return hipSuccess;
+    if (q == hipSuccess) { ctx->dbg.waits_skipped++; return hipSuccess; }
     (void)hipGetLastError();   // hipErrorNotReady is not an error
+    ctx->dbg.waits_enqueued++;
     return hipStreamWaitEvent(ctx->stream, ev, 0);
 }
 // ---- batched reconstructs: one event per batch (fs_context::tail_batch_ev) ----------------------------------------
@@ -50,7 +53,12 @@ hipError_t stream_waits_for_rec(fs_context* ctx, hipStream_t st, Source* s, int 
 }
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot) {
     const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);
-    return hipEventSynchronize(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+    if (!ctx->debug_stalls) return hipEventSynchronize(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipEventSynchronize(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+    ctx->dbg.sync_publish++;
+    ctx->dbg.sync_publish_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    return e;
 }
 hipError_t wait_energy_readers(fs_context* ctx, Source* s, int buf) {
     if (s->red_recorded[buf]) {   // the tail stream may still be summing this buffer over the ranks
@@ -488,6 +496,8 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_DEBUG_REBIN")) ctx->debug_rebin = std::atoi(v);
+    if (const char* v = std::getenv("FS_DEBUG_STALLS")) ctx->debug_stalls = std::atoi(v) != 0;
+    if (const char* v = std::getenv("FS_FLUSH_RECON_ON_COMPUTE")) ctx->flush_recon_on_compute = std::atoi(v) != 0;
     if (const char* v = std::getenv("FS_DEBUG_COHERENT_WAVES")) ctx->debug_coherent = std::atoi(v) != 0;   // timing experiments only: results are void
     if (const char* v = std::getenv("FS_OVER_CAP")) ctx->over_cap_forced = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("FS_WALK_COOP")) ctx->walk.coop = std::atoi(v) ? 1 : 0;
@@ -562,6 +572,12 @@ int fs_context_destroy(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (ctx->device_ok) {
         (void)hipSetDevice(ctx->cfg.device);
+        if (ctx->debug_stalls)
+            std::fprintf(stderr, "[frequensee] stalls: %llu fused launches, %llu flushes of %llu held frames, %llu host waits for a publish (%llu us), "
+                         "%llu waits enqueued on the compute stream (%llu already complete), %llu owed reconstructs on the tail stream\n",
+                         (unsigned long long)ctx->dbg.launches, (unsigned long long)ctx->dbg.flushes, (unsigned long long)ctx->dbg.flushed_frames,
+                         (unsigned long long)ctx->dbg.sync_publish, (unsigned long long)ctx->dbg.sync_publish_us, (unsigned long long)ctx->dbg.waits_enqueued,
+                         (unsigned long long)ctx->dbg.waits_skipped, (unsigned long long)ctx->dbg.owed_on_tail);
         (void)flush_pending(ctx);
         cancel_refine(ctx);
         (void)hipStreamSynchronize(ctx->stream);

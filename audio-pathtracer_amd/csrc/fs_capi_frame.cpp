@@ -2,6 +2,8 @@
 // publish, impulse-response and energy-buffer access (C ABI: include/frequensee.h).
 #include "fs_context.hpp"
 
+#include <chrono>
+
 namespace fsi {
 
 // depth = 0 frames: did a walk's record miss both tiers?  (Called where the compute stream has just been synchronised.)
@@ -42,6 +44,16 @@ namespace {
 // What a held frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum over
 // the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
 // frames (cur rotated): the per-frame fields are switched back for the duration.
+// A reconstruct that no launch is fused with (a flush: fs_submit, fs_synchronize, an observer): on one GPU it goes onto the
+// COMPUTE stream as a batch of one — the kernel writes the published host slot itself, nothing crosses to the tail stream.
+// (Through the tail stream — a handoff event, a kernel and a copy on the priority queue while the compute queue is busy — one
+// flush in three took 6 ms longer than the others on the pool's boxes: tools/repeat_driver_bench.py, the driver's 20-step
+// region read 440 or 880 M rays/s.)  FS_FLUSH_RECON_ON_COMPUTE=0 restores the tail-stream path.
+static int flush_reconstruct(fs_context* ctx, Source* s, const fs_params* p) {
+    if (ctx->flush_recon_on_compute && !ctx->comm && ctx->cfg.world_size == 1) { Source* one = s; return reconstruct_batch(ctx, &one, 1, p, true); }
+    return reconstruct_now(ctx, s, p);
+}
+
 static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false, bool tail_waits_already = false) {
     // the items of a frame were connected by ONE launch: once the tail stream waits behind it (the first item's handoff),
     // the other items' reconstructs are ordered too — no further event pairs on the compute stream (each is a bubble
@@ -73,7 +85,7 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bo
                 fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon; o.reduced = summed;
                 ctx->recon_owed.push_back(o);
             } else {
-                rc = reconstruct_now(ctx, s, &it.recon);
+                rc = flush_reconstruct(ctx, s, &it.recon);
                 if (!rc && s->tail_ordered) tail_behind_launch = true;
             }
         }
@@ -265,13 +277,14 @@ static int run_owed_reconstructs(fs_context* ctx) {
     if (ctx->recon_owed.empty()) return FS_OK;
     std::vector<fs_context::ReconOwed> owed;
     owed.swap(ctx->recon_owed);
+    ctx->dbg.owed_on_tail += owed.size();
     for (const fs_context::ReconOwed& o : owed) {
         Source* s = o.s;
         const int cur = s->cur;
         const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
         s->cur = o.cur; s->cur_fixed = o.fixed; s->reduced = o.reduced; s->handed_off = false;
         s->tail_ordered = o.reduced;   // (the tail stream is behind the all-reduce, which is behind the launch)
-        const int rc = reconstruct_now(ctx, s, &o.p);
+        const int rc = flush_reconstruct(ctx, s, &o.p);
         s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered;
         if (rc) return rc;
     }
@@ -279,21 +292,40 @@ static int run_owed_reconstructs(fs_context* ctx) {
 }
 
 int flush_pending(fs_context* ctx) {
+    using clk = std::chrono::steady_clock;
+    const bool dbg = ctx->debug_stalls;
+    clk::time_point t0, t1, t2;
+    if (dbg) t0 = clk::now();
     if (!ctx->group.empty()) { const int gr = dispatch_group(ctx); if (gr) return gr; }
+    if (dbg) t1 = clk::now();
     { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // (older than every held frame)
+    if (dbg) t2 = clk::now();
     if (ctx->held.empty()) return FS_OK;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ctx->dbg.flushes++; ctx->dbg.flushed_frames += ctx->held.size();
+    long us_launch = 0, us_finish = 0;
     while (!ctx->held.empty()) {
         const fs_context::PipeFrame q = ctx->held.front();
         ctx->held.pop_front();
+        clk::time_point a, b, c;
+        if (dbg) a = clk::now();
         for (int k = q.next_stage; k < (int)q.stages.size(); ++k)
             launch_walk(ctx->scene, q.kp, q.st, stage_launch(ctx, q, k), q.perm, ctx->stream, q.stages[(size_t)k]);
         launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.items[0].s->d_energy[q.items[0].cur],
                        q.fixed ? q.items[0].s->d_fixed[q.items[0].cur] : nullptr, q.wl.queue_head, q.ppw, q.energy_tab, q.fixed_tab,
                        ctx->stream);
         FS_HIP(ctx, hipGetLastError());
+        if (dbg) b = clk::now();
         const int rc = finish_held_frame(ctx, q);
+        if (dbg) { c = clk::now(); us_launch += (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); us_finish += (long)std::chrono::duration_cast<std::chrono::microseconds>(c - b).count(); }
         if (rc) return rc;
+    }
+    if (dbg) {
+        const long total = (long)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count();
+        if (total > 1000)
+            std::fprintf(stderr, "[frequensee] flush %ld us: group %ld, owed reconstructs %ld, launches of held frames %ld, their reconstructs %ld\n", total,
+                         (long)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count(), (long)std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count(),
+                         us_launch, us_finish);
     }
     return FS_OK;
 }
@@ -856,6 +888,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
         bool fused_launch = false;
         if (fp.num_walk > 0 || fp.has_connect || fp.has_plan || fp.num_recon > 0) {
             fused_launch = launch_frame(B, ctx->scene, fp, ctx->stream);
+            ctx->dbg.launches++;
             if (!fused_launch) {   // no fused form: the same passes one after the other
                 if (fp.has_connect) launch_connect(B, ctx->scene, fp.kpc, fp.stc, fp.energy, fp.fixed, fp.scratch_c, fp.ppw, fp.energy_tab, fp.fixed_tab, ctx->stream);
                 for (int i = 0; i < fp.num_walk; ++i)
