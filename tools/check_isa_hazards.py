@@ -13,7 +13,8 @@ of the final ISA, that no instruction reads or writes a VGPR that an inline-asm 
 Rules: a register range becomes IN FLIGHT at an asm `global_load_*` (between ;;#ASMSTART / ;;#ASMEND); every
 `s_waitcnt vmcnt(0)` (ours or the compiler's) lands everything; a later asm load to the same registers is allowed
 (loads return in order); any other instruction that names an in-flight register is a hazard.  The in-flight set is
-propagated over the CFG (union over predecessors, to a fixed point).
+propagated over the CFG (union over predecessors, to a fixed point).  Numeric local labels of inline-asm statements (`2:`,
+`s_cbranch_execz 2f`) are basic-block boundaries and edges like the compiler's own: a branch around a wait keeps its registers in flight.
 Counted waits (round 4, the cooperative traversal): vector memory operations complete in issue order, so
 `s_waitcnt vmcnt(N)` lands everything but the N youngest.  The checker keeps the ORDER of the vector memory instructions
 of the current basic block (asm or not: loads, stores, atomics all count); a counted wait that has at least N of them
@@ -28,6 +29,8 @@ from collections import defaultdict
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 LABEL = re.compile(r"^(\.LBB\d+_\d+):")
+LOCAL = re.compile(r"^\s*(\d+):\s*$")
+LOCAL_BRANCH = re.compile(r"^s_(cbranch_\w+|branch)\s+(\d+)([fb])\b")
 FUNC = re.compile(r"^(_Z\w+):")
 BRANCH = re.compile(r"^\s+s_(cbranch_\w+|branch)\s+(\.LBB\d+_\d+)")
 VMCNT = re.compile(r"vmcnt\((\d+)\)")
@@ -46,7 +49,7 @@ def regs_of(text: str) -> set[int]:
 
 def check_function(name: str, lines: list[str]) -> list[str]:
     # basic blocks: (label or index) -> list of (lineno, text, in_asm)
-    blocks: list[dict] = [{"label": None, "ins": [], "succ": []}]
+    blocks: list[dict] = [{"label": None, "ins": [], "succ": [], "line": 0}]
     in_asm = False
     for no, raw in lines:
         line = raw.split(";")[0].rstrip() if not raw.lstrip().startswith(";;#") else raw.strip()
@@ -58,13 +61,17 @@ def check_function(name: str, lines: list[str]) -> list[str]:
             continue
         m = LABEL.match(raw)
         if m:
-            blocks.append({"label": m.group(1), "ins": [], "succ": []})
+            blocks.append({"label": m.group(1), "ins": [], "succ": [], "line": no})
+            continue
+        m = LOCAL.match(raw)
+        if m:   # a numeric local label of an inline-asm statement (`2:`; branches name it `2f` / `2b`)
+            blocks.append({"label": None, "local": m.group(1), "ins": [], "succ": [], "line": no})
             continue
         if not line.strip() or line.strip().startswith(".") or line.strip().startswith(";"):
             continue
         blocks[-1]["ins"].append((no, line.strip(), in_asm))
         if re.match(r"^\s*s_(cbranch|branch|endpgm|setpc)", line):
-            blocks.append({"label": None, "ins": [], "succ": []})   # fallthrough block after a branch
+            blocks.append({"label": None, "ins": [], "succ": [], "line": no})   # fallthrough block after a branch
     index = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
     for i, b in enumerate(blocks):
         fall = True
@@ -75,6 +82,15 @@ def check_function(name: str, lines: list[str]) -> list[str]:
                 if m.group(2) in index:
                     b["succ"].append(index[m.group(2)])
                 if m.group(1) == "branch":
+                    fall = False
+            ml = LOCAL_BRANCH.match(last)
+            if ml:   # the nearest local label of that number, forwards or backwards — an edge like any other (a branch AROUND a
+                     # wait leaves more in flight than the fall-through path: it must not be dropped)
+                cands = [j for j, c in enumerate(blocks) if c.get("local") == ml.group(2) and ((j > i) if ml.group(3) == "f" else (j <= i))]
+                if not cands:
+                    raise SystemExit(f"{name}: line {no}: local label of `{last}` not found")
+                b["succ"].append(min(cands) if ml.group(3) == "f" else max(cands))
+                if ml.group(1) == "branch":
                     fall = False
             if last.startswith("s_endpgm") or last.startswith("s_setpc"):
                 fall = False
