@@ -51,11 +51,26 @@ hipError_t stream_waits_for_rec(fs_context* ctx, hipStream_t st, Source* s, int 
     if (st == ctx->stream) return compute_waits_for(ctx, s->ev_rec[buf]);
     return hipStreamWaitEvent(st, s->ev_rec[buf], 0);
 }
+// The producer's short waits (the IR ring's back-pressure: a launch or two, ~ 1 ms) POLL the event instead of sleeping on it: a
+// blocking hipEventSynchronize depends on an interrupt reaching the host thread, and on the pool's boxes one such wait in a few
+// hundred came back ~ 6 ms late (the work it waited for long done) — inside a 6 ms timed region that halves the rate
+// (tools/repeat_driver_bench.py).  After 20 ms of polling it falls back to the blocking wait.
+hipError_t wait_event_polling(hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return hipSuccess;
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(ev);
+        __builtin_ia32_pause();
+    }
+}
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot) {
     const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);
-    if (!ctx->debug_stalls) return hipEventSynchronize(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+    if (!ctx->debug_stalls) return wait_event_polling(b ? tail_batch_event(ctx, b) : s->ev[slot]);
     const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t e = hipEventSynchronize(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+    const hipError_t e = wait_event_polling(b ? tail_batch_event(ctx, b) : s->ev[slot]);
     ctx->dbg.sync_publish++;
     ctx->dbg.sync_publish_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     return e;

@@ -60,6 +60,7 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bo
     // between its launches).  Not in deterministic mode: every item's fixed-point rounding runs on the compute stream first.
     // (tail_waits_already: the publishes of this very launch's reconstruct parts made the tail stream wait behind it)
     bool tail_behind_launch = tail_waits_already;
+    const bool flushing = !may_defer_recon;   // called by flush_pending: nothing will be launched behind this frame that its reconstructs could overlap
     // the reconstructs of a frame ride in the next launch all together or not at all (a tail-stream reconstruct in between
     // would have to run the deferred ones first, to keep the IRs in frame order)
     int wanted = 0;
@@ -85,7 +86,9 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bo
                 fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon; o.reduced = summed;
                 ctx->recon_owed.push_back(o);
             } else {
-                rc = flush_reconstruct(ctx, s, &it.recon);
+                // (steady state with more reconstructs than a launch has parts for — cfg5's eight sources: on the tail stream,
+                // beside the next launch; on the compute stream they cost the stream of frames a fifth: 899 -> 705 M rays/s)
+                rc = flushing ? flush_reconstruct(ctx, s, &it.recon) : reconstruct_now(ctx, s, &it.recon);
                 if (!rc && s->tail_ordered) tail_behind_launch = true;
             }
         }
@@ -439,7 +442,7 @@ int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_
         // a table slot the kernel of eight batches ago has certainly left
         const unsigned slot_t = ctx->recon_tab_next++ % fs_context::kReconTabSlots;
         if (ctx->recon_tab_batch[slot_t] && !tail_batch_done(ctx, ctx->recon_tab_batch[slot_t]))
-            FS_HIP(ctx, hipEventSynchronize(tail_batch_event(ctx, ctx->recon_tab_batch[slot_t])));
+            FS_HIP(ctx, wait_event_polling(tail_batch_event(ctx, ctx->recon_tab_batch[slot_t])));
         ReconItem* tab = ctx->h_recon_tab + (size_t)slot_t * fs_context::kReconTabItems;
         std::vector<Source*> order(g, g + n);
         std::sort(order.begin(), order.end());                 // one locking order for every thread
@@ -760,7 +763,7 @@ int frame_resources(fs_context* ctx, Frame& f) {
             }
             hb = ctx->h_batch + (size_t)slot * ctx->batch_cap;
             db = ctx->d_batch + (size_t)slot * ctx->batch_cap;
-            if (ctx->batch_pending[slot]) FS_HIP(ctx, hipEventSynchronize(ctx->ev_batch[slot]));   // its last copy has left the block
+            if (ctx->batch_pending[slot]) FS_HIP(ctx, wait_event_polling(ctx->ev_batch[slot]));   // its last copy has left the block
             std::memcpy(hb, ctx->batch_build.data(), bytes);
             ctx->batch_bytes[slot] = 0;   // (until the copy is enqueued)
             FS_HIP(ctx, hipMemcpyAsync(db, hb, bytes, hipMemcpyHostToDevice, ctx->stream));

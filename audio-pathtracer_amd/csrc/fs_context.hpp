@@ -394,6 +394,7 @@ void poll_published(fs_context* ctx, Source* s);
 bool tail_batch_done(fs_context* ctx, uint64_t id);                 // any thread
 hipEvent_t tail_batch_event(fs_context* ctx, uint64_t id);          // the event that covers batch `id`
 hipError_t stream_waits_for_rec(fs_context* ctx, hipStream_t st, Source* s, int buf);   // st waits for the reconstruct that last read energy buffer `buf` (and wrote d_ir_*)
+hipError_t wait_event_polling(hipEvent_t ev);   // short producer waits: poll, do not sleep (fs_capi_context.cpp)
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot);      // block until the publish in ring slot `slot` has completed
 int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals,
                  int sets, bool staged);
