@@ -98,9 +98,10 @@ __device__ __forceinline__ void sample_sphere(uint32_t pair, uint32_t bs, uint4 
 }
 
 // FMath::VRandCone(n, 90 deg) (ARTS.cpp:313) or cosine-weighted (compat flag)
-__device__ __forceinline__ void sample_cone(float nx, float ny, float nz, float U, float V, int cosine, float& dx,
-                                            float& dy, float& dz) {
-    float cphi, sphi;
+// (two halves: the sample in the cone's own frame depends on the two uniforms only — the cooperative walk lets idle lanes
+// compute it for 64 bounces at a time — the turn into the world on the surface normal; sample_cone = one after the other)
+__device__ __forceinline__ void cone_local(float U, float V, int cosine, float& lx, float& ly, float& cphi) {
+    float sphi;
     if (cosine) {
         cphi = sqrtf(1.0f - V);
         sphi = sqrtf(V);
@@ -111,18 +112,26 @@ __device__ __forceinline__ void sample_cone(float nx, float ny, float nz, float 
     }
     float st, ct;
     sincos2pi(U, st, ct);
+    lx = sphi * ct; ly = sphi * st;
+}
+__device__ __forceinline__ void cone_world(float nx, float ny, float nz, float lx, float ly, float cphi, float& dx, float& dy, float& dz) {
     float sg = copysignf(1.0f, nz);
     float a = -1.0f / (sg + nz);
     float b = nx * ny * a;
     float t0 = fmaf(sg * nx * nx, a, 1.0f), t1 = sg * b, t2 = -sg * nx;
     float b0 = b, b1 = fmaf(ny * ny, a, sg), b2 = -ny;
-    float lx = sphi * ct, ly = sphi * st;
     float d0 = fmaf(lx, t0, fmaf(ly, b0, cphi * nx));
     float d1 = fmaf(lx, t1, fmaf(ly, b1, cphi * ny));
     float d2 = fmaf(lx, t2, fmaf(ly, b2, cphi * nz));
     float l2 = d0 * d0 + d1 * d1 + d2 * d2;
     float inv = 1.0f / sqrtf(l2);
     dx = d0 * inv; dy = d1 * inv; dz = d2 * inv;
+}
+__device__ __forceinline__ void sample_cone(float nx, float ny, float nz, float U, float V, int cosine, float& dx,
+                                            float& dy, float& dz) {
+    float lx, ly, cphi;
+    cone_local(U, V, cosine, lx, ly, cphi);
+    cone_world(nx, ny, nz, lx, ly, cphi, dx, dy, dz);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -712,10 +721,11 @@ __device__ __forceinline__ void walker_start(Walker& w, uint32_t g, uint32_t slo
 // `ray` still holds the previous segment's ray on entry: its direction is the arrival direction at this vertex.
 // LOBES: 0 / 1 = FS_FLAG_MATERIAL_LOBES known at compile time, -1 = read kp.lobes.
 // pre: the Philox words of this bounce, computed ahead by another lane (cooperative walk: the roulette and the sample of a
-// bounce depend on (seed, pair, side, bounce) only) — the same words, so the same walk
+// bounce depend on (seed, pair, side, bounce) only) — the same words, so the same walk.  pre_cone: words y, z, w are already the
+// diffuse sample in the cone's own frame (cone_local) — only for a vertex with a normal, without lobes
 template <int LOBES = -1>
 __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, const DeviceScene& sc,
-                                                const SubpathState& st, Ray& ray, const uint4* pre = nullptr) {
+                                                const SubpathState& st, Ray& ray, const uint4* pre = nullptr, const bool pre_cone = false) {
     const bool lobes_on = LOBES < 0 ? kp.lobes != 0 : LOBES != 0;
     if (w.k >= kp.depth && st.over_levels == 0) return false;             // the depth cap
     const uint32_t bs = ((uint32_t)w.k << 1) | w.side;
@@ -751,7 +761,9 @@ __device__ __forceinline__ bool walker_next_ray(Walker& w, const KParams& kp, co
         w.lobe = pick ? lobe << kLobeShift : 0u;
         float ox = w.px, oy = w.py, oz = w.pz;
         if (lobe == kLobeDiffuse) {
-            sample_cone(w.nx, w.ny, w.nz, u01(r.y), u01(r.z), kp.cosine, dx, dy, dz);
+            // (pre_cone: r.y, r.z, r.w hold cone_local's result for this bounce, computed ahead by another lane — the same operations)
+            if (pre_cone) cone_world(w.nx, w.ny, w.nz, __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w), dx, dy, dz);
+            else sample_cone(w.nx, w.ny, w.nz, u01(r.y), u01(r.z), kp.cosine, dx, dy, dz);
             float cos_theta = dx * w.nx + dy * w.ny + dz * w.nz;
             float pdf = cos_theta / kPi;
             w.prob_new = pdf * kp.rr_prob;
@@ -1807,7 +1819,12 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
                 __builtin_amdgcn_wave_barrier();
                 const int* b = rngb + (lane >> rshift) * 4;
                 const uint32_t bounce = (uint32_t)(lds_ld(b + 3) + (int)(lane & (uint32_t)(RG - 1)));
-                const uint4 pr = philox((uint32_t)lds_ld(b + 0), (bounce << 1) | (uint32_t)lds_ld(b + 1), 0, (uint32_t)lds_ld(b + 2), kp.seed_hi);
+                uint4 pr = philox((uint32_t)lds_ld(b + 0), (bounce << 1) | (uint32_t)lds_ld(b + 1), 0, (uint32_t)lds_ld(b + 2), kp.seed_hi);
+                if (LOBES == 0 && bounce > 0u) {   // every bounce but the first leaves a surface (unless every ray so far missed: the owner
+                    float lx, ly, cphi;            //   then draws its words again): the cone sample's hit-independent half, here
+                    cone_local(u01(pr.y), u01(pr.z), kp.cosine, lx, ly, cphi);
+                    pr.y = __float_as_uint(lx); pr.z = __float_as_uint(ly); pr.w = __float_as_uint(cphi);
+                }
                 lds_st(rngw + 4 * lane + 0, (int)pr.x); lds_st(rngw + 4 * lane + 1, (int)pr.y);
                 lds_st(rngw + 4 * lane + 2, (int)pr.z); lds_st(rngw + 4 * lane + 3, (int)pr.w);
                 __builtin_amdgcn_wave_barrier();
@@ -1819,7 +1836,9 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
                 const int ri = 4 * (((int)lane << rshift) + (w.k - rng_k0));   // owner lane g: its group's lanes start at g * RG
                 const uint4 pre = make_uint4((uint32_t)lds_ld(rngw + ri), (uint32_t)lds_ld(rngw + ri + 1), (uint32_t)lds_ld(rngw + ri + 2),
                                              (uint32_t)lds_ld(rngw + ri + 3));
-                go = walker_next_ray<LOBES>(w, kp, sc, st, ray, &pre);
+                const bool cone_form = LOBES == 0 && w.k > 0;          // what the cache holds for this bounce
+                go = (cone_form && !w.has_normal) ? walker_next_ray<LOBES>(w, kp, sc, st, ray)   // (all misses so far: a sphere sample from the raw words)
+                                                  : walker_next_ray<LOBES>(w, kp, sc, st, ray, &pre, cone_form);
                 if (!go) {
                     walker_finish<EXT>(w, st);
                     if (st.cont_b && w.k >= FS_MAX_DEPTH) st.cont_b[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // a walk of the last schedule bucket: later stages visit this slot again
