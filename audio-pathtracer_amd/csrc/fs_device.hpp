@@ -1613,12 +1613,14 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
 #endif
     if (lane < (unsigned)R) {   // the owners publish their rays, clear their mailboxes and put the root on their group's stack
         // (the ray's reciprocals travel too: the owner has them from make_ray; three v_rcp_f32 and their guards per lane and query saved)
-        int* rw = rayw + lane * kCoopRayWords;
-        lds_st(rw + 0, __float_as_int(own.ox)); lds_st(rw + 1, __float_as_int(own.oy)); lds_st(rw + 2, __float_as_int(own.oz));
-        lds_st(rw + 3, __float_as_int(own.dx)); lds_st(rw + 4, __float_as_int(own.dy)); lds_st(rw + 5, __float_as_int(own.dz));
-        lds_st(rw + 6, __float_as_int(own.ix)); lds_st(rw + 7, __float_as_int(own.iy)); lds_st(rw + 8, __float_as_int(own.iz));
-        lds_st(rw + 9, __float_as_int(has_ray ? tmax : -1.0f));
-        lds_st(rw + 10, (int)ignore);
+        if (R > 1) {
+            int* rw = rayw + lane * kCoopRayWords;
+            lds_st(rw + 0, __float_as_int(own.ox)); lds_st(rw + 1, __float_as_int(own.oy)); lds_st(rw + 2, __float_as_int(own.oz));
+            lds_st(rw + 3, __float_as_int(own.dx)); lds_st(rw + 4, __float_as_int(own.dy)); lds_st(rw + 5, __float_as_int(own.dz));
+            lds_st(rw + 6, __float_as_int(own.ix)); lds_st(rw + 7, __float_as_int(own.iy)); lds_st(rw + 8, __float_as_int(own.iz));
+            lds_st(rw + 9, __float_as_int(has_ray ? tmax : -1.0f));
+            lds_st(rw + 10, (int)ignore);
+        }
         lds_st64(keyw + 4 * lane, ((unsigned long long)__float_as_uint(tmax) << 32) | 0xFFFFFFFFull);
         lds_st(boxw + lane * kCoopBoxWords + 2, -1);
         lds_st(wl + lane * cap, 0);
@@ -1626,12 +1628,23 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
     __builtin_amdgcn_wave_barrier();
     const int* rw = rayw + g * kCoopRayWords;
     Ray r;
-    r.ox = __int_as_float(lds_ld(rw + 0)); r.oy = __int_as_float(lds_ld(rw + 1)); r.oz = __int_as_float(lds_ld(rw + 2));
-    r.dx = __int_as_float(lds_ld(rw + 3)); r.dy = __int_as_float(lds_ld(rw + 4)); r.dz = __int_as_float(lds_ld(rw + 5));
-    r.ix = __int_as_float(lds_ld(rw + 6)); r.iy = __int_as_float(lds_ld(rw + 7)); r.iz = __int_as_float(lds_ld(rw + 8));
+    uint32_t ign;
+    int n;                                                 // pending nodes of this group (the same number in all its lanes)
+    if (R == 1) {   // (wave-uniform) one ray per wave: lane 0's registers are broadcast as they are — no round trip through LDS
+        auto bc = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        r.ox = bc(own.ox); r.oy = bc(own.oy); r.oz = bc(own.oz);
+        r.dx = bc(own.dx); r.dy = bc(own.dy); r.dz = bc(own.dz);
+        r.ix = bc(own.ix); r.iy = bc(own.iy); r.iz = bc(own.iz);
+        ign = (uint32_t)__builtin_amdgcn_readfirstlane((int)ignore);
+        n = __builtin_amdgcn_readfirstlane((has_ray && tmax > 0.0f) ? 1 : 0);
+    } else {
+        r.ox = __int_as_float(lds_ld(rw + 0)); r.oy = __int_as_float(lds_ld(rw + 1)); r.oz = __int_as_float(lds_ld(rw + 2));
+        r.dx = __int_as_float(lds_ld(rw + 3)); r.dy = __int_as_float(lds_ld(rw + 4)); r.dz = __int_as_float(lds_ld(rw + 5));
+        r.ix = __int_as_float(lds_ld(rw + 6)); r.iy = __int_as_float(lds_ld(rw + 7)); r.iz = __int_as_float(lds_ld(rw + 8));
+        ign = (uint32_t)lds_ld(rw + 10);
+        n = __int_as_float(lds_ld(rw + 9)) > 0.0f ? 1 : 0;
+    }
     r.nox = -(r.ox * r.ix); r.noy = -(r.oy * r.iy); r.noz = -(r.oz * r.iz);   // as make_ray
-    const uint32_t ign = (uint32_t)lds_ld(rw + 10);
-    int n = __int_as_float(lds_ld(rw + 9)) > 0.0f ? 1 : 0;   // pending nodes of this group (the same number in all its lanes)
     const unsigned long long gmask = R == 1 ? ~0ull : (((1ull << G) - 1ull) << (g * G));
     const unsigned long long below = gmask & ((1ull << lane) - 1ull);
     const int wshift = cv.wshift, per = (1 << wshift) - 1; // 16 (or 4) lanes per node: lane j takes child j & per of node j >> wshift
@@ -1737,6 +1750,30 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
     // ---- the mailbox holds the closest hit of the group's ray; the lane that found it says which triangle it was
     __builtin_amdgcn_wave_barrier();
     const unsigned long long fin = lds_ld64(keyw + 4 * g);
+    if (R == 1) {   // (wave-uniform) one ray per wave: the finder's registers are read across, no second trip through LDS
+        const unsigned long long who = __ballot(best_leaf >= 0 && best_key == fin);   // (one lane: a triangle is tested once per query)
+        bool found1 = false;
+        if (who != 0ull) {
+            const int f = __ffsll((long long)who) - 1;
+            const int leaf1 = __builtin_amdgcn_readlane(best_leaf, f);
+            const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_surf.x), f));
+            const float sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_surf.y), f));
+            const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_surf.z), f));
+            const float sw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best_surf.w), f));
+            if (lane == 0u) {
+                T.t = __uint_as_float((uint32_t)(fin >> 32));
+                T.id = (uint32_t)fin;
+                T.leaf_index = leaf1;
+                if (surf_out) *surf_out = make_float4(sx, sy, sz, sw);
+                found1 = true;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                    // (the next query's owner rewrites the mailbox)
+#ifdef FS_WAVE_TIMELINE
+        T.sb = (int)(__builtin_amdgcn_s_memtime() - dbg_t3);
+#endif
+        return found1;
+    }
     if (best_leaf >= 0 && best_key == fin) {               // (one lane: a triangle is tested once per query)
         int* bw = boxw + g * kCoopBoxWords;
         lds_st(bw + 2, best_leaf);
