@@ -1693,8 +1693,10 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
         if (COUNT) T.nv += (act && c == 0) ? 1u : 0u;
         // ---- the triangles requested in the previous step, tested while this step's records are in flight
         if (pcnt > 0) {
+            // (both triangles of the leaf in one straight line — two independent chains the scheduler interleaves; a leaf of one
+            // triangle tests the registers' old content with a bound nothing passes)
             bool better = coop_tri<IGN>(f4(X.a0), f4(X.b0), f4(X.c0), r, bound, ign, pfirst, best_key, best_leaf, best_surf);
-            if (pcnt > 1) better = coop_tri<IGN>(f4(X.a1), f4(X.b1), f4(X.c1), r, bound, ign, pfirst + 1, best_key, best_leaf, best_surf) | better;
+            better = coop_tri<IGN>(f4(X.a1), f4(X.b1), f4(X.c1), r, pcnt > 1 ? bound : -1.0f, ign, pfirst + 1, best_key, best_leaf, best_surf) | better;
             for (int i = 2; i < pcnt; ++i) {                // leaves of three and four triangles (FS_BVH_LEAF > 2 only)
                 const Tri48 x = sc.tris[pfirst + i];
                 better = coop_tri<IGN>(x.a, x.b, x.c, r, bound, ign, pfirst + i, best_key, best_leaf, best_surf) | better;
