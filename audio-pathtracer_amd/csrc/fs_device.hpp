@@ -1034,10 +1034,13 @@ __device__ __forceinline__ void plan_body(const uint32_t bid, const uint32_t nbl
 // The same pass for SMALL frames (at most kPlanCoopMax subpaths) and for uncapped walks somebody waits for (at most
 // kPlanCoopMaxUncapped: KParams.plan_coop, set by frame_describe): the roulette of one subpath is a serial chain of Philox
 // evaluations — up to ~85 for the longest of 2 000 uncapped walks, 42 us with a subpath per thread, a tenth of the reference's
-// tick — but its bounces are independent: a wave takes kPlanCoopItems subpaths and evaluates 64 bounces of one at a time,
+// tick — but its bounces are independent: a wave takes plan_coop_items() subpaths and evaluates 64 bounces of one at a time,
 // lane j the roulette of bounce j; the first lane whose draw ends the walk gives its length (ballot + find-first).  (64 draws
 // per subpath where the chain makes 10 on average: for capped walks of a chip-filling frame the chain is the cheaper one.)
-constexpr int kPlanCoopItems = 8;   // subpaths per wave
+// subpaths per wave: 8 for the reference's own frame (2 000 subpaths: 250 waves), more for the ticks of many sources — every
+// workgroup adds its counts to the ~ 30 occupied length buckets with one global atomic each, and with 32 subpaths per workgroup
+// those atomics (40 000 on 65 addresses at 64 000 subpaths) were the pass: 34 us
+__host__ __device__ inline int plan_coop_items(uint32_t lanes) { return lanes <= 4096u ? 8 : (lanes <= 32768u ? 16 : 32); }
 __device__ __forceinline__ void plan_coop_body(const uint32_t bid, const uint32_t nblocks, const KParams& kp,
                                                unsigned* __restrict__ scratch, uint32_t* __restrict__ perm,
                                                float* __restrict__ energy, const int energy_words,
@@ -1058,9 +1061,10 @@ __device__ __forceinline__ void plan_coop_body(const uint32_t bid, const uint32_
     __syncthreads();
     const uint32_t total = 2u * kp.num_local, n = kp.num_local;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t first = (bid * (kBlock / 64) + (threadIdx.x >> 6)) * (uint32_t)kPlanCoopItems;   // this wave's subpaths [first, first + 8)
+    const int items = plan_coop_items(total);
+    const uint32_t first = (bid * (kBlock / 64) + (threadIdx.x >> 6)) * (uint32_t)items;   // this wave's subpaths [first, first + items)
     int my_len = 0;
-    for (int it = 0; it < kPlanCoopItems; ++it) {            // (wave-uniform)
+    for (int it = 0; it < items; ++it) {                     // (wave-uniform)
         const uint32_t g = first + (uint32_t)it;
         if (g >= total) break;
         const uint32_t side = g >= n ? 1u : 0u;
@@ -1080,7 +1084,7 @@ __device__ __forceinline__ void plan_coop_body(const uint32_t bid, const uint32_
         }
         if (lane == (uint32_t)it) my_len = len;
     }
-    const bool mine = lane < (uint32_t)kPlanCoopItems && first + lane < total;
+    const bool mine = lane < (uint32_t)items && first + lane < total;
     const int L = min(my_len, FS_MAX_DEPTH);
     unsigned rank = 0;
     if (mine) {

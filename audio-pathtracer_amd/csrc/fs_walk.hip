@@ -178,7 +178,7 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
 bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort) {
     const uint32_t lanes = 2u * kp.num_local;
     if (lanes == 0 || !kp.russian_roulette) return false;
-    if (blocks) *blocks = kp.plan_coop ? (lanes + (kBlock / 64) * kPlanCoopItems - 1) / ((kBlock / 64) * kPlanCoopItems)   // small frames: a wave per 8 subpaths
+    if (blocks) *blocks = kp.plan_coop ? (lanes + (kBlock / 64) * plan_coop_items(lanes) - 1) / ((kBlock / 64) * plan_coop_items(lanes))   // a wave per 8 .. 32 subpaths
                                                 : (lanes + kBlock * kPlanItems - 1) / (kBlock * kPlanItems);
     if (sort) *sort = wl.plan && kp.depth > 1 && wl.perm;
     return true;
