@@ -2285,12 +2285,12 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
         for (int v = threadIdx.x; v < kBlock * kChunk / 4; v += kBlock) {
             const int s = 4 * v;
             if (base + s + 3 < num_samples) {
-                float4 o;
-                o.x = s_stage[s + (s >> 4)]; o.y = s_stage[s + 1 + ((s + 1) >> 4)];
-                o.z = s_stage[s + 2 + ((s + 2) >> 4)]; o.w = s_stage[s + 3 + ((s + 3) >> 4)];
+                float4 o;   // (sample s of the block lives in row s / kChunk of kChunk + 1 words)
+                o.x = s_stage[s + s / kChunk]; o.y = s_stage[s + 1 + (s + 1) / kChunk];
+                o.z = s_stage[s + 2 + (s + 2) / kChunk]; o.w = s_stage[s + 3 + (s + 3) / kChunk];
                 *reinterpret_cast<float4*>(host_out + base + s) = o;
             } else {
-                for (int e = 0; e < 4; ++e) if (base + s + e < num_samples) host_out[base + s + e] = s_stage[s + e + ((s + e) >> 4)];
+                for (int e = 0; e < 4; ++e) if (base + s + e < num_samples) host_out[base + s + e] = s_stage[s + e + (s + e) / kChunk];
             }
         }
     }

@@ -10,6 +10,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft  # noqa: E402
 pkg = graft.load_package()
+if os.environ.get("FS_LIB_PATH"):   # (an experimental build: tools/build_variant.sh)
+    pkg._capi.LIB_PATH = os.environ["FS_LIB_PATH"]
+    pkg._capi._lib = None
 name = sys.argv[1] if len(sys.argv) > 1 else "starter_room"
 sc = pkg.scenes.by_name(name, 1)
 ctx = pkg.Context(num_bands=1)
