@@ -241,16 +241,16 @@ void launch_connect_t(const DeviceScene& sc_in, const KParams& kp, const Subpath
         hipLaunchKernelGGL((connect_kernel<B, L, BT, CN>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy,   \
                            fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);                                \
     } while (0)
-    // FS_FLAG_DOUBLE_POSITIONS / end-point collision spheres: one instantiation pair with the run-time band count
+    // FS_FLAG_DOUBLE_POSITIONS / end-point collision spheres: one instantiation pair with the run-time band count and run-time lobes
     if (kp.dpos || kp.listener_radius > 0.0f || kp.source_radius > 0.0f) {
         if (B != 0) return launch_connect_t<0>(sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab, s);
         if (batch) {
-            allow_lds(connect_kernel<0, 0, true, false, true>, lds);
-            hipLaunchKernelGGL((connect_kernel<0, 0, true, false, true>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed,
+            allow_lds(connect_kernel<0, -1, true, false, true>, lds);
+            hipLaunchKernelGGL((connect_kernel<0, -1, true, false, true>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed,
                                queue_head, pairs_per_wave, energy_tab, fixed_tab);
         } else {
-            allow_lds(connect_kernel<0, 0, false, false, true>, lds);
-            hipLaunchKernelGGL((connect_kernel<0, 0, false, false, true>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed,
+            allow_lds(connect_kernel<0, -1, false, false, true>, lds);
+            hipLaunchKernelGGL((connect_kernel<0, -1, false, false, true>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed,
                                queue_head, pairs_per_wave, energy_tab, fixed_tab);
         }
         return;

@@ -205,7 +205,7 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
     // record-fetch counting (fs_set_profiling level 3) exists for the default walk only (no lobes)
 #define FS_LAUNCH_WALK(K, GRID, ...)                                                                        \
     do {                                                                                                    \
-        if (kp.dpos || kp.ignore_on || kp.listener_radius > 0.0f || kp.source_radius > 0.0f) { allow_lds(K<0, false, true>, lds_ext); hipLaunchKernelGGL((K<0, false, true>), dim3(GRID), dim3(kBlock), lds_ext, s, __VA_ARGS__); } \
+        if (kp.dpos || kp.ignore_on || kp.listener_radius > 0.0f || kp.source_radius > 0.0f) { allow_lds(K<-1, false, true>, lds_ext); hipLaunchKernelGGL((K<-1, false, true>), dim3(GRID), dim3(kBlock), lds_ext, s, __VA_ARGS__); } /* (lobes: read from kp.lobes) */ \
         else if (kp.lobes) { allow_lds(K<1, false>, lds); hipLaunchKernelGGL((K<1, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }   \
         else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
         else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \

@@ -333,3 +333,33 @@ def test_a_walk_ignores_the_actor_it_starts_from(pkg, oracle_mod, rays, depth):
     ctx.set_listener_object(7)
     assert not ctx.compute_energy_response(s, p).any()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_lobes_survive_an_ignored_actor_and_end_point_spheres(pkg):
+    """the instantiations that carry the ignored actor / the end points' spheres read FS_FLAG_MATERIAL_LOBES at run time (they
+    were compiled without lobes: a batched frame in which ONE source has an actor ran every source through them and
+    dropped the lobes of the others — found by tools/stress.py).  Deterministic mode: a batched frame equals its sources'
+    single frames bit for bit; and lobes change the result whether or not an actor is ignored."""
+    sc = pkg.scenes.starter_room(4)
+    tau, sigma = pkg.scenes.material_lobes(sc)
+    ctx = pkg.Context(num_bands=4)
+    ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma, object_ids=sc.object_ids)
+    ctx.set_listener(sc.listener)
+    s0 = ctx.create_source(sc.source)
+    s1 = ctx.create_source(np.asarray(sc.source, np.float32) + np.array([150, -80, 20], np.float32))
+    LOBES = pkg._capi.FLAG_MATERIAL_LOBES
+    for radius in (0.0, 25.0):
+        p = pkg.default_params(num_rays=4096, depth=8, seed=77, dist_divisor=100.0, flags=LOBES | DET, listener_radius=radius)
+        plain = pkg.default_params(num_rays=4096, depth=8, seed=77, dist_divisor=100.0, flags=DET, listener_radius=radius)
+        ctx.set_source_object(s0)                                      # no actor anywhere: the lobes instantiation
+        ref1 = ctx.compute_energy_response(s1, p).copy()
+        assert not np.array_equal(ref1, ctx.compute_energy_response(s1, plain))           # lobes matter in this scene
+        ctx.set_source_object(s0, int(sc.object_ids[0]))               # s0's walks ignore an actor: the batch runs the EXT instantiations
+        want0 = ctx.compute_energy_response(s0, p).copy()
+        assert not np.array_equal(want0, ctx.compute_energy_response(s0, plain))          # ... which must still pick lobes
+        ctx.compute_energy_response_batch_async([s0, s1], p)
+        ctx.synchronize()
+        assert np.array_equal(ctx.energy_buffer(s0), want0)
+        assert np.array_equal(ctx.energy_buffer(s1), ref1)             # s1 has no actor: its frame is the one without any
+    ctx.close()
