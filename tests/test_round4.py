@@ -335,8 +335,7 @@ def test_a_walk_ignores_the_actor_it_starts_from(pkg, oracle_mod, rays, depth):
     ctx.close()
 
 
-@pytest.mark.gpu
-def test_lobes_survive_an_ignored_actor_and_end_point_spheres(pkg):
+def test_lobes_survive_an_ignored_actor_and_end_point_spheres(pkg, oracle_mod):
     """the instantiations that carry the ignored actor / the end points' spheres read FS_FLAG_MATERIAL_LOBES at run time (they
     were compiled without lobes: a batched frame in which ONE source has an actor ran every source through them and
     dropped the lobes of the others — found by tools/stress.py).  Deterministic mode: a batched frame equals its sources'
@@ -362,4 +361,12 @@ def test_lobes_survive_an_ignored_actor_and_end_point_spheres(pkg):
         ctx.synchronize()
         assert np.array_equal(ctx.energy_buffer(s0), want0)
         assert np.array_equal(ctx.energy_buffer(s1), ref1)             # s1 has no actor: its frame is the one without any
+    # and against the oracle: lobes + the walk's own actor, in fp32 mode
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
+    osc.set_objects(sc.object_ids)
+    pf = pkg.default_params(num_rays=4096, depth=8, seed=77, dist_divisor=100.0, flags=LOBES)
+    got = ctx.compute_energy_response(s0, pf).copy()
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=2048, depth=8, seed=77, dist_divisor=100.0, flags=oracle_mod.FLAG_MATERIAL_LOBES,
+                                                                  source_object=int(sc.object_ids[0])), sc.source, sc.listener)
+    check_energy(got, e32, e64, 4)
     ctx.close()
