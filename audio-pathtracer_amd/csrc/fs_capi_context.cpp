@@ -63,7 +63,9 @@ hipError_t wait_event_polling(hipEvent_t ev) {
         if (q != hipErrorNotReady) return q;
         (void)hipGetLastError();
         if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(ev);
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
     }
 }
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot) {
