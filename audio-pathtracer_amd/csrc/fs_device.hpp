@@ -1666,12 +1666,15 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
     X.a0 = v4f{0.f, 0.f, 0.f, 0.f}; X.b0 = X.a0; X.c0 = X.a0; X.a1 = X.a0; X.b1 = X.a0; X.c1 = X.a0;
     const int q = j >> wshift, c = j & per;
     const int resident = cv.lds_nodes;
-#ifdef FS_WAVE_TIMELINE
+#if defined(FS_WAVE_TIMELINE) && !defined(FS_WAVE_TIMELINE_FINE)
     T.cur = (int)(__builtin_amdgcn_s_memtime() - dbg_t0);
 #endif
     while (true) {
 #ifdef FS_WAVE_TIMELINE
         ++T.sp;                                            // diagnostic build: steps of this query (T.sp is not used here otherwise)
+#endif
+#ifdef FS_WAVE_TIMELINE_FINE
+        const unsigned long long fine_top = __builtin_amdgcn_s_memtime();
 #endif
         const float bound = __int_as_float(lds_ld(bound_w));
         // ---- pop: up to G / 4 nodes, fewer when the stack is close to the room the worst-case descent needs
@@ -1680,6 +1683,11 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
         const int k = n < kw ? n : kw;
         const bool act = q < k;
         const int ref = act ? lds_ld(stk + (n - 1 - q)) : 0;
+#ifdef FS_WAVE_TIMELINE_FINE   // (finer split of a step: T.cur = pop until the stack entry is here, T.sb = boxes + pushes + leaf requests)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long fine_t0 = __builtin_amdgcn_s_memtime();
+        T.cur += (int)(fine_t0 - fine_top);
+#endif
         const uint32_t rec = ((uint32_t)ref << wshift) + (uint32_t)c;
         const bool in_lds = ref < resident;
         // (exactly one request in every step, whatever the lanes need — the counted wait below relies on it: when every
@@ -1696,27 +1704,36 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
         coop_wait_tris_behind_node(X);
         if (COUNT) T.nv += (act && c == 0) ? 1u : 0u;
         // ---- the triangles requested in the previous step, tested while this step's records are in flight
-        if (pcnt > 0) {
-            // (both triangles of the leaf in one straight line — two independent chains the scheduler interleaves; a leaf of one
-            // triangle tests the registers' old content with a bound nothing passes)
-            bool better = coop_tri<IGN>(f4(X.a0), f4(X.b0), f4(X.c0), r, bound, ign, pfirst, best_key, best_leaf, best_surf);
-            better = coop_tri<IGN>(f4(X.a1), f4(X.b1), f4(X.c1), r, pcnt > 1 ? bound : -1.0f, ign, pfirst + 1, best_key, best_leaf, best_surf) | better;
-            for (int i = 2; i < pcnt; ++i) {                // leaves of three and four triangles (FS_BVH_LEAF > 2 only)
-                const Tri48 x = sc.tris[pfirst + i];
-                better = coop_tri<IGN>(x.a, x.b, x.c, r, bound, ign, pfirst + i, best_key, best_leaf, best_surf) | better;
+        auto test_pending = [&]() {
+            if (pcnt > 0) {
+                // (both triangles of the leaf in one straight line — two independent chains the scheduler interleaves; a leaf of one
+                // triangle tests the registers' old content with a bound nothing passes)
+                bool better = coop_tri<IGN>(f4(X.a0), f4(X.b0), f4(X.c0), r, bound, ign, pfirst, best_key, best_leaf, best_surf);
+                better = coop_tri<IGN>(f4(X.a1), f4(X.b1), f4(X.c1), r, pcnt > 1 ? bound : -1.0f, ign, pfirst + 1, best_key, best_leaf, best_surf) | better;
+                for (int i = 2; i < pcnt; ++i) {                // leaves of three and four triangles (FS_BVH_LEAF > 2 only)
+                    const Tri48 x = sc.tris[pfirst + i];
+                    better = coop_tri<IGN>(x.a, x.b, x.c, r, bound, ign, pfirst + i, best_key, best_leaf, best_surf) | better;
+                }
+                if (COUNT) T.nt += (uint32_t)pcnt;
+                if (better) lds_min64(keyw + 4 * g, best_key);  // ds_min_u64: the group's closest hit so far
+                pcnt = 0;
             }
-            if (COUNT) T.nt += (uint32_t)pcnt;
-            if (better) lds_min64(keyw + 4 * g, best_key);  // ds_min_u64: the group's closest hit so far
-            pcnt = 0;
-        }
+        };
+        test_pending();
         // ---- this lane's child box: fp16 planes, entry / exit distances as one fma per plane
 #ifdef FS_WAVE_TIMELINE
         const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
         T.tri_i += (int)(dbg_t2 - dbg_t1);
 #endif
         coop_wait_all(N, X);
+#ifdef FS_WAVE_TIMELINE_FINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #ifdef FS_WAVE_TIMELINE
         T.tri_n += (int)(__builtin_amdgcn_s_memtime() - dbg_t2);
+#endif
+#ifdef FS_WAVE_TIMELINE_FINE
+        const unsigned long long fine_box = __builtin_amdgcn_s_memtime();
 #endif
         const v4u rc = in_lds ? L : N;
         const uint32_t w0 = rc.x, w1 = rc.y, w2 = rc.z;   // (scalars first: __builtin_bit_cast of a vector ELEMENT reads the vector's first word for each of them)
@@ -1747,7 +1764,17 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
         }
         const unsigned long long m_leaf = __ballot(leaf);
         if (m_leaf != 0ull) coop_issue_tris(sc, leaf ? pfirst : 0, m_leaf, __ballot(leaf && pcnt > 1), X);
-        if (__ballot(n > 0 || pcnt > 0) == 0ull) break;
+#ifdef FS_WAVE_TIMELINE_FINE
+        T.sb += (int)(__builtin_amdgcn_s_memtime() - fine_box);
+#endif
+        if (__ballot(n > 0) == 0ull) {
+            // no group of the wave has a node left: only the triangles just requested are pending — they are tested here and now
+            // instead of in another turn of the loop (an empty pop, a record request nobody needs, 64 boxes of zeros: ~ 600 cycles
+            // of the ~ 9 000 of a query)
+            coop_wait_all(N, X);
+            test_pending();
+            break;
+        }
     }
     coop_wait_all(N, X);                                    // (nothing is in flight here; the compiler must know the registers are free)
 #ifdef FS_WAVE_TIMELINE
@@ -1775,7 +1802,7 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
             }
         }
         __builtin_amdgcn_wave_barrier();                    // (the next query's owner rewrites the mailbox)
-#ifdef FS_WAVE_TIMELINE
+#if defined(FS_WAVE_TIMELINE) && !defined(FS_WAVE_TIMELINE_FINE)
         T.sb = (int)(__builtin_amdgcn_s_memtime() - dbg_t3);
 #endif
         return found1;
@@ -1801,7 +1828,7 @@ __device__ __forceinline__ bool trav_coop(const DeviceScene& sc, const CoopView&
         }
     }
     __builtin_amdgcn_wave_barrier();                        // (the next query's owners rewrite the rays and mailboxes)
-#ifdef FS_WAVE_TIMELINE
+#if defined(FS_WAVE_TIMELINE) && !defined(FS_WAVE_TIMELINE_FINE)
     T.sb = (int)(__builtin_amdgcn_s_memtime() - dbg_t3);
 #endif
     return found;
