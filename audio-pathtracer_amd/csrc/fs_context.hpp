@@ -1,6 +1,7 @@
 // fs_context.hpp — the context behind the C ABI (include/frequensee.h) and the helpers its translation units share.
 // Internal: included by fs_capi_context.cpp (lifetime, helpers, stats), fs_capi_scene.cpp (geometry, commits, refit),
-// fs_capi_frame.cpp (sources, the traced frame and its pipeline, reconstruct, energy / IR access), fs_capi_comm.cpp
+// fs_capi_frame.cpp (sources, the traced frame and its pipeline, the reconstruct machinery), fs_capi_ir.cpp (reconstruct / tick /
+// IR / energy entry points), fs_capi_comm.cpp
 // (RCCL behind the ABI) and fs_capi_aux.cpp (legacy tracer, line trace, text interchange, reverb, material FD).
 //
 // Mirrors the roles of UAudioRayTracingSubsystem (context lifetime, geometry/source registries,
