@@ -16,19 +16,18 @@ namespace {
 __global__ __launch_bounds__(kBlock) void reconstruct_kernel(const float* __restrict__ energy, int B, int nb,
                                                              int num_samples, int spb, float* __restrict__ ir_bands,
                                                              float* __restrict__ ir_mono) {
-    extern __shared__ __attribute__((aligned(16))) float s_amp[];  // [nb] amplitude per bin of this row
-    reconstruct_body((int)blockIdx.y, (int)blockIdx.x, energy, B, nb, num_samples, spb, ir_bands, ir_mono, s_amp);
+    extern __shared__ __attribute__((aligned(16))) float s_amp[];  // reconstruct_body_fast's layout
+    reconstruct_body_fast((int)blockIdx.y, (int)blockIdx.x, energy, B, nb, num_samples, spb, ir_bands, ir_mono, s_amp, nullptr);
 }
 
 // many sources' reconstructs as one launch: block -> (item, row, block of chunks); the table lives in pinned host memory
 __global__ __launch_bounds__(kBlock) void reconstruct_batch_kernel(const ReconItem* __restrict__ table, int B, int nb, int num_samples,
                                                                    uint32_t cb) {
-    extern __shared__ __attribute__((aligned(16))) float s_rb[];  // [nb] amplitudes | [kBlock][kChunk + 1] staging of the host copy
+    extern __shared__ __attribute__((aligned(16))) float s_rb[];  // reconstruct_body_fast's layout
     const uint32_t per_item = (uint32_t)(B + 1) * cb;
     const uint32_t item = blockIdx.x / per_item, in_item = blockIdx.x - item * per_item;
     const ReconItem it = table[item];
-    reconstruct_body((int)(in_item / cb), (int)(in_item % cb), it.energy, B, nb, num_samples, it.spb, it.ir_bands, it.ir_mono, s_rb, it.host,
-                     s_rb + nb);
+    reconstruct_body_fast((int)(in_item / cb), (int)(in_item % cb), it.energy, B, nb, num_samples, it.spb, it.ir_bands, it.ir_mono, s_rb, it.host);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -377,14 +376,15 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
     (void)sample_rate;
     int chunks = (num_samples + kChunk - 1) / kChunk;
     dim3 grid((chunks + kBlock - 1) / kBlock, B + 1);
-    hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(kBlock), sizeof(float) * (size_t)num_bins, s, energy, B,
-                       num_bins, num_samples, spb, ir_bands, ir_mono);
+    const size_t lds = sizeof(float) * ((size_t)num_bins + (size_t)kBlock * kChunk + kWarm + (size_t)kBlock * (kChunk + 1));
+    allow_lds(reconstruct_kernel, lds);
+    hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(kBlock), lds, s, energy, B, num_bins, num_samples, spb, ir_bands, ir_mono);
 }
 
 void launch_reconstruct_batch(const ReconItem* table, int count, int B, int num_bins, int num_samples, hipStream_t s) {
     if (count <= 0) return;
     const uint32_t chunks = (uint32_t)((num_samples + kChunk - 1) / kChunk), cb = (chunks + kBlock - 1) / kBlock;
-    const size_t lds = sizeof(float) * ((size_t)num_bins + (size_t)kBlock * (kChunk + 1));
+    const size_t lds = sizeof(float) * ((size_t)num_bins + (size_t)kBlock * kChunk + kWarm + (size_t)kBlock * (kChunk + 1));
     allow_lds(reconstruct_batch_kernel, lds);
     hipLaunchKernelGGL(reconstruct_batch_kernel, dim3((uint32_t)count * (uint32_t)(B + 1) * cb), dim3(kBlock), lds, s, table, B, num_bins,
                        num_samples, cb);

@@ -2270,7 +2270,8 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
     const int chunk = chunk_block * kBlock + threadIdx.x;
     const int s0 = chunk * kChunk;
     const bool to_host = host_out != nullptr && row == B;   // (uniform for the workgroup)
-    if (s0 >= num_samples && !to_host) return;
+    const bool staged = s_stage != nullptr;                 // (uniform) the block's samples leave through LDS: 16-byte stores of consecutive lanes
+    if (s0 >= num_samples && !staged) return;
     float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
     const int s1 = min(s0 + kChunk, num_samples);        // (a thread beyond the end: an empty range, it only joins the barrier below)
     const int i0 = s0 < num_samples ? max(s0 - kWarm, 0) : s1;
@@ -2296,8 +2297,10 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
             y = a + b;                                              // FSAC.cpp:374
         }
         if (i >= s0) {
-            out[i] = y;
-            if (to_host) s_stage[threadIdx.x * (kChunk + 1) + (i - s0)] = y;   // (+ 1: conflict-free rows)
+            // (a thread's own 16 samples lie 64 bytes from its neighbour's: stored one by one, every store instruction of a wave
+            // touches 64 lines — 20 of the 26 us of a one-source reconstruct, the same again for the host copy)
+            if (staged) s_stage[threadIdx.x * (kChunk + 1) + (i - s0)] = y;   // (+ 1: conflict-free rows)
+            else out[i] = y;
         }
         if (++bs == spb) {
             bs = 0;
@@ -2306,7 +2309,7 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
             cur = bin < nb ? s_amp[bin] : 0.0f;
         }
     }
-    if (to_host) {   // the block's kBlock * kChunk consecutive samples, 16 bytes per lane
+    if (staged) {   // the block's kBlock * kChunk consecutive samples, 16 bytes per lane: to the device array, and the channel row to the host slot
         __syncthreads();
         const int base = chunk_block * kBlock * kChunk;
         for (int v = threadIdx.x; v < kBlock * kChunk / 4; v += kBlock) {
@@ -2315,10 +2318,127 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
                 float4 o;   // (sample s of the block lives in row s / kChunk of kChunk + 1 words)
                 o.x = s_stage[s + s / kChunk]; o.y = s_stage[s + 1 + (s + 1) / kChunk];
                 o.z = s_stage[s + 2 + (s + 2) / kChunk]; o.w = s_stage[s + 3 + (s + 3) / kChunk];
-                *reinterpret_cast<float4*>(host_out + base + s) = o;
+                *reinterpret_cast<float4*>(out + base + s) = o;
+                if (to_host) *reinterpret_cast<float4*>(host_out + base + s) = o;
             } else {
-                for (int e = 0; e < 4; ++e) if (base + s + e < num_samples) host_out[base + s + e] = s_stage[s + e + (s + e) / kChunk];
+                for (int e = 0; e < 4; ++e)
+                    if (base + s + e < num_samples) {
+                        const float y1 = s_stage[s + e + (s + e) / kChunk];
+                        out[base + s + e] = y1;
+                        if (to_host) host_out[base + s + e] = y1;
+                    }
             }
+        }
+    }
+}
+
+// The same reconstruct for the kernels that only reconstruct (reconstruct_kernel, reconstruct_batch_kernel), in two phases.  In
+// reconstruct_body a thread's 16 samples cost it a chain of 16 + kWarm interpolated samples — a division, four branches and
+// their bookkeeping each, ~ 60 instructions a sample on a wave that is alone on its SIMD: 20 of the 26 us of a one-source
+// reconstruct (the stores, scattered or not, to the device or to the host, were 2 of them: profiles/r04 notes in DESIGN.md).
+// Here every interpolated sample of the block (and of the kWarm before it) is computed ONCE, by the thread that owns it, into
+// LDS; the filter chain then reads them: three arithmetic instructions a sample.  The same operations on the same operands in
+// the same order as reconstruct_body: the same bits.
+// LDS: s_amp [nb] | s_x [kBlock * kChunk + kWarm] | s_stage [kBlock][kChunk + 1].
+__device__ __forceinline__ void reconstruct_body_fast(const int row, const int chunk_block, const float* __restrict__ energy, int B, int nb,
+                                                      int num_samples, int spb, float* __restrict__ ir_bands, float* __restrict__ ir_mono,
+                                                      float* s_amp, float* host_out) {
+    float* s_x = s_amp + nb;
+    float* s_stage = s_x + kBlock * kChunk + kWarm;
+    const float Pi4 = sqrtf(4.0f * kPi);                           // FSAC.cpp:323
+    for (int i = threadIdx.x; i < nb; i += kBlock) {
+        float e;
+        if (row < B) e = energy[row * nb + i];
+        else {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += energy[b * nb + i];
+            e = s / (float)B;
+        }
+        float a = 0.0f;
+        if (fabsf(e) >= 1e-6f) a = e / sqrtf(e * Pi4);             // FSAC.cpp:343-345
+        s_amp[i] = a;
+    }
+    __syncthreads();
+    const bool to_host = host_out != nullptr && row == B;   // (uniform for the workgroup)
+    float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
+    const int base = chunk_block * kBlock * kChunk;          // the block's first sample
+    const float fspb = (float)spb;
+    // ---- phase 1: the interpolated samples x[base - kWarm .. base + kBlock * kChunk) -> s_x[0 ..): thread t its own kChunk, and the
+    // first kWarm threads one sample each of the run-in (samples before 0 do not exist: never read)
+    auto interp = [&](int i) {
+        const int bin = i / spb, bs = i - bin * spb;
+        float x = 0.0f;
+        if (bin < nb) {
+            const float cur = s_amp[bin];
+            const float prev = bin == 0 ? cur : s_amp[bin - 1];         // FSAC.cpp:347-355
+            const float wgt = (float)bs / fspb;                          // FSAC.cpp:359
+            const float a = (1.0f - wgt) * prev;
+            const float b = wgt * cur;
+            x = a + b;                                                   // FSAC.cpp:360
+        }
+        return x;
+    };
+    {
+        const int s0 = base + (int)threadIdx.x * kChunk;
+        int bin = s0 / spb, bs = s0 - bin * spb;                     // (incrementally within the thread's own samples: no division by spb per sample)
+        float cur = bin < nb ? s_amp[bin] : 0.0f;
+        float prev = bin == 0 ? cur : (bin - 1 < nb ? s_amp[bin - 1] : 0.0f);
+#pragma unroll 4
+        for (int e = 0; e < kChunk; ++e) {
+            float x = 0.0f;
+            if (bin < nb) {
+                const float wgt = (float)bs / fspb;
+                const float a = (1.0f - wgt) * prev;
+                const float b = wgt * cur;
+                x = a + b;
+            }
+            s_x[kWarm + (int)threadIdx.x * kChunk + e] = x;
+            if (++bs == spb) { bs = 0; ++bin; prev = cur; cur = bin < nb ? s_amp[bin] : 0.0f; }
+        }
+        if ((int)threadIdx.x < kWarm) {
+            const int i = base - kWarm + (int)threadIdx.x;
+            s_x[threadIdx.x] = i >= 0 ? interp(i) : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: the one-pole filter over this thread's kChunk samples behind a run-in of kWarm (0.75^96 ~ 1e-12)
+    {
+        const int s0 = base + (int)threadIdx.x * kChunk;
+        const int i0 = max(s0 - kWarm, 0);                           // global index of the first sample of the chain
+        const float* xs = s_x + (i0 - (base - kWarm));               // x[i0] in LDS
+        float y = 0.0f;
+        const int run = s0 - i0;                                     // kWarm, less at the very beginning of the IR
+        float* my = s_stage + threadIdx.x * (kChunk + 1);            // (+ 1: conflict-free rows)
+        int e = 0;
+        if (i0 == 0) {                                               // Filtered[0] = IR[0] FSAC.cpp:371 (the first threads of the first block)
+            y = xs[0];
+            if (run == 0) my[0] = y;
+            e = 1;
+        }
+#pragma unroll 8
+        for (; e < run; ++e) { const float a = 0.25f * xs[e]; const float b = (1.0f - 0.25f) * y; y = a + b; }   // FSAC.cpp:374
+#pragma unroll 4
+        for (; e < run + kChunk; ++e) {
+            const float a = 0.25f * xs[e]; const float b = (1.0f - 0.25f) * y; y = a + b;
+            my[e - run] = y;
+        }
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < kBlock * kChunk / 4; v += kBlock) {   // 16 bytes per lane: the device array, and the channel row to the host slot
+        const int sidx = 4 * v;
+        if (base + sidx + 3 < num_samples) {
+            float4 o;
+            o.x = s_stage[sidx + sidx / kChunk]; o.y = s_stage[sidx + 1 + (sidx + 1) / kChunk];
+            o.z = s_stage[sidx + 2 + (sidx + 2) / kChunk]; o.w = s_stage[sidx + 3 + (sidx + 3) / kChunk];
+            *reinterpret_cast<float4*>(out + base + sidx) = o;
+            if (to_host) *reinterpret_cast<float4*>(host_out + base + sidx) = o;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (base + sidx + e < num_samples) {
+                    const float y1 = s_stage[sidx + e + (sidx + e) / kChunk];
+                    out[base + sidx + e] = y1;
+                    if (to_host) host_out[base + sidx + e] = y1;
+                }
         }
     }
 }
