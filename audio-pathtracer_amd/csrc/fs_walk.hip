@@ -219,6 +219,8 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
         const int W = plain && waves > 4u * (uint32_t)std::max(wl.num_cus, 1) ? kCoopBigWaves : kBlock / 64;
         const uint32_t blocks = (waves + (uint32_t)W - 1) / (uint32_t)W;
         cv.lds_nodes = coop_resident_nodes(cv, W, blocks, wl.num_cus);
+        static const int resident_max = std::getenv("FS_COOP_RESIDENT_MAX") ? std::atoi(std::getenv("FS_COOP_RESIDENT_MAX")) : -1;   // (experiments: fewer staged records)
+        if (resident_max >= 0) cv.lds_nodes = std::min(cv.lds_nodes, resident_max);
         const size_t lds = coop_lds_bytes(W, cv), lds_ext = lds;
         static const bool dbg = std::getenv("FS_DEBUG_SCENE_INFO") != nullptr;   // (read once)
         if (dbg) std::fprintf(stderr, "[frequensee] cooperative walk: %u lanes, %d per wave, %u workgroups of %d waves, %d-wide nodes, %d of %d resident in LDS (%zu bytes)\n",
