@@ -357,6 +357,13 @@ class Context:
     def reset_stats(self):
         self.check(self.lib.fs_reset_stats(self.h))
 
+    def pipeline_counters(self):
+        """fs_get_pipeline_counters: the producer side's host counters since the context was created"""
+        c = _capi.PipelineCounters()
+        c.struct_size = C.sizeof(_capi.PipelineCounters)
+        self.check(self.lib.fs_get_pipeline_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
 
 class FrequenSeeAudioComponent:
     """UFrequenSeeAudioComponent's energy/IR surface (FSAC.h:69-91, 112-113, 133-143)."""

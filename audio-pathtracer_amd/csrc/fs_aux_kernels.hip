@@ -22,12 +22,13 @@ __global__ __launch_bounds__(kBlock) void reconstruct_kernel(const float* __rest
 
 // many sources' reconstructs as one launch: block -> (item, row, block of chunks); the table lives in pinned host memory
 __global__ __launch_bounds__(kBlock) void reconstruct_batch_kernel(const ReconItem* __restrict__ table, int B, int nb, int num_samples,
-                                                                   uint32_t cb) {
+                                                                   uint32_t cb, PublishWord pub) {
     extern __shared__ __attribute__((aligned(16))) float s_rb[];  // reconstruct_body_fast's layout
     const uint32_t per_item = (uint32_t)(B + 1) * cb;
     const uint32_t item = blockIdx.x / per_item, in_item = blockIdx.x - item * per_item;
     const ReconItem it = table[item];
     reconstruct_body_fast((int)(in_item / cb), (int)(in_item % cb), it.energy, B, nb, num_samples, it.spb, it.ir_bands, it.ir_mono, s_rb, it.host);
+    publish_arrive(pub.tickets, gridDim.x, pub.host_word, pub.id);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -381,13 +382,13 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
     hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(kBlock), lds, s, energy, B, num_bins, num_samples, spb, ir_bands, ir_mono);
 }
 
-void launch_reconstruct_batch(const ReconItem* table, int count, int B, int num_bins, int num_samples, hipStream_t s) {
+void launch_reconstruct_batch(const ReconItem* table, int count, int B, int num_bins, int num_samples, hipStream_t s, const PublishWord& pub) {
     if (count <= 0) return;
     const uint32_t chunks = (uint32_t)((num_samples + kChunk - 1) / kChunk), cb = (chunks + kBlock - 1) / kBlock;
     const size_t lds = sizeof(float) * ((size_t)num_bins + (size_t)kBlock * kChunk + kWarm + (size_t)kBlock * (kChunk + 1));
     allow_lds(reconstruct_batch_kernel, lds);
     hipLaunchKernelGGL(reconstruct_batch_kernel, dim3((uint32_t)count * (uint32_t)(B + 1) * cb), dim3(kBlock), lds, s, table, B, num_bins,
-                       num_samples, cb);
+                       num_samples, cb, pub);
 }
 
 void launch_trace_rays(const DeviceScene& sc_in, const float* o, const float* d, const float* tmax, int N, int any_hit,

@@ -204,6 +204,10 @@ int fs_reverb_init(fs_context* ctx, fs_source h, int32_t frame_size) {
     if (frame_size < 1 || frame_size > 16384 || ctx->num_samples - 1 > kReverbRing)
         return ctx->fail(FS_ERR_INVALID_ARGUMENT, "bad reverb frame size / IR longer than the history ring");
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    // Reconstructs on the compute stream record an event for the callbacks only for a source that has a reverb: the ones
+    // already in flight finish before this source gets one.
+    FS_FLUSH(ctx);
+    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->rev_stream));
     if (s->d_ring) { (void)hipFree(s->d_ring); (void)hipFree(s->d_rev_in); (void)hipFree(s->d_rev_cur); (void)hipFree(s->d_rev_out); }
     s->d_ring = s->d_rev_in = s->d_rev_cur = s->d_rev_out = nullptr;

@@ -66,6 +66,7 @@ int reduce_energy(fs_context* ctx, Source* s) {
     } else
         FS_NCCL(ctx, a->AllReduce(s->energy(), s->energy(), words, ncclFloat32, ncclSum, ctx->comm, ctx->copy_stream));
     FS_HIP(ctx, hipEventRecord(s->ev_red[s->cur], ctx->copy_stream));
+    ctx->dbg.tail_ops += 2;   // the collective and its event
     s->red_recorded[s->cur] = true;
     s->reduced = true;
     return FS_OK;
@@ -300,6 +301,7 @@ int fs_gather_energy_async(fs_context* ctx, fs_source h, void** dptr, size_t* by
     FS_NCCL(ctx, a->AllGather(s->energy(), ctx->d_gather, words, ncclFloat32, ctx->peers, ctx->copy_stream));
     // the buffer is being read on the tail stream: the frame after next must not deposit into it before that
     FS_HIP(ctx, hipEventRecord(s->ev_red[s->cur], ctx->copy_stream));
+    ctx->dbg.tail_ops += 2;   // the collective and its event
     s->red_recorded[s->cur] = true;
     if (dptr) *dptr = ctx->d_gather;
     if (bytes) *bytes = sizeof(float) * need;

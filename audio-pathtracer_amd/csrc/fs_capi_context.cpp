@@ -44,6 +44,7 @@ bool tail_batch_done(fs_context* ctx, uint64_t id) {
 }
 hipError_t stream_waits_for_rec(fs_context* ctx, hipStream_t st, Source* s, int buf) {
     if (!s->rec_recorded[buf]) return hipSuccess;
+    if (s->rec_on_compute[buf] && st == ctx->stream) return hipSuccess;   // the same stream, earlier
     if (s->rec_batch[buf]) {
         if (tail_batch_done(ctx, s->rec_batch[buf])) return hipSuccess;
         return hipStreamWaitEvent(st, tail_batch_event(ctx, s->rec_batch[buf]), 0);
@@ -68,11 +69,45 @@ hipError_t wait_event_polling(hipEvent_t ev) {
 #endif
     }
 }
-hipError_t sync_publish(fs_context* ctx, Source* s, int slot) {
-    const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);
-    if (!ctx->debug_stalls) return wait_event_polling(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+// ---- publishes of the compute stream: the launch writes its id into a pinned host word (Source::pub_word, publish_arrive) ----
+bool pub_word_done(const fs_context* ctx, uint64_t id) {
+    return ctx->h_pub_word != nullptr && __atomic_load_n(ctx->h_pub_word, __ATOMIC_ACQUIRE) >= id;
+}
+PublishWord next_pub_word(fs_context* ctx) {
+    PublishWord w;
+    w.tickets = ctx->d_pub_tickets; w.host_word = ctx->h_pub_word; w.id = ctx->pub_issued + 1;
+    return w;
+}
+// The producer's wait for such a publish: the launch is already in the stream, the word arrives by itself — a few hundred
+// microseconds of polling a cached host line, no runtime call.  A word that does not arrive within 50 ms while the stream still
+// has work is waited for with the stream; one that is still missing when the stream is idle belongs to a launch that never ran.
+hipError_t wait_pub_word(fs_context* ctx, uint64_t id) {
     const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t e = wait_event_polling(b ? tail_batch_event(ctx, b) : s->ev[slot]);
+    for (unsigned spins = 0; !pub_word_done(ctx, id); ++spins) {
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            const hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return e;
+            return pub_word_done(ctx, id) ? hipSuccess : hipErrorLaunchFailure;
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return hipSuccess;
+}
+bool slot_published(fs_context* ctx, Source* s, int slot) {
+    const uint64_t w = s->pub_word[slot].load(std::memory_order_acquire);
+    if (w) return pub_word_done(ctx, w);
+    const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);
+    if (b) return tail_batch_done(ctx, b);
+    if (hipEventQuery(s->ev[slot]) != hipSuccess) { (void)hipGetLastError(); return false; }   // (hipErrorNotReady is not an error)
+    return true;
+}
+hipError_t sync_publish(fs_context* ctx, Source* s, int slot) {
+    const uint64_t w = s->pub_word[slot].load(std::memory_order_acquire);
+    const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = w ? wait_pub_word(ctx, w) : wait_event_polling(b ? tail_batch_event(ctx, b) : s->ev[slot]);
     ctx->dbg.sync_publish++;
     ctx->dbg.sync_publish_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     return e;
@@ -91,6 +126,7 @@ hipError_t handoff_energy(fs_context* ctx, Source* s) {
     hipError_t e = hipEventRecord(s->ev_dep, ctx->stream);
     if (e != hipSuccess) return e;
     e = hipStreamWaitEvent(ctx->copy_stream, s->ev_dep, 0);
+    ctx->dbg.tail_ops++;
     if (e == hipSuccess) s->tail_ordered = true;   // until the compute stream writes the buffer again
     return e;
 }
@@ -107,10 +143,7 @@ void free_source(fs_context* ctx, Source* s) {
         if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
         for (int i = 0; i < kEnergyBufs; ++i) if (s->ev_red[i]) (void)hipEventDestroy(s->ev_red[i]);
         if (s->ev_rev) (void)hipEventDestroy(s->ev_rev);
-        if (s->d_ir_bands) (void)hipFree(s->d_ir_bands);
-        if (s->d_ir_mono) (void)hipFree(s->d_ir_mono);
-        if (s->d_ir_spare_bands) (void)hipFree(s->d_ir_spare_bands);
-        if (s->d_ir_spare_mono) (void)hipFree(s->d_ir_spare_mono);
+        if (s->d_ir_bands) (void)hipFree(s->d_ir_bands);   // (d_ir_mono is its last row)
         for (int i = 0; i < kIrRing; ++i) {
             if (s->h_ir[i]) (void)hipHostFree(s->h_ir[i]);
             if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
@@ -234,9 +267,7 @@ void poll_published(fs_context* ctx, Source* s) {
         uint64_t next = f + 1;
         int slot = (int)(next % kIrRing);
         if (s->seq_of[slot].load(std::memory_order_acquire) != next) break;
-        const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);   // a batched publish: its batch's event
-        if (b) { if (!tail_batch_done(ctx, b)) break; }
-        else if (hipEventQuery(s->ev[slot]) != hipSuccess) { (void)hipGetLastError(); break; }   // (hipErrorNotReady is not an error)
+        if (!slot_published(ctx, s, slot)) break;   // the host word, the batch's event or the slot's own (Source::pub_word)
         if (s->seq_of[slot].load(std::memory_order_acquire) != next) break;   // recycled meanwhile: the answer was about a later publish
         f = next;
     }
@@ -565,6 +596,10 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     for (int k = 0; k < fs_context::kTailBatches && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ctx->tail_batch_ev[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_comm_stage, 2048);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_recon_tab, sizeof(ReconItem) * fs_context::kReconTabSlots * fs_context::kReconTabItems, hipHostMallocDefault);
+    // the publish word: coherent (fine-grained) host memory the device writes with system scope while its kernel is still running
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_pub_word, 64, hipHostMallocCoherent);
+    if (e == hipSuccess) { *ctx->h_pub_word = 0ull; e = hipMalloc((void**)&ctx->d_pub_tickets, 64); }
+    if (e == hipSuccess) e = hipMemset(ctx->d_pub_tickets, 0, 64);
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("batched reconstructs: ") + hipGetErrorString(e));
     ctx->device_ok = true;
     // A context overlaps the tail of a frame with the next frame's tracing on two HIP streams.  The runtime multiplexes
@@ -618,14 +653,11 @@ int fs_context_destroy(fs_context* ctx) {
         if (ctx->d_build) (void)hipFree(ctx->d_build);
         if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
         for (hipEvent_t e : ctx->ev_batch) if (e) (void)hipEventDestroy(e);
-        for (int k = 0; k < fs_context::kIrTmp; ++k) {
-            if (ctx->d_ir_tmp[k]) (void)hipFree(ctx->d_ir_tmp[k]);
-            if (ctx->ev_ir_tmp[k]) (void)hipEventDestroy(ctx->ev_ir_tmp[k]);
-        }
-        if (ctx->ev_recon_launch) (void)hipEventDestroy(ctx->ev_recon_launch);
     }
     for (hipEvent_t ev : ctx->tail_batch_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_recon_tab) (void)hipHostFree(ctx->h_recon_tab);
+    if (ctx->h_pub_word) (void)hipHostFree(ctx->h_pub_word);
+    if (ctx->d_pub_tickets) (void)hipFree(ctx->d_pub_tickets);
     if (ctx->d_comm_stage) (void)hipFree(ctx->d_comm_stage);
     join_refine_threads(ctx);   // no background build may outlive the context (the library may be unloaded next)
     for (Source* s : ctx->sources) free_source(ctx, s);
@@ -662,6 +694,18 @@ int fs_set_profiling_interval(fs_context* ctx, int32_t frames) {
     if (!ctx || frames < 1) return FS_ERR_INVALID_ARGUMENT;
     ctx->profile_interval = frames;
     ctx->profile_tick = 0;
+    return FS_OK;
+}
+
+int fs_get_pipeline_counters(fs_context* ctx, fs_pipeline_counters* out) {
+    if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
+    if (out->struct_size != sizeof(fs_pipeline_counters)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_pipeline_counters.struct_size mismatch");
+    out->reserved = 0;
+    out->fused_launches = ctx->dbg.launches; out->flushes = ctx->dbg.flushes; out->flushed_frames = ctx->dbg.flushed_frames;
+    out->host_waits = ctx->dbg.sync_publish; out->host_wait_us = ctx->dbg.sync_publish_us;
+    out->stream_waits_enqueued = ctx->dbg.waits_enqueued; out->stream_waits_skipped = ctx->dbg.waits_skipped;
+    out->tail_stream_ops = ctx->dbg.tail_ops; out->owed_on_tail = ctx->dbg.owed_on_tail;
+    out->publishes_by_word = ctx->dbg.pub_word; out->publishes_by_event = ctx->dbg.pub_event;
     return FS_OK;
 }
 

@@ -100,11 +100,17 @@ static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bo
 
 // ---- reconstructs inside the fused launch ------------------------------------------------------------------------
 // The owed reconstructs become parts of the launch that is being assembled; their sources' IR mutexes are held from here
-// until the publishes are enqueued (a reverb callback must not slip a read of d_ir_mono between the two).
+// until the publishes are noted (a reverb callback must not slip a read of d_ir_mono between the two).
+// The launch publishes by itself (publish_arrive, fs_device.hpp): its reconstruct workgroups write the channel views into the
+// sources' pinned ring slots and the last of them stores the launch's id into the context's host word — no event, no copy
+// command, nothing on the tail stream (ReconstructImpulseResponse leaves the IR in the component's own buffer,
+// FSAC.cpp:377-378; GetImpulseResponse reads that buffer, FSAC.h:113).
 struct OwedLaunch {
     std::vector<fs_context::ReconOwed> owed;
-    std::vector<int> tmp;                                  // index into ctx->d_ir_tmp, or -1: the source's own d_ir_*
+    std::vector<uint64_t> seq;                             // publish number of each entry (ring slot = seq % kIrRing)
+    std::vector<char> newest;                              // the source's newest frame of the launch: its IR becomes the device-resident set
     std::vector<std::unique_lock<std::mutex>> locks;
+    PublishWord pub;
 };
 // never overwrite the front buffer of the source's IR ring: at most kIrRing - 1 publishes in flight (publish seq reuses the
 // slot of seq - kIrRing, so publish seq - kIrRing + 1 must have completed before seq is enqueued).  `more`: publishes about
@@ -122,9 +128,39 @@ static int ir_ring_backpressure(fs_context* ctx, Source* s, int more) {
     }
     return FS_OK;
 }
-// a publish of the source's current IR set has been enqueued on the tail stream as number `seq`
-static void note_publish(Source* s, uint64_t seq, int slot, uint64_t batch = 0) {
-    s->pub_batch[slot] = batch; s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq;
+// publish number `seq` of the source has been enqueued: through the compute stream's host word (word != 0), a tail-stream
+// batch's event (batch != 0) or the slot's own event.  (Readers look at enqueued, then seq_of, then the kind: written in reverse.)
+static void note_publish(fs_context* ctx, Source* s, uint64_t seq, int slot, uint64_t batch = 0, uint64_t word = 0) {
+    if (word) ctx->dbg.pub_word++; else ctx->dbg.pub_event++;
+    s->pub_word[slot] = word; s->pub_batch[slot] = batch; s->seq_of[slot] = seq; s->enqueued = seq;
+}
+// before the COMPUTE stream writes the source's device IR set: whoever reads or writes it on the tail stream goes first
+static hipError_t compute_waits_for_tail_ir(fs_context* ctx, Source* s) {
+    if (s->cur_pub_seq) {
+        const int slot = (int)(s->cur_pub_seq % kIrRing);
+        if (s->seq_of[slot] == s->cur_pub_seq && !s->pub_word[slot]) {   // (a reused slot: that publish completed long ago)
+            const uint64_t pb = s->pub_batch[slot];
+            hipError_t e = hipSuccess;
+            if (!pb) e = compute_waits_for(ctx, s->ev[slot]);
+            else if (!tail_batch_done(ctx, pb)) e = hipStreamWaitEvent(ctx->stream, tail_batch_event(ctx, pb), 0);
+            if (e != hipSuccess) return e;
+        }
+    }
+    if (s->rev_recorded) return compute_waits_for(ctx, s->ev_rev);   // a reverb callback may be reading d_ir_mono
+    return hipSuccess;
+}
+// a table slot of the batch kernel that its previous reader has certainly left
+static int acquire_recon_tab(fs_context* ctx, unsigned* slot_out) {
+    const unsigned slot_t = ctx->recon_tab_next++ % fs_context::kReconTabSlots;
+    if (ctx->recon_tab_batch[slot_t] && !tail_batch_done(ctx, ctx->recon_tab_batch[slot_t]))
+        FS_HIP(ctx, wait_event_polling(tail_batch_event(ctx, ctx->recon_tab_batch[slot_t])));
+    if (ctx->recon_tab_word[slot_t] && !pub_word_done(ctx, ctx->recon_tab_word[slot_t])) FS_HIP(ctx, wait_pub_word(ctx, ctx->recon_tab_word[slot_t]));
+    ctx->recon_tab_batch[slot_t] = 0; ctx->recon_tab_word[slot_t] = 0;
+    *slot_out = slot_t;
+    return FS_OK;
+}
+static int spb_of(const fs_context* ctx, const fs_params& p) {
+    return p.samples_per_bin > 0 ? p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);   // FSAC.cpp:324
 }
 
 static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
@@ -135,10 +171,9 @@ static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
     for (size_t k = take; k < ctx->recon_owed.size(); ++k) ctx->recon_owed[k].age++;
     if (take == 0) return FS_OK;
     // (the entries leave recon_owed only when everything that can fail here has succeeded: on an error they are still owed
-    // and the next flush reconstructs them on the tail stream)
+    // and the next flush reconstructs them)
     ol.owed.assign(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
     const int B = ctx->cfg.num_bands;
-    const size_t row = (size_t)ctx->num_samples;
     std::vector<Source*> distinct;
     for (const fs_context::ReconOwed& o : ol.owed)
         if (std::find(distinct.begin(), distinct.end(), o.s) == distinct.end()) distinct.push_back(o.s);
@@ -151,94 +186,61 @@ static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
         const int br = ir_ring_backpressure(ctx, s, more);
         if (br) { ol.owed.clear(); return br; }
     }
-    auto bail = [&](int rc) { ol.owed.clear(); ol.tmp.clear(); ol.locks.clear(); fp.num_recon = 0; return rc; };
+    auto bail = [&](int rc) { ol.owed.clear(); ol.seq.clear(); ol.newest.clear(); ol.locks.clear(); fp.num_recon = 0; return rc; };
 #define FS_OWED_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(ctx->hip_fail(e_, #call)); } while (0)
     for (Source* s : distinct) ol.locks.emplace_back(s->ir_mu);
     fp.num_recon = 0; fp.recon_B = B; fp.recon_nb = ctx->num_bins; fp.recon_samples = ctx->num_samples;
+    ol.pub = next_pub_word(ctx);
+    fp.pub = ol.pub;
     for (size_t i = 0; i < ol.owed.size(); ++i) {
         const fs_context::ReconOwed& o = ol.owed[i];
         Source* s = o.s;
         bool later = false;                                // a later frame of the same source in this launch?
         for (size_t k = i + 1; k < ol.owed.size(); ++k) later = later || ol.owed[k].s == s;
-        int t = -1;
-        float* bands = nullptr; float* mono = nullptr;
-        if (later) {   // its IR is superseded within the launch: produced in, and published from, a temporary buffer
-            t = (int)(ctx->ir_tmp_next++ % fs_context::kIrTmp);
-            if (!ctx->d_ir_tmp[t]) {
-                FS_OWED_HIP(hipMalloc((void**)&ctx->d_ir_tmp[t], sizeof(float) * (size_t)(B + 1) * row));
-                FS_OWED_HIP(hipEventCreateWithFlags(&ctx->ev_ir_tmp[t], hipEventDisableTiming));
-            }
-            if (ctx->ir_tmp_pending[t]) FS_OWED_HIP(compute_waits_for(ctx, ctx->ev_ir_tmp[t]));   // its last publish has read it
-            bands = ctx->d_ir_tmp[t]; mono = ctx->d_ir_tmp[t] + (size_t)B * row;
-        } else {
-            // The source's newest IR of the launch goes into its SPARE set (and the sets swap when the publish is enqueued):
-            // the publish of the previous frame — a D2H copy on the tail stream, enqueued a launch ago — may still be reading
-            // the current set when this launch's reconstruct workgroups start (small launches: microseconds after the
-            // previous launch ends).  What last read the spare set is two publishes back: its event has long completed.
-            if (!s->d_ir_spare_bands) {
-                FS_OWED_HIP(hipMalloc((void**)&s->d_ir_spare_bands, sizeof(float) * (size_t)B * row));
-                FS_OWED_HIP(hipMalloc((void**)&s->d_ir_spare_mono, sizeof(float) * row));
-            }
-            if (s->spare_pub_seq) {
-                const int slot = (int)(s->spare_pub_seq % kIrRing);
-                if (s->seq_of[slot] == s->spare_pub_seq) {   // (a reused slot: that publish completed long ago)
-                    const uint64_t pb = s->pub_batch[slot];
-                    if (!pb) FS_OWED_HIP(compute_waits_for(ctx, s->ev[slot]));
-                    else if (!tail_batch_done(ctx, pb)) FS_OWED_HIP(hipStreamWaitEvent(ctx->stream, tail_batch_event(ctx, pb), 0));
-                }
-            }
-            if (s->rev_recorded) FS_OWED_HIP(compute_waits_for(ctx, s->ev_rev));   // a reverb callback may be reading either set
-            bands = s->d_ir_spare_bands; mono = s->d_ir_spare_mono;
-        }
+        uint64_t seq = s->enqueued + 1;                    // (the ring's back-pressure was applied above, before the mutexes)
+        for (size_t k = 0; k < i; ++k) seq += ol.owed[k].s == s ? 1 : 0;
+        // An IR that is superseded within the launch only goes to its ring slot (the channel row); the source's newest IR of the
+        // launch also becomes the device-resident set (the reverb's, fs_copy_band_impulse_response's).
+        if (!later) FS_OWED_HIP(compute_waits_for_tail_ir(ctx, s));
         if (o.reduced && s->red_recorded[o.cur]) FS_OWED_HIP(compute_waits_for(ctx, s->ev_red[o.cur]));   // the sum over the ranks (done a launch ago)
-        ol.tmp.push_back(t);
+        ol.seq.push_back(seq); ol.newest.push_back(later ? 0 : 1);
+        fp.recon_spb[fp.num_recon] = spb_of(ctx, o.p);
         FrameParts::Recon& r = fp.recon[fp.num_recon++];
-        r.energy = s->d_energy[o.cur]; r.ir_bands = bands; r.ir_mono = mono;
-        r.spb = o.p.samples_per_bin > 0 ? o.p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);   // FSAC.cpp:324
+        r.energy = s->d_energy[o.cur]; r.ir = later ? nullptr : s->d_ir_bands; r.host = s->h_ir[(int)(seq % kIrRing)];
     }
 #undef FS_OWED_HIP
     ctx->recon_owed.erase(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
     return FS_OK;
 }
-// behind the launch: the reconstruct of buffer `cur` is done (energy buffer reuse, reverb), the tail stream waits for the
-// launch once and publishes every IR in frame order
+// behind the launch: note the publishes (the launch announces them itself); a source with a reverb also gets an event on the
+// compute stream for its callbacks to wait on
 static int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
     if (ol.owed.empty()) return FS_OK;
     const int B = ctx->cfg.num_bands;
-    const size_t row = (size_t)ctx->num_samples;
-    if (!launched_fused)   // no fused form for this launch: the same reconstructs as kernels of their own, on the compute stream
+    if (!launched_fused) {   // no fused form for this launch: the same reconstructs as a batch kernel of their own, on the compute stream
+        unsigned slot_t = 0;
+        { const int ar = acquire_recon_tab(ctx, &slot_t); if (ar) return ar; }
+        ReconItem* tab = ctx->h_recon_tab + (size_t)slot_t * fs_context::kReconTabItems;
         for (size_t i = 0; i < ol.owed.size(); ++i) {
             const fs_context::ReconOwed& o = ol.owed[i];
-            float* bands = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] : o.s->d_ir_spare_bands;
-            float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * row : o.s->d_ir_spare_mono;
-            const int spb = o.p.samples_per_bin > 0 ? o.p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);
-            launch_reconstruct(o.s->d_energy[o.cur], B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, bands, mono, ctx->stream);
+            tab[i].energy = o.s->d_energy[o.cur]; tab[i].ir_bands = ol.newest[i] ? o.s->d_ir_bands : nullptr;
+            tab[i].ir_mono = ol.newest[i] ? o.s->d_ir_mono : nullptr; tab[i].host = o.s->h_ir[(int)(ol.seq[i] % kIrRing)];
+            tab[i].spb = spb_of(ctx, o.p); tab[i].pad = 0;
         }
-    if (!ctx->ev_recon_launch) FS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_recon_launch, hipEventDisableTiming));
-    FS_HIP(ctx, hipEventRecord(ctx->ev_recon_launch, ctx->stream));
-    FS_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_recon_launch, 0));
+        launch_reconstruct_batch(tab, (int)ol.owed.size(), B, ctx->num_bins, ctx->num_samples, ctx->stream, ol.pub);
+        FS_HIP(ctx, hipGetLastError());
+        ctx->recon_tab_word[slot_t] = ol.pub.id;
+    }
+    ctx->pub_issued = ol.pub.id;
     for (size_t i = 0; i < ol.owed.size(); ++i) {
         const fs_context::ReconOwed& o = ol.owed[i];
         Source* s = o.s;
-        FS_HIP(ctx, hipEventRecord(s->ev_rec[o.cur], ctx->copy_stream));   // (behind the one wait above: every reconstruct of the launch is done)
-        s->rec_recorded[o.cur] = true; s->rec_batch[o.cur] = 0;
-        const uint64_t seq = s->enqueued + 1;   // (the ring's back-pressure was applied in owed_prepare, before the mutexes)
-        const int slot = (int)(seq % kIrRing);
-        if (ol.tmp[i] < 0) {   // the spare set holds the source's newest IR: it becomes the current one (ir_mu is held)
-            std::swap(s->d_ir_bands, s->d_ir_spare_bands);
-            std::swap(s->d_ir_mono, s->d_ir_spare_mono);
-            s->spare_pub_seq = s->cur_pub_seq;
-            s->last_rec = o.cur;
+        s->rec_recorded[o.cur] = true; s->rec_on_compute[o.cur] = true; s->rec_batch[o.cur] = 0;
+        if (ol.newest[i]) {   // (ir_mu is held)
+            s->last_rec = o.cur; s->cur_pub_seq = 0; s->dev_ir_word = ol.pub.id;
+            if (s->d_ring) FS_HIP(ctx, hipEventRecord(s->ev_rec[o.cur], ctx->stream));   // fs_reverb_process reads d_ir_mono behind this
         }
-        const float* mono = ol.tmp[i] >= 0 ? ctx->d_ir_tmp[ol.tmp[i]] + (size_t)B * row : s->d_ir_mono;
-        FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], mono, sizeof(float) * row, hipMemcpyDeviceToHost, ctx->copy_stream));
-        FS_HIP(ctx, hipEventRecord(s->ev[slot], ctx->copy_stream));
-        if (ol.tmp[i] < 0) note_publish(s, seq, slot);
-        else { s->pub_batch[slot] = 0; s->seq_of[slot] = seq; s->enqueued = seq; }
-        if (ol.tmp[i] >= 0) {
-            FS_HIP(ctx, hipEventRecord(ctx->ev_ir_tmp[ol.tmp[i]], ctx->copy_stream));
-            ctx->ir_tmp_pending[ol.tmp[i]] = true;
-        }
+        note_publish(ctx, s, ol.seq[i], (int)(ol.seq[i] % kIrRing), 0, ol.pub.id);
     }
     ol.locks.clear();
     return FS_OK;
@@ -365,6 +367,7 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     // already ordered: a second event pair per frame on the compute stream is a second bubble between its launches,
     // 2 % of a cfg3 frame: tools/rccl_tax.sh.)
     if (!s->tail_ordered || (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)) FS_HIP(ctx, handoff_energy(ctx, s));
+    else FS_HIP(ctx, tail_waits_for_compute_ir(ctx, s));   // (a fused reconstruct of an earlier frame may still be writing d_ir_*)
     hipStream_t tail = ctx->copy_stream;
     {
         std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
@@ -376,7 +379,7 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
                            s->d_ir_mono, tail);
         FS_HIP(ctx, hipGetLastError());
         FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], tail));
-        s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = 0;
+        s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = 0; s->rec_on_compute[s->cur] = false;
         s->last_rec = s->cur;
     }
     uint64_t seq = s->enqueued + 1;
@@ -384,7 +387,9 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
                                hipMemcpyDeviceToHost, tail));
     FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
-    note_publish(s, seq, slot);
+    note_publish(ctx, s, seq, slot);
+    s->cur_pub_seq = seq; s->dev_ir_word = 0;
+    ctx->dbg.tail_ops += 4;   // the reconstruct kernel, its event, the copy, the publish event
     if (timed) {
         FS_HIP(ctx, hipEventRecord(tf.e[4], tail));
         tf.has_recon = true;
@@ -394,6 +399,16 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
 }
 
 int ir_ring_backpressure_for(fs_context* ctx, Source* s) { return ir_ring_backpressure(ctx, s, 1); }
+
+// Before the TAIL stream writes the source's device IR set: the compute-stream launch that wrote it last (a fused reconstruct part,
+// a batch behind a tick) may still be running — the compute stream hands over (everything it has enqueued so far goes first).
+hipError_t tail_waits_for_compute_ir(fs_context* ctx, Source* s) {
+    if (!s->dev_ir_word || pub_word_done(ctx, s->dev_ir_word)) return hipSuccess;
+    hipError_t e = hipEventRecord(s->ev_dep, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, s->ev_dep, 0);
+    ctx->dbg.tail_ops++;
+    return e;
+}
 
 // ReconstructImpulseResponse + publish of MANY sources' current frames (the subsystem's loop over ActiveSources,
 // ARTS.cpp:100-126, every one ending in ReconstructImpulseResponse :192): one handoff, ONE kernel that also writes the
@@ -415,44 +430,34 @@ int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_
     const int B = ctx->cfg.num_bands;
     const int spb = p->samples_per_bin > 0 ? p->samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
     hipStream_t tail = on_compute ? ctx->stream : ctx->copy_stream;
-    if (on_compute) {
-        // the batch events stand for "this and every older batch": a batch on the compute stream must not finish before an older
-        // one on the tail stream — nor write d_ir_* under a publish the tail stream still copies from
-        const uint64_t newest = ctx->tail_batch_newest.load(std::memory_order_relaxed);
-        if (newest && !tail_batch_done(ctx, newest)) FS_HIP(ctx, hipStreamWaitEvent(tail, tail_batch_event(ctx, newest), 0));
-        for (int i = 0; i < count; ++i) {
-            Source* s = srcs[i];
-            if (!s->cur_pub_seq) continue;
-            const int slot = (int)(s->cur_pub_seq % kIrRing);
-            if (s->seq_of[slot] != s->cur_pub_seq || s->pub_batch[slot]) continue;   // (a batched publish: covered above)
-            FS_HIP(ctx, compute_waits_for(ctx, s->ev[slot]));
-        }
-    }
     for (int first = 0; first < count; first += fs_context::kReconTabItems) {
         const int n = std::min(count - first, (int)fs_context::kReconTabItems);
         Source* const* g = srcs + first;
         for (int i = 0; i < n; ++i) { const int br = ir_ring_backpressure(ctx, g[i], 1); if (br) return br; }   // (before the mutexes: may wait for the GPU)
         // the tail stream takes over behind everything the compute stream has enqueued for these frames: one event pair
         bool ordered = true;   // (on_compute: the compute stream is behind its own kernels)
-        for (int i = 0; i < n && !on_compute; ++i) ordered = ordered && g[i]->tail_ordered;
+        for (int i = 0; i < n && !on_compute; ++i)
+            ordered = ordered && g[i]->tail_ordered && (!g[i]->dev_ir_word || pub_word_done(ctx, g[i]->dev_ir_word));
         if (!ordered) {
             FS_HIP(ctx, handoff_energy(ctx, g[0]));
             for (int i = 0; i < n; ++i) g[i]->tail_ordered = true;
         }
-        // a table slot the kernel of eight batches ago has certainly left
-        const unsigned slot_t = ctx->recon_tab_next++ % fs_context::kReconTabSlots;
-        if (ctx->recon_tab_batch[slot_t] && !tail_batch_done(ctx, ctx->recon_tab_batch[slot_t]))
-            FS_HIP(ctx, wait_event_polling(tail_batch_event(ctx, ctx->recon_tab_batch[slot_t])));
+        unsigned slot_t = 0;
+        { const int ar = acquire_recon_tab(ctx, &slot_t); if (ar) return ar; }
         ReconItem* tab = ctx->h_recon_tab + (size_t)slot_t * fs_context::kReconTabItems;
         std::vector<Source*> order(g, g + n);
         std::sort(order.begin(), order.end());                 // one locking order for every thread
         std::vector<std::unique_lock<std::mutex>> locks;
         locks.reserve((size_t)n);
         for (Source* s : order) locks.emplace_back(s->ir_mu);  // against fs_reverb_process on the audio thread
-        const uint64_t batch = ctx->tail_batch_newest.load(std::memory_order_relaxed) + 1;
+        // on the tail stream: ONE event for the batch (tail_batch_ev; the ids are totally ordered because only the tail stream
+        // issues them); on the compute stream: the launch announces itself in the host word (publish_arrive)
+        const uint64_t batch = on_compute ? 0 : ctx->tail_batch_newest.load(std::memory_order_relaxed) + 1;
+        const PublishWord pub = on_compute ? next_pub_word(ctx) : PublishWord();
         for (int i = 0; i < n; ++i) {
             Source* s = g[i];
-            if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
+            if (on_compute) FS_HIP(ctx, compute_waits_for_tail_ir(ctx, s));   // nor write d_ir_* under a publish the tail stream still copies from
+            else if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
             // deterministic mode: the collective summed the fixed-point histogram; round it to fp32 once, now
             if (s->cur_fixed && !s->reduced) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
             const uint64_t seq = s->enqueued + 1;
@@ -460,17 +465,29 @@ int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_
             tab[i].energy = s->energy(); tab[i].ir_bands = s->d_ir_bands; tab[i].ir_mono = s->d_ir_mono; tab[i].host = s->h_ir[slot];
             tab[i].spb = spb; tab[i].pad = 0;
         }
-        launch_reconstruct_batch(tab, n, B, ctx->num_bins, ctx->num_samples, tail);
+        launch_reconstruct_batch(tab, n, B, ctx->num_bins, ctx->num_samples, tail, pub);
         FS_HIP(ctx, hipGetLastError());
-        FS_HIP(ctx, hipEventRecord(ctx->tail_batch_ev[batch % fs_context::kTailBatches], tail));
-        ctx->tail_batch_newest.store(batch, std::memory_order_release);
-        ctx->recon_tab_batch[slot_t] = batch;
+        if (on_compute) {
+            ctx->pub_issued = pub.id;
+            ctx->recon_tab_word[slot_t] = pub.id;
+        } else {
+            FS_HIP(ctx, hipEventRecord(ctx->tail_batch_ev[batch % fs_context::kTailBatches], tail));
+            ctx->dbg.tail_ops += 2;
+            ctx->tail_batch_newest.store(batch, std::memory_order_release);
+            ctx->recon_tab_batch[slot_t] = batch;
+        }
         for (int i = 0; i < n; ++i) {
             Source* s = g[i];
-            s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = batch;
+            s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = batch; s->rec_on_compute[s->cur] = on_compute;
             s->last_rec = s->cur;
             const uint64_t seq = s->enqueued + 1;
-            note_publish(s, seq, (int)(seq % kIrRing), batch);
+            note_publish(ctx, s, seq, (int)(seq % kIrRing), batch, pub.id);
+            if (on_compute) {
+                s->cur_pub_seq = 0; s->dev_ir_word = pub.id;
+                if (s->d_ring) FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], ctx->stream));   // fs_reverb_process reads d_ir_mono behind this
+            } else {
+                s->cur_pub_seq = seq; s->dev_ir_word = 0;
+            }
         }
     }
     return FS_OK;
@@ -1073,12 +1090,13 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         if ((e = hipMemsetAsync(s->d_energy[i], 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
         if ((e = hipEventCreateWithFlags(&s->ev_rec[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
-    if ((e = hipMalloc((void**)&s->d_ir_bands, ib * (size_t)ctx->cfg.num_bands)) != hipSuccess) return bail(e, "hipMalloc(ir_bands)");
-    if ((e = hipMalloc((void**)&s->d_ir_mono, ib)) != hipSuccess) return bail(e, "hipMalloc(ir_mono)");
-    if ((e = hipMemsetAsync(s->d_ir_bands, 0, ib * (size_t)ctx->cfg.num_bands, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
-    if ((e = hipMemsetAsync(s->d_ir_mono, 0, ib, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
+    // the device-resident IR set: [B + 1][samples] — the bands, then the channel view (the fused launch derives the one from the other)
+    if ((e = hipMalloc((void**)&s->d_ir_bands, ib * (size_t)(ctx->cfg.num_bands + 1))) != hipSuccess) return bail(e, "hipMalloc(ir_bands)");
+    s->d_ir_mono = s->d_ir_bands + (size_t)ctx->cfg.num_bands * (size_t)ctx->num_samples;
+    if ((e = hipMemsetAsync(s->d_ir_bands, 0, ib * (size_t)(ctx->cfg.num_bands + 1), ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
     for (int i = 0; i < kIrRing; ++i) {
-        if ((e = hipHostMalloc((void**)&s->h_ir[i], ib, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc");
+        // (coherent: reconstruct workgroups write the slot and the host reads it while their kernel is still running — publish_arrive)
+        if ((e = hipHostMalloc((void**)&s->h_ir[i], ib, hipHostMallocCoherent)) != hipSuccess) return bail(e, "hipHostMalloc");
         std::memset(s->h_ir[i], 0, ib);  // ImpulseBuffer[ch].Init(0, NumSamples) FSAC.cpp:24-28
         if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }

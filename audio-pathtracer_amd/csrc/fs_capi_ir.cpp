@@ -108,20 +108,22 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
     const size_t bytes = sizeof(float) * (size_t)n;
     {
         std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
+        FS_HIP(ctx, tail_waits_for_compute_ir(ctx, s));   // (a reconstruct on the compute stream may still be writing d_ir_*)
         if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));
         FS_HIP(ctx, hipMemcpyAsync(s->d_ir_mono, ir, bytes, hipMemcpyHostToDevice, tail));
         for (int b = 0; b < ctx->cfg.num_bands; ++b)
             FS_HIP(ctx, hipMemcpyAsync(s->d_ir_bands + (size_t)b * (size_t)n, s->d_ir_mono, bytes, hipMemcpyDeviceToDevice, tail));
         const int cur = s->last_rec >= 0 ? s->last_rec : s->cur;
         FS_HIP(ctx, hipEventRecord(s->ev_rec[cur], tail));   // the reverb waits on this before reading d_ir_mono
-        s->rec_recorded[cur] = true; s->rec_batch[cur] = 0;
+        s->rec_recorded[cur] = true; s->rec_batch[cur] = 0; s->rec_on_compute[cur] = false;
         s->last_rec = cur;
     }
     uint64_t seq = s->enqueued + 1;
     int slot = (int)(seq % kIrRing);
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, bytes, hipMemcpyDeviceToHost, tail));
     FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
-    s->pub_batch[slot] = 0; s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq;
+    ctx->dbg.tail_ops += 4 + (uint64_t)ctx->cfg.num_bands; ctx->dbg.pub_event++;
+    s->pub_word[slot] = 0; s->pub_batch[slot] = 0; s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq; s->dev_ir_word = 0;
     FS_HIP(ctx, hipStreamSynchronize(tail));   // `ir` is the caller's memory
     poll_published(ctx, s);
     return FS_OK;

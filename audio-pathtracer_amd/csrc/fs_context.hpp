@@ -89,18 +89,25 @@ struct Source {
     // alternating like the energy buffers; cur_fixed = the current frame deposited into d_fixed[cur]
     unsigned long long* d_fixed[kEnergyBufs] = {};
     bool cur_fixed = false;
-    float* d_ir_bands = nullptr;  // [B][samples]
-    float* d_ir_mono = nullptr;   // [samples] channel view (all channels identical, FSAC.cpp:331)
-    // The spare IR set: a reconstruct that rides in a fused launch (compute stream) writes here while the tail stream may still be
-    // publishing the current set; the two swap when that reconstruct's publish is enqueued (under ir_mu).  Allocated at first use.
-    float* d_ir_spare_bands = nullptr; float* d_ir_spare_mono = nullptr;
-    uint64_t cur_pub_seq = 0;          // newest publish that reads the current set (0: none)
-    uint64_t spare_pub_seq = 0;        // newest publish that read what is now the spare set: a writer of the spare set waits for it
+    float* d_ir_bands = nullptr;  // [B + 1][samples]: the bands, then ...
+    float* d_ir_mono = nullptr;   // ... (= d_ir_bands + B * samples) the channel view (all channels identical, FSAC.cpp:331)
+    // newest publish that reads or writes the device IR set from the TAIL stream (a copy command behind reconstruct_now, a batch
+    // kernel): a reconstruct on the compute stream waits for it before it writes the set.  0: none / a compute-stream publish.
+    uint64_t cur_pub_seq = 0;
+    // ... and the other way round: the newest COMPUTE-stream launch that writes the set (its id in fs_context::h_pub_word; 0: none) —
+    // a reconstruct on the tail stream lets the compute stream hand over first while that launch may still be running
+    uint64_t dev_ir_word = 0;
     float* h_ir[kIrRing] = {};  // pinned host copies of the channel view
     hipEvent_t ev[kIrRing] = {};
-    // Batched reconstructs (fs_reconstruct_impulse_response_batch_async) record ONE event for all their sources (fs_context::tail_batch_ev):
-    // rec_batch[i] / pub_batch[slot] != 0 name the batch whose event stands for ev_rec[i] / ev[slot]; 0: the source's own event counts.
+    // How ring slot `slot` is known to be published, in this order: pub_word[slot] != 0 — a launch on the COMPUTE stream whose
+    // reconstruct workgroups wrote the slot themselves and whose id appears in fs_context::h_pub_word (publish_arrive, fs_device.hpp:
+    // no event, nothing on the tail stream); pub_batch[slot] != 0 — a batched reconstruct on the TAIL stream, one event for all its
+    // sources (fs_context::tail_batch_ev); else the slot's own event ev[slot] behind a copy command on the tail stream.
+    // rec_batch[i] != 0 names the tail batch whose event stands for ev_rec[i]; rec_on_compute[i]: the reconstruct ran on the compute
+    // stream — nothing that stream does later needs to wait for it (ev_rec[i] is recorded only for a source with a reverb).
     uint64_t rec_batch[kEnergyBufs] = {};
+    bool rec_on_compute[kEnergyBufs] = {};
+    std::atomic<uint64_t> pub_word[kIrRing] = {};
     std::atomic<uint64_t> pub_batch[kIrRing] = {};
     std::atomic<uint64_t> seq_of[kIrRing] = {};   // (atomics: fs_get_impulse_response_sequence may look from another thread)
     std::atomic<uint64_t> enqueued{0};            // publishes enqueued so far
@@ -217,7 +224,8 @@ struct fs_context {
     std::atomic<uint64_t> tail_batch_newest{0}, tail_batch_done{0};
     static constexpr int kReconTabSlots = 8, kReconTabItems = 256;
     ReconItem* h_recon_tab = nullptr;                  // pinned host: [kReconTabSlots][kReconTabItems], read by the batch kernel in place
-    uint64_t recon_tab_batch[kReconTabSlots] = {};     // the batch that last read slot k
+    uint64_t recon_tab_batch[kReconTabSlots] = {};     // the tail-stream batch that last read slot k, or ...
+    uint64_t recon_tab_word[kReconTabSlots] = {};      // ... the compute-stream launch (publish word id) that did
     unsigned recon_tab_next = 0;
     ncclComm_t peers = nullptr;
     int peers_size = 0;
@@ -267,12 +275,11 @@ struct fs_context {
     std::vector<ReconOwed> recon_owed;
     bool fused_recon = true;                       // FS_FUSED_RECON=0: always the tail stream
     bool fused_recon_comm = true;                  // FS_FUSED_RECON_COMM=0: with a communicator, always the tail stream
-    static constexpr int kIrTmp = 2 * kMaxReconParts;
-    float* d_ir_tmp[kIrTmp] = {};                  // [(B + 1)][samples]: bands, then the channel view
-    hipEvent_t ev_ir_tmp[kIrTmp] = {};             // tail stream: the publish that read buffer k is done
-    bool ir_tmp_pending[kIrTmp] = {};
-    unsigned ir_tmp_next = 0;
-    hipEvent_t ev_recon_launch = nullptr;          // compute stream: the launch with the reconstruct parts is done      // oldest first
+    // Publishes of the compute stream (fused reconstruct parts, batches behind a tick or a flush): the launch writes the ring slots
+    // and then its id into *h_pub_word (pinned, coherent) — see Source::pub_word.  pub_issued = id of the newest such launch.
+    unsigned* d_pub_tickets = nullptr;             // device: the ticket cell of publish_arrive (re-armed by the launch that used it)
+    unsigned long long* h_pub_word = nullptr;
+    uint64_t pub_issued = 0;
     int state_sets = 3;              // sets of the per-frame arrays (subpath state, records, schedules): frames in flight + 1
     bool state_cont = false;         // the sets include continuation records (staged walks)
     std::vector<int> stage_bounds;   // staged depth = 0 walks: the steps at which a walk changes launch (FS_WALK_STAGES)
@@ -307,7 +314,8 @@ struct fs_context {
     // (count, microseconds), waits enqueued on the compute stream for another stream's event, owed reconstructs run on the tail stream
     bool flush_recon_on_compute = true;   // FS_FLUSH_RECON_ON_COMPUTE (fs_capi_frame.cpp: flush_reconstruct)
     bool debug_stalls = false;
-    struct { uint64_t flushes = 0, flushed_frames = 0, sync_publish = 0, sync_publish_us = 0, waits_enqueued = 0, waits_skipped = 0, owed_on_tail = 0, launches = 0; } dbg;
+    struct { uint64_t flushes = 0, flushed_frames = 0, sync_publish = 0, sync_publish_us = 0, waits_enqueued = 0, waits_skipped = 0, owed_on_tail = 0, launches = 0,
+             tail_ops = 0, pub_word = 0, pub_event = 0; } dbg;   // fs_get_pipeline_counters
     int debug_rebin = 0;           // FS_DEBUG_REBIN (experiment, tools/rebin_experiment.py): 1 = the later stages of a waited-for staged walk on dense waves walk their slots in the order of the walks' positions; 2 = the order is computed but not used (its cost alone); 3 = neither (staged walks under the counting instantiation)
     uint32_t* d_rebin = nullptr; unsigned* d_rebin_hist = nullptr; size_t rebin_cap = 0;
     int over_cap_forced = 0;       // FS_OVER_CAP, read at fs_context_create
@@ -396,6 +404,10 @@ bool tail_batch_done(fs_context* ctx, uint64_t id);                 // any threa
 hipEvent_t tail_batch_event(fs_context* ctx, uint64_t id);          // the event that covers batch `id`
 hipError_t stream_waits_for_rec(fs_context* ctx, hipStream_t st, Source* s, int buf);   // st waits for the reconstruct that last read energy buffer `buf` (and wrote d_ir_*)
 hipError_t wait_event_polling(hipEvent_t ev);   // short producer waits: poll, do not sleep (fs_capi_context.cpp)
+bool pub_word_done(const fs_context* ctx, uint64_t id);             // any thread: has compute-stream publish `id` reached the host word?
+hipError_t wait_pub_word(fs_context* ctx, uint64_t id);             // producer: poll the host word (falls back to a stream wait)
+PublishWord next_pub_word(fs_context* ctx);                         // the arguments of the next self-publishing launch (id = pub_issued + 1; commit with ++pub_issued)
+bool slot_published(fs_context* ctx, Source* s, int slot);          // any thread: the publish in ring slot `slot` has completed
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot);      // block until the publish in ring slot `slot` has completed
 int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals,
                  int sets, bool staged);
@@ -416,6 +428,7 @@ int check_overflow(fs_context* ctx);         // depth = 0: did a record miss bot
 int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
 int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p, bool on_compute);   // many sources: one launch, one event
 int ir_ring_backpressure_for(fs_context* ctx, Source* s);   // the IR ring's throttle before one more publish (may block; not under ir_mu)
+hipError_t tail_waits_for_compute_ir(fs_context* ctx, Source* s);   // before the tail stream writes the source's device IR set
 
 // ---- fs_capi_comm.cpp ---------------------------------------------------------------------------------------------
 struct RcclApi {

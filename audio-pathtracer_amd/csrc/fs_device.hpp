@@ -2247,13 +2247,34 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #endif
 constexpr int kChunk = FS_RECON_CHUNK;
 constexpr int kWarm = 96;
+// A publish without the host's help: the reconstruct workgroups of a launch write the channel views straight into the sources'
+// pinned host ring slots; every one of them, once its stores have been acknowledged (system-scope fence by every wave: a wave's
+// s_waitcnt only covers its own stores), takes a ticket, and the workgroup that takes the last one stores the launch's id into
+// the context's pinned host word with a system-scope release — fs_get_impulse_response* and the ring's back-pressure read that
+// word, no event, no copy command, no second stream (fs_capi_frame.cpp: owed_publish).  The ticket cell re-arms itself.
+__device__ __forceinline__ void publish_arrive(unsigned* __restrict__ tickets, unsigned total, unsigned long long* __restrict__ host_word,
+                                               unsigned long long id) {
+    if (tickets == nullptr) return;                       // (uniform: this launch is published through an event)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1u == total) {
+            __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next launch of the stream starts behind this one)
+            __hip_atomic_store(host_word, id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // host_out (optional, row B only): the block's samples also go to that pinned host buffer, staged in `s_stage`
 // (kBlock x (kChunk + 1) floats of LDS) and written with one 16-byte store per lane and instruction.
+// ir_bands == nullptr (a frame whose IR is superseded within its own launch): only the channel row is produced, for the host.
 __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_block, const float* __restrict__ energy, int B, int nb,
                                                  int num_samples, int spb, float* __restrict__ ir_bands,
                                                  float* __restrict__ ir_mono, float* s_amp, float* host_out = nullptr,
                                                  float* s_stage = nullptr) {
     const float Pi4 = sqrtf(4.0f * kPi);                           // FSAC.cpp:323
+    if (ir_bands == nullptr && (row < B || host_out == nullptr)) return;   // (uniform) nobody wants this row
     for (int i = threadIdx.x; i < nb; i += kBlock) {
         float e;
         if (row < B) e = energy[row * nb + i];
@@ -2272,7 +2293,7 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
     const bool to_host = host_out != nullptr && row == B;   // (uniform for the workgroup)
     const bool staged = s_stage != nullptr;                 // (uniform) the block's samples leave through LDS: 16-byte stores of consecutive lanes
     if (s0 >= num_samples && !staged) return;
-    float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
+    float* out = ir_bands == nullptr ? nullptr : (row < B ? ir_bands + (size_t)row * num_samples : ir_mono);   // (nullptr: staged, host only)
     const int s1 = min(s0 + kChunk, num_samples);        // (a thread beyond the end: an empty range, it only joins the barrier below)
     const int i0 = s0 < num_samples ? max(s0 - kWarm, 0) : s1;
     int bin = i0 / spb;
@@ -2300,7 +2321,7 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
             // (a thread's own 16 samples lie 64 bytes from its neighbour's: stored one by one, every store instruction of a wave
             // touches 64 lines — 20 of the 26 us of a one-source reconstruct, the same again for the host copy)
             if (staged) s_stage[threadIdx.x * (kChunk + 1) + (i - s0)] = y;   // (+ 1: conflict-free rows)
-            else out[i] = y;
+            else if (out) out[i] = y;
         }
         if (++bs == spb) {
             bs = 0;
@@ -2318,13 +2339,13 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
                 float4 o;   // (sample s of the block lives in row s / kChunk of kChunk + 1 words)
                 o.x = s_stage[s + s / kChunk]; o.y = s_stage[s + 1 + (s + 1) / kChunk];
                 o.z = s_stage[s + 2 + (s + 2) / kChunk]; o.w = s_stage[s + 3 + (s + 3) / kChunk];
-                *reinterpret_cast<float4*>(out + base + s) = o;
+                if (out) *reinterpret_cast<float4*>(out + base + s) = o;
                 if (to_host) *reinterpret_cast<float4*>(host_out + base + s) = o;
             } else {
                 for (int e = 0; e < 4; ++e)
                     if (base + s + e < num_samples) {
                         const float y1 = s_stage[s + e + (s + e) / kChunk];
-                        out[base + s + e] = y1;
+                        if (out) out[base + s + e] = y1;
                         if (to_host) host_out[base + s + e] = y1;
                     }
             }
@@ -2346,6 +2367,7 @@ __device__ __forceinline__ void reconstruct_body_fast(const int row, const int c
     float* s_x = s_amp + nb;
     float* s_stage = s_x + kBlock * kChunk + kWarm;
     const float Pi4 = sqrtf(4.0f * kPi);                           // FSAC.cpp:323
+    if (ir_bands == nullptr && (row < B || host_out == nullptr)) return;   // (uniform) a superseded frame: only its channel row, for the host
     for (int i = threadIdx.x; i < nb; i += kBlock) {
         float e;
         if (row < B) e = energy[row * nb + i];
@@ -2360,7 +2382,7 @@ __device__ __forceinline__ void reconstruct_body_fast(const int row, const int c
     }
     __syncthreads();
     const bool to_host = host_out != nullptr && row == B;   // (uniform for the workgroup)
-    float* out = row < B ? ir_bands + (size_t)row * num_samples : ir_mono;
+    float* out = ir_bands == nullptr ? nullptr : (row < B ? ir_bands + (size_t)row * num_samples : ir_mono);
     const int base = chunk_block * kBlock * kChunk;          // the block's first sample
     const float fspb = (float)spb;
     // ---- phase 1: the interpolated samples x[base - kWarm .. base + kBlock * kChunk) -> s_x[0 ..): thread t its own kChunk, and the
@@ -2430,13 +2452,13 @@ __device__ __forceinline__ void reconstruct_body_fast(const int row, const int c
             float4 o;
             o.x = s_stage[sidx + sidx / kChunk]; o.y = s_stage[sidx + 1 + (sidx + 1) / kChunk];
             o.z = s_stage[sidx + 2 + (sidx + 2) / kChunk]; o.w = s_stage[sidx + 3 + (sidx + 3) / kChunk];
-            *reinterpret_cast<float4*>(out + base + sidx) = o;
+            if (out) *reinterpret_cast<float4*>(out + base + sidx) = o;
             if (to_host) *reinterpret_cast<float4*>(host_out + base + sidx) = o;
         } else {
             for (int e = 0; e < 4; ++e)
                 if (base + sidx + e < num_samples) {
                     const float y1 = s_stage[sidx + e + (sidx + e) / kChunk];
-                    out[base + sidx + e] = y1;
+                    if (out) out[base + sidx + e] = y1;
                     if (to_host) host_out[base + sidx + e] = y1;
                 }
         }

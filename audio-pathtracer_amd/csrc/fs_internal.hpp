@@ -283,6 +283,7 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
 // of an older one (walked before), the plan pass of the newest.  false = no fused form for this shape (lobes, counting
 // instantiations, experiment walk variants, nothing to do): the caller launches the kernels one after the other.
 constexpr int kMaxWalkParts = 8;   // walk parts of one fused launch = stages of a staged walk in flight
+struct PublishWord { unsigned* tickets = nullptr; unsigned long long* host_word = nullptr; unsigned long long id = 0; };
 struct WalkPart {   // a frame's walks from step stage.begin up to step stage.end
     KParams kp; SubpathState st; WalkLaunch wl;   // wl.queue_head = the frame's scratch set, wl.rays_per_wave
     const uint32_t* perm = nullptr;               // its schedule (nullptr: none)
@@ -299,9 +300,14 @@ struct FrameParts {
     float* const* zero_tab_p = nullptr; int zero_count_p = 0;                              // batched frame: the buffers to flush
     // reconstruct parts: ReconstructImpulseResponse of the frames the PREVIOUS launch connected (single GPU; a sharded
     // frame is reduced on the tail stream first and reconstructed there)
+    // ir = the source's device IR set [(B + 1)][samples] (bands, then the channel view), nullptr for a frame whose IR is superseded
+    // within the launch; host = the pinned ring slot the channel view is also written into (the publish), nullptr: none.
     int num_recon = 0;
-    struct Recon { const float* energy; float* ir_bands; float* ir_mono; int spb; } recon[kMaxReconParts];
+    struct Recon { const float* energy; float* ir; float* host; } recon[kMaxReconParts];
+    int recon_spb[kMaxReconParts] = {};
     int recon_B = 0, recon_nb = 0, recon_samples = 0;
+    // the publish of those host slots (fs_device.hpp: publish_arrive): the ticket cell, the pinned host word, this launch's id (tickets == nullptr: by an event)
+    PublishWord pub;
 };
 bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s);
 // does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule
@@ -334,7 +340,8 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
 // pinned host memory (read by the kernel as it stands); host != nullptr: the channel view is also written straight into
 // that pinned host buffer (the publish: 16-byte stores, a block's 4 096 samples staged in LDS) — no copy command per source.
 struct ReconItem { const float* energy; float* ir_bands; float* ir_mono; float* host; int32_t spb; int32_t pad; };
-void launch_reconstruct_batch(const ReconItem* table, int count, int B, int num_bins, int num_samples, hipStream_t s);
+// pub.tickets != nullptr: the launch announces its own completion in the context's pinned host word (publish_arrive)
+void launch_reconstruct_batch(const ReconItem* table, int count, int B, int num_bins, int num_samples, hipStream_t s, const PublishWord& pub = PublishWord());
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,
                        int32_t* hit, float* t, int32_t* tri, float* normal, hipStream_t s);
 // rays_per_wave < 64: sparse waves whose other lanes help with every closest-hit query; 64 = one ray per lane

@@ -48,7 +48,7 @@
  *             fs_copy_band_impulse_response fs_set_impulse_response fs_trace_rays
  *             fs_save_array_to_file fs_load_float_array fs_save_impulse_response
  *             fs_reverb_init fs_reverb_process fs_reverb_release fs_apply_material_fd
- *             fs_set_profiling fs_set_profiling_interval
+ *             fs_set_profiling fs_set_profiling_interval fs_get_pipeline_counters
  * (tests/test_capi_cpu.py checks that every exported symbol is in exactly one of the two lists.)
  * Environment variables (FS_*) are tuning and diagnostic knobs only; all of them are read ONCE — at fs_context_create, at a
  * scene commit (builder knobs) or at the first launch of a kernel family — never per frame.
@@ -522,6 +522,25 @@ int fs_set_profiling(fs_context* ctx, int32_t level);
 int fs_set_profiling_interval(fs_context* ctx, int32_t frames);
 int fs_get_stats(fs_context* ctx, fs_stats* out);
 int fs_reset_stats(fs_context* ctx);
+/* What the producer's side of a stream of frames did since the context was created (host counters, no device access, any time):
+ * where a timed region can lose time that is not kernel time.  In the steady state of a single-GPU stream of pipelined frames
+ * tail_stream_ops, stream_waits_enqueued and publishes_by_event stay constant: every launch goes onto the compute stream and
+ * publishes its impulse responses by itself (the reference's contract: the IR is in the component's buffer when
+ * ReconstructImpulseResponse returns, FSAC.cpp:377-378 — here: when the launch's id appears in a pinned host word). */
+typedef struct fs_pipeline_counters {
+    uint32_t struct_size;            /* = sizeof(fs_pipeline_counters), set by the caller */
+    uint32_t reserved;
+    uint64_t fused_launches;         /* launches that carry parts of several pipelined frames */
+    uint64_t flushes, flushed_frames;/* held frames that had to finish on kernels of their own (fs_submit, fs_synchronize, an observer) */
+    uint64_t host_waits, host_wait_us;   /* the producer waited for a publish: the IR ring's back-pressure, its only throttle */
+    uint64_t stream_waits_enqueued;  /* waits for another stream's event put on the compute stream ... */
+    uint64_t stream_waits_skipped;   /* ... and those not needed because the event had completed */
+    uint64_t tail_stream_ops;        /* commands enqueued on the tail stream: hand-overs, reconstruct kernels, copies, event records, collectives */
+    uint64_t owed_on_tail;           /* reconstructs that missed their fused launch and ran on kernels of their own */
+    uint64_t publishes_by_word;      /* impulse responses published by the launch itself (compute stream, pinned host word) */
+    uint64_t publishes_by_event;     /* ... through an event on the tail stream (a copy command or a batch kernel there) */
+} fs_pipeline_counters;
+int fs_get_pipeline_counters(fs_context* ctx, fs_pipeline_counters* out);
 
 #if defined(FS_BUILDING_LIBRARY) && defined(__GNUC__)
 #pragma GCC visibility pop
