@@ -44,7 +44,7 @@ EXPORTS = [
     "fs_reconstruct_impulse_response_async", "fs_reconstruct_impulse_response_batch_async", "fs_update_sources", "fs_synchronize", "fs_get_impulse_response", "fs_get_impulse_response_sequence",
     "fs_copy_impulse_response", "fs_copy_band_impulse_response", "fs_get_energy_buffer", "fs_flush_energy_buffer",
     "fs_add_energy_at_delay", "fs_update_energy_buffer", "fs_num_bins", "fs_num_samples", "fs_trace_rays",
-    "fs_set_profiling", "fs_set_profiling_interval", "fs_get_stats", "fs_reset_stats", "fs_get_pipeline_counters",
+    "fs_set_profiling", "fs_set_profiling_interval", "fs_get_stats", "fs_reset_stats", "fs_get_pipeline_counters", "fs_get_streams",
     "fs_sound_params_default", "fs_scene_set_objects", "fs_update_sound", "fs_get_occlusion_attenuation",
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
@@ -250,6 +250,7 @@ def load():
         "fs_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
         "fs_reset_stats": (C.c_int, [vp]),
         "fs_get_pipeline_counters": (C.c_int, [vp, C.POINTER(PipelineCounters)]),
+        "fs_get_streams": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
         "fs_sound_params_default": (None, [C.POINTER(SoundParams)]),
         "fs_scene_set_objects": (C.c_int, [vp, vp, i32]),
         "fs_update_sound": (C.c_int, [vp, i32, C.POINTER(SoundParams), C.POINTER(SoundResult)]),

@@ -357,6 +357,12 @@ class Context:
     def reset_stats(self):
         self.check(self.lib.fs_reset_stats(self.h))
 
+    def streams(self):
+        """fs_get_streams: (compute stream, tail stream) as integer hipStream_t handles"""
+        a, b = C.c_void_p(), C.c_void_p()
+        self.check(self.lib.fs_get_streams(self.h, C.byref(a), C.byref(b)))
+        return int(a.value or 0), int(b.value or 0)
+
     def pipeline_counters(self):
         """fs_get_pipeline_counters: the producer side's host counters since the context was created"""
         c = _capi.PipelineCounters()

@@ -709,6 +709,14 @@ int fs_get_pipeline_counters(fs_context* ctx, fs_pipeline_counters* out) {
     return FS_OK;
 }
 
+int fs_get_streams(fs_context* ctx, void** compute_stream, void** tail_stream) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
+    if (compute_stream) *compute_stream = (void*)ctx->stream;
+    if (tail_stream) *tail_stream = (void*)ctx->copy_stream;
+    return FS_OK;
+}
+
 int fs_get_stats(fs_context* ctx, fs_stats* out) {
     if (!ctx || !out) return FS_ERR_INVALID_ARGUMENT;
     FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first

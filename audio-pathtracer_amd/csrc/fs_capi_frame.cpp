@@ -359,6 +359,9 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) {  // ARTS.cpp:191 literally
         FS_HIP(ctx, wait_energy_readers(ctx, s));
         FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
+        // (deterministic mode: the fp32 buffer is re-derived from the fixed-point histogram below — the flush empties that one too)
+        if (s->cur_fixed && s->d_fixed[s->cur])
+            FS_HIP(ctx, hipMemsetAsync(s->d_fixed[s->cur], 0, sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
     }
     // The tail stream takes over: it waits for this frame's deposit (and runs behind any collective the caller
     // put there after fs_energy_handoff), reconstructs and publishes while the compute stream goes on to the
@@ -626,7 +629,8 @@ void frame_describe(fs_context* ctx, Frame& f) {
         for (int bound : bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
-    } else if (!f.pipe_ok && (f.unbounded || (ctx->debug_rebin && p->russian_roulette && p->depth > 1)) && plain &&   // (FS_DEBUG_REBIN: the experiment also stages capped walks) !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on && (ctx->profiling < 3 || ctx->debug_rebin) &&
+    } else if (!f.pipe_ok && (f.unbounded || (ctx->debug_rebin && p->russian_roulette && p->depth > 1)) && plain &&   // (FS_DEBUG_REBIN: the experiment also stages capped walks)
+               !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on && (ctx->profiling < 3 || ctx->debug_rebin) &&
                !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from) {
         // A depth = 0 frame that is waited for (not held): the same stages, one launch after the other on the stream.  The
         // frame's time is its longest walk — a chain of ~ log(subpaths) / log(1 / rr) dependent bounces — and what a bounce

@@ -48,7 +48,7 @@
  *             fs_copy_band_impulse_response fs_set_impulse_response fs_trace_rays
  *             fs_save_array_to_file fs_load_float_array fs_save_impulse_response
  *             fs_reverb_init fs_reverb_process fs_reverb_release fs_apply_material_fd
- *             fs_set_profiling fs_set_profiling_interval fs_get_pipeline_counters
+ *             fs_set_profiling fs_set_profiling_interval fs_get_pipeline_counters fs_get_streams
  * (tests/test_capi_cpu.py checks that every exported symbol is in exactly one of the two lists.)
  * Environment variables (FS_*) are tuning and diagnostic knobs only; all of them are read ONCE — at fs_context_create, at a
  * scene commit (builder knobs) or at the first launch of a kernel family — never per frame.
@@ -541,6 +541,10 @@ typedef struct fs_pipeline_counters {
     uint64_t publishes_by_event;     /* ... through an event on the tail stream (a copy command or a batch kernel there) */
 } fs_pipeline_counters;
 int fs_get_pipeline_counters(fs_context* ctx, fs_pipeline_counters* out);
+/* The context's HIP streams as hipStream_t values: the compute stream (fs_config.stream if the caller gave one, else the
+ * context's own) and the tail stream (what fs_energy_handoff returns too).  For measurement — events recorded on the stream
+ * the launches really go to — and for hosts that order work of their own behind a frame.  Either pointer may be NULL. */
+int fs_get_streams(fs_context* ctx, void** compute_stream, void** tail_stream);
 
 #if defined(FS_BUILDING_LIBRARY) && defined(__GNUC__)
 #pragma GCC visibility pop

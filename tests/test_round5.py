@@ -1,0 +1,225 @@
+"""Round 5: the streamed path publishes its impulse responses from the launch itself (ring slot writes by the reconstruct
+workgroups + a pinned host word, csrc/fs_device.hpp: publish_arrive) — the reference's contract is that the IR is in the
+component's buffer when ReconstructImpulseResponse returns (FrequenSeeAudioComponent.cpp:377-378) and GetImpulseResponse
+reads that buffer (FrequenSeeAudioComponent.h:113).  Results must not depend on which of the three publish mechanisms
+(host word / tail-stream batch event / tail-stream copy + event) carried a frame."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import IR_TOL, TIGHT_TOL, make_ctx, rel_rms  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+DET = 8           # FS_FLAG_DETERMINISTIC
+FLUSH2 = 2        # FS_FLAG_FLUSH_BEFORE_RECONSTRUCT: such a reconstruct always takes the tail stream (reconstruct_now)
+
+
+def frames(pkg, n, rays=16384, flags=DET, seed0=500):
+    return [pkg.default_params(num_rays=rays, depth=8, seed=seed0 + i, flags=flags) for i in range(n)]
+
+
+@pytest.mark.parametrize("fpl", [1, 2, 4])
+def test_streamed_frames_publish_from_the_launch_itself(pkg, scene_factory, fpl):
+    """Steady state of a single-GPU stream of pipelined frames: nothing is enqueued on the tail stream, no cross-stream
+    wait reaches the compute stream, every IR is published through the host word — and arrives without any host-side
+    synchronisation call (the consumer only polls the sequence number)."""
+    sc = scene_factory("starter_room", 4)
+    ctx, src = make_ctx(pkg, sc)
+    ctx.set_pipelining(2)
+    ctx.set_frames_per_launch(fpl)
+    warm = frames(pkg, 8, seed0=100)
+    for p in warm:
+        ctx.compute_energy_response_async(src, p); ctx.reconstruct_impulse_response_async(src, p)
+    ctx.synchronize()
+    seq0 = ctx.impulse_response_sequence(src)
+    assert seq0 == len(warm)
+    c0 = ctx.pipeline_counters()
+    ps = frames(pkg, 40)
+    for p in ps:
+        ctx.compute_energy_response_async(src, p); ctx.reconstruct_impulse_response_async(src, p)
+    ctx.submit()                       # the held frames' last passes: enqueued, not waited for
+    c1 = ctx.pipeline_counters()
+    d = {k: c1[k] - c0[k] for k in c0}
+    assert d["tail_stream_ops"] == 0 and d["publishes_by_event"] == 0 and d["stream_waits_enqueued"] == 0, d
+    assert d["publishes_by_word"] == len(ps) and d["fused_launches"] >= len(ps) // fpl, d
+    t0 = time.time()
+    while ctx.impulse_response_sequence(src) < seq0 + len(ps):     # lock-free poll: no stream wait anywhere
+        assert time.time() - t0 < 20.0, "the publishes never arrived in the host word"
+    got = ctx.impulse_response_view(src, 0).copy()
+    # the last frame against a context that waits for every frame
+    plain, qs = make_ctx(pkg, sc)
+    plain.compute_energy_response(qs, ps[-1]); plain.reconstruct_impulse_response(qs, ps[-1])
+    assert np.array_equal(got, plain.impulse_response(qs, 0)) and np.abs(got).max() > 0
+    ctx.synchronize()
+    for b in range(4):                 # the device-resident set (the reverb's, fs_copy_band_impulse_response's) is the last frame's too
+        assert np.array_equal(ctx.band_impulse_response(src, b), plain.band_impulse_response(qs, b))
+    plain.close(); ctx.close()
+
+
+def test_audio_thread_reads_while_pipelined_frames_are_produced(pkg, scene_factory):
+    """The reader-thread test of test_gpu_parity.py on the streamed path: the reader takes whatever
+    fs_get_impulse_response points at while fused launches write ring slots and the host word underneath it.  In
+    deterministic mode each of the two parameter sets has one bit-exact IR: every read must equal one of them — a slot
+    announced before its samples had landed, or recycled too early, would match neither."""
+    sc = scene_factory("starter_room", 4)
+    ctx, src = make_ctx(pkg, sc)
+    params = [pkg.default_params(num_rays=8192, depth=8, seed=s_, dist_divisor=100.0, flags=DET) for s_ in (5, 6)]
+    irs = []
+    for p in params:
+        ctx.compute_energy_response(src, p); ctx.reconstruct_impulse_response(src, p)
+        irs.append(ctx.impulse_response(src, 0).copy())
+    assert not np.array_equal(irs[0], irs[1]) and irs[0].any()
+    ctx.set_pipelining(2); ctx.set_frames_per_launch(2)
+    stop = threading.Event()
+    seen = {"reads": 0, "bad": 0, "a": 0, "b": 0, "seq_max": 0}
+
+    def reader():
+        while not stop.is_set():
+            seen["seq_max"] = max(seen["seq_max"], ctx.impulse_response_sequence(src))
+            v = ctx.impulse_response_view(src, 0).copy()
+            seen["reads"] += 1
+            if np.array_equal(v, irs[0]):
+                seen["a"] += 1
+            elif np.array_equal(v, irs[1]):
+                seen["b"] += 1
+            else:
+                seen["bad"] += 1
+
+    th = threading.Thread(target=reader)
+    th.start()
+    try:
+        for f in range(400):
+            ctx.compute_energy_response_async(src, params[(f >> 1) & 1])    # (two frames per launch: both sets reach the front)
+            ctx.reconstruct_impulse_response_async(src, params[(f >> 1) & 1])
+        ctx.synchronize()
+    finally:
+        stop.set()
+        th.join()
+    assert seen["bad"] == 0 and seen["reads"] > 20 and seen["a"] > 0 and seen["b"] > 0, seen
+    assert ctx.impulse_response_sequence(src) == 402
+    assert np.array_equal(ctx.impulse_response(src, 0), irs[1])     # frames 398, 399 used the second set
+    ctx.close()
+
+
+def test_publish_mechanisms_interleave(pkg, scene_factory):
+    """Fused launches (host word), a literal second flush (tail stream: kernel + copy + event) and waited-for frames
+    (compute-stream batch of one) in one stream of one source: every observation equals the same frame on a context that
+    waits for everything — the published IR and the device-resident per-band set, whoever wrote it last."""
+    sc = scene_factory("starter_room", 4)
+    ctx, src = make_ctx(pkg, sc)
+    ref, rs = make_ctx(pkg, sc)
+    ctx.set_pipelining(2); ctx.set_frames_per_launch(2)
+    ps = frames(pkg, 24, rays=8192)
+
+    def expect(p, recon_flags=0):
+        q = pkg.default_params(num_rays=p.num_rays, depth=p.depth, seed=p.seed, flags=p.flags | recon_flags)
+        ref.compute_energy_response(rs, p); ref.reconstruct_impulse_response(rs, q)
+        return ref.impulse_response(rs, 0).copy(), [ref.band_impulse_response(rs, b).copy() for b in range(4)]
+
+    def check(p, recon_flags=0):
+        ir, bands = expect(p, recon_flags)
+        assert np.array_equal(ctx.impulse_response(src, 0), ir)
+        for b in range(4):
+            assert np.array_equal(ctx.band_impulse_response(src, b), bands[b]), b
+
+    k = 0
+    for rnd in range(3):
+        for _ in range(5):             # fused launches
+            ctx.compute_energy_response_async(src, ps[k]); ctx.reconstruct_impulse_response_async(src, ps[k]); k += 1
+        ctx.synchronize()
+        check(ps[k - 1])
+        # the tail stream right behind fused launches that are still running (no wait in between)
+        ctx.compute_energy_response_async(src, ps[k]); ctx.reconstruct_impulse_response_async(src, ps[k]); k += 1
+        q = ps[k]; k += 1
+        ctx.compute_energy_response_async(src, q)
+        qf = pkg.default_params(num_rays=q.num_rays, depth=q.depth, seed=q.seed, flags=q.flags | FLUSH2)
+        ctx.reconstruct_impulse_response_async(src, qf)            # reconstruct_now: all zeros (the literal second flush)
+        ctx.synchronize()
+        assert not ctx.impulse_response(src, 0).any()
+        for b in range(4):
+            assert not ctx.band_impulse_response(src, b).any()
+        # ... and a fused launch right behind the tail stream's reconstruct
+        ctx.compute_energy_response_async(src, ps[k]); ctx.reconstruct_impulse_response_async(src, ps[k]); k += 1
+        ctx.synchronize()
+        check(ps[k - 1])
+    c = ctx.pipeline_counters()
+    assert c["publishes_by_word"] > 0 and c["publishes_by_event"] == 3, c
+    assert ctx.impulse_response_sequence(src) == k
+    ref.close(); ctx.close()
+
+
+def test_reverb_reads_behind_fused_reconstructs(pkg, scene_factory):
+    """fs_reverb_process (audio thread, own stream) convolves with the device-resident IR: behind a stream of fused launches
+    its output equals that of a context whose reconstructs are waited for.  (A source with a reverb gets an event on the
+    compute stream behind every launch that rewrites its IR; one without does not — fs_reverb_init drains what is in flight.)"""
+    sc = scene_factory("starter_room", 4)
+    ctx, src = make_ctx(pkg, sc)
+    ref, rs = make_ctx(pkg, sc)
+    ctx.set_pipelining(2); ctx.set_frames_per_launch(2)
+    ps = frames(pkg, 10, rays=8192)
+    for p in ps[:4]:                   # launches in flight when the reverb is created
+        ctx.compute_energy_response_async(src, p); ctx.reconstruct_impulse_response_async(src, p)
+    ctx.reverb_init(src, 256); ref.reverb_init(rs, 256)
+    rng = np.random.default_rng(3)
+    audio = rng.standard_normal((6, 512)).astype(np.float32) * 0.1
+    for i, p in enumerate(ps[4:]):
+        ctx.compute_energy_response_async(src, p); ctx.reconstruct_impulse_response_async(src, p)
+        ref.compute_energy_response(rs, p); ref.reconstruct_impulse_response(rs, p)
+        if i % 2 == 1:                 # (two frames per launch: after an odd frame both have been sent off)
+            ctx.submit()
+            a = ctx.reverb_process(src, audio[i])
+            b = ref.reverb_process(rs, audio[i])
+            assert np.array_equal(a, b), i
+        else:
+            ref.reverb_process(rs, audio[i]); ctx.synchronize(); ctx.reverb_process(src, audio[i])   # keep the two histories in step
+    ref.close(); ctx.close()
+
+
+def test_pipeline_counters_argument_errors(pkg, scene_factory):
+    import ctypes as C
+    sc = scene_factory("shoebox", 1)
+    ctx, src = make_ctx(pkg, sc)
+    c = pkg._capi.PipelineCounters()
+    c.struct_size = 8
+    assert ctx.lib.fs_get_pipeline_counters(ctx.h, C.byref(c)) == pkg._capi.ERR_INVALID_ARGUMENT
+    assert ctx.lib.fs_get_pipeline_counters(ctx.h, None) == pkg._capi.ERR_INVALID_ARGUMENT
+    d = ctx.pipeline_counters()
+    assert set(d) >= {"fused_launches", "tail_stream_ops", "publishes_by_word", "publishes_by_event", "host_waits"}
+    ctx.close()
+
+
+# ---- the guards of the waited-for staged walk ---------------------------------------------------
+@pytest.mark.parametrize("what", ["source_object", "listener_radius"])
+def test_uncapped_frames_with_an_ignored_actor_or_end_point_spheres(pkg, oracle_mod, monkeypatch, what):
+    """depth = 0, 32 768 subpaths (above the size from which a waited-for uncapped frame walks in stages), with the walk's own
+    actor ignored (AddIgnoredActor, ARTS.cpp:322-327) or with end-point spheres: the frame equals the oracle's and — bit for
+    bit in deterministic mode — the same frame on a context that never stages (FS_SYNC_WALK_STAGES empty)."""
+    from test_round4 import _room_with_a_box_around_the_source
+    from test_gpu_parity import check_energy
+    sc, tris, mats, obj = _room_with_a_box_around_the_source(pkg)
+    rays = 32768
+    kw = dict(listener_radius=34.0, source_radius=20.0) if what == "listener_radius" else {}
+
+    def run(flags):
+        ctx = pkg.Context(num_bands=1)
+        ctx.set_scene(tris, mats, sc.absorption, object_ids=obj)
+        ctx.set_listener(sc.listener)
+        s = ctx.create_source(sc.source)
+        ctx.set_source_object(s, 7)     # (the source sits inside its own box: without its actor ignored nothing gets out)
+        e = ctx.compute_energy_response(s, pkg.default_params(num_rays=rays, depth=0, seed=77, flags=flags, **kw)).copy()
+        st = ctx.stats()
+        ctx.close()
+        return e, st
+
+    got, st = run(0)
+    det_staged, _ = run(DET)
+    monkeypatch.setenv("FS_SYNC_WALK_STAGES", "")
+    det_plain, _ = run(DET)
+    assert got.any() and np.array_equal(det_staged, det_plain)
+    osc = oracle_mod.Scene(tris, mats, sc.absorption)
+    osc.set_objects(obj)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=0, seed=77, source_object=7, **kw), sc.source, sc.listener)
+    check_energy(got, e32, e64, 1)
+    assert st["deposits"] == cnt.connected
