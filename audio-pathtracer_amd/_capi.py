@@ -49,7 +49,7 @@ EXPORTS = [
     "fs_save_array_to_file", "fs_load_float_array", "fs_save_impulse_response",
     "fs_reverb_init", "fs_reverb_process", "fs_reverb_release",
     "fs_apply_material_fd", "fs_energy_handoff", "fs_scene_update_triangles", "fs_scene_refit", "fs_set_impulse_response",
-    "fs_scene_commit_fast", "fs_comm_unique_id", "fs_comm_init", "fs_comm_attach", "fs_comm_detach", "fs_comm_enable_oneshot", "fs_shard_range",
+    "fs_scene_commit_fast", "fs_comm_unique_id", "fs_comm_init", "fs_comm_attach", "fs_comm_detach", "fs_comm_info", "fs_comm_enable_oneshot", "fs_shard_range",
     "fs_peers_init", "fs_peers_detach", "fs_gather_energy", "fs_gather_energy_async", "fs_set_pipelining", "fs_set_walk_stages", "fs_set_frames_per_launch", "fs_submit", "fs_scene_commit_progressive", "fs_scene_refine_pending", "fs_scene_refine_wait",
 ]
 COMM_ID_BYTES = 128
@@ -266,6 +266,7 @@ def load():
         "fs_comm_init": (C.c_int, [vp, vp, C.c_size_t]),
         "fs_comm_attach": (C.c_int, [vp, vp]),
         "fs_comm_detach": (C.c_int, [vp]),
+        "fs_comm_info": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "fs_comm_enable_oneshot": (C.c_int, [vp]),
         "fs_shard_range": (C.c_int, [C.c_uint32, i32, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "fs_peers_init": (C.c_int, [vp, vp, C.c_size_t, i32, i32]),

@@ -86,6 +86,12 @@ class Context:
         """collective: the energy buffer's sum over the ranks as one peer-write exchange (HIP IPC mailboxes) instead of ncclAllReduce"""
         self.check(self.lib.fs_comm_enable_oneshot(self.h))
 
+    def comm_info(self):
+        """fs_comm_info: (ranks of the attached communicator as RCCL counts them, this rank, collective kind 0 / 1 / 2)"""
+        n, r, k = C.c_int32(), C.c_int32(), C.c_int32()
+        self.check(self.lib.fs_comm_info(self.h, C.byref(n), C.byref(r), C.byref(k)))
+        return int(n.value), int(r.value), int(k.value)
+
     def comm_detach(self):
         self.check(self.lib.fs_comm_detach(self.h))
 

@@ -230,6 +230,21 @@ int fs_comm_attach(fs_context* ctx, void* nccl_comm) {
     return FS_OK;
 }
 
+int fs_comm_info(fs_context* ctx, int32_t* ranks, int32_t* rank, int32_t* collective) {
+    if (!ctx) return FS_ERR_INVALID_ARGUMENT;
+    int n = 0, r = -1;
+    if (ctx->comm) {
+        RcclApi* a = rccl();
+        if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
+        FS_NCCL(ctx, a->CommCount(ctx->comm, &n));
+        FS_NCCL(ctx, a->CommUserRank(ctx->comm, &r));
+    }
+    if (ranks) *ranks = n;
+    if (rank) *rank = r;
+    if (collective) *collective = !ctx->comm ? 0 : (ctx->oneshot.on && !ctx->oneshot.broken ? 2 : 1);
+    return FS_OK;
+}
+
 int fs_comm_detach(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first

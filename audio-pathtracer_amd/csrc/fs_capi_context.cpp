@@ -551,6 +551,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_COOP")) ctx->walk.coop = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_FUSED_RECON")) ctx->fused_recon = std::atoi(v) != 0;
     if (const char* v = std::getenv("FS_FUSED_RECON_COMM")) ctx->fused_recon_comm = std::atoi(v) != 0;
+    if (const char* v = std::getenv("FS_FUSED_DRAIN")) ctx->fused_drain = std::atoi(v) != 0;
     ctx->hist_window = default_hist_window(ctx->cfg.num_bands);
     if (const char* v = std::getenv("FS_STACK_ROWS_CAP")) ctx->stack_rows_cap = std::max(kDeepChunk + 4, std::min(kStackDepth + 1, std::atoi(v)));
     if (const char* v = std::getenv("FS_HIST_WINDOW")) ctx->hist_window = std::max(1, std::min(4096, std::atoi(v)));

@@ -54,13 +54,13 @@ static int flush_reconstruct(fs_context* ctx, Source* s, const fs_params* p) {
     return reconstruct_now(ctx, s, p);
 }
 
-static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false, bool tail_waits_already = false) {
+static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false, bool tail_waits_already = false, bool draining = false) {
     // the items of a frame were connected by ONE launch: once the tail stream waits behind it (the first item's handoff),
     // the other items' reconstructs are ordered too — no further event pairs on the compute stream (each is a bubble
     // between its launches).  Not in deterministic mode: every item's fixed-point rounding runs on the compute stream first.
     // (tail_waits_already: the publishes of this very launch's reconstruct parts made the tail stream wait behind it)
     bool tail_behind_launch = tail_waits_already;
-    const bool flushing = !may_defer_recon;   // called by flush_pending: nothing will be launched behind this frame that its reconstructs could overlap
+    const bool flushing = !may_defer_recon || draining;   // called by flush_pending: nothing will be launched behind this frame that its reconstructs could overlap
     // the reconstructs of a frame ride in the next launch all together or not at all (a tail-stream reconstruct in between
     // would have to run the deferred ones first, to keep the IRs in frame order)
     int wanted = 0;
@@ -296,6 +296,51 @@ static int run_owed_reconstructs(fs_context* ctx) {
     return FS_OK;
 }
 
+// A flush on one GPU drains the pipeline through the SAME fused launches the stream of frames uses, only without a newest frame:
+// every launch carries the next walk stage of every held frame, the connect pass of the oldest complete one and the reconstructs
+// owed by the launch before — the passes keep overlapping each other and the IRs are published by the launches themselves.
+// (Until round 5 every held frame finished on kernels of its own, one after the other: walk, connect, reconstruct, walk, ... —
+// six kernels in a row behind a stream of cfg3 frames, 0.4 ms of the driver's 5.9 ms timed region.)
+static int drain_fused(fs_context* ctx) {
+    const int B = ctx->cfg.num_bands;
+    bool counted = false;
+    for (int guard = 0; (!ctx->held.empty() || !ctx->recon_owed.empty()) && guard < 8 * (kMaxWalkParts + 4); ++guard) {
+        if (!counted && !ctx->held.empty()) { ctx->dbg.flushes++; ctx->dbg.flushed_frames += ctx->held.size(); counted = true; }
+        FrameParts fp;
+        bool connects = false;
+        std::vector<size_t> advanced;
+        for (size_t k = 0; k < ctx->held.size(); ++k) {
+            fs_context::PipeFrame& q = ctx->held[k];
+            if (q.next_stage < (int)q.stages.size()) {
+                if (held_walk_part(ctx, q, fp)) advanced.push_back(k);
+            } else if (k == 0 && !connects) {
+                held_connect_part(q, fp);
+                connects = true;
+            }
+        }
+        OwedLaunch owed;
+        { const int orc = owed_prepare(ctx, fp, owed); if (orc) return orc; }
+        if (!(fp.num_walk > 0 || fp.has_connect || fp.num_recon > 0)) break;   // (nothing a launch could carry: the loop below finishes the rest)
+        const bool fused = launch_frame(B, ctx->scene, fp, ctx->stream);
+        ctx->dbg.launches++;
+        if (!fused) {   // no fused form: the same passes one after the other
+            if (fp.has_connect) launch_connect(B, ctx->scene, fp.kpc, fp.stc, fp.energy, fp.fixed, fp.scratch_c, fp.ppw, fp.energy_tab, fp.fixed_tab, ctx->stream);
+            for (int i = 0; i < fp.num_walk; ++i)
+                launch_walk(ctx->scene, fp.walk[i].kp, fp.walk[i].st, fp.walk[i].wl, fp.walk[i].perm, ctx->stream, fp.walk[i].stage);
+        }
+        FS_HIP(ctx, hipGetLastError());
+        { const int prc = owed_publish(ctx, owed, fused); if (prc) return prc; }
+        for (size_t k : advanced) ctx->held[k].next_stage++;
+        if (connects) {
+            const fs_context::PipeFrame done = ctx->held.front();
+            ctx->held.pop_front();
+            const int rc = finish_held_frame(ctx, done, /*may_defer_recon=*/true, false, /*draining=*/true);
+            if (rc) return rc;
+        }
+    }
+    return FS_OK;
+}
+
 int flush_pending(fs_context* ctx) {
     using clk = std::chrono::steady_clock;
     const bool dbg = ctx->debug_stalls;
@@ -303,6 +348,12 @@ int flush_pending(fs_context* ctx) {
     if (dbg) t0 = clk::now();
     if (!ctx->group.empty()) { const int gr = dispatch_group(ctx); if (gr) return gr; }
     if (dbg) t1 = clk::now();
+    if (ctx->fused_drain && ctx->fused_recon && !ctx->comm && ctx->cfg.world_size == 1 && ctx->profiling < 2 &&
+        (!ctx->held.empty() || !ctx->recon_owed.empty())) {
+        FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
+        const int dr = drain_fused(ctx);
+        if (dr) return dr;
+    }
     { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // (older than every held frame)
     if (dbg) t2 = clk::now();
     if (ctx->held.empty()) return FS_OK;
@@ -613,7 +664,9 @@ void frame_describe(fs_context* ctx, Frame& f) {
     // launch carries one frame's worth of work and no chain longer than a stage.
     const bool plain = !(p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY |
                                      FS_FLAG_DOUBLE_POSITIONS));
-    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on &&
+    // (a walk that ignores the actor it starts from — what the reference's GeneratePath always does, ARTS.cpp:322-327 — is held
+    // like any other: the fused launch has a flavour whose walk parts carry the ignored actor, fs_frame_ext.hip)
+    f.pipe_ok = ctx->pipelining > 0 && ctx->profiling < 2 && plain && !(p->listener_radius > 0.0f || p->source_radius > 0.0f) &&
                 (p->depth > 0 || (f.unbounded && ctx->pipelining >= 2));
     kp.plan_coop = (2ull * kp.num_local <= kPlanCoopMax || (f.unbounded && !f.pipe_ok && 2ull * kp.num_local <= kPlanCoopMaxUncapped)) ? 1 : 0;
     f.stages.clear();
@@ -630,7 +683,7 @@ void frame_describe(fs_context* ctx, Frame& f) {
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
     } else if (!f.pipe_ok && (f.unbounded || (ctx->debug_rebin && p->russian_roulette && p->depth > 1)) && plain &&   // (FS_DEBUG_REBIN: the experiment also stages capped walks)
-               !(p->listener_radius > 0.0f || p->source_radius > 0.0f) && !kp.ignore_on && (ctx->profiling < 3 || ctx->debug_rebin) &&
+               (ctx->profiling < 3 || ctx->debug_rebin) &&   // (an ignored actor or end-point spheres: the stage kernels' EXT instantiations — tests/test_round5.py)
                !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from) {
         // A depth = 0 frame that is waited for (not held): the same stages, one launch after the other on the stream.  The
         // frame's time is its longest walk — a chain of ~ log(subpaths) / log(1 / rr) dependent bounces — and what a bounce
@@ -1022,7 +1075,6 @@ bool groupable(const fs_context* ctx, const fs_params* p) {
     if (p->flags & (FS_FLAG_MATERIAL_LOBES | FS_FLAG_MIS_BALANCE | FS_FLAG_ALL_CONNECTIONS | FS_FLAG_ACCUMULATE_ENERGY | FS_FLAG_DOUBLE_POSITIONS))
         return false;
     if (p->listener_radius > 0.0f || p->source_radius > 0.0f) return false;
-    if (ctx->listener_object != FS_NO_OBJECT) return false;   // (a source with an actor of its own is checked by the caller)
     const bool unbounded = p->depth == 0 && p->russian_roulette && p->rr_prob < 1.0f;
     if (!(p->depth > 0 || (unbounded && ctx->pipelining >= 2))) return false;
     return (uint64_t)ctx->frames_per_launch * (p->num_rays / 2) <= (1ull << 29);
@@ -1175,7 +1227,7 @@ int fs_compute_energy_response_async(fs_context* ctx, fs_source h, const fs_para
     fs_params def;
     const fs_params* q = p;
     if (!q) { fs_params_default(&def); q = &def; }
-    if (q->struct_size == sizeof(fs_params) && s->object == FS_NO_OBJECT && groupable(ctx, q)) {
+    if (q->struct_size == sizeof(fs_params) && groupable(ctx, q)) {
         if (!ctx->group.empty() && (!same_but_seed(ctx->group[0].p, *q) || std::memcmp(ctx->group[0].lis, ctx->listener, sizeof(ctx->listener)) != 0)) {
             const int gr = dispatch_group(ctx);   // (a batched frame has ONE listener position)
             if (gr) return gr;

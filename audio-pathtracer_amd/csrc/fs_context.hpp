@@ -275,6 +275,7 @@ struct fs_context {
     std::vector<ReconOwed> recon_owed;
     bool fused_recon = true;                       // FS_FUSED_RECON=0: always the tail stream
     bool fused_recon_comm = true;                  // FS_FUSED_RECON_COMM=0: with a communicator, always the tail stream
+    bool fused_drain = true;                       // FS_FUSED_DRAIN=0: a flush lets every held frame finish on kernels of its own (round 4's form)
     // Publishes of the compute stream (fused reconstruct parts, batches behind a tick or a flush): the launch writes the ring slots
     // and then its id into *h_pub_word (pinned, coherent) — see Source::pub_word.  pub_issued = id of the newest such launch.
     unsigned* d_pub_tickets = nullptr;             // device: the ticket cell of publish_arrive (re-armed by the launch that used it)

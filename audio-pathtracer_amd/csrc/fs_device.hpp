@@ -1310,7 +1310,9 @@ __device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_co
 }
 
 
-template <int LOBES, bool COUNT, bool EXT = false>
+// IGN (= EXT unless said otherwise): the queries skip the triangles of the actor the walk starts from; the fused frame kernel's
+// EXT flavour asks for that alone (IGN without EXT: no double positions, no end-point spheres — 23 -> 64 spilled registers with them)
+template <int LOBES, bool COUNT, bool EXT = false, bool IGN = EXT>
 __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
                                                  const uint32_t* __restrict__ perm, const WalkStage sr = WalkStage(),
@@ -1349,7 +1351,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
 #ifdef FS_WAVE_TIMELINE
         const unsigned long long tl_a = __builtin_amdgcn_s_memtime();
 #endif
-        trav_run_shared<COUNT, EXT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, true, w.ign);   // (EXT: the walk's own actor is ignored)
+        trav_run_shared<COUNT, IGN>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, true, w.ign);   // (IGN: the walk's own actor is ignored)
 #ifdef FS_WAVE_TIMELINE
         tl_trav += __builtin_amdgcn_s_memtime() - tl_a;
         ++tl_seg;
@@ -1387,7 +1389,7 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
 // its longest chain of closest-hit queries.  Here a wave owns only `rays_per_wave` subpaths (its first lanes) and
 // the other lanes help with every query — the legacy tracer's scheme (update_sound_shared_kernel).  The loop is
 // wave-uniform: lanes whose walk has ended (or that never had one) keep calling the shared traversal as helpers.
-template <int LOBES, bool COUNT, bool EXT = false>
+template <int LOBES, bool COUNT, bool EXT = false, bool IGN = EXT>
 __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
                                                  const uint32_t* __restrict__ perm, const int rays_per_wave,
@@ -1425,7 +1427,7 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
         }
         if (__ballot(go) == 0ull) break;
         Trav T;
-        trav_run_shared<COUNT, EXT>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go, w.ign);
+        trav_run_shared<COUNT, IGN>(sc, ray, T, stack, s_dyn, kp.max_trace_dist, go, w.ign);
         if (COUNT) { cnt_nv += T.nv; cnt_nt += T.nt; }
         if (go) walker_apply_hit<EXT>(w, kp, sc, st, ray, T);
     }

@@ -5,11 +5,29 @@
 // workgroups share a CU, for launches that fill the chip — and through fs_frame_wide.hip with FS_FRAME_WIDE defined:
 // no register limit, the tree's worst-case stack rows in LDS and none of the deep-store logic in the traversal, for
 // launches too small for occupancy to matter (cfg2: 0.105 -> 0.097 ms, cfg4 at 131 072 rays: 400 -> 435 M rays/s).
+//
+// And once more per flavour with FS_FRAME_EXT defined (fs_frame_ext.hip, fs_frame_wide_ext.hip): the walk parts are the EXT
+// instantiations, whose queries skip the triangles of the actor the walk starts from (AddIgnoredActor, ARTS.cpp:322-327 — what the
+// reference's GeneratePath ALWAYS does; fs_source_set_object / fs_listener_set_object).  Until round 5 such frames were never
+// held by fs_set_pipelining: a plugin whose source actors carry registered meshes got the unpipelined rate.
+#ifdef FS_FRAME_EXT
+#define FS_FRAME_EXT_ON true
+#else
+#define FS_FRAME_EXT_ON false
+#endif
 #ifdef FS_FRAME_WIDE
 #define FS_DEEP_NO_CHECK 1
 #define FS_FRAME_MIN_WAVES 1
+#ifdef FS_FRAME_EXT
+#define frame_kernel frame_kernel_wide_ext
+#define FS_LAUNCH_FRAME launch_frame_wide_ext
+#else
 #define frame_kernel frame_kernel_wide
 #define FS_LAUNCH_FRAME launch_frame_wide
+#endif
+#elif defined(FS_FRAME_EXT)
+#define frame_kernel frame_kernel_ext
+#define FS_LAUNCH_FRAME launch_frame_narrow_ext
 #else
 #define FS_LAUNCH_FRAME launch_frame_narrow
 #endif
@@ -68,8 +86,8 @@ __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(Devic
     for (int i = 0; i < a.num_walk; ++i) {
         const WalkArgs& w = a.walk[i];
         if (b < w.block_end) {
-            if (w.rays_per_wave < 64) walk_sparse_body<0, false>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.rays_per_wave, w.stage);
-            else walk_shared_body<0, false>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.stage);
+            if (w.rays_per_wave < 64) walk_sparse_body<0, false, false, FS_FRAME_EXT_ON>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.rays_per_wave, w.stage);
+            else walk_shared_body<0, false, false, FS_FRAME_EXT_ON>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.stage);
             return;
         }
         first = w.block_end;
@@ -118,8 +136,8 @@ bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStrea
     for (int i = 0; i < f.num_walk; ++i) {
         const WalkPart& p = f.walk[i];
         if (!FS_SHARED_WALK(p.wl)) return false;
-        if (p.kp.lobes || p.kp.count || p.kp.dpos || p.kp.ignore_on || p.kp.listener_radius > 0.0f || p.kp.source_radius > 0.0f || p.kp.num_local == 0)
-            return false;   // the default instantiations only
+        if (p.kp.lobes || p.kp.count || p.kp.dpos || (p.kp.ignore_on && !FS_FRAME_EXT_ON) || p.kp.listener_radius > 0.0f || p.kp.source_radius > 0.0f || p.kp.num_local == 0)
+            return false;   // the default instantiations only (the EXT flavour: + the walk's own actor)
         WalkArgs& w = a.walk[a.num_walk++];
         w.kp = p.kp; w.st = p.st; w.scratch = p.wl.queue_head; w.perm = p.perm; w.stage = p.stage;
         w.rays_per_wave = p.wl.rays_per_wave > 0 && p.wl.rays_per_wave < 64 ? p.wl.rays_per_wave : 64;
@@ -128,7 +146,7 @@ bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStrea
         const uint32_t waves = (lanes + (uint32_t)w.rays_per_wave - 1) / (uint32_t)w.rays_per_wave;
         blocks += (waves + kBlock / 64 - 1) / (kBlock / 64);
         w.block_end = blocks;
-        lds = std::max(lds, stack_bytes(sc) + kShareLdsBytes);
+        lds = std::max(lds, stack_bytes(sc) + (FS_FRAME_EXT_ON ? kShareIgnLdsBytes : kShareLdsBytes));
     }
     if (f.has_connect) {
         if (f.kpc.lobes || f.kpc.count || f.kpc.dpos || f.kpc.num_local == 0 || f.ppw < 1 || f.ppw > 64) return false;
@@ -186,8 +204,10 @@ bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStrea
     return true;
 }
 
-#ifndef FS_FRAME_WIDE
+#if !defined(FS_FRAME_WIDE) && !defined(FS_FRAME_EXT)
 bool launch_frame_wide(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s, uint32_t* blocks_only);   // fs_frame_wide.hip
+bool launch_frame_narrow_ext(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s, uint32_t* blocks_only);   // fs_frame_ext.hip
+bool launch_frame_wide_ext(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s, uint32_t* blocks_only);     // fs_frame_wide_ext.hip
 
 // Launches with fewer workgroups than the chip holds at four per CU take the wide flavour (see the top of the file), and
 // so do small frames that only reach that many workgroups because their walks run on sparse waves (a few subpaths per
@@ -195,7 +215,11 @@ bool launch_frame_wide(int B, const DeviceScene& sc, const FrameParts& f, hipStr
 constexpr uint32_t kFrameNarrowFromBlocks = 1024;
 bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t s) {
     uint32_t blocks = 0;
-    if (!launch_frame_narrow(B, sc, f, s, &blocks)) return false;
+    bool ext = false;   // some walk of the launch ignores the actor it starts from: the EXT flavours
+    for (int i = 0; i < f.num_walk; ++i) ext = ext || f.walk[i].kp.ignore_on != 0;
+    const auto narrow = ext ? launch_frame_narrow_ext : launch_frame_narrow;
+    const auto wide = ext ? launch_frame_wide_ext : launch_frame_wide;
+    if (!narrow(B, sc, f, s, &blocks)) return false;
     static const bool dbg = std::getenv("FS_DEBUG_FRAME") != nullptr;
     if (dbg) std::fprintf(stderr, "[launch_frame] blocks %u stack_worst %d rows %d limit %d\n", blocks, sc.stack_worst, sc.stack_rows, sc.stack_limit);
     bool dense = f.num_walk == 0;
@@ -204,9 +228,9 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
         DeviceScene w = sc;
         w.stack_rows = sc.stack_worst; w.stack_limit = sc.stack_worst; w.stack_attn = 0x7FFFFFFFu;
         w.deep = nullptr; w.deep_lanes = 0; w.deep_owner = nullptr;
-        return launch_frame_wide(B, w, f, s, nullptr);
+        return wide(B, w, f, s, nullptr);
     }
-    return launch_frame_narrow(B, sc, f, s, nullptr);
+    return narrow(B, sc, f, s, nullptr);
 }
 #endif
 

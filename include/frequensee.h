@@ -44,7 +44,7 @@
  *             fs_reconstruct_impulse_response_async fs_reconstruct_impulse_response_batch_async fs_synchronize fs_submit
  *             fs_set_pipelining fs_set_walk_stages fs_set_frames_per_launch
  *             fs_energy_device_ptr fs_energy_handoff fs_shard_range fs_comm_unique_id fs_comm_init fs_comm_attach
- *             fs_comm_enable_oneshot fs_comm_detach fs_peers_init fs_peers_detach fs_gather_energy fs_gather_energy_async
+ *             fs_comm_enable_oneshot fs_comm_detach fs_comm_info fs_peers_init fs_peers_detach fs_gather_energy fs_gather_energy_async
  *             fs_copy_band_impulse_response fs_set_impulse_response fs_trace_rays
  *             fs_save_array_to_file fs_load_float_array fs_save_impulse_response
  *             fs_reverb_init fs_reverb_process fs_reverb_release fs_apply_material_fd
@@ -335,6 +335,11 @@ int fs_comm_attach(fs_context* ctx, void* nccl_comm /* ncclComm_t */);
  * return FS_ERR_COMM after a bounded wait. */
 int fs_comm_enable_oneshot(fs_context* ctx);
 int fs_comm_detach(fs_context* ctx);   /* destroys a communicator made by fs_comm_init; fs_context_destroy calls it */
+/* What the attached communicator says about itself (ncclCommCount / ncclCommUserRank asked of RCCL now, not the configured
+ * values) and how the energy buffer is summed: *collective = 0 none (no communicator), 1 ncclAllReduce on the tail stream,
+ * 2 the one-shot peer-write exchange (fs_comm_enable_oneshot).  Without a communicator: *ranks = 0, *rank = -1.
+ * A measurement that reports these proves by itself how many ranks took part in its collective. */
+int fs_comm_info(fs_context* ctx, int32_t* ranks, int32_t* rank, int32_t* collective);
 /* cfg5 — independent sources, one per GPU ("optional ncclAllGather of 8 x 32 KB so any rank can serve any
  * source's IR").  Nothing of a frame is sharded or reduced there (fs_config.world_size stays 1); a PEER communicator
  * of the processes that each own a source serves one collective only:

@@ -223,3 +223,91 @@ def test_uncapped_frames_with_an_ignored_actor_or_end_point_spheres(pkg, oracle_
     e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=0, seed=77, source_object=7, **kw), sc.source, sc.listener)
     check_energy(got, e32, e64, 1)
     assert st["deposits"] == cnt.connected
+
+
+# ---- the walker's own actor on the fast path ------------------------------------------------------
+@pytest.mark.parametrize("fpl", [1, 2])
+@pytest.mark.parametrize("depth", [8, 0])
+def test_pipelined_frames_ignore_the_walkers_own_actor(pkg, oracle_mod, fpl, depth):
+    """GeneratePath always ignores the walking actor (AddIgnoredActor, ARTS.cpp:322-327).  Frames of a source with an actor of
+    its own (and of a listener with one) are held by fs_set_pipelining like any other — the fused launch's EXT flavour,
+    csrc/fs_frame_ext.hip — and give, bit for bit in deterministic mode, what a context that waits for every frame gives;
+    in fp32 mode the frame equals the oracle's with the same source_object."""
+    from test_round4 import _room_with_a_box_around_the_source
+    from test_gpu_parity import check_energy
+    sc, tris, mats, obj = _room_with_a_box_around_the_source(pkg)
+    rays = 16384
+
+    def make(pipe):
+        ctx = pkg.Context(num_bands=1)
+        ctx.set_scene(tris, mats, sc.absorption, object_ids=obj)
+        ctx.set_listener(sc.listener)
+        s = ctx.create_source(sc.source)
+        ctx.set_source_object(s, 7)
+        if pipe:
+            ctx.set_pipelining(2); ctx.set_frames_per_launch(fpl)
+        return ctx, s
+
+    plain, ps = make(False)
+    pipe, qs = make(True)
+    c0 = pipe.pipeline_counters()
+    for i in range(9):
+        p = pkg.default_params(num_rays=rays, depth=depth, seed=900 + i, flags=DET)
+        plain.compute_energy_response_async(ps, p); plain.reconstruct_impulse_response_async(ps, p)
+        pipe.compute_energy_response_async(qs, p); pipe.reconstruct_impulse_response_async(qs, p)
+    plain.synchronize(); pipe.synchronize()
+    c1 = pipe.pipeline_counters()
+    assert c1["fused_launches"] - c0["fused_launches"] >= 9 // fpl          # the frames WERE held
+    want_e, got_e = plain.energy_buffer(ps), pipe.energy_buffer(qs)
+    assert want_e.any() and np.array_equal(got_e, want_e)
+    assert np.array_equal(pipe.impulse_response(qs, 0), plain.impulse_response(ps, 0))
+    a, b = plain.stats(), pipe.stats()
+    for k in ("frames", "rays", "segments", "connections_tested", "deposits"):
+        assert a[k] == b[k], k
+    # fp32 mode against the oracle, through the pipelined context (the blocking call lets the held frames finish)
+    got = pipe.compute_energy_response(qs, pkg.default_params(num_rays=rays, depth=depth, seed=31)).copy()
+    osc = oracle_mod.Scene(tris, mats, sc.absorption)
+    osc.set_objects(obj)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, depth=depth, seed=31, source_object=7), sc.source, sc.listener)
+    assert cnt.connected > 0
+    check_energy(got, e32, e64, 1)
+    # the listener's actor instead: its walks ignore the box, the source's (inside the box) do not — trapped, no energy, also when held
+    pipe.set_source_object(qs)
+    pipe.set_listener_object(7)
+    p = pkg.default_params(num_rays=rays, depth=depth, seed=31, flags=DET)
+    for _ in range(4):
+        pipe.compute_energy_response_async(qs, p); pipe.reconstruct_impulse_response_async(qs, p)
+    pipe.synchronize()
+    assert not pipe.energy_buffer(qs).any()
+    plain.close(); pipe.close()
+
+
+def test_grouped_frames_keep_each_sources_actor(pkg, scene_factory):
+    """Two sources stream through one pipelined context, one with an actor of its own, one without: frames of the two are
+    never confused (a frame is traced with the actor of ITS source), whatever shares a launch with it."""
+    from test_round4 import _room_with_a_box_around_the_source
+    sc, tris, mats, obj = _room_with_a_box_around_the_source(pkg)
+
+    def make(pipe):
+        ctx = pkg.Context(num_bands=1)
+        ctx.set_scene(tris, mats, sc.absorption, object_ids=obj)
+        ctx.set_listener(sc.listener)
+        a = ctx.create_source(sc.source)                                                  # inside the box: needs its actor ignored
+        b = ctx.create_source(np.asarray(sc.source, np.float32) + np.float32(120.0))      # outside, no actor
+        ctx.set_source_object(a, 7)
+        if pipe:
+            ctx.set_pipelining(2); ctx.set_frames_per_launch(2)
+        return ctx, a, b
+
+    plain, pa, pb = make(False)
+    pipe, qa, qb = make(True)
+    for i in range(8):
+        p = pkg.default_params(num_rays=8192, depth=8, seed=40 + i, flags=DET)
+        for ctx, s in ((plain, pa if i % 3 else pb), (pipe, qa if i % 3 else qb)):
+            ctx.compute_energy_response_async(s, p); ctx.reconstruct_impulse_response_async(s, p)
+    plain.synchronize(); pipe.synchronize()
+    for s_plain, s_pipe in ((pa, qa), (pb, qb)):
+        assert plain.energy_buffer(s_plain).any()
+        assert np.array_equal(pipe.energy_buffer(s_pipe), plain.energy_buffer(s_plain))
+        assert np.array_equal(pipe.impulse_response(s_pipe, 0), plain.impulse_response(s_plain, 0))
+    plain.close(); pipe.close()
