@@ -38,7 +38,11 @@ CASES = [
     # arrays from scenes.material_lobes(scene) ("lobes": 1 is a fixture key, not a parameter)
     ("cfg1_shoebox_material_lobes", "shoebox", 1, 512, 6, 0x5EED, {"flags": 64, "lobes": 1}),
     ("cfg2_starter_room_material_lobes", "starter_room", 4, 2048, 8, 9, {"flags": 64, "lobes": 1}),
+    # BASELINE.json configs[4] (8 sources x 131 072 rays in old_mine, one listener): source 4 of the eight — what a batched frame
+    # must give that source ("source": k is a fixture key: the source sits at scene.extra_sources[k])
+    ("cfg5_multi_source", "old_mine", 8, 65536, 8, 0x5EED, {"source": 4}),
 ]
+FIXTURE_KEYS = ("lobes", "source")   # keys of `extra` that describe the fixture, not oracle parameters
 
 
 def main():
@@ -50,18 +54,19 @@ def main():
         sc = pkg.scenes.by_name(scene, bands)
         tau, sigma = pkg.scenes.material_lobes(sc) if extra.get("lobes") else (None, None)
         osc = oracle.Scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
-        p = oracle.default_params(num_pairs=pairs, depth=depth, seed=seed, **{k: v for k, v in extra.items() if k != "lobes"})
-        e32, e64, cnt = osc.compute_energy_mt(p, sc.source, sc.listener, threads=8) if pairs > 20000 else \
-            osc.compute_energy(p, sc.source, sc.listener)
+        p = oracle.default_params(num_pairs=pairs, depth=depth, seed=seed, **{k: v for k, v in extra.items() if k not in FIXTURE_KEYS})
+        src_pos = sc.extra_sources[int(extra["source"])] if "source" in extra else sc.source
+        e32, e64, cnt = osc.compute_energy_mt(p, src_pos, sc.listener, threads=8) if pairs > 20000 else \
+            osc.compute_energy(p, src_pos, sc.listener)
         if pairs > 20000:  # the literal sequential-f32 histogram needs the single-threaded order
-            e32 = osc.compute_energy(p, sc.source, sc.listener)[0]
+            e32 = osc.compute_energy(p, src_pos, sc.listener)[0]
         ir = np.stack([oracle.reconstruct(e32[b]) for b in range(bands)])
         mean_e = (e32.astype(np.float32).sum(axis=0, dtype=np.float32) / np.float32(bands)).astype(np.float32) \
             if bands > 1 else e32[0]
         rng = np.random.default_rng(seed)
         lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
         n_rays = 256
-        o = np.where(rng.random((n_rays, 1)) < 0.5, sc.source + rng.normal(0, 50, (n_rays, 3)),
+        o = np.where(rng.random((n_rays, 1)) < 0.5, src_pos + rng.normal(0, 50, (n_rays, 3)),
                      rng.uniform(lo, hi, (n_rays, 3))).astype(np.float32)
         d = rng.normal(size=(n_rays, 3))
         d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)

@@ -1337,6 +1337,8 @@ def test_gpu_matches_golden(pkg, scene_factory, path):
     if extra.pop("lobes", 0):      # fixture key: seeded Transmission / Scattering arrays on the scene (row f4)
         tau, sigma = pkg.scenes.material_lobes(sc)
         ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption, transmission=tau, scattering=sigma)
+    if "source" in extra:          # fixture key: the source sits at one of the scene's extra positions (cfg5)
+        src = ctx.create_source(sc.extra_sources[int(extra.pop("source"))])
     p = pkg.default_params(num_rays=2 * int(z["pairs"]), depth=int(z["depth"]), seed=int(z["seed"]), **extra)
     e = ctx.compute_energy_response(src, p)
     assert np.array_equal(e != 0, z["energy_f32"] != 0)

@@ -253,7 +253,7 @@ def test_staged_walks_of_waited_frames_equal_the_walk_in_one_piece(pkg, oracle_m
 
 
 # ---- cfg5 at its full size ---------------------------------------------------------------------------------------
-def test_cfg5_full_size_batched_frame_equals_eight_frames(pkg, scene_factory):
+def test_cfg5_full_size_batched_frame_equals_eight_frames(pkg, oracle_mod, scene_factory):
     """BASELINE.json configs[4] at full size: 8 sources x 131 072 rays, one listener, depth 8, 8 bands, as ONE batched
     frame (what bench.py times for cfg5 on one GPU) must give every source exactly the histogram and IR of its own frame —
     bit for bit in deterministic mode — also pipelined, and with the batched reconstruct."""
@@ -277,6 +277,24 @@ def test_cfg5_full_size_batched_frame_equals_eight_frames(pkg, scene_factory):
             assert np.array_equal(ctx.energy_buffer(s), e) and np.array_equal(ctx.impulse_response(s, 0), ir)
     st = ctx.stats()
     assert st["rays"] == 3 * 8 * 131072
+    # ... and the batched frame against the ORACLE at full size (round 5): source 4 of the eight, fp32 mode — the committed
+    # fixture tests/golden/cfg5_multi_source.npz (the oracle's frame of that source alone) and the oracle itself on all cores
+    import os
+    from test_gpu_parity import check_energy
+    pf = pkg.default_params(num_rays=131072, depth=8, seed=0x5EED)
+    ctx.set_pipelining(0)
+    ctx.compute_energy_response_batch_async(srcs, pf)
+    ctx.synchronize()
+    got = ctx.energy_buffer(srcs[4]).copy()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg5_multi_source.npz"))
+    assert int(z["pairs"]) == 65536 and int(z["depth"]) == 8 and int(z["seed"]) == 0x5EED
+    check_energy(got, z["energy_f32"], z["energy_f64"], 8)
+    assert ctx.stats()["deposits"] - st["deposits"] >= int(z["connected"])      # (the batch's counters cover all eight sources)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy_mt(oracle_mod.default_params(num_pairs=65536, depth=8, seed=0x5EED), pos[4], sc.listener, threads=8)
+    assert cnt.connected == int(z["connected"])
+    for b in range(8):
+        assert rel_rms(got[b], e64[b]) <= TIGHT_TOL
     ctx.close()
 
 
