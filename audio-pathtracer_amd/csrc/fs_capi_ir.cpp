@@ -77,8 +77,14 @@ int fs_update_sources(fs_context* ctx, const fs_source* sources, int32_t count, 
     if (count == 0) return FS_OK;
     fs_params def;
     if (!p) { fs_params_default(&def); p = &def; }
+    if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
     std::vector<Source*> srcs((size_t)count);
     int rc = FS_OK;
+    // depth = 0 only: a tick whose record store overflowed is traced and reconstructed again (up to 4 attempts; the store has been
+    // grown meanwhile).  Its reconstruct rode behind the frame without a wait in between — that wait would cost every tick of the
+    // reference's own mode ~ 15 us for an event of the first few ticks at most — so the impulse responses (and sequence numbers)
+    // published by an attempt that then reports FS_ERR_OVERFLOW are PROVISIONAL: the next attempt publishes the complete ones
+    // behind them, and only after the last failed attempt does an incomplete IR stay in front (the call returns FS_ERR_OVERFLOW).
     for (int attempt = 0; attempt < 4; ++attempt) {
         rc = fs_compute_energy_response_batch_async(ctx, sources, count, p);
         if (rc) return rc;

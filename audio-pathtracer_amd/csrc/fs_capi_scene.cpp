@@ -170,6 +170,11 @@ static int refresh_coop_nodes(fs_context* ctx, bool topology_changed) {
     // one-node-at-a-time descents: 15 new entries per 16-wide level at most; the 4-wide tree's bound is the builder's (+ the popped node's four)
     ctx->coop_info.wide16 = CoopView{ctx->d_coop16, 0, ctx->coop16_nodes, 4, (int16_t)(15 * ((ctx->coop_levels + 1) / 2) + 1)};
     ctx->coop_info.wide4 = CoopView{ctx->d_coop, 0, (int32_t)n, 2, (int16_t)(std::max(ctx->bvh.stack_need, 2) + 4)};
+    // The cooperative records hold ABSOLUTE world coordinates rounded outwards to fp16 (fs_refit.hip): conservative at any size,
+    // but the fp16 ulp is 8 units at 10^4 and 16 - 32 at a few 10^4 (beyond 65 504 the planes are infinite): on a large map the
+    // boxes stop culling and the search degenerates silently.  Such scenes take the lane-private traversal (node-relative 8-bit
+    // grids) for their small frames instead: coop_view finds no usable record array.
+    if (ctx->amax > kCoopMaxCoordinate) { ctx->coop_info.wide16.rec = nullptr; ctx->coop_info.wide4.rec = nullptr; }
     static const bool dbg_info = std::getenv("FS_DEBUG_SCENE_INFO") != nullptr;   // (what DESIGN.md quotes)
     if (dbg_info)
         std::fprintf(stderr, "[frequensee] tree: %zu 4-wide nodes in %d levels -> %d 16-wide nodes\n", n, levels, ctx->coop16_nodes);

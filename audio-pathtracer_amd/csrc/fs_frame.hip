@@ -82,15 +82,19 @@ __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(Devic
         b -= a.connect_blocks;
     }
     const uint32_t cb = a.connect_first ? 0u : a.connect_blocks;   // connect workgroups behind the walk parts
+    // which walk part this workgroup belongs to (a scalar search; the walk itself runs OUTSIDE the loop: inside it every value
+    // that is live across the walk was loop-carried as far as the register allocator could tell)
     uint32_t first = 0;
+    int part = -1;
     for (int i = 0; i < a.num_walk; ++i) {
-        const WalkArgs& w = a.walk[i];
-        if (b < w.block_end) {
-            if (w.rays_per_wave < 64) walk_sparse_body<0, false, false, FS_FRAME_EXT_ON>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.rays_per_wave, w.stage);
-            else walk_shared_body<0, false, false, FS_FRAME_EXT_ON>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.stage);
-            return;
-        }
-        first = w.block_end;
+        if (b < a.walk[i].block_end) { part = i; break; }
+        first = a.walk[i].block_end;
+    }
+    if (part >= 0) {
+        const WalkArgs& w = a.walk[part];
+        if (w.rays_per_wave < 64) walk_sparse_body<0, false, false, FS_FRAME_EXT_ON>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.rays_per_wave, w.stage);
+        else walk_shared_body<0, false, false, FS_FRAME_EXT_ON>(b - first, sc, w.kp, w.st, w.scratch, w.perm, w.stage);
+        return;
     }
     if (b < first + cb) {
         connect_body<B, 0, BATCH, false>(b - first, a.connect_blocks, sc, a.kpc, a.stc, a.energy, a.fixed, a.scratch_c,

@@ -81,6 +81,7 @@ struct CoopView {
     int16_t wshift, stack_need;
 };
 struct CoopInfo { CoopView wide16{}, wide4{}; };
+constexpr float kCoopMaxCoordinate = 16384.0f;   // largest |coordinate| (UE units) of a scene whose small frames use the cooperative traversal (fp16 ulp 8 there)
 
 // Per-lane traversal stack in LDS: DeviceScene.stack_rows rows of kBlock ints, sized at run time from the committed
 // tree (its worst-case need + kStackSlack), passed as dynamic shared memory.  A node visit that pushes writes its

@@ -12,9 +12,12 @@
  * Conventions: extern "C", POD only, every call returns an int status (FS_OK == 0), no exception
  * crosses the boundary, output buffers are caller-allocated, handles are opaque.  Positions are
  * Unreal units (cm).  One context drives one HIP device.  Its tracing is ordered on one HIP stream (the
- * "compute" stream: its own, or the caller's via fs_config.stream); the tail of a frame — a caller's
- * multi-GPU reduce, the reconstruct and the publish of the impulse response — runs on a second stream of
- * the context, concurrently with the next frame's tracing (fs_energy_handoff).  A context is not re-entrant:
+ * "compute" stream: its own, or the caller's via fs_config.stream).  On one GPU the reconstruct and the publish of
+ * the impulse response ride on that stream too: the reconstruct workgroups write the pinned host ring slot themselves
+ * and announce it in a pinned host word — no second queue, no copy command, no event in the steady state of a stream
+ * of frames.  The context's second ("tail") stream carries what has to run beside the tracing: a multi-GPU reduce
+ * (the library's or a caller's behind fs_energy_handoff) with the reconstruct of such a frame, and the few reconstructs
+ * with per-kernel timing or a literal second flush.  A context is not re-entrant:
  * one producer thread (the game thread) calls compute/reconstruct; concurrently with it any number of threads may
  * read published impulse responses (fs_get_impulse_response), and ONE audio render thread may run the reverb callback
  * (fs_reverb_process) — it has a HIP stream of its own and is never queued behind a traced frame.
@@ -411,7 +414,9 @@ int fs_synchronize(fs_context* ctx);
 /* UpdateSources (ARTS.cpp:100-126) as the game thread runs it: one UpdateSource (:128-195) for every listed source — trace,
  * deposit, reconstruct — and every IR is in its published host buffer when the call returns.  = the batched compute call +
  * the batched reconstruct + fs_synchronize, with the reconstructs riding on the compute stream (nothing else to overlap
- * with when the caller waits); a depth = 0 frame whose records overflowed is traced again like fs_compute_energy_response. */
+ * with when the caller waits); a depth = 0 frame whose records overflowed is traced again like fs_compute_energy_response
+ * — the impulse responses (and sequence numbers) such a failed attempt published meanwhile are PROVISIONAL: the retry publishes
+ * the complete ones behind them before the call returns (a concurrent reader may see one for a few hundred microseconds). */
 int fs_update_sources(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 
 /* GetImpulseResponse() (FSAC.h:113): pointer to the PUBLISHED [num_samples] channel buffer, valid

@@ -311,3 +311,27 @@ def test_grouped_frames_keep_each_sources_actor(pkg, scene_factory):
         assert np.array_equal(pipe.energy_buffer(s_pipe), plain.energy_buffer(s_plain))
         assert np.array_equal(pipe.impulse_response(s_pipe, 0), plain.impulse_response(s_plain, 0))
     plain.close(); pipe.close()
+
+
+# ---- the cooperative traversal's fp16 boxes on a large map --------------------------------------------
+def test_small_frames_far_from_the_origin(pkg, oracle_mod, scene_factory):
+    """A tick-sized frame (the cooperative traversal's domain) in a scene 300 m from the origin: beyond 16 384 units the
+    fp16 world-space boxes of the cooperative records stop culling, so such scenes use the lane-private traversal for their
+    small frames — results equal the oracle's either way (closest hits do not depend on the tree)."""
+    from test_gpu_parity import check_energy
+    sc = scene_factory("starter_room", 1)
+    off = np.array([30000.0, -21000.0, 500.0], np.float32)
+    tris = (np.asarray(sc.triangles, np.float32).reshape(-1, 3, 3) + off).astype(np.float32)
+    ctx = pkg.Context(num_bands=1)
+    ctx.set_scene(tris, sc.material_ids, sc.absorption)
+    lis = (np.asarray(sc.listener, np.float32) + off).astype(np.float32)
+    srcp = (np.asarray(sc.source, np.float32) + off).astype(np.float32)
+    ctx.set_listener(lis)
+    s = ctx.create_source(srcp)
+    p = pkg.default_params(num_rays=2000, depth=0, seed=11, flags=pkg._capi.FLAG_FIXED_NORM_1000)
+    got = ctx.compute_energy_response(s, p).copy()
+    osc = oracle_mod.Scene(tris, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=1000, depth=0, seed=11, flags=oracle_mod.FLAG_FIXED_NORM_1000), srcp, lis)
+    assert cnt.connected > 0
+    check_energy(got, e32, e64, 1)
+    ctx.close()
