@@ -212,7 +212,7 @@ hipEvent_t take_event(fs_context* ctx) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    (void)hipEventCreateWithFlags(&e, hipEventReleaseToDevice);   // (timing events: no system-scope cache flush between the kernels they time)
     return e;
 }
 

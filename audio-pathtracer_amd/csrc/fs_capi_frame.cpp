@@ -320,7 +320,12 @@ static int drain_fused(fs_context* ctx) {
         }
         OwedLaunch owed;
         { const int orc = owed_prepare(ctx, fp, owed); if (orc) return orc; }
-        if (!(fp.num_walk > 0 || fp.has_connect || fp.num_recon > 0)) break;   // (nothing a launch could carry: the loop below finishes the rest)
+        if (!(fp.num_walk > 0 || fp.has_connect || fp.num_recon > 0)) {
+            // nothing a launch could carry.  With a communicator the reconstructs of the frames just summed become due one round
+            // later (ReconOwed::age, raised by owed_prepare): go round again; anything else is left to the loop in flush_pending.
+            if (!ctx->recon_owed.empty() && ctx->recon_owed.front().reduced && ctx->recon_owed.front().age >= 1) continue;
+            break;
+        }
         const bool fused = launch_frame(B, ctx->scene, fp, ctx->stream);
         ctx->dbg.launches++;
         if (!fused) {   // no fused form: the same passes one after the other
@@ -348,7 +353,10 @@ int flush_pending(fs_context* ctx) {
     if (dbg) t0 = clk::now();
     if (!ctx->group.empty()) { const int gr = dispatch_group(ctx); if (gr) return gr; }
     if (dbg) t1 = clk::now();
-    if (ctx->fused_drain && ctx->fused_recon && !ctx->comm && ctx->cfg.world_size == 1 && ctx->profiling < 2 &&
+    // (one GPU, or the pairs of a frame shared between ranks with the LIBRARY's collective: the sums over the ranks go onto the
+    // tail stream as before, the reconstructs ride behind them in the drain's launches and publish through the host word)
+    const bool drainable = (!ctx->comm && ctx->cfg.world_size == 1) || (ctx->comm != nullptr && ctx->fused_recon_comm);
+    if (ctx->fused_drain && ctx->fused_recon && drainable && ctx->profiling < 2 &&
         (!ctx->held.empty() || !ctx->recon_owed.empty())) {
         FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
         const int dr = drain_fused(ctx);
@@ -568,8 +576,8 @@ int ensure_energy_buffer(fs_context* ctx, Source* s, int b) {
     const size_t eb = sizeof(float) * (size_t)ctx->cfg.num_bands * (size_t)ctx->num_bins;
     FS_HIP(ctx, hipMalloc((void**)&s->d_energy[b], eb));
     FS_HIP(ctx, hipMemsetAsync(s->d_energy[b], 0, eb, ctx->stream));
-    if (!s->ev_rec[b]) FS_HIP(ctx, hipEventCreateWithFlags(&s->ev_rec[b], hipEventDisableTiming));
-    if (!s->ev_red[b]) FS_HIP(ctx, hipEventCreateWithFlags(&s->ev_red[b], hipEventDisableTiming));
+    if (!s->ev_rec[b]) FS_HIP(ctx, hipEventCreateWithFlags(&s->ev_rec[b], kDeviceEventFlags));
+    if (!s->ev_red[b]) FS_HIP(ctx, hipEventCreateWithFlags(&s->ev_red[b], kDeviceEventFlags));
     return FS_OK;
 }
 
@@ -1144,7 +1152,7 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
     for (int i = 0; i < kEnergyBufsBase; ++i) {   // (the rest of the rotation: at first use, ensure_energy_buffer)
         if ((e = hipMalloc((void**)&s->d_energy[i], eb)) != hipSuccess) return bail(e, "hipMalloc(energy)");
         if ((e = hipMemsetAsync(s->d_energy[i], 0, eb, ctx->stream)) != hipSuccess) return bail(e, "hipMemsetAsync");
-        if ((e = hipEventCreateWithFlags(&s->ev_rec[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&s->ev_rec[i], kDeviceEventFlags)) != hipSuccess) return bail(e, "hipEventCreate");
     }
     // the device-resident IR set: [B + 1][samples] — the bands, then the channel view (the fused launch derives the one from the other)
     if ((e = hipMalloc((void**)&s->d_ir_bands, ib * (size_t)(ctx->cfg.num_bands + 1))) != hipSuccess) return bail(e, "hipMalloc(ir_bands)");
@@ -1156,10 +1164,10 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
         std::memset(s->h_ir[i], 0, ib);  // ImpulseBuffer[ch].Init(0, NumSamples) FSAC.cpp:24-28
         if ((e = hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     }
-    if ((e = hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&s->ev_dep, kDeviceEventFlags)) != hipSuccess) return bail(e, "hipEventCreate");
     for (int i = 0; i < kEnergyBufsBase; ++i)
-        if ((e = hipEventCreateWithFlags(&s->ev_red[i], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipEventCreateWithFlags(&s->ev_rev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&s->ev_red[i], kDeviceEventFlags)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&s->ev_rev, kDeviceEventFlags)) != hipSuccess) return bail(e, "hipEventCreate");
     // the initial fills above ran on the compute stream; the first reconstruct runs on the tail stream
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     s->alive = true;

@@ -60,6 +60,14 @@ constexpr int kScratchSets = kMaxSets;
 static_assert(kMaxSets >= kMaxWalkParts + 3, "a staged frame is in flight for stages + 2 launches and its buffer is read one more");
 static_assert(kEnergyBufs >= 4 * (kMaxWalkParts + 3), "four frames of one source per launch, each owning its buffer for stages + 3 launches");
 
+// Events that order work of two streams of the SAME device (the compute stream's hand-over to the tail stream, the sum over the
+// ranks back to the compute stream, the reverb stream's reads): a DEVICE-scope release.  The default — a system-scope fence when
+// the event is recorded — writes every dirty L2 line back and invalidates the caches: behind a frame kernel that has just written
+// 100 MB of records that is tens of microseconds in which nothing runs, and the next launch starts on cold caches
+// (tools/rccl_tax.sh: a one-rank communicator cost 7.5 % of the plain rate with default events).  Events the HOST inspects
+// before it reads host memory (the publishes' ev[slot], tail_batch_ev) keep the system scope.
+constexpr unsigned kDeviceEventFlags = hipEventDisableTiming | hipEventReleaseToDevice;
+
 struct Source {
     bool alive = false;
     float pos[3] = {0, 0, 0};
