@@ -590,6 +590,15 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
         ctx->sync_stage_bounds = b;   // empty: such frames walk in one piece
     }
     if (const char* v = std::getenv("FS_SYNC_STAGE_FROM")) ctx->sync_stage_from = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("FS_SYNC_STAGE_RPW")) {
+        for (const char* q = v; *q;) {
+            char* end = nullptr;
+            const long x = std::strtol(q, &end, 10);
+            if (end == q) break;
+            ctx->sync_stage_rpw.push_back((int)std::max(0l, std::min(64l, x)));
+            q = *end ? end + 1 : end;
+        }
+    }
     if (const char* v = std::getenv("FS_SOUND_RAYS_PER_WAVE")) ctx->sound_rays_per_wave = std::max(1, std::min(64, std::atoi(v)));
     e = hipMalloc((void**)&ctx->walk.queue_head, sizeof(unsigned) * kScratchSets * kScratchAllocWords);   // each set with its counters
     if (e == hipSuccess) e = hipMemset(ctx->walk.queue_head, 0, sizeof(unsigned) * kScratchSets * kScratchAllocWords);

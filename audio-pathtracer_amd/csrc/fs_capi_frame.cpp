@@ -1009,6 +1009,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
                 wk.rays_per_wave = k == 0 ? (ctx->sync_first_rays_per_wave > 0 ? ctx->sync_first_rays_per_wave : (2ull * kp.num_local >= 131072ull ? 32 : 16)) :
                                    ctx->sync_late_rays_per_wave > 0 ? ctx->sync_late_rays_per_wave :
                     auto_rays_per_wave(walk_stage_slots(kp, f.stages[k].begin), std::min(kp.depth, f.stages[k].end) - f.stages[k].begin, k > 0 ? 8192ull : 0ull);
+            if (ctx->walk_rays_per_wave <= 0 && k < ctx->sync_stage_rpw.size() && ctx->sync_stage_rpw[k] > 0) wk.rays_per_wave = ctx->sync_stage_rpw[k];
             WalkStage sr = f.stages[k];
             const uint32_t* rebin = nullptr;
             if ((ctx->debug_rebin == 1 || ctx->debug_rebin == 2) && k > 0 && wk.rays_per_wave >= 64) {   // (experiment: DESIGN.md section 5)

@@ -296,6 +296,7 @@ struct fs_context {
     std::vector<int> sync_stage_bounds;   // the same for depth = 0 frames that are waited for (stages back to back; FS_SYNC_WALK_STAGES)
     int sync_first_rays_per_wave = 0;     // subpaths per wave of the first stage, 0 = by frame size (FS_SYNC_FIRST_RPW)
     int sync_late_rays_per_wave = 0;      // subpaths per wave of the later stages, 0 = by the number of survivors (FS_SYNC_LATE_RPW)
+    std::vector<int> sync_stage_rpw;      // subpaths per wave of stage k of such a frame, overriding the two above where > 0 (FS_SYNC_STAGE_RPW: "32,64,0")
     int sync_stage_from = 16384;          // ... of at least this many subpaths (smaller frames: every walk has a wave of its own anyway)
     int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
     std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
