@@ -2250,20 +2250,33 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 constexpr int kChunk = FS_RECON_CHUNK;
 constexpr int kWarm = 96;
 // A publish without the host's help: the reconstruct workgroups of a launch write the channel views straight into the sources'
-// pinned host ring slots; every one of them, once its stores have been acknowledged (system-scope fence by every wave: a wave's
-// s_waitcnt only covers its own stores), takes a ticket, and the workgroup that takes the last one stores the launch's id into
-// the context's pinned host word with a system-scope release — fs_get_impulse_response* and the ring's back-pressure read that
-// word, no event, no copy command, no second stream (fs_capi_frame.cpp: owed_publish).  The ticket cell re-arms itself.
+// pinned host ring slots; every one of them, once its stores have been acknowledged, takes a ticket, and the workgroup that takes
+// the last one stores the launch's id into the context's pinned host word — fs_get_impulse_response* and the ring's back-pressure
+// read that word: no event, no copy command, no second stream (fs_capi_frame.cpp: owed_publish).  The ticket cell re-arms itself.
+// The samples go to the host with SYSTEM-scope stores (store_sys: sc0 sc1 — written through to the host before they are
+// acknowledged), so a wave whose store counter has run out (s_waitcnt vmcnt(0): on gfx9 stores count there too) knows that its
+// samples are where the host reads them; the barrier collects the workgroup's waves, the tickets the launch's workgroups, and the
+// word — a system-scope store as well — is issued only then: it can never overtake the samples.  Two things that do NOT work:
+// plain stores + the counter (the word overtook the samples: tests/test_round3.py's stream of grouped frames read 6 of 7
+// publishes too early — plain stores to fine-grained memory are acknowledged by the L2, not by the host), and a system-scope
+// FENCE per wave (__threadfence_system(): correct, but it also writes back every dirty L2 line of the chip each time: the 3 072
+// reconstruct workgroups of a 128-source tick paid 0.27 ms for it, the fused frame kernel 3 %).
+__device__ __forceinline__ void store_sys(float* p, const float4 v) {   // 16 bytes, system scope (p 16-byte aligned)
+    typedef float sys_v4f __attribute__((ext_vector_type(4)));
+    const sys_v4f x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void store_sys(float* p, const float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void publish_arrive(unsigned* __restrict__ tickets, unsigned total, unsigned long long* __restrict__ host_word,
                                                unsigned long long id) {
     if (tickets == nullptr) return;                       // (uniform: this launch is published through an event)
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t + 1u == total) {
             __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next launch of the stream starts behind this one)
-            __hip_atomic_store(host_word, id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_word, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -2342,13 +2355,13 @@ __device__ __forceinline__ void reconstruct_body(const int row, const int chunk_
                 o.x = s_stage[s + s / kChunk]; o.y = s_stage[s + 1 + (s + 1) / kChunk];
                 o.z = s_stage[s + 2 + (s + 2) / kChunk]; o.w = s_stage[s + 3 + (s + 3) / kChunk];
                 if (out) *reinterpret_cast<float4*>(out + base + s) = o;
-                if (to_host) *reinterpret_cast<float4*>(host_out + base + s) = o;
+                if (to_host) store_sys(host_out + base + s, o);
             } else {
                 for (int e = 0; e < 4; ++e)
                     if (base + s + e < num_samples) {
                         const float y1 = s_stage[s + e + (s + e) / kChunk];
                         if (out) out[base + s + e] = y1;
-                        if (to_host) host_out[base + s + e] = y1;
+                        if (to_host) store_sys(host_out + base + s + e, y1);
                     }
             }
         }
@@ -2455,13 +2468,13 @@ __device__ __forceinline__ void reconstruct_body_fast(const int row, const int c
             o.x = s_stage[sidx + sidx / kChunk]; o.y = s_stage[sidx + 1 + (sidx + 1) / kChunk];
             o.z = s_stage[sidx + 2 + (sidx + 2) / kChunk]; o.w = s_stage[sidx + 3 + (sidx + 3) / kChunk];
             if (out) *reinterpret_cast<float4*>(out + base + sidx) = o;
-            if (to_host) *reinterpret_cast<float4*>(host_out + base + sidx) = o;
+            if (to_host) store_sys(host_out + base + sidx, o);
         } else {
             for (int e = 0; e < 4; ++e)
                 if (base + sidx + e < num_samples) {
                     const float y1 = s_stage[sidx + e + (sidx + e) / kChunk];
                     if (out) out[base + sidx + e] = y1;
-                    if (to_host) host_out[base + sidx + e] = y1;
+                    if (to_host) store_sys(host_out + base + sidx + e, y1);
                 }
         }
     }
