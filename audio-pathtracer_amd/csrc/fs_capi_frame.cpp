@@ -1,561 +1,7 @@
-// fs_capi_frame.cpp — sources, the traced frame (UpdateSource, ARTS.cpp:128-195) and its pipeline, reconstruct /
-// publish, impulse-response and energy-buffer access (C ABI: include/frequensee.h).
+// fs_capi_frame.cpp — sources and the traced frame (UpdateSource, ARTS.cpp:128-195): describe / resources / commit / launch,
+// grouped frames, and the entry points of the hot call (C ABI: include/frequensee.h).  The pipeline around it (held frames, the
+// flush) is fs_capi_pipeline.cpp, reconstruct + publish fs_capi_publish.cpp.
 #include "fs_context.hpp"
-
-#include <chrono>
-
-namespace fsi {
-
-// depth = 0 frames: did a walk's record miss both tiers?  (Called where the compute stream has just been synchronised.)
-// Then the frame's energy is incomplete: the tier is grown for the next attempt and the caller is told.
-int check_overflow(fs_context* ctx) {
-    if (!ctx->overflow_armed || !ctx->h_overflow) return FS_OK;
-    ctx->overflow_armed = false;
-    unsigned flag = *reinterpret_cast<volatile unsigned*>(ctx->h_overflow);   // (pinned host word, the stream has been synchronised)
-    if (ctx->comm) {
-        // sharded frame: the ranks must agree — a rank that traced the frame again alone would issue one all-reduce more
-        // than the others.  Every rank armed the word for the same frames, so every rank gets here: MAX over the ranks
-        // (through the context's device staging: the communicator sums device memory).
-        RcclApi* a = rccl();
-        if (!a) return ctx->fail(FS_ERR_COMM, "communicator attached but librccl is not loadable");
-        unsigned* d = reinterpret_cast<unsigned*>(ctx->d_comm_stage);
-        FS_HIP(ctx, hipMemcpyAsync(d, &flag, sizeof(flag), hipMemcpyHostToDevice, ctx->stream));
-        FS_NCCL(ctx, a->AllReduce(d, d, 1, ncclUint32, ncclMax, ctx->comm, ctx->stream));
-        FS_HIP(ctx, hipMemcpyAsync(&flag, d, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
-        FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    if (!flag) return FS_OK;
-    *reinterpret_cast<volatile unsigned*>(ctx->h_overflow) = 0u;
-    // two things can overflow: the second record tier (more walks beyond FS_MAX_DEPTH steps than it has slots) and the
-    // lanes of a later stage of a staged walk (more survivors than provisioned) — the retry gets more of both
-    ctx->stage_margin = std::min(ctx->stage_margin * 2.0f, 64.0f);
-    const uint32_t grown = (uint32_t)std::min<uint64_t>((uint64_t)std::max<uint32_t>(ctx->over_cap, 16) * 4, 1u << 28);
-    if (ctx->d_over_np) (void)hipFree(ctx->d_over_np);
-    if (ctx->d_over_mat) (void)hipFree(ctx->d_over_mat);
-    if (ctx->d_over_pos) (void)hipFree(ctx->d_over_pos);
-    ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->over_cap_pos = 0;
-    ctx->over_cap = grown;   // ensure_state allocates at this size next time
-    return ctx->fail(FS_ERR_OVERFLOW, "depth = 0: more walks than expected outlived " + std::to_string(FS_MAX_DEPTH) +
-                     " steps; the record tier has been grown — trace the frame again");
-}
-
-// ---- pipelined frames ---------------------------------------------------------------------------------------------
-namespace {
-// What a held frame still owes once its connect pass has been enqueued: the fixed-point -> fp32 rounding, the sum over
-// the ranks, and the reconstruct the caller asked for in the meantime.  The source may already have moved on to later
-// frames (cur rotated): the per-frame fields are switched back for the duration.
-// A reconstruct that no launch is fused with (a flush: fs_submit, fs_synchronize, an observer): on one GPU it goes onto the
-// COMPUTE stream as a batch of one — the kernel writes the published host slot itself, nothing crosses to the tail stream.
-// (Through the tail stream — a handoff event, a kernel and a copy on the priority queue while the compute queue is busy — one
-// flush in three took 6 ms longer than the others on the pool's boxes: tools/repeat_driver_bench.py, the driver's 20-step
-// region read 440 or 880 M rays/s.)  FS_FLUSH_RECON_ON_COMPUTE=0 restores the tail-stream path.
-static int flush_reconstruct(fs_context* ctx, Source* s, const fs_params* p) {
-    if (ctx->flush_recon_on_compute && !ctx->comm && ctx->cfg.world_size == 1) { Source* one = s; return reconstruct_batch(ctx, &one, 1, p, true); }
-    return reconstruct_now(ctx, s, p);
-}
-
-static int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false, bool tail_waits_already = false, bool draining = false) {
-    // the items of a frame were connected by ONE launch: once the tail stream waits behind it (the first item's handoff),
-    // the other items' reconstructs are ordered too — no further event pairs on the compute stream (each is a bubble
-    // between its launches).  Not in deterministic mode: every item's fixed-point rounding runs on the compute stream first.
-    // (tail_waits_already: the publishes of this very launch's reconstruct parts made the tail stream wait behind it)
-    bool tail_behind_launch = tail_waits_already;
-    const bool flushing = !may_defer_recon || draining;   // called by flush_pending: nothing will be launched behind this frame that its reconstructs could overlap
-    // the reconstructs of a frame ride in the next launch all together or not at all (a tail-stream reconstruct in between
-    // would have to run the deferred ones first, to keep the IRs in frame order)
-    int wanted = 0;
-    for (const fs_context::PipeFrame::Item& it : q.items) wanted += it.want_recon ? 1 : 0;
-    if (wanted + (int)ctx->recon_owed.size() > kMaxReconParts) may_defer_recon = false;
-    for (const fs_context::PipeFrame::Item& it : q.items) {
-        Source* s = it.s;
-        const bool moved_on = s->cur != it.cur;
-        const int cur = s->cur;
-        const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
-        s->cur = it.cur; s->cur_fixed = q.fixed; s->reduced = false; s->handed_off = false;
-        s->tail_ordered = tail_behind_launch && !q.fixed;
-        int rc = FS_OK;
-        if (q.fixed) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), ctx->cfg.num_bands * ctx->num_bins, ctx->stream);
-        if (ctx->comm) { rc = reduce_energy(ctx, s); if (!rc && s->tail_ordered) tail_behind_launch = true; }
-        if (!rc && it.want_recon) {
-            // plain reconstruct: it rides in the next fused launch (fs_context::recon_owed) — on one GPU; with the library's
-            // collective, in the launch after next, behind the all-reduce just enqueued on the tail stream
-            const bool single = !ctx->comm && ctx->cfg.world_size == 1;
-            const bool summed = ctx->comm != nullptr && ctx->fused_recon_comm && s->reduced && s->red_recorded[it.cur];
-            if (may_defer_recon && ctx->fused_recon && (single || summed) && ctx->profiling < 2 &&
-                !(it.recon.flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)) {
-                fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon; o.reduced = summed;
-                ctx->recon_owed.push_back(o);
-            } else {
-                // (steady state with more reconstructs than a launch has parts for — cfg5's eight sources: on the tail stream,
-                // beside the next launch; on the compute stream they cost the stream of frames a fifth: 899 -> 705 M rays/s)
-                rc = flushing ? flush_reconstruct(ctx, s, &it.recon) : reconstruct_now(ctx, s, &it.recon);
-                if (!rc && s->tail_ordered) tail_behind_launch = true;
-            }
-        }
-        if (moved_on) { s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered; }
-        if (rc) return rc;
-    }
-    return FS_OK;
-}
-
-// ---- reconstructs inside the fused launch ------------------------------------------------------------------------
-// The owed reconstructs become parts of the launch that is being assembled; their sources' IR mutexes are held from here
-// until the publishes are noted (a reverb callback must not slip a read of d_ir_mono between the two).
-// The launch publishes by itself (publish_arrive, fs_device.hpp): its reconstruct workgroups write the channel views into the
-// sources' pinned ring slots and the last of them stores the launch's id into the context's host word — no event, no copy
-// command, nothing on the tail stream (ReconstructImpulseResponse leaves the IR in the component's own buffer,
-// FSAC.cpp:377-378; GetImpulseResponse reads that buffer, FSAC.h:113).
-struct OwedLaunch {
-    std::vector<fs_context::ReconOwed> owed;
-    std::vector<uint64_t> seq;                             // publish number of each entry (ring slot = seq % kIrRing)
-    std::vector<char> newest;                              // the source's newest frame of the launch: its IR becomes the device-resident set
-    std::vector<std::unique_lock<std::mutex>> locks;
-    PublishWord pub;
-};
-// never overwrite the front buffer of the source's IR ring: at most kIrRing - 1 publishes in flight (publish seq reuses the
-// slot of seq - kIrRing, so publish seq - kIrRing + 1 must have completed before seq is enqueued).  `more`: publishes about
-// to be enqueued.  May block the host (the ring is the producer's only throttle) — call it without holding ir_mu.
-static int ir_ring_backpressure(fs_context* ctx, Source* s, int more) {
-    poll_published(ctx, s);
-    for (int j = 1; j <= more; ++j) {
-        if (s->enqueued + (uint64_t)j < (uint64_t)kIrRing) continue;
-        const uint64_t must = s->enqueued + (uint64_t)j + 1 - (uint64_t)kIrRing;
-        const int slot = (int)(must % kIrRing);
-        if (s->seq_of[slot] == must && s->front.load(std::memory_order_relaxed) < must) {
-            FS_HIP(ctx, sync_publish(ctx, s, slot));
-            poll_published(ctx, s);
-        }
-    }
-    return FS_OK;
-}
-// publish number `seq` of the source has been enqueued: through the compute stream's host word (word != 0), a tail-stream
-// batch's event (batch != 0) or the slot's own event.  (Readers look at enqueued, then seq_of, then the kind: written in reverse.)
-static void note_publish(fs_context* ctx, Source* s, uint64_t seq, int slot, uint64_t batch = 0, uint64_t word = 0) {
-    if (word) ctx->dbg.pub_word++; else ctx->dbg.pub_event++;
-    s->pub_word[slot] = word; s->pub_batch[slot] = batch; s->seq_of[slot] = seq; s->enqueued = seq;
-}
-// before the COMPUTE stream writes the source's device IR set: whoever reads or writes it on the tail stream goes first
-static hipError_t compute_waits_for_tail_ir(fs_context* ctx, Source* s) {
-    if (s->cur_pub_seq) {
-        const int slot = (int)(s->cur_pub_seq % kIrRing);
-        if (s->seq_of[slot] == s->cur_pub_seq && !s->pub_word[slot]) {   // (a reused slot: that publish completed long ago)
-            const uint64_t pb = s->pub_batch[slot];
-            hipError_t e = hipSuccess;
-            if (!pb) e = compute_waits_for(ctx, s->ev[slot]);
-            else if (!tail_batch_done(ctx, pb)) e = hipStreamWaitEvent(ctx->stream, tail_batch_event(ctx, pb), 0);
-            if (e != hipSuccess) return e;
-        }
-    }
-    if (s->rev_recorded) return compute_waits_for(ctx, s->ev_rev);   // a reverb callback may be reading d_ir_mono
-    return hipSuccess;
-}
-// a table slot of the batch kernel that its previous reader has certainly left
-static int acquire_recon_tab(fs_context* ctx, unsigned* slot_out) {
-    const unsigned slot_t = ctx->recon_tab_next++ % fs_context::kReconTabSlots;
-    if (ctx->recon_tab_batch[slot_t] && !tail_batch_done(ctx, ctx->recon_tab_batch[slot_t]))
-        FS_HIP(ctx, wait_event_polling(tail_batch_event(ctx, ctx->recon_tab_batch[slot_t])));
-    if (ctx->recon_tab_word[slot_t] && !pub_word_done(ctx, ctx->recon_tab_word[slot_t])) FS_HIP(ctx, wait_pub_word(ctx, ctx->recon_tab_word[slot_t]));
-    ctx->recon_tab_batch[slot_t] = 0; ctx->recon_tab_word[slot_t] = 0;
-    *slot_out = slot_t;
-    return FS_OK;
-}
-static int spb_of(const fs_context* ctx, const fs_params& p) {
-    return p.samples_per_bin > 0 ? p.samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);   // FSAC.cpp:324
-}
-
-static int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
-    if (ctx->recon_owed.empty()) return FS_OK;
-    size_t take = 0;   // the oldest entries that are due (frame order: a prefix); summed entries wait one launch (ReconOwed::reduced)
-    while (take < ctx->recon_owed.size() && take < (size_t)kMaxReconParts &&
-           (!ctx->recon_owed[take].reduced || ctx->recon_owed[take].age >= 1)) ++take;
-    for (size_t k = take; k < ctx->recon_owed.size(); ++k) ctx->recon_owed[k].age++;
-    if (take == 0) return FS_OK;
-    // (the entries leave recon_owed only when everything that can fail here has succeeded: on an error they are still owed
-    // and the next flush reconstructs them)
-    ol.owed.assign(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
-    const int B = ctx->cfg.num_bands;
-    std::vector<Source*> distinct;
-    for (const fs_context::ReconOwed& o : ol.owed)
-        if (std::find(distinct.begin(), distinct.end(), o.s) == distinct.end()) distinct.push_back(o.s);
-    std::sort(distinct.begin(), distinct.end());           // one locking order for every thread
-    // the ring's back-pressure BEFORE the IR mutexes are taken: it may wait for the GPU, and fs_reverb_process on the audio
-    // thread must never queue behind such a wait
-    for (Source* s : distinct) {
-        int more = 0;
-        for (const fs_context::ReconOwed& o : ol.owed) more += o.s == s ? 1 : 0;
-        const int br = ir_ring_backpressure(ctx, s, more);
-        if (br) { ol.owed.clear(); return br; }
-    }
-    auto bail = [&](int rc) { ol.owed.clear(); ol.seq.clear(); ol.newest.clear(); ol.locks.clear(); fp.num_recon = 0; return rc; };
-#define FS_OWED_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(ctx->hip_fail(e_, #call)); } while (0)
-    for (Source* s : distinct) ol.locks.emplace_back(s->ir_mu);
-    fp.num_recon = 0; fp.recon_B = B; fp.recon_nb = ctx->num_bins; fp.recon_samples = ctx->num_samples;
-    ol.pub = next_pub_word(ctx);
-    fp.pub = ol.pub;
-    for (size_t i = 0; i < ol.owed.size(); ++i) {
-        const fs_context::ReconOwed& o = ol.owed[i];
-        Source* s = o.s;
-        bool later = false;                                // a later frame of the same source in this launch?
-        for (size_t k = i + 1; k < ol.owed.size(); ++k) later = later || ol.owed[k].s == s;
-        uint64_t seq = s->enqueued + 1;                    // (the ring's back-pressure was applied above, before the mutexes)
-        for (size_t k = 0; k < i; ++k) seq += ol.owed[k].s == s ? 1 : 0;
-        // An IR that is superseded within the launch only goes to its ring slot (the channel row); the source's newest IR of the
-        // launch also becomes the device-resident set (the reverb's, fs_copy_band_impulse_response's).
-        if (!later) FS_OWED_HIP(compute_waits_for_tail_ir(ctx, s));
-        if (o.reduced && s->red_recorded[o.cur]) FS_OWED_HIP(compute_waits_for(ctx, s->ev_red[o.cur]));   // the sum over the ranks (done a launch ago)
-        ol.seq.push_back(seq); ol.newest.push_back(later ? 0 : 1);
-        fp.recon_spb[fp.num_recon] = spb_of(ctx, o.p);
-        FrameParts::Recon& r = fp.recon[fp.num_recon++];
-        r.energy = s->d_energy[o.cur]; r.ir = later ? nullptr : s->d_ir_bands; r.host = s->h_ir[(int)(seq % kIrRing)];
-    }
-#undef FS_OWED_HIP
-    ctx->recon_owed.erase(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
-    return FS_OK;
-}
-// behind the launch: note the publishes (the launch announces them itself); a source with a reverb also gets an event on the
-// compute stream for its callbacks to wait on
-static int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
-    if (ol.owed.empty()) return FS_OK;
-    const int B = ctx->cfg.num_bands;
-    if (!launched_fused) {   // no fused form for this launch: the same reconstructs as a batch kernel of their own, on the compute stream
-        unsigned slot_t = 0;
-        { const int ar = acquire_recon_tab(ctx, &slot_t); if (ar) return ar; }
-        ReconItem* tab = ctx->h_recon_tab + (size_t)slot_t * fs_context::kReconTabItems;
-        for (size_t i = 0; i < ol.owed.size(); ++i) {
-            const fs_context::ReconOwed& o = ol.owed[i];
-            tab[i].energy = o.s->d_energy[o.cur]; tab[i].ir_bands = ol.newest[i] ? o.s->d_ir_bands : nullptr;
-            tab[i].ir_mono = ol.newest[i] ? o.s->d_ir_mono : nullptr; tab[i].host = o.s->h_ir[(int)(ol.seq[i] % kIrRing)];
-            tab[i].spb = spb_of(ctx, o.p); tab[i].pad = 0;
-        }
-        launch_reconstruct_batch(tab, (int)ol.owed.size(), B, ctx->num_bins, ctx->num_samples, ctx->stream, ol.pub);
-        FS_HIP(ctx, hipGetLastError());
-        ctx->recon_tab_word[slot_t] = ol.pub.id;
-    }
-    ctx->pub_issued = ol.pub.id;
-    for (size_t i = 0; i < ol.owed.size(); ++i) {
-        const fs_context::ReconOwed& o = ol.owed[i];
-        Source* s = o.s;
-        s->rec_recorded[o.cur] = true; s->rec_on_compute[o.cur] = true; s->rec_batch[o.cur] = 0;
-        if (ol.newest[i]) {   // (ir_mu is held)
-            s->last_rec = o.cur; s->cur_pub_seq = 0; s->dev_ir_word = ol.pub.id;
-            if (s->d_ring) FS_HIP(ctx, hipEventRecord(s->ev_rec[o.cur], ctx->stream));   // fs_reverb_process reads d_ir_mono behind this
-        }
-        note_publish(ctx, s, ol.seq[i], (int)(ol.seq[i] % kIrRing), 0, ol.pub.id);
-    }
-    ol.locks.clear();
-    return FS_OK;
-}
-
-static void held_connect_part(const fs_context::PipeFrame& q, FrameParts& f) {
-    const fs_context::PipeFrame::Item& it = q.items[0];
-    f.has_connect = true; f.kpc = q.kp; f.stc = q.st; f.energy = it.s->d_energy[it.cur];
-    f.fixed = q.fixed ? it.s->d_fixed[it.cur] : nullptr; f.scratch_c = q.wl.queue_head; f.ppw = q.ppw;
-    f.energy_tab = q.energy_tab; f.fixed_tab = q.fixed_tab;
-}
-// rays per wave of a walk stage: by the number of walks it still has and the steps they have left at most
-static WalkLaunch stage_launch(const fs_context* ctx, const fs_context::PipeFrame& q, int stage) {
-    WalkLaunch wl = q.wl;
-    const WalkStage& sr = q.stages[(size_t)stage];
-    // inside a fused launch the chip is full: dense waves for every stage that still has a few thousand walks, sparse
-    // waves (the other lanes help with every query) only for the few long walks of the late stages, whose chain of
-    // dependent bounces is what matters (profiles/r03_stage_sweep.log: the stand-alone frames' rule — ~4096 sparse waves
-    // for mid-size frames — costs 0.87 instead of 0.63 ms per frame here; raising the late stages' wave priority: nothing)
-    if (sr.begin > 0 && ctx->walk_rays_per_wave <= 0)
-        wl.rays_per_wave = walk_stage_slots(q.kp, sr.begin) >= (uint32_t)ctx->stage_dense_from ? 64 : 16;
-    return wl;
-}
-// the next stage of a held frame's walk as a part of the fused launch; false: the launch has no room for more walk parts
-static bool held_walk_part(const fs_context* ctx, const fs_context::PipeFrame& q, FrameParts& f) {
-    if (f.num_walk >= kMaxWalkParts) return false;
-    WalkPart& w = f.walk[f.num_walk++];
-    w.kp = q.kp; w.st = q.st; w.wl = stage_launch(ctx, q, q.next_stage); w.perm = q.perm; w.stage = q.stages[(size_t)q.next_stage];
-    return true;
-}
-}  // namespace
-
-// Let every held frame finish on its own kernels, oldest first: something needs their results (or their buffers) now.
-int dispatch_group(fs_context* ctx);   // below: the frames collected by fs_set_frames_per_launch go first
-
-// the reconstructs that were waiting for the next fused launch, on the tail stream after all (a flush, or a reconstruct
-// that must not overtake them)
-static int run_owed_reconstructs(fs_context* ctx) {
-    if (ctx->recon_owed.empty()) return FS_OK;
-    std::vector<fs_context::ReconOwed> owed;
-    owed.swap(ctx->recon_owed);
-    ctx->dbg.owed_on_tail += owed.size();
-    for (const fs_context::ReconOwed& o : owed) {
-        Source* s = o.s;
-        const int cur = s->cur;
-        const bool cur_fixed = s->cur_fixed, reduced = s->reduced, handed_off = s->handed_off, tail_ordered = s->tail_ordered;
-        s->cur = o.cur; s->cur_fixed = o.fixed; s->reduced = o.reduced; s->handed_off = false;
-        s->tail_ordered = o.reduced;   // (the tail stream is behind the all-reduce, which is behind the launch)
-        const int rc = flush_reconstruct(ctx, s, &o.p);
-        s->cur = cur; s->cur_fixed = cur_fixed; s->reduced = reduced; s->handed_off = handed_off; s->tail_ordered = tail_ordered;
-        if (rc) return rc;
-    }
-    return FS_OK;
-}
-
-// A flush on one GPU drains the pipeline through the SAME fused launches the stream of frames uses, only without a newest frame:
-// every launch carries the next walk stage of every held frame, the connect pass of the oldest complete one and the reconstructs
-// owed by the launch before — the passes keep overlapping each other and the IRs are published by the launches themselves.
-// (Until round 5 every held frame finished on kernels of its own, one after the other: walk, connect, reconstruct, walk, ... —
-// six kernels in a row behind a stream of cfg3 frames, 0.4 ms of the driver's 5.9 ms timed region.)
-static int drain_fused(fs_context* ctx) {
-    const int B = ctx->cfg.num_bands;
-    bool counted = false;
-    for (int guard = 0; (!ctx->held.empty() || !ctx->recon_owed.empty()) && guard < 8 * (kMaxWalkParts + 4); ++guard) {
-        if (!counted && !ctx->held.empty()) { ctx->dbg.flushes++; ctx->dbg.flushed_frames += ctx->held.size(); counted = true; }
-        FrameParts fp;
-        bool connects = false;
-        std::vector<size_t> advanced;
-        for (size_t k = 0; k < ctx->held.size(); ++k) {
-            fs_context::PipeFrame& q = ctx->held[k];
-            if (q.next_stage < (int)q.stages.size()) {
-                if (held_walk_part(ctx, q, fp)) advanced.push_back(k);
-            } else if (k == 0 && !connects) {
-                held_connect_part(q, fp);
-                connects = true;
-            }
-        }
-        OwedLaunch owed;
-        { const int orc = owed_prepare(ctx, fp, owed); if (orc) return orc; }
-        if (!(fp.num_walk > 0 || fp.has_connect || fp.num_recon > 0)) {
-            // nothing a launch could carry.  With a communicator the reconstructs of the frames just summed become due one round
-            // later (ReconOwed::age, raised by owed_prepare): go round again; anything else is left to the loop in flush_pending.
-            if (!ctx->recon_owed.empty() && ctx->recon_owed.front().reduced && ctx->recon_owed.front().age >= 1) continue;
-            break;
-        }
-        const bool fused = launch_frame(B, ctx->scene, fp, ctx->stream);
-        ctx->dbg.launches++;
-        if (!fused) {   // no fused form: the same passes one after the other
-            if (fp.has_connect) launch_connect(B, ctx->scene, fp.kpc, fp.stc, fp.energy, fp.fixed, fp.scratch_c, fp.ppw, fp.energy_tab, fp.fixed_tab, ctx->stream);
-            for (int i = 0; i < fp.num_walk; ++i)
-                launch_walk(ctx->scene, fp.walk[i].kp, fp.walk[i].st, fp.walk[i].wl, fp.walk[i].perm, ctx->stream, fp.walk[i].stage);
-        }
-        FS_HIP(ctx, hipGetLastError());
-        { const int prc = owed_publish(ctx, owed, fused); if (prc) return prc; }
-        for (size_t k : advanced) ctx->held[k].next_stage++;
-        if (connects) {
-            const fs_context::PipeFrame done = ctx->held.front();
-            ctx->held.pop_front();
-            const int rc = finish_held_frame(ctx, done, /*may_defer_recon=*/true, false, /*draining=*/true);
-            if (rc) return rc;
-        }
-    }
-    return FS_OK;
-}
-
-int flush_pending(fs_context* ctx) {
-    using clk = std::chrono::steady_clock;
-    const bool dbg = ctx->debug_stalls;
-    clk::time_point t0, t1, t2;
-    if (dbg) t0 = clk::now();
-    if (!ctx->group.empty()) { const int gr = dispatch_group(ctx); if (gr) return gr; }
-    if (dbg) t1 = clk::now();
-    // (one GPU, or the pairs of a frame shared between ranks with the LIBRARY's collective: the sums over the ranks go onto the
-    // tail stream as before, the reconstructs ride behind them in the drain's launches and publish through the host word)
-    const bool drainable = (!ctx->comm && ctx->cfg.world_size == 1) || (ctx->comm != nullptr && ctx->fused_recon_comm);
-    if (ctx->fused_drain && ctx->fused_recon && drainable && ctx->profiling < 2 &&
-        (!ctx->held.empty() || !ctx->recon_owed.empty())) {
-        FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-        const int dr = drain_fused(ctx);
-        if (dr) return dr;
-    }
-    { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // (older than every held frame)
-    if (dbg) t2 = clk::now();
-    if (ctx->held.empty()) return FS_OK;
-    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    ctx->dbg.flushes++; ctx->dbg.flushed_frames += ctx->held.size();
-    long us_launch = 0, us_finish = 0;
-    while (!ctx->held.empty()) {
-        const fs_context::PipeFrame q = ctx->held.front();
-        ctx->held.pop_front();
-        clk::time_point a, b, c;
-        if (dbg) a = clk::now();
-        for (int k = q.next_stage; k < (int)q.stages.size(); ++k)
-            launch_walk(ctx->scene, q.kp, q.st, stage_launch(ctx, q, k), q.perm, ctx->stream, q.stages[(size_t)k]);
-        launch_connect(ctx->cfg.num_bands, ctx->scene, q.kp, q.st, q.items[0].s->d_energy[q.items[0].cur],
-                       q.fixed ? q.items[0].s->d_fixed[q.items[0].cur] : nullptr, q.wl.queue_head, q.ppw, q.energy_tab, q.fixed_tab,
-                       ctx->stream);
-        FS_HIP(ctx, hipGetLastError());
-        if (dbg) b = clk::now();
-        const int rc = finish_held_frame(ctx, q);
-        if (dbg) { c = clk::now(); us_launch += (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); us_finish += (long)std::chrono::duration_cast<std::chrono::microseconds>(c - b).count(); }
-        if (rc) return rc;
-    }
-    if (dbg) {
-        const long total = (long)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count();
-        if (total > 1000)
-            std::fprintf(stderr, "[frequensee] flush %ld us: group %ld, owed reconstructs %ld, launches of held frames %ld, their reconstructs %ld\n", total,
-                         (long)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count(), (long)std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count(),
-                         us_launch, us_finish);
-    }
-    return FS_OK;
-}
-
-int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
-    { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // IRs are published in frame order
-    // ReconstructImpulseResponse is not linear in the energy (a = e / sqrt(e * Pi4)): the IR of a rank's PARTIAL
-    // histogram is not a partial IR.  A sharded context only reconstructs a frame that was summed over the ranks — by
-    // the library (fs_comm_init / fs_comm_attach) or by the caller's collective on the tail stream (fs_energy_handoff).
-    if (ctx->cfg.world_size > 1 && !s->reduced && !s->handed_off)
-        return ctx->fail(FS_ERR_COMM, "world_size > 1: the energy buffer holds this rank's partial sums only — attach a "
-                                      "communicator (fs_comm_init) or reduce it behind fs_energy_handoff before reconstructing");
-    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    const int B = ctx->cfg.num_bands;
-    int spb = p->samples_per_bin > 0 ? p->samples_per_bin
-                                     : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
-
-    { const int br = ir_ring_backpressure(ctx, s, 1); if (br) return br; }
-    TimedFrame tf{};
-    bool timed = ctx->profiling >= 2;
-    if (timed) {
-        for (int i = 0; i < 5; ++i) tf.e[i] = nullptr;
-        tf.e[3] = take_event(ctx);
-        tf.e[4] = take_event(ctx);
-    }
-    if (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT) {  // ARTS.cpp:191 literally
-        FS_HIP(ctx, wait_energy_readers(ctx, s));
-        FS_HIP(ctx, hipMemsetAsync(s->energy(), 0, sizeof(float) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
-        // (deterministic mode: the fp32 buffer is re-derived from the fixed-point histogram below — the flush empties that one too)
-        if (s->cur_fixed && s->d_fixed[s->cur])
-            FS_HIP(ctx, hipMemsetAsync(s->d_fixed[s->cur], 0, sizeof(unsigned long long) * (size_t)B * (size_t)ctx->num_bins, ctx->stream));
-    }
-    // The tail stream takes over: it waits for this frame's deposit (and runs behind any collective the caller
-    // put there after fs_energy_handoff), reconstructs and publishes while the compute stream goes on to the
-    // next frame.  Reconstructs and publishes of one source are ordered among themselves by the tail stream.
-    // (A frame the library has just summed over the ranks — or that the caller took over with fs_energy_handoff — is
-    // already ordered: a second event pair per frame on the compute stream is a second bubble between its launches,
-    // 2 % of a cfg3 frame: tools/rccl_tax.sh.)
-    if (!s->tail_ordered || (p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT)) FS_HIP(ctx, handoff_energy(ctx, s));
-    else FS_HIP(ctx, tail_waits_for_compute_ir(ctx, s));   // (a fused reconstruct of an earlier frame may still be writing d_ir_*)
-    hipStream_t tail = ctx->copy_stream;
-    {
-        std::lock_guard<std::mutex> g(s->ir_mu);   // against fs_reverb_process on the audio thread
-        if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
-        if (timed) FS_HIP(ctx, hipEventRecord(tf.e[3], tail));
-        // deterministic mode: the collective summed the fixed-point histogram; round it to fp32 once, now
-        if (s->cur_fixed && !s->reduced) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
-        launch_reconstruct(s->energy(), B, ctx->num_bins, ctx->cfg.sample_rate, ctx->num_samples, spb, s->d_ir_bands,
-                           s->d_ir_mono, tail);
-        FS_HIP(ctx, hipGetLastError());
-        FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], tail));
-        s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = 0; s->rec_on_compute[s->cur] = false;
-        s->last_rec = s->cur;
-    }
-    uint64_t seq = s->enqueued + 1;
-    int slot = (int)(seq % kIrRing);
-    FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
-                               hipMemcpyDeviceToHost, tail));
-    FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
-    note_publish(ctx, s, seq, slot);
-    s->cur_pub_seq = seq; s->dev_ir_word = 0;
-    ctx->dbg.tail_ops += 4;   // the reconstruct kernel, its event, the copy, the publish event
-    if (timed) {
-        FS_HIP(ctx, hipEventRecord(tf.e[4], tail));
-        tf.has_recon = true;
-        ctx->pending.push_back(tf);
-    }
-    return FS_OK;
-}
-
-int ir_ring_backpressure_for(fs_context* ctx, Source* s) { return ir_ring_backpressure(ctx, s, 1); }
-
-// Before the TAIL stream writes the source's device IR set: the compute-stream launch that wrote it last (a fused reconstruct part,
-// a batch behind a tick) may still be running — the compute stream hands over (everything it has enqueued so far goes first).
-hipError_t tail_waits_for_compute_ir(fs_context* ctx, Source* s) {
-    if (!s->dev_ir_word || pub_word_done(ctx, s->dev_ir_word)) return hipSuccess;
-    hipError_t e = hipEventRecord(s->ev_dep, ctx->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, s->ev_dep, 0);
-    ctx->dbg.tail_ops++;
-    return e;
-}
-
-// ReconstructImpulseResponse + publish of MANY sources' current frames (the subsystem's loop over ActiveSources,
-// ARTS.cpp:100-126, every one ending in ReconstructImpulseResponse :192): one handoff, ONE kernel that also writes the
-// channel views straight into the sources' pinned host ring slots, ONE event — instead of a wait, a kernel, a copy and
-// three event records per source (67 us per source of host and queue time: 128 sources took 8.6 ms, 32 took 2.8).
-// Anything unusual about a source's frame (a literal second flush, per-kernel timing) sends the whole batch the ordinary way.
-// on_compute (fs_update_sources: the caller waits for the tick anyway): the launch goes onto the COMPUTE stream, right behind
-// the frame's connect pass — no event pair, no second stream to wake (12 us between the two kernels of a one-source tick).
-int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p, bool on_compute) {
-    { const int orc = run_owed_reconstructs(ctx); if (orc) return orc; }   // IRs are published in frame order
-    bool plain = ctx->profiling < 2 && !(p->flags & FS_FLAG_FLUSH_BEFORE_RECONSTRUCT);   // (also for ONE source: no copy command, one event)
-    for (int i = 0; i < count; ++i)
-        if (ctx->cfg.world_size > 1 && !srcs[i]->reduced && !srcs[i]->handed_off) plain = false;   // (reconstruct_now refuses with the message)
-    if (!plain) {
-        for (int i = 0; i < count; ++i) { const int rc = reconstruct_now(ctx, srcs[i], p); if (rc) return rc; }
-        return FS_OK;
-    }
-    FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    const int B = ctx->cfg.num_bands;
-    const int spb = p->samples_per_bin > 0 ? p->samples_per_bin : (int)std::ceil(ctx->cfg.bin_duration * (float)ctx->cfg.sample_rate);  // FSAC.cpp:324
-    hipStream_t tail = on_compute ? ctx->stream : ctx->copy_stream;
-    for (int first = 0; first < count; first += fs_context::kReconTabItems) {
-        const int n = std::min(count - first, (int)fs_context::kReconTabItems);
-        Source* const* g = srcs + first;
-        for (int i = 0; i < n; ++i) { const int br = ir_ring_backpressure(ctx, g[i], 1); if (br) return br; }   // (before the mutexes: may wait for the GPU)
-        // the tail stream takes over behind everything the compute stream has enqueued for these frames: one event pair
-        bool ordered = true;   // (on_compute: the compute stream is behind its own kernels)
-        for (int i = 0; i < n && !on_compute; ++i)
-            ordered = ordered && g[i]->tail_ordered && (!g[i]->dev_ir_word || pub_word_done(ctx, g[i]->dev_ir_word));
-        if (!ordered) {
-            FS_HIP(ctx, handoff_energy(ctx, g[0]));
-            for (int i = 0; i < n; ++i) g[i]->tail_ordered = true;
-        }
-        unsigned slot_t = 0;
-        { const int ar = acquire_recon_tab(ctx, &slot_t); if (ar) return ar; }
-        ReconItem* tab = ctx->h_recon_tab + (size_t)slot_t * fs_context::kReconTabItems;
-        std::vector<Source*> order(g, g + n);
-        std::sort(order.begin(), order.end());                 // one locking order for every thread
-        std::vector<std::unique_lock<std::mutex>> locks;
-        locks.reserve((size_t)n);
-        for (Source* s : order) locks.emplace_back(s->ir_mu);  // against fs_reverb_process on the audio thread
-        // on the tail stream: ONE event for the batch (tail_batch_ev; the ids are totally ordered because only the tail stream
-        // issues them); on the compute stream: the launch announces itself in the host word (publish_arrive)
-        const uint64_t batch = on_compute ? 0 : ctx->tail_batch_newest.load(std::memory_order_relaxed) + 1;
-        const PublishWord pub = on_compute ? next_pub_word(ctx) : PublishWord();
-        for (int i = 0; i < n; ++i) {
-            Source* s = g[i];
-            if (on_compute) FS_HIP(ctx, compute_waits_for_tail_ir(ctx, s));   // nor write d_ir_* under a publish the tail stream still copies from
-            else if (s->rev_recorded) FS_HIP(ctx, hipStreamWaitEvent(tail, s->ev_rev, 0));   // a reverb callback may be reading d_ir_mono
-            // deterministic mode: the collective summed the fixed-point histogram; round it to fp32 once, now
-            if (s->cur_fixed && !s->reduced) launch_fixed_to_energy(s->d_fixed[s->cur], s->energy(), B * ctx->num_bins, tail);
-            const uint64_t seq = s->enqueued + 1;
-            const int slot = (int)(seq % kIrRing);
-            tab[i].energy = s->energy(); tab[i].ir_bands = s->d_ir_bands; tab[i].ir_mono = s->d_ir_mono; tab[i].host = s->h_ir[slot];
-            tab[i].spb = spb; tab[i].pad = 0;
-        }
-        launch_reconstruct_batch(tab, n, B, ctx->num_bins, ctx->num_samples, tail, pub);
-        FS_HIP(ctx, hipGetLastError());
-        if (on_compute) {
-            ctx->pub_issued = pub.id;
-            ctx->recon_tab_word[slot_t] = pub.id;
-        } else {
-            FS_HIP(ctx, hipEventRecord(ctx->tail_batch_ev[batch % fs_context::kTailBatches], tail));
-            ctx->dbg.tail_ops += 2;
-            ctx->tail_batch_newest.store(batch, std::memory_order_release);
-            ctx->recon_tab_batch[slot_t] = batch;
-        }
-        for (int i = 0; i < n; ++i) {
-            Source* s = g[i];
-            s->rec_recorded[s->cur] = true; s->rec_batch[s->cur] = batch; s->rec_on_compute[s->cur] = on_compute;
-            s->last_rec = s->cur;
-            const uint64_t seq = s->enqueued + 1;
-            note_publish(ctx, s, seq, (int)(seq % kIrRing), batch, pub.id);
-            if (on_compute) {
-                s->cur_pub_seq = 0; s->dev_ir_word = pub.id;
-                if (s->d_ring) FS_HIP(ctx, hipEventRecord(s->ev_rec[s->cur], ctx->stream));   // fs_reverb_process reads d_ir_mono behind this
-            } else {
-                s->cur_pub_seq = seq; s->dev_ir_word = 0;
-            }
-        }
-    }
-    return FS_OK;
-}
-
-}  // namespace fsi
 
 // ---- one traced frame ----------------------------------------------------------------------------------------------
 // UpdateSource up to the deposit (ARTS.cpp:128-173) for `count` sources (count == 1: the plain call).  A batch lays the

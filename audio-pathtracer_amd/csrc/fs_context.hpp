@@ -433,11 +433,35 @@ void wait_refine(const std::shared_ptr<RefineJob>& j);
 void join_refine_threads(fs_context* ctx);
 
 // ---- fs_capi_frame.cpp --------------------------------------------------------------------------------------------
-int flush_pending(fs_context* ctx);          // pipelined frames: let every held frame finish on its own kernels
+int dispatch_group(fs_context* ctx);         // the frames collected by fs_set_frames_per_launch as ONE batched frame
+
+// ---- fs_capi_pipeline.cpp -----------------------------------------------------------------------------------------
+int flush_pending(fs_context* ctx);          // pipelined frames: drain the pipeline (fused launches, or every held frame on its own kernels)
 int check_overflow(fs_context* ctx);         // depth = 0: did a record miss both tiers?  (stream just synchronised)
+// what a held frame still owes once its connect pass has been enqueued (fixed-point rounding, the sum over the ranks, its reconstruct)
+int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_defer_recon = false, bool tail_waits_already = false, bool draining = false);
+void held_connect_part(const fs_context::PipeFrame& q, FrameParts& f);                         // a held frame's connect pass as a part of the fused launch
+bool held_walk_part(const fs_context* ctx, const fs_context::PipeFrame& q, FrameParts& f);   // ... its next walk stage (false: no room for more walk parts)
+WalkLaunch stage_launch(const fs_context* ctx, const fs_context::PipeFrame& q, int stage);
+
+// ---- fs_capi_publish.cpp ------------------------------------------------------------------------------------------
+// The reconstruct parts of a fused launch: owed_prepare turns the owed reconstructs into parts of the launch being assembled (and
+// takes their sources' IR mutexes), owed_publish notes the publishes behind the launch (which announces them itself).
+struct OwedLaunch {
+    std::vector<fs_context::ReconOwed> owed;
+    std::vector<uint64_t> seq;                             // publish number of each entry (ring slot = seq % kIrRing)
+    std::vector<char> newest;                              // the source's newest frame of the launch: its IR becomes the device-resident set
+    std::vector<std::unique_lock<std::mutex>> locks;
+    PublishWord pub;
+};
+int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol);
+int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused);
+int run_owed_reconstructs(fs_context* ctx);  // the reconstructs that were waiting for the next fused launch, on kernels of their own after all
+int flush_reconstruct(fs_context* ctx, Source* s, const fs_params* p);   // a reconstruct no launch is fused with (one GPU: a compute-stream batch of one)
 int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p);
 int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_params* p, bool on_compute);   // many sources: one launch, one event
-int ir_ring_backpressure_for(fs_context* ctx, Source* s);   // the IR ring's throttle before one more publish (may block; not under ir_mu)
+int ir_ring_backpressure(fs_context* ctx, Source* s, int more);   // the IR ring's throttle before `more` publishes (may block; not under ir_mu)
+int ir_ring_backpressure_for(fs_context* ctx, Source* s);
 hipError_t tail_waits_for_compute_ir(fs_context* ctx, Source* s);   // before the tail stream writes the source's device IR set
 
 // ---- fs_capi_comm.cpp ---------------------------------------------------------------------------------------------

@@ -12,8 +12,8 @@ if [[ "$flags" == *FS_WAVE_TIMELINE* || "$flags" == *FS_TRAV_STATS* ]]; then
   cd audio-pathtracer_amd/csrc
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -munsafe-fp-atomics --offload-arch=gfx950 \
     -Wall -Wextra -Wno-unused-parameter "$@" -shared -o ../../tools/tmp/$name/libfrequensee.so -x hip \
-    fs_capi_context.cpp fs_capi_scene.cpp fs_capi_frame.cpp fs_capi_comm.cpp fs_capi_aux.cpp fs_bvh.cpp \
-    fs_kernels_all.hip fs_frame_wide.hip fs_fft.hip fs_refit.hip fs_build.hip fs_oneshot.hip
+    fs_capi_context.cpp fs_capi_scene.cpp fs_capi_frame.cpp fs_capi_pipeline.cpp fs_capi_publish.cpp fs_capi_ir.cpp fs_capi_comm.cpp fs_capi_aux.cpp fs_bvh.cpp \
+    fs_kernels_all.hip fs_frame_wide.hip fs_frame_ext.hip fs_frame_wide_ext.hip fs_fft.hip fs_refit.hip fs_build.hip fs_oneshot.hip
 else
   make -s -C audio-pathtracer_amd/csrc -j8 lib OBJ=build_$name OUT=../../tools/tmp/$name EXTRA="$flags"
 fi
