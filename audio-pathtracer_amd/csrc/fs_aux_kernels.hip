@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kBlock) void reconstruct_batch_kernel(const ReconIt
     const uint32_t per_item = (uint32_t)(B + 1) * cb;
     const uint32_t item = blockIdx.x / per_item, in_item = blockIdx.x - item * per_item;
     const ReconItem it = table[item];
-    reconstruct_body_fast((int)(in_item / cb), (int)(in_item % cb), it.energy, B, nb, num_samples, it.spb, it.ir_bands, it.ir_mono, s_rb, it.host);
+    reconstruct_body_fast((int)(in_item / cb), (int)(in_item % cb), it.energy, B, nb, num_samples, it.spb, it.ir_bands, it.ir_mono, s_rb, it.host, it.mask);
     publish_arrive(pub.tickets, gridDim.x, pub.host_word, pub.id);
 }
 

@@ -103,6 +103,21 @@ bool slot_published(fs_context* ctx, Source* s, int slot) {
     if (hipEventQuery(s->ev[slot]) != hipSuccess) { (void)hipGetLastError(); return false; }   // (hipErrorNotReady is not an error)
     return true;
 }
+// ---- zero-block masks of the host ring slots (fs_context::d_slot_masks) -----------------------------------------------------
+static bool slot_masks_usable(const fs_context* ctx, const Source* s) {
+    // (a mask word has 32 bits: one per block of kBlock * kChunk = 4 096 samples)
+    return ctx->d_slot_masks != nullptr && s->mask_index >= 0 && s->mask_index < kMaxMaskSources && ctx->num_samples <= 32 * 4096;
+}
+uint32_t* slot_mask_ptr(const fs_context* ctx, const Source* s, int slot) {
+    return slot_masks_usable(ctx, s) ? ctx->d_slot_masks + (size_t)s->mask_index * kIrRing + (size_t)slot : nullptr;
+}
+uint16_t slot_mask_index(const fs_context* ctx, const Source* s, int slot) {
+    return slot_masks_usable(ctx, s) ? (uint16_t)(s->mask_index * kIrRing + slot) : kNoSlotMask;
+}
+hipError_t slot_mask_all_dirty(fs_context* ctx, const Source* s, int slot, hipStream_t st) {
+    uint32_t* w = slot_mask_ptr(ctx, s, slot);
+    return w ? hipMemsetAsync(w, 0xFF, sizeof(uint32_t), st) : hipSuccess;
+}
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot) {
     const uint64_t w = s->pub_word[slot].load(std::memory_order_acquire);
     const uint64_t b = s->pub_batch[slot].load(std::memory_order_acquire);
@@ -407,6 +422,7 @@ int check_params(fs_context* ctx, const fs_params* p) {
     if (!p) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "params is NULL");
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
     if (p->depth < 0 || p->depth > FS_MAX_DEPTH) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "depth out of range");
+    if (p->samples_per_bin < 0 || p->samples_per_bin > 32767) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "samples_per_bin out of range (0 = from the configuration, else 1 .. 32767)");
     if (p->num_rays & 1u) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "num_rays must be even (source + listener subpaths)");
     if (p->num_rays > (1u << 30)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "num_rays above 2^30 per frame (32-bit subpath indices)");
     if ((p->flags & FS_FLAG_MATERIAL_LOBES) && (p->flags & FS_FLAG_MIS_BALANCE))
@@ -608,8 +624,12 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_recon_tab, sizeof(ReconItem) * fs_context::kReconTabSlots * fs_context::kReconTabItems, hipHostMallocDefault);
     // the publish word: coherent (fine-grained) host memory the device writes with system scope while its kernel is still running
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_pub_word, 64, hipHostMallocCoherent);
-    if (e == hipSuccess) { *ctx->h_pub_word = 0ull; e = hipMalloc((void**)&ctx->d_pub_tickets, 64); }
-    if (e == hipSuccess) e = hipMemset(ctx->d_pub_tickets, 0, 64);
+    // ONE device allocation: the ticket cell of publish_arrive (kSlotMaskOffsetWords words), then the zero-block masks of the ring slots
+    static_assert(kMaxMaskSources * kIrRing < (int)kNoSlotMask, "slot mask indices are 16 bits");
+    const size_t pub_bytes = sizeof(uint32_t) * ((size_t)kSlotMaskOffsetWords + (size_t)kMaxMaskSources * kIrRing);
+    if (e == hipSuccess) { *ctx->h_pub_word = 0ull; e = hipMalloc((void**)&ctx->d_pub_tickets, pub_bytes); }
+    if (e == hipSuccess) e = hipMemset(ctx->d_pub_tickets, 0, pub_bytes);
+    if (e == hipSuccess) ctx->d_slot_masks = reinterpret_cast<uint32_t*>(ctx->d_pub_tickets) + kSlotMaskOffsetWords;
     if (e != hipSuccess) return ctx->fail(FS_ERR_NO_DEVICE, std::string("batched reconstructs: ") + hipGetErrorString(e));
     ctx->device_ok = true;
     // A context overlaps the tail of a frame with the next frame's tracing on two HIP streams.  The runtime multiplexes
@@ -667,7 +687,7 @@ int fs_context_destroy(fs_context* ctx) {
     for (hipEvent_t ev : ctx->tail_batch_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->h_recon_tab) (void)hipHostFree(ctx->h_recon_tab);
     if (ctx->h_pub_word) (void)hipHostFree(ctx->h_pub_word);
-    if (ctx->d_pub_tickets) (void)hipFree(ctx->d_pub_tickets);
+    if (ctx->d_pub_tickets) (void)hipFree(ctx->d_pub_tickets);   // (d_slot_masks lives in the same allocation)
     if (ctx->d_comm_stage) (void)hipFree(ctx->d_comm_stage);
     join_refine_threads(ctx);   // no background build may outlive the context (the library may be unloaded next)
     for (Source* s : ctx->sources) free_source(ctx, s);

@@ -619,10 +619,18 @@ int fs_source_create(fs_context* ctx, fs_source* out) {
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     s->alive = true;
     // RegisterSource: ActiveSources.Add (ARTS.cpp:45-48); reuse a dead slot if any
+    size_t idx = ctx->sources.size();
     for (size_t i = 0; i < ctx->sources.size(); ++i)
-        if (!ctx->sources[i]) { ctx->sources[i] = s; *out = (fs_source)i; return FS_OK; }
-    ctx->sources.push_back(s);
-    *out = (fs_source)(ctx->sources.size() - 1);
+        if (!ctx->sources[i]) { idx = i; break; }
+    if (idx == ctx->sources.size()) ctx->sources.push_back(nullptr);
+    ctx->sources[idx] = s;
+    // the new ring slots are all zero: so are their zero-block masks (the handle's previous owner may have left bits behind)
+    if (idx < (size_t)kMaxMaskSources && ctx->d_slot_masks) {
+        s->mask_index = (int)idx;
+        if ((e = hipMemsetAsync(ctx->d_slot_masks + idx * kIrRing, 0, sizeof(uint32_t) * kIrRing, ctx->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { ctx->sources[idx] = nullptr; return bail(e, "hipMemsetAsync(slot masks)"); }
+    }
+    *out = (fs_source)idx;
     return FS_OK;
 }
 

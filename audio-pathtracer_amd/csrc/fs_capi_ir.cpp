@@ -15,6 +15,7 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
     fs_params def;
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    if (p->samples_per_bin < 0 || p->samples_per_bin > 32767) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "samples_per_bin out of range (0 = from the configuration, else 1 .. 32767)");
     // grouped frames: the source's current frame still waits for its launch — the reconstruct is recorded with it
     for (size_t k = ctx->group.size(); k-- > 0;) {
         fs_context::GroupEntry& e = ctx->group[k];
@@ -52,6 +53,7 @@ int fs_reconstruct_impulse_response_batch_async(fs_context* ctx, const fs_source
     fs_params def;
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    if (p->samples_per_bin < 0 || p->samples_per_bin > 32767) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "samples_per_bin out of range (0 = from the configuration, else 1 .. 32767)");
     std::vector<Source*> srcs((size_t)count);
     for (int32_t i = 0; i < count; ++i) {
         srcs[(size_t)i] = get_source(ctx, sources[i]);
@@ -78,6 +80,7 @@ int fs_update_sources(fs_context* ctx, const fs_source* sources, int32_t count, 
     fs_params def;
     if (!p) { fs_params_default(&def); p = &def; }
     if (p->struct_size != sizeof(fs_params)) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "fs_params.struct_size mismatch");
+    if (p->samples_per_bin < 0 || p->samples_per_bin > 32767) return ctx->fail(FS_ERR_INVALID_ARGUMENT, "samples_per_bin out of range (0 = from the configuration, else 1 .. 32767)");
     std::vector<Source*> srcs((size_t)count);
     int rc = FS_OK;
     // depth = 0 only: a tick whose record store overflowed is traced and reconstructed again (up to 4 attempts; the store has been
@@ -127,6 +130,7 @@ int fs_set_impulse_response(fs_context* ctx, fs_source h, const float* ir, int32
     uint64_t seq = s->enqueued + 1;
     int slot = (int)(seq % kIrRing);
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, bytes, hipMemcpyDeviceToHost, tail));
+    FS_HIP(ctx, slot_mask_all_dirty(ctx, s, slot, tail));
     FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
     ctx->dbg.tail_ops += 4 + (uint64_t)ctx->cfg.num_bands; ctx->dbg.pub_event++;
     s->pub_word[slot] = 0; s->pub_batch[slot] = 0; s->seq_of[slot] = seq; s->enqueued = seq; s->cur_pub_seq = seq; s->dev_ir_word = 0;

@@ -103,8 +103,9 @@ int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
         if (!later) FS_OWED_HIP(compute_waits_for_tail_ir(ctx, s));
         if (o.reduced && s->red_recorded[o.cur]) FS_OWED_HIP(compute_waits_for(ctx, s->ev_red[o.cur]));   // the sum over the ranks (done a launch ago)
         ol.seq.push_back(seq); ol.newest.push_back(later ? 0 : 1);
-        fp.recon_spb[fp.num_recon] = spb_of(ctx, o.p);
+        fp.recon_spb[fp.num_recon] = (int16_t)std::min(spb_of(ctx, o.p), 32767);
         FrameParts::Recon& r = fp.recon[fp.num_recon++];
+        fp.recon_mask_idx[fp.num_recon - 1] = slot_mask_index(ctx, s, (int)(seq % kIrRing));
         r.energy = s->d_energy[o.cur]; r.ir = later ? nullptr : s->d_ir_bands; r.host = s->h_ir[(int)(seq % kIrRing)];
     }
 #undef FS_OWED_HIP
@@ -125,6 +126,7 @@ int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
             const fs_context::ReconOwed& o = ol.owed[i];
             tab[i].energy = o.s->d_energy[o.cur]; tab[i].ir_bands = ol.newest[i] ? o.s->d_ir_bands : nullptr;
             tab[i].ir_mono = ol.newest[i] ? o.s->d_ir_mono : nullptr; tab[i].host = o.s->h_ir[(int)(ol.seq[i] % kIrRing)];
+            tab[i].mask = slot_mask_ptr(ctx, o.s, (int)(ol.seq[i] % kIrRing));
             tab[i].spb = spb_of(ctx, o.p); tab[i].pad = 0;
         }
         launch_reconstruct_batch(tab, (int)ol.owed.size(), B, ctx->num_bins, ctx->num_samples, ctx->stream, ol.pub);
@@ -230,6 +232,7 @@ int reconstruct_now(fs_context* ctx, Source* s, const fs_params* p) {
     int slot = (int)(seq % kIrRing);
     FS_HIP(ctx, hipMemcpyAsync(s->h_ir[slot], s->d_ir_mono, sizeof(float) * (size_t)ctx->num_samples,
                                hipMemcpyDeviceToHost, tail));
+    FS_HIP(ctx, slot_mask_all_dirty(ctx, s, slot, tail));   // (a copy wrote every block: the kernels' zero-block bookkeeping starts over)
     FS_HIP(ctx, hipEventRecord(s->ev[slot], tail));
     note_publish(ctx, s, seq, slot);
     s->cur_pub_seq = seq; s->dev_ir_word = 0;
@@ -307,6 +310,7 @@ int reconstruct_batch(fs_context* ctx, Source* const* srcs, int count, const fs_
             const uint64_t seq = s->enqueued + 1;
             const int slot = (int)(seq % kIrRing);
             tab[i].energy = s->energy(); tab[i].ir_bands = s->d_ir_bands; tab[i].ir_mono = s->d_ir_mono; tab[i].host = s->h_ir[slot];
+            tab[i].mask = slot_mask_ptr(ctx, s, slot);
             tab[i].spb = spb; tab[i].pad = 0;
         }
         launch_reconstruct_batch(tab, n, B, ctx->num_bins, ctx->num_samples, tail, pub);

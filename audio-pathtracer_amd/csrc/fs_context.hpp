@@ -106,6 +106,7 @@ struct Source {
     // a reconstruct on the tail stream lets the compute stream hand over first while that launch may still be running
     uint64_t dev_ir_word = 0;
     float* h_ir[kIrRing] = {};  // pinned host copies of the channel view
+    int mask_index = -1;        // this source's row of fs_context::d_slot_masks (its handle; -1: none — every block is always written)
     hipEvent_t ev[kIrRing] = {};
     // How ring slot `slot` is known to be published, in this order: pub_word[slot] != 0 — a launch on the COMPUTE stream whose
     // reconstruct workgroups wrote the slot themselves and whose id appears in fs_context::h_pub_word (publish_arrive, fs_device.hpp:
@@ -287,6 +288,10 @@ struct fs_context {
     // Publishes of the compute stream (fused reconstruct parts, batches behind a tick or a flush): the launch writes the ring slots
     // and then its id into *h_pub_word (pinned, coherent) — see Source::pub_word.  pub_issued = id of the newest such launch.
     unsigned* d_pub_tickets = nullptr;             // device: the ticket cell of publish_arrive (re-armed by the launch that used it)
+    // zero-block masks of the sources' host ring slots (fs_device.hpp: host_block_wanted): [kMaxMaskSources][kIrRing] words on the
+    // device, bit b of word (source, slot) = block b of that slot may hold non-zero samples.  Kept by the reconstruct kernels; a
+    // copy command into a slot (reconstruct_now, fs_set_impulse_response) sets the slot's word to all ones behind itself.
+    uint32_t* d_slot_masks = nullptr;
     unsigned long long* h_pub_word = nullptr;
     uint64_t pub_issued = 0;
     int state_sets = 3;              // sets of the per-frame arrays (subpath state, records, schedules): frames in flight + 1
@@ -418,6 +423,9 @@ bool pub_word_done(const fs_context* ctx, uint64_t id);             // any threa
 hipError_t wait_pub_word(fs_context* ctx, uint64_t id);             // producer: poll the host word (falls back to a stream wait)
 PublishWord next_pub_word(fs_context* ctx);                         // the arguments of the next self-publishing launch (id = pub_issued + 1; commit with ++pub_issued)
 bool slot_published(fs_context* ctx, Source* s, int slot);          // any thread: the publish in ring slot `slot` has completed
+uint32_t* slot_mask_ptr(const fs_context* ctx, const Source* s, int slot);   // the slot's zero-block mask word on the device (nullptr: none)
+uint16_t slot_mask_index(const fs_context* ctx, const Source* s, int slot);  // ... as an index into d_slot_masks (kNoSlotMask: none)
+hipError_t slot_mask_all_dirty(fs_context* ctx, const Source* s, int slot, hipStream_t st);   // behind a copy command into the slot
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot);      // block until the publish in ring slot `slot` has completed
 int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals,
                  int sets, bool staged);

@@ -284,6 +284,9 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
 // of an older one (walked before), the plan pass of the newest.  false = no fused form for this shape (lobes, counting
 // instantiations, experiment walk variants, nothing to do): the caller launches the kernels one after the other.
 constexpr int kMaxWalkParts = 8;   // walk parts of one fused launch = stages of a staged walk in flight
+constexpr uint16_t kNoSlotMask = 0xFFFFu;
+constexpr int kSlotMaskOffsetWords = 16;  // the mask table starts this many 32-bit words behind PublishWord::tickets
+constexpr int kMaxMaskSources = 1024;     // sources (by handle) whose ring slots have zero-block masks; later ones always write every block
 struct PublishWord { unsigned* tickets = nullptr; unsigned long long* host_word = nullptr; unsigned long long id = 0; };
 struct WalkPart {   // a frame's walks from step stage.begin up to step stage.end
     KParams kp; SubpathState st; WalkLaunch wl;   // wl.queue_head = the frame's scratch set, wl.rays_per_wave
@@ -305,7 +308,10 @@ struct FrameParts {
     // within the launch; host = the pinned ring slot the channel view is also written into (the publish), nullptr: none.
     int num_recon = 0;
     struct Recon { const float* energy; float* ir; float* host; } recon[kMaxReconParts];
-    int recon_spb[kMaxReconParts] = {};
+    int16_t recon_spb[kMaxReconParts] = {};   // (16 bits each: the fused launch's 4 KB of kernel arguments are full)
+    // the host slots' zero-block masks (ReconItem::mask) as indices into the context's table, which lives kSlotMaskOffsetWords
+    // behind the ticket cell pub.tickets in ONE device allocation (no pointer of its own in the arguments); kNoSlotMask = none
+    uint16_t recon_mask_idx[kMaxReconParts] = {};
     int recon_B = 0, recon_nb = 0, recon_samples = 0;
     // the publish of those host slots (fs_device.hpp: publish_arrive): the ticket cell, the pinned host word, this launch's id (tickets == nullptr: by an event)
     PublishWord pub;
@@ -340,7 +346,9 @@ void launch_reconstruct(const float* energy, int B, int num_bins, int sample_rat
 // ReconstructImpulseResponse of MANY sources as one launch (fs_reconstruct_impulse_response_batch_async): a table of items in
 // pinned host memory (read by the kernel as it stands); host != nullptr: the channel view is also written straight into
 // that pinned host buffer (the publish: 16-byte stores, a block's 4 096 samples staged in LDS) — no copy command per source.
-struct ReconItem { const float* energy; float* ir_bands; float* ir_mono; float* host; int32_t spb; int32_t pad; };
+// mask (optional): the device word that says which 4 096-sample blocks of the host slot may hold non-zero samples (bit b = block b):
+// a block whose samples are all exactly zero is not written across the bus again when the slot's block is known to be zero.
+struct ReconItem { const float* energy; float* ir_bands; float* ir_mono; float* host; uint32_t* mask; int32_t spb; int32_t pad; };
 // pub.tickets != nullptr: the launch announces its own completion in the context's pinned host word (publish_arrive)
 void launch_reconstruct_batch(const ReconItem* table, int count, int B, int num_bins, int num_samples, hipStream_t s, const PublishWord& pub = PublishWord());
 void launch_trace_rays(const DeviceScene& sc, const float* o, const float* d, const float* tmax, int N, int any_hit,

@@ -335,3 +335,85 @@ def test_small_frames_far_from_the_origin(pkg, oracle_mod, scene_factory):
     assert cnt.connected > 0
     check_energy(got, e32, e64, 1)
     ctx.close()
+
+
+# ---- zero blocks of the published IR stay on the device side of the bus ------------------------------------------------
+@pytest.mark.parametrize("path", ["waited", "streamed"])
+def test_zero_blocks_of_the_ring_slots_are_rewritten_when_they_must_be(pkg, scene_factory, path):
+    """The reconstruct workgroups skip the host write of a 4 096-sample block whose samples are all exactly zero when the ring
+    slot's block is known to be zero already (csrc/fs_device.hpp: host_block_wanted; a room's IR ends after a quarter of the
+    second).  The published IR must not depend on what the slot held eight publishes ago: energies with deposits in LATE bins
+    (every block non-zero) and in early bins only alternate in runs longer and shorter than the ring, through the batch kernel
+    (waited-for reconstructs), the fused launch (streamed frames with an installed energy buffer are not traced, so the streamed
+    leg alternates traced frames of two distances scales), a copy command (fs_set_impulse_response) in between; every published
+    IR equals the one a fresh context produces for the same energy."""
+    sc = scene_factory("starter_room", 4)
+    ctx, src = make_ctx(pkg, sc)
+    nb = ctx.num_bins
+    rng = np.random.default_rng(5)
+
+    def energy(kind):
+        e = np.zeros((4, nb), np.float32)
+        if kind == "late":
+            e[:, rng.integers(0, nb, 40)] = rng.random(40).astype(np.float32) + 0.1
+            e[:, nb - 1] = 0.5
+        elif kind == "early":
+            e[:, rng.integers(0, 30, 10)] = rng.random(10).astype(np.float32) + 0.1
+        elif kind == "middle":
+            e[:, 400 + rng.integers(0, 50, 10)] = rng.random(10).astype(np.float32) + 0.1
+        return e
+
+    def reference_ir(e):
+        ref, rs = make_ctx(pkg, sc)
+        ref.update_energy_buffer(rs, e)
+        ref.reconstruct_impulse_response(rs)
+        out = ref.impulse_response(rs, 0).copy()
+        ref.close()
+        return out
+
+    if path == "waited":
+        seq = ["late"] * 3 + ["early"] * 11 + ["zero"] * 2 + ["middle"] * 9 + ["late"] * 9 + ["early"] * 3 + ["set"] + ["early"] * 10 + ["zero"] * 9
+        refs = {}
+        for i, kind in enumerate(seq):
+            if kind == "set":                                   # a copy command writes a whole slot behind the kernels' back
+                ir = (rng.random(ctx.num_samples).astype(np.float32) - 0.5)
+                ctx.set_impulse_response(src, ir)
+                assert np.array_equal(ctx.impulse_response(src, 0), ir)
+                continue
+            e = energy(kind)
+            ctx.update_energy_buffer(src, e)
+            ctx.reconstruct_impulse_response(src)
+            got = ctx.impulse_response(src, 0)
+            want = reference_ir(e)
+            assert np.array_equal(got, want), (i, kind, int(np.flatnonzero(got != want)[0]))
+            if kind == "early":
+                assert not got[3 * 4096:].any()                 # the tail really is exact zeros (what the rule relies on)
+    else:
+        # streamed frames, two per launch: long runs of far deposits (delays x 100 and a gain that lifts them over the amplitude threshold: blocks 4 - 6) then
+        # of near ones (the defaults: block 0), each published IR picked up by its number and compared with an unpipelined context
+        ctx.set_pipelining(2); ctx.set_frames_per_launch(2)
+        ref, rs = make_ctx(pkg, sc)
+        far, near = dict(dist_divisor=10.0, energy_gain=1e12), dict()      # far: amplitudes in blocks 4 - 6 only; near: in block 0 only
+        kinds = [far] * 12 + [near] * 20 + [far] * 3 + [near] * 13
+        params = [pkg.default_params(num_rays=4096, depth=8, seed=800 + i, flags=DET, **kw) for i, kw in enumerate(kinds)]
+        want = []
+        for p in params:
+            ref.compute_energy_response(rs, p); ref.reconstruct_impulse_response(rs, p)
+            want.append(ref.impulse_response(rs, 0).copy())
+        assert all(w[4 * 4096:7 * 4096].any() and not w[:3 * 4096].any() for w in want[:12])      # far frames: late blocks only
+        assert all(w[:4096].any() and not w[2 * 4096:].any() for w in want[12:32])                 # near frames: the first block only
+        seen = {}
+        for p in params:
+            ctx.compute_energy_response_async(src, p); ctx.reconstruct_impulse_response_async(src, p)
+            k0 = ctx.impulse_response_sequence(src)
+            if k0 and k0 not in seen:
+                a = ctx.impulse_response_view(src, 0).copy()
+                if ctx.impulse_response_sequence(src) == k0:
+                    seen[k0] = a
+        ctx.synchronize()
+        seen[len(params)] = ctx.impulse_response(src, 0).copy()
+        assert len(seen) >= 8
+        bad = [k for k, a in sorted(seen.items()) if not np.array_equal(a, want[k - 1])]
+        assert not bad, (bad, sorted(seen))
+        ref.close()
+    ctx.close()
