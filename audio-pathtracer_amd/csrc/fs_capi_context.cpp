@@ -111,9 +111,6 @@ static bool slot_masks_usable(const fs_context* ctx, const Source* s) {
 uint32_t* slot_mask_ptr(const fs_context* ctx, const Source* s, int slot) {
     return slot_masks_usable(ctx, s) ? ctx->d_slot_masks + (size_t)s->mask_index * kIrRing + (size_t)slot : nullptr;
 }
-uint16_t slot_mask_index(const fs_context* ctx, const Source* s, int slot) {
-    return slot_masks_usable(ctx, s) ? (uint16_t)(s->mask_index * kIrRing + slot) : kNoSlotMask;
-}
 hipError_t slot_mask_all_dirty(fs_context* ctx, const Source* s, int slot, hipStream_t st) {
     uint32_t* w = slot_mask_ptr(ctx, s, slot);
     return w ? hipMemsetAsync(w, 0xFF, sizeof(uint32_t), st) : hipSuccess;
@@ -625,7 +622,6 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     // the publish word: coherent (fine-grained) host memory the device writes with system scope while its kernel is still running
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_pub_word, 64, hipHostMallocCoherent);
     // ONE device allocation: the ticket cell of publish_arrive (kSlotMaskOffsetWords words), then the zero-block masks of the ring slots
-    static_assert(kMaxMaskSources * kIrRing < (int)kNoSlotMask, "slot mask indices are 16 bits");
     const size_t pub_bytes = sizeof(uint32_t) * ((size_t)kSlotMaskOffsetWords + (size_t)kMaxMaskSources * kIrRing);
     if (e == hipSuccess) { *ctx->h_pub_word = 0ull; e = hipMalloc((void**)&ctx->d_pub_tickets, pub_bytes); }
     if (e == hipSuccess) e = hipMemset(ctx->d_pub_tickets, 0, pub_bytes);

@@ -55,7 +55,7 @@ int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_
     // would have to run the deferred ones first, to keep the IRs in frame order)
     int wanted = 0;
     for (const fs_context::PipeFrame::Item& it : q.items) wanted += it.want_recon ? 1 : 0;
-    if (wanted + (int)ctx->recon_owed.size() > kMaxReconParts) may_defer_recon = false;
+    if (wanted + (int)ctx->recon_owed.size() > kMaxReconParts) may_defer_recon = false;   // (256: one table slot)
     for (const fs_context::PipeFrame::Item& it : q.items) {
         Source* s = it.s;
         const bool moved_on = s->cur != it.cur;

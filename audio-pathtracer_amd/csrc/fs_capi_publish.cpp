@@ -77,18 +77,20 @@ int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
     for (const fs_context::ReconOwed& o : ol.owed)
         if (std::find(distinct.begin(), distinct.end(), o.s) == distinct.end()) distinct.push_back(o.s);
     std::sort(distinct.begin(), distinct.end());           // one locking order for every thread
-    // the ring's back-pressure BEFORE the IR mutexes are taken: it may wait for the GPU, and fs_reverb_process on the audio
-    // thread must never queue behind such a wait
+    // the ring's back-pressure and the table slot BEFORE the IR mutexes are taken: both may wait for the GPU, and
+    // fs_reverb_process on the audio thread must never queue behind such a wait
     for (Source* s : distinct) {
         int more = 0;
         for (const fs_context::ReconOwed& o : ol.owed) more += o.s == s ? 1 : 0;
         const int br = ir_ring_backpressure(ctx, s, more);
         if (br) { ol.owed.clear(); return br; }
     }
+    { const int ar = acquire_recon_tab(ctx, &ol.tab_slot); if (ar) { ol.owed.clear(); return ar; } }
+    ReconItem* tab = ctx->h_recon_tab + (size_t)ol.tab_slot * fs_context::kReconTabItems;
     auto bail = [&](int rc) { ol.owed.clear(); ol.seq.clear(); ol.newest.clear(); ol.locks.clear(); fp.num_recon = 0; return rc; };
 #define FS_OWED_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bail(ctx->hip_fail(e_, #call)); } while (0)
     for (Source* s : distinct) ol.locks.emplace_back(s->ir_mu);
-    fp.num_recon = 0; fp.recon_B = B; fp.recon_nb = ctx->num_bins; fp.recon_samples = ctx->num_samples;
+    fp.num_recon = 0; fp.recon_tab = tab; fp.recon_B = B; fp.recon_nb = ctx->num_bins; fp.recon_samples = ctx->num_samples;
     ol.pub = next_pub_word(ctx);
     fp.pub = ol.pub;
     for (size_t i = 0; i < ol.owed.size(); ++i) {
@@ -98,41 +100,31 @@ int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol) {
         for (size_t k = i + 1; k < ol.owed.size(); ++k) later = later || ol.owed[k].s == s;
         uint64_t seq = s->enqueued + 1;                    // (the ring's back-pressure was applied above, before the mutexes)
         for (size_t k = 0; k < i; ++k) seq += ol.owed[k].s == s ? 1 : 0;
+        const int slot = (int)(seq % kIrRing);
         // An IR that is superseded within the launch only goes to its ring slot (the channel row); the source's newest IR of the
         // launch also becomes the device-resident set (the reverb's, fs_copy_band_impulse_response's).
         if (!later) FS_OWED_HIP(compute_waits_for_tail_ir(ctx, s));
         if (o.reduced && s->red_recorded[o.cur]) FS_OWED_HIP(compute_waits_for(ctx, s->ev_red[o.cur]));   // the sum over the ranks (done a launch ago)
         ol.seq.push_back(seq); ol.newest.push_back(later ? 0 : 1);
-        fp.recon_spb[fp.num_recon] = (int16_t)std::min(spb_of(ctx, o.p), 32767);
-        FrameParts::Recon& r = fp.recon[fp.num_recon++];
-        fp.recon_mask_idx[fp.num_recon - 1] = slot_mask_index(ctx, s, (int)(seq % kIrRing));
-        r.energy = s->d_energy[o.cur]; r.ir = later ? nullptr : s->d_ir_bands; r.host = s->h_ir[(int)(seq % kIrRing)];
+        ReconItem& r = tab[fp.num_recon++];
+        r.energy = s->d_energy[o.cur]; r.ir_bands = later ? nullptr : s->d_ir_bands; r.ir_mono = later ? nullptr : s->d_ir_mono;
+        r.host = s->h_ir[slot]; r.mask = slot_mask_ptr(ctx, s, slot); r.spb = spb_of(ctx, o.p); r.pad = 0;
     }
 #undef FS_OWED_HIP
     ctx->recon_owed.erase(ctx->recon_owed.begin(), ctx->recon_owed.begin() + (long)take);
     return FS_OK;
 }
-
 // behind the launch: note the publishes (the launch announces them itself); a source with a reverb also gets an event on the
 // compute stream for its callbacks to wait on
 int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused) {
     if (ol.owed.empty()) return FS_OK;
     const int B = ctx->cfg.num_bands;
-    if (!launched_fused) {   // no fused form for this launch: the same reconstructs as a batch kernel of their own, on the compute stream
-        unsigned slot_t = 0;
-        { const int ar = acquire_recon_tab(ctx, &slot_t); if (ar) return ar; }
-        ReconItem* tab = ctx->h_recon_tab + (size_t)slot_t * fs_context::kReconTabItems;
-        for (size_t i = 0; i < ol.owed.size(); ++i) {
-            const fs_context::ReconOwed& o = ol.owed[i];
-            tab[i].energy = o.s->d_energy[o.cur]; tab[i].ir_bands = ol.newest[i] ? o.s->d_ir_bands : nullptr;
-            tab[i].ir_mono = ol.newest[i] ? o.s->d_ir_mono : nullptr; tab[i].host = o.s->h_ir[(int)(ol.seq[i] % kIrRing)];
-            tab[i].mask = slot_mask_ptr(ctx, o.s, (int)(ol.seq[i] % kIrRing));
-            tab[i].spb = spb_of(ctx, o.p); tab[i].pad = 0;
-        }
-        launch_reconstruct_batch(tab, (int)ol.owed.size(), B, ctx->num_bins, ctx->num_samples, ctx->stream, ol.pub);
+    if (!launched_fused) {   // no fused form for this launch: the same table through the batch kernel, on the compute stream
+        launch_reconstruct_batch(ctx->h_recon_tab + (size_t)ol.tab_slot * fs_context::kReconTabItems, (int)ol.owed.size(), B, ctx->num_bins,
+                                 ctx->num_samples, ctx->stream, ol.pub);
         FS_HIP(ctx, hipGetLastError());
-        ctx->recon_tab_word[slot_t] = ol.pub.id;
     }
+    ctx->recon_tab_word[ol.tab_slot] = ol.pub.id;          // the slot's reader: this launch
     ctx->pub_issued = ol.pub.id;
     for (size_t i = 0; i < ol.owed.size(); ++i) {
         const fs_context::ReconOwed& o = ol.owed[i];

@@ -424,7 +424,6 @@ hipError_t wait_pub_word(fs_context* ctx, uint64_t id);             // producer:
 PublishWord next_pub_word(fs_context* ctx);                         // the arguments of the next self-publishing launch (id = pub_issued + 1; commit with ++pub_issued)
 bool slot_published(fs_context* ctx, Source* s, int slot);          // any thread: the publish in ring slot `slot` has completed
 uint32_t* slot_mask_ptr(const fs_context* ctx, const Source* s, int slot);   // the slot's zero-block mask word on the device (nullptr: none)
-uint16_t slot_mask_index(const fs_context* ctx, const Source* s, int slot);  // ... as an index into d_slot_masks (kNoSlotMask: none)
 hipError_t slot_mask_all_dirty(fs_context* ctx, const Source* s, int slot, hipStream_t st);   // behind a copy command into the slot
 hipError_t sync_publish(fs_context* ctx, Source* s, int slot);      // block until the publish in ring slot `slot` has completed
 int ensure_state(fs_context* ctx, uint32_t n_local, int levels, bool unbounded, double rr_prob, bool want_positions, bool want_normals,
@@ -461,6 +460,7 @@ struct OwedLaunch {
     std::vector<char> newest;                              // the source's newest frame of the launch: its IR becomes the device-resident set
     std::vector<std::unique_lock<std::mutex>> locks;
     PublishWord pub;
+    unsigned tab_slot = 0;                                 // the slot of fs_context::h_recon_tab that holds the launch's items
 };
 int owed_prepare(fs_context* ctx, FrameParts& fp, OwedLaunch& ol);
 int owed_publish(fs_context* ctx, OwedLaunch& ol, bool launched_fused);

@@ -58,7 +58,7 @@ struct FrameArgs {
     KParams kpp; unsigned* scratch_p; uint32_t* perm_p; float* zero_p; int zero_words_p; float* const* zero_tab_p; int zero_count_p;
     uint32_t plan_blocks;
     // reconstruct parts (behind the plan part): (B + 1) rows x recon_cb blocks of chunks per item
-    int num_recon; FrameParts::Recon recon[kMaxReconParts]; int16_t recon_spb[kMaxReconParts]; uint16_t recon_mask_idx[kMaxReconParts];
+    int num_recon; const ReconItem* recon_tab;   // (items in pinned host memory: FrameParts::recon_tab)
     int recon_B, recon_nb, recon_samples; uint32_t recon_cb;
     PublishWord pub;
     uint32_t connect_first;   // the connect part takes the FIRST workgroups of the grid (see FS_LAUNCH_FRAME)
@@ -108,12 +108,10 @@ __global__ __launch_bounds__(kBlock, FS_FRAME_MIN_WAVES) void frame_kernel(Devic
         extern __shared__ __attribute__((aligned(16))) int s_dyn_r[];
         const uint32_t rb = b - first - cb - a.plan_blocks, per_item = (uint32_t)(a.recon_B + 1) * a.recon_cb;
         const uint32_t item = rb / per_item, in_item = rb - item * per_item;
-        const FrameParts::Recon& r = a.recon[item];
+        const ReconItem it = a.recon_tab[item];
         float* const s_amp = reinterpret_cast<float*>(s_dyn_r);
-        reconstruct_body((int)(in_item / a.recon_cb), (int)(in_item % a.recon_cb), r.energy, a.recon_B, a.recon_nb, a.recon_samples, a.recon_spb[item],
-                         r.ir, r.ir ? r.ir + (size_t)a.recon_B * (size_t)a.recon_samples : nullptr, s_amp, r.host, s_amp + a.recon_nb,
-                         a.pub.tickets != nullptr && a.recon_mask_idx[item] != kNoSlotMask
-                             ? reinterpret_cast<uint32_t*>(a.pub.tickets) + kSlotMaskOffsetWords + a.recon_mask_idx[item] : nullptr);
+        reconstruct_body((int)(in_item / a.recon_cb), (int)(in_item % a.recon_cb), it.energy, a.recon_B, a.recon_nb, a.recon_samples, it.spb,
+                         it.ir_bands, it.ir_mono, s_amp, it.host, s_amp + a.recon_nb, it.mask);
         publish_arrive(a.pub.tickets, (uint32_t)a.num_recon * per_item, a.pub.host_word, a.pub.id);
     }
 }
@@ -188,9 +186,9 @@ bool FS_LAUNCH_FRAME(int B, const DeviceScene& sc, const FrameParts& f, hipStrea
         blocks += pb;
     }
     if (f.num_recon > 0) {
-        if (f.num_recon > kMaxReconParts || f.recon_B < 1 || f.recon_nb < 1 || f.recon_samples < 1) return false;
+        if (f.num_recon > kMaxReconParts || f.recon_tab == nullptr || f.recon_B < 1 || f.recon_nb < 1 || f.recon_samples < 1) return false;
         a.num_recon = f.num_recon;
-        for (int i = 0; i < f.num_recon; ++i) { a.recon[i] = f.recon[i]; a.recon_spb[i] = f.recon_spb[i]; a.recon_mask_idx[i] = f.recon_mask_idx[i]; }
+        a.recon_tab = f.recon_tab;
         a.recon_B = f.recon_B; a.recon_nb = f.recon_nb; a.recon_samples = f.recon_samples;
         a.pub = f.pub;
         const uint32_t chunks = (uint32_t)((f.recon_samples + kChunk - 1) / kChunk);

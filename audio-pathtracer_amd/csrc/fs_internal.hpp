@@ -234,7 +234,7 @@ struct DeepStore {
 };
 constexpr int kStackRowsCap = 21;       // LDS rows for pending entries when the tree's worst case needs more (+ 1 row of deep counts)
 constexpr int kDeepChunk = 8;           // entries moved per trip to / from the deep store
-constexpr int kMaxReconParts = 4;       // reconstruct parts of a fused launch (the frames of a group, the sources of a small batch; the 4 KB of kernel arguments are full)
+constexpr int kMaxReconParts = 256;     // reconstruct parts of a fused launch = items of one table slot (fs_context::kReconTabItems)
 
 // ---- host BVH builder ------------------------------------------------------------------------------
 struct HostBVH {
@@ -284,8 +284,7 @@ const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* ener
 // of an older one (walked before), the plan pass of the newest.  false = no fused form for this shape (lobes, counting
 // instantiations, experiment walk variants, nothing to do): the caller launches the kernels one after the other.
 constexpr int kMaxWalkParts = 8;   // walk parts of one fused launch = stages of a staged walk in flight
-constexpr uint16_t kNoSlotMask = 0xFFFFu;
-constexpr int kSlotMaskOffsetWords = 16;  // the mask table starts this many 32-bit words behind PublishWord::tickets
+constexpr int kSlotMaskOffsetWords = 16;  // the mask table starts this many 32-bit words behind the ticket cell (one device allocation)
 constexpr int kMaxMaskSources = 1024;     // sources (by handle) whose ring slots have zero-block masks; later ones always write every block
 struct PublishWord { unsigned* tickets = nullptr; unsigned long long* host_word = nullptr; unsigned long long id = 0; };
 struct WalkPart {   // a frame's walks from step stage.begin up to step stage.end
@@ -304,14 +303,12 @@ struct FrameParts {
     float* const* zero_tab_p = nullptr; int zero_count_p = 0;                              // batched frame: the buffers to flush
     // reconstruct parts: ReconstructImpulseResponse of the frames the PREVIOUS launch connected (single GPU; a sharded
     // frame is reduced on the tail stream first and reconstructed there)
-    // ir = the source's device IR set [(B + 1)][samples] (bands, then the channel view), nullptr for a frame whose IR is superseded
-    // within the launch; host = the pinned ring slot the channel view is also written into (the publish), nullptr: none.
+    // a table of ReconItem in pinned host memory (fs_context::h_recon_tab: the parts read their item across the bus, as the batch
+    // kernel does — the launch's 4 KB of arguments hold no per-item data, so a launch carries as many reconstructs as are owed:
+    // cfg5's eight sources per frame no longer fall back to kernels of their own on the tail stream).  ir_bands / ir_mono =
+    // nullptr for a frame whose IR is superseded within the launch; host = the pinned ring slot (the publish).
     int num_recon = 0;
-    struct Recon { const float* energy; float* ir; float* host; } recon[kMaxReconParts];
-    int16_t recon_spb[kMaxReconParts] = {};   // (16 bits each: the fused launch's 4 KB of kernel arguments are full)
-    // the host slots' zero-block masks (ReconItem::mask) as indices into the context's table, which lives kSlotMaskOffsetWords
-    // behind the ticket cell pub.tickets in ONE device allocation (no pointer of its own in the arguments); kNoSlotMask = none
-    uint16_t recon_mask_idx[kMaxReconParts] = {};
+    const struct ReconItem* recon_tab = nullptr;
     int recon_B = 0, recon_nb = 0, recon_samples = 0;
     // the publish of those host slots (fs_device.hpp: publish_arrive): the ticket cell, the pinned host word, this launch's id (tickets == nullptr: by an event)
     PublishWord pub;
