@@ -3,6 +3,7 @@ workgroups + a pinned host word, csrc/fs_device.hpp: publish_arrive) — the ref
 component's buffer when ReconstructImpulseResponse returns (FrequenSeeAudioComponent.cpp:377-378) and GetImpulseResponse
 reads that buffer (FrequenSeeAudioComponent.h:113).  Results must not depend on which of the three publish mechanisms
 (host word / tail-stream batch event / tail-stream copy + event) carried a frame."""
+import os
 import threading
 import time
 
@@ -25,6 +26,8 @@ def test_streamed_frames_publish_from_the_launch_itself(pkg, scene_factory, fpl)
     """Steady state of a single-GPU stream of pipelined frames: nothing is enqueued on the tail stream, no cross-stream
     wait reaches the compute stream, every IR is published through the host word — and arrives without any host-side
     synchronisation call (the consumer only polls the sequence number)."""
+    if os.environ.get("FS_FUSED_RECON") == "0":
+        pytest.skip("the diagnostic switch FS_FUSED_RECON=0 sends every reconstruct to the tail stream: the counters asserted here are about the default")
     sc = scene_factory("starter_room", 4)
     ctx, src = make_ctx(pkg, sc)
     ctx.set_pipelining(2)
@@ -145,7 +148,8 @@ def test_publish_mechanisms_interleave(pkg, scene_factory):
         ctx.synchronize()
         check(ps[k - 1])
     c = ctx.pipeline_counters()
-    assert c["publishes_by_word"] > 0 and c["publishes_by_event"] == 3, c
+    if os.environ.get("FS_FUSED_RECON") != "0":        # (the diagnostic switch sends every reconstruct to the tail stream)
+        assert c["publishes_by_word"] > 0 and c["publishes_by_event"] == 3, c
     assert ctx.impulse_response_sequence(src) == k
     ref.close(); ctx.close()
 
