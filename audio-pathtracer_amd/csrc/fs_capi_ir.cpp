@@ -1,6 +1,6 @@
 // fs_capi_ir.cpp — the reconstruct / publish entry points, the tick as one call, impulse-response and energy-buffer access
 // (C ABI: include/frequensee.h).  The machinery behind them — the tail stream, the fused reconstruct parts, the IR ring —
-// lives with the frame pipeline in fs_capi_frame.cpp.
+// lives in fs_capi_publish.cpp (and the frame pipeline around it in fs_capi_pipeline.cpp).
 #include "fs_context.hpp"
 
 using namespace fsi;

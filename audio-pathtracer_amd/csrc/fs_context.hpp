@@ -1,8 +1,9 @@
 // fs_context.hpp — the context behind the C ABI (include/frequensee.h) and the helpers its translation units share.
 // Internal: included by fs_capi_context.cpp (lifetime, helpers, stats), fs_capi_scene.cpp (geometry, commits, refit),
-// fs_capi_frame.cpp (sources, the traced frame and its pipeline, the reconstruct machinery), fs_capi_ir.cpp (reconstruct / tick /
-// IR / energy entry points), fs_capi_comm.cpp
-// (RCCL behind the ABI) and fs_capi_aux.cpp (legacy tracer, line trace, text interchange, reverb, material FD).
+// fs_capi_frame.cpp (sources, the traced frame: describe / resources / commit / launch), fs_capi_pipeline.cpp (held frames, the
+// drain), fs_capi_publish.cpp (reconstruct + publish: the IR ring, the host word, the fused launch's reconstruct parts),
+// fs_capi_ir.cpp (reconstruct / tick / IR / energy entry points), fs_capi_comm.cpp (RCCL behind the ABI) and fs_capi_aux.cpp
+// (legacy tracer, line trace, text interchange, reverb, material FD).
 //
 // Mirrors the roles of UAudioRayTracingSubsystem (context lifetime, geometry/source registries,
 // per-source update: AudioRayTracingSubsystem.cpp:32-53, 128-195) and of UFrequenSeeAudioComponent's
@@ -327,7 +328,7 @@ struct fs_context {
     bool debug_coherent = false;   // FS_DEBUG_COHERENT_WAVES (KParams.debug_coherent)
     // FS_DEBUG_STALLS: where the producer waited (printed by fs_context_destroy): flushes of held frames, host waits for a publish
     // (count, microseconds), waits enqueued on the compute stream for another stream's event, owed reconstructs run on the tail stream
-    bool flush_recon_on_compute = true;   // FS_FLUSH_RECON_ON_COMPUTE (fs_capi_frame.cpp: flush_reconstruct)
+    bool flush_recon_on_compute = true;   // FS_FLUSH_RECON_ON_COMPUTE (fs_capi_publish.cpp: flush_reconstruct)
     bool debug_stalls = false;
     struct { uint64_t flushes = 0, flushed_frames = 0, sync_publish = 0, sync_publish_us = 0, waits_enqueued = 0, waits_skipped = 0, owed_on_tail = 0, launches = 0,
              tail_ops = 0, pub_word = 0, pub_event = 0; } dbg;   // fs_get_pipeline_counters

@@ -2252,7 +2252,7 @@ constexpr int kWarm = 96;
 // A publish without the host's help: the reconstruct workgroups of a launch write the channel views straight into the sources'
 // pinned host ring slots; every one of them, once its stores have been acknowledged, takes a ticket, and the workgroup that takes
 // the last one stores the launch's id into the context's pinned host word — fs_get_impulse_response* and the ring's back-pressure
-// read that word: no event, no copy command, no second stream (fs_capi_frame.cpp: owed_publish).  The ticket cell re-arms itself.
+// read that word: no event, no copy command, no second stream (fs_capi_publish.cpp: owed_publish).  The ticket cell re-arms itself.
 // The samples go to the host with SYSTEM-scope stores (store_sys: sc0 sc1 — written through to the host before they are
 // acknowledged), so a wave whose store counter has run out (s_waitcnt vmcnt(0): on gfx9 stores count there too) knows that its
 // samples are where the host reads them; the barrier collects the workgroup's waves, the tickets the launch's workgroups, and the

@@ -1,5 +1,5 @@
 // fs_frame.hip — pipelined frames: ONE launch for the walk of one frame, the connect pass of an older one and the plan
-// pass of the newest (fs_set_pipelining; fs_capi_frame.cpp).
+// pass of the newest (fs_set_pipelining; fs_capi_frame.cpp: frame_launch, fs_capi_pipeline.cpp: drain_fused).
 //
 // Compiled twice (Makefile): as it stands — the kernel limited to 128 VGPRs and the LDS stack capped, so that four
 // workgroups share a CU, for launches that fill the chip — and through fs_frame_wide.hip with FS_FRAME_WIDE defined:
