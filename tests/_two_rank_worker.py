@@ -62,9 +62,12 @@ if mode == "gather":
     ctx.close()
     np.savez(out, **res)
     sys.exit(0)
+assert ctx.comm_info() == (0, -1, 0)                                  # fs_comm_info without a communicator
 ctx.comm_init(uid)
+assert ctx.comm_info() == (world, rank, 1), ctx.comm_info()           # what the communicator itself says (ncclCommCount / UserRank), all-reduce
 if os.environ.get("FS_TEST_ONESHOT") == "1":
     ctx.comm_enable_oneshot()     # the sum over the ranks through the peers' IPC-mapped mailboxes instead of ncclAllReduce
+    assert ctx.comm_info() == (world, rank, 2), ctx.comm_info()
 if os.environ.get("FS_TEST_PIPELINE") == "1":
     ctx.set_pipelining(2)         # held-back connect passes: the all-reduce and the reconstruct follow them
 FPL = int(os.environ.get("FS_TEST_FPL", "1"))

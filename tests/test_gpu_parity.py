@@ -874,7 +874,9 @@ def test_library_collective_one_rank(pkg, oracle_mod, scene_factory):
     sc = scene_factory("starter_room", 4)
     plain, psrc = make_ctx(pkg, sc)
     ctx = pkg.Context(num_bands=4)
+    assert ctx.comm_info() == (0, -1, 0)
     ctx.comm_init(pkg.Context.comm_unique_id())           # before set_scene: rank 0 builds + broadcasts the tree
+    assert ctx.comm_info() == (1, 0, 1)                   # fs_comm_info asks RCCL itself: one rank, this is rank 0, ncclAllReduce
     ctx.set_scene(sc.triangles, sc.material_ids, sc.absorption)
     ctx.set_listener(sc.listener)
     src = ctx.create_source(sc.source)
