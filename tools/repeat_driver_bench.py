@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""The driver's exact bench command several times in a row (fresh process each): value, ms per step and the launch period —
-a 20-step timed region is 6 ms, so anything that stalls the producer once shows.
+"""The driver's bench command several times in a row INSIDE ONE LEASE (fresh process each, with --no-cpu-baseline --no-extra): value,
+ms per step and the launch period — a 20-step timed region is 6 ms, so anything that stalls the producer once shows.
+NOT the driver's situation: the driver's process is the first GPU work of a fresh lease and runs the command without
+the two switches — tools/fresh_lease_driver_bench.sh (+ tools/fresh_lease_summary.py) reproduces that, one gpurun lease per run.
 usage: python tools/repeat_driver_bench.py [runs [KEY=VALUE ...]]   (environment of the bench processes)"""
 import json
 import os
