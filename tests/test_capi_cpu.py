@@ -71,6 +71,24 @@ def test_struct_layouts_match_header(pkg):
     assert (c.num_bands, c.sample_rate, c.num_channels, c.world_size) == (1, 48000, 2, 1)
 
 
+def test_pipeline_counters_layout_and_null_arguments(pkg):
+    """fs_pipeline_counters (round 5): the ctypes mirror has the header's layout — struct_size + reserved + 11 counters of 64 bits —
+    and the measurement entry points reject null arguments without a context (no device needed)."""
+    lib = pkg._capi.load()
+    header = open(os.path.join(ROOT, "include", "frequensee.h")).read()
+    body = header[header.index("typedef struct fs_pipeline_counters {"):header.index("} fs_pipeline_counters;")]
+    names = re.findall(r"uint64_t ([a-z_, ]+);", body)
+    fields = [n.strip() for grp in names for n in grp.split(",")]
+    mirror = [k for k, _ in pkg._capi.PipelineCounters._fields_ if k not in ("struct_size", "reserved")]
+    assert fields == mirror, (fields, mirror)
+    assert C.sizeof(pkg._capi.PipelineCounters) == 8 + 8 * len(fields)
+    pc = pkg._capi.PipelineCounters()
+    pc.struct_size = C.sizeof(pkg._capi.PipelineCounters)
+    assert lib.fs_get_pipeline_counters(None, C.byref(pc)) == pkg._capi.ERR_INVALID_ARGUMENT
+    assert lib.fs_get_streams(None, None, None) == pkg._capi.ERR_INVALID_ARGUMENT
+    assert lib.fs_comm_info(None, None, None, None) == pkg._capi.ERR_INVALID_ARGUMENT
+
+
 def test_fails_loudly_without_a_device(pkg):
     """No CPU fallback: without a HIP device the context reports FS_ERR_NO_DEVICE."""
     import torch
