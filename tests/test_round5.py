@@ -421,3 +421,67 @@ def test_zero_blocks_of_the_ring_slots_are_rewritten_when_they_must_be(pkg, scen
         assert not bad, (bad, sorted(seen))
         ref.close()
     ctx.close()
+
+
+# ---- randomized parameters against the oracle ---------------------------------------------------------------------------
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        rr = int(rng.random() < 0.8)
+        depth = int(rng.choice([0, 1, 2, 3, 5, 8, 12, 17, 33])) if rr else int(rng.choice([1, 2, 4, 7]))
+        kw = dict(depth=depth, russian_roulette=rr, seed=int(rng.integers(1, 1 << 48)),
+                  rr_prob=float(rng.choice([0.5, 0.75, 0.9, 0.95])), dist_divisor=float(rng.choice([100.0, 300.0, 1000.0])),
+                  surface_offset=float(rng.choice([0.05, 0.1, 0.5])), connect_pullback=float(rng.choice([0.05, 0.1, 1.0])),
+                  min_seg=float(rng.choice([0.0, 0.5, 1.0])), prob_exponent=float(rng.choice([0.1, 0.25, 1.0])),
+                  energy_clamp=float(rng.choice([0.5, 1.0, 100.0])), energy_gain=float(rng.choice([1.0, 10.0, 1e3])),
+                  sound_speed=float(rng.choice([300.0, 343.0])), max_trace_dist=float(rng.choice([1500.0, 1e6])))
+        flags = (4 if rng.random() < 0.3 else 0) | (1 if rng.random() < 0.3 else 0)      # cosine sampling, the fixed 1/1000 normaliser
+        cases.append((str(rng.choice(["shoebox", "starter_room"])), int(rng.choice([2, 254, 1000, 4096, 16384])), flags, kw,
+                      [float(x) for x in rng.choice([0.0, 0.01, 0.05, 0.2], 8)],
+                      rng.random(6) if rng.random() < 0.5 else None))      # (half of the cases: source and listener somewhere else in the scene's box)
+    return cases
+
+
+@pytest.mark.parametrize("mode", ["waited", "streamed"])
+def test_energy_and_published_ir_parity_over_random_parameters(pkg, oracle_mod, scene_factory, mode):
+    """64 seeded random parameter sets (depth caps 0 .. 33, roulette on / off and its probability, distance scale, offsets, clamp
+    and gain, air absorption per band, cosine sampling, the literal normaliser; 2 .. 16 384 subpaths, two scenes): the energy
+    histogram against the oracle's (same occupied bins, <= TIGHT_TOL relative RMS per band) and the PUBLISHED impulse response
+    against the oracle's reconstruct of the oracle's band-mean energy — frames waited for one by one, and the same frames
+    streamed through the pipeline (two per launch) with the last one of every scene checked."""
+    from test_gpu_parity import check_energy
+    cases = _random_cases(64, 20250105)
+    ctxs = {}
+    for name, rays, flags, kw, air, where in cases:
+        bands = 1 if name == "shoebox" else 4
+        sc = scene_factory(name, bands)
+        if name not in ctxs:
+            ctx, src = make_ctx(pkg, sc)
+            if mode == "streamed":
+                ctx.set_pipelining(2); ctx.set_frames_per_launch(2)
+            ctxs[name] = (ctx, src, oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption), sc)
+        ctx, src, osc, sc = ctxs[name]
+        spos, lpos = np.asarray(sc.source, np.float32), np.asarray(sc.listener, np.float32)
+        if where is not None:
+            lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+            spos = (lo + (0.1 + 0.8 * where[:3]) * (hi - lo)).astype(np.float32)
+            lpos = (lo + (0.1 + 0.8 * where[3:]) * (hi - lo)).astype(np.float32)
+        ctx.set_source_position(src, spos); ctx.set_listener(lpos)
+        p = pkg.default_params(num_rays=rays, flags=flags, air_absorption=air, **kw)
+        if mode == "waited":
+            got = ctx.compute_energy_response(src, p).copy()
+            ctx.reconstruct_impulse_response(src, p)
+        else:
+            ctx.compute_energy_response_async(src, p); ctx.reconstruct_impulse_response_async(src, p)
+            ctx.synchronize()
+            got = ctx.energy_buffer(src).copy()
+        op = oracle_mod.default_params(num_pairs=rays // 2, flags=flags, air_absorption=air, **kw)
+        e32, e64, cnt = osc.compute_energy(op, spos, lpos)
+        check_energy(got, e32, e64, bands)
+        mean_e = (e32.astype(np.float32).sum(axis=0, dtype=np.float32) / np.float32(bands)).astype(np.float32) if bands > 1 else e32[0]
+        ir_ref = oracle_mod.reconstruct(mean_e)
+        ir = ctx.impulse_response(src, 0)
+        assert np.abs(ir - ir_ref).max() <= IR_TOL * max(float(np.abs(ir_ref).max()), 1e-30), (name, rays, kw)
+    for ctx, *_ in ctxs.values():
+        ctx.close()
