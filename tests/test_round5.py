@@ -485,3 +485,34 @@ def test_energy_and_published_ir_parity_over_random_parameters(pkg, oracle_mod, 
         assert np.abs(ir - ir_ref).max() <= IR_TOL * max(float(np.abs(ir_ref).max()), 1e-30), (name, rays, kw)
     for ctx, *_ in ctxs.values():
         ctx.close()
+
+
+def test_ticks_over_random_sources_and_parameters(pkg, oracle_mod, scene_factory):
+    """fs_update_sources (UpdateSources, ARTS.cpp:100-126) with 1 .. 9 sources at random places and random parameters, 12 ticks:
+    every source's energy equals the oracle's frame for that source and its published IR the oracle's reconstruct — also when the
+    set of sources and the frame size change from tick to tick (tables, masks and ring slots are reused across ticks)."""
+    from test_gpu_parity import check_energy
+    sc = scene_factory("starter_room", 4)
+    ctx, _ = make_ctx(pkg, sc)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    rng = np.random.default_rng(77)
+    lo, hi = sc.triangles.min(axis=(0, 1)), sc.triangles.max(axis=(0, 1))
+    pos = [(lo + (0.15 + 0.7 * rng.random(3)) * (hi - lo)).astype(np.float32) for _ in range(9)]
+    srcs = [ctx.create_source(q) for q in pos]
+    for tick in range(12):
+        k = int(rng.integers(1, 10))
+        pick = sorted(rng.choice(9, k, replace=False).tolist())
+        rays = int(rng.choice([2, 500, 2000, 6000]))
+        kw = dict(depth=int(rng.choice([0, 0, 4, 9])), seed=int(rng.integers(1, 1 << 40)), dist_divisor=float(rng.choice([100.0, 1000.0])),
+                  energy_gain=float(rng.choice([10.0, 1e3])))
+        flags = 1 if rng.random() < 0.5 else 0
+        ctx.update_sources([srcs[i] for i in pick], pkg.default_params(num_rays=rays, flags=flags, **kw))
+        for i in pick:
+            e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=rays // 2, flags=flags, **kw), pos[i], sc.listener)
+            got = ctx.energy_buffer(srcs[i])
+            check_energy(got, e32, e64, 4)
+            mean_e = (e32.astype(np.float32).sum(axis=0, dtype=np.float32) / np.float32(4)).astype(np.float32)
+            ir_ref = oracle_mod.reconstruct(mean_e)
+            ir = ctx.impulse_response(srcs[i], 0)
+            assert np.abs(ir - ir_ref).max() <= IR_TOL * max(float(np.abs(ir_ref).max()), 1e-30), (tick, i)
+    ctx.close()
