@@ -419,14 +419,18 @@ int fs_synchronize(fs_context* ctx);
  * the complete ones behind them before the call returns (a concurrent reader may see one for a few hundred microseconds). */
 int fs_update_sources(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* params);
 
-/* GetImpulseResponse() (FSAC.h:113): pointer to the PUBLISHED [num_samples] channel buffer, valid
- * until the second-next publish; lock-free for the audio thread (RVB.cpp:136). */
+/* GetImpulseResponse() (FSAC.h:113): pointer to the PUBLISHED [num_samples] channel buffer — a slot of the source's ring of 8
+ * pinned host buffers — valid for the next 7 publishes of the source; lock-free and without a runtime call, for the audio
+ * thread (RVB.cpp:136).  The buffer is written by the launch that reconstructs the frame (ReconstructImpulseResponse leaves the IR
+ * in the component's own buffer, FSAC.cpp:377-378) and becomes the front when fs_get_impulse_response_sequence (or any producer
+ * call) has noticed the launch's announcement. */
 int fs_get_impulse_response(fs_context* ctx, fs_source src, int32_t channel, const float** data, int32_t* n);
 int fs_copy_impulse_response(fs_context* ctx, fs_source src, int32_t channel, float* out, int32_t n);
 /* Number of IRs of this source published so far (0: the zero-initialised buffer of FSAC.cpp:24-28 is in front): the k-th
  * reconstruct / fs_set_impulse_response of a source is publish k, and fs_get_impulse_response returns publish
  * `*completed` or a newer one.  Any thread, no lock; it also notices publishes that completed since the producer's last
- * call into the library (one event query per publish in flight), which fs_get_impulse_response alone does not.  A consumer that reads it before and after
+ * call into the library (a load of the context's publish word; an event query only for the few publishes that went through the
+ * tail stream), which fs_get_impulse_response alone does not.  A consumer that reads it before and after
  * copying the buffer knows that the copy is whole (the pointer stays valid for 7 publishes), and the reverb callback can
  * keep the IR's spectrum while the number stands still instead of transforming the IR every callback (RVB.cpp:188). */
 int fs_get_impulse_response_sequence(fs_context* ctx, fs_source src, uint64_t* completed);
