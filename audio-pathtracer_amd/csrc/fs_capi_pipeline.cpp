@@ -76,8 +76,10 @@ int finish_held_frame(fs_context* ctx, const fs_context::PipeFrame& q, bool may_
                 fs_context::ReconOwed o; o.s = s; o.cur = it.cur; o.fixed = q.fixed; o.p = it.recon; o.reduced = summed;
                 ctx->recon_owed.push_back(o);
             } else {
-                // (steady state with more reconstructs than a launch has parts for — cfg5's eight sources: on the tail stream,
-                // beside the next launch; on the compute stream they cost the stream of frames a fifth: 899 -> 705 M rays/s)
+                // (what cannot ride in a fused launch: a literal second flush, per-kernel timing, a sharded frame without the library's
+                // collective, more than a table slot's 256 reconstructs at once — on the tail stream beside the next launch, or, when
+                // nothing will be launched behind it, through flush_reconstruct.  Until round 5 a launch had four reconstruct parts and
+                // cfg5's eight sources per frame took this path in steady state.)
                 rc = flushing ? flush_reconstruct(ctx, s, &it.recon) : reconstruct_now(ctx, s, &it.recon);
                 if (!rc && s->tail_ordered) tail_behind_launch = true;
             }
