@@ -45,6 +45,10 @@ def test_bench_two_ranks_on_one_gpu(fake_rccl, tmp_path):  # noqa: F811
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["steps"] == 6 and res["scaling"] == "weak" and res["value"] > 0
     assert res["config"]["rays_per_frame"] == 2 * 262144 and "all-reduce" in res["config"]["collective"]
+    # round 5: the line proves its N by itself (fs_comm_info asks the communicator) and carries the timed region's timeline
+    assert res["config"]["rccl_ranks"] == 2 and res["config"]["rccl_rank"] == 0 and res["config"]["collective_kind"] == "ncclAllReduce"
+    tl = res["timeline"]
+    assert len(tl["step_host_ms"]) == 6 and tl["library"]["publishes_by_word"] + tl["library"]["publishes_by_event"] == 6
     ex = res["extra"]
     assert ex["cfg4_old_mine_1m_d12"]["value"] > 0 and ex["cfg4_old_mine_1m_d12"]["scaling"] == "strong"
     assert ex["cfg5_multi_source"]["value"] > 0 and ex["cfg5_multi_source"]["sources_per_rank"] == 4
