@@ -174,6 +174,7 @@ class PipelineCounters(C.Structure):
         ("owed_on_tail", C.c_uint64),
         ("publishes_by_word", C.c_uint64),
         ("publishes_by_event", C.c_uint64),
+        ("lane_launches", C.c_uint64),
     ]
 
     def as_dict(self):

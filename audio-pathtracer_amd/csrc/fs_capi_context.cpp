@@ -601,8 +601,16 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
             q = *end ? end + 1 : end;
         }
         ctx->sync_stage_bounds = b;   // empty: such frames walk in one piece
+        ctx->sync_stage_bounds_default = false;
     }
     if (const char* v = std::getenv("FS_SYNC_STAGE_FROM")) ctx->sync_stage_from = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("FS_SYNC_LANE")) {
+        int len = 0, end = 0;
+        if (std::sscanf(v, "%d,%d", &len, &end) >= 1) {
+            ctx->sync_lane_len = std::max(-1, std::min(FS_MAX_DEPTH, len));   // (-1: the default rule, 0: no lane)
+            ctx->sync_lane_end = end > 0 ? end : (1 << 30);
+        }
+    }
     if (const char* v = std::getenv("FS_SYNC_STAGE_RPW")) {
         for (const char* q = v; *q;) {
             char* end = nullptr;
@@ -732,6 +740,7 @@ int fs_get_pipeline_counters(fs_context* ctx, fs_pipeline_counters* out) {
     out->stream_waits_enqueued = ctx->dbg.waits_enqueued; out->stream_waits_skipped = ctx->dbg.waits_skipped;
     out->tail_stream_ops = ctx->dbg.tail_ops; out->owed_on_tail = ctx->dbg.owed_on_tail;
     out->publishes_by_word = ctx->dbg.pub_word; out->publishes_by_event = ctx->dbg.pub_event;
+    out->lane_launches = ctx->dbg.lane_launches;
     return FS_OK;
 }
 

@@ -37,6 +37,7 @@ struct Frame {
     int B = 1, levels = 0;
     bool batch = false, unbounded = false, all_conn = false, mis = false, fixed = false, accumulate = false, pipe_ok = false;
     std::vector<WalkStage> stages;      // the walk in one piece, or the stages of a pipelined depth = 0 frame
+    int lane_len = 0;                   // a waited-for staged frame: walks of this many steps or more take the long-walk lane (0: none)
     // frame_resources
     unsigned fidx = 0;                  // the frame's index: which state / schedule / scratch set it uses
     SubpathState st{};
@@ -49,6 +50,26 @@ struct Frame {
     unsigned long long* const* fixed_tab = nullptr;
     bool used_batch_slot = false;
 };
+
+// The long-walk lane of a waited-for staged frame and, with the default bound, where its first stage ends (measured:
+// tools/lane_sweep.py, profiles/r05_lane_sweep*.jsonl — ticks of 16 ... 128 reference sources and the 262 144-ray frame on both scenes).
+//   len: the lane holds about 800 walks (three cooperative waves per CU beside the first stage's): n * rr^len = 800;
+//   bound: the first stage ends 18 steps (at rr = 0.9; scaled by log 0.9 / log rr otherwise) before the lane begins, within
+//          20 ... 34 — a small frame's survivors are few and cheap, a large frame's are a throughput problem of their own.
+// Lengths live in the plan pass's buckets (<= FS_MAX_DEPTH): a roulette so close to 1 that 800 walks outlive them gets no lane.
+static bool sync_lane_plan(const fs_context* ctx, const KParams& kp, int* len, int* bound) {
+    *len = 0; *bound = 0;
+    if (ctx->sync_lane_len == 0 || !kp.russian_roulette || !(kp.rr_prob > 0.0f && kp.rr_prob < 1.0f)) return false;
+    if (ctx->sync_lane_len > 0) { *len = ctx->sync_lane_len; return true; }
+    const double n = 2.0 * (double)kp.num_local, lq = std::log(1.0 / (double)kp.rr_prob), s = 0.10536 / lq;   // s: steps per step of rr = 0.9
+    if (n < 4096.0) return false;
+    const double L = std::log(n / 800.0) / lq;
+    if (L > (double)FS_MAX_DEPTH || L < 8.0) return false;
+    const int b = (int)std::lround(std::min(std::max(L - 18.0 * s, 20.0 * s), 34.0 * s));
+    if (b < 2 || (double)b + 4.0 > L) return false;
+    *len = (int)std::lround(L); *bound = b;
+    return true;
+}
 
 void frame_describe(fs_context* ctx, Frame& f) {
     const fs_params* p = f.p;
@@ -124,6 +145,7 @@ void frame_describe(fs_context* ctx, Frame& f) {
                 (p->depth > 0 || (f.unbounded && ctx->pipelining >= 2));
     kp.plan_coop = (2ull * kp.num_local <= kPlanCoopMax || (f.unbounded && !f.pipe_ok && 2ull * kp.num_local <= kPlanCoopMaxUncapped)) ? 1 : 0;
     f.stages.clear();
+    f.lane_len = 0;
     if (f.pipe_ok && f.unbounded && !ctx->stage_bounds.empty()) {
         int begin = 0;
         // launches of two or more frames have thicker late stages: fewer, longer stages measure 3 % faster there
@@ -143,8 +165,11 @@ void frame_describe(fs_context* ctx, Frame& f) {
         // frame's time is its longest walk — a chain of ~ log(subpaths) / log(1 / rr) dependent bounces — and what a bounce
         // costs depends on who shares the wave: the first stage walks everybody on dense waves (that is where the work is),
         // the few survivors of every later stage get waves of their own whose idle lanes search with them.
-        int begin = 0;
-        for (int bound : ctx->sync_stage_bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
+        int begin = 0, lane_bound = 0;
+        std::vector<int> own_bound;
+        const bool lane = sync_lane_plan(ctx, kp, &f.lane_len, &lane_bound);
+        if (lane && ctx->sync_stage_bounds_default && lane_bound > 0) own_bound.push_back(lane_bound);
+        for (int bound : own_bound.empty() ? ctx->sync_stage_bounds : own_bound) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
     } else {
@@ -446,7 +471,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
         return FS_OK;
     }
     if (f.stages.size() > 1) {   // a staged walk that is waited for: its stages back to back
-        for (size_t k = 0; k < f.stages.size(); ++k) {
+        auto stage_launch_of = [&](size_t k) {
             WalkLaunch wk = wl;
             if (ctx->walk_rays_per_wave <= 0)
                 // (profiles/r04_sync_stage_sweep4.jsonl: the first stage — everybody, at most `bound` steps — does best on waves of 16
@@ -456,7 +481,31 @@ int frame_launch(fs_context* ctx, Frame& f) {
                                    ctx->sync_late_rays_per_wave > 0 ? ctx->sync_late_rays_per_wave :
                     auto_rays_per_wave(walk_stage_slots(kp, f.stages[k].begin), std::min(kp.depth, f.stages[k].end) - f.stages[k].begin, k > 0 ? 8192ull : 0ull);
             if (ctx->walk_rays_per_wave <= 0 && k < ctx->sync_stage_rpw.size() && ctx->sync_stage_rpw[k] > 0) wk.rays_per_wave = ctx->sync_stage_rpw[k];
+            return wk;
+        };
+        // The long-walk lane: the frame's time is its longest walk's chain of queries, and a query of a walk that shares a sparse
+        // wave of the first stage takes three to five times what it takes a cooperative wave.  The walks the plan pass found to be
+        // of lane_len steps or more (a few hundred: the first slots of the schedule) take cooperative waves from step 0 on, in the
+        // same launch as the first stage, and go on beside the survivors in the second.
+        const int lane_len = f.lane_len, lane_end = ctx->sync_lane_end;
+        uint32_t lane_cap = 0;
+        if (lane_len > 0 && !ctx->debug_rebin && walk_lane_possible(ctx->scene, kp, stage_launch_of(0), stage_launch_of(1), perm)) {
+            const double expect = 2.0 * (double)kp.num_local * std::pow((double)kp.rr_prob, (double)lane_len);
+            lane_cap = (uint32_t)std::min<double>(2.0 * (double)kp.num_local, 1.3 * expect + 64.0);
+            for (size_t k = 2; k < f.stages.size(); ++k)   // (the stages behind the second only have to SKIP the lane: any kernel but the dense one can)
+                if (stage_launch_of(k).rays_per_wave >= 64) lane_cap = 0;
+        }
+        for (size_t k = 0; k < f.stages.size(); ++k) {
+            WalkLaunch wk = stage_launch_of(k);
             WalkStage sr = f.stages[k];
+            WalkLane ln;
+            if (lane_cap > 0) {
+                ln.len = lane_len; ln.cap = lane_cap;
+                const int split = std::max(lane_end, f.stages[0].end);   // the lane's steps [0, split) run beside the first stage
+                if (k == 0) { ln.begin = 0; ln.end = split; ln.mode = kLaneSplit; ctx->dbg.lane_launches++; }
+                else if (k == 1 && split < (1 << 30)) { ln.begin = split; ln.end = 1 << 30; ln.mode = kLaneBoth; }
+                else ln.mode = kLaneSkip;
+            }
             const uint32_t* rebin = nullptr;
             if ((ctx->debug_rebin == 1 || ctx->debug_rebin == 2) && k > 0 && wk.rays_per_wave >= 64) {   // (experiment: DESIGN.md section 5)
                 const size_t lanes = 2 * (size_t)kp.num_local;
@@ -475,7 +524,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
                              ctx->d_rebin_hist + (kRebinKeys + 1), ctx->stream);
                 if (ctx->debug_rebin == 1) rebin = ctx->d_rebin;
             }
-            launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, sr, rebin);
+            launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, sr, rebin, ln);
         }
     } else {
         launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);

@@ -303,6 +303,11 @@ struct fs_context {
     int sync_first_rays_per_wave = 0;     // subpaths per wave of the first stage, 0 = by frame size (FS_SYNC_FIRST_RPW)
     int sync_late_rays_per_wave = 0;      // subpaths per wave of the later stages, 0 = by the number of survivors (FS_SYNC_LATE_RPW)
     std::vector<int> sync_stage_rpw;      // subpaths per wave of stage k of such a frame, overriding the two above where > 0 (FS_SYNC_STAGE_RPW: "32,64,0")
+    // the long-walk lane of such a frame (WalkLane): walks of sync_lane_len steps or more take cooperative waves of their
+    // own from step 0 on, steps [0, sync_lane_end) beside the first stage, the rest beside the second (FS_SYNC_LANE: "len,end"; len 0: off)
+    // -1 (default): by the frame's size and the roulette — sync_lane_plan, fs_capi_frame.cpp; with it the ONE default bound moves too
+    int sync_lane_len = -1, sync_lane_end = 1 << 30;
+    bool sync_stage_bounds_default = true;
     int sync_stage_from = 16384;          // ... of at least this many subpaths (smaller frames: every walk has a wave of its own anyway)
     int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
     std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
@@ -331,7 +336,7 @@ struct fs_context {
     bool flush_recon_on_compute = true;   // FS_FLUSH_RECON_ON_COMPUTE (fs_capi_publish.cpp: flush_reconstruct)
     bool debug_stalls = false;
     struct { uint64_t flushes = 0, flushed_frames = 0, sync_publish = 0, sync_publish_us = 0, waits_enqueued = 0, waits_skipped = 0, owed_on_tail = 0, launches = 0,
-             tail_ops = 0, pub_word = 0, pub_event = 0; } dbg;   // fs_get_pipeline_counters
+             tail_ops = 0, pub_word = 0, pub_event = 0, lane_launches = 0; } dbg;   // fs_get_pipeline_counters
     int debug_rebin = 0;           // FS_DEBUG_REBIN (experiment, tools/rebin_experiment.py): 1 = the later stages of a waited-for staged walk on dense waves walk their slots in the order of the walks' positions; 2 = the order is computed but not used (its cost alone); 3 = neither (staged walks under the counting instantiation)
     uint32_t* d_rebin = nullptr; unsigned* d_rebin_hist = nullptr; size_t rebin_cap = 0;
     int over_cap_forced = 0;       // FS_OVER_CAP, read at fs_context_create

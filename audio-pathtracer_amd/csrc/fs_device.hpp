@@ -940,6 +940,15 @@ __device__ __forceinline__ uint32_t stage_slots(const WalkStage& sr, const Subpa
     return n;
 }
 
+// slots of the long-walk lane (WalkLane): the walks of len steps or more, at most cap — the same number in every
+// part of every launch of the frame (a function of the plan pass's bucket counts alone)
+__device__ __forceinline__ uint32_t lane_slots(const WalkLane& ln, const unsigned* s_cnt) {
+    if (ln.len <= 0) return 0u;
+    uint32_t n = 0;
+    for (int L = min(ln.len, FS_MAX_DEPTH); L <= FS_MAX_DEPTH; ++L) n += s_cnt[L];
+    return min(n, ln.cap);
+}
+
 template <bool EXT = false>
 __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathState& st) {
     if (EXT && st.end_posd) { st.end_posd[3 * (size_t)w.slot] = w.dpx; st.end_posd[3 * (size_t)w.slot + 1] = w.dpy; st.end_posd[3 * (size_t)w.slot + 2] = w.dpz; }
@@ -1393,7 +1402,7 @@ template <int LOBES, bool COUNT, bool EXT = false, bool IGN = EXT>
 __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
                                                  const uint32_t* __restrict__ perm, const int rays_per_wave,
-                                                 const WalkStage sr = WalkStage()) {
+                                                 const WalkStage sr = WalkStage(), const WalkLane ln = WalkLane()) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
@@ -1405,6 +1414,7 @@ __device__ __forceinline__ void walk_sparse_body(const uint32_t bid, const Devic
     const uint32_t wave = bid * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
     bool alive = lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
+    if (ln.len > 0 && ln.mode == kLaneSkip) alive = alive && slot >= lane_slots(ln, s_cnt);   // (the long-walk lane's slots: cooperative waves of the same launch)
     int* stack = &s_stack[threadIdx.x];
     Walker w;
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
@@ -1843,7 +1853,7 @@ template <int LOBES, bool COUNT, bool EXT = false>
 __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceScene& sc, const CoopView& cv, const KParams& kp,
                                                const SubpathState& st, const unsigned* __restrict__ scratch,
                                                const uint32_t* __restrict__ perm, const int rays_per_wave,
-                                               const WalkStage sr = WalkStage()) {
+                                               const WalkStage sr_in = WalkStage(), const WalkLane ln = WalkLane()) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [lds_nodes][16] records of 4 words | [waves][kCoopWaveWords]
     __shared__ unsigned s_cnt[kPlanBuckets];
     if (perm) {
@@ -1854,7 +1864,15 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
     const uint32_t wave = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
     int* wl = coop_wave_words(cv, s_dyn);
-    bool alive = lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
+    // the stage of this lane's walk: the launch's, or the long-walk lane's own (WalkLane; the lane's slots come first)
+    WalkStage sr = sr_in;
+    bool mine = true;
+    if (ln.len > 0) {
+        const bool in_lane = slot < lane_slots(ln, s_cnt);
+        if (in_lane) { sr.begin = ln.begin; sr.end = ln.end; }
+        mine = ln.mode == kLaneBoth || (ln.mode == kLaneOnly) == in_lane;
+    }
+    bool alive = mine && lane < (uint32_t)rays_per_wave && slot < stage_slots(sr, st, 2u * kp.num_local, s_cnt);
     Walker w;
     walker_start(w, alive ? (perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot) : 0u,
                  slot, kp, st, alive && sr.begin == 0);
@@ -2548,7 +2566,8 @@ inline size_t device_lds_per_block() {
 // fits, else its top.  A launch whose workgroups all fit the chip at once (one per CU) may take the CU's whole LDS; one
 // that comes in rounds leaves room for a second workgroup per CU.
 inline int coop_resident_nodes(const CoopView& cv, int waves_per_block, uint32_t blocks, int num_cus) {
-    const size_t cu_lds = 160 * 1024, per_block = std::min(device_lds_per_block(), blocks <= (uint32_t)std::max(num_cus, 1) ? cu_lds : cu_lds / 2);
+    static const int per_cu = std::getenv("FS_COOP_WG_PER_CU") ? std::max(1, std::atoi(std::getenv("FS_COOP_WG_PER_CU"))) : 2;   // (experiments)
+    const size_t cu_lds = 160 * 1024, per_block = std::min(device_lds_per_block(), blocks <= (uint32_t)std::max(num_cus, 1) ? cu_lds : cu_lds / (size_t)per_cu);
     const size_t fixed = kCoopWaveBytes * (size_t)waves_per_block + 1024;   // + the kernels' small static arrays
     if (per_block <= fixed || !cv.rec) return 0;
     return (int)std::min<size_t>((size_t)std::max(cv.nodes, 0), (per_block - fixed) / ((size_t)16 << cv.wshift));

@@ -221,6 +221,17 @@ struct WalkStage {
     int32_t begin = 0, end = 1 << 30;
     uint32_t slots_cap = 0xFFFFFFFFu;
 };
+// The long-walk lane of a waited-for staged frame (fs_capi_frame.cpp): the longest walks — those of
+// len steps or more, at most cap of them: the FIRST slots of the length-sorted schedule — walk on cooperative waves of
+// their own from step 0 on, with their own stage bounds, beside the launch's other walks.  len = 0: no such lane.
+struct WalkLane {
+    int32_t len = 0;
+    uint32_t cap = 0;
+    int32_t begin = 0, end = 1 << 30;   // the lane's stage in this launch
+    int32_t mode = 0;                   // kLaneBoth / kLaneOnly / kLaneSkip: which of the two classes of slots this part walks
+};
+constexpr int32_t kLaneBoth = 0, kLaneOnly = 1, kLaneSkip = 2;
+constexpr int32_t kLaneSplit = 3;   // (to launch_walk: ONE launch whose first workgroups are the lane's cooperative waves — kLaneOnly — and whose others walk the rest — kLaneSkip)
 
 // host side of DeviceScene.deep: owned by the context, grown by the launchers (attach_deep) when a grid has more lanes
 // than the store has columns.  A replaced buffer stays allocated until the scene is freed: launches already in the
@@ -317,7 +328,11 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
 // does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule
 bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s, const WalkStage& stage = WalkStage(), const uint32_t* rebin = nullptr);
+                 const uint32_t* perm, hipStream_t s, const WalkStage& stage = WalkStage(), const uint32_t* rebin = nullptr,
+                 const WalkLane& lane = WalkLane());
+// can a staged frame whose first stage launches like `first` and whose later ones like `late` have a long-walk lane
+// (WalkLane)?  (sparse first stage, cooperative later stages, a cooperative view of the tree for one walk per wave)
+bool walk_lane_possible(const DeviceScene& sc, const KParams& kp, const WalkLaunch& first, const WalkLaunch& late, const uint32_t* perm);
 // (rebin — FS_DEBUG_REBIN, the re-binning experiment of DESIGN.md section 5, dense waves only: lane i of the stage walks slot
 // rebin[i], the stage's slots ordered by (cell of the walk's position, octant of its surface normal); null: lane i = slot i)
 // lanes a walk stage needs: all subpaths for a stage that starts at step 0, else the expected number of walks longer than

@@ -68,16 +68,16 @@ template <int LOBES, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(kBlock) void walk_kernel_sparse(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
                                                              const uint32_t* __restrict__ perm, int rays_per_wave,
-                                                             WalkStage stage) {
-    walk_sparse_body<LOBES, COUNT, EXT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave, stage);
+                                                             WalkStage stage, WalkLane lane) {
+    walk_sparse_body<LOBES, COUNT, EXT>(blockIdx.x, sc, kp, st, scratch, perm, rays_per_wave, stage, lane);
 }
 
 template <int LOBES, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(kBlock) void walk_kernel_coop(DeviceScene sc, CoopView cv, KParams kp, SubpathState st,
                                                            const unsigned* __restrict__ scratch,
                                                            const uint32_t* __restrict__ perm, int rays_per_wave,
-                                                           WalkStage stage) {
-    walk_coop_body<LOBES, COUNT, EXT>(blockIdx.x, sc, cv, kp, st, scratch, perm, rays_per_wave, stage);
+                                                           WalkStage stage, WalkLane lane) {
+    walk_coop_body<LOBES, COUNT, EXT>(blockIdx.x, sc, cv, kp, st, scratch, perm, rays_per_wave, stage, lane);
 }
 // the default instantiation with eight waves per workgroup: one workgroup per CU keeps sixteen hundred more resident
 // records in its LDS than two workgroups of four waves could (fs_device.hpp: coop_lds_bytes)
@@ -85,8 +85,24 @@ constexpr int kCoopBigWaves = 8;
 __global__ __launch_bounds__(64 * kCoopBigWaves) void walk_kernel_coop_big(DeviceScene sc, CoopView cv, KParams kp, SubpathState st,
                                                                            const unsigned* __restrict__ scratch,
                                                                            const uint32_t* __restrict__ perm, int rays_per_wave,
-                                                                           WalkStage stage) {
-    walk_coop_body<0, false, false>(blockIdx.x, sc, cv, kp, st, scratch, perm, rays_per_wave, stage);
+                                                                           WalkStage stage, WalkLane lane) {
+    walk_coop_body<0, false, false>(blockIdx.x, sc, cv, kp, st, scratch, perm, rays_per_wave, stage, lane);
+}
+
+// A first stage with a long-walk lane (WalkLane): the first lane_blocks workgroups are cooperative waves of ONE walk each
+// — the frame's longest walks, whose chain of queries sets the frame's time, at the cooperative search's latency from step 0 on —
+// the others walk everybody else on sparse waves as before.  One launch: the two run side by side.
+template <int LOBES, bool COUNT, bool EXT = false>
+__global__ __launch_bounds__(kBlock) void walk_kernel_lane(DeviceScene sc, CoopView cv, KParams kp, SubpathState st,
+                                                           const unsigned* __restrict__ scratch, const uint32_t* __restrict__ perm,
+                                                           int rays_per_wave, WalkStage stage, WalkLane lane, uint32_t lane_blocks) {
+    if (blockIdx.x < lane_blocks) {
+        lane.mode = kLaneOnly;
+        walk_coop_body<LOBES, COUNT, EXT>(blockIdx.x, sc, cv, kp, st, scratch, perm, 1, stage, lane);
+    } else {
+        lane.mode = kLaneSkip;
+        walk_sparse_body<LOBES, COUNT, EXT>(blockIdx.x - lane_blocks, sc, kp, st, scratch, perm, rays_per_wave, stage, lane);
+    }
 }
 
 // ---- FS_DEBUG_REBIN: the re-binning experiment -----------------------------------------------
@@ -193,10 +209,18 @@ uint32_t walk_stage_slots(const KParams& kp, int begin) {
     return (uint32_t)std::min<double>((double)lanes, (double)std::max(kp.stage_margin, 1.3f) * expect + 1024.0);
 }
 
+bool walk_lane_possible(const DeviceScene& sc, const KParams& kp, const WalkLaunch& first, const WalkLaunch& late, const uint32_t* perm) {
+    if (!perm || !kp.russian_roulette || kp.count) return false;
+    if (!FS_SHARED_WALK(first) || !first.coop || first.rays_per_wave <= 0 || first.rays_per_wave >= 64) return false;
+    if (!FS_SHARED_WALK(late) || !late.coop || !coop_rays_per_wave(late.rays_per_wave)) return false;
+    return coop_view(sc, 1) != nullptr && coop_view(sc, late.rays_per_wave) != nullptr;
+}
+
 void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s, const WalkStage& stage_in, const uint32_t* rebin) {
+                 const uint32_t* perm, hipStream_t s, const WalkStage& stage_in, const uint32_t* rebin, const WalkLane& lane_in) {
     DeviceScene sc = sc_in;
     WalkStage stage = stage_in;
+    WalkLane lane = lane_in;
     if (stage.begin > 0 && stage.slots_cap == 0xFFFFFFFFu) stage.slots_cap = walk_stage_slots(kp, stage.begin);
     uint32_t lanes = stage.begin > 0 ? stage.slots_cap : 2u * kp.num_local;   // a later stage only has lanes for the walks still alive
     if (lanes == 0) return;
@@ -210,13 +234,32 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
         else if (kp.count) { allow_lds(K<0, true>, lds); hipLaunchKernelGGL((K<0, true>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }     \
         else { allow_lds(K<0, false>, lds); hipLaunchKernelGGL((K<0, false>), dim3(GRID), dim3(kBlock), lds, s, __VA_ARGS__); }                 \
     } while (0)
+    if (lane.len > 0 && lane.mode == kLaneSplit) {   // a first stage on sparse waves + the long-walk lane on cooperative ones
+        const CoopView* lv = shared && wl.coop && perm && wl.rays_per_wave > 0 && wl.rays_per_wave < 64 ? coop_view(sc, 1) : nullptr;
+        if (lv && lane.cap > 0) {
+            CoopView cv = *lv;
+            const size_t lds_walk = stack_bytes(sc) + kShareLdsBytes, lds_walk_ext = stack_bytes(sc) + kShareIgnLdsBytes;
+            const uint32_t lane_blocks = (lane.cap + kBlock / 64 - 1) / (kBlock / 64);
+            const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
+            const uint32_t blocks = lane_blocks + (waves + kBlock / 64 - 1) / (kBlock / 64);
+            // the lane's resident records: what fits into the LDS the sparse workgroups of the launch take anyway
+            const size_t lane_fixed = kCoopWaveBytes * (size_t)(kBlock / 64);
+            cv.lds_nodes = lds_walk > lane_fixed ? (int)std::min<size_t>((size_t)std::max(cv.nodes, 0), (lds_walk - lane_fixed) / ((size_t)16 << cv.wshift)) : 0;
+            const size_t lds = std::max(lds_walk, coop_lds_bytes(kBlock / 64, cv)), lds_ext = std::max(lds_walk_ext, coop_lds_bytes(kBlock / 64, cv));
+            if (!attach_deep(sc, blocks)) return;
+            FS_LAUNCH_WALK(walk_kernel_lane, blocks, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage, lane, lane_blocks);
+            return;
+        }
+        lane.len = 0;   // (no cooperative view of this tree, or dense waves: everybody walks the stage as before)
+    }
     const CoopView* cvp = shared && wl.coop && coop_rays_per_wave(wl.rays_per_wave) ? coop_view(sc, wl.rays_per_wave) : nullptr;
     if (cvp) {   // a handful of subpaths per wave: every query searched by a whole group of lanes
         CoopView cv = *cvp;
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const bool plain = !(kp.dpos || kp.ignore_on || kp.listener_radius > 0.0f || kp.source_radius > 0.0f || kp.lobes || kp.count);
         // workgroups of eight waves when the frame needs more than four waves per CU (and the instantiation exists)
-        const int W = plain && waves > 4u * (uint32_t)std::max(wl.num_cus, 1) ? kCoopBigWaves : kBlock / 64;
+        static const bool big_ok = !(std::getenv("FS_COOP_BIG") && std::atoi(std::getenv("FS_COOP_BIG")) == 0);   // (experiments)
+        const int W = big_ok && plain && waves > 4u * (uint32_t)std::max(wl.num_cus, 1) ? kCoopBigWaves : kBlock / 64;
         const uint32_t blocks = (waves + (uint32_t)W - 1) / (uint32_t)W;
         cv.lds_nodes = coop_resident_nodes(cv, W, blocks, wl.num_cus);
         static const int resident_max = std::getenv("FS_COOP_RESIDENT_MAX") ? std::atoi(std::getenv("FS_COOP_RESIDENT_MAX")) : -1;   // (experiments: fewer staged records)
@@ -227,9 +270,9 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
                               lanes, wl.rays_per_wave, blocks, W, 1 << cv.wshift, cv.lds_nodes, cv.nodes, lds);
         if (W == kCoopBigWaves) {
             allow_lds(walk_kernel_coop_big, lds);
-            hipLaunchKernelGGL(walk_kernel_coop_big, dim3(blocks), dim3(64 * W), lds, s, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
+            hipLaunchKernelGGL(walk_kernel_coop_big, dim3(blocks), dim3(64 * W), lds, s, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage, lane);
         } else {
-            FS_LAUNCH_WALK(walk_kernel_coop, blocks, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
+            FS_LAUNCH_WALK(walk_kernel_coop, blocks, sc, cv, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage, lane);
         }
         return;
     }
@@ -238,7 +281,7 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const uint32_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
         if (!attach_deep(sc, blocks)) return;
-        FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage);
+        FS_LAUNCH_WALK(walk_kernel_sparse, blocks, sc, kp, st, wl.queue_head, perm, wl.rays_per_wave, stage, lane);
         return;
     }
     if (!attach_deep(sc, full)) return;

@@ -553,6 +553,7 @@ typedef struct fs_pipeline_counters {
     uint64_t owed_on_tail;           /* reconstructs that missed their fused launch and ran on kernels of their own */
     uint64_t publishes_by_word;      /* impulse responses published by the launch itself (compute stream, pinned host word) */
     uint64_t publishes_by_event;     /* ... through an event on the tail stream (a copy command or a batch kernel there) */
+    uint64_t lane_launches;          /* first-stage launches of waited-for uncapped frames that carried a long-walk lane (cooperative waves for the longest walks) */
 } fs_pipeline_counters;
 int fs_get_pipeline_counters(fs_context* ctx, fs_pipeline_counters* out);
 /* The context's HIP streams as hipStream_t values: the compute stream (fs_config.stream if the caller gave one, else the

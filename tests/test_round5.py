@@ -516,3 +516,57 @@ def test_ticks_over_random_sources_and_parameters(pkg, oracle_mod, scene_factory
             ir = ctx.impulse_response(srcs[i], 0)
             assert np.abs(ir - ir_ref).max() <= IR_TOL * max(float(np.abs(ir_ref).max()), 1e-30), (tick, i)
     ctx.close()
+
+
+# ---- the long-walk lane of waited-for uncapped frames --------------------------------------------------------------------------
+@pytest.mark.parametrize("bounds,lane", [("24", "40,78"), ("24", "30,0"), ("16", "8,40"), ("24", "64,80"), ("24", "20,24"), ("5,9,70", "12,30"),
+                                          ("24", "2,50"), (None, None)])
+def test_the_long_walk_lane_changes_nothing_but_the_time(pkg, oracle_mod, scene_factory, monkeypatch, bounds, lane):
+    """FS_SYNC_LANE = "len,end": the walks of `len` steps or more (the plan pass knows every walk's length) take cooperative waves
+    of their own from step 0 on — steps [0, end) in the launch of the first stage, the rest in the second's (end 0: all of it in
+    the first; no setting: length and first bound by the frame's size, sync_lane_plan in fs_capi_frame.cpp).  Whatever the setting — the lane ending inside the main record tier, beyond it, at the first bound, finishing in the
+    first launch, holding most of the frame — energies (deterministic mode: bit for bit), IRs and counters are those of the walk
+    in one piece; batched sources and a walk that ignores its own actor too; and the frame equals the oracle's."""
+    from test_gpu_parity import check_energy
+    from test_round4 import _room_with_a_box_around_the_source
+    sc = scene_factory("starter_room", 4)
+    scb, tris, mats, obj = _room_with_a_box_around_the_source(pkg)
+    out = {}
+    for mode in ("whole", "lane"):
+        if mode == "lane" and bounds is None:   # the library's defaults (frames of 16 384 subpaths or more walk in stages)
+            for k in ("FS_SYNC_WALK_STAGES", "FS_SYNC_LANE", "FS_SYNC_STAGE_FROM"):
+                monkeypatch.delenv(k, raising=False)
+        else:
+            monkeypatch.setenv("FS_SYNC_WALK_STAGES", bounds if mode == "lane" else "")
+            monkeypatch.setenv("FS_SYNC_LANE", lane if mode == "lane" else "0")
+            monkeypatch.setenv("FS_SYNC_STAGE_FROM", "1")
+        ctx, s = make_ctx(pkg, sc)
+        s2 = ctx.create_source(np.asarray(sc.source, np.float32) + np.float32(40.0))
+        p = pkg.default_params(num_rays=24576, depth=0, seed=91, flags=DET)
+        e = ctx.compute_energy_response(s, p).copy()
+        ctx.reconstruct_impulse_response(s, p)
+        got = [e, ctx.impulse_response(s, 0).copy()]
+        for seed in (92, 93):   # (the second frame finds the first one's continuation records in the state set)
+            ctx.compute_energy_response_batch_async([s, s2], pkg.default_params(num_rays=6000, depth=0, seed=seed, flags=DET))
+            ctx.synchronize()
+            got += [ctx.energy_buffer(s).copy(), ctx.energy_buffer(s2).copy()]
+        st = ctx.stats()
+        got.append(np.asarray([st[k] for k in ("segments", "connections_tested", "deposits", "frames", "rays")], np.int64))
+        plain = ctx.compute_energy_response(s, pkg.default_params(num_rays=24576, depth=0, seed=91)).copy()
+        assert ctx.pipeline_counters()["lane_launches"] == (0 if mode == "whole" else 2 if bounds is None else 4)
+        ctx.close()
+        # a walk that ignores the actor it starts from (the EXT instantiations of the same kernels)
+        cb = pkg.Context(num_bands=1)
+        cb.set_scene(tris, mats, scb.absorption, object_ids=obj)
+        cb.set_listener(scb.listener)
+        sb = cb.create_source(scb.source)
+        cb.set_source_object(sb, 7)
+        got.append(cb.compute_energy_response(sb, pkg.default_params(num_rays=32768, depth=0, seed=77, flags=DET)).copy())
+        cb.close()
+        out[mode] = got + [plain]
+    assert out["whole"][0].any() and out["whole"][3].any() and out["whole"][-2].any()
+    for a, b in zip(out["whole"][:-1], out["lane"][:-1]):
+        assert np.array_equal(a, b)
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy(oracle_mod.default_params(num_pairs=12288, depth=0, seed=91), sc.source, sc.listener)
+    check_energy(out["lane"][-1], e32, e64, 4)

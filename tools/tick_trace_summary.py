@@ -7,7 +7,7 @@ import json
 import sys
 
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-KNOWN = ["plan_kernel", "walk_kernel_coop_big", "walk_kernel_coop", "walk_kernel_sparse", "walk_kernel_shared", "connect_kernel",
+KNOWN = ["plan_kernel", "walk_kernel_lane", "walk_kernel_coop_big", "walk_kernel_coop", "walk_kernel_sparse", "walk_kernel_shared", "connect_kernel",
          "reconstruct_batch_kernel", "reconstruct_kernel", "fixed_to_energy", "coop16_kernel", "coop_nodes_kernel"]
 rows = []
 for r in csv.DictReader(open(f)):
