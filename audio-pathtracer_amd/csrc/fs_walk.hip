@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_lane(DeviceScene sc, CoopV
                                                            int rays_per_wave, WalkStage stage, WalkLane lane, uint32_t lane_blocks) {
     if (blockIdx.x < lane_blocks) {
         lane.mode = kLaneOnly;
+        __builtin_amdgcn_s_setprio(3);   // (the chain's waves ahead of the first stage's at the issue port: 1 % of the 262 144-ray frame)
         walk_coop_body<LOBES, COUNT, EXT>(blockIdx.x, sc, cv, kp, st, scratch, perm, 1, stage, lane);
     } else {
         lane.mode = kLaneSkip;

@@ -14,6 +14,9 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 import __graft_entry__ as graft
 pkg = graft.load_package()
+if os.environ.get("FS_LIB_PATH"):   # (an experimental build: tools/build_variant.sh)
+    pkg._capi.LIB_PATH = os.path.abspath(os.environ["FS_LIB_PATH"])
+    pkg._capi._lib = None
 scene = sys.argv[1]
 res = {}
 # the headline-sized frame
