@@ -1861,6 +1861,10 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
     }
     coop_stage_nodes(cv, s_dyn);                            // (with the barrier the bucket counts need)
     const uint32_t lane = threadIdx.x & 63u;
+    // (consecutive waves, consecutive slots: the eight longest walks of a frame share a CU, two to a SIMD.  Strided over the workgroups
+    // instead — wave w of workgroup b = wave number w * gridDim.x + b — they have a CU each; measured: one-source tick's walk kernel
+    // 243.8 -> 241.2 us, and frames of more waves than the chip holds LOSE — a workgroup then lives as long as its longest walk with seven
+    // dead waves: 8-source tick 0.42 -> 0.55 ms.  Not kept)
     const uint32_t wave = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t slot = wave * (uint32_t)rays_per_wave + lane;
     int* wl = coop_wave_words(cv, s_dyn);
@@ -1958,7 +1962,9 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
     if (lane == 0u && g_wave_buf) {   // [0] start, [1] end (100 MHz) | cycles: [2] in queries, [3] in all, [6] in the loop head | [4] traversal steps, [5] queries
         unsigned long long* o = g_wave_buf + 8ull * wave;
         o[0] = tl_r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tl_trav;
-        o[3] = __builtin_amdgcn_s_memtime() - tl_c0; o[4] = tl_steps; o[5] = tl_seg; o[6] = tl_next;
+        o[3] = __builtin_amdgcn_s_memtime() - tl_c0; o[4] = tl_steps; o[6] = tl_next;
+        o[5] = tl_seg | ((unsigned long long)__builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4) << 32)             // HW_REG_HW_ID bits [15:0]: wave, simd, pipe, cu, sh, se
+               | ((unsigned long long)(__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xFu) << 48);           // HW_REG_XCC_ID
         o[7] = (tl_pro & 0xFFFFull) | ((tl_tri / 16) & 0xFFFFull) << 16 | ((tl_nodewait / 16) & 0xFFFFull) << 32 | ((tl_epi / 16) & 0xFFFFull) << 48;   // (/16, 16 bits each)
         o[7] = (tl_pro / 16 & 0xFFFFull) | (o[7] & ~0xFFFFull);
     }
