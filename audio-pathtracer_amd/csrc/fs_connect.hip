@@ -5,13 +5,13 @@
 namespace fs {
 namespace {
 
-template <int B, int LOBES, bool BATCH, bool COUNT, bool EXT = false>
-__global__ __launch_bounds__(kBlock, 4) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
+template <int B, int LOBES, bool BATCH, bool COUNT, bool EXT = false, int AHEAD = 1>
+__global__ __launch_bounds__(kBlock, AHEAD > 4 ? 2 : 4) void connect_kernel(DeviceScene sc, KParams kp, SubpathState st,
                                                          float* __restrict__ energy,
                                                          unsigned long long* __restrict__ fixed, unsigned* queue_head,
                                                          int pairs_per_wave, float* const* __restrict__ energy_tab,
                                                          unsigned long long* const* __restrict__ fixed_tab) {
-    connect_body<B, LOBES, BATCH, COUNT, EXT>(blockIdx.x, gridDim.x, sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);
+    connect_body<B, LOBES, BATCH, COUNT, EXT, AHEAD>(blockIdx.x, gridDim.x, sc, kp, st, energy, fixed, queue_head, pairs_per_wave, energy_tab, fixed_tab);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -221,6 +221,9 @@ __global__ __launch_bounds__(kBlock) void fixed_to_energy_kernel(const unsigned 
     if (i < words) energy[i] = (float)((double)fixed[i] * (1.0 / kFixedScale));
 }
 
+#ifndef FS_CONNECT_AHEAD_N
+#define FS_CONNECT_AHEAD_N 4
+#endif
 template <int B>
 void launch_connect_t(const DeviceScene& sc_in, const KParams& kp, const SubpathState& st, float* energy,
                       unsigned long long* fixed, unsigned* queue_head, int pairs_per_wave, float* const* energy_tab,
@@ -252,6 +255,21 @@ void launch_connect_t(const DeviceScene& sc_in, const KParams& kp, const Subpath
             allow_lds(connect_kernel<0, -1, false, false, true>, lds);
             hipLaunchKernelGGL((connect_kernel<0, -1, false, false, true>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed,
                                queue_head, pairs_per_wave, energy_tab, fixed_tab);
+        }
+        return;
+    }
+    // uncapped walks (the waited-for frames; the pipelined ones connect inside the fused launch): paths of up to a few hundred
+    // segments, evaluated by ONE lane when the wave is dense — four records in flight (connect_body's AHEAD)
+    static const int ahead = std::getenv("FS_CONNECT_AHEAD") ? std::atoi(std::getenv("FS_CONNECT_AHEAD")) : 4;   // (0 / 1: one at a time)
+    if (st.over_levels != 0 && !kp.lobes && !kp.count && ahead > 1) {
+        if (batch) {
+            allow_lds(connect_kernel<B, 0, true, false, false, FS_CONNECT_AHEAD_N>, lds);
+            hipLaunchKernelGGL((connect_kernel<B, 0, true, false, false, FS_CONNECT_AHEAD_N>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head,
+                               pairs_per_wave, energy_tab, fixed_tab);
+        } else {
+            allow_lds(connect_kernel<B, 0, false, false, false, FS_CONNECT_AHEAD_N>, lds);
+            hipLaunchKernelGGL((connect_kernel<B, 0, false, false, false, FS_CONNECT_AHEAD_N>), dim3(blocks), dim3(kBlock), lds, s, sc, kp, st, energy, fixed, queue_head,
+                               pairs_per_wave, energy_tab, fixed_tab);
         }
         return;
     }

@@ -1982,7 +1982,12 @@ __device__ __forceinline__ void walk_coop_body(const uint32_t bid, const DeviceS
 // BATCH: a batched frame (fs_compute_energy_response_batch): the pairs of several sources lie end to end
 // (kp.pairs_per_source each) and every source has its own energy buffer (energy_tab / fixed_tab); a workgroup
 // takes (source, chunk) items and flushes its LDS histogram whenever the source changes.
-template <int B, int LOBES, bool BATCH, bool COUNT, bool EXT = false>
+// AHEAD (the connect kernels of uncapped walks that are waited for): a lane that evaluates its pair's path alone requests the
+// records of AHEAD segments at once and applies them in path order — the same operations in the same order.  The records of a
+// walk lie a whole level apart ([step][slot]): one at a time, every segment of a 100-segment path waited for its own miss.
+// (Also measured: the paths of 40 segments or more evaluated by the whole wave, as a sparse wave does for every path — no gain
+// on top of this: 88 -> 92 us at cfg3's size.  With the records ahead the longest path is no longer what the pass waits for.)
+template <int B, int LOBES, bool BATCH, bool COUNT, bool EXT = false, int AHEAD = 1>
 __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t nblocks, const DeviceScene& sc,
                                              const KParams& kp, const SubpathState& st, float* __restrict__ energy,
                                              unsigned long long* __restrict__ fixed, unsigned* queue_head,
@@ -2070,6 +2075,48 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
 #pragma unroll
         for (int b = 0; b < Bands<B>::kMax; ++b) E[b] = 1.0f;
         float sd = 0.0f;
+        // one lane evaluates its pair's connected path alone: EvaluatePath over F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
+        auto eval_alone = [&]() {
+        const int kf = (int)Fm.y, kl = (int)Lm.y;
+        if (AHEAD > 1) {
+            for (int j0 = 0; j0 < kf; j0 += AHEAD) {                      // source-side segments F_j -> F_j+1, AHEAD records in flight
+                float2 np[AHEAD];
+                uint32_t mt[AHEAD];
+#pragma unroll
+                for (int u = 0; u < AHEAD; ++u) { const int j = min(j0 + u, kf - 1); np[u] = load_np(st, total, j, sf); mt[u] = load_mat(st, total, j, sf); }
+#pragma unroll
+                for (int u = 0; u < AHEAD; ++u)
+                    if (j0 + u < kf) { sd += np[u].x; apply_segment<B, LOBES>(E, np[u].x, mt[u], np[u].y, kp, sc); }
+            }
+        } else
+        for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
+            const float2 np = load_np(st, total, j, sf);
+            sd += np.x;                                               // ARTS.cpp:374
+            apply_segment<B, LOBES>(E, np.x, load_mat(st, total, j, sf), np.y, kp, sc);
+        }
+        {                                                             // connection segment: F_k's material/prob
+            float dist = sqrtf(l2);
+            float nd = (EXT && kp.dpos) ? conn_nd : dist / kp.dist_divisor;
+            sd += nd;
+            apply_segment<B, LOBES>(E, nd, Fm.x, F.w, kp, sc);
+        }
+        if (AHEAD > 1) {
+            for (int j0 = kl - 1; j0 >= 0; j0 -= AHEAD) {                 // listener-side segments B_j+1 -> B_j
+                float2 np[AHEAD];
+                uint32_t mt[AHEAD];
+#pragma unroll
+                for (int u = 0; u < AHEAD; ++u) { const int j = max(j0 - u, 0); np[u] = load_np(st, total, j, sl); mt[u] = load_mat(st, total, j, sl); }
+#pragma unroll
+                for (int u = 0; u < AHEAD; ++u)
+                    if (j0 - u >= 0) { sd += np[u].x; apply_segment<B, LOBES>(E, np[u].x, mt[u], np[u].y, kp, sc); }
+            }
+        } else
+        for (int j = kl - 1; j >= 0; --j) {                           // listener-side segments B_j+1 -> B_j
+            const float2 np = load_np(st, total, j, sl);
+            sd += np.x;
+            apply_segment<B, LOBES>(E, np.x, load_mat(st, total, j, sl), np.y, kp, sc);
+        }
+        };
         if (ppw == 1u || (ppw <= 8u && st.over_levels != 0)) {
             // Few pairs per wave (the reference's own frames: one; ticks of several sources with uncapped walks: up to eight, of
             // which a fifth connect — and a connected path of uncapped walks has up to a few hundred segments, 40 us of ONE
@@ -2142,24 +2189,7 @@ __device__ __forceinline__ void connect_body(const uint32_t bid, const uint32_t 
         // be traced again (FS_ERR_OVERFLOW); its pair must not be evaluated, the records it would read do not exist
         if (st.over_levels && !(rec_fits(st, (int)Fm.y - 1, sf) && rec_fits(st, (int)Lm.y - 1, sl))) return;
         ++my_deposits;
-        // EvaluatePath over the connected path F0..Fk, Bm..B0 (ARTS.cpp:262-267, 360-420), in path order
-        const int kf = (int)Fm.y, kl = (int)Lm.y;
-        for (int j = 0; j < kf; ++j) {                                // source-side segments F_j -> F_j+1
-            const float2 np = load_np(st, total, j, sf);
-            sd += np.x;                                               // ARTS.cpp:374
-            apply_segment<B, LOBES>(E, np.x, load_mat(st, total, j, sf), np.y, kp, sc);
-        }
-        {                                                             // connection segment: F_k's material/prob
-            float dist = sqrtf(l2);
-            float nd = (EXT && kp.dpos) ? conn_nd : dist / kp.dist_divisor;
-            sd += nd;
-            apply_segment<B, LOBES>(E, nd, Fm.x, F.w, kp, sc);
-        }
-        for (int j = kl - 1; j >= 0; --j) {                           // listener-side segments B_j+1 -> B_j
-            const float2 np = load_np(st, total, j, sl);
-            sd += np.x;
-            apply_segment<B, LOBES>(E, np.x, load_mat(st, total, j, sl), np.y, kp, sc);
-        }
+        eval_alone();
         }
         float delay = sd / kp.sound_speed;                            // ARTS.cpp:419
         float x = (delay * 1000.f) / 1.0f;                            // FSAC.h:89, BinSizeMs = 1
