@@ -42,7 +42,16 @@ int fs_reconstruct_impulse_response_async(fs_context* ctx, fs_source h, const fs
         break;
     }
     FS_FLUSH(ctx);
-    return reconstruct_now(ctx, s, p);
+    // A frame nobody holds (pipelining off, or a frame of another shape).  A producer that WAITS for every frame — it has synchronized
+    // since this source's last reconstruct: the reference's UpdateSource, FSAC.cpp:377-378 — gets the short way: on one GPU the
+    // reconstruct goes onto the COMPUTE stream as a batch of one, like a flush's; the kernel writes the published host slot itself — no
+    // hand-over to the tail stream, no copy command, no mask reset (30 us of gaps between four small commands: the reference-sized
+    // update 0.32 -> 0.29 ms).  A producer that streams frames without waiting keeps the tail stream's overlap with its next frame
+    // (712 against 688 M rays/s for unpipelined cfg3 frames), and a buffer the tail stream owns (fs_energy_handoff: the caller's
+    // collective is there) is reconstructed there, behind it.
+    const bool waited = s->recon_sync_mark != ctx->syncs;
+    s->recon_sync_mark = ctx->syncs;
+    return (s->tail_ordered || !waited) ? reconstruct_now(ctx, s, p) : flush_reconstruct(ctx, s, p);
 }
 
 int fs_reconstruct_impulse_response_batch_async(fs_context* ctx, const fs_source* sources, int32_t count, const fs_params* p) {
@@ -143,6 +152,7 @@ int fs_synchronize(fs_context* ctx) {
     if (!ctx) return FS_ERR_INVALID_ARGUMENT;
     if (!ctx->device_ok) return ctx->fail(FS_ERR_NO_DEVICE, "no HIP device available (no CPU fallback)");
     FS_FLUSH(ctx);   // pipelined frames: a held-back connect pass goes first
+    ctx->syncs++;
     FS_HIP(ctx, hipSetDevice(ctx->cfg.device));
     FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     FS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));

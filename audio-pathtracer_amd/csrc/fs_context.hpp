@@ -103,6 +103,7 @@ struct Source {
     // newest publish that reads or writes the device IR set from the TAIL stream (a copy command behind reconstruct_now, a batch
     // kernel): a reconstruct on the compute stream waits for it before it writes the set.  0: none / a compute-stream publish.
     uint64_t cur_pub_seq = 0;
+    uint64_t recon_sync_mark = ~0ull;    // fs_context::syncs at this source's last stand-alone reconstruct (fs_reconstruct_impulse_response_async)
     // ... and the other way round: the newest COMPUTE-stream launch that writes the set (its id in fs_context::h_pub_word; 0: none) —
     // a reconstruct on the tail stream lets the compute stream hand over first while that launch may still be running
     uint64_t dev_ir_word = 0;
@@ -308,6 +309,7 @@ struct fs_context {
     // -1 (default): by the frame's size and the roulette — sync_lane_plan, fs_capi_frame.cpp; with it the ONE default bound moves too
     int sync_lane_len = -1, sync_lane_end = 1 << 30;
     bool sync_stage_bounds_default = true;
+    uint64_t syncs = 0;                   // fs_synchronize calls (a stand-alone reconstruct asks whether its producer waits for every frame: Source::recon_sync_mark)
     int sync_stage_from = 16384;          // ... of at least this many subpaths (smaller frames: every walk has a wave of its own anyway)
     int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
     std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
