@@ -167,7 +167,9 @@ void frame_describe(fs_context* ctx, Frame& f) {
         // the few survivors of every later stage get waves of their own whose idle lanes search with them.
         int begin = 0, lane_bound = 0;
         std::vector<int> own_bound;
-        const bool lane = sync_lane_plan(ctx, kp, &f.lane_len, &lane_bound);
+        // (no cooperative view of the tree — a map beyond kCoopMaxCoordinate —, no lane: the bound stays where it does best without one)
+        const bool lane = (ctx->coop_info.wide16.rec != nullptr || ctx->coop_info.wide4.rec != nullptr) && sync_lane_plan(ctx, kp, &f.lane_len, &lane_bound);
+        if (!lane) f.lane_len = 0;
         if (lane && ctx->sync_stage_bounds_default && lane_bound > 0) own_bound.push_back(lane_bound);
         for (int bound : own_bound.empty() ? ctx->sync_stage_bounds : own_bound) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
@@ -486,7 +488,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
         // The long-walk lane: the frame's time is its longest walk's chain of queries, and a query of a walk that shares a sparse
         // wave of the first stage takes three to five times what it takes a cooperative wave.  The walks the plan pass found to be
         // of lane_len steps or more (a few hundred: the first slots of the schedule) take cooperative waves from step 0 on, in the
-        // same launch as the first stage, and go on beside the survivors in the second.
+        // same launch as the first stage (to their end by default; FS_SYNC_LANE's `end`: the rest beside the survivors in the second).
         const int lane_len = f.lane_len, lane_end = ctx->sync_lane_end;
         uint32_t lane_cap = 0;
         if (lane_len > 0 && !ctx->debug_rebin && walk_lane_possible(ctx->scene, kp, stage_launch_of(0), stage_launch_of(1), perm)) {
