@@ -603,7 +603,7 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
         ctx->sync_stage_bounds = b;   // empty: such frames walk in one piece
         ctx->sync_stage_bounds_default = false;
     }
-    if (const char* v = std::getenv("FS_SYNC_STAGE_FROM")) ctx->sync_stage_from = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("FS_SYNC_STAGE_FROM")) { ctx->sync_stage_from = std::max(1, std::atoi(v)); ctx->sync_stage_from_default = false; }
     if (const char* v = std::getenv("FS_SYNC_LANE")) {
         int len = 0, end = 0;
         if (std::sscanf(v, "%d,%d", &len, &end) >= 1) {

@@ -57,6 +57,7 @@ struct Frame {
 //   bound: the first stage ends 18 steps (at rr = 0.9; scaled by log 0.9 / log rr otherwise) before the lane begins, within
 //          20 ... 34 — a small frame's survivors are few and cheap, a large frame's are a throughput problem of their own.
 // Lengths live in the plan pass's buckets (<= FS_MAX_DEPTH): a roulette so close to 1 that 800 walks outlive them gets no lane.
+constexpr int kSyncStageFromWithoutLane = 16384;   // (round 4's threshold: without a lane a 16 000-subpath frame does better in one piece)
 static bool sync_lane_plan(const fs_context* ctx, const KParams& kp, int* len, int* bound) {
     *len = 0; *bound = 0;
     if (ctx->sync_lane_len == 0 || !kp.russian_roulette || !(kp.rr_prob > 0.0f && kp.rr_prob < 1.0f)) return false;
@@ -160,7 +161,9 @@ void frame_describe(fs_context* ctx, Frame& f) {
         f.stages.push_back(last);
     } else if (!f.pipe_ok && (f.unbounded || (ctx->debug_rebin && p->russian_roulette && p->depth > 1)) && plain &&   // (FS_DEBUG_REBIN: the experiment also stages capped walks)
                (ctx->profiling < 3 || ctx->debug_rebin) &&   // (an ignored actor or end-point spheres: the stage kernels' EXT instantiations — tests/test_round5.py)
-               !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from) {
+               !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from &&
+               (2ull * kp.num_local >= (unsigned long long)kSyncStageFromWithoutLane || !ctx->sync_stage_from_default ||
+                ((ctx->coop_info.wide16.rec != nullptr || ctx->coop_info.wide4.rec != nullptr) && ctx->sync_lane_len != 0 && ctx->sync_stage_bounds_default))) {
         // A depth = 0 frame that is waited for (not held): the same stages, one launch after the other on the stream.  The
         // frame's time is its longest walk — a chain of ~ log(subpaths) / log(1 / rr) dependent bounces — and what a bounce
         // costs depends on who shares the wave: the first stage walks everybody on dense waves (that is where the work is),

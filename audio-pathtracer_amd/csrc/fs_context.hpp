@@ -310,7 +310,8 @@ struct fs_context {
     int sync_lane_len = -1, sync_lane_end = 1 << 30;
     bool sync_stage_bounds_default = true;
     uint64_t syncs = 0;                   // fs_synchronize calls (a stand-alone reconstruct asks whether its producer waits for every frame: Source::recon_sync_mark)
-    int sync_stage_from = 16384;          // ... of at least this many subpaths (smaller frames: every walk has a wave of its own anyway)
+    bool sync_stage_from_default = true;
+    int sync_stage_from = 15000;          // ... of at least this many subpaths (smaller frames: every walk has a wave of its own anyway; with the long-walk lane an 8-source tick — 16 000 — gains 5 %, 14 000 lose: profiles/r05_stage_from.jsonl; 16 384 until then)
     int stage_dense_from = 4096;     // stages with at least this many (provisioned) walks use dense waves (FS_STAGE_DENSE_FROM)
     std::shared_ptr<RefineJob> refine;   // fs_scene_commit_progressive: the background build whose tree replaces the device-built one
     std::vector<std::thread> refine_threads;   // every background build ever started (cancelled ones too): joined before the context goes

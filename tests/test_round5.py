@@ -533,7 +533,7 @@ def test_the_long_walk_lane_changes_nothing_but_the_time(pkg, oracle_mod, scene_
     scb, tris, mats, obj = _room_with_a_box_around_the_source(pkg)
     out = {}
     for mode in ("whole", "lane"):
-        if mode == "lane" and bounds is None:   # the library's defaults (frames of 16 384 subpaths or more walk in stages)
+        if mode == "lane" and bounds is None:   # the library's defaults (frames of 15 000 subpaths or more walk in stages)
             for k in ("FS_SYNC_WALK_STAGES", "FS_SYNC_LANE", "FS_SYNC_STAGE_FROM"):
                 monkeypatch.delenv(k, raising=False)
         else:
