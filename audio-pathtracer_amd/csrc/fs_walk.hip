@@ -259,8 +259,7 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
         const uint32_t waves = (lanes + (uint32_t)wl.rays_per_wave - 1) / (uint32_t)wl.rays_per_wave;
         const bool plain = !(kp.dpos || kp.ignore_on || kp.listener_radius > 0.0f || kp.source_radius > 0.0f || kp.lobes || kp.count);
         // workgroups of eight waves when the frame needs more than four waves per CU (and the instantiation exists)
-        static const bool big_ok = !(std::getenv("FS_COOP_BIG") && std::atoi(std::getenv("FS_COOP_BIG")) == 0);   // (experiments)
-        const int W = big_ok && plain && waves > 4u * (uint32_t)std::max(wl.num_cus, 1) ? kCoopBigWaves : kBlock / 64;
+        const int W = plain && waves > 4u * (uint32_t)std::max(wl.num_cus, 1) ? kCoopBigWaves : kBlock / 64;
         const uint32_t blocks = (waves + (uint32_t)W - 1) / (uint32_t)W;
         cv.lds_nodes = coop_resident_nodes(cv, W, blocks, wl.num_cus);
         static const int resident_max = std::getenv("FS_COOP_RESIDENT_MAX") ? std::atoi(std::getenv("FS_COOP_RESIDENT_MAX")) : -1;   // (experiments: fewer staged records)
