@@ -206,9 +206,6 @@ void free_state(fs_context* ctx) {
         if (q) (void)hipFree(q);
     if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
     ctx->h_overflow = nullptr;
-    if (ctx->d_rebin) (void)hipFree(ctx->d_rebin);
-    if (ctx->d_rebin_hist) (void)hipFree(ctx->d_rebin_hist);
-    ctx->d_rebin = nullptr; ctx->d_rebin_hist = nullptr; ctx->rebin_cap = 0;
     ctx->d_over_np = nullptr; ctx->d_over_mat = nullptr; ctx->d_over_pos = nullptr; ctx->d_overflow = nullptr; ctx->d_cont = nullptr; ctx->d_end_posd = nullptr;
     ctx->over_cap = ctx->over_cap_pos = 0; ctx->cap_posd = 0;
     if (ctx->walk.perm) (void)hipFree(ctx->walk.perm);
@@ -556,10 +553,8 @@ int fs_context_create(const fs_config* cfg, fs_context** out) {
     if (const char* v = std::getenv("FS_WALK_VARIANT")) ctx->walk.variant = std::atoi(v) == 0 ? 0 : 2;
 #endif
     if (const char* v = std::getenv("FS_WALK_PLAN")) ctx->walk.plan = std::atoi(v) ? 1 : 0;
-    if (const char* v = std::getenv("FS_DEBUG_REBIN")) ctx->debug_rebin = std::atoi(v);
     if (const char* v = std::getenv("FS_DEBUG_STALLS")) ctx->debug_stalls = std::atoi(v) != 0;
     if (const char* v = std::getenv("FS_FLUSH_RECON_ON_COMPUTE")) ctx->flush_recon_on_compute = std::atoi(v) != 0;
-    if (const char* v = std::getenv("FS_DEBUG_COHERENT_WAVES")) ctx->debug_coherent = std::atoi(v) != 0;   // timing experiments only: results are void
     if (const char* v = std::getenv("FS_OVER_CAP")) ctx->over_cap_forced = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("FS_WALK_COOP")) ctx->walk.coop = std::atoi(v) ? 1 : 0;
     if (const char* v = std::getenv("FS_FUSED_RECON")) ctx->fused_recon = std::atoi(v) != 0;

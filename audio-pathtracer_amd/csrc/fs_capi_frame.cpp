@@ -99,7 +99,6 @@ void frame_describe(fs_context* ctx, Frame& f) {
     kp.depth = f.unbounded ? FS_MAX_DEPTH + kOverLevels : f.levels;
     kp.mis_depth = f.unbounded ? kUnboundedDepth : f.levels;
     kp.russian_roulette = p->russian_roulette ? 1 : 0;
-    kp.debug_coherent = ctx->debug_coherent ? 1 : 0;
     kp.cosine = (p->flags & FS_FLAG_COSINE_SAMPLING) ? 1 : 0;
     kp.rr_prob = p->rr_prob;
     kp.stage_margin = ctx->stage_margin;
@@ -159,8 +158,8 @@ void frame_describe(fs_context* ctx, Frame& f) {
         for (int bound : bounds) { WalkStage sr; sr.begin = begin; sr.end = bound; f.stages.push_back(sr); begin = bound; }
         WalkStage last; last.begin = begin; last.end = 1 << 30;
         f.stages.push_back(last);
-    } else if (!f.pipe_ok && (f.unbounded || (ctx->debug_rebin && p->russian_roulette && p->depth > 1)) && plain &&   // (FS_DEBUG_REBIN: the experiment also stages capped walks)
-               (ctx->profiling < 3 || ctx->debug_rebin) &&   // (an ignored actor or end-point spheres: the stage kernels' EXT instantiations — tests/test_round5.py)
+    } else if (!f.pipe_ok && f.unbounded && plain && ctx->profiling < 3 &&
+               // (an ignored actor or end-point spheres stage too: the stage kernels' EXT instantiations — tests/test_round5.py)
                !ctx->sync_stage_bounds.empty() && 2ull * kp.num_local >= (unsigned long long)ctx->sync_stage_from &&
                (2ull * kp.num_local >= (unsigned long long)kSyncStageFromWithoutLane || !ctx->sync_stage_from_default ||
                 ((ctx->coop_info.wide16.rec != nullptr || ctx->coop_info.wide4.rec != nullptr) && ctx->sync_lane_len != 0 && ctx->sync_stage_bounds_default))) {
@@ -494,7 +493,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
         // same launch as the first stage (to their end by default; FS_SYNC_LANE's `end`: the rest beside the survivors in the second).
         const int lane_len = f.lane_len, lane_end = ctx->sync_lane_end;
         uint32_t lane_cap = 0;
-        if (lane_len > 0 && !ctx->debug_rebin && walk_lane_possible(ctx->scene, kp, stage_launch_of(0), stage_launch_of(1), perm)) {
+        if (lane_len > 0 && walk_lane_possible(ctx->scene, kp, stage_launch_of(0), stage_launch_of(1), perm)) {
             const double expect = 2.0 * (double)kp.num_local * std::pow((double)kp.rr_prob, (double)lane_len);
             lane_cap = (uint32_t)std::min<double>(2.0 * (double)kp.num_local, 1.3 * expect + 64.0);
             for (size_t k = 2; k < f.stages.size(); ++k)   // (the stages behind the second only have to SKIP the lane: any kernel but the dense one can)
@@ -511,25 +510,7 @@ int frame_launch(fs_context* ctx, Frame& f) {
                 else if (k == 1 && split < (1 << 30)) { ln.begin = split; ln.end = 1 << 30; ln.mode = kLaneBoth; }
                 else ln.mode = kLaneSkip;
             }
-            const uint32_t* rebin = nullptr;
-            if ((ctx->debug_rebin == 1 || ctx->debug_rebin == 2) && k > 0 && wk.rays_per_wave >= 64) {   // (experiment: DESIGN.md section 5)
-                const size_t lanes = 2 * (size_t)kp.num_local;
-                if (lanes > ctx->rebin_cap) {
-                    FS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    if (ctx->d_rebin) (void)hipFree(ctx->d_rebin);
-                    if (ctx->d_rebin_hist) (void)hipFree(ctx->d_rebin_hist);
-                    ctx->d_rebin = nullptr; ctx->d_rebin_hist = nullptr; ctx->rebin_cap = 0;
-                    FS_HIP(ctx, hipMalloc((void**)&ctx->d_rebin, sizeof(uint32_t) * lanes));
-                    FS_HIP(ctx, hipMalloc((void**)&ctx->d_rebin_hist, sizeof(unsigned) * 2 * (kRebinKeys + 1)));
-                    FS_HIP(ctx, hipMemsetAsync(ctx->d_rebin_hist, 0, sizeof(unsigned) * 2 * (kRebinKeys + 1), ctx->stream));
-                    ctx->rebin_cap = lanes;
-                }
-                sr.slots_cap = walk_stage_slots(kp, sr.begin);
-                launch_rebin(ctx->scene, st, wl.queue_head, sr.begin, sr.slots_cap, ctx->d_rebin, ctx->d_rebin_hist,
-                             ctx->d_rebin_hist + (kRebinKeys + 1), ctx->stream);
-                if (ctx->debug_rebin == 1) rebin = ctx->d_rebin;
-            }
-            launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, sr, rebin, ln);
+            launch_walk(ctx->scene, kp, st, wk, perm, ctx->stream, sr, ln);
         }
     } else {
         launch_walk(ctx->scene, kp, st, wl, perm, ctx->stream);

@@ -333,15 +333,12 @@ struct fs_context {
     double* d_end_posd = nullptr; size_t cap_posd = 0;   // FS_FLAG_DOUBLE_POSITIONS: end points in double [lanes][3] (such frames are never held: one set)
     float4* d_cont = nullptr;        // continuation records of staged walks: [state_sets][2][cap_lanes]
     uint32_t over_cap = 0, over_cap_pos = 0;
-    bool debug_coherent = false;   // FS_DEBUG_COHERENT_WAVES (KParams.debug_coherent)
     // FS_DEBUG_STALLS: where the producer waited (printed by fs_context_destroy): flushes of held frames, host waits for a publish
     // (count, microseconds), waits enqueued on the compute stream for another stream's event, owed reconstructs run on the tail stream
     bool flush_recon_on_compute = true;   // FS_FLUSH_RECON_ON_COMPUTE (fs_capi_publish.cpp: flush_reconstruct)
     bool debug_stalls = false;
     struct { uint64_t flushes = 0, flushed_frames = 0, sync_publish = 0, sync_publish_us = 0, waits_enqueued = 0, waits_skipped = 0, owed_on_tail = 0, launches = 0,
              tail_ops = 0, pub_word = 0, pub_event = 0, lane_launches = 0; } dbg;   // fs_get_pipeline_counters
-    int debug_rebin = 0;           // FS_DEBUG_REBIN (experiment, tools/rebin_experiment.py): 1 = the later stages of a waited-for staged walk on dense waves walk their slots in the order of the walks' positions; 2 = the order is computed but not used (its cost alone); 3 = neither (staged walks under the counting instantiation)
-    uint32_t* d_rebin = nullptr; unsigned* d_rebin_hist = nullptr; size_t rebin_cap = 0;
     int over_cap_forced = 0;       // FS_OVER_CAP, read at fs_context_create
     unsigned* d_overflow = nullptr;   // the device's address of ...
     unsigned* h_overflow = nullptr;   // ... this pinned host word

@@ -1324,8 +1324,7 @@ __device__ __forceinline__ void add_fetch_counts(unsigned* scratch, int first_co
 template <int LOBES, bool COUNT, bool EXT = false, bool IGN = EXT>
 __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const DeviceScene& sc, const KParams& kp,
                                                  const SubpathState& st, const unsigned* __restrict__ scratch,
-                                                 const uint32_t* __restrict__ perm, const WalkStage sr = WalkStage(),
-                                                 const uint32_t* __restrict__ rebin = nullptr) {
+                                                 const uint32_t* __restrict__ perm, const WalkStage sr = WalkStage()) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];   // [stack_rows][kBlock] | work-sharing area
     int* s_stack = s_dyn;
     __shared__ unsigned s_cnt[kPlanBuckets];
@@ -1335,10 +1334,8 @@ __device__ __forceinline__ void walk_shared_body(const uint32_t bid, const Devic
     if (perm) __syncthreads();
     const uint32_t li = bid * kBlock + threadIdx.x;
     if (li >= stage_slots(sr, st, 2u * kp.num_local, s_cnt)) return;
-    const uint32_t slot = rebin ? rebin[li] : li;   // (FS_DEBUG_REBIN: the stage's slots in the order of the walks' positions)
-    // (FS_DEBUG_COHERENT_WAVES: every lane of the wave walks the subpath of the wave's first slot — timing experiments only)
-    const uint32_t gslot = kp.debug_coherent ? (slot & ~63u) : slot;
-    const uint32_t g = perm ? planned_subpath(gslot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : gslot;
+    const uint32_t slot = li;
+    const uint32_t g = perm ? planned_subpath(slot, min(kp.depth, FS_MAX_DEPTH), 2u * kp.num_local, s_cnt, perm) : slot;
     int* stack = &s_stack[threadIdx.x];
     Walker w;
     walker_start(w, g, slot, kp, st, sr.begin == 0);

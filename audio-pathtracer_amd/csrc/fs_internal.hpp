@@ -144,8 +144,6 @@ struct KParams {
                            //   roulette practically never reaches: 0.9^512 ~ 4e-24)
     int32_t mis_depth;     // depth cap D of the all-connections weights (kUnboundedDepth for depth = 0)
     int16_t russian_roulette;
-    int16_t debug_coherent;   // FS_DEBUG_COHERENT_WAVES (timing experiments only, results are void): all 64 lanes of a dense walk wave walk the SAME subpath
-                              //   — the ceiling of what re-binning subpaths for coherence could buy
     int16_t cosine;
     int16_t ignore_on;     // some walk of the frame ignores an actor: the EXT instantiations run (16 bits each: the fused launch's 4 KB of arguments are full)
     int32_t lobes;         // 1 = FS_FLAG_MATERIAL_LOBES: the walk picks a specular / diffuse / transmitted lobe per vertex
@@ -328,21 +326,13 @@ bool launch_frame(int B, const DeviceScene& sc, const FrameParts& f, hipStream_t
 // does this frame have a plan pass (roulette on, not empty)?  blocks / sort: its grid and whether it writes the schedule
 bool plan_shape(const KParams& kp, const WalkLaunch& wl, uint32_t* blocks, bool* sort);
 void launch_walk(const DeviceScene& sc, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s, const WalkStage& stage = WalkStage(), const uint32_t* rebin = nullptr,
-                 const WalkLane& lane = WalkLane());
+                 const uint32_t* perm, hipStream_t s, const WalkStage& stage = WalkStage(), const WalkLane& lane = WalkLane());
 // can a staged frame whose first stage launches like `first` and whose later ones like `late` have a long-walk lane
 // (WalkLane)?  (sparse first stage, cooperative later stages, a cooperative view of the tree for one walk per wave)
 bool walk_lane_possible(const DeviceScene& sc, const KParams& kp, const WalkLaunch& first, const WalkLaunch& late, const uint32_t* perm);
-// (rebin — FS_DEBUG_REBIN, the re-binning experiment of DESIGN.md section 5, dense waves only: lane i of the stage walks slot
-// rebin[i], the stage's slots ordered by (cell of the walk's position, octant of its surface normal); null: lane i = slot i)
 // lanes a walk stage needs: all subpaths for a stage that starts at step 0, else the expected number of walks longer than
 // stage.begin under the roulette (x1.3 + 1024: the count is binomial, the margin is hundreds of standard deviations)
 uint32_t walk_stage_slots(const KParams& kp, int begin);
-// FS_DEBUG_REBIN: the slots of the stage that begins at step `begin`, ordered by where their walks are (counting sort over
-// kRebinKeys keys: histogram, scan, scatter) -> rebin[0 .. n); hist / offs: kRebinKeys + 1 words each, hist zero on entry (and on exit)
-constexpr int kRebinKeys = 1 << 15;
-void launch_rebin(const DeviceScene& sc, const SubpathState& st, const unsigned* scratch, int begin, uint32_t slots_cap,
-                  uint32_t* rebin, unsigned* hist, unsigned* offs, hipStream_t s);
 // fixed != nullptr: deterministic mode, deposits go to the [B][bins] u64 fixed-point histogram instead
 // energy_tab / fixed_tab: per-source buffers of a batched frame (device arrays of kp.num_local / kp.pairs_per_source
 // pointers), null for one source (`energy` / `fixed` are used)

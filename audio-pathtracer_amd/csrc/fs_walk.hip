@@ -59,9 +59,8 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_simple(DeviceScene sc, KPa
 template <int LOBES, bool COUNT, bool EXT = false>
 __global__ __launch_bounds__(kBlock) void walk_kernel_shared(DeviceScene sc, KParams kp, SubpathState st,
                                                              const unsigned* __restrict__ scratch,
-                                                             const uint32_t* __restrict__ perm, WalkStage stage,
-                                                             const uint32_t* __restrict__ rebin) {
-    walk_shared_body<LOBES, COUNT, EXT>(blockIdx.x, sc, kp, st, scratch, perm, stage, rebin);
+                                                             const uint32_t* __restrict__ perm, WalkStage stage) {
+    walk_shared_body<LOBES, COUNT, EXT>(blockIdx.x, sc, kp, st, scratch, perm, stage);
 }
 
 template <int LOBES, bool COUNT, bool EXT = false>
@@ -106,78 +105,7 @@ __global__ __launch_bounds__(kBlock) void walk_kernel_lane(DeviceScene sc, CoopV
     }
 }
 
-// ---- FS_DEBUG_REBIN: the re-binning experiment -----------------------------------------------
-// key of a suspended walk: the Morton code of its position's cell (16 x 16 x 16 over the root node's grid) and the octant of
-// the surface normal it leaves from (the next direction is sampled around it); walks that have ended sort behind all others
-__device__ __forceinline__ uint32_t spread4(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }
-__device__ __forceinline__ uint32_t rebin_key(const NodeQ4* nodes, const SubpathState& st, uint32_t slot) {
-    const float4 a = st.cont_a[slot], c = st.cont_b[slot];
-    if (!(__float_as_uint(c.w) & kContAlive)) return (uint32_t)kRebinKeys;
-    const float ox = nodes[0].ox, oy = nodes[0].oy, oz = nodes[0].oz, sx = nodes[0].sx, sy = nodes[0].sy, sz = nodes[0].sz;
-    const uint32_t qx = (uint32_t)fminf(fmaxf((a.x - ox) / sx, 0.0f), 255.0f) >> 4;
-    const uint32_t qy = (uint32_t)fminf(fmaxf((a.y - oy) / sy, 0.0f), 255.0f) >> 4;
-    const uint32_t qz = (uint32_t)fminf(fmaxf((a.z - oz) / sz, 0.0f), 255.0f) >> 4;
-    const uint32_t cell = spread4(qx) | (spread4(qy) << 1) | (spread4(qz) << 2);
-    const uint32_t oct = (c.x < 0.0f ? 1u : 0u) | (c.y < 0.0f ? 2u : 0u) | (c.z < 0.0f ? 4u : 0u);
-    return (cell << 3) | oct;
-}
-__device__ __forceinline__ uint32_t rebin_slots(const unsigned* scratch, int begin, uint32_t cap) {
-    uint32_t n = 0;
-    for (int L = min(begin, FS_MAX_DEPTH); L <= FS_MAX_DEPTH; ++L) n += scratch[1 + L];
-    return min(n, cap);
-}
-__global__ __launch_bounds__(kBlock) void rebin_hist_kernel(const NodeQ4* nodes, SubpathState st, const unsigned* scratch, int begin,
-                                                            uint32_t cap, unsigned* hist) {
-    const uint32_t n = rebin_slots(scratch, begin, cap);
-    // (the loop is wave-uniform: n is rounded up to whole waves; walks that have ended share ONE key — one atomic per wave for them)
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ((n + 63u) & ~63u); i += gridDim.x * kBlock) {
-        const uint32_t key = i < n ? rebin_key(nodes, st, i) : 0xFFFFFFFFu;
-        const unsigned long long dead = __ballot(key == (uint32_t)kRebinKeys);
-        if (key < (uint32_t)kRebinKeys) atomicAdd(&hist[key], 1u);
-        else if (key == (uint32_t)kRebinKeys && (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)dead) - 1)) atomicAdd(&hist[kRebinKeys], (unsigned)__popcll(dead));
-    }
-}
-__global__ __launch_bounds__(1024) void rebin_scan_kernel(unsigned* hist, unsigned* offs) {
-    constexpr int kPer = (kRebinKeys + 1 + 1023) / 1024;
-    __shared__ unsigned s_sum[1024];
-    const int first = (int)threadIdx.x * kPer;
-    unsigned mine = 0;
-    for (int i = first; i < min(first + kPer, kRebinKeys + 1); ++i) mine += hist[i];
-    s_sum[threadIdx.x] = mine;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = (int)threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0u;
-        __syncthreads();
-        s_sum[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned run = s_sum[threadIdx.x] - mine;
-    for (int i = first; i < min(first + kPer, kRebinKeys + 1); ++i) { const unsigned h = hist[i]; offs[i] = run; run += h; hist[i] = 0u; }
-}
-__global__ __launch_bounds__(kBlock) void rebin_scatter_kernel(const NodeQ4* nodes, SubpathState st, const unsigned* scratch, int begin,
-                                                               uint32_t cap, unsigned* offs, uint32_t* rebin) {
-    const uint32_t n = rebin_slots(scratch, begin, cap);
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ((n + 63u) & ~63u); i += gridDim.x * kBlock) {
-        const uint32_t key = i < n ? rebin_key(nodes, st, i) : 0xFFFFFFFFu;
-        const unsigned long long dead = __ballot(key == (uint32_t)kRebinKeys);
-        const unsigned lane = threadIdx.x & 63u, leader = dead ? (unsigned)(__ffsll((long long)dead) - 1) : 0u;
-        unsigned base = 0u;
-        if (dead && lane == leader) base = atomicAdd(&offs[kRebinKeys], (unsigned)__popcll(dead));
-        base = (unsigned)__shfl((int)base, (int)leader);
-        if (key < (uint32_t)kRebinKeys) rebin[atomicAdd(&offs[key], 1u)] = i;
-        else if (key == (uint32_t)kRebinKeys) rebin[base + (unsigned)__popcll(dead & ((1ull << lane) - 1ull))] = i;
-    }
-}
-
 }  // namespace
-
-void launch_rebin(const DeviceScene& sc, const SubpathState& st, const unsigned* scratch, int begin, uint32_t slots_cap,
-                  uint32_t* rebin, unsigned* hist, unsigned* offs, hipStream_t s) {
-    const uint32_t blocks = std::max(1u, std::min((slots_cap + kBlock - 1) / kBlock, 2048u));
-    hipLaunchKernelGGL(rebin_hist_kernel, dim3(blocks), dim3(kBlock), 0, s, sc.nodes, st, scratch, begin, slots_cap, hist);
-    hipLaunchKernelGGL(rebin_scan_kernel, dim3(1), dim3(1024), 0, s, hist, offs);
-    hipLaunchKernelGGL(rebin_scatter_kernel, dim3(blocks), dim3(kBlock), 0, s, sc.nodes, st, scratch, begin, slots_cap, offs, rebin);
-}
 
 const uint32_t* launch_plan(const KParams& kp, const WalkLaunch& wl, float* energy, int energy_words,
                             float* const* energy_tab, int energy_count, hipStream_t s) {
@@ -218,7 +146,7 @@ bool walk_lane_possible(const DeviceScene& sc, const KParams& kp, const WalkLaun
 }
 
 void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState& st, const WalkLaunch& wl,
-                 const uint32_t* perm, hipStream_t s, const WalkStage& stage_in, const uint32_t* rebin, const WalkLane& lane_in) {
+                 const uint32_t* perm, hipStream_t s, const WalkStage& stage_in, const WalkLane& lane_in) {
     DeviceScene sc = sc_in;
     WalkStage stage = stage_in;
     WalkLane lane = lane_in;
@@ -287,7 +215,7 @@ void launch_walk(const DeviceScene& sc_in, const KParams& kp, const SubpathState
     if (!attach_deep(sc, full)) return;
     if (shared) {   // the lobes of FS_FLAG_MATERIAL_LOBES are compiled out of the default instantiation
         const size_t lds = stack_bytes(sc) + kShareLdsBytes, lds_ext = stack_bytes(sc) + kShareIgnLdsBytes;
-        FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm, stage, rebin);
+        FS_LAUNCH_WALK(walk_kernel_shared, full, sc, kp, st, wl.queue_head, perm, stage);
         return;
     }
 #undef FS_LAUNCH_WALK
