@@ -71,7 +71,7 @@ def test_line_trace_matches_brute_force(pkg, oracle_mod, scene_factory, name, bu
     ctx.close()
 
 
-SOUPS = ["uniform", "slivers", "duplicates", "huge_coordinates", "coplanar_grid", "one_triangle", "tiny_and_big"]
+SOUPS = ["uniform", "slivers", "duplicates", "huge_coordinates", "coplanar_grid", "one_triangle", "tiny_and_big", "zero_area"]
 
 
 @pytest.mark.parametrize("build", ["host_sah", "device_morton"])
@@ -79,7 +79,8 @@ SOUPS = ["uniform", "slivers", "duplicates", "huge_coordinates", "coplanar_grid"
 def test_line_trace_fuzz_soups(pkg, oracle_mod, kind, build):
     """Random triangle soups that stress the builder and the tests at their edges: needle triangles, exact
     duplicates (ties broken by input index), coordinates around 1e6 cm, a coplanar grid (rays in the plane, rays
-    through shared edges and vertices), a single triangle, four orders of magnitude of triangle sizes.  Closest
+    through shared edges and vertices), a single triangle, four orders of magnitude of triangle sizes, triangles
+    without area among ordinary ones.  Closest
     hits must equal the oracle's brute-force scan bit for bit, any-hits must agree."""
     import zlib
     rng = np.random.default_rng(zlib.crc32(kind.encode()))   # stable across processes (str hashes are salted)
@@ -108,6 +109,15 @@ def test_line_trace_fuzz_soups(pkg, oracle_mod, kind, build):
                               np.stack([p00, p11, p01], -2).reshape(-1, 3, 3)], axis=0)
     elif kind == "one_triangle":
         tri = np.array([[[0, 0, 0], [100, 0, 0], [0, 100, 0]]], dtype=np.float64)
+    elif kind == "zero_area":
+        # a level's collision mesh as exporters leave it: among ordinary triangles, triangles without area — two corners equal,
+        # all three equal, three corners on a line.  No ray hits them (det = 0 exactly or the barycentric test fails) and the
+        # builders must neither choke on their empty boxes nor on the normal 0 / 0 they store for them
+        c = rng.uniform(-1500, 1500, (1800, 1, 3))
+        tri = c + rng.normal(0, 70, (1800, 3, 3))
+        tri[0::6, 1] = tri[0::6, 0]
+        tri[1::6, 1] = tri[1::6, 0]; tri[1::6, 2] = tri[1::6, 0]
+        tri[2::6, 2] = 0.5 * (tri[2::6, 0] + tri[2::6, 1])
     else:
         c = rng.uniform(-1000, 1000, (2500, 1, 3))
         size = 10.0 ** rng.uniform(-1.5, 2.5, (2500, 1, 1))
