@@ -1373,12 +1373,23 @@ def test_gpu_matches_golden(pkg, scene_factory, path):
 
 
 # ---- BASELINE.json's largest sizes through size-independent properties ----------------------------------------------
-def test_full_size_properties_cfg4(pkg, scene_factory):
-    """cfg4 shape (1 048 576 rays, depth 12, 8 bands): too slow for the oracle in a unit test, so check
-    linearity (shards sum to the whole), mass bound, idempotence and sensitivity to the seed."""
+def test_full_size_properties_cfg4(pkg, oracle_mod, scene_factory):
+    """cfg4 shape (1 048 576 rays, depth 12, 8 bands): linearity (shards sum to the whole), mass bound, idempotence and
+    sensitivity to the seed — and, since the oracle runs on native threads (a few CPU-seconds for this frame), the whole frame
+    against the oracle with its observed work counters, like cfg1 - cfg3."""
     sc = scene_factory("old_mine", 8)
     p = pkg.default_params(num_rays=1048576, depth=12)
     ctx, src = make_ctx(pkg, sc)
+    ps = pkg.default_params(num_rays=1048576, depth=12, seed=0x5EED)
+    e_gpu = ctx.compute_energy_response(src, ps).copy()
+    st = ctx.stats()
+    osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
+    e32, e64, cnt = osc.compute_energy_mt(oracle_mod.default_params(num_pairs=524288, depth=12, seed=0x5EED), sc.source, sc.listener, 8)
+    assert cnt.connected > 50000
+    assert (st["segments"], st["connections_tested"], st["deposits"]) == (cnt.closest_rays, cnt.any_rays, cnt.connected)
+    assert np.array_equal(e_gpu != 0, e64 != 0)
+    for b in range(8):
+        assert rel_rms(e_gpu[b], e64[b]) <= TIGHT_TOL, (b, rel_rms(e_gpu[b], e64[b]))
     full = ctx.compute_energy_response(src, p)
     again = ctx.compute_energy_response(src, p)
     assert np.array_equal(full != 0, again != 0)
