@@ -973,7 +973,10 @@ __device__ __forceinline__ void walker_finish(const Walker& w, const SubpathStat
 //   scratch[0] = subpath queue head (persistent walk), [1, 1 + kPlanBuckets) = bucket counts.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kPlanBuckets = FS_MAX_DEPTH + 1;
-constexpr int kPlanItems = 4;   // subpaths per plan-kernel thread
+#ifndef FS_PLAN_ITEMS
+#define FS_PLAN_ITEMS 4
+#endif
+constexpr int kPlanItems = FS_PLAN_ITEMS;   // subpaths per plan-kernel thread
 
 __device__ __forceinline__ int planned_length(uint32_t g, const KParams& kp) {
     const uint32_t n = kp.num_local;

@@ -166,7 +166,10 @@ struct KParams {
                            // straight to the energy buffer with global atomics (kHistWindow, or all bins if fewer)
 };
 
-constexpr uint32_t kPlanCoopMax = 32768, kPlanCoopMaxUncapped = 1u << 17;   // KParams.plan_coop (fs_device.hpp: plan_coop_body)
+#ifndef FS_PLAN_COOP_MAX_UNCAPPED
+#define FS_PLAN_COOP_MAX_UNCAPPED (1u << 17)
+#endif
+constexpr uint32_t kPlanCoopMax = 32768, kPlanCoopMaxUncapped = FS_PLAN_COOP_MAX_UNCAPPED;   // KParams.plan_coop (fs_device.hpp: plan_coop_body)
 
 // legacy forward tracer (UpdateSound) constants and device-side accumulators
 struct SoundKParams {
