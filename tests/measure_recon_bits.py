@@ -2,7 +2,7 @@
 """How far is the chunked reconstruct (each chunk restarts the one-pole filter 96 samples early, fs_device.hpp: reconstruct_body*)
 from the serial recurrence of FSAC.cpp:366-375 in BITS?  Counts the samples of the band IRs and of the channel view that differ
 from the oracle's serial loop, and the largest difference in ulps.  (loads the oracle: a measurement script, GPU box)
-usage: python tools/recon_bits.py > profiles/r05_recon_bits.json"""
+usage: python tests/measure_recon_bits.py > profiles/r05_recon_bits.json"""
 import json
 import os
 import sys
