@@ -41,6 +41,8 @@ CASES = [
     # BASELINE.json configs[4] (8 sources x 131 072 rays in old_mine, one listener): source 4 of the eight — what a batched frame
     # must give that source ("source": k is a fixture key: the source sits at scene.extra_sources[k])
     ("cfg5_multi_source", "old_mine", 8, 65536, 8, 0x5EED, {"source": 4}),
+    # BASELINE.json configs[3] at FULL size: 1 048 576 rays (524 288 pairs), depth 12 — the frame the 8 ranks' shards sum to
+    ("cfg4_old_mine_1m_d12", "old_mine", 8, 524288, 12, 0x5EED, {}),
 ]
 FIXTURE_KEYS = ("lobes", "source")   # keys of `extra` that describe the fixture, not oracle parameters
 
