@@ -60,14 +60,14 @@ def _worker(rank, world, port, pairs, out_path):
     dist.destroy_process_group()
 
 
-def test_world_size_2_gloo_matches_single_rank(pkg, oracle_mod, tmp_path):
+@pytest.mark.parametrize("world,pairs", [(2, 3000), (3, 3001)])    # (3 ranks, a pair count none of them divides: ragged shares)
+def test_world_size_2_gloo_matches_single_rank(pkg, oracle_mod, tmp_path, world, pairs):
     import torch.multiprocessing as mp
-    pairs = 3000
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "sum.npy")
-    mp.spawn(_worker, args=(2, port, pairs, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, pairs, out), nprocs=world, join=True)
     sc = pkg.scenes.by_name("starter_room", 4)
     osc = oracle_mod.Scene(sc.triangles, sc.material_ids, sc.absorption)
     p = oracle_mod.default_params(num_pairs=pairs, depth=8, seed=0x5EED)
