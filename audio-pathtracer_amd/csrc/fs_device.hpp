@@ -326,6 +326,28 @@ __device__ __forceinline__ void trav_settle(const DeviceScene& sc, Trav& T, int*
 // lost a day's first build to exactly that; tools/check_isa_hazards.py now proves the absence of such accesses on the
 // final ISA).  A tied operand chain issue -> wait -> use has no phi to resolve.  (2) Every wave executes the same
 // number of vector memory instructions per step whatever its lanes need, so counted waits stay possible.
+// cache-policy bits of the step's triangle / node requests (-DFS_TRI_NT=1: nt, 2: sc0, 3: sc1, 4: sc0 sc1; FS_NODE_NT alike):
+// measured, none kept
+#if FS_TRI_NT == 1
+#define FS_TRI_LOAD_POLICY " nt"
+#elif FS_TRI_NT == 2
+#define FS_TRI_LOAD_POLICY " sc0"
+#elif FS_TRI_NT == 3
+#define FS_TRI_LOAD_POLICY " sc1"
+#elif FS_TRI_NT == 4
+#define FS_TRI_LOAD_POLICY " sc0 sc1"
+#else
+#define FS_TRI_LOAD_POLICY ""
+#endif
+#if FS_NODE_NT == 1
+#define FS_NODE_LOAD_POLICY " nt"
+#elif FS_NODE_NT == 2
+#define FS_NODE_LOAD_POLICY " sc0"
+#elif FS_NODE_NT == 3
+#define FS_NODE_LOAD_POLICY " sc1"
+#else
+#define FS_NODE_LOAD_POLICY ""
+#endif
 __device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T, NodeRegs& N, TriRegs& X) {
     const unsigned long long mn = __ballot(T.cur >= 0), mt = __ballot(T.tri_i < T.tri_n);   // subsets of EXEC
     // (addresses of lanes that want nothing are never dereferenced)
@@ -334,10 +356,10 @@ __device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T,
     unsigned long long sv;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "s_mov_b64 exec, %[mn]\n\t"
-                 "global_load_dwordx4 %[q0], %[np], off\n\t"
-                 "global_load_dwordx4 %[q1], %[np], off offset:16\n\t"
-                 "global_load_dwordx4 %[q2], %[np], off offset:32\n\t"
-                 "global_load_dwordx4 %[q3], %[np], off offset:48\n\t"
+                 "global_load_dwordx4 %[q0], %[np], off" FS_NODE_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %[q1], %[np], off offset:16" FS_NODE_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %[q2], %[np], off offset:32" FS_NODE_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %[q3], %[np], off offset:48" FS_NODE_LOAD_POLICY "\n\t"
 #if defined(FS_SENS_XLOADS)
                  "global_load_dwordx4 %[x0], %[np], off\n\t"
 #if FS_SENS_XLOADS >= 2
@@ -348,9 +370,9 @@ __device__ __forceinline__ void trav_issue(const DeviceScene& sc, const Trav& T,
 #ifndef FS_NO_TRI_SKIP
                  "s_cbranch_execz 1f\n\t"      // one wave step in four has no lane with a pending triangle
 #endif
-                 "global_load_dwordx4 %[ta], %[tp], off\n\t"
-                 "global_load_dwordx4 %[tb], %[tp], off offset:16\n\t"
-                 "global_load_dwordx4 %[tc], %[tp], off offset:32\n"
+                 "global_load_dwordx4 %[ta], %[tp], off" FS_TRI_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %[tb], %[tp], off offset:16" FS_TRI_LOAD_POLICY "\n\t"
+                 "global_load_dwordx4 %[tc], %[tp], off offset:32" FS_TRI_LOAD_POLICY "\n"
                  "1:\n\t"
                  "s_mov_b64 exec, %[sv]"
                  : [q0] "+&v"(N.q0), [q1] "+&v"(N.q1), [q2] "+&v"(N.q2), [q3] "+&v"(N.q3),
