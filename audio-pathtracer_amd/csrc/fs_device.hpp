@@ -1187,6 +1187,7 @@ constexpr size_t kShareLdsBytes = ShareArea<false, false>::kBytes;      // 60 B 
 // once this many lanes have nothing to do: feeding the first few idle lanes costs every lane more than it returns.
 // Measured at cfg3 (profiles/r02_share_min_idle.log): 1 / 4 / 8 / 16 / 24 / 32 / 48 -> walk 0.304 / 0.303 / 0.298 /
 // 0.294 / 0.300 / 0.309 / 0.334 ms, connect 0.075 -> 0.072 ms at 16.  Sparse waves start above it.
+// (again on round 5's fused stream, profiles/r05_share_min_idle.log: 8 / 12 / 16 / 20 / 24 -> 971 / 981 / 988 / 981 / 975 M rays/s.)
 #ifndef FS_SHARE_MIN_IDLE
 #define FS_SHARE_MIN_IDLE 16
 #endif
